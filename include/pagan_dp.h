@@ -1,0 +1,182 @@
+/*
+ * pagan_dp.h -- C ABI of the MI355X pairwise graph-vs-graph Viterbi aligner.
+ *
+ * This is the drop-in seam between a guide-tree walk (the reference's
+ * Node::align_sequences_this_node, src/main/node.cpp:52-192) and the pairwise
+ * aligner it calls (Viterbi_alignment::align, src/main/viterbi_alignment.cpp:187-465;
+ * interface in src/main/viterbi_alignment.h:214-223).  The reference has no
+ * FFI layer; these entry points are what a binding at that seam would call.
+ *
+ * Conventions:
+ *   - a graph has sites 0..n_sites-1; site 0 is the start site, site
+ *     n_sites-1 the stop site (src/main/sequence.cpp:155-158,292-301);
+ *   - the DP matrices are Lx x Ly with Lx = left.n_sites-1, Ly = right.n_sites-1
+ *     (viterbi_alignment.cpp:229-247); the stop sites only enter the end corner;
+ *   - bwd edge lists are in the order Site::get_first_bwd_edge/get_next_bwd_edge
+ *     iterate them (src/main/sequence.h:395-417) -- the order decides ties;
+ *   - matrix labels follow enum Matrix_pt {x_mat=0,y_mat=1,m_mat=2}
+ *     (src/main/basic_alignment.h:107);
+ *   - path states follow Site::Path_state (src/main/sequence.h:229):
+ *     matched=2, xgapped=3, ygapped=4, xskipped=5, yskipped=6.
+ *
+ * All pointers are host pointers borrowed for the duration of the call unless
+ * stated otherwise.  No function throws or exits; errors are negative codes.
+ */
+#ifndef PAGAN_DP_H
+#define PAGAN_DP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error / status codes ------------------------------------------------ */
+#define PAGAN_OK              0
+#define PAGAN_E_ARG          -1   /* null pointer / inconsistent sizes                 */
+#define PAGAN_E_GRAPH        -2   /* malformed CSR graph (offsets, edge direction)     */
+#define PAGAN_E_BAND         -3   /* band arrays wrong length or not monotone          */
+#define PAGAN_E_MODEL        -4   /* state outside the model table                     */
+#define PAGAN_E_NODEVICE     -5   /* no HIP device / HIP runtime error                 */
+#define PAGAN_E_NOMEM        -6   /* device or host allocation failed                  */
+#define PAGAN_E_INTERNAL     -7
+/* result.status: alignment-level outcome (the call itself still returns PAGAN_OK)    */
+#define PAGAN_DP_REACHED      0
+#define PAGAN_DP_UNREACHABLE  1   /* end corner score is -inf ("anchored alignment
+                                     failed", viterbi_alignment.cpp:298-323); caller
+                                     decides whether to retry without a band          */
+
+/* ---- option bits (the Settings flags that change the DP) --- */
+#define PAGAN_OPT_NO_TERMINAL_EDGES        1u  /* --no-terminal-edges (VA:866,877)      */
+#define PAGAN_OPT_NO_REDUCED_TERMINAL_PEN  2u  /* --no-reduced-terminal-penalties
+                                                  (basic_alignment.h:627-628)          */
+
+enum { PAGAN_X_MAT = 0, PAGAN_Y_MAT = 1, PAGAN_M_MAT = 2 };
+enum { PAGAN_MATCHED = 2, PAGAN_XGAPPED = 3, PAGAN_YGAPPED = 4,
+       PAGAN_XSKIPPED = 5, PAGAN_YSKIPPED = 6 };
+
+/* One child Sequence flattened to CSR: replaces the Site/Edge read accessors
+ * the DP uses (src/main/sequence.h:80-96,262,395-417,831).                     */
+typedef struct pagan_graph {
+    int32_t        n_sites;   /* including start and stop site                        */
+    int32_t        n_edges;   /* size of the edge-id space (Sequence::edges_length()) */
+    const int32_t *state;     /* [n_sites] Site::character_state (-1 at the ends)     */
+    const int32_t *bwd_off;   /* [n_sites+1] offsets into bwd_*                       */
+    const int32_t *bwd_src;   /* [bwd_off[n_sites]] Edge::start_site_index            */
+    const float   *bwd_logw;  /* [..] Edge::log_posterior_weight (float, logf)        */
+    const int32_t *bwd_eid;   /* [..] Edge::index                                     */
+} pagan_graph;
+
+/* Per-alignment Evol_model view (src/utils/evol_model.h:59-63,78-88).          */
+typedef struct pagan_model {
+    int32_t      n_states;        /* S: 15 DNA, 211 protein, ...                      */
+    const float *log_score;       /* [S*S], log_score(a,b) = log_score[a + b*S]
+                                     (Db_matrix::g, src/utils/db_matrix.h:76-83)      */
+    float        log_gap_open;    /* Evol_model::log_id_prob                          */
+    float        log_gap_ext;     /* Evol_model::log_ext_prob                         */
+    float        log_gap_end_ext; /* Evol_model::log_end_ext_prob                     */
+    float        log_non_gap;     /* Evol_model::log_match_prob                       */
+} pagan_model;
+
+/* The "tunnel" (Viterbi_alignment::upper_bound/lower_bound, filled by
+ * define_tunnel, viterbi_alignment.cpp:148-164).  Row i of the left graph may
+ * use columns max(0,upper[i]) .. min(lower[i],Ly-1)
+ * (src/utils/tunnel_matrix.h:194).  n must be >= Lx; entries beyond Lx-1 are
+ * ignored (find_anchors.cpp:373 emits length1+1 of them).                       */
+typedef struct pagan_band {
+    int32_t        n;
+    const int32_t *upper;
+    const int32_t *lower;
+} pagan_band;
+
+typedef struct pagan_opts {
+    uint32_t flags;    /* PAGAN_OPT_*                                                 */
+    int32_t  device;   /* HIP device ordinal, -1 = current                            */
+} pagan_opts;
+
+/* One alignment column = one Site of the parent sequence
+ * (Basic_alignment::create_ancestral_sequence, basic_alignment.cpp:61-179).     */
+typedef struct pagan_col {
+    int32_t left;        /* left child site index, -1 if none                         */
+    int32_t right;       /* right child site index, -1 if none                        */
+    int32_t path_state;  /* PAGAN_MATCHED ... PAGAN_YSKIPPED                          */
+} pagan_col;
+
+/* What Viterbi_alignment::align leaves behind for build_ancestral_sequence:
+ * the path (viterbi_alignment.cpp:1038-1189), the end-corner cell `max_end`
+ * (viterbi_alignment.cpp:289-296) and the child edges marked used
+ * (Edge::is_used(true) at viterbi_alignment.cpp:1054-1057,1079-1101,1128,1155). */
+typedef struct pagan_result {
+    int32_t    status;        /* PAGAN_DP_REACHED / PAGAN_DP_UNREACHABLE              */
+    double     score;         /* max_end.score: the node's Viterbi log score          */
+    int32_t    end_matrix;    /* max_end.matrix                                       */
+    int32_t    end_x, end_y;  /* max_end.x_ind / y_ind                                */
+    int32_t    end_x_edge, end_y_edge;
+    int32_t    n_cols;
+    pagan_col *cols;          /* [n_cols] forward order, skip columns included        */
+    int32_t    n_left_used;
+    int32_t   *left_used;     /* edge ids of the left graph marked used (ascending)   */
+    int32_t    n_right_used;
+    int32_t   *right_used;
+    int64_t    cells;         /* in-band DP cells filled                              */
+    double     fill_ms;       /* device time of the fill kernel (HIP events)          */
+    double     trace_ms;      /* device time of end corner + traceback                */
+} pagan_result;
+
+typedef struct pagan_job {
+    const pagan_graph *left;
+    const pagan_graph *right;
+    const pagan_model *model;
+    const pagan_band  *band;   /* NULL = full matrix (--no-anchors)                   */
+} pagan_job;
+
+/* ---- entry points --------------------------------------------------------- */
+
+/* Replaces Viterbi_alignment::align up to (not including) build_ancestral_sequence
+ * (viterbi_alignment.cpp:187-384).  Fill, end corner and traceback run on the GPU.
+ * Fails with PAGAN_E_NODEVICE when no HIP device is usable: there is no CPU path. */
+int pagan_dp_align(const pagan_graph *left, const pagan_graph *right,
+                   const pagan_model *model, const pagan_band *band,
+                   const pagan_opts *opts, pagan_result *out);
+
+/* Same, for n independent alignments in one launch (the ready nodes of one
+ * guide-tree level, node.cpp:227-285).  out[k] is filled for every job.         */
+int pagan_dp_align_batch(int32_t n, const pagan_job *jobs,
+                         const pagan_opts *opts, pagan_result *out);
+
+void pagan_result_free(pagan_result *r);
+
+/* Viterbi_alignment::get_predicted_memory_consumption (viterbi_alignment.cpp:555-568)
+ * restated for the device layout: bytes of HBM one alignment needs.             */
+int64_t pagan_dp_predict_bytes(int32_t left_sites, int32_t right_sites,
+                               const pagan_band *band);
+
+/* Number of in-band cells, SURVEY.md s.8(d): sum_i (min(lower,Ly-1)-max(upper,0)+1). */
+int64_t pagan_dp_count_cells(int32_t left_sites, int32_t right_sites,
+                             const pagan_band *band);
+
+int pagan_dp_device_count(void);
+int pagan_dp_select_device(int32_t device);
+
+/* ---- resident-batch interface (used by bench.py and the tree driver) ------
+ * Uploads the jobs once, keeps them in HBM, and lets the caller re-run the hot
+ * path on the resident inputs.  pagan_batch_run leaves results on the device;
+ * pagan_batch_fetch copies them out.                                            */
+typedef struct pagan_batch pagan_batch;
+
+int  pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
+                        pagan_batch **out);
+int  pagan_batch_run(pagan_batch *b);                 /* fill + traceback, async  */
+int  pagan_batch_sync(pagan_batch *b);
+int  pagan_batch_fetch(pagan_batch *b, pagan_result *out /* [n] */);
+/* device milliseconds of the last run: [0]=fill kernel, [1]=end corner+traceback  */
+int  pagan_batch_last_ms(pagan_batch *b, double ms[2]);
+int64_t pagan_batch_cells(const pagan_batch *b);
+void pagan_batch_destroy(pagan_batch *b);
+
+const char *pagan_dp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAGAN_DP_H */

@@ -1,0 +1,177 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes front end of the CPU oracle (oracle_dp.cpp, oracle_host.cpp).
+
+PARITY UNPINNED -- see the header of oracle_dp.cpp.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this package; the product (pagan2-msa_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pagan2_msa_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libpagan_oracle.so")
+_lib = None
+
+DNA_ALPHABET = "ACGTRYMKWSBDHVN"      # Model_factory::dna_full_char_alphabet, model_factory.cpp:103
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_dp.cpp", "oracle_host.cpp", "Makefile")]
+    srcs.append(os.path.join(_HERE, "..", "include", "pagan_dp.h"))
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return LIB_PATH
+    subprocess.run(["make", "-C", _HERE, "-B"], check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        gp, mp, bp, op, rp = (C.POINTER(abi.CGraph), C.POINTER(abi.CModel), C.POINTER(abi.CBand),
+                              C.POINTER(abi.COpts), C.POINTER(abi.CResult))
+        i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        L.oracle_dp_align.argtypes = [gp, gp, mp, bp, op, rp]
+        L.oracle_dp_align.restype = C.c_int
+        L.oracle_result_free.argtypes = [rp]
+        L.oracle_result_free.restype = None
+        L.oracle_graph_leaf.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.oracle_graph_leaf.restype = C.c_void_p
+        L.oracle_graph_free.argtypes = [C.c_void_p]
+        L.oracle_graph_free.restype = None
+        for f in ("oracle_graph_n_sites", "oracle_graph_n_edges", "oracle_graph_n_bwd"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_int
+        L.oracle_graph_flatten.argtypes = [C.c_void_p, i32p, i32p, i32p, f32p, i32p]
+        L.oracle_graph_flatten.restype = None
+        L.oracle_graph_attrs.argtypes = [C.c_void_p, i32p, f32p, i32p, f32p]
+        L.oracle_graph_attrs.restype = None
+        L.oracle_graph_fwd.argtypes = [C.c_void_p, i32p, i32p]
+        L.oracle_graph_fwd.restype = None
+        L.oracle_graph_mark_used.argtypes = [C.c_void_p, C.c_int, i32p]
+        L.oracle_graph_mark_used.restype = None
+        L.oracle_graph_parent.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.CCol), C.c_int, C.c_float,
+                                          C.c_float, i32p, C.c_int, C.c_int, C.c_int]
+        L.oracle_graph_parent.restype = C.c_void_p
+        L.oracle_graph_string.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p]
+        L.oracle_graph_string.restype = C.c_int
+        L.oracle_define_tunnel.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int,
+                                           C.c_int, i32p, i32p]
+        L.oracle_define_tunnel.restype = C.c_int
+        L.oracle_dna_parsimony.argtypes = [i32p]
+        L.oracle_dna_parsimony.restype = None
+        _lib = L
+    return _lib
+
+
+def dp_align(left, right, model, band=None, flags=0):
+    """CPU restatement of Viterbi_alignment::align; same inputs/outputs as pagan2_msa_amd.align."""
+    L = lib()
+    opts = abi.COpts(flags, -1)
+    res = abi.CResult()
+    rc = L.oracle_dp_align(C.byref(left.c), C.byref(right.c), C.byref(model.c),
+                           C.byref(band.c) if band is not None else None, C.byref(opts), C.byref(res))
+    try:
+        if rc != 0:
+            raise RuntimeError("oracle_dp_align failed with code %d" % rc)
+        return abi.Result(res)
+    finally:
+        L.oracle_result_free(C.byref(res))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class OGraph:
+    """Handle on an oracle-side Sequence graph (linked edge lists as in the reference)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def leaf(cls, seq, alphabet=DNA_ALPHABET, flags=0):
+        return cls(lib().oracle_graph_leaf(seq.encode(), alphabet.encode(), flags))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_graph_free(self.h)
+            self.h = None
+
+    def flatten(self):
+        L = lib()
+        ns, ne, nb = L.oracle_graph_n_sites(self.h), L.oracle_graph_n_edges(self.h), L.oracle_graph_n_bwd(self.h)
+        state = np.zeros(ns, np.int32)
+        off = np.zeros(ns + 1, np.int32)
+        src = np.zeros(max(nb, 1), np.int32)
+        lw = np.zeros(max(nb, 1), np.float32)
+        eid = np.zeros(max(nb, 1), np.int32)
+        L.oracle_graph_flatten(self.h, _ip(state), _ip(off), _ip(src), _fp(lw), _ip(eid))
+        return abi.Graph(state, off, src[:nb], lw[:nb], eid[:nb], n_edges=ne)
+
+    def attrs(self):
+        L = lib()
+        ns, ne = L.oracle_graph_n_sites(self.h), L.oracle_graph_n_edges(self.h)
+        sa = np.zeros((ns, 8), np.int32)
+        sd = np.zeros(ns, np.float32)
+        ea = np.zeros((max(ne, 1), 6), np.int32)
+        ef = np.zeros((max(ne, 1), 3), np.float32)
+        L.oracle_graph_attrs(self.h, _ip(sa), _fp(sd), _ip(ea), _fp(ef))
+        return sa, sd, ea[:ne], ef[:ne]
+
+    def fwd(self):
+        L = lib()
+        ns, ne = L.oracle_graph_n_sites(self.h), L.oracle_graph_n_edges(self.h)
+        off = np.zeros(ns + 1, np.int32)
+        eid = np.zeros(max(ne, 1), np.int32)
+        L.oracle_graph_fwd(self.h, _ip(off), _ip(eid))
+        return off, eid[:off[-1]]
+
+    def mark_used(self, eids):
+        e = np.ascontiguousarray(eids, np.int32)
+        lib().oracle_graph_mark_used(self.h, int(e.shape[0]), _ip(e))
+
+    def string(self, with_gaps, alphabet=DNA_ALPHABET):
+        L = lib()
+        buf = C.create_string_buffer(L.oracle_graph_n_sites(self.h) + 1)
+        n = L.oracle_graph_string(self.h, 1 if with_gaps else 0, alphabet.encode(), buf)
+        return buf.raw[:n].decode()
+
+    @classmethod
+    def parent(cls, left, right, result, lbl, rbl, parsimony, char_as, flags=0):
+        """left/right: OGraph children; result: abi.Result of their alignment."""
+        left.mark_used(result.left_used)
+        right.mark_used(result.right_used)
+        cols = np.ascontiguousarray(result.cols, np.int32)
+        pars = np.ascontiguousarray(parsimony, np.int32)
+        S = int(round(pars.size ** 0.5))
+        h = lib().oracle_graph_parent(left.h, right.h, C.cast(_ip(cols), C.POINTER(abi.CCol)), int(cols.shape[0]),
+                                      lbl, rbl, _ip(pars), S, char_as, flags)
+        return cls(h)
+
+
+def dna_parsimony():
+    t = np.zeros(225, np.int32)
+    lib().oracle_dna_parsimony(_ip(t))
+    return t
+
+
+def define_tunnel(left, right, min_length=30, trim=5, width=15, alphabet=DNA_ALPHABET):
+    """--use-prefix-anchors band for two OGraphs (Viterbi_alignment::define_tunnel)."""
+    s1, s2 = left.string(False, alphabet), right.string(False, alphabet)
+    g1, g2 = left.string(True, alphabet), right.string(True, alphabet)
+    up = np.zeros(len(g1) + 1, np.int32)
+    lo = np.zeros(len(g1) + 1, np.int32)
+    nh = lib().oracle_define_tunnel(s1.encode(), s2.encode(), g1.encode(), g2.encode(), min_length, trim, width,
+                                    _ip(up), _ip(lo))
+    return abi.Band(up, lo), nh

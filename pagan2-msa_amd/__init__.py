@@ -1,0 +1,134 @@
+"""pagan2-msa_amd: MI355X-native pairwise graph-vs-graph Viterbi aligner (PAGAN2's
+Viterbi_alignment hot path) behind the C ABI of include/pagan_dp.h.
+
+Python here is plumbing: it loads libpagan_dp.so (HIP kernels + C ABI, built in-tree by
+build.py) and mirrors the reference's call surface for this path:
+
+    align(left, right, model, band=None, flags=0)      <- Viterbi_alignment::align
+    align_batch(jobs, flags=0)                          (ready nodes of one tree level)
+    Batch(jobs).run() / .fetch()                        (inputs resident in HBM)
+
+There is no CPU fallback: if the library or a HIP device is missing the calls raise.
+"""
+import ctypes as C
+import os
+
+from . import abi
+from .abi import Band, Graph, Model, Result  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpagan_dp.so")
+_lib = None
+
+
+class PaganError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__("%s failed with code %d" % (what, code))
+        self.code = code
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it has not been built (see build.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libpagan_dp.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _lib = abi.declare(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def device_count():
+    return lib().pagan_dp_device_count()
+
+
+def _check(code, what):
+    if code != abi.PAGAN_OK:
+        raise PaganError(code, what)
+
+
+def _jobs_array(jobs):
+    arr = (abi.CJob * len(jobs))()
+    for k, (left, right, model, band) in enumerate(jobs):
+        arr[k].left = C.pointer(left.c)
+        arr[k].right = C.pointer(right.c)
+        arr[k].model = C.pointer(model.c)
+        arr[k].band = C.pointer(band.c) if band is not None else None
+    return arr
+
+
+def align_batch(jobs, flags=0, device=-1):
+    """jobs: list of (Graph left, Graph right, Model, Band|None).  Returns [Result]."""
+    L = lib()
+    arr = _jobs_array(jobs)
+    opts = abi.COpts(flags, device)
+    res = (abi.CResult * len(jobs))()
+    rc = L.pagan_dp_align_batch(len(jobs), arr, C.byref(opts), res)
+    try:
+        _check(rc, "pagan_dp_align_batch")
+        return [Result(r) for r in res]
+    finally:
+        for r in res:
+            L.pagan_result_free(C.byref(r))
+
+
+def align(left, right, model, band=None, flags=0, device=-1):
+    """Mirror of Viterbi_alignment::align (+ define_tunnel's band as an argument)."""
+    L = lib()
+    opts = abi.COpts(flags, device)
+    res = abi.CResult()
+    rc = L.pagan_dp_align(C.byref(left.c), C.byref(right.c), C.byref(model.c),
+                          C.byref(band.c) if band is not None else None, C.byref(opts), C.byref(res))
+    try:
+        _check(rc, "pagan_dp_align")
+        return Result(res)
+    finally:
+        L.pagan_result_free(C.byref(res))
+
+
+class Batch:
+    """Jobs uploaded once and kept resident in HBM; run() replays the hot path on them."""
+
+    def __init__(self, jobs, flags=0, device=-1):
+        self._L = lib()
+        self.jobs = list(jobs)          # keeps the numpy arrays alive
+        self.n = len(self.jobs)
+        arr = _jobs_array(self.jobs)
+        opts = abi.COpts(flags, device)
+        self._h = C.c_void_p()
+        _check(self._L.pagan_batch_create(self.n, arr, C.byref(opts), C.byref(self._h)), "pagan_batch_create")
+
+    @property
+    def cells(self):
+        return self._L.pagan_batch_cells(self._h)
+
+    def run(self):
+        _check(self._L.pagan_batch_run(self._h), "pagan_batch_run")
+
+    def sync(self):
+        _check(self._L.pagan_batch_sync(self._h), "pagan_batch_sync")
+
+    def last_ms(self):
+        ms = (C.c_double * 2)()
+        _check(self._L.pagan_batch_last_ms(self._h, ms), "pagan_batch_last_ms")
+        return ms[0], ms[1]
+
+    def fetch(self):
+        res = (abi.CResult * self.n)()
+        rc = self._L.pagan_batch_fetch(self._h, res)
+        try:
+            _check(rc, "pagan_batch_fetch")
+            return [Result(r) for r in res]
+        finally:
+            for r in res:
+                self._L.pagan_result_free(C.byref(r))
+
+    def close(self):
+        if self._h:
+            self._L.pagan_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,505 @@
+// dp_abi.hip -- the C ABI of include/pagan_dp.h on top of the gfx950 kernels.
+//
+// Host work done here is bookkeeping only: validate the borrowed inputs, turn the row band
+// (upper/lower per left site, the reference's "tunnel") into the per-anti-diagonal index the
+// kernels use, stage everything into ONE device arena per batch, launch, and turn the
+// device's list of visited path cells into the reference's path (skip columns + used edges,
+// Viterbi_alignment::backtrack_new_path, src/main/viterbi_alignment.cpp:1038-1189).
+// There is no CPU fill or traceback here: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/pagan_dp.h"
+#include "dp_device.h"
+
+template <int BLOCK> __global__ void pg_fill_wavefront(const PgDevJob *jobs, unsigned flags);
+__global__ void pg_end_and_trace(const PgDevJob *jobs);
+
+namespace {
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            if (std::getenv("PAGAN_DP_VERBOSE"))                                                 \
+                std::fprintf(stderr, "pagan_dp: %s failed: %s\n", #expr, hipGetErrorString(e__)); \
+            return e__ == hipErrorOutOfMemory ? PAGAN_E_NOMEM : PAGAN_E_NODEVICE;                \
+        }                                                                                        \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+int check_graph(const pagan_graph *g) {
+    if (!g || g->n_sites < 2 || g->n_edges < 0 || !g->state || !g->bwd_off) return PAGAN_E_GRAPH;
+    if (g->bwd_off[0] != 0) return PAGAN_E_GRAPH;
+    for (int s = 0; s < g->n_sites; ++s) {
+        const int a = g->bwd_off[s], b = g->bwd_off[s + 1];
+        if (b < a || b - a > PG_MAX_SLOT) return PAGAN_E_GRAPH;
+        if (b > a && (!g->bwd_src || !g->bwd_logw || !g->bwd_eid)) return PAGAN_E_GRAPH;
+        for (int k = a; k < b; ++k) {
+            if (g->bwd_src[k] < 0 || g->bwd_src[k] >= s) return PAGAN_E_GRAPH;      // edges point forward
+            if (g->bwd_eid[k] < 0 || g->bwd_eid[k] >= g->n_edges) return PAGAN_E_GRAPH;
+        }
+    }
+    return PAGAN_OK;
+}
+
+// Row band clamped as Tunnel_matrix does (src/utils/tunnel_matrix.h:194).
+struct RowBand {
+    std::vector<int> lo, hi;
+    int build(int Lx, int Ly, const pagan_band *band) {
+        lo.assign(Lx, 0);
+        hi.assign(Lx, Ly - 1);
+        if (band) {
+            if (band->n < Lx || !band->upper || !band->lower) return PAGAN_E_BAND;
+            for (int i = 0; i < Lx; ++i) {
+                lo[i] = band->upper[i] > 0 ? band->upper[i] : 0;
+                hi[i] = band->lower[i] < Ly - 1 ? band->lower[i] : Ly - 1;
+            }
+            // The tunnel must be monotone (tunnel_matrix.h:162-164) and must hold the start
+            // corner, where the reference writes M[0][0] = 0 (VA:725-736).
+            if (lo[0] > 0 || hi[0] < 0) return PAGAN_E_BAND;
+            for (int i = 1; i < Lx; ++i)
+                if (lo[i] < lo[i - 1] || hi[i] < hi[i - 1]) return PAGAN_E_BAND;
+        }
+        return PAGAN_OK;
+    }
+    int64_t cells() const {
+        int64_t c = 0;
+        for (size_t i = 0; i < lo.size(); ++i) if (hi[i] >= lo[i]) c += hi[i] - lo[i] + 1;
+        return c;
+    }
+};
+
+// Per anti-diagonal d = i+j: the in-band rows form one interval [imin,imax] because
+// lo[i]+i and hi[i]+i are strictly increasing for a monotone band.
+struct DiagIndex {
+    std::vector<int> imin, imax;
+    std::vector<long long> doff;
+    long long cells = 0;
+    int max_width = 0;
+    void build(int Lx, int Ly, const RowBand &rb) {
+        const int nd = Lx + Ly - 1;
+        imin.resize(nd); imax.resize(nd); doff.resize(nd);
+        int a = -1, b = 0;       // a = max{i: lo[i]+i <= d}, b = min{i: hi[i]+i >= d}
+        cells = 0; max_width = 0;
+        for (int d = 0; d < nd; ++d) {
+            while (a + 1 < Lx && rb.lo[a + 1] + (a + 1) <= d) ++a;
+            while (b < Lx && rb.hi[b] + b < d) ++b;
+            imin[d] = b; imax[d] = a; doff[d] = cells;
+            const int w = a - b + 1;
+            if (w > 0) { cells += w; if (w > max_width) max_width = w; }
+        }
+    }
+};
+
+struct HostJob {
+    const pagan_graph *L, *R;
+    int Lx, Ly;
+    DiagIndex dx;
+};
+
+struct Arena {
+    char *dev = nullptr;
+    size_t size = 0;
+};
+
+} // namespace
+
+struct pagan_batch {
+    int n = 0;
+    int device = 0;
+    uint32_t flags = 0;
+    int block = 64;
+    std::vector<HostJob> jobs;
+    std::vector<PgDevJob> dj;
+    Arena arena;
+    PgDevJob *d_jobs = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int64_t cells = 0;
+    size_t out_bytes = 0;
+    bool ran = false;
+    // D2H staging (pinned)
+    std::vector<size_t> trace_off;   // byte offsets of trace/endcell/endscore inside the arena
+    std::vector<size_t> end_off, score_off;
+};
+
+namespace {
+
+int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb) {
+    if (!jb.left || !jb.right || !jb.model) return PAGAN_E_ARG;
+    int rc;
+    if ((rc = check_graph(jb.left)) != PAGAN_OK) return rc;
+    if ((rc = check_graph(jb.right)) != PAGAN_OK) return rc;
+    const pagan_model *m = jb.model;
+    if (m->n_states <= 0 || !m->log_score) return PAGAN_E_MODEL;
+    hj->L = jb.left; hj->R = jb.right;
+    hj->Lx = jb.left->n_sites - 1; hj->Ly = jb.right->n_sites - 1;
+    for (int s = 1; s < hj->Lx; ++s)
+        if (jb.left->state[s] < 0 || jb.left->state[s] >= m->n_states) return PAGAN_E_MODEL;
+    for (int s = 1; s < hj->Ly; ++s)
+        if (jb.right->state[s] < 0 || jb.right->state[s] >= m->n_states) return PAGAN_E_MODEL;
+    if ((rc = rb->build(hj->Lx, hj->Ly, jb.band)) != PAGAN_OK) return rc;
+    hj->dx.build(hj->Lx, hj->Ly, *rb);
+    if (hj->dx.cells != rb->cells()) return PAGAN_E_INTERNAL;
+    return PAGAN_OK;
+}
+
+// Bump allocator over the arena: first pass sizes it, second pass hands out pointers.
+struct Carver {
+    size_t cur = 0;
+    char *base = nullptr;
+    template <class T> T *take(size_t count) {
+        size_t off = cur;
+        cur = align_up(cur + sizeof(T) * (count ? count : 1));
+        return base ? reinterpret_cast<T *>(base + off) : reinterpret_cast<T *>(off);
+    }
+};
+
+// Lays one job out in the arena.  With `base == nullptr` only sizes are accumulated.
+void carve_job(Carver &c, const pagan_job &jb, const HostJob &hj, PgDevJob *d) {
+    const pagan_graph *L = jb.left, *R = jb.right;
+    const int nbL = L->bwd_off[L->n_sites], nbR = R->bwd_off[R->n_sites];
+    d->Lx = hj.Lx; d->Ly = hj.Ly; d->nd = hj.Lx + hj.Ly - 1; d->S = jb.model->n_states;
+    d->go = jb.model->log_gap_open; d->ge = jb.model->log_gap_ext;
+    d->gE = jb.model->log_gap_end_ext; d->ng = jb.model->log_non_gap;
+    d->stL = c.take<int>(L->n_sites); d->offL = c.take<int>(L->n_sites + 1);
+    d->srcL = c.take<int>(nbL); d->lwL = c.take<float>(nbL);
+    d->stR = c.take<int>(R->n_sites); d->offR = c.take<int>(R->n_sites + 1);
+    d->srcR = c.take<int>(nbR); d->lwR = c.take<float>(nbR);
+    d->table = c.take<float>((size_t)d->S * d->S);
+    d->imin = c.take<int>(d->nd); d->imax = c.take<int>(d->nd); d->doff = c.take<long long>(d->nd);
+    d->cells = hj.dx.cells;
+}
+void carve_outputs(Carver &c, const HostJob &hj, PgDevJob *d) {
+    for (int m = 0; m < 3; ++m) d->sc[m] = c.take<double>((size_t)hj.dx.cells);
+    for (int m = 0; m < 3; ++m) d->bp[m] = c.take<unsigned>((size_t)hj.dx.cells);
+    d->trace = c.take<int>(3 * (size_t)(hj.Lx + hj.Ly));
+    d->endcell = c.take<int>(8);
+    d->endscore = c.take<double>(1);
+}
+
+template <class T> void put(std::vector<char> &stage, const void *devptr_as_off, const T *src, size_t count) {
+    if (count) std::memcpy(stage.data() + reinterpret_cast<size_t>(devptr_as_off), src, sizeof(T) * count);
+}
+
+int launch_fill(pagan_batch *b) {
+    dim3 grid(b->n);
+    switch (b->block) {
+    case 64: hipLaunchKernelGGL(pg_fill_wavefront<64>, grid, dim3(64), 0, b->stream, b->d_jobs, b->flags); break;
+    case 256: hipLaunchKernelGGL(pg_fill_wavefront<256>, grid, dim3(256), 0, b->stream, b->d_jobs, b->flags); break;
+    default: hipLaunchKernelGGL(pg_fill_wavefront<1024>, grid, dim3(1024), 0, b->stream, b->d_jobs, b->flags); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return PAGAN_OK;
+}
+
+// Host side of backtrack_new_path (VA:1038-1189): the device reports the visited cells
+// end -> start; this re-inserts the skipped child sites (insert_preexisting_gap,
+// viterbi_alignment.h:146-193), applies insert_new_path_pointer's `i>0 || j>0` rule
+// (viterbi_alignment.h:196-200), marks the child edges the path used, and numbers the
+// columns the way create_ancestral_sequence consumes them (basic_alignment.cpp:73-171).
+int replay(const HostJob &hj, const int *endcell, double endscore, const int *trace, pagan_result *out) {
+    const pagan_graph *L = hj.L, *R = hj.R;
+    const int Lx = hj.Lx, Ly = hj.Ly;
+    std::memset(out, 0, sizeof(*out));
+    out->cells = hj.dx.cells;
+    out->score = endscore;
+    out->end_matrix = endcell[1]; out->end_x = endcell[2]; out->end_y = endcell[3];
+    out->end_x_edge = endcell[4] >= 0 ? L->bwd_eid[L->bwd_off[Lx] + endcell[4]] : -1;
+    out->end_y_edge = endcell[5] >= 0 ? R->bwd_eid[R->bwd_off[Ly] + endcell[5]] : -1;
+    if (endcell[0] == 1) { out->status = PAGAN_DP_UNREACHABLE; return PAGAN_OK; }
+    if (endcell[0] != 0) return PAGAN_E_INTERNAL;
+    const int n = endcell[6];
+
+    std::vector<char> lused(L->n_edges, 0), rused(R->n_edges, 0);
+    struct Step { int8_t matrix; int8_t real; };
+    std::vector<Step> stack;
+    stack.reserve((size_t)Lx + Ly);
+    auto find_edge = [](const pagan_graph *g, int start, int site) {
+        for (int k = g->bwd_off[site]; k < g->bwd_off[site + 1]; ++k)
+            if (g->bwd_src[k] == start) return g->bwd_eid[k];
+        return -1;
+    };
+    if (out->end_x_edge >= 0) lused[out->end_x_edge] = 1;              // VA:1054-1057
+    if (out->end_y_edge >= 0) rused[out->end_y_edge] = 1;
+    int i = Lx - 1, j = Ly - 1;
+    int x_ind = endcell[2], y_ind = endcell[3];
+    bool first_x = true, first_y = true;
+    auto skips = [&](int xi, int yi) {
+        while (xi < i) { stack.push_back({PAGAN_X_MAT, 0}); --i; }
+        while (yi < j) { stack.push_back({PAGAN_Y_MAT, 0}); --j; }
+    };
+    auto push = [&](int matrix) { if (i > 0 || j > 0) stack.push_back({(int8_t)matrix, 1}); };
+    skips(x_ind, y_ind);
+    push(endcell[1]);
+    for (int t = 0; t < n; ++t) {
+        const int ci = trace[3 * t], cj = trace[3 * t + 1];
+        const unsigned w = (unsigned)trace[3 * t + 2];
+        const int vit = (int)(w & 3u), k1 = (int)((w >> 2) & 32767u), k2 = (int)(w >> 17);
+        if (ci != i || cj != j) return PAGAN_E_INTERNAL;
+        // the cell's `from` label is the matrix of the next visited cell; for the last one
+        // it is never pushed (i<1 && j<1 after it), so any value does
+        const int from = (t + 1 < n) ? (int)((unsigned)trace[3 * (t + 1) + 2] & 3u) : PAGAN_M_MAT;
+        if (vit == PAGAN_M_MAT) {
+            if (first_x) { int e = find_edge(L, x_ind, Lx); if (e >= 0) lused[e] = 1; first_x = false; }
+            if (first_y) { int e = find_edge(R, y_ind, Ly); if (e >= 0) rused[e] = 1; first_y = false; }
+            const int el = L->bwd_off[i] + k1, er = R->bwd_off[j] + k2;
+            x_ind = L->bwd_src[el]; y_ind = R->bwd_src[er];
+            lused[L->bwd_eid[el]] = 1; rused[R->bwd_eid[er]] = 1;
+            --i; --j;
+        } else if (vit == PAGAN_X_MAT) {
+            if (first_x) { int e = find_edge(L, x_ind, Lx); if (e >= 0) lused[e] = 1; first_x = false; }
+            const int el = L->bwd_off[i] + k1;
+            x_ind = L->bwd_src[el]; y_ind = j;
+            lused[L->bwd_eid[el]] = 1;
+            --i;
+        } else if (vit == PAGAN_Y_MAT) {
+            if (first_y) { int e = find_edge(R, y_ind, Ly); if (e >= 0) rused[e] = 1; first_y = false; }
+            const int er = R->bwd_off[j] + k2;
+            y_ind = R->bwd_src[er]; x_ind = i;
+            rused[R->bwd_eid[er]] = 1;
+            --j;
+        } else {
+            return PAGAN_E_INTERNAL;
+        }
+        skips(x_ind, y_ind);
+        push(from);
+    }
+    if (!(i < 1 && j < 1)) return PAGAN_E_INTERNAL;
+
+    out->n_cols = (int32_t)stack.size();
+    out->cols = (pagan_col *)std::malloc(sizeof(pagan_col) * (stack.size() + 1));
+    if (!out->cols) return PAGAN_E_NOMEM;
+    int l_pos = 1, r_pos = 1;
+    for (size_t k = 0; k < stack.size(); ++k) {
+        const Step &s = stack[stack.size() - 1 - k];
+        pagan_col c;
+        if (s.matrix == PAGAN_X_MAT) { c.left = l_pos++; c.right = -1; c.path_state = s.real ? PAGAN_XGAPPED : PAGAN_XSKIPPED; }
+        else if (s.matrix == PAGAN_Y_MAT) { c.left = -1; c.right = r_pos++; c.path_state = s.real ? PAGAN_YGAPPED : PAGAN_YSKIPPED; }
+        else { c.left = l_pos++; c.right = r_pos++; c.path_state = PAGAN_MATCHED; }
+        out->cols[k] = c;
+    }
+    if (l_pos != Lx || r_pos != Ly) { std::free(out->cols); out->cols = nullptr; return PAGAN_E_INTERNAL; }
+    auto collect = [](const std::vector<char> &u, int32_t *cnt, int32_t **arr) {
+        int c = 0;
+        for (char x : u) c += x;
+        *arr = (int32_t *)std::malloc(sizeof(int32_t) * (c + 1));
+        int k = 0;
+        for (size_t e = 0; e < u.size(); ++e) if (u[e]) (*arr)[k++] = (int32_t)e;
+        *cnt = c;
+    };
+    collect(lused, &out->n_left_used, &out->left_used);
+    collect(rused, &out->n_right_used, &out->right_used);
+    out->status = PAGAN_DP_REACHED;
+    return PAGAN_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *pagan_dp_version(void) { return "pagan_dp 0.1 (gfx950 wavefront)"; }
+
+int pagan_dp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pagan_dp_select_device(int32_t device) {
+    HIP_TRY(hipSetDevice(device));
+    return PAGAN_OK;
+}
+
+int64_t pagan_dp_count_cells(int32_t left_sites, int32_t right_sites, const pagan_band *band) {
+    if (left_sites < 2 || right_sites < 2) return PAGAN_E_ARG;
+    RowBand rb;
+    int rc = rb.build(left_sites - 1, right_sites - 1, band);
+    if (rc != PAGAN_OK) return rc;
+    return rb.cells();
+}
+
+// Device bytes for one alignment: 36 B per in-band cell (3 x (f64 score + u32 back-pointer))
+// plus the per-diagonal index and the trace buffer.  Graph/model inputs are negligible.
+int64_t pagan_dp_predict_bytes(int32_t left_sites, int32_t right_sites, const pagan_band *band) {
+    int64_t cells = pagan_dp_count_cells(left_sites, right_sites, band);
+    if (cells < 0) return cells;
+    const int64_t nd = (int64_t)left_sites + right_sites - 3;
+    return cells * 36 + nd * 16 + (nd + 1) * 12 + 64 * 1024;
+}
+
+int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts, pagan_batch **out) {
+    if (n <= 0 || !jobs || !out) return PAGAN_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PAGAN_E_NODEVICE;
+    pagan_batch *b = new (std::nothrow) pagan_batch();
+    if (!b) return PAGAN_E_NOMEM;
+    struct Guard { pagan_batch *b; ~Guard() { if (b) pagan_batch_destroy(b); } } guard{b};
+    b->n = n;
+    b->flags = opts ? opts->flags : 0;
+    if (opts && opts->device >= 0) HIP_TRY(hipSetDevice(opts->device));
+    HIP_TRY(hipGetDevice(&b->device));
+    b->jobs.resize(n);
+    b->dj.resize(n);
+    int max_w = 0;
+    for (int k = 0; k < n; ++k) {
+        RowBand rb;
+        int rc = validate_job(jobs[k], &b->jobs[k], &rb);
+        if (rc != PAGAN_OK) return rc;
+        b->cells += b->jobs[k].dx.cells;
+        if (b->jobs[k].dx.max_width > max_w) max_w = b->jobs[k].dx.max_width;
+    }
+    b->block = max_w <= 64 ? 64 : (max_w <= 512 ? 256 : 1024);
+
+    // pass 1: sizes.  Inputs first (one contiguous upload), outputs after.
+    Carver sizer;
+    PgDevJob *jobs_off = sizer.take<PgDevJob>(n);
+    for (int k = 0; k < n; ++k) carve_job(sizer, jobs[k], b->jobs[k], &b->dj[k]);
+    const size_t in_bytes = sizer.cur;
+    for (int k = 0; k < n; ++k) carve_outputs(sizer, b->jobs[k], &b->dj[k]);
+    b->arena.size = sizer.cur;
+    HIP_TRY(hipMalloc((void **)&b->arena.dev, b->arena.size));
+
+    // pass 2: stage inputs (offsets from pass 1 index the staging buffer), then rebase.
+    std::vector<char> stage(in_bytes);
+    for (int k = 0; k < n; ++k) {
+        const pagan_job &jb = jobs[k];
+        const HostJob &hj = b->jobs[k];
+        const PgDevJob &d = b->dj[k];
+        const pagan_graph *L = jb.left, *R = jb.right;
+        put(stage, d.stL, L->state, L->n_sites); put(stage, d.offL, L->bwd_off, L->n_sites + 1);
+        put(stage, d.srcL, L->bwd_src, L->bwd_off[L->n_sites]); put(stage, d.lwL, L->bwd_logw, L->bwd_off[L->n_sites]);
+        put(stage, d.stR, R->state, R->n_sites); put(stage, d.offR, R->bwd_off, R->n_sites + 1);
+        put(stage, d.srcR, R->bwd_src, R->bwd_off[R->n_sites]); put(stage, d.lwR, R->bwd_logw, R->bwd_off[R->n_sites]);
+        put(stage, d.table, jb.model->log_score, (size_t)d.S * d.S);
+        put(stage, d.imin, hj.dx.imin.data(), hj.dx.imin.size());
+        put(stage, d.imax, hj.dx.imax.data(), hj.dx.imax.size());
+        put(stage, d.doff, hj.dx.doff.data(), hj.dx.doff.size());
+    }
+    b->trace_off.resize(n); b->end_off.resize(n); b->score_off.resize(n);
+    char *base = b->arena.dev;
+    auto rebase = [&](auto *&p) { p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(base + reinterpret_cast<size_t>(p)); };
+    for (int k = 0; k < n; ++k) {
+        PgDevJob &d = b->dj[k];
+        b->trace_off[k] = reinterpret_cast<size_t>(d.trace);
+        b->end_off[k] = reinterpret_cast<size_t>(d.endcell);
+        b->score_off[k] = reinterpret_cast<size_t>(d.endscore);
+        rebase(d.stL); rebase(d.offL); rebase(d.srcL); rebase(d.lwL);
+        rebase(d.stR); rebase(d.offR); rebase(d.srcR); rebase(d.lwR);
+        rebase(d.table); rebase(d.imin); rebase(d.imax); rebase(d.doff);
+        for (int m = 0; m < 3; ++m) { rebase(d.sc[m]); rebase(d.bp[m]); }
+        rebase(d.trace); rebase(d.endcell); rebase(d.endscore);
+    }
+    std::memcpy(stage.data() + reinterpret_cast<size_t>(jobs_off), b->dj.data(), sizeof(PgDevJob) * n);
+    b->d_jobs = reinterpret_cast<PgDevJob *>(base + reinterpret_cast<size_t>(jobs_off));
+    HIP_TRY(hipStreamCreate(&b->stream));
+    for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipMemcpyAsync(base, stage.data(), in_bytes, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    guard.b = nullptr;
+    *out = b;
+    return PAGAN_OK;
+}
+
+int pagan_batch_run(pagan_batch *b) {
+    if (!b) return PAGAN_E_ARG;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipEventRecord(b->ev[0], b->stream));
+    int rc = launch_fill(b);
+    if (rc != PAGAN_OK) return rc;
+    HIP_TRY(hipEventRecord(b->ev[1], b->stream));
+    hipLaunchKernelGGL(pg_end_and_trace, dim3(b->n), dim3(64), 0, b->stream, b->d_jobs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->ev[2], b->stream));
+    b->ran = true;
+    return PAGAN_OK;
+}
+
+int pagan_batch_sync(pagan_batch *b) {
+    if (!b) return PAGAN_E_ARG;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return PAGAN_OK;
+}
+
+int pagan_batch_last_ms(pagan_batch *b, double ms[2]) {
+    if (!b || !b->ran) return PAGAN_E_ARG;
+    HIP_TRY(hipEventSynchronize(b->ev[2]));
+    float a = 0, c = 0;
+    HIP_TRY(hipEventElapsedTime(&a, b->ev[0], b->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&c, b->ev[1], b->ev[2]));
+    ms[0] = a; ms[1] = c;
+    return PAGAN_OK;
+}
+
+int64_t pagan_batch_cells(const pagan_batch *b) { return b ? b->cells : 0; }
+
+int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
+    if (!b || !out || !b->ran) return PAGAN_E_ARG;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    double ms[2] = {0, 0};
+    pagan_batch_last_ms(b, ms);
+    for (int k = 0; k < b->n; ++k) std::memset(&out[k], 0, sizeof(pagan_result));
+    int first_err = PAGAN_OK;
+    std::vector<int> trace;
+    for (int k = 0; k < b->n; ++k) {
+        const HostJob &hj = b->jobs[k];
+        int endcell[8];
+        double endscore;
+        HIP_TRY(hipMemcpy(endcell, b->arena.dev + b->end_off[k], sizeof(endcell), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&endscore, b->arena.dev + b->score_off[k], sizeof(double), hipMemcpyDeviceToHost));
+        const int nt = endcell[0] == 0 ? endcell[6] : 0;
+        trace.resize(3 * (size_t)nt + 3);
+        if (nt > 0)
+            HIP_TRY(hipMemcpy(trace.data(), b->arena.dev + b->trace_off[k], sizeof(int) * 3 * (size_t)nt, hipMemcpyDeviceToHost));
+        int rc = replay(hj, endcell, endscore, trace.data(), &out[k]);
+        out[k].fill_ms = ms[0];
+        out[k].trace_ms = ms[1];
+        if (rc != PAGAN_OK && first_err == PAGAN_OK) first_err = rc;
+    }
+    return first_err;
+}
+
+void pagan_batch_destroy(pagan_batch *b) {
+    if (!b) return;
+    if (b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
+    for (auto &e : b->ev) if (e) hipEventDestroy(e);
+    if (b->arena.dev) hipFree(b->arena.dev);
+    delete b;
+}
+
+int pagan_dp_align_batch(int32_t n, const pagan_job *jobs, const pagan_opts *opts, pagan_result *out) {
+    if (!out) return PAGAN_E_ARG;
+    pagan_batch *b = nullptr;
+    int rc = pagan_batch_create(n, jobs, opts, &b);
+    if (rc != PAGAN_OK) return rc;
+    rc = pagan_batch_run(b);
+    if (rc == PAGAN_OK) rc = pagan_batch_fetch(b, out);
+    pagan_batch_destroy(b);
+    return rc;
+}
+
+int pagan_dp_align(const pagan_graph *left, const pagan_graph *right, const pagan_model *model,
+                   const pagan_band *band, const pagan_opts *opts, pagan_result *out) {
+    pagan_job jb{left, right, model, band};
+    return pagan_dp_align_batch(1, &jb, opts, out);
+}
+
+void pagan_result_free(pagan_result *r) {
+    if (!r) return;
+    std::free(r->cols); std::free(r->left_used); std::free(r->right_used);
+    r->cols = nullptr; r->left_used = nullptr; r->right_used = nullptr;
+    r->n_cols = r->n_left_used = r->n_right_used = 0;
+}
+
+} // extern "C"

@@ -1,0 +1,45 @@
+// dp_device.h -- device-side job descriptor shared by the kernels and the C-ABI layer.
+//
+// HBM layout of one alignment (all arrays 256-B aligned inside one arena per batch):
+//
+//   inputs   left/right graph CSR (state, bwd_off, bwd_src, bwd_logw) -- 4 B per site + 8 B per edge
+//            model table S*S f32
+//            diagonal index: imin[d], imax[d] (i32), doff[d] (i64) for d = 0 .. Lx+Ly-2
+//   outputs  score[3][cells] f64  (M, X, Y)   } DIAGONAL-MAJOR: cell (i,j), d=i+j, lives at
+//            bp[3][cells]    u32  (M, X, Y)   } doff[d] + (i - imin[d]) -- one anti-diagonal is
+//                                                contiguous, so a wavefront's loads/stores coalesce
+//            trace[Lx+Ly] {i,j,mat|slots}      visited cells of the Viterbi path, end to start
+//            endcell                           the end-corner result (max_end)
+//
+// A back-pointer packs what Matrix_pointer (basic_alignment.h:33-50) records for the Viterbi
+// path: the predecessor matrix and WHICH bwd edges were taken, as slots into the two sites'
+// bwd lists (x_ind/y_ind/x_edge_ind/y_edge_ind follow from the slot via the CSR arrays):
+//   bits 0-1  from: 0 = X, 1 = Y, 2 = M, 3 = none (cell kept score -inf / matrix -1)
+//   bits 2-16 slot in the left site's bwd list   (M and X cells)
+//   bits 17-31 slot in the right site's bwd list (M and Y cells)
+#pragma once
+#include <stdint.h>
+
+#define PG_BP_NONE 3u
+#define PG_MAX_SLOT 32767
+
+struct PgDevJob {
+    int Lx, Ly;              // matrix dimensions (sites minus the stop site)
+    int nd;                  // number of anti-diagonals = Lx + Ly - 1
+    int S;                   // model states
+    float go, ge, gE, ng;    // log_gap_open, log_gap_ext, log_gap_end_ext, log_non_gap
+    // left / right graph (device pointers)
+    const int *stL, *offL, *srcL; const float *lwL;
+    const int *stR, *offR, *srcR; const float *lwR;
+    const float *table;      // [a + b*S]
+    // band in diagonal form
+    const int *imin, *imax;
+    const long long *doff;
+    long long cells;
+    // outputs
+    double *sc[3];           // indexed by PAGAN_X_MAT / Y_MAT / M_MAT
+    unsigned *bp[3];
+    int *trace;              // [3 * (Lx+Ly)]
+    int *endcell;            // [8]: status, matrix, x_ind, y_ind, slot_l, slot_r, n_trace, pad ; score in endscore
+    double *endscore;        // [1]
+};
