@@ -1,0 +1,112 @@
+/*
+ * pagan_host.h -- C ABI of the host-side guide-tree walk that drives pagan_dp.h.
+ *
+ * Mirrors the part of the reference's Node class that calls the aligner:
+ * Node::start_alignment / start_openmp_alignment -> align_sequences_this_node
+ * (src/main/node.h:880-938, src/main/node.cpp:52-285): post-order over a rooted binary guide
+ * tree; at every internal node build the Evol_model for dist = d_left + d_right, define the
+ * tunnel from anchors, call the pairwise aligner (GPU), build the parent Sequence graph.
+ * Nodes whose children are finished are independent and are aligned as one batch
+ * (node.cpp:227-285), optionally spread over several devices (no collectives).
+ *
+ * Also exposes the host graph builder on its own (pagan_hgraph_*), the counterpart of
+ * Sequence construction (src/main/sequence.cpp:152-303) and
+ * Basic_alignment::build_ancestral_sequence (src/main/basic_alignment.cpp:36-653).
+ */
+#ifndef PAGAN_HOST_H
+#define PAGAN_HOST_H
+
+#include <stdint.h>
+#include "pagan_dp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAGAN_E_TREE   -20   /* Newick parse error / tree not rooted binary / unknown leaf */
+#define PAGAN_E_MEMCAP -21   /* one alignment would not fit the device memory budget         */
+
+typedef struct pagan_msa pagan_msa;
+
+typedef struct pagan_msa_opts {
+    int32_t  use_anchors;        /* 0 = --no-anchors (full matrix), 1 = --use-prefix-anchors      */
+    int32_t  anchors_offset;     /* --anchors-offset, default 15 (settings.cpp:157)              */
+    int32_t  prefix_hit_length;  /* --prefix-hit-length, default 30 (settings.cpp:160)           */
+    int32_t  hit_trim;           /* --exonerate-hit-trim, default 5 (settings.cpp:155)           */
+    uint32_t dp_flags;           /* PAGAN_OPT_*                                                  */
+    int32_t  leaf_flags;         /* 1 = --454, 2 = --homopolymer (sequence.cpp:205,253)          */
+    int32_t  keep_all_edges;     /* --keep-all-edges (basic_alignment.h:572-586)                 */
+    int32_t  n_devices;          /* devices to farm ready nodes over; 0 = just the current one   */
+    int32_t  first_device;       /* ordinal of the first device used                             */
+    int32_t  host_threads;       /* threads for anchors / graph building; 0 = hardware           */
+    float    truncate_branches;  /* --truncate-branches, default 0.2 (settings.cpp:228)          */
+    int64_t  device_mem_budget;  /* bytes of HBM one batch may use; 0 = 80% of free memory       */
+} pagan_msa_opts;
+
+void pagan_msa_default_opts(pagan_msa_opts *o);
+
+typedef struct pagan_node_info {
+    int32_t node, left, right;   /* node ids: leaves 0..n-1 in input order, internal n..2n-2
+                                    in alignment (post-order) order                              */
+    int32_t level;               /* batch (tree level) the node was aligned in                   */
+    int32_t left_sites, right_sites, sites;
+    int32_t n_hits;
+    int64_t cells;
+    double  dist;                /* d_left + d_right after truncation (node.cpp:70)               */
+    double  score;
+    int32_t status;
+} pagan_node_info;
+
+typedef struct pagan_msa_timing {
+    double total_s, model_s, anchors_s, dp_wall_s, dp_fill_dev_s, dp_trace_dev_s, build_s;
+} pagan_msa_timing;
+
+int  pagan_msa_create(int32_t n_seqs, const char *const *names, const char *const *seqs,
+                      const char *newick, const pagan_msa_opts *opts, pagan_msa **out);
+/* Progressive alignment of every internal node; the DP runs on the GPU(s).               */
+int  pagan_msa_align(pagan_msa *m);
+int  pagan_msa_n_internal(const pagan_msa *m);
+int  pagan_msa_node_info(const pagan_msa *m, int32_t k, pagan_node_info *out);
+/* Borrowed views (valid until pagan_msa_destroy) of what node k's alignment consumed and
+ * produced: usable as a pagan_job for pagan_batch_create / the oracle.                   */
+int  pagan_msa_node_job(const pagan_msa *m, int32_t k, pagan_job *out);
+int  pagan_msa_node_result(const pagan_msa *m, int32_t k, pagan_result *out);
+int  pagan_msa_timing_get(const pagan_msa *m, pagan_msa_timing *out);
+int  pagan_msa_alignment_length(const pagan_msa *m);
+/* Row of leaf `leaf` (input order) of the final alignment, '-' for gaps; buf >= length+1. */
+int  pagan_msa_alignment_row(const pagan_msa *m, int32_t leaf, char *buf);
+void *pagan_msa_node_graph(const pagan_msa *m, int32_t node);   /* a pagan_hgraph (borrowed)  */
+void pagan_msa_destroy(pagan_msa *m);
+
+/* ---- host graphs on their own ---------------------------------------------------------- */
+typedef struct pagan_hgraph pagan_hgraph;
+pagan_hgraph *pagan_hgraph_leaf(const char *residues, const char *full_alphabet, int32_t flags);
+/* flags: bit0 reads/keep-all-edges settings, bit1 --no-reduced-terminal-penalties            */
+pagan_hgraph *pagan_hgraph_parent(pagan_hgraph *left, pagan_hgraph *right, const pagan_result *res,
+                                  float left_branch, float right_branch, const int32_t *parsimony,
+                                  int32_t n_states, int32_t char_as, int32_t flags);
+void pagan_hgraph_view(const pagan_hgraph *g, pagan_graph *out);
+/* site_attr [n_sites][8] = state,type,path_state,left,right,count_since_used,ambiguous,n_fwd;
+ * site_dist [n_sites]; edge_attr [n_edges][6] = start,end,used,count_since_used,
+ * count_as_skipped,linked; edge_f [n_edges][3] = weight,log_weight,dist_since_used.       */
+void pagan_hgraph_attrs(const pagan_hgraph *g, int32_t *site_attr, float *site_dist,
+                        int32_t *edge_attr, float *edge_f);
+void pagan_hgraph_fwd(const pagan_hgraph *g, int32_t *fwd_off, int32_t *fwd_eid);
+int  pagan_hgraph_string(const pagan_hgraph *g, int32_t with_gaps, const char *full_alphabet, char *out);
+void pagan_hgraph_free(pagan_hgraph *g);
+
+/* Viterbi_alignment::define_tunnel for --use-prefix-anchors; upper/lower hold
+ * strlen(gapped1)+1 entries.  Returns the number of anchors used.                        */
+int  pagan_define_tunnel(const char *s1, const char *s2, const char *gapped1, const char *gapped2,
+                         int32_t prefix_hit_length, int32_t hit_trim, int32_t offset,
+                         int32_t *upper, int32_t *lower);
+
+/* DNA Evol_model for a distance: table [a + b*15] (15x15 floats), params[4] =
+ * log_gap_open, log_gap_ext, log_gap_end_ext, log_non_gap; parsimony [i + j*15].          */
+int  pagan_dna_model(const float base_freq[4], double distance, float *table, float *params,
+                     int32_t *parsimony);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAGAN_HOST_H */

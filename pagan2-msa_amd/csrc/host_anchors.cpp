@@ -1,0 +1,191 @@
+// host_anchors.cpp -- see host_anchors.h.
+//
+// The reference sorts char* suffix pointers of two NUL-terminated copies with qsort+strcmp
+// (glibc's qsort is a stable merge sort here) and reports every adjacent cross-string pair
+// with a common prefix >= min_length (find_anchors.cpp:66-85).  That order is the suffix
+// array of  a + '\0' + b + '\1'  over an alphabet where both sentinels sort below every
+// residue and '\0' < '\1': a shorter suffix sorts first, and of two identical suffixes the
+// one from `a` comes first, which is what the stable sort of [a-suffixes..., b-suffixes...]
+// yields.  So the suffix array is built directly (prefix doubling with counting sorts,
+// O(n log maxLCP)) and the common prefixes come from Kasai's LCP pass instead of strcmp
+// walks; the hit list is identical and in identical order.
+#include "host_anchors.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace pagan {
+
+namespace {
+
+// Suffix array of `t` (values < sigma), prefix doubling.
+void suffix_array(const std::vector<int> &t, int sigma, std::vector<int> *sa_out, std::vector<int> *rank_out) {
+    const int n = (int)t.size();
+    std::vector<int> sa(n), rk(n), tmp(n), cnt(std::max(sigma, n) + 1);
+    // initial sort by first symbol
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (int i = 0; i < n; ++i) cnt[t[i] + 1]++;
+    for (int c = 0; c < sigma; ++c) cnt[c + 1] += cnt[c];
+    for (int i = 0; i < n; ++i) sa[cnt[t[i]]++] = i;
+    rk[sa[0]] = 0;
+    int classes = 1;
+    for (int i = 1; i < n; ++i) { if (t[sa[i]] != t[sa[i - 1]]) classes++; rk[sa[i]] = classes - 1; }
+    std::vector<int> sa2(n);
+    for (int k = 1; classes < n; k <<= 1) {
+        // order by second key: suffixes i with i+k >= n come first (empty second key), then by sa order
+        int p = 0;
+        for (int i = n - k; i < n; ++i) sa2[p++] = i;
+        for (int i = 0; i < n; ++i) if (sa[i] >= k) sa2[p++] = sa[i] - k;
+        // stable counting sort by first key
+        std::fill(cnt.begin(), cnt.begin() + classes + 1, 0);
+        for (int i = 0; i < n; ++i) cnt[rk[i] + 1]++;
+        for (int c = 0; c < classes; ++c) cnt[c + 1] += cnt[c];
+        for (int i = 0; i < n; ++i) sa[cnt[rk[sa2[i]]]++] = sa2[i];
+        tmp[sa[0]] = 0;
+        int nc = 1;
+        for (int i = 1; i < n; ++i) {
+            const int a = sa[i - 1], b = sa[i];
+            const int ra2 = a + k < n ? rk[a + k] : -1, rb2 = b + k < n ? rk[b + k] : -1;
+            if (rk[a] != rk[b] || ra2 != rb2) nc++;
+            tmp[b] = nc - 1;
+        }
+        rk.swap(tmp);
+        classes = nc;
+    }
+    *sa_out = std::move(sa);
+    *rank_out = std::move(rk);
+}
+
+// Overlap filter shared by find_long_substrings (:89-126) and check_hits_order_conflict (:232-278):
+// walk the hits in order, drop one that touches an already covered site of either string.
+void drop_overlapping(std::vector<Hit> *hits, int len1, int len2) {
+    std::vector<uint8_t> h1(len1, 0), h2(len2, 0);
+    size_t out = 0;
+    for (size_t k = 0; k < hits->size(); ++k) {
+        const Hit h = (*hits)[k];
+        bool overlap = false;
+        for (int i = h.s1, j = h.s2; i < h.s1 + h.len && j < h.s2 + h.len; ++i, ++j)
+            if (h1[i] || h2[j]) { overlap = true; break; }
+        if (overlap) continue;
+        for (int i = h.s1, j = h.s2; i < h.s1 + h.len && j < h.s2 + h.len; ++i, ++j) { h1[i] = 1; h2[j] = 1; }
+        (*hits)[out++] = h;
+    }
+    hits->resize(out);
+}
+
+} // namespace
+
+void prefix_hits(const std::string &a, const std::string &b, int min_length, std::vector<Hit> *hits) {
+    const int len1 = (int)a.size(), len2 = (int)b.size();
+    const int n = len1 + len2 + 2;
+    std::vector<int> t(n);
+    for (int i = 0; i < len1; ++i) t[i] = (unsigned char)a[i] + 2;
+    t[len1] = 0;
+    for (int i = 0; i < len2; ++i) t[len1 + 1 + i] = (unsigned char)b[i] + 2;
+    t[n - 1] = 1;
+    std::vector<int> sa, rk;
+    suffix_array(t, 258, &sa, &rk);
+    // Kasai: lcp[r] = common prefix of suffixes at ranks r-1 and r.  The sentinels are unique,
+    // so a common prefix never runs through one -- it is the strcmp prefix of the two strings.
+    std::vector<int> lcp(n, 0);
+    for (int i = 0, h = 0; i < n; ++i) {
+        if (rk[i] == 0) { h = 0; continue; }
+        const int j = sa[rk[i] - 1];
+        while (i + h < n && j + h < n && t[i + h] == t[j + h] && t[i + h] > 1) ++h;
+        lcp[rk[i]] = h;
+        if (h > 0) --h;
+    }
+    // The two sentinel suffixes sort first and are not part of the reference's pointer array.
+    for (int r = 1; r < n; ++r) {
+        const int p = sa[r - 1], q = sa[r];
+        if (p == len1 || p == n - 1 || q == len1 || q == n - 1) continue;
+        const bool p1 = p < len1, q1 = q < len1;
+        if (p1 == q1) continue;                                   // different_strings, find_anchors.h:107-115
+        if (lcp[r] < min_length) continue;
+        Hit h;
+        h.s1 = p1 ? p : q;
+        h.s2 = (p1 ? q : p) - (len1 + 1);
+        h.len = lcp[r]; h.score = lcp[r];
+        hits->push_back(h);
+    }
+    std::sort(hits->begin(), hits->end(), [](Hit p, Hit q) { return p.len > q.len; });   // :87
+    drop_overlapping(hits, len1, len2);
+}
+
+void resolve_conflicts(int len1, int len2, int trim, std::vector<Hit> *hits) {
+    std::sort(hits->begin(), hits->end(), [](Hit p, Hit q) { return p.score > q.score; });   // :230
+    for (Hit &h : *hits) h.len -= trim * 2;          // :252; the start shifts at :248-251 are no-ops
+    drop_overlapping(hits, len1, len2);
+    std::sort(hits->begin(), hits->end(), [](Hit p, Hit q) { return p.s1 == q.s1 ? p.s2 < q.s2 : p.s1 < q.s1; });   // :280
+    // :282-304: neighbours out of order in the second string -> drop the lower-scoring one and
+    // re-test the survivor against the next hit.  `kept` is the hits before it1, in order.
+    std::vector<Hit> kept;
+    kept.reserve(hits->size());
+    size_t k = 0;
+    const size_t n = hits->size();
+    if (n == 0) return;
+    Hit cur = (*hits)[k++];
+    while (k < n) {
+        const Hit nxt = (*hits)[k];
+        if (cur.s2 > nxt.s2) {
+            if (cur.score < nxt.score) cur = nxt;    // erase it1; it1 now names the old it2
+            ++k;                                     // either way the pair shrinks to one hit
+            continue;
+        }
+        kept.push_back(cur);
+        cur = nxt;
+        ++k;
+    }
+    kept.push_back(cur);
+    hits->swap(kept);
+}
+
+void hits_to_band(const std::vector<Hit> &hits, const std::string &str1, const std::string &str2, int width,
+                  std::vector<int32_t> *upper, std::vector<int32_t> *lower) {
+    const int length1 = (int)str1.size(), length2 = (int)str2.size();
+    std::vector<int> index1, index2;
+    index1.reserve(length1); index2.reserve(length2);
+    for (int i = 0; i < length1; ++i) if (str1[i] != '-') index1.push_back(i + 1);
+    for (int i = 0; i < length2; ++i) if (str2[i] != '-') index2.push_back(i + 1);
+    std::vector<int> diag(length1 + 1, -1);
+    for (const Hit &h : hits) {
+        int i = 0;
+        for (; i < h.len; ++i) diag[index1[h.s1 + i]] = index2[h.s2 + i];
+        if (h.s1 + i < (int)index1.size() && index1[h.s1 + i] < (int)diag.size()) diag[index1[h.s1 + i]] = -2;
+    }
+    upper->assign(length1 + 1, 0);
+    lower->assign(length1 + 1, 0);
+    int y1 = 0, y2 = 0, prev_y = 0, m_count = 0;
+    for (int i = 0; i <= length1; ++i) {                                   // :373-408
+        if (i >= width && diag[i - width] >= 0) y1 = diag[i - width];
+        if (diag[i] >= 0) y2 = diag[i] - width;
+        const bool run = diag[i] >= 0 && i > 0 && diag[i - 1] + 1 == diag[i];
+        if (run) m_count++; else if (diag[i] == -2) m_count = 0;
+        int y = std::max(std::min(y1, y2), 0);
+        if (run && m_count >= width) prev_y = y;
+        (*upper)[i] = std::max(std::min(y, prev_y), 0);
+    }
+    y1 = y2 = prev_y = length2; m_count = 0;
+    for (int i = length1; i >= 0; --i) {                                   // :416-447
+        if (i <= length1 - width && diag[i + width] >= 0) y1 = diag[i + width];
+        if (diag[i] >= 0) y2 = diag[i] + width;
+        const bool run = diag[i] >= 0 && i < length1 && diag[i + 1] - 1 == diag[i];
+        if (run) m_count++; else if (diag[i] == -2) m_count = 0;
+        int y = std::min(std::max(y1, y2), length2);
+        if (run && m_count >= width) prev_y = y;
+        (*lower)[i] = std::min(std::max(y, prev_y), length2);
+    }
+}
+
+int define_tunnel(const std::string &s1, const std::string &s2, const std::string &g1, const std::string &g2,
+                  const AnchorSettings &as, std::vector<int32_t> *upper, std::vector<int32_t> *lower) {
+    std::vector<Hit> hits;
+    prefix_hits(s1, s2, as.prefix_hit_length, &hits);
+    // check_hits_order_conflict receives the GAPPED strings' lengths (viterbi_alignment.cpp:138-161)
+    resolve_conflicts((int)g1.size(), (int)g2.size(), as.hit_trim, &hits);
+    hits_to_band(hits, g1, g2, as.offset, upper, lower);
+    return (int)hits.size();
+}
+
+} // namespace pagan

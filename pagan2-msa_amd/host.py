@@ -1,0 +1,302 @@
+"""ctypes front end of include/pagan_host.h: the host-side guide-tree walk (Node mirror), the
+host graph builder (Sequence / build_ancestral_sequence mirror), anchors and the DNA model.
+All of it lives in libpagan_dp.so; the DP itself always runs on the GPU."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+PAGAN_E_TREE = -20
+PAGAN_E_MEMCAP = -21
+DNA_FULL = "ACGTRYMKWSBDHVN"
+
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+
+
+class CMsaOpts(C.Structure):
+    _fields_ = [("use_anchors", C.c_int32), ("anchors_offset", C.c_int32), ("prefix_hit_length", C.c_int32),
+                ("hit_trim", C.c_int32), ("dp_flags", C.c_uint32), ("leaf_flags", C.c_int32),
+                ("keep_all_edges", C.c_int32), ("n_devices", C.c_int32), ("first_device", C.c_int32),
+                ("host_threads", C.c_int32), ("truncate_branches", C.c_float), ("device_mem_budget", C.c_int64)]
+
+
+class CNodeInfo(C.Structure):
+    _fields_ = [("node", C.c_int32), ("left", C.c_int32), ("right", C.c_int32), ("level", C.c_int32),
+                ("left_sites", C.c_int32), ("right_sites", C.c_int32), ("sites", C.c_int32), ("n_hits", C.c_int32),
+                ("cells", C.c_int64), ("dist", C.c_double), ("score", C.c_double), ("status", C.c_int32)]
+
+
+class CTiming(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("total_s", "model_s", "anchors_s", "dp_wall_s", "dp_fill_dev_s",
+                                           "dp_trace_dev_s", "build_s")]
+
+
+_declared = False
+
+
+def _lib():
+    from . import lib
+    L = lib()
+    global _declared
+    if not _declared:
+        vp = C.c_void_p
+        L.pagan_msa_default_opts.argtypes = [C.POINTER(CMsaOpts)]
+        L.pagan_msa_default_opts.restype = None
+        L.pagan_msa_create.argtypes = [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_char_p,
+                                       C.POINTER(CMsaOpts), C.POINTER(vp)]
+        L.pagan_msa_create.restype = C.c_int
+        L.pagan_msa_align.argtypes = [vp]
+        L.pagan_msa_align.restype = C.c_int
+        L.pagan_msa_n_internal.argtypes = [vp]
+        L.pagan_msa_n_internal.restype = C.c_int
+        L.pagan_msa_node_info.argtypes = [vp, C.c_int32, C.POINTER(CNodeInfo)]
+        L.pagan_msa_node_info.restype = C.c_int
+        L.pagan_msa_node_job.argtypes = [vp, C.c_int32, C.POINTER(abi.CJob)]
+        L.pagan_msa_node_job.restype = C.c_int
+        L.pagan_msa_node_result.argtypes = [vp, C.c_int32, C.POINTER(abi.CResult)]
+        L.pagan_msa_node_result.restype = C.c_int
+        L.pagan_msa_timing_get.argtypes = [vp, C.POINTER(CTiming)]
+        L.pagan_msa_timing_get.restype = C.c_int
+        L.pagan_msa_alignment_length.argtypes = [vp]
+        L.pagan_msa_alignment_length.restype = C.c_int
+        L.pagan_msa_alignment_row.argtypes = [vp, C.c_int32, C.c_char_p]
+        L.pagan_msa_alignment_row.restype = C.c_int
+        L.pagan_msa_node_graph.argtypes = [vp, C.c_int32]
+        L.pagan_msa_node_graph.restype = vp
+        L.pagan_msa_destroy.argtypes = [vp]
+        L.pagan_msa_destroy.restype = None
+        L.pagan_hgraph_leaf.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
+        L.pagan_hgraph_leaf.restype = vp
+        L.pagan_hgraph_parent.argtypes = [vp, vp, C.POINTER(abi.CResult), C.c_float, C.c_float, _i32p, C.c_int32,
+                                          C.c_int32, C.c_int32]
+        L.pagan_hgraph_parent.restype = vp
+        L.pagan_hgraph_view.argtypes = [vp, C.POINTER(abi.CGraph)]
+        L.pagan_hgraph_view.restype = None
+        L.pagan_hgraph_attrs.argtypes = [vp, _i32p, _f32p, _i32p, _f32p]
+        L.pagan_hgraph_attrs.restype = None
+        L.pagan_hgraph_fwd.argtypes = [vp, _i32p, _i32p]
+        L.pagan_hgraph_fwd.restype = None
+        L.pagan_hgraph_string.argtypes = [vp, C.c_int32, C.c_char_p, C.c_char_p]
+        L.pagan_hgraph_string.restype = C.c_int
+        L.pagan_hgraph_free.argtypes = [vp]
+        L.pagan_hgraph_free.restype = None
+        L.pagan_define_tunnel.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32,
+                                          C.c_int32, _i32p, _i32p]
+        L.pagan_define_tunnel.restype = C.c_int
+        L.pagan_dna_model.argtypes = [_f32p, C.c_double, _f32p, _f32p, _i32p]
+        L.pagan_dna_model.restype = C.c_int
+        _declared = True
+    return L
+
+
+HOST_EXPORTED = ["pagan_msa_default_opts", "pagan_msa_create", "pagan_msa_align", "pagan_msa_n_internal",
+                 "pagan_msa_node_info", "pagan_msa_node_job", "pagan_msa_node_result", "pagan_msa_timing_get",
+                 "pagan_msa_alignment_length", "pagan_msa_alignment_row", "pagan_msa_node_graph",
+                 "pagan_msa_destroy", "pagan_hgraph_leaf", "pagan_hgraph_parent", "pagan_hgraph_view",
+                 "pagan_hgraph_attrs", "pagan_hgraph_fwd", "pagan_hgraph_string", "pagan_hgraph_free",
+                 "pagan_define_tunnel", "pagan_dna_model"]
+
+
+def _ip(a):
+    return a.ctypes.data_as(_i32p)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _graph_from_view(v):
+    """Copies a borrowed pagan_graph view into an abi.Graph."""
+    ns = v.n_sites
+    off = np.ctypeslib.as_array(v.bwd_off, shape=(ns + 1,)).copy()
+    nb = int(off[-1])
+    if nb:
+        src = np.ctypeslib.as_array(v.bwd_src, shape=(nb,)).copy()
+        lw = np.ctypeslib.as_array(v.bwd_logw, shape=(nb,)).copy()
+        eid = np.ctypeslib.as_array(v.bwd_eid, shape=(nb,)).copy()
+    else:
+        src, lw, eid = np.zeros(0, np.int32), np.zeros(0, np.float32), np.zeros(0, np.int32)
+    return abi.Graph(np.ctypeslib.as_array(v.state, shape=(ns,)).copy(), off, src, lw, eid, n_edges=v.n_edges)
+
+
+class HGraph:
+    """Host sequence graph (leaf or parent).  `owned=False` for graphs borrowed from an Msa."""
+
+    def __init__(self, handle, owned=True, keep=None):
+        self.h, self.owned, self._keep = handle, owned, keep
+
+    @classmethod
+    def leaf(cls, seq, alphabet=DNA_FULL, flags=0):
+        return cls(_lib().pagan_hgraph_leaf(seq.encode(), alphabet.encode(), flags))
+
+    @classmethod
+    def parent(cls, left, right, result, lbl, rbl, parsimony, char_as, flags=0):
+        """result: abi.Result (columns + used edges) of aligning left and right."""
+        r = abi.CResult()
+        cols = np.ascontiguousarray(result.cols, np.int32)
+        lu = np.ascontiguousarray(result.left_used, np.int32)
+        ru = np.ascontiguousarray(result.right_used, np.int32)
+        r.n_cols = int(cols.shape[0])
+        r.cols = C.cast(_ip(cols), C.POINTER(abi.CCol))
+        r.n_left_used, r.left_used = int(lu.shape[0]), _ip(lu)
+        r.n_right_used, r.right_used = int(ru.shape[0]), _ip(ru)
+        pars = np.ascontiguousarray(parsimony, np.int32)
+        S = int(round(pars.size ** 0.5))
+        return cls(_lib().pagan_hgraph_parent(left.h, right.h, C.byref(r), lbl, rbl, _ip(pars), S, char_as, flags))
+
+    def __del__(self):
+        if getattr(self, "owned", False) and self.h:
+            _lib().pagan_hgraph_free(self.h)
+            self.h = None
+
+    def flatten(self):
+        v = abi.CGraph()
+        _lib().pagan_hgraph_view(self.h, C.byref(v))
+        return _graph_from_view(v)
+
+    def attrs(self):
+        v = abi.CGraph()
+        L = _lib()
+        L.pagan_hgraph_view(self.h, C.byref(v))
+        ns, ne = v.n_sites, v.n_edges
+        sa = np.zeros((ns, 8), np.int32)
+        sd = np.zeros(ns, np.float32)
+        ea = np.zeros((max(ne, 1), 6), np.int32)
+        ef = np.zeros((max(ne, 1), 3), np.float32)
+        L.pagan_hgraph_attrs(self.h, _ip(sa), _fp(sd), _ip(ea), _fp(ef))
+        return sa, sd, ea[:ne], ef[:ne]
+
+    def fwd(self):
+        v = abi.CGraph()
+        L = _lib()
+        L.pagan_hgraph_view(self.h, C.byref(v))
+        off = np.zeros(v.n_sites + 1, np.int32)
+        eid = np.zeros(max(v.n_edges, 1), np.int32)
+        L.pagan_hgraph_fwd(self.h, _ip(off), _ip(eid))
+        return off, eid[:off[-1]]
+
+    def string(self, with_gaps, alphabet=DNA_FULL):
+        v = abi.CGraph()
+        L = _lib()
+        L.pagan_hgraph_view(self.h, C.byref(v))
+        buf = C.create_string_buffer(v.n_sites + 1)
+        n = L.pagan_hgraph_string(self.h, 1 if with_gaps else 0, alphabet.encode(), buf)
+        return buf.raw[:n].decode()
+
+
+def define_tunnel(s1, s2, g1, g2, prefix_hit_length=30, hit_trim=5, offset=15):
+    up = np.zeros(len(g1) + 1, np.int32)
+    lo = np.zeros(len(g1) + 1, np.int32)
+    n = _lib().pagan_define_tunnel(s1.encode(), s2.encode(), g1.encode(), g2.encode(), prefix_hit_length, hit_trim,
+                                   offset, _ip(up), _ip(lo))
+    return abi.Band(up, lo), n
+
+
+def dna_model(base_freq, dist):
+    """(abi.Model, parsimony[225]) for a DNA alignment at distance `dist`."""
+    bf = np.ascontiguousarray(base_freq, np.float32)
+    table = np.zeros(225, np.float32)
+    params = np.zeros(4, np.float32)
+    pars = np.zeros(225, np.int32)
+    rc = _lib().pagan_dna_model(_fp(bf), float(dist), _fp(table), _fp(params), _ip(pars))
+    if rc != 0:
+        raise RuntimeError("pagan_dna_model failed: %d" % rc)
+    return abi.Model(table.reshape(15, 15).T, *params), pars
+
+
+class Msa:
+    """Progressive alignment of sequences on a rooted binary guide tree (Node mirror)."""
+
+    def __init__(self, names, seqs, newick, **opts):
+        L = _lib()
+        o = CMsaOpts()
+        L.pagan_msa_default_opts(C.byref(o))
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError("unknown option %s" % k)
+            setattr(o, k, v)
+        self.n = len(names)
+        na = (C.c_char_p * self.n)(*[s.encode() for s in names])
+        sa = (C.c_char_p * self.n)(*[s.encode() for s in seqs])
+        self._h = C.c_void_p()
+        rc = L.pagan_msa_create(self.n, na, sa, newick.encode(), C.byref(o), C.byref(self._h))
+        if rc != 0:
+            from . import PaganError
+            raise PaganError(rc, "pagan_msa_create")
+        self._L = L
+
+    def align(self):
+        rc = self._L.pagan_msa_align(self._h)
+        if rc != 0:
+            from . import PaganError
+            raise PaganError(rc, "pagan_msa_align")
+        return self
+
+    @property
+    def n_internal(self):
+        return self._L.pagan_msa_n_internal(self._h)
+
+    def node_info(self, k):
+        info = CNodeInfo()
+        self._L.pagan_msa_node_info(self._h, k, C.byref(info))
+        return info
+
+    def node_cjob(self, k):
+        """Borrowed CJob (pointers into the Msa; valid while it lives)."""
+        j = abi.CJob()
+        rc = self._L.pagan_msa_node_job(self._h, k, C.byref(j))
+        if rc != 0:
+            raise RuntimeError("pagan_msa_node_job failed: %d" % rc)
+        return j
+
+    def node_job(self, k):
+        """(Graph, Graph, Model, Band|None) copies of node k's aligner inputs."""
+        j = self.node_cjob(k)
+        left, right = _graph_from_view(j.left.contents), _graph_from_view(j.right.contents)
+        m = j.model.contents
+        S = m.n_states
+        table = np.ctypeslib.as_array(m.log_score, shape=(S * S,)).copy()
+        model = abi.Model(table.reshape(S, S).T, m.log_gap_open, m.log_gap_ext, m.log_gap_end_ext, m.log_non_gap)
+        band = None
+        if j.band:
+            b = j.band.contents
+            band = abi.Band(np.ctypeslib.as_array(b.upper, shape=(b.n,)).copy(),
+                            np.ctypeslib.as_array(b.lower, shape=(b.n,)).copy())
+        return left, right, model, band
+
+    def node_result(self, k):
+        r = abi.CResult()
+        rc = self._L.pagan_msa_node_result(self._h, k, C.byref(r))
+        if rc != 0:
+            raise RuntimeError("pagan_msa_node_result failed: %d" % rc)
+        return abi.Result(r)
+
+    def node_graph(self, node):
+        return HGraph(self._L.pagan_msa_node_graph(self._h, node), owned=False, keep=self)
+
+    def timing(self):
+        t = CTiming()
+        self._L.pagan_msa_timing_get(self._h, C.byref(t))
+        return {k: getattr(t, k) for k, _ in CTiming._fields_}
+
+    def alignment(self):
+        n = self._L.pagan_msa_alignment_length(self._h)
+        rows = []
+        buf = C.create_string_buffer(n + 1)
+        for k in range(self.n):
+            self._L.pagan_msa_alignment_row(self._h, k, buf)
+            rows.append(buf.raw[:n].decode())
+        return rows
+
+    def close(self):
+        if self._h:
+            self._L.pagan_msa_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

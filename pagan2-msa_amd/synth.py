@@ -61,6 +61,83 @@ def evolve_balanced(n_leaves, length, branch=0.05, sub=0.04, indel_start=0.004, 
     return names, seqs, newick
 
 
+def _mutator(rng, A, sub, indel_start, mean_len):
+    p_geo = 1.0 / mean_len
+
+    def mutate(seq):
+        n = seq.shape[0]
+        out = seq.copy()
+        subs = rng.random(n) < sub
+        k = int(subs.sum())
+        if k:
+            out[subs] = (out[subs] + rng.integers(1, A, k)) % A
+        keep = np.ones(n, bool)
+        for s in np.nonzero(rng.random(n) < indel_start)[0]:
+            keep[s:s + int(rng.geometric(p_geo))] = False
+        ins_at = np.nonzero(rng.random(n) < indel_start)[0]
+        pieces, prev = [], 0
+        for s in ins_at:
+            pieces.append(out[prev:s][keep[prev:s]])
+            pieces.append(rng.integers(0, A, int(rng.geometric(p_geo))).astype(out.dtype))
+            prev = s
+        pieces.append(out[prev:][keep[prev:]])
+        return np.concatenate(pieces)
+    return mutate
+
+
+def evolve_caterpillar(n_leaves, length, branch=0.03, sub=0.03, indel_start=0.02, mean_len=3.0, seed=0,
+                       alphabet=DNA):
+    """Same substitution/indel process down a caterpillar tree (((S0,S1),S2),S3)...: the deep
+    pair's private insertions stay skipped for many levels, which is what drives the
+    reference's skipped-edge limits (basic_alignment.cpp:370-489,587-592)."""
+    rng = np.random.default_rng(seed)
+    mutate = _mutator(rng, len(alphabet), sub, indel_start, mean_len)
+    anc = rng.integers(0, len(alphabet), length).astype(np.int8)
+    leaves = [None] * n_leaves
+    for k in range(n_leaves - 1, 1, -1):
+        leaves[k] = mutate(anc)
+        anc = mutate(anc)
+    leaves[0], leaves[1] = mutate(anc), mutate(anc)
+    names = ["S%03d" % k for k in range(n_leaves)]
+    seqs = ["".join(alphabet[c] for c in s) for s in leaves]
+    tree = "(%s:%g,%s:%g)" % (names[0], branch, names[1], branch)
+    for k in range(2, n_leaves):
+        tree = "(%s:%g,%s:%g)" % (tree, branch, names[k], branch)
+    return names, seqs, tree + ";"
+
+
+def parse_newick(newick):
+    """Tiny rooted-binary Newick reader for tests: returns nested (left, right, dist) /
+    (name, dist) tuples in the order the guide tree is walked."""
+    pos = [0]
+    s = newick.strip().rstrip(";")
+
+    def node():
+        if s[pos[0]] == "(":
+            pos[0] += 1
+            left = node()
+            assert s[pos[0]] == ","
+            pos[0] += 1
+            right = node()
+            assert s[pos[0]] == ")"
+            pos[0] += 1
+            return ("internal", left, right, dist())
+        j = pos[0]
+        while pos[0] < len(s) and s[pos[0]] not in ":,()":
+            pos[0] += 1
+        return ("leaf", s[j:pos[0]], dist())
+
+    def dist():
+        if pos[0] < len(s) and s[pos[0]] == ":":
+            j = pos[0] + 1
+            pos[0] = j
+            while pos[0] < len(s) and s[pos[0]] not in ",()":
+                pos[0] += 1
+            return float(s[j:pos[0]])
+        return 0.0
+    return node()
+
+
 def chain_graph(seq, alphabet=DNA_FULL):
     """Plain leaf graph of a sequence string (Sequence::create_default_sequence, no 454 edges)."""
     return Graph.chain(np.array([alphabet.index(c) for c in seq], np.int32))
