@@ -9,11 +9,11 @@ from pagan2_msa_amd import host, synth
 pytestmark = pytest.mark.gpu
 
 
-def check_tree(msa, seqs, oracle):
+def check_tree(msa, seqs, oracle, flags=0):
     kinds = set()
     for k in range(msa.n_internal):
         left, right, model, band = msa.node_job(k)
-        want = oracle.dp_align(left, right, model, band)
+        want = oracle.dp_align(left, right, model, band, flags=flags)
         got = msa.node_result(k)
         assert got.same_alignment(want), "node %d differs" % k
         kinds.update(got.cols[:, 2].tolist())
@@ -40,7 +40,7 @@ def test_full_matrix_tree_8x300_with_option_bits(pg, oracle):
     names, seqs, nwk = synth.evolve_balanced(8, 300, branch=0.05, sub=0.04, indel_start=0.01, mean_len=4, seed=22)
     for flags in (0, 1, 2):
         msa = host.Msa(names, seqs, nwk, use_anchors=0, dp_flags=flags).align()
-        check_tree(msa, seqs, oracle)
+        check_tree(msa, seqs, oracle, flags)
 
 
 def test_caterpillar_with_deleted_ranges(pg, oracle):
