@@ -20,8 +20,15 @@
 #include "../../include/pagan_dp.h"
 #include "dp_device.h"
 
-template <int BLOCK> __global__ void pg_fill_wavefront(const PgDevJob *jobs, unsigned flags);
+template <int BLOCK> __global__ void pg_fill_wavefront(const PgDevJob *jobs, const int *which, unsigned flags);
+__global__ void pg_fill_ring(const PgDevJob *jobs, const int *which, unsigned flags);
 __global__ void pg_end_and_trace(const PgDevJob *jobs);
+
+// limits of the LDS-staged kernel (dp_kernels.hip: RW site window, EC edge ring)
+#define PG_RING_MAX_WIDTH 256
+#define PG_RING_SITE_SPAN 576
+#define PG_RING_EDGE_CAP 2048
+unsigned pg_ring_lds_bytes();
 
 namespace {
 
@@ -105,7 +112,17 @@ struct HostJob {
     const pagan_graph *L, *R;
     int Lx, Ly;
     DiagIndex dx;
+    bool ring_ok = false;        // fits the LDS-staged narrow-band kernel
 };
+
+// The ring kernel keeps the bwd edges of ~256 consecutive sites in a 1024-entry LDS ring.
+bool edges_fit_ring(const pagan_graph *g, int rows) {
+    for (int i = 0; i < rows; ++i) {
+        const int e = i + PG_RING_SITE_SPAN < rows ? i + PG_RING_SITE_SPAN : rows;
+        if (g->bwd_off[e] - g->bwd_off[i] > PG_RING_EDGE_CAP) return false;
+    }
+    return true;
+}
 
 struct Arena {
     char *dev = nullptr;
@@ -123,6 +140,8 @@ struct pagan_batch {
     std::vector<PgDevJob> dj;
     Arena arena;
     PgDevJob *d_jobs = nullptr;
+    int *d_which = nullptr;      // [n]: ring-kernel jobs first, then the wide ones
+    int n_ring = 0, n_wide = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     int64_t cells = 0;
@@ -151,6 +170,10 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb) {
     if ((rc = rb->build(hj->Lx, hj->Ly, jb.band)) != PAGAN_OK) return rc;
     hj->dx.build(hj->Lx, hj->Ly, *rb);
     if (hj->dx.cells != rb->cells()) return PAGAN_E_INTERNAL;
+    // The LDS-staged kernel suits banded work: most diagonals narrow.  A full matrix (or a band that is
+    // mostly wider than the ring) goes to the multi-wave HBM wavefront instead.
+    hj->ring_ok = hj->dx.cells <= (long long)PG_RING_MAX_WIDTH * hj->dx.imin.size() / 2 &&
+                  edges_fit_ring(jb.left, hj->Lx) && edges_fit_ring(jb.right, hj->Ly);
     return PAGAN_OK;
 }
 
@@ -181,8 +204,8 @@ void carve_job(Carver &c, const pagan_job &jb, const HostJob &hj, PgDevJob *d) {
     d->cells = hj.dx.cells;
 }
 void carve_outputs(Carver &c, const HostJob &hj, PgDevJob *d) {
-    for (int m = 0; m < 3; ++m) d->sc[m] = c.take<double>((size_t)hj.dx.cells);
-    for (int m = 0; m < 3; ++m) d->bp[m] = c.take<unsigned>((size_t)hj.dx.cells);
+    d->sc = c.take<double>(3 * (size_t)hj.dx.cells);
+    d->bp = c.take<unsigned>(3 * (size_t)hj.dx.cells);
     d->trace = c.take<int>(3 * (size_t)(hj.Lx + hj.Ly));
     d->endcell = c.take<int>(8);
     d->endscore = c.take<double>(1);
@@ -193,11 +216,24 @@ template <class T> void put(std::vector<char> &stage, const void *devptr_as_off,
 }
 
 int launch_fill(pagan_batch *b) {
-    dim3 grid(b->n);
-    switch (b->block) {
-    case 64: hipLaunchKernelGGL(pg_fill_wavefront<64>, grid, dim3(64), 0, b->stream, b->d_jobs, b->flags); break;
-    case 256: hipLaunchKernelGGL(pg_fill_wavefront<256>, grid, dim3(256), 0, b->stream, b->d_jobs, b->flags); break;
-    default: hipLaunchKernelGGL(pg_fill_wavefront<1024>, grid, dim3(1024), 0, b->stream, b->d_jobs, b->flags); break;
+    if (b->n_ring > 0) {
+        static bool lds_set = false;      // > 64 KB of dynamic LDS has to be opted into once per process
+        if (!lds_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_ring),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_ring_lds_bytes()));
+            lds_set = true;
+        }
+        hipLaunchKernelGGL(pg_fill_ring, dim3(b->n_ring), dim3(128), pg_ring_lds_bytes(), b->stream, b->d_jobs,
+                           b->d_which, b->flags);
+    }
+    if (b->n_wide > 0) {
+        dim3 grid(b->n_wide);
+        const int *which = b->d_which + b->n_ring;
+        switch (b->block) {
+        case 64: hipLaunchKernelGGL(pg_fill_wavefront<64>, grid, dim3(64), 0, b->stream, b->d_jobs, which, b->flags); break;
+        case 256: hipLaunchKernelGGL(pg_fill_wavefront<256>, grid, dim3(256), 0, b->stream, b->d_jobs, which, b->flags); break;
+        default: hipLaunchKernelGGL(pg_fill_wavefront<1024>, grid, dim3(1024), 0, b->stream, b->d_jobs, which, b->flags); break;
+        }
     }
     HIP_TRY(hipGetLastError());
     return PAGAN_OK;
@@ -353,18 +389,25 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     b->jobs.resize(n);
     b->dj.resize(n);
     int max_w = 0;
+    const bool force_v1 = std::getenv("PAGAN_DP_FORCE_GLOBAL_WAVEFRONT") != nullptr;   // A/B switch for profiling
+    std::vector<int> which_ring, which_wide;
     for (int k = 0; k < n; ++k) {
         RowBand rb;
         int rc = validate_job(jobs[k], &b->jobs[k], &rb);
         if (rc != PAGAN_OK) return rc;
         b->cells += b->jobs[k].dx.cells;
+        if (b->jobs[k].ring_ok && !force_v1) { which_ring.push_back(k); continue; }
+        which_wide.push_back(k);
         if (b->jobs[k].dx.max_width > max_w) max_w = b->jobs[k].dx.max_width;
     }
+    b->n_ring = (int)which_ring.size(); b->n_wide = (int)which_wide.size();
+    which_ring.insert(which_ring.end(), which_wide.begin(), which_wide.end());
     b->block = max_w <= 64 ? 64 : (max_w <= 512 ? 256 : 1024);
 
     // pass 1: sizes.  Inputs first (one contiguous upload), outputs after.
     Carver sizer;
     PgDevJob *jobs_off = sizer.take<PgDevJob>(n);
+    int *which_off = sizer.take<int>(n);
     for (int k = 0; k < n; ++k) carve_job(sizer, jobs[k], b->jobs[k], &b->dj[k]);
     const size_t in_bytes = sizer.cur;
     for (int k = 0; k < n; ++k) carve_outputs(sizer, b->jobs[k], &b->dj[k]);
@@ -398,11 +441,13 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         rebase(d.stL); rebase(d.offL); rebase(d.srcL); rebase(d.lwL);
         rebase(d.stR); rebase(d.offR); rebase(d.srcR); rebase(d.lwR);
         rebase(d.table); rebase(d.imin); rebase(d.imax); rebase(d.doff);
-        for (int m = 0; m < 3; ++m) { rebase(d.sc[m]); rebase(d.bp[m]); }
+        rebase(d.sc); rebase(d.bp);
         rebase(d.trace); rebase(d.endcell); rebase(d.endscore);
     }
     std::memcpy(stage.data() + reinterpret_cast<size_t>(jobs_off), b->dj.data(), sizeof(PgDevJob) * n);
+    std::memcpy(stage.data() + reinterpret_cast<size_t>(which_off), which_ring.data(), sizeof(int) * n);
     b->d_jobs = reinterpret_cast<PgDevJob *>(base + reinterpret_cast<size_t>(jobs_off));
+    b->d_which = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(which_off));
     HIP_TRY(hipStreamCreate(&b->stream));
     for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipMemcpyAsync(base, stage.data(), in_bytes, hipMemcpyHostToDevice, b->stream));

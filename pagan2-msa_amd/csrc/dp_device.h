@@ -5,9 +5,12 @@
 //   inputs   left/right graph CSR (state, bwd_off, bwd_src, bwd_logw) -- 4 B per site + 8 B per edge
 //            model table S*S f32
 //            diagonal index: imin[d], imax[d] (i32), doff[d] (i64) for d = 0 .. Lx+Ly-2
-//   outputs  score[3][cells] f64  (M, X, Y)   } DIAGONAL-MAJOR: cell (i,j), d=i+j, lives at
-//            bp[3][cells]    u32  (M, X, Y)   } doff[d] + (i - imin[d]) -- one anti-diagonal is
-//                                                contiguous, so a wavefront's loads/stores coalesce
+//   outputs  score[cells][3] f64  (X, Y, M)   } DIAGONAL-MAJOR: cell (i,j), d=i+j, lives at
+//            bp[cells][3]    u32  (X, Y, M)   } doff[d] + (i - imin[d]) -- one anti-diagonal is
+//                                                contiguous, so a wavefront's loads/stores coalesce;
+//                                                the three states of a cell sit together (24 B + 12 B):
+//                                                one address computation and three store
+//                                                instructions per cell
 //            trace[Lx+Ly] {i,j,mat|slots}      visited cells of the Viterbi path, end to start
 //            endcell                           the end-corner result (max_end)
 //
@@ -37,8 +40,8 @@ struct PgDevJob {
     const long long *doff;
     long long cells;
     // outputs
-    double *sc[3];           // indexed by PAGAN_X_MAT / Y_MAT / M_MAT
-    unsigned *bp[3];
+    double *sc;              // [cells][3], state index = PAGAN_X_MAT / Y_MAT / M_MAT
+    unsigned *bp;            // [cells][3]
     int *trace;              // [3 * (Lx+Ly)]
     int *endcell;            // [8]: status, matrix, x_ind, y_ind, slot_l, slot_r, n_trace, pad ; score in endscore
     double *endscore;        // [1]
