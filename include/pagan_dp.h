@@ -173,6 +173,8 @@ int  pagan_batch_fetch(pagan_batch *b, pagan_result *out /* [n] */);
 int  pagan_batch_last_ms(pagan_batch *b, double ms[2]);
 int64_t pagan_batch_cells(const pagan_batch *b);
 void pagan_batch_destroy(pagan_batch *b);
+/* diagnostic builds only: raw bytes of job k's device trace buffer                    */
+int  pagan_batch_debug_trace(pagan_batch *b, int32_t k, void *dst, int64_t bytes);
 
 const char *pagan_dp_version(void);
 

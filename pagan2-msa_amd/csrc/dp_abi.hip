@@ -223,7 +223,7 @@ int launch_fill(pagan_batch *b) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_ring_lds_bytes()));
             lds_set = true;
         }
-        hipLaunchKernelGGL(pg_fill_ring, dim3(b->n_ring), dim3(128), pg_ring_lds_bytes(), b->stream, b->d_jobs,
+        hipLaunchKernelGGL(pg_fill_ring, dim3(b->n_ring), dim3(320), pg_ring_lds_bytes(), b->stream, b->d_jobs,
                            b->d_which, b->flags);
     }
     if (b->n_wide > 0) {
@@ -513,6 +513,14 @@ int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
         if (rc != PAGAN_OK && first_err == PAGAN_OK) first_err = rc;
     }
     return first_err;
+}
+
+// Diagnostic: raw copy of job k's trace buffer (used by tools/ with a -DPG_STAMPS build).
+int pagan_batch_debug_trace(pagan_batch *b, int32_t k, void *dst, int64_t bytes) {
+    if (!b || k < 0 || k >= b->n || !dst) return PAGAN_E_ARG;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(dst, b->arena.dev + b->trace_off[k], (size_t)bytes, hipMemcpyDeviceToHost));
+    return PAGAN_OK;
 }
 
 void pagan_batch_destroy(pagan_batch *b) {

@@ -205,30 +205,29 @@ template __global__ void pg_fill_wavefront<1024>(const PgDevJob *, const int *, 
 // ---------------------------------------------------------------------------------------------
 // Banded wavefront with the active band staged in LDS ("ring" kernel).
 //
-// One workgroup of two wave64 per alignment: a COMPUTE wave and a LOADER wave.
-//
-// Compute wave: lane l owns the rows i with i % 64 == l that are inside the band on the
-// current anti-diagonal -- one row on most diagonals (anchors-offset 15 gives a median of 16
-// cells per diagonal, a 99th percentile near 100), a few on the wide ones.  Per step:
-//   - the scores of the last RK diagonals live in an LDS ring  sc[d % RK][i % WMAX][M,X,Y];
+// One workgroup per alignment: NW compute waves + one loader wave, one s_barrier per
+// anti-diagonal.  Thread T of the compute waves owns the rows i with i % NT == T (NT = 64 NW)
+// that are inside the band on the current diagonal, so up to NT cells are computed at once
+// and a cell's slot in the ring is i % NT.  Per step (anti-diagonal d):
+//   - the scores of the last RK diagonals live in an LDS ring  sc[d % RK][i % NT][X,Y,M];
 //     every predecessor within RK diagonals is an LDS read guarded by that diagonal's
 //     [imin,imax] interval;
-//   - site data, bwd edges and the per-diagonal band index are read from LDS rings that the
-//     loader wave keeps filled ahead of the band;
-//   - scores and back-pointers stream to HBM with coalesced stores nobody waits for.
-//   In the steady state this wave issues NO vector-memory load: vmcnt returns in order, so a
-//   single load would stall on every store still in flight to HBM (measured: 5.6 us per
-//   diagonal with the loads in this wave, see profiles/).
-//   - a graph edge reaching >= RK diagonals back reads what this same wave stored to HBM
-//     earlier (a wave's vector memory operations are performed in order);
-//   - a diagonal wider than WMAX (a box between distant anchors) is computed from HBM
-//     operands like the wide kernel does, and marked "not in the ring".
-// Loader wave: coalesced loads of the next 64 left sites / right sites (+ their bwd edges) /
-// diagonal descriptors into the rings whenever the compute wave's published progress leaves
-// room; publishes "loaded up to" counters after its LDS writes have landed.
-// The two waves meet once at the start (__syncthreads) and then only through those counters.
-#define RK 8
-#define WMAX 256
+//   - site data, bwd edges and the per-diagonal band index sit in LDS rings that the loader
+//     wave refills with coalesced loads (64 sites / diagonals at a time) one step ahead;
+//   - scores and back-pointers stream to HBM with coalesced stores nobody waits for: the
+//     compute waves issue NO vector-memory load in the steady state (vmcnt returns in order,
+//     a load would stall on every store still in flight -- measured 5.6 us per diagonal);
+//   - a wave whose cells are all "simple" (both sites have one bwd edge, from the
+//     predecessor site, weight 1) runs straight-line code: three 24-byte LDS reads, nine
+//     candidates; otherwise each lane walks its (left edge, right edge) pairs in the
+//     reference's order;
+//   - a graph edge reaching >= RK diagonals back reads HBM; `s_waitcnt vmcnt(24)` once per
+//     step bounds how far any wave's stores may lag, so a cell that old has landed;
+//   - a diagonal wider than NT (a box between distant anchors) is computed from HBM operands
+//     between two full drains and marked "not in the ring".
+#define NW 4
+#define NT (64 * NW)
+#define RK 16
 #define RW 512
 #define EC 2048
 #define DR 256
@@ -237,7 +236,7 @@ template __global__ void pg_fill_wavefront<1024>(const PgDevJob *, const int *, 
 #define PG_SIMPLE 0x10000
 
 struct RingSmem {
-    double sc[RK][WMAX][3];                 // X, Y, M
+    double sc[RK][NT][3];                   // X, Y, M
     int dmn[RK], dmx[RK], did[RK];          // per slot: band interval and WHICH diagonal it holds (-1: none)
     int stL[RW], ebL[RW], eeL[RW];
     int stR[RW], ebR[RW], eeR[RW];
@@ -245,20 +244,16 @@ struct RingSmem {
     int esR[EC]; float ewR[EC];
     int dlo[DR], dhi[DR]; long long dbase[DR];
     float table[256];
-    int rows_loaded, cols_loaded, diags_loaded;     // loader -> compute
-    int prog_row, prog_col, prog_d;                 // compute -> loader: lowest row / column / diagonal still needed
 };
 
 unsigned pg_ring_lds_bytes() { return (unsigned)sizeof(RingSmem); }
 
 extern __shared__ __attribute__((aligned(16))) char pg_ring_lds[];
 #define SM (*reinterpret_cast<RingSmem *>(pg_ring_lds))
-// Cross-wave counters: relaxed workgroup-scope atomics on the LDS symbol (plain ds_read/ds_write
-// that the compiler neither caches nor fences; a `volatile` cast turned into flat accesses).
-#define SM_GET(field) __hip_atomic_load(&SM.field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define SM_PUT(field, v) __hip_atomic_store(&SM.field, (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
-// Loads the COMPUTE wave needs only on rare paths (an edge reaching past the ring).  Issued as
+namespace {
+
+// Loads the COMPUTE waves need only on rare paths (an edge reaching past the ring).  Issued as
 // inline asm with their own wait so that the compiler's waitcnt insertion never places a
 // vmcnt(0) -- which would also wait for every store in flight -- on the common path.
 __device__ __forceinline__ double far_f64(PG_GLOBAL const double *p) {
@@ -282,11 +277,15 @@ __device__ __forceinline__ long long far_i64(PG_GLOBAL const long long *p) {
     return v;
 }
 
-namespace {
+// Workgroup barrier that orders LDS traffic only.  (__syncthreads() also waits for vmcnt(0),
+// i.e. for this wave's HBM stores -- exactly what the steady state must not do.)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // Scores of cell (p,q) on an earlier diagonal; -inf outside the tunnel.
 __device__ __forceinline__ void ring_load(const View &J, int d, int mn1, int mx1, bool in1, int mn2, int mx2, bool in2,
-                                          int p, int q, double &ms, double &xs, double &ys) {
+                                          int p, int q, double &xs, double &ys, double &ms) {
     const double NI = neg_inf();
     const int dd = p + q, age = d - dd;
     ms = NI; xs = NI; ys = NI;
@@ -301,132 +300,122 @@ __device__ __forceinline__ void ring_load(const View &J, int d, int mn1, int mx1
     }
     if (p < mn || p > mx) return;
     if (ring) {
-        xs = SM.sc[dd & (RK - 1)][p & (WMAX - 1)][PG_X];
-        ys = SM.sc[dd & (RK - 1)][p & (WMAX - 1)][PG_Y];
-        ms = SM.sc[dd & (RK - 1)][p & (WMAX - 1)][PG_M];
+        xs = SM.sc[dd & (RK - 1)][p & (NT - 1)][PG_X];
+        ys = SM.sc[dd & (RK - 1)][p & (NT - 1)][PG_Y];
+        ms = SM.sc[dd & (RK - 1)][p & (NT - 1)][PG_M];
     } else {
         const long long ix = far_i64(J.doff + dd) + (p - mn);
         xs = far_f64(J.sc + 3 * ix + PG_X); ys = far_f64(J.sc + 3 * ix + PG_Y); ms = far_f64(J.sc + 3 * ix + PG_M);
     }
 }
 
-// Loader wave: keeps the LDS rings ahead of the compute wave.  Every ring entry below the
-// published progress is dead and may be overwritten.
-__device__ __forceinline__ void ring_loader(const View &J, int lane) {
-    int rows = 0, cols = 0, diags = 0;
-    while (rows < J.Lx || cols < J.Ly || diags < J.nd) {
-        bool progressed = false;
-        const int p_row = SM_GET(prog_row), p_col = SM_GET(prog_col), p_d = SM_GET(prog_d);
-        if (diags < J.nd && diags + 64 - p_d <= DR) {
-            const int dd = diags + lane;
-            if (dd < J.nd) { SM.dlo[dd & (DR - 1)] = J.imin[dd]; SM.dhi[dd & (DR - 1)] = J.imax[dd]; SM.dbase[dd & (DR - 1)] = J.doff[dd]; }
-            diags += 64;
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            if (lane == 0) SM_PUT(diags_loaded, diags);
-            progressed = true;
-        }
-        if (rows < J.Lx && rows + 64 - p_row <= RW) {
-            const int rend = rows + 64 < J.Lx ? rows + 64 : J.Lx;
-            const int e0 = J.offL[rows], e1 = J.offL[rend];
-            if (e1 - J.offL[p_row < J.Lx ? p_row : J.Lx] <= EC) {
-                const int r = rows + lane;
-                if (r < J.Lx) {
-                    const int b = J.offL[r], en = J.offL[r + 1];
-                    int st = J.stL[r] & 0xffff;
-                    if (r > 0 && en - b == 1 && J.srcL[b] == r - 1 && J.lwL[b] == 0.0f) st |= PG_SIMPLE;
-                    SM.stL[r & (RW - 1)] = st; SM.ebL[r & (RW - 1)] = b; SM.eeL[r & (RW - 1)] = en;
-                }
-                for (int e = e0 + lane; e < e1; e += 64) { SM.esL[e & (EC - 1)] = J.srcL[e]; SM.ewL[e & (EC - 1)] = J.lwL[e]; }
-                rows += 64;
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                if (lane == 0) SM_PUT(rows_loaded, rows);
-                progressed = true;
-            }
-        }
-        if (cols < J.Ly && cols + 64 - p_col <= RW) {
-            const int rend = cols + 64 < J.Ly ? cols + 64 : J.Ly;
-            const int e0 = J.offR[cols], e1 = J.offR[rend];
-            if (e1 - J.offR[p_col < J.Ly ? p_col : J.Ly] <= EC) {
-                const int r = cols + lane;
-                if (r < J.Ly) {
-                    const int b = J.offR[r], en = J.offR[r + 1];
-                    int st = J.stR[r] & 0xffff;
-                    if (r > 0 && en - b == 1 && J.srcR[b] == r - 1 && J.lwR[b] == 0.0f) st |= PG_SIMPLE;
-                    SM.stR[r & (RW - 1)] = st; SM.ebR[r & (RW - 1)] = b; SM.eeR[r & (RW - 1)] = en;
-                }
-                for (int e = e0 + lane; e < e1; e += 64) { SM.esR[e & (EC - 1)] = J.srcR[e]; SM.ewR[e & (EC - 1)] = J.lwR[e]; }
-                cols += 64;
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                if (lane == 0) SM_PUT(cols_loaded, cols);
-                progressed = true;
-            }
-        }
-        if (!progressed) __builtin_amdgcn_s_sleep(16);
+// ---- loader wave -------------------------------------------------------------------------
+__device__ __forceinline__ void load_diag_chunk(const View &J, int first, int lane) {
+    const int dd = first + lane;
+    if (dd < J.nd) { SM.dlo[dd & (DR - 1)] = J.imin[dd]; SM.dhi[dd & (DR - 1)] = J.imax[dd]; SM.dbase[dd & (DR - 1)] = J.doff[dd]; }
+}
+__device__ __forceinline__ void load_site_chunk(int first, int lane, int n, gint_p st, gint_p off, gint_p src, gfloat_p lw,
+                                                int *cst, int *ceb, int *cee, int *ces, float *cew) {
+    const int r = first + lane;
+    if (r < n) {
+        const int b = off[r], en = off[r + 1];
+        int w = st[r] & 0xffff;
+        if (r > 0 && en - b == 1 && src[b] == r - 1 && lw[b] == 0.0f) w |= PG_SIMPLE;
+        cst[r & (RW - 1)] = w; ceb[r & (RW - 1)] = b; cee[r & (RW - 1)] = en;
     }
+    const int rend = first + 64 < n ? first + 64 : n;
+    const int e0 = off[first], e1 = off[rend];
+    for (int e = e0 + lane; e < e1; e += 64) { ces[e & (EC - 1)] = src[e]; cew[e & (EC - 1)] = lw[e]; }
 }
 
 } // namespace
 
-__global__ __launch_bounds__(128) void pg_fill_ring(const PgDevJob *__restrict__ jobs, const int *__restrict__ which,
-                                                    unsigned flags) {
+__global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restrict__ jobs, const int *__restrict__ which,
+                                                        unsigned flags) {
     const View J = load_view(jobs + which[blockIdx.x]);
     const bool no_terminal_edges = flags & 1u;
     const bool reduced_terminal = !(flags & 2u);
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const bool tab_lds = J.S <= 16;
-    if (tab_lds) for (int k = threadIdx.x; k < J.S * J.S; k += 128) SM.table[k] = J.table[k];
-    for (int k = threadIdx.x; k < RK; k += 128) { SM.dmn[k] = 0; SM.dmx[k] = -1; SM.did[k] = -1; }
-    if (threadIdx.x == 0) {
-        SM.rows_loaded = 0; SM.cols_loaded = 0; SM.diags_loaded = 0;
-        SM.prog_row = 0; SM.prog_col = 0; SM.prog_d = 0;
-    }
-    __syncthreads();
-    if (threadIdx.x >= 64) { ring_loader(J, lane); return; }
+    if (tab_lds) for (int k = tid; k < J.S * J.S; k += NT + 64) SM.table[k] = J.table[k];
+    for (int k = tid; k < RK; k += NT + 64) { SM.dmn[k] = 0; SM.dmx[k] = -1; SM.did[k] = -1; }
 
+    if (tid >= NT) {
+        // ================= loader wave: stays one diagonal ahead of the compute waves =================
+        int rows = 0, cols = 0, diags = 0;
+        load_diag_chunk(J, 0, lane); diags = 64;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        {   // everything diagonal 0 needs
+            const int lo = SM.dlo[0], hi = SM.dhi[0];
+            if (hi - lo + 1 <= NT) {
+                while (hi >= rows && rows < J.Lx) { load_site_chunk(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL, SM.stL, SM.ebL, SM.eeL, SM.esL, SM.ewL); rows += 64; }
+                while (0 - lo >= cols && cols < J.Ly) { load_site_chunk(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR, SM.stR, SM.ebR, SM.eeR, SM.esR, SM.ewR); cols += 64; }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                                            // (B0) compute may start diagonal 0
+        for (int d = 0; d < J.nd; ++d) {
+            const bool wide = SM.dhi[d & (DR - 1)] - SM.dlo[d & (DR - 1)] + 1 > NT;
+            if (wide) lds_barrier();                              // (Bw) mirrors the compute waves' drain barrier
+            const int dn = d + 1;
+            if (dn < J.nd) {
+                if (dn >= diags) { load_diag_chunk(J, diags, lane); diags += 64; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+                const int lo = SM.dlo[dn & (DR - 1)], hi = SM.dhi[dn & (DR - 1)];
+                if (hi - lo + 1 <= NT) {
+                    while (hi >= rows && rows < J.Lx) { load_site_chunk(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL, SM.stL, SM.ebL, SM.eeL, SM.esL, SM.ewL); rows += 64; }
+                    while (dn - lo >= cols && cols < J.Ly) { load_site_chunk(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR, SM.stR, SM.ebR, SM.eeR, SM.esR, SM.ewR); cols += 64; }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            lds_barrier();                                        // (Bd) end of diagonal d
+        }
+        return;
+    }
+
+    // ================= compute waves =================
     const double NI = neg_inf();
     int mn1 = 0, mx1 = -1, mn2 = 0, mx2 = -1;
     bool in1 = false, in2 = false;
     Diag g1 = {0, -1, 0}, g2 = {0, -1, 0};
     const double go = (double)J.go, ng = (double)J.ng;
     const double tng2 = (double)(2 * J.ng), tng1 = (double)(0.0f + J.ng);
-    int rows_ok = 0, cols_ok = 0, diags_ok = 0;          // cached copies of the loader's counters
+    lds_barrier();                                                // (B0)
     for (int d = 0; d < J.nd; ++d) {
-        while (diags_ok <= d) { diags_ok = SM_GET(diags_loaded); if (diags_ok <= d) __builtin_amdgcn_s_sleep(2); }
-        asm volatile("" ::: "memory");      // ring reads stay behind the counter they depend on
         const int lo = SM.dlo[d & (DR - 1)], hi = SM.dhi[d & (DR - 1)];
         const long long base = SM.dbase[d & (DR - 1)];
-        const bool wide = hi - lo + 1 > WMAX;
-        if (lane == 0 && (d & 7) == 0) { SM_PUT(prog_row, lo); SM_PUT(prog_col, d - hi > 0 ? d - hi : 0); SM_PUT(prog_d, d); }
+        const bool wide = hi - lo + 1 > NT;
         if (wide) {
-            // rare: a box between anchors wider than the ring -- every operand from HBM/L2
-            for (int i = lo + lane; i <= hi; i += 64)
+            // rare: a box between anchors wider than the ring.  Every wave drains its stores, then all
+            // cells are computed from HBM/L2 operands, then drained again so that later diagonals
+            // (which find "not in the ring") read landed data.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();                                        // (Bw)
+            for (int i = lo + tid; i <= hi; i += NT)
                 fill_cell_hbm(J, d, g1, g2, i, d - i, base + (i - lo), no_terminal_edges, reduced_terminal);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            if (hi >= lo) {
-                while (rows_ok <= hi && rows_ok < J.Lx) { rows_ok = SM_GET(rows_loaded); if (rows_ok <= hi && rows_ok < J.Lx) __builtin_amdgcn_s_sleep(2); }
-                while (cols_ok <= d - lo && cols_ok < J.Ly) { cols_ok = SM_GET(cols_loaded); if (cols_ok <= d - lo && cols_ok < J.Ly) __builtin_amdgcn_s_sleep(2); }
-                asm volatile("" ::: "memory");
-            }
-            // ---- fast path: every cell of this diagonal is "simple" and both previous diagonals are
-            // in the ring.  Straight-line code: three 24-byte LDS reads, nine candidates.
-            const int i0 = lo + ((lane - lo) & 63);
-            bool simple = true;
+            const int i = lo + ((tid - lo) & (NT - 1));
+            const int j = d - i;
+            const bool active = i <= hi;
             int wi = 0, wj = 0;
-            if (i0 <= hi) {
-                wi = SM.stL[i0 & (RW - 1)]; wj = SM.stR[(d - i0) & (RW - 1)];
-                simple = (wi & wj & PG_SIMPLE) != 0;      // implies i0 >= 1 and j >= 1
+            bool simple = true;
+            if (active) {
+                wi = SM.stL[i & (RW - 1)]; wj = SM.stR[j & (RW - 1)];
+                simple = (wi & wj & PG_SIMPLE) != 0;                      // implies i >= 1 and j >= 1
             }
-            if (hi - lo < 64 && in1 && in2 && __all(simple)) {
-                if (i0 <= hi) {
-                    const int i = i0, j = d - i0;
+            double bx = NI, by = NI, bm = NI;
+            unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
+            if (in1 && in2 && __all(simple)) {
+                // ---- every cell of this wave is simple: straight-line code ----
+                if (active) {
                     const int s1 = (d - 1) & (RK - 1), s2 = (d - 2) & (RK - 1);
                     const bool inA = i - 1 >= mn1 && i - 1 <= mx1;       // (i-1, j)   on d-1
                     const bool inB = i >= mn1 && i <= mx1;               // (i, j-1)   on d-1
                     const bool inC = i - 1 >= mn2 && i - 1 <= mx2;       // (i-1, j-1) on d-2
-                    const double *A = SM.sc[s1][(i - 1) & (WMAX - 1)];
-                    const double *B = SM.sc[s1][i & (WMAX - 1)];
-                    const double *Cc = SM.sc[s2][(i - 1) & (WMAX - 1)];
-                    // unconditional reads (the slots always exist), selected afterwards
+                    const double *A = SM.sc[s1][(i - 1) & (NT - 1)];
+                    const double *B = SM.sc[s1][i & (NT - 1)];
+                    const double *Cc = SM.sc[s2][(i - 1) & (NT - 1)];
                     const double a0 = A[PG_X], a1 = A[PG_Y], a2 = A[PG_M];
                     const double b0 = B[PG_X], b1 = B[PG_Y], b2 = B[PG_M];
                     const double c0 = Cc[PG_X], c1 = Cc[PG_Y], c2 = Cc[PG_M];
@@ -439,8 +428,7 @@ __global__ __launch_bounds__(128) void pg_fill_ring(const PgDevJob *__restrict__
                     const double extY = (double)((i == J.Lx - 1 && !no_terminal_edges) ? J.gE : J.ge);
                     const double openX = (reduced_terminal && i == 1) ? 0.0 : go;
                     const double openY = (reduced_terminal && j == 1) ? 0.0 : go;
-                    double bx = NI, by = NI, bm = NI, c;
-                    unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
+                    double c;
                     c = xA + extX;          if (c > bx) { bx = c; px = PG_X; }
                     c = (yA + 0.0) + go;    if (c > bx) { bx = c; px = PG_Y; }
                     c = (mA + ng) + openX;  if (c > bx) { bx = c; px = PG_M; }
@@ -451,90 +439,73 @@ __global__ __launch_bounds__(128) void pg_fill_ring(const PgDevJob *__restrict__
                     c = mC + tM;            if (c > bm) { bm = c; pm = PG_M; }     // + 0.0 + 0.0 (log-weights) omitted: exact
                     c = xC + tX;            if (c > bm) { bm = c; pm = PG_X; }
                     c = yC + tX;            if (c > bm) { bm = c; pm = PG_Y; }
-                    SM.sc[d & (RK - 1)][i & (WMAX - 1)][PG_X] = bx;
-                    SM.sc[d & (RK - 1)][i & (WMAX - 1)][PG_Y] = by;
-                    SM.sc[d & (RK - 1)][i & (WMAX - 1)][PG_M] = bm;
-                    store_cell(J.sc, J.bp, base + (i - lo), bx, by, bm, px, py, pm);
                 }
-            } else
-            for (int i = lo + ((lane - lo) & 63); i <= hi; i += 64) {
-                const int j = d - i;
-                double bx = NI, by = NI, bm = NI;
-                unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
-                if (i == 0 && j == 0) {
-                    bm = 0.0;
-                } else {
-                    int l0 = 0, l1 = 0, r0 = 0, r1 = 0;
-                    if (i > 0) { l0 = SM.ebL[i & (RW - 1)]; l1 = SM.eeL[i & (RW - 1)]; }
-                    if (j > 0) { r0 = SM.ebR[j & (RW - 1)]; r1 = SM.eeR[j & (RW - 1)]; }
-                    if (i > 0) {
-                        const bool end_gap = (j == 0 || j == J.Ly - 1) && !no_terminal_edges;
-                        const double ext = (double)(end_gap ? J.gE : J.ge);
-                        for (int e = l0; e < l1; ++e) {
-                            const int p = SM.esL[e & (EC - 1)];
-                            double ms, xs, ys;
-                            ring_load(J, d, mn1, mx1, in1, mn2, mx2, in2, p, j, ms, xs, ys);
-                            const double open = (reduced_terminal && p == 0) ? 0.0 : go;
-                            double c = xs + ext;
-                            if (c > bx) { bx = c; px = pack_bp(PG_X, e - l0, 0); }
-                            c = (ys + 0.0) + go;
-                            if (c > bx) { bx = c; px = pack_bp(PG_Y, e - l0, 0); }
-                            c = (ms + ng) + open;
-                            if (c > bx) { bx = c; px = pack_bp(PG_M, e - l0, 0); }
-                        }
-                    }
-                    if (j > 0) {
-                        const bool end_gap = (i == 0 || i == J.Lx - 1) && !no_terminal_edges;
-                        const double ext = (double)(end_gap ? J.gE : J.ge);
-                        for (int e = r0; e < r1; ++e) {
-                            const int q = SM.esR[e & (EC - 1)];
-                            double ms, xs, ys;
-                            ring_load(J, d, mn1, mx1, in1, mn2, mx2, in2, i, q, ms, xs, ys);
-                            const double open = (reduced_terminal && q == 0) ? 0.0 : go;
-                            double c = ys + ext;
-                            if (c > by) { by = c; py = pack_bp(PG_Y, 0, e - r0); }
-                            c = (xs + 0.0) + go;
-                            if (c > by) { by = c; py = pack_bp(PG_X, 0, e - r0); }
-                            c = (ms + ng) + open;
-                            if (c > by) { by = c; py = pack_bp(PG_M, 0, e - r0); }
-                        }
-                    }
-                    if (i > 0 && j > 0 && l1 > l0 && r1 > r0) {
-                        const int ti = (SM.stL[i & (RW - 1)] & 0xffff) + (SM.stR[j & (RW - 1)] & 0xffff) * J.S;
+            } else {
+                // ---- general: each lane walks its (left edge, right edge) pairs row-major, which visits
+                // X candidates in left-list order, Y candidates in right-list order and M candidates in
+                // the reference's pair order (VA:1396-1433) ----
+                int l0 = 0, nL = 0, r0 = 0, nR = 0, n_items = 0;
+                double tM = 0, tX = 0, extX = 0, extY = 0;
+                if (active) {
+                    if (i > 0) { l0 = SM.ebL[i & (RW - 1)]; nL = SM.eeL[i & (RW - 1)] - l0; }
+                    if (j > 0) { r0 = SM.ebR[j & (RW - 1)]; nR = SM.eeR[j & (RW - 1)] - r0; }
+                    if (i == 0 && j == 0) bm = 0.0;                        // initialise_array_corner, VA:725-736
+                    else n_items = (nL > 0 ? nL : 1) * (nR > 0 ? nR : 1);
+                    if (nL > 0 && nR > 0) {
+                        const int ti = (wi & 0xffff) + (wj & 0xffff) * J.S;
                         const float smf = tab_lds ? SM.table[ti] : far_f32(J.table + ti);
-                        const double tM = tng2 + (double)smf;
-                        const double tX = tng1 + (double)smf;
-                        for (int e1 = l0; e1 < l1; ++e1) {
-                            const int p = SM.esL[e1 & (EC - 1)];
-                            const double lw = (double)SM.ewL[e1 & (EC - 1)];
-                            for (int e2 = r0; e2 < r1; ++e2) {
-                                const int q = SM.esR[e2 & (EC - 1)];
-                                const double rw = (double)SM.ewR[e2 & (EC - 1)];
-                                double ms, xs, ys;
-                                ring_load(J, d, mn1, mx1, in1, mn2, mx2, in2, p, q, ms, xs, ys);
-                                double c = ((ms + tM) + lw) + rw;
-                                if (c > bm) { bm = c; pm = pack_bp(PG_M, e1 - l0, e2 - r0); }
-                                c = ((xs + tX) + lw) + rw;
-                                if (c > bm) { bm = c; pm = pack_bp(PG_X, e1 - l0, e2 - r0); }
-                                c = ((ys + tX) + lw) + rw;
-                                if (c > bm) { bm = c; pm = pack_bp(PG_Y, e1 - l0, e2 - r0); }
-                            }
+                        tM = tng2 + (double)smf; tX = tng1 + (double)smf;
+                    }
+                    extX = (double)(((j == 0 || j == J.Ly - 1) && !no_terminal_edges) ? J.gE : J.ge);
+                    extY = (double)(((i == 0 || i == J.Lx - 1) && !no_terminal_edges) ? J.gE : J.ge);
+                }
+                const int nRp = nR > 0 ? nR : 1;
+                int k1 = 0, k2 = 0;
+                for (int t = 0; __any(t < n_items); ++t) {
+                    if (t < n_items) {
+                        int p = 0, q = 0;
+                        double lw = 0, rw = 0, xs, ys, ms, c;
+                        if (nL > 0) { p = SM.esL[(l0 + k1) & (EC - 1)]; lw = (double)SM.ewL[(l0 + k1) & (EC - 1)]; }
+                        if (nR > 0) { q = SM.esR[(r0 + k2) & (EC - 1)]; rw = (double)SM.ewR[(r0 + k2) & (EC - 1)]; }
+                        if (nL > 0 && k2 == 0) {                                     // X candidates of left edge k1
+                            ring_load(J, d, mn1, mx1, in1, mn2, mx2, in2, p, j, xs, ys, ms);
+                            const double open = (reduced_terminal && p == 0) ? 0.0 : go;
+                            c = xs + extX;          if (c > bx) { bx = c; px = pack_bp(PG_X, k1, 0); }
+                            c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, k1, 0); }
+                            c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, k1, 0); }
                         }
+                        if (nR > 0 && k1 == 0) {                                     // Y candidates of right edge k2
+                            ring_load(J, d, mn1, mx1, in1, mn2, mx2, in2, i, q, xs, ys, ms);
+                            const double open = (reduced_terminal && q == 0) ? 0.0 : go;
+                            c = ys + extY;          if (c > by) { by = c; py = pack_bp(PG_Y, 0, k2); }
+                            c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, k2); }
+                            c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, k2); }
+                        }
+                        if (nL > 0 && nR > 0) {                                      // M candidates of the pair
+                            ring_load(J, d, mn1, mx1, in1, mn2, mx2, in2, p, q, xs, ys, ms);
+                            c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_M, k1, k2); }
+                            c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_X, k1, k2); }
+                            c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, k1, k2); }
+                        }
+                        if (++k2 == nRp) { k2 = 0; ++k1; }
                     }
                 }
-                SM.sc[d & (RK - 1)][i & (WMAX - 1)][PG_X] = bx;
-                SM.sc[d & (RK - 1)][i & (WMAX - 1)][PG_Y] = by;
-                SM.sc[d & (RK - 1)][i & (WMAX - 1)][PG_M] = bm;
+            }
+            if (active) {
+                SM.sc[d & (RK - 1)][i & (NT - 1)][PG_X] = bx;
+                SM.sc[d & (RK - 1)][i & (NT - 1)][PG_Y] = by;
+                SM.sc[d & (RK - 1)][i & (NT - 1)][PG_M] = bm;
                 store_cell(J.sc, J.bp, base + (i - lo), bx, by, bm, px, py, pm);
             }
         }
-        if (lane == 0) { SM.dmn[d & (RK - 1)] = lo; SM.dmx[d & (RK - 1)] = hi; SM.did[d & (RK - 1)] = wide ? -1 : d; }
+        if (tid == 0) { SM.dmn[d & (RK - 1)] = lo; SM.dmx[d & (RK - 1)] = hi; SM.did[d & (RK - 1)] = wide ? -1 : d; }
         mn2 = mn1; mx2 = mx1; in2 = in1; mn1 = lo; mx1 = hi; in1 = !wide;
         g2 = g1; g1 = {lo, hi, base};
-        __builtin_amdgcn_wave_barrier();
+        // every store older than the newest 24 of this wave has landed: with 3 stores per step that
+        // is everything >= 8 diagonals old, so cells that have left the RK-deep ring are readable
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        lds_barrier();                                            // (Bd)
     }
-    // let the loader finish whatever it was still allowed to prefetch
-    if (lane == 0) { SM_PUT(prog_row, J.Lx); SM_PUT(prog_col, J.Ly); SM_PUT(prog_d, J.nd); }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,15 +1,30 @@
-import sys, time, ctypes as C
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Diagnostic: one 2 x 100 kb banded alignment; kernel times, and with a -DPG_STAMPS build of
+the library (tools/build_stamps.sh) the per-path step counts and cycle shares of pg_fill_ring."""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import pagan2_msa_amd as pg
 from pagan2_msa_amd import synth, host, abi
-names, seqs, nwk = synth.evolve_balanced(2, 100000, branch=0.01, sub=0.008, indel_start=0.0008, mean_len=4.0, seed=5)
+
+leaves = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+names, seqs, nwk = synth.evolve_balanced(leaves, 100000, branch=0.01, sub=0.008, indel_start=0.0008, mean_len=4.0, seed=5)
 msa = host.Msa(names, seqs, nwk, use_anchors=1).align()
 print("timing", msa.timing())
-l, r, m, b = msa.node_job(0)
-for rep in range(2):
-    batch = pg.Batch([(l, r, m, b)])
-    for k in range(3):
-        batch.run(); batch.sync()
-        print("cells", batch.cells, "ms", batch.last_ms(), "nd", l.n_sites + r.n_sites - 3)
-    batch.close()
+k = msa.n_internal - 1
+l, r, m, b = msa.node_job(k)
+batch = pg.Batch([(l, r, m, b)])
+for rep in range(3):
+    batch.run(); batch.sync()
+    print("node", k, "cells", batch.cells, "ms", batch.last_ms(), "nd", l.n_sites + r.n_sites - 3)
+if os.environ.get("PG_STAMPS"):
+    n_int = 3 * (l.n_sites + r.n_sites - 2)
+    raw = np.zeros(n_int, np.int32)
+    pg.lib().pagan_batch_debug_trace(batch._h, 0, raw.ctypes.data_as(C.c_void_p), raw.nbytes)
+    a = raw[n_int - 40:].view(np.uint64).reshape(4, 5).astype(np.float64)
+    for name, row in zip(("register", "lds-fast", "general", "wide"), a):
+        n = max(row[0], 1)
+        print("%-9s steps %8d  cycles/step: head %7.1f select %7.1f compute %7.1f tail %7.1f  total %8.1f" %
+              (name, row[0], row[1] / n, row[2] / n, row[3] / n, row[4] / n, row[1:].sum() / n))
+    print("total cycles %.3e (s_memtime ticks)" % a[:, 1:].sum())
