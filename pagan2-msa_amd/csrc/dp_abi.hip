@@ -22,7 +22,10 @@
 
 template <int BLOCK> __global__ void pg_fill_wavefront(const PgDevJob *jobs, const int *which, unsigned flags);
 __global__ void pg_fill_ring(const PgDevJob *jobs, const int *which, unsigned flags);
-__global__ void pg_end_and_trace(const PgDevJob *jobs);
+__global__ void pg_end_corner(const PgDevJob *jobs);
+__global__ void pg_trace_spec(const PgDevJob *jobs);
+__global__ void pg_trace_compose(const PgDevJob *jobs);
+__global__ void pg_trace_emit(const PgDevJob *jobs);
 
 // limits of the LDS-staged kernel (dp_kernels.hip: RW site window, EC edge ring)
 #define PG_RING_MAX_WIDTH 256
@@ -113,6 +116,8 @@ struct HostJob {
     int Lx, Ly;
     DiagIndex dx;
     bool ring_ok = false;        // fits the LDS-staged narrow-band kernel
+    int n_bound = 0;             // traceback boundaries (dp_device.h)
+    std::vector<int> tb;         // [n_bound + 2] table offsets
 };
 
 // The ring kernel keeps the bwd edges of ~256 consecutive sites in a 1024-entry LDS ring.
@@ -142,6 +147,7 @@ struct pagan_batch {
     PgDevJob *d_jobs = nullptr;
     int *d_which = nullptr;      // [n]: ring-kernel jobs first, then the wide ones
     int n_ring = 0, n_wide = 0;
+    int max_bound = 0;           // largest traceback boundary count of any job
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     int64_t cells = 0;
@@ -172,6 +178,21 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb) {
     if (hj->dx.cells != rb->cells()) return PAGAN_E_INTERNAL;
     // The LDS-staged kernel suits banded work: most diagonals narrow.  A full matrix (or a band that is
     // mostly wider than the ring) goes to the multi-wave HBM wavefront instead.
+    // traceback boundaries k = 1..K at diagonals k*PG_SEG (<= nd-1): 3 table entries per cell of
+    // the diagonals k*PG_SEG and k*PG_SEG-1
+    {
+        const int nd = hj->Lx + hj->Ly - 1;
+        hj->n_bound = (nd - 1) / PG_SEG;
+        hj->tb.assign(hj->n_bound + 2, 0);
+        int run = 0;
+        for (int k = 1; k <= hj->n_bound; ++k) {
+            hj->tb[k] = run;
+            const int D = k * PG_SEG;
+            const int wa = hj->dx.imax[D] - hj->dx.imin[D] + 1, wb = hj->dx.imax[D - 1] - hj->dx.imin[D - 1] + 1;
+            run += 3 * ((wa > 0 ? wa : 0) + (wb > 0 ? wb : 0));
+        }
+        hj->tb[hj->n_bound + 1] = run;
+    }
     hj->ring_ok = hj->dx.cells <= (long long)PG_RING_MAX_WIDTH * hj->dx.imin.size() / 2 &&
                   edges_fit_ring(jb.left, hj->Lx) && edges_fit_ring(jb.right, hj->Ly);
     return PAGAN_OK;
@@ -202,11 +223,15 @@ void carve_job(Carver &c, const pagan_job &jb, const HostJob &hj, PgDevJob *d) {
     d->table = c.take<float>((size_t)d->S * d->S);
     d->imin = c.take<int>(d->nd); d->imax = c.take<int>(d->nd); d->doff = c.take<long long>(d->nd);
     d->cells = hj.dx.cells;
+    d->n_bound = hj.n_bound;
+    d->tb = c.take<int>(hj.tb.size());
 }
 void carve_outputs(Carver &c, const HostJob &hj, PgDevJob *d) {
     d->sc = c.take<double>(3 * (size_t)hj.dx.cells);
     d->bp = c.take<unsigned>(3 * (size_t)hj.dx.cells);
     d->trace = c.take<int>(3 * (size_t)(hj.Lx + hj.Ly));
+    d->ttab = c.take<int>(4 * (size_t)hj.tb.back());
+    d->segs = c.take<int>(6 * (size_t)(2 * hj.n_bound + 8));
     d->endcell = c.take<int>(8);
     d->endscore = c.take<double>(1);
 }
@@ -281,7 +306,7 @@ int replay(const HostJob &hj, const int *endcell, double endscore, const int *tr
     for (int t = 0; t < n; ++t) {
         const int ci = trace[3 * t], cj = trace[3 * t + 1];
         const unsigned w = (unsigned)trace[3 * t + 2];
-        const int vit = (int)(w & 3u), k1 = (int)((w >> 2) & 32767u), k2 = (int)(w >> 17);
+        const int vit = (int)(w & 3u), k1 = (int)((w >> 4) & 16383u), k2 = (int)(w >> 18);
         if (ci != i || cj != j) return PAGAN_E_INTERNAL;
         // the cell's `from` label is the matrix of the next visited cell; for the last one
         // it is never pushed (i<1 && j<1 after it), so any value does
@@ -396,6 +421,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         int rc = validate_job(jobs[k], &b->jobs[k], &rb);
         if (rc != PAGAN_OK) return rc;
         b->cells += b->jobs[k].dx.cells;
+        if (b->jobs[k].n_bound > b->max_bound) b->max_bound = b->jobs[k].n_bound;
         if (b->jobs[k].ring_ok && !force_v1) { which_ring.push_back(k); continue; }
         which_wide.push_back(k);
         if (b->jobs[k].dx.max_width > max_w) max_w = b->jobs[k].dx.max_width;
@@ -429,6 +455,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         put(stage, d.imin, hj.dx.imin.data(), hj.dx.imin.size());
         put(stage, d.imax, hj.dx.imax.data(), hj.dx.imax.size());
         put(stage, d.doff, hj.dx.doff.data(), hj.dx.doff.size());
+        put(stage, d.tb, hj.tb.data(), hj.tb.size());
     }
     b->trace_off.resize(n); b->end_off.resize(n); b->score_off.resize(n);
     char *base = b->arena.dev;
@@ -440,9 +467,9 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         b->score_off[k] = reinterpret_cast<size_t>(d.endscore);
         rebase(d.stL); rebase(d.offL); rebase(d.srcL); rebase(d.lwL);
         rebase(d.stR); rebase(d.offR); rebase(d.srcR); rebase(d.lwR);
-        rebase(d.table); rebase(d.imin); rebase(d.imax); rebase(d.doff);
+        rebase(d.table); rebase(d.imin); rebase(d.imax); rebase(d.doff); rebase(d.tb);
         rebase(d.sc); rebase(d.bp);
-        rebase(d.trace); rebase(d.endcell); rebase(d.endscore);
+        rebase(d.trace); rebase(d.endcell); rebase(d.endscore); rebase(d.segs); rebase(d.ttab);
     }
     std::memcpy(stage.data() + reinterpret_cast<size_t>(jobs_off), b->dj.data(), sizeof(PgDevJob) * n);
     std::memcpy(stage.data() + reinterpret_cast<size_t>(which_off), which_ring.data(), sizeof(int) * n);
@@ -464,7 +491,12 @@ int pagan_batch_run(pagan_batch *b) {
     int rc = launch_fill(b);
     if (rc != PAGAN_OK) return rc;
     HIP_TRY(hipEventRecord(b->ev[1], b->stream));
-    hipLaunchKernelGGL(pg_end_and_trace, dim3(b->n), dim3(64), 0, b->stream, b->d_jobs);
+    hipLaunchKernelGGL(pg_end_corner, dim3(b->n), dim3(64), 0, b->stream, b->d_jobs);
+    if (b->max_bound > 0)
+        hipLaunchKernelGGL(pg_trace_spec, dim3(b->max_bound, b->n), dim3(128), 0, b->stream, b->d_jobs);
+    hipLaunchKernelGGL(pg_trace_compose, dim3(b->n), dim3(64), 0, b->stream, b->d_jobs);
+    if (b->max_bound > 0)
+        hipLaunchKernelGGL(pg_trace_emit, dim3((2 * b->max_bound + 8 + 63) / 64, b->n), dim3(64), 0, b->stream, b->d_jobs);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[2], b->stream));
     b->ran = true;

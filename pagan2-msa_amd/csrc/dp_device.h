@@ -17,14 +17,23 @@
 // A back-pointer packs what Matrix_pointer (basic_alignment.h:33-50) records for the Viterbi
 // path: the predecessor matrix and WHICH bwd edges were taken, as slots into the two sites'
 // bwd lists (x_ind/y_ind/x_edge_ind/y_edge_ind follow from the slot via the CSR arrays):
-//   bits 0-1  from: 0 = X, 1 = Y, 2 = M, 3 = none (cell kept score -inf / matrix -1)
-//   bits 2-16 slot in the left site's bwd list   (M and X cells)
-//   bits 17-31 slot in the right site's bwd list (M and Y cells)
+//   bits 0-1   from: 0 = X, 1 = Y, 2 = M, 3 = none (cell kept score -inf / matrix -1)
+//   bit  2     the left edge taken starts at site i-1   } lets the traceback step without
+//   bit  3     the right edge taken starts at site j-1  } touching the graph arrays
+//   bits 4-17  slot in the left site's bwd list   (M and X cells)
+//   bits 18-31 slot in the right site's bwd list  (M and Y cells)
+//
+// Traceback (dp_kernels.hip, pg_trace_*): the path is cut at "boundary" diagonal pairs
+// {k*PG_SEG, k*PG_SEG-1}; ttab[tb[k] + 3*c + s] describes where the chase that starts in
+// state s of the c-th cell of boundary k arrives at boundary k-1 and after how many cells.
 #pragma once
 #include <stdint.h>
 
 #define PG_BP_NONE 3u
-#define PG_MAX_SLOT 32767
+#define PG_BP_ADJL 4u
+#define PG_BP_ADJR 8u
+#define PG_MAX_SLOT 16383
+#define PG_SEG 256           // diagonals per traceback segment
 
 struct PgDevJob {
     int Lx, Ly;              // matrix dimensions (sites minus the stop site)
@@ -43,6 +52,11 @@ struct PgDevJob {
     double *sc;              // [cells][3], state index = PAGAN_X_MAT / Y_MAT / M_MAT
     unsigned *bp;            // [cells][3]
     int *trace;              // [3 * (Lx+Ly)]
-    int *endcell;            // [8]: status, matrix, x_ind, y_ind, slot_l, slot_r, n_trace, pad ; score in endscore
+    int *endcell;            // [8]: status, matrix, x_ind, y_ind, slot_l, slot_r, n_trace, n_segments ; score in endscore
     double *endscore;        // [1]
+    // segmented traceback
+    int n_bound;             // K: boundaries k = 1..K at diagonals k*PG_SEG
+    const int *tb;           // [K+2] first table entry of boundary k (tb[K+1] = total)
+    int *ttab;               // [total][4]: exit i, exit j, exit matrix | kind<<2, cells visited (-1: dead entry)
+    int *segs;               // [2K+8][6]: start i, j, matrix, cells, output offset, pad
 };

@@ -30,8 +30,8 @@ namespace {
 
 __device__ __forceinline__ double neg_inf() { return -__builtin_huge_val(); }
 
-__device__ __forceinline__ unsigned pack_bp(unsigned from, int k1, int k2) {
-    return from | ((unsigned)k1 << 2) | ((unsigned)k2 << 17);
+__device__ __forceinline__ unsigned pack_bp(unsigned from, int k1, int k2, bool adjl, bool adjr) {
+    return from | (adjl ? PG_BP_ADJL : 0u) | (adjr ? PG_BP_ADJR : 0u) | ((unsigned)k1 << 4) | ((unsigned)k2 << 18);
 }
 
 // Pointers read out of a descriptor in memory are generic to the compiler (flat_* accesses,
@@ -56,6 +56,7 @@ struct View {
     gdouble_w sc;            // [cells][3]  X, Y, M
     gu32_w bp;               // [cells][3]
     gint_w trace, endcell; gdouble_w endscore;
+    int n_bound; gint_p tb; gint_w ttab, segs;
 };
 
 __device__ __forceinline__ View load_view(const PgDevJob *__restrict__ j) {
@@ -67,6 +68,7 @@ __device__ __forceinline__ View load_view(const PgDevJob *__restrict__ j) {
     v.table = (gfloat_p)j->table; v.imin = (gint_p)j->imin; v.imax = (gint_p)j->imax; v.doff = (gll_p)j->doff;
     v.sc = (gdouble_w)j->sc; v.bp = (gu32_w)j->bp;
     v.trace = (gint_w)j->trace; v.endcell = (gint_w)j->endcell; v.endscore = (gdouble_w)j->endscore;
+    v.n_bound = j->n_bound; v.tb = (gint_p)j->tb; v.ttab = (gint_w)j->ttab; v.segs = (gint_w)j->segs;
     return v;
 }
 
@@ -121,11 +123,11 @@ __device__ __forceinline__ void fill_cell_hbm(const View &J, int d, const Diag &
                 if (ix >= 0) { xs = J.sc[3 * ix + PG_X]; ys = J.sc[3 * ix + PG_Y]; ms = J.sc[3 * ix + PG_M]; }
                 const double open = (reduced_terminal && p == 0) ? 0.0 : go;        // BA.h:490-513
                 double c = xs + ext;                                                 // score_gap_ext
-                if (c > bx) { bx = c; px = pack_bp(PG_X, e - l0, 0); }
+                if (c > bx) { bx = c; px = pack_bp(PG_X, e - l0, 0, p == i - 1, false); }
                 c = (ys + 0.0) + go;                                                 // score_gap_double
-                if (c > bx) { bx = c; px = pack_bp(PG_Y, e - l0, 0); }
+                if (c > bx) { bx = c; px = pack_bp(PG_Y, e - l0, 0, p == i - 1, false); }
                 c = (ms + ng) + open;                                                // score_gap_open
-                if (c > bx) { bx = c; px = pack_bp(PG_M, e - l0, 0); }
+                if (c > bx) { bx = c; px = pack_bp(PG_M, e - l0, 0, p == i - 1, false); }
             }
         }
         // ---- Y: gap in the left sequence, consumes right site j (VA:927-944) ----
@@ -139,11 +141,11 @@ __device__ __forceinline__ void fill_cell_hbm(const View &J, int d, const Diag &
                 if (ix >= 0) { xs = J.sc[3 * ix + PG_X]; ys = J.sc[3 * ix + PG_Y]; ms = J.sc[3 * ix + PG_M]; }
                 const double open = (reduced_terminal && q == 0) ? 0.0 : go;
                 double c = ys + ext;
-                if (c > by) { by = c; py = pack_bp(PG_Y, 0, e - r0); }
+                if (c > by) { by = c; py = pack_bp(PG_Y, 0, e - r0, false, q == j - 1); }
                 c = (xs + 0.0) + go;
-                if (c > by) { by = c; py = pack_bp(PG_X, 0, e - r0); }
+                if (c > by) { by = c; py = pack_bp(PG_X, 0, e - r0, false, q == j - 1); }
                 c = (ms + ng) + open;
-                if (c > by) { by = c; py = pack_bp(PG_M, 0, e - r0); }
+                if (c > by) { by = c; py = pack_bp(PG_M, 0, e - r0, false, q == j - 1); }
             }
         }
         // ---- M: both sites consumed (VA:956-963, 1353-1436) ----
@@ -161,11 +163,11 @@ __device__ __forceinline__ void fill_cell_hbm(const View &J, int d, const Diag &
                     double xs = NI, ys = NI, ms = NI;
                     if (ix >= 0) { xs = J.sc[3 * ix + PG_X]; ys = J.sc[3 * ix + PG_Y]; ms = J.sc[3 * ix + PG_M]; }
                     double c = ((ms + tM) + lw) + rw;                                // score_m_match
-                    if (c > bm) { bm = c; pm = pack_bp(PG_M, e1 - l0, e2 - r0); }
+                    if (c > bm) { bm = c; pm = pack_bp(PG_M, e1 - l0, e2 - r0, p == i - 1, q == j - 1); }
                     c = ((xs + tX) + lw) + rw;                                       // score_x_match
-                    if (c > bm) { bm = c; pm = pack_bp(PG_X, e1 - l0, e2 - r0); }
+                    if (c > bm) { bm = c; pm = pack_bp(PG_X, e1 - l0, e2 - r0, p == i - 1, q == j - 1); }
                     c = ((ys + tX) + lw) + rw;                                       // score_y_match
-                    if (c > bm) { bm = c; pm = pack_bp(PG_Y, e1 - l0, e2 - r0); }
+                    if (c > bm) { bm = c; pm = pack_bp(PG_Y, e1 - l0, e2 - r0, p == i - 1, q == j - 1); }
                 }
             }
         }
@@ -283,29 +285,26 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Scores of cell (p,q) on an earlier diagonal; -inf outside the tunnel.
-__device__ __forceinline__ void ring_load(const View &J, int d, int mn1, int mx1, bool in1, int mn2, int mx2, bool in2,
-                                          int p, int q, double &xs, double &ys, double &ms) {
+// Scores of cell (p,q) on an earlier diagonal; -inf outside the tunnel.  Branch-light: the slot's
+// descriptor and scores are read unconditionally (the slot always exists) and selected
+// afterwards; only a cell that is not in the ring takes the (rare) HBM branch.
+__device__ __forceinline__ void ring_load(const View &J, int d, int p, int q, double &xs, double &ys, double &ms) {
     const double NI = neg_inf();
-    const int dd = p + q, age = d - dd;
-    ms = NI; xs = NI; ys = NI;
-    bool ring;
-    int mn, mx;
-    if (age == 1) { ring = in1; mn = mn1; mx = mx1; }
-    else if (age == 2) { ring = in2; mn = mn2; mx = mx2; }
-    else {
-        ring = age < RK && SM.did[dd & (RK - 1)] == dd;
-        if (ring) { mn = SM.dmn[dd & (RK - 1)]; mx = SM.dmx[dd & (RK - 1)]; }
-        else { mn = far_i32(J.imin + dd); mx = far_i32(J.imax + dd); }
-    }
-    if (p < mn || p > mx) return;
-    if (ring) {
-        xs = SM.sc[dd & (RK - 1)][p & (NT - 1)][PG_X];
-        ys = SM.sc[dd & (RK - 1)][p & (NT - 1)][PG_Y];
-        ms = SM.sc[dd & (RK - 1)][p & (NT - 1)][PG_M];
-    } else {
-        const long long ix = far_i64(J.doff + dd) + (p - mn);
-        xs = far_f64(J.sc + 3 * ix + PG_X); ys = far_f64(J.sc + 3 * ix + PG_Y); ms = far_f64(J.sc + 3 * ix + PG_M);
+    const int dd = p + q, slot = dd & (RK - 1);
+    const int id = SM.did[slot], mn = SM.dmn[slot], mx = SM.dmx[slot];
+    const double rx = SM.sc[slot][p & (NT - 1)][PG_X];
+    const double ry = SM.sc[slot][p & (NT - 1)][PG_Y];
+    const double rm = SM.sc[slot][p & (NT - 1)][PG_M];
+    const bool ring = id == dd;                       // dd < d always, so a match means "diagonal dd is resident"
+    const bool ok = ring && p >= mn && p <= mx;
+    xs = ok ? rx : NI; ys = ok ? ry : NI; ms = ok ? rm : NI;
+    if (!ring) {
+        // left the ring (edge reaching >= RK diagonals back) or never entered it (wide diagonal)
+        const int fmn = far_i32(J.imin + dd), fmx = far_i32(J.imax + dd);
+        if (p >= fmn && p <= fmx) {
+            const long long ix = far_i64(J.doff + dd) + (p - fmn);
+            xs = far_f64(J.sc + 3 * ix + PG_X); ys = far_f64(J.sc + 3 * ix + PG_Y); ms = far_f64(J.sc + 3 * ix + PG_M);
+        }
     }
 }
 
@@ -429,16 +428,16 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
                     const double openX = (reduced_terminal && i == 1) ? 0.0 : go;
                     const double openY = (reduced_terminal && j == 1) ? 0.0 : go;
                     double c;
-                    c = xA + extX;          if (c > bx) { bx = c; px = PG_X; }
-                    c = (yA + 0.0) + go;    if (c > bx) { bx = c; px = PG_Y; }
-                    c = (mA + ng) + openX;  if (c > bx) { bx = c; px = PG_M; }
-                    c = yB + extY;          if (c > by) { by = c; py = PG_Y; }
-                    c = (xB + 0.0) + go;    if (c > by) { by = c; py = PG_X; }
-                    c = (mB + ng) + openY;  if (c > by) { by = c; py = PG_M; }
+                    c = xA + extX;          if (c > bx) { bx = c; px = PG_X | PG_BP_ADJL; }
+                    c = (yA + 0.0) + go;    if (c > bx) { bx = c; px = PG_Y | PG_BP_ADJL; }
+                    c = (mA + ng) + openX;  if (c > bx) { bx = c; px = PG_M | PG_BP_ADJL; }
+                    c = yB + extY;          if (c > by) { by = c; py = PG_Y | PG_BP_ADJR; }
+                    c = (xB + 0.0) + go;    if (c > by) { by = c; py = PG_X | PG_BP_ADJR; }
+                    c = (mB + ng) + openY;  if (c > by) { by = c; py = PG_M | PG_BP_ADJR; }
                     const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
-                    c = mC + tM;            if (c > bm) { bm = c; pm = PG_M; }     // + 0.0 + 0.0 (log-weights) omitted: exact
-                    c = xC + tX;            if (c > bm) { bm = c; pm = PG_X; }
-                    c = yC + tX;            if (c > bm) { bm = c; pm = PG_Y; }
+                    c = mC + tM;            if (c > bm) { bm = c; pm = PG_M | PG_BP_ADJL | PG_BP_ADJR; }     // + 0.0 + 0.0 (log-weights) omitted: exact
+                    c = xC + tX;            if (c > bm) { bm = c; pm = PG_X | PG_BP_ADJL | PG_BP_ADJR; }
+                    c = yC + tX;            if (c > bm) { bm = c; pm = PG_Y | PG_BP_ADJL | PG_BP_ADJR; }
                 }
             } else {
                 // ---- general: each lane walks its (left edge, right edge) pairs row-major, which visits
@@ -468,24 +467,24 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
                         if (nL > 0) { p = SM.esL[(l0 + k1) & (EC - 1)]; lw = (double)SM.ewL[(l0 + k1) & (EC - 1)]; }
                         if (nR > 0) { q = SM.esR[(r0 + k2) & (EC - 1)]; rw = (double)SM.ewR[(r0 + k2) & (EC - 1)]; }
                         if (nL > 0 && k2 == 0) {                                     // X candidates of left edge k1
-                            ring_load(J, d, mn1, mx1, in1, mn2, mx2, in2, p, j, xs, ys, ms);
+                            ring_load(J, d, p, j, xs, ys, ms);
                             const double open = (reduced_terminal && p == 0) ? 0.0 : go;
-                            c = xs + extX;          if (c > bx) { bx = c; px = pack_bp(PG_X, k1, 0); }
-                            c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, k1, 0); }
-                            c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, k1, 0); }
+                            c = xs + extX;          if (c > bx) { bx = c; px = pack_bp(PG_X, k1, 0, p == i - 1, false); }
+                            c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, k1, 0, p == i - 1, false); }
+                            c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, k1, 0, p == i - 1, false); }
                         }
                         if (nR > 0 && k1 == 0) {                                     // Y candidates of right edge k2
-                            ring_load(J, d, mn1, mx1, in1, mn2, mx2, in2, i, q, xs, ys, ms);
+                            ring_load(J, d, i, q, xs, ys, ms);
                             const double open = (reduced_terminal && q == 0) ? 0.0 : go;
-                            c = ys + extY;          if (c > by) { by = c; py = pack_bp(PG_Y, 0, k2); }
-                            c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, k2); }
-                            c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, k2); }
+                            c = ys + extY;          if (c > by) { by = c; py = pack_bp(PG_Y, 0, k2, false, q == j - 1); }
+                            c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, k2, false, q == j - 1); }
+                            c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, k2, false, q == j - 1); }
                         }
                         if (nL > 0 && nR > 0) {                                      // M candidates of the pair
-                            ring_load(J, d, mn1, mx1, in1, mn2, mx2, in2, p, q, xs, ys, ms);
-                            c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_M, k1, k2); }
-                            c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_X, k1, k2); }
-                            c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, k1, k2); }
+                            ring_load(J, d, p, q, xs, ys, ms);
+                            c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_M, k1, k2, p == i - 1, q == j - 1); }
+                            c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_X, k1, k2, p == i - 1, q == j - 1); }
+                            c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, k1, k2, p == i - 1, q == j - 1); }
                         }
                         if (++k2 == nRp) { k2 = 0; ++k1; }
                     }
@@ -509,13 +508,70 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// End corner (iterate_bwd_edges_for_end_corner, VA:1440-1552, score_gap_close VA:2221-2255)
-// and the pointer chase of backtrack_new_path (VA:1038-1189).  One lane per alignment: the
-// chase is a serial dependency chain.  It emits the visited cells as (i, j, w) with
-// w = the cell's own matrix in bits 0-1 and its two edge slots in bits 2-31 (the cell's
-// `from` label is the next entry's matrix); skip columns and used-edge marks are derived
-// from that list on the host.
-__global__ void pg_end_and_trace(const PgDevJob *__restrict__ jobs) {
+// End corner and traceback.
+//
+// pg_end_corner: iterate_bwd_edges_for_end_corner (VA:1440-1552) with score_gap_close
+// (VA:2221-2255); one lane per alignment.
+//
+// Traceback (backtrack_new_path, VA:1038-1189) is a pointer chase through the back-pointers:
+// ~(Lx+Ly)/2..(Lx+Ly) dependent HBM reads if done by one lane (70-100 ms for 2 x 100 kb).
+// Instead the path is cut at boundary diagonal pairs {k*PG_SEG, k*PG_SEG-1}, k = 1..K -- a move
+// lowers d by 1 (gap) or 2 (match), so a path can only skip a pair through a long graph edge:
+//   pg_trace_spec     every (cell, state) on every boundary chases to the next lower boundary,
+//                     all in parallel, and records where it arrives and after how many cells;
+//   pg_trace_compose  one lane per alignment hops from the end cell through those tables
+//                     (K dependent reads instead of Lx+Ly), producing (start, length, offset)
+//                     per segment; a long edge that jumps over a boundary is chased serially
+//                     up to the next one;
+//   pg_trace_emit     every segment is chased again in parallel, writing the visited cells
+//                     (i, j, w) at its offset; w = the cell's own matrix in bits 0-1 and its
+//                     back-pointer bits 2-31 (the cell's `from` label is the next entry's
+//                     matrix).  Skip columns and used-edge marks are derived on the host.
+namespace {
+
+struct TNode { int i, j, vit; };
+
+__device__ __forceinline__ bool trace_done(const TNode &n) { return n.i < 1 && n.j < 1; }
+
+// One chase step: emit (i, j, w) for the cell `n` names and move to its predecessor.
+__device__ __forceinline__ bool trace_step(const View &J, TNode &n, int &w) {
+    if (n.vit < 0 || n.vit > 2 || n.i < 0 || n.j < 0 || n.i >= J.Lx || n.j >= J.Ly) return false;
+    const int dd = n.i + n.j;
+    const int mn = J.imin[dd], mx = J.imax[dd];
+    if (n.i < mn || n.i > mx) return false;
+    const long long ix = J.doff[dd] + (n.i - mn);
+    const unsigned b = J.bp[3 * ix + n.vit];
+    w = (int)((unsigned)n.vit | (b & ~3u));
+    const unsigned from = b & 3u;
+    if (from == PG_BP_NONE) return false;
+    const int k1 = (int)((b >> 4) & 16383u), k2 = (int)(b >> 18);
+    if (n.vit != PG_Y) n.i = (b & PG_BP_ADJL) ? n.i - 1 : J.srcL[J.offL[n.i] + k1];
+    if (n.vit != PG_X) n.j = (b & PG_BP_ADJR) ? n.j - 1 : J.srcR[J.offR[n.j] + k2];
+    n.vit = (int)from;
+    return true;
+}
+
+// boundary a diagonal belongs to (0 = none): d == k*SEG or d == k*SEG - 1, 1 <= k <= K
+__device__ __forceinline__ int boundary_of(int d, int K) {
+    if (d <= 0) return 0;
+    int k = 0;
+    if (d % PG_SEG == 0) k = d / PG_SEG; else if ((d + 1) % PG_SEG == 0) k = (d + 1) / PG_SEG;
+    return (k >= 1 && k <= K) ? k : 0;
+}
+
+// index of node n inside boundary k's table block
+__device__ __forceinline__ int entry_index(const View &J, int k, const TNode &n) {
+    const int D = k * PG_SEG, dd = n.i + n.j;
+    if (dd == D) return 3 * (n.i - J.imin[D]) + n.vit;
+    const int w = J.imax[D] - J.imin[D] + 1;
+    return 3 * (w > 0 ? w : 0) + 3 * (n.i - J.imin[D - 1]) + n.vit;
+}
+
+enum { EXIT_ENTRY = 0, EXIT_MISS = 1, EXIT_DONE = 2 };
+
+} // namespace
+
+__global__ void pg_end_corner(const PgDevJob *__restrict__ jobs) {
     if (threadIdx.x != 0) return;
     const View J = load_view(jobs + blockIdx.x);
     const double NI = neg_inf();
@@ -559,28 +615,87 @@ __global__ void pg_end_and_trace(const PgDevJob *__restrict__ jobs) {
     }
     J.endscore[0] = best;
     gint_w ec = J.endcell;
-    ec[1] = mat; ec[2] = xi; ec[3] = yi; ec[4] = kl; ec[5] = kr;
-    if (!(best > NI)) { ec[0] = 1; ec[6] = 0; return; }
+    ec[1] = mat; ec[2] = xi; ec[3] = yi; ec[4] = kl; ec[5] = kr; ec[6] = 0; ec[7] = 0;
+    ec[0] = (best > NI) ? 0 : 1;
+}
 
-    // ---- traceback: i,j jump straight to the predecessor cell; the host re-inserts the
-    // skipped sites (insert_preexisting_gap, viterbi_alignment.h:146-193) ----
-    int vit = mat, i = xi, j = yi, n = 0, status = 0;
-    const int cap = Lx + Ly;
-    gint_w tr = J.trace;
-    while (!(i < 1 && j < 1)) {
-        if (n >= cap || vit > 2 || vit < 0) { status = 2; break; }
-        const long long ix = hbm_index(J, -10, none, none, i, j);
-        if (ix < 0) { status = 2; break; }
-        const unsigned b = J.bp[3 * ix + vit];
-        tr[3 * n] = i; tr[3 * n + 1] = j; tr[3 * n + 2] = (int)((unsigned)vit | (b & ~3u));
-        ++n;
-        const unsigned from = b & 3u;
-        const int k1 = (int)((b >> 2) & 32767u), k2 = (int)(b >> 17);
-        if (from == PG_BP_NONE) { status = 2; break; }
-        if (vit == PG_M) { i = J.srcL[J.offL[i] + k1]; j = J.srcR[J.offR[j] + k2]; }
-        else if (vit == PG_X) { i = J.srcL[J.offL[i] + k1]; }
-        else { j = J.srcR[J.offR[j] + k2]; }
-        vit = (int)from;
+// grid (K_max, n_jobs): block b.x handles boundary k = b.x + 1 of job b.y
+__global__ __launch_bounds__(128) void pg_trace_spec(const PgDevJob *__restrict__ jobs) {
+    const View J = load_view(jobs + blockIdx.y);
+    const int k = blockIdx.x + 1;
+    if (k > J.n_bound || J.endcell[0] != 0) return;
+    const int D = k * PG_SEG;
+    const int mnA = J.imin[D], wA = max(J.imax[D] - mnA + 1, 0);
+    const int mnB = J.imin[D - 1], wB = max(J.imax[D - 1] - mnB + 1, 0);
+    const int n_entries = 3 * (wA + wB);
+    const int low = (k - 1) * PG_SEG;                // next lower boundary pair {low, low-1}; k == 1: run to the start
+    gint_w tab = J.ttab + 4 * (long long)J.tb[k];
+    for (int e = threadIdx.x; e < n_entries; e += blockDim.x) {
+        TNode n;
+        if (e < 3 * wA) { n.i = mnA + e / 3; n.j = D - n.i; } else { n.i = mnB + (e - 3 * wA) / 3; n.j = D - 1 - n.i; }
+        n.vit = e % 3;
+        int steps = 0, kind = EXIT_DONE, w;
+        bool ok = true;
+        for (;;) {
+            if (trace_done(n)) { kind = EXIT_DONE; break; }
+            const int dd = n.i + n.j;
+            if (steps > 0 && k > 1 && dd <= low) { kind = dd >= low - 1 ? EXIT_ENTRY : EXIT_MISS; break; }
+            if (steps > 4 * PG_SEG || !trace_step(J, n, w)) { ok = false; break; }
+            ++steps;
+        }
+        tab[4 * e] = n.i; tab[4 * e + 1] = n.j; tab[4 * e + 2] = (n.vit & 3) | (kind << 2); tab[4 * e + 3] = ok ? steps : -1;
     }
-    ec[0] = status; ec[6] = n;
+}
+
+__global__ void pg_trace_compose(const PgDevJob *__restrict__ jobs) {
+    if (threadIdx.x != 0) return;
+    const View J = load_view(jobs + blockIdx.x);
+    gint_w ec = J.endcell;
+    if (ec[0] != 0) return;
+    TNode n; n.vit = ec[1]; n.i = ec[2]; n.j = ec[3];
+    const int cap = J.Lx + J.Ly, seg_cap = 2 * J.n_bound + 8;
+    int off = 0, nseg = 0, status = 0;
+    gint_w tr = J.trace;
+    while (!trace_done(n)) {
+        if (off >= cap) { status = 2; break; }
+        const int k = boundary_of(n.i + n.j, J.n_bound);
+        if (k > 0) {
+            const int mnD = J.imin[n.i + n.j], mxD = J.imax[n.i + n.j];
+            if (n.i < mnD || n.i > mxD || n.vit < 0 || n.vit > 2) { status = 2; break; }
+            PG_GLOBAL const int *e = J.ttab + 4 * ((long long)J.tb[k] + entry_index(J, k, n));
+            const int steps = e[3];
+            if (steps <= 0 || nseg >= seg_cap || off + steps > cap) { status = 2; break; }
+            gint_w sg = J.segs + 6 * nseg++;
+            sg[0] = n.i; sg[1] = n.j; sg[2] = n.vit; sg[3] = steps; sg[4] = off;
+            off += steps;
+            n.i = e[0]; n.j = e[1]; n.vit = e[2] & 3;
+        } else {
+            // not on a boundary pair (the first cells below the end corner, or a long edge that
+            // jumped over a pair): chase serially until one is reached
+            int w;
+            const int ci = n.i, cj = n.j;
+            if (!trace_step(J, n, w)) { status = 2; break; }
+            tr[3 * off] = ci; tr[3 * off + 1] = cj; tr[3 * off + 2] = w;
+            ++off;
+        }
+    }
+    ec[0] = status; ec[6] = off; ec[7] = nseg;
+}
+
+// grid (ceil(max_segments / 64), n_jobs), one lane per segment
+__global__ __launch_bounds__(64) void pg_trace_emit(const PgDevJob *__restrict__ jobs) {
+    const View J = load_view(jobs + blockIdx.y);
+    if (J.endcell[0] != 0) return;
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= J.endcell[7]) return;
+    PG_GLOBAL const int *sg = J.segs + 6 * s;
+    TNode n; n.i = sg[0]; n.j = sg[1]; n.vit = sg[2];
+    const int steps = sg[3];
+    gint_w tr = J.trace + 3 * (long long)sg[4];
+    for (int t = 0; t < steps; ++t) {
+        int w;
+        const int ci = n.i, cj = n.j;
+        if (!trace_step(J, n, w)) { J.endcell[0] = 2; return; }     // cannot happen: pg_trace_spec walked the same cells
+        tr[3 * t] = ci; tr[3 * t + 1] = cj; tr[3 * t + 2] = w;
+    }
 }

@@ -28,3 +28,13 @@ if os.environ.get("PG_STAMPS"):
         print("%-9s steps %8d  cycles/step: head %7.1f select %7.1f compute %7.1f tail %7.1f  total %8.1f" %
               (name, row[0], row[1] / n, row[2] / n, row[3] / n, row[4] / n, row[1:].sum() / n))
     print("total cycles %.3e (s_memtime ticks)" % a[:, 1:].sum())
+if os.environ.get("PG_CHECK"):
+    import oracle
+    bad = 0
+    for kk in range(msa.n_internal):
+        a, b2, m2, bb = msa.node_job(kk)
+        want = oracle.dp_align(a, b2, m2, bb)
+        ok = msa.node_result(kk).same_alignment(want)
+        bad += not ok
+        print("node", kk, "level", msa.node_info(kk).level, "cells", want.cells, "OK" if ok else "MISMATCH", flush=True)
+    print("mismatches:", bad)
