@@ -175,6 +175,8 @@ int64_t pagan_batch_cells(const pagan_batch *b);
 void pagan_batch_destroy(pagan_batch *b);
 /* diagnostic builds only: raw bytes of job k's device trace buffer                    */
 int  pagan_batch_debug_trace(pagan_batch *b, int32_t k, void *dst, int64_t bytes);
+/* diagnostic: overwrite all device outputs with 0xFF (NaN scores) before a run           */
+int  pagan_batch_debug_poison(pagan_batch *b);
 
 const char *pagan_dp_version(void);
 

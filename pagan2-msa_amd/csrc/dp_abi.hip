@@ -151,7 +151,7 @@ struct pagan_batch {
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     int64_t cells = 0;
-    size_t out_bytes = 0;
+    size_t out_begin = 0;        // arena offset where the output arrays start
     bool ran = false;
     // D2H staging (pinned)
     std::vector<size_t> trace_off;   // byte offsets of trace/endcell/endscore inside the arena
@@ -436,6 +436,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     int *which_off = sizer.take<int>(n);
     for (int k = 0; k < n; ++k) carve_job(sizer, jobs[k], b->jobs[k], &b->dj[k]);
     const size_t in_bytes = sizer.cur;
+    b->out_begin = in_bytes;
     for (int k = 0; k < n; ++k) carve_outputs(sizer, b->jobs[k], &b->dj[k]);
     b->arena.size = sizer.cur;
     HIP_TRY(hipMalloc((void **)&b->arena.dev, b->arena.size));
@@ -545,6 +546,15 @@ int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
         if (rc != PAGAN_OK && first_err == PAGAN_OK) first_err = rc;
     }
     return first_err;
+}
+
+// Diagnostic: fill every output array of the batch (scores, back-pointers, traceback tables) with
+// 0xFF bytes -- NaN scores -- so that a read of a cell that has not been written yet in THIS run
+// cannot silently return the previous run's (identical) value.
+int pagan_batch_debug_poison(pagan_batch *b) {
+    if (!b) return PAGAN_E_ARG;
+    HIP_TRY(hipMemsetAsync(b->arena.dev + b->out_begin, 0xFF, b->arena.size - b->out_begin, b->stream));
+    return PAGAN_OK;
 }
 
 // Diagnostic: raw copy of job k's trace buffer (used by tools/ with a -DPG_STAMPS build).

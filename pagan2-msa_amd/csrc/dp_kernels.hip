@@ -223,8 +223,8 @@ template __global__ void pg_fill_wavefront<1024>(const PgDevJob *, const int *, 
 //     predecessor site, weight 1) runs straight-line code: three 24-byte LDS reads, nine
 //     candidates; otherwise each lane walks its (left edge, right edge) pairs in the
 //     reference's order;
-//   - a graph edge reaching >= RK diagonals back reads HBM; `s_waitcnt vmcnt(24)` once per
-//     step bounds how far any wave's stores may lag, so a cell that old has landed;
+//   - a graph edge reaching >= RK diagonals back reads HBM (L1-bypassing loads); every wave
+//     drains its stores once per RK/2 diagonals, so a cell that old has landed;
 //   - a diagonal wider than NT (a box between distant anchors) is computed from HBM operands
 //     between two full drains and marked "not in the ring".
 #define NW 4
@@ -260,22 +260,22 @@ namespace {
 // vmcnt(0) -- which would also wait for every store in flight -- on the common path.
 __device__ __forceinline__ double far_f64(PG_GLOBAL const double *p) {
     double v;
-    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
 __device__ __forceinline__ int far_i32(PG_GLOBAL const int *p) {
     int v;
-    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
 __device__ __forceinline__ float far_f32(PG_GLOBAL const float *p) {
     float v;
-    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
 __device__ __forceinline__ long long far_i64(PG_GLOBAL const long long *p) {
     long long v;
-    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
 
@@ -295,7 +295,9 @@ __device__ __forceinline__ void ring_load(const View &J, int d, int p, int q, do
     const double rx = SM.sc[slot][p & (NT - 1)][PG_X];
     const double ry = SM.sc[slot][p & (NT - 1)][PG_Y];
     const double rm = SM.sc[slot][p & (NT - 1)][PG_M];
-    const bool ring = id == dd;                       // dd < d always, so a match means "diagonal dd is resident"
+    // Resident = the slot still names diagonal dd AND dd is younger than the ring is deep: at age
+    // RK the slot is the one the current diagonal is being written into by other lanes and waves.
+    const bool ring = id == dd && d - dd < RK;
     const bool ok = ring && p >= mn && p <= mx;
     xs = ok ? rx : NI; ys = ok ? ry : NI; ms = ok ? rm : NI;
     if (!ring) {
@@ -500,9 +502,10 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
         if (tid == 0) { SM.dmn[d & (RK - 1)] = lo; SM.dmx[d & (RK - 1)] = hi; SM.did[d & (RK - 1)] = wide ? -1 : d; }
         mn2 = mn1; mx2 = mx1; in2 = in1; mn1 = lo; mx1 = hi; in1 = !wide;
         g2 = g1; g1 = {lo, hi, base};
-        // every store older than the newest 24 of this wave has landed: with 3 stores per step that
-        // is everything >= 8 diagonals old, so cells that have left the RK-deep ring are readable
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        // A cell read back from HBM (an edge reaching >= RK diagonals back) must have landed, whichever
+        // wave stored it: every wave drains its stores once per RK/2 diagonals, so after the barriers
+        // of the following diagonals nothing older than RK diagonals is still in flight.
+        if ((d & (RK / 2 - 1)) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();                                            // (Bd)
     }
 }

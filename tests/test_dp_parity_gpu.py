@@ -156,3 +156,56 @@ def test_invalid_inputs_are_error_codes(pg):
     with pytest.raises(pg.PaganError) as e:
         pg.align(broken, right, model)
     assert e.value.code == abi.PAGAN_E_GRAPH
+
+
+def banded_around_diagonal(left, right, rng, lo_w=4, hi_w=30):
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    centre = np.linspace(0, Ly - 1, Lx)
+    up = np.maximum.accumulate(np.clip(centre - rng.integers(lo_w, hi_w, Lx), 0, None)).astype(np.int32)
+    lo = np.maximum.accumulate(np.clip(centre + rng.integers(lo_w, hi_w, Lx), 0, Ly + 5)).astype(np.int32)
+    up[0] = 0
+    return abi.Band(up, lo)
+
+
+def test_ring_kernel_long_edges_around_ring_depth(pg, oracle):
+    """Banded jobs (LDS ring kernel) whose graph edges reach 1..40 diagonals back: predecessors in
+    the ring, exactly at its depth, and beyond it (read back from HBM).  Output buffers are
+    poisoned between runs so a read of a not-yet-written cell cannot pass by luck; repeated
+    runs catch wave-timing races."""
+    rng = np.random.default_rng(11)
+    jobs = []
+    for seed in range(6):
+        left = synth.random_graph(700 + 50 * seed, 15, 900 + seed, p_extra=0.25, max_deg=3, max_span=12 + 5 * seed, p_dead=0.01)
+        right = synth.random_graph(720 + 40 * seed, 15, 950 + seed, p_extra=0.25, max_deg=3, max_span=30 - 4 * seed)
+        jobs.append((left, right, synth.random_model(15, seed), banded_around_diagonal(left, right, rng)))
+    want = [oracle.dp_align(*j) for j in jobs]
+    batch = pg.Batch(jobs)
+    for rep in range(6):
+        assert pg.lib().pagan_batch_debug_poison(batch._h) == 0
+        batch.run()
+        for k, got in enumerate(batch.fetch()):
+            assert_same(got, want[k], "rep %d job %d" % (rep, k))
+    batch.close()
+
+
+def test_ring_kernel_wide_boxes_inside_a_band(pg, oracle):
+    """A band that is narrow except for boxes wider than the ring (256 cells): the kernel leaves
+    the ring for those diagonals (HBM operands, full drains) and re-enters it afterwards."""
+    rng = np.random.default_rng(5)
+    left = synth.random_graph(1500, 15, 41, p_extra=0.1, max_span=20)
+    right = synth.random_graph(1500, 15, 42, p_extra=0.1, max_span=20)
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    up = np.clip(np.arange(Lx) - 12, 0, None).astype(np.int32)
+    lo = np.clip(np.arange(Lx) + 12, 0, Ly).astype(np.int32)
+    for a in (300, 900):                      # two 340 x 340 boxes
+        up[a:a + 340] = up[a]
+        lo[a:a + 340] = lo[a + 339]
+    band = abi.Band(up, lo)
+    model = synth.random_model(15, 9)
+    want = oracle.dp_align(left, right, model, band)
+    batch = pg.Batch([(left, right, model, band)])
+    for rep in range(3):
+        pg.lib().pagan_batch_debug_poison(batch._h)
+        batch.run()
+        assert_same(batch.fetch()[0], want, "rep %d" % rep)
+    batch.close()
