@@ -144,9 +144,10 @@ def main():
                        "anchors": "prefix, offset 15" if anchors else "none", "node_alignments": n_nodes,
                        "cells_per_step_per_gpu": int(cells), "parallelism": "independent node alignments per GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "pg_fill_wavefront", "avg_launch_ms": fill_avg_ms,
-                         "algorithmic_bytes_per_cell": BYTES_PER_CELL},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, cells),
+                         "kernel": "pg_fill_ring" if anchors else "pg_fill_wavefront", "avg_launch_ms": fill_avg_ms,
+                         "algorithmic_bytes_per_cell": BYTES_PER_CELL,
+                         "algorithmic_bytes_per_launch": BYTES_PER_CELL * int(cells)},
             "kernels_ms": {"fill": fill_avg_ms, "end_and_trace": float(np.mean(trace_ms))},
             "e2e_wall_s": e2e_wall,
             "e2e_breakdown_s": tm,
@@ -158,6 +159,20 @@ def main():
     L.pagan_batch_destroy(hb)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(workload, cells):
+    """HBM bytes per launch of the fill kernel from the committed rocprofv3 --pmc passes of this same
+    command (WRITE_SIZE and FETCH_SIZE need separate passes and cannot be collected from inside
+    the bench); None when the profile is for another workload or cell count."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fill_ring.json")
+    try:
+        prof = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if prof.get("workload") != workload or prof.get("cells_per_launch") != int(cells):
+        return None
+    return prof["hbm_bytes_per_launch"]
 
 
 def cpu_baseline(msa, n_nodes, budget_s):
