@@ -109,13 +109,8 @@ def main():
         trace_ms.append(ms[1])
     fence()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    tot_cells = torch.tensor([float(cells)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot_cells, op=dist.ReduceOp.SUM)
-    elapsed_max = float(tmax.item())
-    total_cells = float(tot_cells.item())
+    from pagan2_msa_amd import dist as pdist
+    elapsed_max, total_cells = pdist.reduce_step(elapsed, cells, device="cuda")
 
     # parity spot check of the resident batch against what the tree walk produced
     res = (abi.CResult * n_nodes)()

@@ -45,6 +45,11 @@ typedef struct pagan_msa_opts {
 
 void pagan_msa_default_opts(pagan_msa_opts *o);
 
+/* The work-queue rule that spreads a tree level's ready nodes (node.cpp:273-285 run_nodes) over
+ * devices or ranks: largest cost first, each unit to the least-loaded worker.  owner[k] in
+ * [0, n_workers).  Pure host function (no GPU).                                             */
+void pagan_assign_units(int32_t n, const int64_t *cost, int32_t n_workers, int32_t *owner);
+
 typedef struct pagan_node_info {
     int32_t node, left, right;   /* node ids: leaves 0..n-1 in input order, internal n..2n-2
                                     in alignment (post-order) order                              */

@@ -214,6 +214,21 @@ void build_rows(pagan_msa *m) {
 
 extern "C" {
 
+// Work-queue assignment shared by the in-process multi-device walk and the one-process-per-GPU
+// bench: units sorted by cost (largest first, stable), each to the currently least-loaded worker.
+void pagan_assign_units(int32_t n, const int64_t *cost, int32_t n_workers, int32_t *owner) {
+    if (n <= 0 || n_workers <= 0) return;
+    std::vector<int> order(n);
+    for (int k = 0; k < n; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    std::vector<int64_t> load(n_workers, 0);
+    for (int k : order) {
+        int best = 0;
+        for (int d = 1; d < n_workers; ++d) if (load[d] < load[best]) best = d;
+        owner[k] = best; load[best] += cost[k];
+    }
+}
+
 void pagan_msa_default_opts(pagan_msa_opts *o) {
     std::memset(o, 0, sizeof(*o));
     o->use_anchors = 1; o->anchors_offset = 15; o->prefix_hit_length = 30; o->hit_trim = 5;
@@ -347,14 +362,13 @@ int pagan_msa_align(pagan_msa *m) {
             cost[k] = pagan_dp_count_cells(w.gl.n_sites, w.gr.n_sites, w.banded ? &w.pb : nullptr);
             if (cost[k] < 0) return (int)cost[k];
         }
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+        std::vector<int64_t> oc(order.size());
+        for (size_t r = 0; r < order.size(); ++r) oc[r] = cost[order[r]];
+        std::vector<int32_t> owner(order.size());
+        pagan_assign_units((int32_t)order.size(), oc.data(), ndev, owner.data());
         std::vector<std::vector<int>> per_dev(ndev);
-        std::vector<int64_t> load(ndev, 0);
-        for (int k : order) {                                   // least-loaded device gets the next node
-            int best = 0;
-            for (int d = 1; d < ndev; ++d) if (load[d] < load[best]) best = d;
-            per_dev[best].push_back(k); load[best] += cost[k];
-        }
+        for (size_t r = 0; r < order.size(); ++r) per_dev[owner[r]].push_back(order[r]);
+        for (auto &v : per_dev) std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return cost[a] > cost[b]; });
         std::vector<int> rcs(ndev, PAGAN_OK);
         std::vector<double> fms(ndev, 0), tms(ndev, 0);
         {

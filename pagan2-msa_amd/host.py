@@ -85,13 +85,15 @@ def _lib():
         L.pagan_define_tunnel.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32,
                                           C.c_int32, _i32p, _i32p]
         L.pagan_define_tunnel.restype = C.c_int
+        L.pagan_assign_units.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.c_int32, _i32p]
+        L.pagan_assign_units.restype = None
         L.pagan_dna_model.argtypes = [_f32p, C.c_double, _f32p, _f32p, _i32p]
         L.pagan_dna_model.restype = C.c_int
         _declared = True
     return L
 
 
-HOST_EXPORTED = ["pagan_msa_default_opts", "pagan_msa_create", "pagan_msa_align", "pagan_msa_n_internal",
+HOST_EXPORTED = ["pagan_assign_units", "pagan_msa_default_opts", "pagan_msa_create", "pagan_msa_align", "pagan_msa_n_internal",
                  "pagan_msa_node_info", "pagan_msa_node_job", "pagan_msa_node_result", "pagan_msa_timing_get",
                  "pagan_msa_alignment_length", "pagan_msa_alignment_row", "pagan_msa_node_graph",
                  "pagan_msa_destroy", "pagan_hgraph_leaf", "pagan_hgraph_parent", "pagan_hgraph_view",
@@ -184,6 +186,14 @@ class HGraph:
         buf = C.create_string_buffer(v.n_sites + 1)
         n = L.pagan_hgraph_string(self.h, 1 if with_gaps else 0, alphabet.encode(), buf)
         return buf.raw[:n].decode()
+
+
+def assign_units(costs, n_workers):
+    """owner[k] for every unit: largest first, least-loaded worker (pagan_assign_units)."""
+    c = np.ascontiguousarray(costs, np.int64)
+    owner = np.zeros(c.shape[0], np.int32)
+    _lib().pagan_assign_units(int(c.shape[0]), c.ctypes.data_as(C.POINTER(C.c_int64)), int(n_workers), _ip(owner))
+    return owner
 
 
 def define_tunnel(s1, s2, g1, g2, prefix_hit_length=30, hit_trim=5, offset=15):
