@@ -21,7 +21,7 @@
 #include "dp_device.h"
 
 template <int BLOCK> __global__ void pg_fill_wavefront(const PgDevJob *jobs, const int *which, unsigned flags);
-__global__ void pg_fill_ring(const PgDevJob *jobs, const int *which, unsigned flags);
+template <bool TAB_LDS> __global__ void pg_fill_ring(const PgDevJob *jobs, const int *which, unsigned flags);
 __global__ void pg_end_corner(const PgDevJob *jobs);
 __global__ void pg_trace_spec(const PgDevJob *jobs);
 __global__ void pg_trace_compose(const PgDevJob *jobs);
@@ -147,6 +147,7 @@ struct pagan_batch {
     PgDevJob *d_jobs = nullptr;
     int *d_which = nullptr;      // [n]: ring-kernel jobs first, then the wide ones
     int n_ring = 0, n_wide = 0;
+    int n_ring_small = 0;        // ring jobs whose model table fits the LDS cache (listed first)
     int max_bound = 0;           // largest traceback boundary count of any job
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -222,6 +223,7 @@ void carve_job(Carver &c, const pagan_job &jb, const HostJob &hj, PgDevJob *d) {
     d->srcR = c.take<int>(nbR); d->lwR = c.take<float>(nbR);
     d->table = c.take<float>((size_t)d->S * d->S);
     d->imin = c.take<int>(d->nd); d->imax = c.take<int>(d->nd); d->doff = c.take<long long>(d->nd);
+    d->dsc = c.take<int>(4 * (size_t)d->nd);
     d->cells = hj.dx.cells;
     d->n_bound = hj.n_bound;
     d->tb = c.take<int>(hj.tb.size());
@@ -244,12 +246,19 @@ int launch_fill(pagan_batch *b) {
     if (b->n_ring > 0) {
         static bool lds_set = false;      // > 64 KB of dynamic LDS has to be opted into once per process
         if (!lds_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_ring),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_ring<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_ring_lds_bytes()));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_ring<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_ring_lds_bytes()));
             lds_set = true;
         }
-        hipLaunchKernelGGL(pg_fill_ring, dim3(b->n_ring), dim3(320), pg_ring_lds_bytes(), b->stream, b->d_jobs,
-                           b->d_which, b->flags);
+        // model tables of <= 16 states (DNA: 15) are cached in LDS; larger ones stay in HBM/L2
+        if (b->n_ring_small > 0)
+            hipLaunchKernelGGL(pg_fill_ring<true>, dim3(b->n_ring_small), dim3(320), pg_ring_lds_bytes(), b->stream,
+                               b->d_jobs, b->d_which, b->flags);
+        if (b->n_ring > b->n_ring_small)
+            hipLaunchKernelGGL(pg_fill_ring<false>, dim3(b->n_ring - b->n_ring_small), dim3(320), pg_ring_lds_bytes(),
+                               b->stream, b->d_jobs, b->d_which + b->n_ring_small, b->flags);
     }
     if (b->n_wide > 0) {
         dim3 grid(b->n_wide);
@@ -415,17 +424,22 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     b->dj.resize(n);
     int max_w = 0;
     const bool force_v1 = std::getenv("PAGAN_DP_FORCE_GLOBAL_WAVEFRONT") != nullptr;   // A/B switch for profiling
-    std::vector<int> which_ring, which_wide;
+    std::vector<int> which_ring, which_ring_big, which_wide;
     for (int k = 0; k < n; ++k) {
         RowBand rb;
         int rc = validate_job(jobs[k], &b->jobs[k], &rb);
         if (rc != PAGAN_OK) return rc;
         b->cells += b->jobs[k].dx.cells;
         if (b->jobs[k].n_bound > b->max_bound) b->max_bound = b->jobs[k].n_bound;
-        if (b->jobs[k].ring_ok && !force_v1) { which_ring.push_back(k); continue; }
+        if (b->jobs[k].ring_ok && !force_v1) {
+            (jobs[k].model->n_states <= 16 ? which_ring : which_ring_big).push_back(k);
+            continue;
+        }
         which_wide.push_back(k);
         if (b->jobs[k].dx.max_width > max_w) max_w = b->jobs[k].dx.max_width;
     }
+    b->n_ring_small = (int)which_ring.size();
+    which_ring.insert(which_ring.end(), which_ring_big.begin(), which_ring_big.end());
     b->n_ring = (int)which_ring.size(); b->n_wide = (int)which_wide.size();
     which_ring.insert(which_ring.end(), which_wide.begin(), which_wide.end());
     b->block = max_w <= 64 ? 64 : (max_w <= 512 ? 256 : 1024);
@@ -456,6 +470,14 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         put(stage, d.imin, hj.dx.imin.data(), hj.dx.imin.size());
         put(stage, d.imax, hj.dx.imax.data(), hj.dx.imax.size());
         put(stage, d.doff, hj.dx.doff.data(), hj.dx.doff.size());
+        {
+            std::vector<int> packed(4 * hj.dx.imin.size());
+            for (size_t t = 0; t < hj.dx.imin.size(); ++t) {
+                packed[4 * t] = hj.dx.imin[t]; packed[4 * t + 1] = hj.dx.imax[t];
+                packed[4 * t + 2] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[4 * t + 3] = (int)(hj.dx.doff[t] >> 32);
+            }
+            put(stage, d.dsc, packed.data(), packed.size());
+        }
         put(stage, d.tb, hj.tb.data(), hj.tb.size());
     }
     b->trace_off.resize(n); b->end_off.resize(n); b->score_off.resize(n);
@@ -468,7 +490,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         b->score_off[k] = reinterpret_cast<size_t>(d.endscore);
         rebase(d.stL); rebase(d.offL); rebase(d.srcL); rebase(d.lwL);
         rebase(d.stR); rebase(d.offR); rebase(d.srcR); rebase(d.lwR);
-        rebase(d.table); rebase(d.imin); rebase(d.imax); rebase(d.doff); rebase(d.tb);
+        rebase(d.table); rebase(d.imin); rebase(d.imax); rebase(d.doff); rebase(d.tb); rebase(d.dsc);
         rebase(d.sc); rebase(d.bp);
         rebase(d.trace); rebase(d.endcell); rebase(d.endscore); rebase(d.segs); rebase(d.ttab);
     }

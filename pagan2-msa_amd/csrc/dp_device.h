@@ -47,6 +47,7 @@ struct PgDevJob {
     // band in diagonal form
     const int *imin, *imax;
     const long long *doff;
+    const int *dsc;          // [nd][4] = imin, imax, doff low, doff high: one 16-byte scalar load per diagonal
     long long cells;
     // outputs
     double *sc;              // [cells][3], state index = PAGAN_X_MAT / Y_MAT / M_MAT

@@ -44,6 +44,10 @@ typedef PG_GLOBAL const long long *gll_p;
 typedef PG_GLOBAL double *gdouble_w;
 typedef PG_GLOBAL unsigned *gu32_w;
 typedef PG_GLOBAL int *gint_w;
+typedef int pg_i4 __attribute__((ext_vector_type(4)));
+// read-only for the whole kernel and indexed uniformly: constant address space, so hipcc uses
+// s_load (scalar cache, lgkmcnt) instead of a vector load that would queue behind the stores
+typedef __attribute__((address_space(4))) const pg_i4 *cdesc_p;
 
 // Job descriptor flattened to scalars (SGPRs): no arrays, never address-taken.
 struct View {
@@ -52,7 +56,7 @@ struct View {
     gint_p stL, offL, srcL; gfloat_p lwL;
     gint_p stR, offR, srcR; gfloat_p lwR;
     gfloat_p table;
-    gint_p imin, imax; gll_p doff;
+    gint_p imin, imax; gll_p doff; cdesc_p dsc;
     gdouble_w sc;            // [cells][3]  X, Y, M
     gu32_w bp;               // [cells][3]
     gint_w trace, endcell; gdouble_w endscore;
@@ -65,7 +69,7 @@ __device__ __forceinline__ View load_view(const PgDevJob *__restrict__ j) {
     v.go = j->go; v.ge = j->ge; v.gE = j->gE; v.ng = j->ng;
     v.stL = (gint_p)j->stL; v.offL = (gint_p)j->offL; v.srcL = (gint_p)j->srcL; v.lwL = (gfloat_p)j->lwL;
     v.stR = (gint_p)j->stR; v.offR = (gint_p)j->offR; v.srcR = (gint_p)j->srcR; v.lwR = (gfloat_p)j->lwR;
-    v.table = (gfloat_p)j->table; v.imin = (gint_p)j->imin; v.imax = (gint_p)j->imax; v.doff = (gll_p)j->doff;
+    v.table = (gfloat_p)j->table; v.imin = (gint_p)j->imin; v.imax = (gint_p)j->imax; v.doff = (gll_p)j->doff; v.dsc = (cdesc_p)j->dsc;
     v.sc = (gdouble_w)j->sc; v.bp = (gu32_w)j->bp;
     v.trace = (gint_w)j->trace; v.endcell = (gint_w)j->endcell; v.endscore = (gdouble_w)j->endscore;
     v.n_bound = j->n_bound; v.tb = (gint_p)j->tb; v.ttab = (gint_w)j->ttab; v.segs = (gint_w)j->segs;
@@ -219,16 +223,21 @@ template __global__ void pg_fill_wavefront<1024>(const PgDevJob *, const int *, 
 //   - scores and back-pointers stream to HBM with coalesced stores nobody waits for: the
 //     compute waves issue NO vector-memory load in the steady state (vmcnt returns in order,
 //     a load would stall on every store still in flight -- measured 5.6 us per diagonal);
+//   - every thread writes its slot of the diagonal's ring row -- scores inside the band, -inf
+//     outside -- so reading a predecessor needs no band test, only "is that diagonal resident";
 //   - a wave whose cells are all "simple" (both sites have one bwd edge, from the
 //     predecessor site, weight 1) runs straight-line code: three 24-byte LDS reads, nine
 //     candidates; otherwise each lane walks its (left edge, right edge) pairs in the
 //     reference's order;
 //   - a graph edge reaching >= RK diagonals back reads HBM (L1-bypassing loads); every wave
 //     drains its stores once per RK/2 diagonals, so a cell that old has landed;
-//   - a diagonal wider than NT (a box between distant anchors) is computed from HBM operands
+//   - a diagonal wider than NTW (a box between distant anchors) is computed from HBM operands
 //     between two full drains and marked "not in the ring".
 #define NW 4
 #define NT (64 * NW)
+// widest diagonal kept in the ring: leaves RK rows of slack on either side of the NT-slot window so
+// that a predecessor row just outside an older diagonal's band can never alias a row inside it
+#define NTW (NT - 16)
 #define RK 16
 #define RW 512
 #define EC 2048
@@ -239,12 +248,10 @@ template __global__ void pg_fill_wavefront<1024>(const PgDevJob *, const int *, 
 
 struct RingSmem {
     double sc[RK][NT][3];                   // X, Y, M
-    int dmn[RK], dmx[RK], did[RK];          // per slot: band interval and WHICH diagonal it holds (-1: none)
     int stL[RW], ebL[RW], eeL[RW];
     int stR[RW], ebR[RW], eeR[RW];
     int esL[EC]; float ewL[EC];
     int esR[EC]; float ewR[EC];
-    int dlo[DR], dhi[DR]; long long dbase[DR];
     float table[256];
 };
 
@@ -285,23 +292,21 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Scores of cell (p,q) on an earlier diagonal; -inf outside the tunnel.  Branch-light: the slot's
-// descriptor and scores are read unconditionally (the slot always exists) and selected
-// afterwards; only a cell that is not in the ring takes the (rare) HBM branch.
-__device__ __forceinline__ void ring_load(const View &J, int d, int p, int q, double &xs, double &ys, double &ms) {
-    const double NI = neg_inf();
+// Scores of cell (p,q) on an earlier diagonal; -inf outside the tunnel.  Every slot of a resident
+// ring row is valid -- threads outside the band write -inf into theirs -- so a resident cell is
+// three LDS reads with no band test.  `resident` has bit (dd % RK) set when diagonal dd (one of
+// the last RK-1) went through the ring; anything else is read back from HBM.
+__device__ __forceinline__ void ring_load(const View &J, int d, unsigned resident, int p, int q,
+                                          double &xs, double &ys, double &ms) {
     const int dd = p + q, slot = dd & (RK - 1);
-    const int id = SM.did[slot], mn = SM.dmn[slot], mx = SM.dmx[slot];
-    const double rx = SM.sc[slot][p & (NT - 1)][PG_X];
-    const double ry = SM.sc[slot][p & (NT - 1)][PG_Y];
-    const double rm = SM.sc[slot][p & (NT - 1)][PG_M];
-    // Resident = the slot still names diagonal dd AND dd is younger than the ring is deep: at age
-    // RK the slot is the one the current diagonal is being written into by other lanes and waves.
-    const bool ring = id == dd && d - dd < RK;
-    const bool ok = ring && p >= mn && p <= mx;
-    xs = ok ? rx : NI; ys = ok ? ry : NI; ms = ok ? rm : NI;
-    if (!ring) {
+    if (d - dd < RK && ((resident >> slot) & 1u)) {
+        xs = SM.sc[slot][p & (NT - 1)][PG_X];
+        ys = SM.sc[slot][p & (NT - 1)][PG_Y];
+        ms = SM.sc[slot][p & (NT - 1)][PG_M];
+    } else {
         // left the ring (edge reaching >= RK diagonals back) or never entered it (wide diagonal)
+        const double NI = neg_inf();
+        xs = NI; ys = NI; ms = NI;
         const int fmn = far_i32(J.imin + dd), fmx = far_i32(J.imax + dd);
         if (p >= fmn && p <= fmx) {
             const long long ix = far_i64(J.doff + dd) + (p - fmn);
@@ -310,11 +315,56 @@ __device__ __forceinline__ void ring_load(const View &J, int d, int p, int q, do
     }
 }
 
-// ---- loader wave -------------------------------------------------------------------------
-__device__ __forceinline__ void load_diag_chunk(const View &J, int first, int lane) {
-    const int dd = first + lane;
-    if (dd < J.nd) { SM.dlo[dd & (DR - 1)] = J.imin[dd]; SM.dhi[dd & (DR - 1)] = J.imax[dd]; SM.dbase[dd & (DR - 1)] = J.doff[dd]; }
+// Resident cell read with no residency test of its own (the caller established it): scores of
+// (p,q), or -inf when `has` is false (a site's missing second edge).
+__device__ __forceinline__ void ring_cell(int p, int q, bool has, double &xs, double &ys, double &ms) {
+    const int slot = (p + q) & (RK - 1);
+    const double rx = SM.sc[slot][p & (NT - 1)][PG_X];
+    const double ry = SM.sc[slot][p & (NT - 1)][PG_Y];
+    const double rm = SM.sc[slot][p & (NT - 1)][PG_M];
+    const double NI = neg_inf();
+    xs = has ? rx : NI; ys = has ? ry : NI; ms = has ? rm : NI;
 }
+
+// True when every active lane of the wave can take the straight-line two-edge path: both sites
+// have one or two bwd edges and every predecessor diagonal they reach is resident in the ring.
+__device__ __forceinline__ bool dual_ok(int d, unsigned resident, bool active, int i, int j) {
+    bool ok = true;
+    if (active) {
+        const int l0 = SM.ebL[i & (RW - 1)], nL = SM.eeL[i & (RW - 1)] - l0;
+        const int r0 = SM.ebR[j & (RW - 1)], nR = SM.eeR[j & (RW - 1)] - r0;
+        ok = nL >= 1 && nL <= 2 && nR >= 1 && nR <= 2;
+        if (ok) {
+            const int pa = SM.esL[l0 & (EC - 1)], pb = nL == 2 ? SM.esL[(l0 + 1) & (EC - 1)] : pa;
+            const int qa = SM.esR[r0 & (EC - 1)], qb = nR == 2 ? SM.esR[(r0 + 1) & (EC - 1)] : qa;
+            const int pm_ = pa < pb ? pa : pb, qm_ = qa < qb ? qa : qb;      // the farthest predecessors
+            // oldest diagonal touched is pm_ + qm_; every diagonal from there to d-1 must be resident
+            const int age = d - (pm_ + qm_);
+            ok = age < RK;
+            if (ok) {
+                // bits of the slots of diagonals d-age .. d-1 (a contiguous run, modulo RK)
+                const unsigned run = ((1u << age) - 1u);
+                const int first = (d - age) & (RK - 1);
+                const unsigned need = ((run << first) | (run >> (RK - first))) & ((1u << RK) - 1u);
+                ok = (resident & need) == need;
+            }
+        }
+    }
+    return __all(ok);
+}
+
+// First-wins maximum of three candidates (first_is_bigger, basic_alignment.h:449-462, applied in
+// candidate order to an incumbent of -inf): the value is the plain maximum, the winner is the
+// first candidate equal to it, and nobody wins when all three are -inf.
+__device__ __forceinline__ double first_max3(double c1, double c2, double c3, unsigned f1, unsigned f2, unsigned f3,
+                                             unsigned &bp) {
+    const double m23 = c2 > c3 ? c2 : c3;
+    const double m = c1 > m23 ? c1 : m23;          // no NaNs on this path, so this is max()
+    bp = (m == neg_inf()) ? PG_BP_NONE : (c1 == m ? f1 : (c2 == m ? f2 : f3));
+    return m;
+}
+
+// ---- loader wave -------------------------------------------------------------------------
 __device__ __forceinline__ void load_site_chunk(int first, int lane, int n, gint_p st, gint_p off, gint_p src, gfloat_p lw,
                                                 int *cst, int *ceb, int *cee, int *ces, float *cew) {
     const int r = first + lane;
@@ -329,8 +379,28 @@ __device__ __forceinline__ void load_site_chunk(int first, int lane, int n, gint
     for (int e = e0 + lane; e < e1; e += 64) { ces[e & (EC - 1)] = src[e]; cew[e & (EC - 1)] = lw[e]; }
 }
 
+// everything diagonal `dn` needs from the site/edge windows
+__device__ __forceinline__ void loader_prepare(const View &J, int dn, int lane, int &rows, int &cols) {
+    const pg_i4 ds = J.dsc[dn];
+    const int lo = ds.x, hi = ds.y;
+    if (hi - lo + 1 > NTW) return;                                // wide diagonals read HBM
+    bool any = false;
+    while (hi >= rows && rows < J.Lx) { load_site_chunk(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL, SM.stL, SM.ebL, SM.eeL, SM.esL, SM.ewL); rows += 64; any = true; }
+    while (dn - lo >= cols && cols < J.Ly) { load_site_chunk(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR, SM.stR, SM.ebR, SM.eeR, SM.esR, SM.ewR); cols += 64; any = true; }
+    if (any) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 } // namespace
 
+#ifdef PG_STAMPS
+// Diagnostic build only (tools/build_stamps.sh): s_memtime stamps accumulated per wave and written
+// to the tail of the (still unused) trace buffer.  Never compiled into the shipped library.
+#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#else
+#define STAMP(var)
+#endif
+
+template <bool TAB_LDS>
 __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restrict__ jobs, const int *__restrict__ which,
                                                         unsigned flags) {
     const View J = load_view(jobs + which[blockIdx.x]);
@@ -338,67 +408,72 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
     const bool reduced_terminal = !(flags & 2u);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const bool tab_lds = J.S <= 16;
-    if (tab_lds) for (int k = tid; k < J.S * J.S; k += NT + 64) SM.table[k] = J.table[k];
-    for (int k = tid; k < RK; k += NT + 64) { SM.dmn[k] = 0; SM.dmx[k] = -1; SM.did[k] = -1; }
+    if (TAB_LDS) for (int k = tid; k < J.S * J.S; k += NT + 64) SM.table[k] = J.table[k];
 
     if (tid >= NT) {
         // ================= loader wave: stays one diagonal ahead of the compute waves =================
-        int rows = 0, cols = 0, diags = 0;
-        load_diag_chunk(J, 0, lane); diags = 64;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        {   // everything diagonal 0 needs
-            const int lo = SM.dlo[0], hi = SM.dhi[0];
-            if (hi - lo + 1 <= NT) {
-                while (hi >= rows && rows < J.Lx) { load_site_chunk(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL, SM.stL, SM.ebL, SM.eeL, SM.esL, SM.ewL); rows += 64; }
-                while (0 - lo >= cols && cols < J.Ly) { load_site_chunk(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR, SM.stR, SM.ebR, SM.eeR, SM.esR, SM.ewR); cols += 64; }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int rows = 0, cols = 0;
+        loader_prepare(J, 0, lane, rows, cols);
         lds_barrier();                                            // (B0) compute may start diagonal 0
+#ifdef PG_STAMPS
+        unsigned long long lw = 0, lb = 0;
+#endif
         for (int d = 0; d < J.nd; ++d) {
-            const bool wide = SM.dhi[d & (DR - 1)] - SM.dlo[d & (DR - 1)] + 1 > NT;
-            if (wide) lds_barrier();                              // (Bw) mirrors the compute waves' drain barrier
-            const int dn = d + 1;
-            if (dn < J.nd) {
-                if (dn >= diags) { load_diag_chunk(J, diags, lane); diags += 64; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
-                const int lo = SM.dlo[dn & (DR - 1)], hi = SM.dhi[dn & (DR - 1)];
-                if (hi - lo + 1 <= NT) {
-                    while (hi >= rows && rows < J.Lx) { load_site_chunk(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL, SM.stL, SM.ebL, SM.eeL, SM.esL, SM.ewL); rows += 64; }
-                    while (dn - lo >= cols && cols < J.Ly) { load_site_chunk(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR, SM.stR, SM.ebR, SM.eeR, SM.esR, SM.ewR); cols += 64; }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-            }
+            STAMP(t0);
+            const pg_i4 ds = J.dsc[d];
+            if (ds.y - ds.x + 1 > NTW) lds_barrier();             // (Bw) mirrors the compute waves' drain barrier
+            if (d + 1 < J.nd) loader_prepare(J, d + 1, lane, rows, cols);
+            STAMP(t1);
             lds_barrier();                                        // (Bd) end of diagonal d
+#ifdef PG_STAMPS
+            { STAMP(t2); lw += t1 - t0; lb += t2 - t1; }
+#endif
         }
+#ifdef PG_STAMPS
+        if (lane == 0) { PG_GLOBAL unsigned long long *o = (PG_GLOBAL unsigned long long *)(J.trace + 3 * (J.Lx + J.Ly) - 80); o[32] = lw; o[33] = lb; }
+#endif
         return;
     }
 
     // ================= compute waves =================
     const double NI = neg_inf();
-    int mn1 = 0, mx1 = -1, mn2 = 0, mx2 = -1;
-    bool in1 = false, in2 = false;
-    Diag g1 = {0, -1, 0}, g2 = {0, -1, 0};
-    const double go = (double)J.go, ng = (double)J.ng;
+    const double go = (double)J.go, ng = (double)J.ng, ge = (double)J.ge;
     const double tng2 = (double)(2 * J.ng), tng1 = (double)(0.0f + J.ng);
+    unsigned resident = 0;                                        // bit (dd % RK): diagonal dd is in the ring
+    pg_i4 nxt = J.dsc[0];
     lds_barrier();                                                // (B0)
+#ifdef PG_STAMPS
+    unsigned long long acc[2][4] = {};      // [wave had active cells?][steps, head, work, barrier]
+#endif
     for (int d = 0; d < J.nd; ++d) {
-        const int lo = SM.dlo[d & (DR - 1)], hi = SM.dhi[d & (DR - 1)];
-        const long long base = SM.dbase[d & (DR - 1)];
-        const bool wide = hi - lo + 1 > NT;
+        STAMP(t0);
+        const pg_i4 cur = nxt;
+        nxt = J.dsc[d + 1 < J.nd ? d + 1 : d];                    // scalar prefetch for the next step
+        const int lo = cur.x, hi = cur.y;
+        const long long base = ((long long)cur.w << 32) | (unsigned)cur.z;
+        const bool wide = hi - lo + 1 > NTW;
+        const unsigned slot_bit = 1u << (d & (RK - 1));
+        STAMP(t1);
+        bool had = false;
         if (wide) {
             // rare: a box between anchors wider than the ring.  Every wave drains its stores, then all
             // cells are computed from HBM/L2 operands, then drained again so that later diagonals
             // (which find "not in the ring") read landed data.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();                                        // (Bw)
+            const pg_i4 p1 = J.dsc[d > 0 ? d - 1 : 0], p2 = J.dsc[d > 1 ? d - 2 : 0];
+            const Diag g1 = {p1.x, d > 0 ? p1.y : p1.x - 1, ((long long)p1.w << 32) | (unsigned)p1.z};
+            const Diag g2 = {p2.x, d > 1 ? p2.y : p2.x - 1, ((long long)p2.w << 32) | (unsigned)p2.z};
             for (int i = lo + tid; i <= hi; i += NT)
                 fill_cell_hbm(J, d, g1, g2, i, d - i, base + (i - lo), no_terminal_edges, reduced_terminal);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            resident &= ~slot_bit;
         } else {
-            const int i = lo + ((tid - lo) & (NT - 1));
+            const int off = (tid - lo) & (NT - 1);                // position of this thread's row in the band
+            const int i = lo + off;
             const int j = d - i;
             const bool active = i <= hi;
+            had = __any(active);
             int wi = 0, wj = 0;
             bool simple = true;
             if (active) {
@@ -407,39 +482,76 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
             }
             double bx = NI, by = NI, bm = NI;
             unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
-            if (in1 && in2 && __all(simple)) {
-                // ---- every cell of this wave is simple: straight-line code ----
+            // interior: no first/last row or column on this diagonal, so every gap extension is the
+            // normal one and every gap open pays the full penalty (BA.h:490-513, VA:864-879)
+            const bool interior = lo >= 2 && hi <= J.Lx - 2 && d - hi >= 2 && d - lo <= J.Ly - 2;
+            const unsigned prev2 = (1u << ((d - 1) & (RK - 1))) | (1u << ((d - 2) & (RK - 1)));
+            if ((resident & prev2) == prev2 && interior && __all(simple)) {
+                // ---- every cell of this wave is simple: straight-line code, no band tests ----
                 if (active) {
-                    const int s1 = (d - 1) & (RK - 1), s2 = (d - 2) & (RK - 1);
-                    const bool inA = i - 1 >= mn1 && i - 1 <= mx1;       // (i-1, j)   on d-1
-                    const bool inB = i >= mn1 && i <= mx1;               // (i, j-1)   on d-1
-                    const bool inC = i - 1 >= mn2 && i - 1 <= mx2;       // (i-1, j-1) on d-2
-                    const double *A = SM.sc[s1][(i - 1) & (NT - 1)];
-                    const double *B = SM.sc[s1][i & (NT - 1)];
-                    const double *Cc = SM.sc[s2][(i - 1) & (NT - 1)];
-                    const double a0 = A[PG_X], a1 = A[PG_Y], a2 = A[PG_M];
-                    const double b0 = B[PG_X], b1 = B[PG_Y], b2 = B[PG_M];
-                    const double c0 = Cc[PG_X], c1 = Cc[PG_Y], c2 = Cc[PG_M];
-                    const double xA = inA ? a0 : NI, yA = inA ? a1 : NI, mA = inA ? a2 : NI;
-                    const double xB = inB ? b0 : NI, yB = inB ? b1 : NI, mB = inB ? b2 : NI;
-                    const double xC = inC ? c0 : NI, yC = inC ? c1 : NI, mC = inC ? c2 : NI;
+                    const double *A = SM.sc[(d - 1) & (RK - 1)][(i - 1) & (NT - 1)];   // (i-1, j)   on d-1
+                    const double *B = SM.sc[(d - 1) & (RK - 1)][i & (NT - 1)];         // (i, j-1)   on d-1
+                    const double *Cc = SM.sc[(d - 2) & (RK - 1)][(i - 1) & (NT - 1)];  // (i-1, j-1) on d-2
+                    const double xA = A[PG_X], yA = A[PG_Y], mA = A[PG_M];
+                    const double xB = B[PG_X], yB = B[PG_Y], mB = B[PG_M];
+                    const double xC = Cc[PG_X], yC = Cc[PG_Y], mC = Cc[PG_M];
                     const int ti = (wi & 0xffff) + (wj & 0xffff) * J.S;
-                    const float smf = tab_lds ? SM.table[ti] : far_f32(J.table + ti);
-                    const double extX = (double)((j == J.Ly - 1 && !no_terminal_edges) ? J.gE : J.ge);
-                    const double extY = (double)((i == J.Lx - 1 && !no_terminal_edges) ? J.gE : J.ge);
-                    const double openX = (reduced_terminal && i == 1) ? 0.0 : go;
-                    const double openY = (reduced_terminal && j == 1) ? 0.0 : go;
-                    double c;
-                    c = xA + extX;          if (c > bx) { bx = c; px = PG_X | PG_BP_ADJL; }
-                    c = (yA + 0.0) + go;    if (c > bx) { bx = c; px = PG_Y | PG_BP_ADJL; }
-                    c = (mA + ng) + openX;  if (c > bx) { bx = c; px = PG_M | PG_BP_ADJL; }
-                    c = yB + extY;          if (c > by) { by = c; py = PG_Y | PG_BP_ADJR; }
-                    c = (xB + 0.0) + go;    if (c > by) { by = c; py = PG_X | PG_BP_ADJR; }
-                    c = (mB + ng) + openY;  if (c > by) { by = c; py = PG_M | PG_BP_ADJR; }
+                    const float smf = TAB_LDS ? SM.table[ti] : far_f32(J.table + ti);
                     const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
-                    c = mC + tM;            if (c > bm) { bm = c; pm = PG_M | PG_BP_ADJL | PG_BP_ADJR; }     // + 0.0 + 0.0 (log-weights) omitted: exact
-                    c = xC + tX;            if (c > bm) { bm = c; pm = PG_X | PG_BP_ADJL | PG_BP_ADJR; }
-                    c = yC + tX;            if (c > bm) { bm = c; pm = PG_Y | PG_BP_ADJL | PG_BP_ADJR; }
+                    // `+ 0.0` (log_gap_close, unit edge weights) is omitted: exact, no score is ever -0.0
+                    bx = first_max3(xA + ge, yA + go, (mA + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
+                    by = first_max3(yB + ge, xB + go, (mB + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
+                    bm = first_max3(mC + tM, xC + tX, yC + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
+                                    PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
+                }
+            } else if (interior && dual_ok(d, resident, active, i, j)) {
+                // ---- every site of this wave has one or two bwd edges and every predecessor is in the
+                // ring: straight-line code over the (at most) 2 x 2 edge pairs, a missing second edge
+                // contributing -inf candidates.  Same candidate order as the loop below.
+                if (active) {
+                    const int l0 = SM.ebL[i & (RW - 1)], r0 = SM.ebR[j & (RW - 1)];
+                    const bool hasLb = SM.eeL[i & (RW - 1)] - l0 == 2, hasRb = SM.eeR[j & (RW - 1)] - r0 == 2;
+                    const int pa = SM.esL[l0 & (EC - 1)], pb = hasLb ? SM.esL[(l0 + 1) & (EC - 1)] : pa;
+                    const int qa = SM.esR[r0 & (EC - 1)], qb = hasRb ? SM.esR[(r0 + 1) & (EC - 1)] : qa;
+                    const double lwa = (double)SM.ewL[l0 & (EC - 1)], lwb = (double)SM.ewL[(l0 + 1) & (EC - 1)];
+                    const double rwa = (double)SM.ewR[r0 & (EC - 1)], rwb = (double)SM.ewR[(r0 + 1) & (EC - 1)];
+                    const int ti = (wi & 0xffff) + (wj & 0xffff) * J.S;
+                    const float smf = TAB_LDS ? SM.table[ti] : far_f32(J.table + ti);
+                    const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
+                    double xs, ys, ms, c;
+                    // X: left edge a, then b
+                    ring_cell(pa, j, true, xs, ys, ms);
+                    { const double open = (reduced_terminal && pa == 0) ? 0.0 : go; const bool adj = pa == i - 1;
+                      c = xs + ge;            if (c > bx) { bx = c; px = pack_bp(PG_X, 0, 0, adj, false); }
+                      c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, 0, 0, adj, false); }
+                      c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, 0, 0, adj, false); } }
+                    ring_cell(pb, j, hasLb, xs, ys, ms);
+                    { const double open = (reduced_terminal && pb == 0) ? 0.0 : go; const bool adj = pb == i - 1;
+                      c = xs + ge;            if (c > bx) { bx = c; px = pack_bp(PG_X, 1, 0, adj, false); }
+                      c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, 1, 0, adj, false); }
+                      c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, 1, 0, adj, false); } }
+                    // Y: right edge a, then b
+                    ring_cell(i, qa, true, xs, ys, ms);
+                    { const double open = (reduced_terminal && qa == 0) ? 0.0 : go; const bool adj = qa == j - 1;
+                      c = ys + ge;            if (c > by) { by = c; py = pack_bp(PG_Y, 0, 0, false, adj); }
+                      c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, 0, false, adj); }
+                      c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, 0, false, adj); } }
+                    ring_cell(i, qb, hasRb, xs, ys, ms);
+                    { const double open = (reduced_terminal && qb == 0) ? 0.0 : go; const bool adj = qb == j - 1;
+                      c = ys + ge;            if (c > by) { by = c; py = pack_bp(PG_Y, 0, 1, false, adj); }
+                      c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, 1, false, adj); }
+                      c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, 1, false, adj); } }
+                    // M: (a,a) (a,b) (b,a) (b,b)
+#define PG_DUAL_M(P, Q, K1, K2, LW, RW, HAS)                                                                         \
+                    ring_cell(P, Q, HAS, xs, ys, ms);                                                                \
+                    c = ((ms + tM) + LW) + RW;  if (c > bm) { bm = c; pm = pack_bp(PG_M, K1, K2, P == i - 1, Q == j - 1); } \
+                    c = ((xs + tX) + LW) + RW;  if (c > bm) { bm = c; pm = pack_bp(PG_X, K1, K2, P == i - 1, Q == j - 1); } \
+                    c = ((ys + tX) + LW) + RW;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, K1, K2, P == i - 1, Q == j - 1); }
+                    PG_DUAL_M(pa, qa, 0, 0, lwa, rwa, true)
+                    PG_DUAL_M(pa, qb, 0, 1, lwa, rwb, hasRb)
+                    PG_DUAL_M(pb, qa, 1, 0, lwb, rwa, hasLb)
+                    PG_DUAL_M(pb, qb, 1, 1, lwb, rwb, hasLb && hasRb)
+#undef PG_DUAL_M
                 }
             } else {
                 // ---- general: each lane walks its (left edge, right edge) pairs row-major, which visits
@@ -454,7 +566,7 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
                     else n_items = (nL > 0 ? nL : 1) * (nR > 0 ? nR : 1);
                     if (nL > 0 && nR > 0) {
                         const int ti = (wi & 0xffff) + (wj & 0xffff) * J.S;
-                        const float smf = tab_lds ? SM.table[ti] : far_f32(J.table + ti);
+                        const float smf = TAB_LDS ? SM.table[ti] : far_f32(J.table + ti);
                         tM = tng2 + (double)smf; tX = tng1 + (double)smf;
                     }
                     extX = (double)(((j == 0 || j == J.Ly - 1) && !no_terminal_edges) ? J.gE : J.ge);
@@ -469,21 +581,21 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
                         if (nL > 0) { p = SM.esL[(l0 + k1) & (EC - 1)]; lw = (double)SM.ewL[(l0 + k1) & (EC - 1)]; }
                         if (nR > 0) { q = SM.esR[(r0 + k2) & (EC - 1)]; rw = (double)SM.ewR[(r0 + k2) & (EC - 1)]; }
                         if (nL > 0 && k2 == 0) {                                     // X candidates of left edge k1
-                            ring_load(J, d, p, j, xs, ys, ms);
+                            ring_load(J, d, resident, p, j, xs, ys, ms);
                             const double open = (reduced_terminal && p == 0) ? 0.0 : go;
                             c = xs + extX;          if (c > bx) { bx = c; px = pack_bp(PG_X, k1, 0, p == i - 1, false); }
                             c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, k1, 0, p == i - 1, false); }
                             c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, k1, 0, p == i - 1, false); }
                         }
                         if (nR > 0 && k1 == 0) {                                     // Y candidates of right edge k2
-                            ring_load(J, d, i, q, xs, ys, ms);
+                            ring_load(J, d, resident, i, q, xs, ys, ms);
                             const double open = (reduced_terminal && q == 0) ? 0.0 : go;
                             c = ys + extY;          if (c > by) { by = c; py = pack_bp(PG_Y, 0, k2, false, q == j - 1); }
                             c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, k2, false, q == j - 1); }
                             c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, k2, false, q == j - 1); }
                         }
                         if (nL > 0 && nR > 0) {                                      // M candidates of the pair
-                            ring_load(J, d, p, q, xs, ys, ms);
+                            ring_load(J, d, resident, p, q, xs, ys, ms);
                             c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_M, k1, k2, p == i - 1, q == j - 1); }
                             c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_X, k1, k2, p == i - 1, q == j - 1); }
                             c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, k1, k2, p == i - 1, q == j - 1); }
@@ -492,23 +604,34 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
                     }
                 }
             }
-            if (active) {
-                SM.sc[d & (RK - 1)][i & (NT - 1)][PG_X] = bx;
-                SM.sc[d & (RK - 1)][i & (NT - 1)][PG_Y] = by;
-                SM.sc[d & (RK - 1)][i & (NT - 1)][PG_M] = bm;
-                store_cell(J.sc, J.bp, base + (i - lo), bx, by, bm, px, py, pm);
-            }
+            // EVERY thread writes its slot of this diagonal's ring row (slot == thread id, since
+            // i = tid mod NT): the cell's scores inside the band, -inf outside it.
+            SM.sc[d & (RK - 1)][tid][PG_X] = bx;
+            SM.sc[d & (RK - 1)][tid][PG_Y] = by;
+            SM.sc[d & (RK - 1)][tid][PG_M] = bm;
+            if (active) store_cell(J.sc, J.bp, base + off, bx, by, bm, px, py, pm);
+            resident |= slot_bit;
         }
-        if (tid == 0) { SM.dmn[d & (RK - 1)] = lo; SM.dmx[d & (RK - 1)] = hi; SM.did[d & (RK - 1)] = wide ? -1 : d; }
-        mn2 = mn1; mx2 = mx1; in2 = in1; mn1 = lo; mx1 = hi; in1 = !wide;
-        g2 = g1; g1 = {lo, hi, base};
         // A cell read back from HBM (an edge reaching >= RK diagonals back) must have landed, whichever
         // wave stored it: every wave drains its stores once per RK/2 diagonals, so after the barriers
         // of the following diagonals nothing older than RK diagonals is still in flight.
         if ((d & (RK / 2 - 1)) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(t2);
         lds_barrier();                                            // (Bd)
+#ifdef PG_STAMPS
+        { STAMP(t3); const int h = had ? 1 : 0; acc[h][0] += 1; acc[h][1] += t1 - t0; acc[h][2] += t2 - t1; acc[h][3] += t3 - t2; }
+#endif
     }
+#ifdef PG_STAMPS
+    if (lane == 0) {
+        PG_GLOBAL unsigned long long *o = (PG_GLOBAL unsigned long long *)(J.trace + 3 * (J.Lx + J.Ly) - 80) + 8 * (tid >> 6);
+        for (int h = 0; h < 2; ++h) for (int m = 0; m < 4; ++m) o[4 * h + m] = acc[h][m];
+    }
+#endif
 }
+
+template __global__ void pg_fill_ring<true>(const PgDevJob *, const int *, unsigned);
+template __global__ void pg_fill_ring<false>(const PgDevJob *, const int *, unsigned);
 
 // ---------------------------------------------------------------------------------------------
 // End corner and traceback.
