@@ -193,6 +193,15 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb) {
             run += 3 * ((wa > 0 ? wa : 0) + (wb > 0 ? wb : 0));
         }
         hj->tb[hj->n_bound + 1] = run;
+        // The segmented traceback chases from EVERY cell of every boundary: worth it for a narrow
+        // band over a long path (2 x 100 kb: 1.3e5 chases of 256 cells against one chase of 2e5),
+        // wasteful for a short path through a full matrix (thousands of cells per boundary).  Fall
+        // back to the single serial chase (pg_trace_compose with no boundaries) in that case.
+        const long long speculative = (long long)run / 3 * PG_SEG, serial = (long long)hj->Lx + hj->Ly;
+        if (serial < 20000 || speculative > 2000 * serial) {
+            hj->n_bound = 0;
+            hj->tb.assign(2, 0);
+        }
     }
     hj->ring_ok = hj->dx.cells <= (long long)PG_RING_MAX_WIDTH * hj->dx.imin.size() / 2 &&
                   edges_fit_ring(jb.left, hj->Lx) && edges_fit_ring(jb.right, hj->Ly);

@@ -326,24 +326,24 @@ __device__ __forceinline__ void ring_cell(int p, int q, bool has, double &xs, do
     xs = has ? rx : NI; ys = has ? ry : NI; ms = has ? rm : NI;
 }
 
-// True when every active lane of the wave can take the straight-line two-edge path: both sites
-// have one or two bwd edges and every predecessor diagonal they reach is resident in the ring.
-__device__ __forceinline__ bool dual_ok(int d, unsigned resident, bool active, int i, int j) {
+// True when every active lane of the wave has at least one bwd edge on both sites and every
+// predecessor diagonal its edges reach is resident in the ring (so its item loop can read cells
+// with ring_cell, without per-read residency branches).
+__device__ __forceinline__ bool all_resident(int d, unsigned resident, bool active, int i, int j) {
     bool ok = true;
     if (active) {
         const int l0 = SM.ebL[i & (RW - 1)], nL = SM.eeL[i & (RW - 1)] - l0;
         const int r0 = SM.ebR[j & (RW - 1)], nR = SM.eeR[j & (RW - 1)] - r0;
-        ok = nL >= 1 && nL <= 2 && nR >= 1 && nR <= 2;
+        ok = nL >= 1 && nR >= 1 && nL <= 8 && nR <= 8;
         if (ok) {
-            const int pa = SM.esL[l0 & (EC - 1)], pb = nL == 2 ? SM.esL[(l0 + 1) & (EC - 1)] : pa;
-            const int qa = SM.esR[r0 & (EC - 1)], qb = nR == 2 ? SM.esR[(r0 + 1) & (EC - 1)] : qa;
-            const int pm_ = pa < pb ? pa : pb, qm_ = qa < qb ? qa : qb;      // the farthest predecessors
+            int pm_ = SM.esL[l0 & (EC - 1)], qm_ = SM.esR[r0 & (EC - 1)];      // the farthest predecessors
+            for (int k = 1; k < nL; ++k) { const int p = SM.esL[(l0 + k) & (EC - 1)]; pm_ = p < pm_ ? p : pm_; }
+            for (int k = 1; k < nR; ++k) { const int q = SM.esR[(r0 + k) & (EC - 1)]; qm_ = q < qm_ ? q : qm_; }
             // oldest diagonal touched is pm_ + qm_; every diagonal from there to d-1 must be resident
             const int age = d - (pm_ + qm_);
             ok = age < RK;
             if (ok) {
-                // bits of the slots of diagonals d-age .. d-1 (a contiguous run, modulo RK)
-                const unsigned run = ((1u << age) - 1u);
+                const unsigned run = ((1u << age) - 1u);                         // diagonals d-age .. d-1, modulo RK
                 const int first = (d - age) & (RK - 1);
                 const unsigned need = ((run << first) | (run >> (RK - first))) & ((1u << RK) - 1u);
                 ok = (resident & need) == need;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
 #endif
         }
 #ifdef PG_STAMPS
-        if (lane == 0) { PG_GLOBAL unsigned long long *o = (PG_GLOBAL unsigned long long *)(J.trace + 3 * (J.Lx + J.Ly) - 80); o[32] = lw; o[33] = lb; }
+        if (lane == 0) { PG_GLOBAL unsigned long long *o = (PG_GLOBAL unsigned long long *)(J.trace + 3 * (J.Lx + J.Ly) - 200); o[80] = lw; o[81] = lb; }
 #endif
         return;
     }
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
     pg_i4 nxt = J.dsc[0];
     lds_barrier();                                                // (B0)
 #ifdef PG_STAMPS
-    unsigned long long acc[2][4] = {};      // [wave had active cells?][steps, head, work, barrier]
+    unsigned long long acc[5][4] = {};      // [idle, fast, dual, general, wide][steps, head, work, barrier]
 #endif
     for (int d = 0; d < J.nd; ++d) {
         STAMP(t0);
@@ -454,8 +454,10 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
         const bool wide = hi - lo + 1 > NTW;
         const unsigned slot_bit = 1u << (d & (RK - 1));
         STAMP(t1);
-        bool had = false;
+        int kind = 0; (void)kind;
+        bool had = false; (void)had;
         if (wide) {
+            kind = 4;
             // rare: a box between anchors wider than the ring.  Every wave drains its stores, then all
             // cells are computed from HBM/L2 operands, then drained again so that later diagonals
             // (which find "not in the ring") read landed data.
@@ -487,6 +489,7 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
             const bool interior = lo >= 2 && hi <= J.Lx - 2 && d - hi >= 2 && d - lo <= J.Ly - 2;
             const unsigned prev2 = (1u << ((d - 1) & (RK - 1))) | (1u << ((d - 2) & (RK - 1)));
             if ((resident & prev2) == prev2 && interior && __all(simple)) {
+                kind = 1;
                 // ---- every cell of this wave is simple: straight-line code, no band tests ----
                 if (active) {
                     const double *A = SM.sc[(d - 1) & (RK - 1)][(i - 1) & (NT - 1)];   // (i-1, j)   on d-1
@@ -504,56 +507,52 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
                     bm = first_max3(mC + tM, xC + tX, yC + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
                                     PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
                 }
-            } else if (interior && dual_ok(d, resident, active, i, j)) {
-                // ---- every site of this wave has one or two bwd edges and every predecessor is in the
-                // ring: straight-line code over the (at most) 2 x 2 edge pairs, a missing second edge
-                // contributing -inf candidates.  Same candidate order as the loop below.
+            } else if (interior && all_resident(d, resident, active, i, j)) {
+                kind = 2;
+                // ---- multi-edge sites, every predecessor in the ring: each lane walks its (left edge,
+                // right edge) pairs row-major -- X candidates in left-list order, Y candidates in
+                // right-list order, M candidates in the reference's pair order (VA:1396-1433) -- with
+                // branch-free cell reads.
+                int l0 = 0, nL = 0, r0 = 0, nR = 1, n_items = 0;
+                double tM = 0, tX = 0;
                 if (active) {
-                    const int l0 = SM.ebL[i & (RW - 1)], r0 = SM.ebR[j & (RW - 1)];
-                    const bool hasLb = SM.eeL[i & (RW - 1)] - l0 == 2, hasRb = SM.eeR[j & (RW - 1)] - r0 == 2;
-                    const int pa = SM.esL[l0 & (EC - 1)], pb = hasLb ? SM.esL[(l0 + 1) & (EC - 1)] : pa;
-                    const int qa = SM.esR[r0 & (EC - 1)], qb = hasRb ? SM.esR[(r0 + 1) & (EC - 1)] : qa;
-                    const double lwa = (double)SM.ewL[l0 & (EC - 1)], lwb = (double)SM.ewL[(l0 + 1) & (EC - 1)];
-                    const double rwa = (double)SM.ewR[r0 & (EC - 1)], rwb = (double)SM.ewR[(r0 + 1) & (EC - 1)];
+                    l0 = SM.ebL[i & (RW - 1)]; nL = SM.eeL[i & (RW - 1)] - l0;
+                    r0 = SM.ebR[j & (RW - 1)]; nR = SM.eeR[j & (RW - 1)] - r0;
+                    n_items = nL * nR;
                     const int ti = (wi & 0xffff) + (wj & 0xffff) * J.S;
                     const float smf = TAB_LDS ? SM.table[ti] : far_f32(J.table + ti);
-                    const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
-                    double xs, ys, ms, c;
-                    // X: left edge a, then b
-                    ring_cell(pa, j, true, xs, ys, ms);
-                    { const double open = (reduced_terminal && pa == 0) ? 0.0 : go; const bool adj = pa == i - 1;
-                      c = xs + ge;            if (c > bx) { bx = c; px = pack_bp(PG_X, 0, 0, adj, false); }
-                      c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, 0, 0, adj, false); }
-                      c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, 0, 0, adj, false); } }
-                    ring_cell(pb, j, hasLb, xs, ys, ms);
-                    { const double open = (reduced_terminal && pb == 0) ? 0.0 : go; const bool adj = pb == i - 1;
-                      c = xs + ge;            if (c > bx) { bx = c; px = pack_bp(PG_X, 1, 0, adj, false); }
-                      c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, 1, 0, adj, false); }
-                      c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, 1, 0, adj, false); } }
-                    // Y: right edge a, then b
-                    ring_cell(i, qa, true, xs, ys, ms);
-                    { const double open = (reduced_terminal && qa == 0) ? 0.0 : go; const bool adj = qa == j - 1;
-                      c = ys + ge;            if (c > by) { by = c; py = pack_bp(PG_Y, 0, 0, false, adj); }
-                      c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, 0, false, adj); }
-                      c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, 0, false, adj); } }
-                    ring_cell(i, qb, hasRb, xs, ys, ms);
-                    { const double open = (reduced_terminal && qb == 0) ? 0.0 : go; const bool adj = qb == j - 1;
-                      c = ys + ge;            if (c > by) { by = c; py = pack_bp(PG_Y, 0, 1, false, adj); }
-                      c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, 1, false, adj); }
-                      c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, 1, false, adj); } }
-                    // M: (a,a) (a,b) (b,a) (b,b)
-#define PG_DUAL_M(P, Q, K1, K2, LW, RW, HAS)                                                                         \
-                    ring_cell(P, Q, HAS, xs, ys, ms);                                                                \
-                    c = ((ms + tM) + LW) + RW;  if (c > bm) { bm = c; pm = pack_bp(PG_M, K1, K2, P == i - 1, Q == j - 1); } \
-                    c = ((xs + tX) + LW) + RW;  if (c > bm) { bm = c; pm = pack_bp(PG_X, K1, K2, P == i - 1, Q == j - 1); } \
-                    c = ((ys + tX) + LW) + RW;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, K1, K2, P == i - 1, Q == j - 1); }
-                    PG_DUAL_M(pa, qa, 0, 0, lwa, rwa, true)
-                    PG_DUAL_M(pa, qb, 0, 1, lwa, rwb, hasRb)
-                    PG_DUAL_M(pb, qa, 1, 0, lwb, rwa, hasLb)
-                    PG_DUAL_M(pb, qb, 1, 1, lwb, rwb, hasLb && hasRb)
-#undef PG_DUAL_M
+                    tM = tng2 + (double)smf; tX = tng1 + (double)smf;
+                }
+                int k1 = 0, k2 = 0;
+                for (int t = 0; __any(t < n_items); ++t) {
+                    if (t < n_items) {
+                        const int p = SM.esL[(l0 + k1) & (EC - 1)], q = SM.esR[(r0 + k2) & (EC - 1)];
+                        const double lw = (double)SM.ewL[(l0 + k1) & (EC - 1)], rw = (double)SM.ewR[(r0 + k2) & (EC - 1)];
+                        const bool adjl = p == i - 1, adjr = q == j - 1;
+                        double xs, ys, ms, c;
+                        if (k2 == 0) {                                               // X candidates of left edge k1
+                            ring_cell(p, j, true, xs, ys, ms);
+                            const double open = (reduced_terminal && p == 0) ? 0.0 : go;
+                            c = xs + ge;            if (c > bx) { bx = c; px = pack_bp(PG_X, k1, 0, adjl, false); }
+                            c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, k1, 0, adjl, false); }
+                            c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, k1, 0, adjl, false); }
+                        }
+                        if (k1 == 0) {                                               // Y candidates of right edge k2
+                            ring_cell(i, q, true, xs, ys, ms);
+                            const double open = (reduced_terminal && q == 0) ? 0.0 : go;
+                            c = ys + ge;            if (c > by) { by = c; py = pack_bp(PG_Y, 0, k2, false, adjr); }
+                            c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, k2, false, adjr); }
+                            c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, k2, false, adjr); }
+                        }
+                        ring_cell(p, q, true, xs, ys, ms);                           // M candidates of the pair
+                        c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_M, k1, k2, adjl, adjr); }
+                        c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_X, k1, k2, adjl, adjr); }
+                        c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, k1, k2, adjl, adjr); }
+                        if (++k2 == nR) { k2 = 0; ++k1; }
+                    }
                 }
             } else {
+                kind = 3;
                 // ---- general: each lane walks its (left edge, right edge) pairs row-major, which visits
                 // X candidates in left-list order, Y candidates in right-list order and M candidates in
                 // the reference's pair order (VA:1396-1433) ----
@@ -619,13 +618,13 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
         STAMP(t2);
         lds_barrier();                                            // (Bd)
 #ifdef PG_STAMPS
-        { STAMP(t3); const int h = had ? 1 : 0; acc[h][0] += 1; acc[h][1] += t1 - t0; acc[h][2] += t2 - t1; acc[h][3] += t3 - t2; }
+        { STAMP(t3); const int h = (kind == 4 || had) ? kind : 0; acc[h][0] += 1; acc[h][1] += t1 - t0; acc[h][2] += t2 - t1; acc[h][3] += t3 - t2; }
 #endif
     }
 #ifdef PG_STAMPS
     if (lane == 0) {
-        PG_GLOBAL unsigned long long *o = (PG_GLOBAL unsigned long long *)(J.trace + 3 * (J.Lx + J.Ly) - 80) + 8 * (tid >> 6);
-        for (int h = 0; h < 2; ++h) for (int m = 0; m < 4; ++m) o[4 * h + m] = acc[h][m];
+        PG_GLOBAL unsigned long long *o = (PG_GLOBAL unsigned long long *)(J.trace + 3 * (J.Lx + J.Ly) - 200) + 20 * (tid >> 6);
+        for (int h = 0; h < 5; ++h) for (int m = 0; m < 4; ++m) o[4 * h + m] = acc[h][m];
     }
 #endif
 }

@@ -22,15 +22,15 @@ if os.environ.get("PG_STAMPS"):
     n_int = 3 * (l.n_sites + r.n_sites - 2)
     raw = np.zeros(n_int, np.int32)
     pg.lib().pagan_batch_debug_trace(batch._h, 0, raw.ctypes.data_as(C.c_void_p), raw.nbytes)
-    a = raw[n_int - 80:].view(np.uint64).astype(np.float64)
+    a = raw[n_int - 200:].view(np.uint64).astype(np.float64)
     for w in range(4):
-        for h, name in ((1, "active"), (0, "idle")):
-            row = a[8 * w + 4 * h: 8 * w + 4 * h + 4]
+        for h, name in enumerate(("idle", "fast", "multi", "general", "wide")):
+            row = a[20 * w + 4 * h: 20 * w + 4 * h + 4]
             n = max(row[0], 1)
-            print("wave %d %-6s steps %8d  cycles/step: head %7.1f work %7.1f barrier-wait %7.1f" %
+            print("wave %d %-7s steps %8d  cycles/step: head %7.1f work %8.1f barrier-wait %8.1f" %
                   (w, name, row[0], row[1] / n, row[2] / n, row[3] / n))
     nd = l.n_sites + r.n_sites - 3
-    print("loader: work %.1f barrier-wait %.1f cycles/step" % (a[32] / nd, a[33] / nd))
+    print("loader: work %.1f barrier-wait %.1f cycles/step" % (a[80] / nd, a[81] / nd))
 if os.environ.get("PG_CHECK"):
     import oracle
     bad = 0
