@@ -245,6 +245,7 @@ template __global__ void pg_fill_wavefront<1024>(const PgDevJob *, const int *, 
 // bit set in the cached state word of a site whose only bwd edge comes from its predecessor
 // site with weight 1 (log-weight +0.0): adding that weight is an exact no-op
 #define PG_SIMPLE 0x10000
+#define PG_SPAN_SHIFT 17
 
 struct RingSmem {
     double sc[RK][NT][3];                   // X, Y, M
@@ -280,6 +281,19 @@ __device__ __forceinline__ float far_f32(PG_GLOBAL const float *p) {
     asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
+__device__ __forceinline__ pg_i4 far_desc(PG_GLOBAL const pg_i4 *p) {
+    pg_i4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+// the three scores of one cell (X, Y, M: 24 contiguous bytes), one wait for both loads
+__device__ __forceinline__ void far_cell(PG_GLOBAL const double *p, double &xs, double &ys, double &ms) {
+    typedef double pg_d2 __attribute__((ext_vector_type(2)));
+    pg_d2 xy; double m;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(xy), "=&v"(m) : "v"(p) : "memory");
+    xs = xy.x; ys = xy.y; ms = m;
+}
 __device__ __forceinline__ long long far_i64(PG_GLOBAL const long long *p) {
     long long v;
     asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
@@ -304,13 +318,14 @@ __device__ __forceinline__ void ring_load(const View &J, int d, unsigned residen
         ys = SM.sc[slot][p & (NT - 1)][PG_Y];
         ms = SM.sc[slot][p & (NT - 1)][PG_M];
     } else {
-        // left the ring (edge reaching >= RK diagonals back) or never entered it (wide diagonal)
+        // left the ring (edge reaching >= RK diagonals back) or never entered it (wide diagonal):
+        // two dependent HBM round trips -- the diagonal's packed descriptor, then the cell's 24 bytes
         const double NI = neg_inf();
         xs = NI; ys = NI; ms = NI;
-        const int fmn = far_i32(J.imin + dd), fmx = far_i32(J.imax + dd);
-        if (p >= fmn && p <= fmx) {
-            const long long ix = far_i64(J.doff + dd) + (p - fmn);
-            xs = far_f64(J.sc + 3 * ix + PG_X); ys = far_f64(J.sc + 3 * ix + PG_Y); ms = far_f64(J.sc + 3 * ix + PG_M);
+        const pg_i4 ds = far_desc((PG_GLOBAL const pg_i4 *)J.dsc + dd);
+        if (p >= ds.x && p <= ds.y) {
+            const long long ix = (((long long)ds.w << 32) | (unsigned)ds.z) + (p - ds.x);
+            far_cell(J.sc + 3 * ix, xs, ys, ms);
         }
     }
 }
@@ -327,27 +342,20 @@ __device__ __forceinline__ void ring_cell(int p, int q, bool has, double &xs, do
 }
 
 // True when every active lane of the wave has at least one bwd edge on both sites and every
-// predecessor diagonal its edges reach is resident in the ring (so its item loop can read cells
-// with ring_cell, without per-read residency branches).
-__device__ __forceinline__ bool all_resident(int d, unsigned resident, bool active, int i, int j) {
+// predecessor diagonal its edges can reach is resident in the ring (so its item loop can read
+// cells with ring_cell, without per-read residency branches).  The reach is bounded by the two
+// sites' farthest edges: a pair (p,q) lies (i-p)+(j-q) <= spanL+spanR diagonals back.
+__device__ __forceinline__ bool all_resident(int d, unsigned resident, bool active, int wi, int wj) {
     bool ok = true;
     if (active) {
-        const int l0 = SM.ebL[i & (RW - 1)], nL = SM.eeL[i & (RW - 1)] - l0;
-        const int r0 = SM.ebR[j & (RW - 1)], nR = SM.eeR[j & (RW - 1)] - r0;
-        ok = nL >= 1 && nR >= 1 && nL <= 8 && nR <= 8;
+        const int sl = (wi >> PG_SPAN_SHIFT) & 255, sr = (wj >> PG_SPAN_SHIFT) & 255;
+        const int age = sl + sr;
+        ok = sl > 0 && sr > 0 && age < RK;
         if (ok) {
-            int pm_ = SM.esL[l0 & (EC - 1)], qm_ = SM.esR[r0 & (EC - 1)];      // the farthest predecessors
-            for (int k = 1; k < nL; ++k) { const int p = SM.esL[(l0 + k) & (EC - 1)]; pm_ = p < pm_ ? p : pm_; }
-            for (int k = 1; k < nR; ++k) { const int q = SM.esR[(r0 + k) & (EC - 1)]; qm_ = q < qm_ ? q : qm_; }
-            // oldest diagonal touched is pm_ + qm_; every diagonal from there to d-1 must be resident
-            const int age = d - (pm_ + qm_);
-            ok = age < RK;
-            if (ok) {
-                const unsigned run = ((1u << age) - 1u);                         // diagonals d-age .. d-1, modulo RK
-                const int first = (d - age) & (RK - 1);
-                const unsigned need = ((run << first) | (run >> (RK - first))) & ((1u << RK) - 1u);
-                ok = (resident & need) == need;
-            }
+            const unsigned run = ((1u << age) - 1u);                         // diagonals d-age .. d-1, modulo RK
+            const int first = (d - age) & (RK - 1);
+            const unsigned need = ((run << first) | (run >> (RK - first))) & ((1u << RK) - 1u);
+            ok = (resident & need) == need;
         }
     }
     return __all(ok);
@@ -372,6 +380,12 @@ __device__ __forceinline__ void load_site_chunk(int first, int lane, int n, gint
         const int b = off[r], en = off[r + 1];
         int w = st[r] & 0xffff;
         if (r > 0 && en - b == 1 && src[b] == r - 1 && lw[b] == 0.0f) w |= PG_SIMPLE;
+        // farthest bwd edge of the site, in sites (0 = no edge at all, saturates at 255): lets the compute
+        // waves bound how far back a cell reaches without walking its edge list
+        int span = 0;
+        for (int e = b; e < en && e < b + 16; ++e) { const int sp = r - src[e]; span = sp > span ? sp : span; }
+        if (en - b > 16 || span > 255) span = 255;
+        w |= span << PG_SPAN_SHIFT;
         cst[r & (RW - 1)] = w; ceb[r & (RW - 1)] = b; cee[r & (RW - 1)] = en;
     }
     const int rend = first + 64 < n ? first + 64 : n;
@@ -507,7 +521,7 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
                     bm = first_max3(mC + tM, xC + tX, yC + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
                                     PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
                 }
-            } else if (interior && all_resident(d, resident, active, i, j)) {
+            } else if (interior && all_resident(d, resident, active, wi, wj)) {
                 kind = 2;
                 // ---- multi-edge sites, every predecessor in the ring: each lane walks its (left edge,
                 // right edge) pairs row-major -- X candidates in left-list order, Y candidates in
@@ -533,21 +547,24 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
                         if (k2 == 0) {                                               // X candidates of left edge k1
                             ring_cell(p, j, true, xs, ys, ms);
                             const double open = (reduced_terminal && p == 0) ? 0.0 : go;
-                            c = xs + ge;            if (c > bx) { bx = c; px = pack_bp(PG_X, k1, 0, adjl, false); }
-                            c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, k1, 0, adjl, false); }
-                            c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, k1, 0, adjl, false); }
+                            const unsigned w = pack_bp(0, k1, 0, adjl, false);
+                            c = xs + ge;            if (c > bx) { bx = c; px = w | PG_X; }
+                            c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = w | PG_Y; }
+                            c = (ms + ng) + open;   if (c > bx) { bx = c; px = w | PG_M; }
                         }
                         if (k1 == 0) {                                               // Y candidates of right edge k2
                             ring_cell(i, q, true, xs, ys, ms);
                             const double open = (reduced_terminal && q == 0) ? 0.0 : go;
-                            c = ys + ge;            if (c > by) { by = c; py = pack_bp(PG_Y, 0, k2, false, adjr); }
-                            c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, k2, false, adjr); }
-                            c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, k2, false, adjr); }
+                            const unsigned w = pack_bp(0, 0, k2, false, adjr);
+                            c = ys + ge;            if (c > by) { by = c; py = w | PG_Y; }
+                            c = (xs + 0.0) + go;    if (c > by) { by = c; py = w | PG_X; }
+                            c = (ms + ng) + open;   if (c > by) { by = c; py = w | PG_M; }
                         }
                         ring_cell(p, q, true, xs, ys, ms);                           // M candidates of the pair
-                        c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_M, k1, k2, adjl, adjr); }
-                        c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_X, k1, k2, adjl, adjr); }
-                        c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, k1, k2, adjl, adjr); }
+                        const unsigned w = pack_bp(0, k1, k2, adjl, adjr);
+                        c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_M; }
+                        c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_X; }
+                        c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_Y; }
                         if (++k2 == nR) { k2 = 0; ++k1; }
                     }
                 }
