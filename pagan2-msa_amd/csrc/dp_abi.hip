@@ -263,10 +263,10 @@ int launch_fill(pagan_batch *b) {
         }
         // model tables of <= 16 states (DNA: 15) are cached in LDS; larger ones stay in HBM/L2
         if (b->n_ring_small > 0)
-            hipLaunchKernelGGL(pg_fill_ring<true>, dim3(b->n_ring_small), dim3(320), pg_ring_lds_bytes(), b->stream,
+            hipLaunchKernelGGL(pg_fill_ring<true>, dim3(b->n_ring_small), dim3(576), pg_ring_lds_bytes(), b->stream,
                                b->d_jobs, b->d_which, b->flags);
         if (b->n_ring > b->n_ring_small)
-            hipLaunchKernelGGL(pg_fill_ring<false>, dim3(b->n_ring - b->n_ring_small), dim3(320), pg_ring_lds_bytes(),
+            hipLaunchKernelGGL(pg_fill_ring<false>, dim3(b->n_ring - b->n_ring_small), dim3(576), pg_ring_lds_bytes(),
                                b->stream, b->d_jobs, b->d_which + b->n_ring_small, b->flags);
     }
     if (b->n_wide > 0) {

@@ -211,10 +211,14 @@ template __global__ void pg_fill_wavefront<1024>(const PgDevJob *, const int *, 
 // ---------------------------------------------------------------------------------------------
 // Banded wavefront with the active band staged in LDS ("ring" kernel).
 //
-// One workgroup per alignment: NW compute waves + one loader wave, one s_barrier per
-// anti-diagonal.  Thread T of the compute waves owns the rows i with i % NT == T (NT = 64 NW)
-// that are inside the band on the current diagonal, so up to NT cells are computed at once
-// and a cell's slot in the ring is i % NT.  Per step (anti-diagonal d):
+// One workgroup per alignment: 2 NW compute waves + one loader wave, one s_barrier per
+// anti-diagonal.  Slot u = i % NT (NT = 64 NW) of the current diagonal is worked on by TWO
+// threads: thread u (waves 0..NW-1, the "gap" role) computes the X and Y states of the cell,
+// thread NT+u (waves NW..2NW-1, the "match" role) its M state.  The two roles read the same
+// predecessors and write disjoint outputs, so splitting the states needs no combine step and
+// takes ~40 % of the instructions off each wave -- the fill is instruction-issue bound (one
+// wave issues a VALU instruction every 4-5 cycles), not bandwidth bound.  Up to NT cells are
+// computed at once.  Per step (anti-diagonal d):
 //   - the scores of the last RK diagonals live in an LDS ring  sc[d % RK][i % NT][X,Y,M];
 //     every predecessor within RK diagonals is an LDS read guarded by that diagonal's
 //     [imin,imax] interval;
@@ -406,72 +410,47 @@ __device__ __forceinline__ void loader_prepare(const View &J, int dn, int lane, 
 
 } // namespace
 
-#ifdef PG_STAMPS
-// Diagnostic build only (tools/build_stamps.sh): s_memtime stamps accumulated per wave and written
-// to the tail of the (still unused) trace buffer.  Never compiled into the shipped library.
-#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
-#else
-#define STAMP(var)
-#endif
-
 template <bool TAB_LDS>
-__global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restrict__ jobs, const int *__restrict__ which,
-                                                        unsigned flags) {
+__global__ __launch_bounds__(2 * NT + 64) void pg_fill_ring(const PgDevJob *__restrict__ jobs, const int *__restrict__ which,
+                                                            unsigned flags) {
     const View J = load_view(jobs + which[blockIdx.x]);
     const bool no_terminal_edges = flags & 1u;
     const bool reduced_terminal = !(flags & 2u);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    if (TAB_LDS) for (int k = tid; k < J.S * J.S; k += NT + 64) SM.table[k] = J.table[k];
+    if (TAB_LDS) for (int k = tid; k < J.S * J.S; k += 2 * NT + 64) SM.table[k] = J.table[k];
 
-    if (tid >= NT) {
+    if (tid >= 2 * NT) {
         // ================= loader wave: stays one diagonal ahead of the compute waves =================
         int rows = 0, cols = 0;
         loader_prepare(J, 0, lane, rows, cols);
         lds_barrier();                                            // (B0) compute may start diagonal 0
-#ifdef PG_STAMPS
-        unsigned long long lw = 0, lb = 0;
-#endif
         for (int d = 0; d < J.nd; ++d) {
-            STAMP(t0);
             const pg_i4 ds = J.dsc[d];
             if (ds.y - ds.x + 1 > NTW) lds_barrier();             // (Bw) mirrors the compute waves' drain barrier
             if (d + 1 < J.nd) loader_prepare(J, d + 1, lane, rows, cols);
-            STAMP(t1);
             lds_barrier();                                        // (Bd) end of diagonal d
-#ifdef PG_STAMPS
-            { STAMP(t2); lw += t1 - t0; lb += t2 - t1; }
-#endif
         }
-#ifdef PG_STAMPS
-        if (lane == 0) { PG_GLOBAL unsigned long long *o = (PG_GLOBAL unsigned long long *)(J.trace + 3 * (J.Lx + J.Ly) - 200); o[80] = lw; o[81] = lb; }
-#endif
         return;
     }
 
     // ================= compute waves =================
+    const bool match_role = tid >= NT;                            // wave-uniform: waves NW..2NW-1
+    const int u = tid & (NT - 1);                                 // ring slot this thread works on
     const double NI = neg_inf();
     const double go = (double)J.go, ng = (double)J.ng, ge = (double)J.ge;
     const double tng2 = (double)(2 * J.ng), tng1 = (double)(0.0f + J.ng);
     unsigned resident = 0;                                        // bit (dd % RK): diagonal dd is in the ring
     pg_i4 nxt = J.dsc[0];
     lds_barrier();                                                // (B0)
-#ifdef PG_STAMPS
-    unsigned long long acc[5][4] = {};      // [idle, fast, dual, general, wide][steps, head, work, barrier]
-#endif
     for (int d = 0; d < J.nd; ++d) {
-        STAMP(t0);
         const pg_i4 cur = nxt;
         nxt = J.dsc[d + 1 < J.nd ? d + 1 : d];                    // scalar prefetch for the next step
         const int lo = cur.x, hi = cur.y;
         const long long base = ((long long)cur.w << 32) | (unsigned)cur.z;
         const bool wide = hi - lo + 1 > NTW;
         const unsigned slot_bit = 1u << (d & (RK - 1));
-        STAMP(t1);
-        int kind = 0; (void)kind;
-        bool had = false; (void)had;
         if (wide) {
-            kind = 4;
             // rare: a box between anchors wider than the ring.  Every wave drains its stores, then all
             // cells are computed from HBM/L2 operands, then drained again so that later diagonals
             // (which find "not in the ring") read landed data.
@@ -480,16 +459,15 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
             const pg_i4 p1 = J.dsc[d > 0 ? d - 1 : 0], p2 = J.dsc[d > 1 ? d - 2 : 0];
             const Diag g1 = {p1.x, d > 0 ? p1.y : p1.x - 1, ((long long)p1.w << 32) | (unsigned)p1.z};
             const Diag g2 = {p2.x, d > 1 ? p2.y : p2.x - 1, ((long long)p2.w << 32) | (unsigned)p2.z};
-            for (int i = lo + tid; i <= hi; i += NT)
+            for (int i = lo + tid; i <= hi; i += 2 * NT)
                 fill_cell_hbm(J, d, g1, g2, i, d - i, base + (i - lo), no_terminal_edges, reduced_terminal);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             resident &= ~slot_bit;
         } else {
-            const int off = (tid - lo) & (NT - 1);                // position of this thread's row in the band
+            const int off = (u - lo) & (NT - 1);                  // position of this thread's row in the band
             const int i = lo + off;
             const int j = d - i;
             const bool active = i <= hi;
-            had = __any(active);
             int wi = 0, wj = 0;
             bool simple = true;
             if (active) {
@@ -498,152 +476,171 @@ __global__ __launch_bounds__(NT + 64) void pg_fill_ring(const PgDevJob *__restri
             }
             double bx = NI, by = NI, bm = NI;
             unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
+            bool all_by_gap = false;                              // general path: the gap-role thread does all three states
             // interior: no first/last row or column on this diagonal, so every gap extension is the
             // normal one and every gap open pays the full penalty (BA.h:490-513, VA:864-879)
             const bool interior = lo >= 2 && hi <= J.Lx - 2 && d - hi >= 2 && d - lo <= J.Ly - 2;
             const unsigned prev2 = (1u << ((d - 1) & (RK - 1))) | (1u << ((d - 2) & (RK - 1)));
             if ((resident & prev2) == prev2 && interior && __all(simple)) {
-                kind = 1;
                 // ---- every cell of this wave is simple: straight-line code, no band tests ----
-                if (active) {
+                // `+ 0.0` (log_gap_close, unit edge weights) is omitted: exact, no score is ever -0.0
+                if (active && !match_role) {
                     const double *A = SM.sc[(d - 1) & (RK - 1)][(i - 1) & (NT - 1)];   // (i-1, j)   on d-1
                     const double *B = SM.sc[(d - 1) & (RK - 1)][i & (NT - 1)];         // (i, j-1)   on d-1
-                    const double *Cc = SM.sc[(d - 2) & (RK - 1)][(i - 1) & (NT - 1)];  // (i-1, j-1) on d-2
                     const double xA = A[PG_X], yA = A[PG_Y], mA = A[PG_M];
                     const double xB = B[PG_X], yB = B[PG_Y], mB = B[PG_M];
+                    bx = first_max3(xA + ge, yA + go, (mA + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
+                    by = first_max3(yB + ge, xB + go, (mB + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
+                }
+                if (active && match_role) {
+                    const double *Cc = SM.sc[(d - 2) & (RK - 1)][(i - 1) & (NT - 1)];  // (i-1, j-1) on d-2
                     const double xC = Cc[PG_X], yC = Cc[PG_Y], mC = Cc[PG_M];
                     const int ti = (wi & 0xffff) + (wj & 0xffff) * J.S;
                     const float smf = TAB_LDS ? SM.table[ti] : far_f32(J.table + ti);
                     const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
-                    // `+ 0.0` (log_gap_close, unit edge weights) is omitted: exact, no score is ever -0.0
-                    bx = first_max3(xA + ge, yA + go, (mA + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
-                    by = first_max3(yB + ge, xB + go, (mB + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
                     bm = first_max3(mC + tM, xC + tX, yC + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
                                     PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
                 }
             } else if (interior && all_resident(d, resident, active, wi, wj)) {
-                kind = 2;
-                // ---- multi-edge sites, every predecessor in the ring: each lane walks its (left edge,
-                // right edge) pairs row-major -- X candidates in left-list order, Y candidates in
-                // right-list order, M candidates in the reference's pair order (VA:1396-1433) -- with
-                // branch-free cell reads.
-                int l0 = 0, nL = 0, r0 = 0, nR = 1, n_items = 0;
-                double tM = 0, tX = 0;
+                // ---- multi-edge sites, every predecessor in the ring, branch-free cell reads.  Gap role:
+                // X candidates in left-list order, Y candidates in right-list order.  Match role: the
+                // (left edge, right edge) pairs row-major, the reference's pair order (VA:1396-1433).
+                int l0 = 0, nL = 0, r0 = 0, nR = 1;
                 if (active) {
                     l0 = SM.ebL[i & (RW - 1)]; nL = SM.eeL[i & (RW - 1)] - l0;
                     r0 = SM.ebR[j & (RW - 1)]; nR = SM.eeR[j & (RW - 1)] - r0;
-                    n_items = nL * nR;
-                    const int ti = (wi & 0xffff) + (wj & 0xffff) * J.S;
-                    const float smf = TAB_LDS ? SM.table[ti] : far_f32(J.table + ti);
-                    tM = tng2 + (double)smf; tX = tng1 + (double)smf;
                 }
-                int k1 = 0, k2 = 0;
-                for (int t = 0; __any(t < n_items); ++t) {
-                    if (t < n_items) {
-                        const int p = SM.esL[(l0 + k1) & (EC - 1)], q = SM.esR[(r0 + k2) & (EC - 1)];
-                        const double lw = (double)SM.ewL[(l0 + k1) & (EC - 1)], rw = (double)SM.ewR[(r0 + k2) & (EC - 1)];
-                        const bool adjl = p == i - 1, adjr = q == j - 1;
+                if (!match_role) {
+                    const int n_items = active ? (nL > nR ? nL : nR) : 0;
+                    for (int t = 0; __any(t < n_items); ++t) {
                         double xs, ys, ms, c;
-                        if (k2 == 0) {                                               // X candidates of left edge k1
+                        if (t < nL && active) {                                      // X candidates of left edge t
+                            const int p = SM.esL[(l0 + t) & (EC - 1)];
                             ring_cell(p, j, true, xs, ys, ms);
                             const double open = (reduced_terminal && p == 0) ? 0.0 : go;
-                            const unsigned w = pack_bp(0, k1, 0, adjl, false);
+                            const unsigned w = pack_bp(0, t, 0, p == i - 1, false);
                             c = xs + ge;            if (c > bx) { bx = c; px = w | PG_X; }
                             c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = w | PG_Y; }
                             c = (ms + ng) + open;   if (c > bx) { bx = c; px = w | PG_M; }
                         }
-                        if (k1 == 0) {                                               // Y candidates of right edge k2
+                        if (t < nR && active) {                                      // Y candidates of right edge t
+                            const int q = SM.esR[(r0 + t) & (EC - 1)];
                             ring_cell(i, q, true, xs, ys, ms);
                             const double open = (reduced_terminal && q == 0) ? 0.0 : go;
-                            const unsigned w = pack_bp(0, 0, k2, false, adjr);
+                            const unsigned w = pack_bp(0, 0, t, false, q == j - 1);
                             c = ys + ge;            if (c > by) { by = c; py = w | PG_Y; }
                             c = (xs + 0.0) + go;    if (c > by) { by = c; py = w | PG_X; }
                             c = (ms + ng) + open;   if (c > by) { by = c; py = w | PG_M; }
                         }
-                        ring_cell(p, q, true, xs, ys, ms);                           // M candidates of the pair
-                        const unsigned w = pack_bp(0, k1, k2, adjl, adjr);
-                        c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_M; }
-                        c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_X; }
-                        c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_Y; }
-                        if (++k2 == nR) { k2 = 0; ++k1; }
                     }
-                }
-            } else {
-                kind = 3;
-                // ---- general: each lane walks its (left edge, right edge) pairs row-major, which visits
-                // X candidates in left-list order, Y candidates in right-list order and M candidates in
-                // the reference's pair order (VA:1396-1433) ----
-                int l0 = 0, nL = 0, r0 = 0, nR = 0, n_items = 0;
-                double tM = 0, tX = 0, extX = 0, extY = 0;
-                if (active) {
-                    if (i > 0) { l0 = SM.ebL[i & (RW - 1)]; nL = SM.eeL[i & (RW - 1)] - l0; }
-                    if (j > 0) { r0 = SM.ebR[j & (RW - 1)]; nR = SM.eeR[j & (RW - 1)] - r0; }
-                    if (i == 0 && j == 0) bm = 0.0;                        // initialise_array_corner, VA:725-736
-                    else n_items = (nL > 0 ? nL : 1) * (nR > 0 ? nR : 1);
-                    if (nL > 0 && nR > 0) {
+                } else {
+                    int n_items = 0;
+                    double tM = 0, tX = 0;
+                    if (active) {
+                        n_items = nL * nR;
                         const int ti = (wi & 0xffff) + (wj & 0xffff) * J.S;
                         const float smf = TAB_LDS ? SM.table[ti] : far_f32(J.table + ti);
                         tM = tng2 + (double)smf; tX = tng1 + (double)smf;
                     }
-                    extX = (double)(((j == 0 || j == J.Ly - 1) && !no_terminal_edges) ? J.gE : J.ge);
-                    extY = (double)(((i == 0 || i == J.Lx - 1) && !no_terminal_edges) ? J.gE : J.ge);
+                    int k1 = 0, k2 = 0;
+                    for (int t = 0; __any(t < n_items); ++t) {
+                        if (t < n_items) {
+                            const int p = SM.esL[(l0 + k1) & (EC - 1)], q = SM.esR[(r0 + k2) & (EC - 1)];
+                            const double lw = (double)SM.ewL[(l0 + k1) & (EC - 1)], rw = (double)SM.ewR[(r0 + k2) & (EC - 1)];
+                            double xs, ys, ms, c;
+                            ring_cell(p, q, true, xs, ys, ms);
+                            const unsigned w = pack_bp(0, k1, k2, p == i - 1, q == j - 1);
+                            c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_M; }
+                            c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_X; }
+                            c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_Y; }
+                            if (++k2 == nR) { k2 = 0; ++k1; }
+                        }
+                    }
                 }
-                const int nRp = nR > 0 ? nR : 1;
-                int k1 = 0, k2 = 0;
-                for (int t = 0; __any(t < n_items); ++t) {
-                    if (t < n_items) {
-                        int p = 0, q = 0;
-                        double lw = 0, rw = 0, xs, ys, ms, c;
-                        if (nL > 0) { p = SM.esL[(l0 + k1) & (EC - 1)]; lw = (double)SM.ewL[(l0 + k1) & (EC - 1)]; }
-                        if (nR > 0) { q = SM.esR[(r0 + k2) & (EC - 1)]; rw = (double)SM.ewR[(r0 + k2) & (EC - 1)]; }
-                        if (nL > 0 && k2 == 0) {                                     // X candidates of left edge k1
-                            ring_load(J, d, resident, p, j, xs, ys, ms);
-                            const double open = (reduced_terminal && p == 0) ? 0.0 : go;
-                            c = xs + extX;          if (c > bx) { bx = c; px = pack_bp(PG_X, k1, 0, p == i - 1, false); }
-                            c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, k1, 0, p == i - 1, false); }
-                            c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, k1, 0, p == i - 1, false); }
+            } else {
+                // ---- general (first/last rows and columns, sites without predecessors, edges reaching past
+                // the ring): the gap-role thread computes all three states, walking its (left edge, right
+                // edge) pairs row-major, which visits X candidates in left-list order, Y candidates in
+                // right-list order and M candidates in the reference's pair order (VA:1396-1433) ----
+                all_by_gap = true;
+                if (!match_role) {
+                    int l0 = 0, nL = 0, r0 = 0, nR = 0, n_items = 0;
+                    double tM = 0, tX = 0, extX = 0, extY = 0;
+                    if (active) {
+                        if (i > 0) { l0 = SM.ebL[i & (RW - 1)]; nL = SM.eeL[i & (RW - 1)] - l0; }
+                        if (j > 0) { r0 = SM.ebR[j & (RW - 1)]; nR = SM.eeR[j & (RW - 1)] - r0; }
+                        if (i == 0 && j == 0) bm = 0.0;                        // initialise_array_corner, VA:725-736
+                        else n_items = (nL > 0 ? nL : 1) * (nR > 0 ? nR : 1);
+                        if (nL > 0 && nR > 0) {
+                            const int ti = (wi & 0xffff) + (wj & 0xffff) * J.S;
+                            const float smf = TAB_LDS ? SM.table[ti] : far_f32(J.table + ti);
+                            tM = tng2 + (double)smf; tX = tng1 + (double)smf;
                         }
-                        if (nR > 0 && k1 == 0) {                                     // Y candidates of right edge k2
-                            ring_load(J, d, resident, i, q, xs, ys, ms);
-                            const double open = (reduced_terminal && q == 0) ? 0.0 : go;
-                            c = ys + extY;          if (c > by) { by = c; py = pack_bp(PG_Y, 0, k2, false, q == j - 1); }
-                            c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, k2, false, q == j - 1); }
-                            c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, k2, false, q == j - 1); }
+                        extX = (double)(((j == 0 || j == J.Ly - 1) && !no_terminal_edges) ? J.gE : J.ge);
+                        extY = (double)(((i == 0 || i == J.Lx - 1) && !no_terminal_edges) ? J.gE : J.ge);
+                    }
+                    const int nRp = nR > 0 ? nR : 1;
+                    int k1 = 0, k2 = 0;
+                    for (int t = 0; __any(t < n_items); ++t) {
+                        if (t < n_items) {
+                            int p = 0, q = 0;
+                            double lw = 0, rw = 0, xs, ys, ms, c;
+                            if (nL > 0) { p = SM.esL[(l0 + k1) & (EC - 1)]; lw = (double)SM.ewL[(l0 + k1) & (EC - 1)]; }
+                            if (nR > 0) { q = SM.esR[(r0 + k2) & (EC - 1)]; rw = (double)SM.ewR[(r0 + k2) & (EC - 1)]; }
+                            if (nL > 0 && k2 == 0) {                                     // X candidates of left edge k1
+                                ring_load(J, d, resident, p, j, xs, ys, ms);
+                                const double open = (reduced_terminal && p == 0) ? 0.0 : go;
+                                c = xs + extX;          if (c > bx) { bx = c; px = pack_bp(PG_X, k1, 0, p == i - 1, false); }
+                                c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, k1, 0, p == i - 1, false); }
+                                c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, k1, 0, p == i - 1, false); }
+                            }
+                            if (nR > 0 && k1 == 0) {                                     // Y candidates of right edge k2
+                                ring_load(J, d, resident, i, q, xs, ys, ms);
+                                const double open = (reduced_terminal && q == 0) ? 0.0 : go;
+                                c = ys + extY;          if (c > by) { by = c; py = pack_bp(PG_Y, 0, k2, false, q == j - 1); }
+                                c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, k2, false, q == j - 1); }
+                                c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, k2, false, q == j - 1); }
+                            }
+                            if (nL > 0 && nR > 0) {                                      // M candidates of the pair
+                                ring_load(J, d, resident, p, q, xs, ys, ms);
+                                c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_M, k1, k2, p == i - 1, q == j - 1); }
+                                c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_X, k1, k2, p == i - 1, q == j - 1); }
+                                c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, k1, k2, p == i - 1, q == j - 1); }
+                            }
+                            if (++k2 == nRp) { k2 = 0; ++k1; }
                         }
-                        if (nL > 0 && nR > 0) {                                      // M candidates of the pair
-                            ring_load(J, d, resident, p, q, xs, ys, ms);
-                            c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_M, k1, k2, p == i - 1, q == j - 1); }
-                            c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_X, k1, k2, p == i - 1, q == j - 1); }
-                            c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, k1, k2, p == i - 1, q == j - 1); }
-                        }
-                        if (++k2 == nRp) { k2 = 0; ++k1; }
                     }
                 }
             }
-            // EVERY thread writes its slot of this diagonal's ring row (slot == thread id, since
-            // i = tid mod NT): the cell's scores inside the band, -inf outside it.
-            SM.sc[d & (RK - 1)][tid][PG_X] = bx;
-            SM.sc[d & (RK - 1)][tid][PG_Y] = by;
-            SM.sc[d & (RK - 1)][tid][PG_M] = bm;
-            if (active) store_cell(J.sc, J.bp, base + off, bx, by, bm, px, py, pm);
+            // EVERY slot of this diagonal's ring row is written (slot == u, since i = u mod NT): the
+            // cell's scores inside the band, -inf outside it.  Each role commits the states it computed.
+            gdouble_w orow = J.sc + 3 * (base + off);
+            gu32_w brow = J.bp + 3 * (base + off);
+            if (!match_role) {
+                SM.sc[d & (RK - 1)][u][PG_X] = bx;
+                SM.sc[d & (RK - 1)][u][PG_Y] = by;
+                if (all_by_gap) SM.sc[d & (RK - 1)][u][PG_M] = bm;
+                if (active) {
+                    typedef double d2 __attribute__((ext_vector_type(2)));
+                    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                    d2 xy; xy.x = bx; xy.y = by;
+                    *(PG_GLOBAL d2 *)orow = xy;
+                    u2 b2; b2.x = px; b2.y = py;
+                    *(PG_GLOBAL u2 *)brow = b2;
+                    if (all_by_gap) { orow[PG_M] = bm; brow[PG_M] = pm; }
+                }
+            } else if (!all_by_gap) {
+                SM.sc[d & (RK - 1)][u][PG_M] = bm;
+                if (active) { orow[PG_M] = bm; brow[PG_M] = pm; }
+            }
             resident |= slot_bit;
         }
         // A cell read back from HBM (an edge reaching >= RK diagonals back) must have landed, whichever
         // wave stored it: every wave drains its stores once per RK/2 diagonals, so after the barriers
         // of the following diagonals nothing older than RK diagonals is still in flight.
         if ((d & (RK / 2 - 1)) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        STAMP(t2);
         lds_barrier();                                            // (Bd)
-#ifdef PG_STAMPS
-        { STAMP(t3); const int h = (kind == 4 || had) ? kind : 0; acc[h][0] += 1; acc[h][1] += t1 - t0; acc[h][2] += t2 - t1; acc[h][3] += t3 - t2; }
-#endif
     }
-#ifdef PG_STAMPS
-    if (lane == 0) {
-        PG_GLOBAL unsigned long long *o = (PG_GLOBAL unsigned long long *)(J.trace + 3 * (J.Lx + J.Ly) - 200) + 20 * (tid >> 6);
-        for (int h = 0; h < 5; ++h) for (int m = 0; m < 4; ++m) o[4 * h + m] = acc[h][m];
-    }
-#endif
 }
 
 template __global__ void pg_fill_ring<true>(const PgDevJob *, const int *, unsigned);
