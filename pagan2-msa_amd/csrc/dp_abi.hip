@@ -8,6 +8,7 @@
 // There is no CPU fill or traceback here: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -22,6 +23,7 @@
 
 template <int BLOCK> __global__ void pg_fill_wavefront(const PgDevJob *jobs, const int *which, unsigned flags);
 template <bool TAB_LDS> __global__ void pg_fill_ring(const PgDevJob *jobs, const int *which, unsigned flags);
+template <bool TAB_LDS> __global__ void pg_fill_pipe(const PgDevJob *jobs, const int *which, unsigned flags);
 __global__ void pg_end_corner(const PgDevJob *jobs);
 __global__ void pg_trace_spec(const PgDevJob *jobs);
 __global__ void pg_trace_compose(const PgDevJob *jobs);
@@ -32,6 +34,12 @@ __global__ void pg_trace_emit(const PgDevJob *jobs);
 #define PG_RING_SITE_SPAN 576
 #define PG_RING_EDGE_CAP 2048
 unsigned pg_ring_lds_bytes();
+// limits of the register-wavefront kernel (dp_pipe.hip: PNTW lanes, PAGE ring reach, PEC edge window)
+#define PG_PIPE_WIDTH 240
+#define PG_PIPE_REACH 16
+#define PG_PIPE_EDGE_CAP 1024
+#define PG_PIPE_SITE_EDGES 126
+unsigned pg_pipe_lds_bytes();
 
 namespace {
 
@@ -116,17 +124,86 @@ struct HostJob {
     int Lx, Ly;
     DiagIndex dx;
     bool ring_ok = false;        // fits the LDS-staged narrow-band kernel
+    std::vector<uint8_t> cls;    // per diagonal: how dp_pipe.hip computes it (empty: not a pipe job)
     int n_bound = 0;             // traceback boundaries (dp_device.h)
     std::vector<int> tb;         // [n_bound + 2] table offsets
 };
 
 // The ring kernel keeps the bwd edges of ~256 consecutive sites in a 1024-entry LDS ring.
-bool edges_fit_ring(const pagan_graph *g, int rows) {
+bool edges_fit_ring(const pagan_graph *g, int rows, int cap = PG_RING_EDGE_CAP, int per_site = PG_MAX_SLOT) {
     for (int i = 0; i < rows; ++i) {
         const int e = i + PG_RING_SITE_SPAN < rows ? i + PG_RING_SITE_SPAN : rows;
-        if (g->bwd_off[e] - g->bwd_off[i] > PG_RING_EDGE_CAP) return false;
+        if (g->bwd_off[e] - g->bwd_off[i] > cap) return false;
+        if (g->bwd_off[i + 1] - g->bwd_off[i] > per_site) return false;
     }
     return true;
+}
+
+// What the fill kernel may assume about a site without looking at its edge list.
+struct SiteFeat {
+    std::vector<int> span;            // farthest bwd edge, in sites (0: no bwd edge)
+    std::vector<int> not_simple;      // prefix count of sites that are not "one edge from the previous site, weight 1"
+    std::vector<int> no_pred;         // prefix count of sites without bwd edges
+    void build(const pagan_graph *g, int n) {
+        span.assign(n, 0); not_simple.assign(n + 1, 0); no_pred.assign(n + 1, 0);
+        for (int s = 0; s < n; ++s) {
+            const int a = g->bwd_off[s], b = g->bwd_off[s + 1];
+            int sp = 0;
+            for (int k = a; k < b; ++k) sp = std::max(sp, s - g->bwd_src[k]);
+            span[s] = sp;
+            const bool simple = s > 0 && b - a == 1 && g->bwd_src[a] == s - 1 && g->bwd_logw[a] == 0.0f;
+            not_simple[s + 1] = not_simple[s] + (simple ? 0 : 1);
+            no_pred[s + 1] = no_pred[s] + (b == a ? 1 : 0);
+        }
+    }
+};
+
+// Class of every anti-diagonal for dp_pipe.hip (its header explains the four code paths):
+//   3  wider than PG_PIPE_WIDTH cells;
+//   2  touches the first/last two rows or columns, holds a site without bwd edges, follows a wide
+//      diagonal within the ring's reach, or holds a cell (i,j) whose farthest predecessor pair lies
+//      span(i) + span(j) >= PG_PIPE_REACH diagonals back;
+//   1  holds a site that is not simple;   0  otherwise.
+void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, const RowBand &rb,
+                        const DiagIndex &dx, std::vector<uint8_t> *out) {
+    const int nd = Lx + Ly - 1;
+    SiteFeat fl, fr;
+    fl.build(L, Lx); fr.build(R, Ly);
+    std::vector<int> far(nd + 1, 0);
+    auto mark = [&](int d0, int d1) { if (d0 <= d1) { ++far[d0]; --far[d1 + 1]; } };
+    std::vector<int> multi_cols;                       // columns with span >= 2, ascending
+    for (int j = 0; j < Ly; ++j) if (fr.span[j] >= 2) multi_cols.push_back(j);
+    for (int i = 0; i < Lx; ++i) {
+        if (rb.hi[i] < rb.lo[i]) continue;
+        const int sl = fl.span[i];
+        if (sl >= PG_PIPE_REACH - 1) { mark(i + rb.lo[i], i + rb.hi[i]); continue; }   // any column: span(j) >= 1
+        if (sl < 2) continue;                          // with span(i) <= 1 only span(j) >= REACH-1 matters: below
+        for (auto it = std::lower_bound(multi_cols.begin(), multi_cols.end(), rb.lo[i]);
+             it != multi_cols.end() && *it <= rb.hi[i]; ++it)
+            if (sl + fr.span[*it] >= PG_PIPE_REACH) mark(i + *it, i + *it);
+    }
+    for (int j = 0; j < Ly; ++j) {
+        if (fr.span[j] < PG_PIPE_REACH - 1) continue;
+        // rows whose band holds column j: hi[] and lo[] are monotone
+        const int i1 = (int)(std::lower_bound(rb.hi.begin(), rb.hi.end(), j) - rb.hi.begin());
+        const int i2 = (int)(std::upper_bound(rb.lo.begin(), rb.lo.end(), j) - rb.lo.begin()) - 1;
+        mark(i1 + j, i2 + j);
+    }
+    out->assign(nd, 0);
+    int run = 0, last_wide = -1000;
+    for (int d = 0; d < nd; ++d) {
+        run += far[d];
+        const int lo = dx.imin[d], hi = dx.imax[d];
+        uint8_t c;
+        if (hi - lo + 1 > PG_PIPE_WIDTH) { c = 3; last_wide = d; }
+        else if (d - last_wide < PG_PIPE_REACH) c = 2;
+        else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c = 2;
+        else if (run > 0) c = 2;
+        else if (fl.no_pred[hi + 1] - fl.no_pred[lo] > 0 || fr.no_pred[d - lo + 1] - fr.no_pred[d - hi] > 0) c = 2;
+        else if (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0) c = 1;
+        else c = 0;
+        (*out)[d] = c;
+    }
 }
 
 struct Arena {
@@ -148,6 +225,7 @@ struct pagan_batch {
     int *d_which = nullptr;      // [n]: ring-kernel jobs first, then the wide ones
     int n_ring = 0, n_wide = 0;
     int n_ring_small = 0;        // ring jobs whose model table fits the LDS cache (listed first)
+    bool use_pipe = true;        // LDS-staged jobs run pg_fill_pipe (default) or the older pg_fill_ring
     int max_bound = 0;           // largest traceback boundary count of any job
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -161,7 +239,7 @@ struct pagan_batch {
 
 namespace {
 
-int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb) {
+int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
     if (!jb.left || !jb.right || !jb.model) return PAGAN_E_ARG;
     int rc;
     if ((rc = check_graph(jb.left)) != PAGAN_OK) return rc;
@@ -203,8 +281,14 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb) {
             hj->tb.assign(2, 0);
         }
     }
-    hj->ring_ok = hj->dx.cells <= (long long)PG_RING_MAX_WIDTH * hj->dx.imin.size() / 2 &&
-                  edges_fit_ring(jb.left, hj->Lx) && edges_fit_ring(jb.right, hj->Ly);
+    const bool narrow = hj->dx.cells <= (long long)PG_RING_MAX_WIDTH * hj->dx.imin.size() / 2;
+    if (use_pipe) {
+        hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES) &&
+                      edges_fit_ring(jb.right, hj->Ly, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES);
+        if (hj->ring_ok) classify_diagonals(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, &hj->cls);
+    } else {
+        hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx) && edges_fit_ring(jb.right, hj->Ly);
+    }
     return PAGAN_OK;
 }
 
@@ -233,6 +317,8 @@ void carve_job(Carver &c, const pagan_job &jb, const HostJob &hj, PgDevJob *d) {
     d->table = c.take<float>((size_t)d->S * d->S);
     d->imin = c.take<int>(d->nd); d->imax = c.take<int>(d->nd); d->doff = c.take<long long>(d->nd);
     d->dsc = c.take<int>(4 * (size_t)d->nd);
+    d->psc = hj.cls.empty() ? nullptr : c.take<int>(8 * (size_t)d->nd);
+    d->fill_status = c.take<int>(1);
     d->cells = hj.dx.cells;
     d->n_bound = hj.n_bound;
     d->tb = c.take<int>(hj.tb.size());
@@ -259,15 +345,29 @@ int launch_fill(pagan_batch *b) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_ring_lds_bytes()));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_ring<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_ring_lds_bytes()));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_pipe<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_pipe_lds_bytes()));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_pipe<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_pipe_lds_bytes()));
             lds_set = true;
         }
         // model tables of <= 16 states (DNA: 15) are cached in LDS; larger ones stay in HBM/L2
-        if (b->n_ring_small > 0)
-            hipLaunchKernelGGL(pg_fill_ring<true>, dim3(b->n_ring_small), dim3(576), pg_ring_lds_bytes(), b->stream,
-                               b->d_jobs, b->d_which, b->flags);
-        if (b->n_ring > b->n_ring_small)
-            hipLaunchKernelGGL(pg_fill_ring<false>, dim3(b->n_ring - b->n_ring_small), dim3(576), pg_ring_lds_bytes(),
-                               b->stream, b->d_jobs, b->d_which + b->n_ring_small, b->flags);
+        const int n_small = b->n_ring_small, n_big = b->n_ring - b->n_ring_small;
+        if (b->use_pipe) {
+            if (n_small > 0)
+                hipLaunchKernelGGL(pg_fill_pipe<true>, dim3(n_small), dim3(320), pg_pipe_lds_bytes(), b->stream,
+                                   b->d_jobs, b->d_which, b->flags);
+            if (n_big > 0)
+                hipLaunchKernelGGL(pg_fill_pipe<false>, dim3(n_big), dim3(320), pg_pipe_lds_bytes(), b->stream,
+                                   b->d_jobs, b->d_which + n_small, b->flags);
+        } else {
+            if (n_small > 0)
+                hipLaunchKernelGGL(pg_fill_ring<true>, dim3(n_small), dim3(576), pg_ring_lds_bytes(), b->stream,
+                                   b->d_jobs, b->d_which, b->flags);
+            if (n_big > 0)
+                hipLaunchKernelGGL(pg_fill_ring<false>, dim3(n_big), dim3(576), pg_ring_lds_bytes(), b->stream,
+                                   b->d_jobs, b->d_which + n_small, b->flags);
+        }
     }
     if (b->n_wide > 0) {
         dim3 grid(b->n_wide);
@@ -433,10 +533,13 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     b->dj.resize(n);
     int max_w = 0;
     const bool force_v1 = std::getenv("PAGAN_DP_FORCE_GLOBAL_WAVEFRONT") != nullptr;   // A/B switch for profiling
+    // A/B switch: PAGAN_DP_FILL=ring runs the barrier-per-diagonal LDS kernel instead of the register wavefront
+    if (const char *f = std::getenv("PAGAN_DP_FILL")) b->use_pipe = std::strcmp(f, "ring") != 0;
+    if (const char *f = std::getenv("PAGAN_DP_DEBUG_FLAGS")) b->flags |= (uint32_t)std::strtoul(f, nullptr, 0) & 0xff00u;
     std::vector<int> which_ring, which_ring_big, which_wide;
     for (int k = 0; k < n; ++k) {
         RowBand rb;
-        int rc = validate_job(jobs[k], &b->jobs[k], &rb);
+        int rc = validate_job(jobs[k], &b->jobs[k], &rb, b->use_pipe);
         if (rc != PAGAN_OK) return rc;
         b->cells += b->jobs[k].dx.cells;
         if (b->jobs[k].n_bound > b->max_bound) b->max_bound = b->jobs[k].n_bound;
@@ -487,6 +590,15 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             }
             put(stage, d.dsc, packed.data(), packed.size());
         }
+        if (!hj.cls.empty()) {
+            std::vector<int> packed(8 * hj.dx.imin.size(), 0);
+            for (size_t t = 0; t < hj.dx.imin.size(); ++t) {
+                packed[8 * t] = hj.dx.imin[t]; packed[8 * t + 1] = hj.dx.imax[t];
+                packed[8 * t + 2] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[8 * t + 3] = (int)(hj.dx.doff[t] >> 32);
+                packed[8 * t + 4] = hj.cls[t];
+            }
+            put(stage, d.psc, packed.data(), packed.size());
+        }
         put(stage, d.tb, hj.tb.data(), hj.tb.size());
     }
     b->trace_off.resize(n); b->end_off.resize(n); b->score_off.resize(n);
@@ -499,7 +611,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         b->score_off[k] = reinterpret_cast<size_t>(d.endscore);
         rebase(d.stL); rebase(d.offL); rebase(d.srcL); rebase(d.lwL);
         rebase(d.stR); rebase(d.offR); rebase(d.srcR); rebase(d.lwR);
-        rebase(d.table); rebase(d.imin); rebase(d.imax); rebase(d.doff); rebase(d.tb); rebase(d.dsc);
+        rebase(d.table); rebase(d.imin); rebase(d.imax); rebase(d.doff); rebase(d.tb); rebase(d.dsc); if (d.psc) rebase(d.psc); rebase(d.fill_status);
         rebase(d.sc); rebase(d.bp);
         rebase(d.trace); rebase(d.endcell); rebase(d.endscore); rebase(d.segs); rebase(d.ttab);
     }

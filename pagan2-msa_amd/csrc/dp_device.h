@@ -48,6 +48,9 @@ struct PgDevJob {
     const int *imin, *imax;
     const long long *doff;
     const int *dsc;          // [nd][4] = imin, imax, doff low, doff high: one 16-byte scalar load per diagonal
+    const int *psc;          // [nd][8] = imin, imax, doff low, doff high, class, 0, 0, 0 (dp_pipe.hip; null for
+                             //           jobs of the wide kernel); class: 0 simple, 1 multi-edge, 2 general, 3 wide
+    int *fill_status;        // [1] 0 = filled; nonzero = the fill kernel abandoned a wait (internal error)
     long long cells;
     // outputs
     double *sc;              // [cells][3], state index = PAGAN_X_MAT / Y_MAT / M_MAT

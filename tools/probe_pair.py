@@ -11,6 +11,8 @@ from pagan2_msa_amd import synth, host, abi
 leaves = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 names, seqs, nwk = synth.evolve_balanced(leaves, 100000, branch=0.01, sub=0.008, indel_start=0.0008, mean_len=4.0, seed=5)
 msa = host.Msa(names, seqs, nwk, use_anchors=1).align()
+if os.environ.get("PG_NOSTORE"):
+    os.environ["PAGAN_DP_DEBUG_FLAGS"] = "0x100"
 print("timing", msa.timing())
 k = msa.n_internal - 1
 l, r, m, b = msa.node_job(k)
@@ -22,15 +24,11 @@ if os.environ.get("PG_STAMPS"):
     n_int = 3 * (l.n_sites + r.n_sites - 2)
     raw = np.zeros(n_int, np.int32)
     pg.lib().pagan_batch_debug_trace(batch._h, 0, raw.ctypes.data_as(C.c_void_p), raw.nbytes)
-    a = raw[n_int - 200:].view(np.uint64).astype(np.float64)
+    a = raw[n_int - 64:]
     for w in range(4):
-        for h, name in enumerate(("idle", "fast", "multi", "general", "wide")):
-            row = a[20 * w + 4 * h: 20 * w + 4 * h + 4]
-            n = max(row[0], 1)
-            print("wave %d %-7s steps %8d  cycles/step: head %7.1f work %8.1f barrier-wait %8.1f" %
-                  (w, name, row[0], row[1] / n, row[2] / n, row[3] / n))
-    nd = l.n_sites + r.n_sites - 3
-    print("loader: work %.1f barrier-wait %.1f cycles/step" % (a[80] / nd, a[81] / nd))
+        row = a[12 * w: 12 * w + 9]
+        print("wave %d polls: rows %d cols %d down %d up %d | sync boundary reads %d rendezvous %d active steps %d | "
+              "kcycles total %d in polls %d" % ((w,) + tuple(int(x) for x in row)))
 if os.environ.get("PG_CHECK"):
     import oracle
     bad = 0
