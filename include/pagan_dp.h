@@ -175,6 +175,8 @@ int64_t pagan_batch_cells(const pagan_batch *b);
 void pagan_batch_destroy(pagan_batch *b);
 /* diagnostic builds only: raw bytes of job k's device trace buffer                    */
 int  pagan_batch_debug_trace(pagan_batch *b, int32_t k, void *dst, int64_t bytes);
+/* diagnostic: job k's scores, [cells][3] doubles (X, Y, M), diagonal-major                */
+int  pagan_batch_debug_scores(pagan_batch *b, int32_t k, double *dst, int64_t count);
 /* diagnostic: overwrite all device outputs with 0xFF (NaN scores) before a run           */
 int  pagan_batch_debug_poison(pagan_batch *b);
 

@@ -122,6 +122,18 @@ class Batch:
             for r in res:
                 self._L.pagan_result_free(C.byref(r))
 
+    def debug_scores(self, k):
+        """Diagnostic: job k's device score array as [cells, 3] float64 (X, Y, M), diagonal-major."""
+        import numpy as np
+        out = np.empty((self.cells_of(k), 3), np.float64)
+        _check(self._L.pagan_batch_debug_scores(self._h, k, out.ctypes.data_as(C.POINTER(C.c_double)), out.size),
+               "pagan_batch_debug_scores")
+        return out
+
+    def cells_of(self, k):
+        left, right, _, band = self.jobs[k]
+        return self._L.pagan_dp_count_cells(left.n_sites, right.n_sites, C.byref(band.c) if band is not None else None)
+
     def close(self):
         if self._h:
             self._L.pagan_batch_destroy(self._h)

@@ -39,6 +39,8 @@ unsigned pg_ring_lds_bytes();
 #define PG_PIPE_REACH 16
 #define PG_PIPE_EDGE_CAP 1024
 #define PG_PIPE_SITE_EDGES 126
+#define PG_PIPE_RING 20
+#define PG_PIPE_WAKE 6
 unsigned pg_pipe_lds_bytes();
 
 namespace {
@@ -125,6 +127,7 @@ struct HostJob {
     DiagIndex dx;
     bool ring_ok = false;        // fits the LDS-staged narrow-band kernel
     std::vector<uint8_t> cls;    // per diagonal: how dp_pipe.hip computes it (empty: not a pipe job)
+    std::vector<int> sched;      // dp_pipe.hip: awake intervals of the four compute waves (dp_device.h)
     int n_bound = 0;             // traceback boundaries (dp_device.h)
     std::vector<int> tb;         // [n_bound + 2] table offsets
 };
@@ -158,11 +161,12 @@ struct SiteFeat {
     }
 };
 
-// Class of every anti-diagonal for dp_pipe.hip (its header explains the four code paths):
-//   3  wider than PG_PIPE_WIDTH cells;
-//   2  touches the first/last two rows or columns, holds a site without bwd edges, follows a wide
-//      diagonal within the ring's reach, or holds a cell (i,j) whose farthest predecessor pair lies
-//      span(i) + span(j) >= PG_PIPE_REACH diagonals back;
+// Class of every anti-diagonal for dp_pipe.hip (its header explains the five code paths):
+//   4  wider than PG_PIPE_WIDTH cells;
+//   3  touches the first/last two rows or columns, holds a site without bwd edges, or follows a wide
+//      diagonal within the ring's reach;
+//   2  holds a cell (i,j) whose farthest predecessor pair lies span(i) + span(j) >= PG_PIPE_REACH
+//      diagonals back;
 //   1  holds a site that is not simple;   0  otherwise.
 void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, const RowBand &rb,
                         const DiagIndex &dx, std::vector<uint8_t> *out) {
@@ -195,14 +199,49 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
         run += far[d];
         const int lo = dx.imin[d], hi = dx.imax[d];
         uint8_t c;
-        if (hi - lo + 1 > PG_PIPE_WIDTH) { c = 3; last_wide = d; }
-        else if (d - last_wide < PG_PIPE_REACH) c = 2;
-        else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c = 2;
+        if (hi - lo + 1 > PG_PIPE_WIDTH) { c = 4; last_wide = d; }
+        else if (d - last_wide < PG_PIPE_REACH) c = 3;
+        else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c = 3;
+        else if (fl.no_pred[hi + 1] - fl.no_pred[lo] > 0 || fr.no_pred[d - lo + 1] - fr.no_pred[d - hi] > 0) c = 3;
         else if (run > 0) c = 2;
-        else if (fl.no_pred[hi + 1] - fl.no_pred[lo] > 0 || fr.no_pred[d - lo + 1] - fr.no_pred[d - hi] > 0) c = 2;
         else if (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0) c = 1;
         else c = 0;
         (*out)[d] = c;
+    }
+}
+
+// Awake intervals of dp_pipe.hip's compute waves.  Wave w owns the rows r with (r % 256) / 64 == w; it
+// has to run from PG_PIPE_WAKE diagonals before one of its rows enters the band (operand prefetch
+// pipeline) until PG_PIPE_RING diagonals after the last one left (so that all its ring columns hold
+// -inf again); every wave runs on wide diagonals.  Layout: dp_device.h, PgDevJob::sched.
+void schedule_waves(const DiagIndex &dx, const std::vector<uint8_t> &cls, std::vector<int> *out) {
+    const int nd = (int)cls.size();
+    std::vector<int> lists[4];
+    std::vector<int> next_active(nd + 1);
+    for (int w = 0; w < 4; ++w) {
+        auto active = [&](int d) {
+            if (cls[d] == 4) return true;
+            const int lo = dx.imin[d], hi = dx.imax[d];
+            if (hi < lo) return false;
+            const int a = (lo - 64 * w) & 255;                 // lo's position relative to the wave's block
+            return a < 64 || lo + (256 - a) <= hi;
+        };
+        next_active[nd] = 1 << 30;
+        for (int d = nd - 1; d >= 0; --d) next_active[d] = active(d) ? d : next_active[d + 1];
+        int last_active = -(1 << 30);
+        bool awake = false;
+        for (int d = 0; d < nd; ++d) {
+            if (next_active[d] == d) last_active = d;
+            const bool need = next_active[d] - d <= PG_PIPE_WAKE || d - last_active <= PG_PIPE_RING;
+            if (need != awake) { lists[w].push_back(d); awake = need; }
+        }
+        if (awake) lists[w].push_back(nd);
+        lists[w].push_back(nd); lists[w].push_back(nd);
+    }
+    out->assign(4, 0);
+    for (int w = 0; w < 4; ++w) {
+        (*out)[w] = (int)out->size();
+        out->insert(out->end(), lists[w].begin(), lists[w].end());
     }
 }
 
@@ -285,7 +324,10 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
     if (use_pipe) {
         hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES) &&
                       edges_fit_ring(jb.right, hj->Ly, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES);
-        if (hj->ring_ok) classify_diagonals(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, &hj->cls);
+        if (hj->ring_ok) {
+            classify_diagonals(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, &hj->cls);
+            schedule_waves(hj->dx, hj->cls, &hj->sched);
+        }
     } else {
         hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx) && edges_fit_ring(jb.right, hj->Ly);
     }
@@ -318,6 +360,7 @@ void carve_job(Carver &c, const pagan_job &jb, const HostJob &hj, PgDevJob *d) {
     d->imin = c.take<int>(d->nd); d->imax = c.take<int>(d->nd); d->doff = c.take<long long>(d->nd);
     d->dsc = c.take<int>(4 * (size_t)d->nd);
     d->psc = hj.cls.empty() ? nullptr : c.take<int>(8 * (size_t)d->nd);
+    d->sched = hj.cls.empty() ? nullptr : c.take<int>(hj.sched.size());
     d->fill_status = c.take<int>(1);
     d->cells = hj.dx.cells;
     d->n_bound = hj.n_bound;
@@ -397,7 +440,10 @@ int replay(const HostJob &hj, const int *endcell, double endscore, const int *tr
     out->end_x_edge = endcell[4] >= 0 ? L->bwd_eid[L->bwd_off[Lx] + endcell[4]] : -1;
     out->end_y_edge = endcell[5] >= 0 ? R->bwd_eid[R->bwd_off[Ly] + endcell[5]] : -1;
     if (endcell[0] == 1) { out->status = PAGAN_DP_UNREACHABLE; return PAGAN_OK; }
-    if (endcell[0] != 0) return PAGAN_E_INTERNAL;
+    if (endcell[0] != 0) {
+        if (std::getenv("PAGAN_DP_VERBOSE")) std::fprintf(stderr, "pagan_dp: device status %d\n", endcell[0]);
+        return PAGAN_E_INTERNAL;
+    }
     const int n = endcell[6];
 
     std::vector<char> lused(L->n_edges, 0), rused(R->n_edges, 0);
@@ -594,10 +640,16 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             std::vector<int> packed(8 * hj.dx.imin.size(), 0);
             for (size_t t = 0; t < hj.dx.imin.size(); ++t) {
                 packed[8 * t] = hj.dx.imin[t]; packed[8 * t + 1] = hj.dx.imax[t];
-                packed[8 * t + 2] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[8 * t + 3] = (int)(hj.dx.doff[t] >> 32);
-                packed[8 * t + 4] = hj.cls[t];
+                const long long boff = 24 * hj.dx.doff[t];
+                packed[8 * t + 2] = (int)(boff & 0xffffffffLL); packed[8 * t + 3] = (int)(boff >> 32);
+                unsigned mask = 0;
+                for (int a = 1; a < PG_PIPE_REACH; ++a)
+                    if ((long long)t - a >= 0 && hj.cls[t - a] <= 3) mask |= 1u << a;
+                packed[8 * t + 4] = (int)(hj.cls[t] | (mask << 4));
+                packed[8 * t + 5] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[8 * t + 6] = (int)(hj.dx.doff[t] >> 32);
             }
             put(stage, d.psc, packed.data(), packed.size());
+            put(stage, d.sched, hj.sched.data(), hj.sched.size());
         }
         put(stage, d.tb, hj.tb.data(), hj.tb.size());
     }
@@ -611,7 +663,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         b->score_off[k] = reinterpret_cast<size_t>(d.endscore);
         rebase(d.stL); rebase(d.offL); rebase(d.srcL); rebase(d.lwL);
         rebase(d.stR); rebase(d.offR); rebase(d.srcR); rebase(d.lwR);
-        rebase(d.table); rebase(d.imin); rebase(d.imax); rebase(d.doff); rebase(d.tb); rebase(d.dsc); if (d.psc) rebase(d.psc); rebase(d.fill_status);
+        rebase(d.table); rebase(d.imin); rebase(d.imax); rebase(d.doff); rebase(d.tb); rebase(d.dsc); if (d.psc) { rebase(d.psc); rebase(d.sched); } rebase(d.fill_status);
         rebase(d.sc); rebase(d.bp);
         rebase(d.trace); rebase(d.endcell); rebase(d.endscore); rebase(d.segs); rebase(d.ttab);
     }
@@ -697,6 +749,14 @@ int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
 int pagan_batch_debug_poison(pagan_batch *b) {
     if (!b) return PAGAN_E_ARG;
     HIP_TRY(hipMemsetAsync(b->arena.dev + b->out_begin, 0xFF, b->arena.size - b->out_begin, b->stream));
+    return PAGAN_OK;
+}
+
+// Diagnostic: job k's score array, [cells][3] doubles in diagonal-major order (dp_device.h).
+int pagan_batch_debug_scores(pagan_batch *b, int32_t k, double *dst, int64_t count) {
+    if (!b || k < 0 || k >= b->n || !dst || count > 3 * b->jobs[k].dx.cells) return PAGAN_E_ARG;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(dst, b->dj[k].sc, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
     return PAGAN_OK;
 }
 

@@ -547,7 +547,8 @@ __global__ void pg_end_corner(const PgDevJob *__restrict__ jobs) {
     gint_w ec = J.endcell;
     ec[1] = mat; ec[2] = xi; ec[3] = yi; ec[4] = kl; ec[5] = kr; ec[6] = 0; ec[7] = 0;
     ec[0] = (best > NI) ? 0 : 1;
-    if (jobs[blockIdx.x].fill_status[0] != 0) ec[0] = 3;           // the fill kernel gave up on a wait: no result
+    // the fill kernel gave up on a wait (dp_pipe.hip, poll_ge): no result; the status names the wait
+    if (jobs[blockIdx.x].fill_status[0] != 0) ec[0] = 0x40000000 | jobs[blockIdx.x].fill_status[0];
 }
 
 // grid (K_max, n_jobs): block b.x handles boundary k = b.x + 1 of job b.y

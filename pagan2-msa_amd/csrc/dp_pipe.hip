@@ -4,34 +4,41 @@
 // Viterbi_alignment::compute_fwd_scores, src/main/viterbi_alignment.cpp:856-971, with
 // iterate_bwd_edges_for_gap VA:1328-1349 and iterate_bwd_edges_for_match VA:1353-1436).
 // What changes is how one anti-diagonal hands its scores to the next.  The fill is a chain of
-// ~2e5 dependent diagonals of 25-250 cells; its speed is the latency of ONE diagonal step.  The
-// ring kernel (dp_kernels.hip) pays an LDS write -> s_barrier -> LDS read round trip per step;
-// here the hand-over stays in registers:
+// ~2e5 dependent diagonals of 25-250 cells; its speed is the latency of ONE diagonal step, and
+// a lone wave issues one instruction per ~4-5 cycles, so that latency is the number of
+// instructions a wave executes per step.  The ring kernel (dp_kernels.hip) pays an LDS write ->
+// s_barrier -> LDS read round trip per step on top; here the hand-over stays in registers:
 //
 //   - lane T of the PNT = 256 compute lanes owns the rows i with i % 256 == T, one row at a
 //     time, and keeps its row's scores of the previous diagonal in VGPRs.  Cell (i,j) needs
 //     (i,j-1): the lane's own registers; (i-1,j): lane T-1's registers, one DPP wave shift;
 //     (i-1,j-1): what that shift delivered one step earlier.  No LDS read, no barrier.
 //   - lane 0 of a wave takes row i-1 from lane 63 of the wave "upstream" through an LDS ring
-//     sc[d % PRK][row % 256][X,Y,M] that every lane also writes each step (-inf outside the
-//     band), and that multi-edge sites read their older predecessors from;
+//     sc[d % PRK][row % 256][X,Y,M] that every awake lane also writes each step (-inf outside
+//     the band), and that multi-edge sites read their older predecessors from;
 //   - there is NO workgroup barrier.  Each wave publishes the last diagonal it completed in
 //     LDS; a wave with cells on diagonal d waits (cached flag, re-read only when stale) until
 //     its upstream neighbour has completed d-1, and no wave runs more than PLEAD diagonals
 //     ahead of its downstream neighbour, which keeps the last PAGE diagonals of the ring
 //     intact for it.  The band is a diagonal stripe, so the waves form a pipeline: the wave
-//     holding the top of the band leads, the others follow a step behind, none of them waits
-//     in the steady state;
+//     holding the top of the band leads, the others follow a step behind;
+//   - a wave whose 64 rows are nowhere near the band SLEEPS: the host lists, per wave, the
+//     diagonal intervals in which it must be awake (rows within reach of the band, plus PRK
+//     steps afterwards so that its ring columns are flushed to -inf).  A sleeping wave publishes
+//     "completed everything up to my next wake-up" and costs nothing; with a 25-70 cell band
+//     one or two waves carry the step and nobody waits for idle ones;
 //   - the host classifies every diagonal (dp_abi.hip, classify_diagonals): 0 = all cells
 //     simple (straight-line code), 1 = multi-edge sites whose predecessors are all in the
-//     ring (straight-line code for the simple lanes, an item loop for the others), 2 =
-//     general (first/last rows and columns, sites without predecessors, edges reaching past
-//     the ring: all waves rendezvous, drain their stores and read what they need from
-//     HBM/L2), 3 = wider than the lanes (computed from HBM operands like the wide kernel);
-//   - a loader wave stages 16-byte site records (state, flags, first two bwd edges) and the
-//     bwd edge lists in LDS windows ahead of the slowest compute wave;
+//     ring (straight-line code for the simple lanes, an item loop for the others), 2 = same
+//     with edges reaching past the ring (those cells come from L2; every wave keeps all but
+//     its last 24 stores retired, so a diagonal 8 steps behind every wave has landed), 3 =
+//     general (first/last rows and columns, sites without predecessors, the steps after a wide
+//     diagonal: all awake waves rendezvous and drain), 4 = wider than the lanes (computed
+//     from HBM operands like the wide kernel);
+//   - a loader wave stages 16-byte site records (state, flags, first two bwd edges), the bwd
+//     edge lists and the recent diagonal descriptors in LDS windows ahead of the slowest wave;
 //   - scores and back-pointers stream to HBM with stores nobody waits for; compute waves
-//     issue no vector-memory load outside class 2/3 diagonals.
+//     issue no vector-memory load outside class 2-4 diagonals.
 #include "dp_kcommon.h"
 
 #define PNW 4
@@ -42,7 +49,10 @@
 #define PLEAD (PRK - PAGE + 1)   // a wave computes D only when its downstream neighbour completed D-PLEAD
 #define PRW 512                  // site-record window (sites)
 #define PEC 1024                 // bwd-edge window (edges)
+#define PDR 128                  // descriptor window (diagonals)
+#define PDR_REACH 60             // oldest diagonal looked up in it
 #define PLOOK 64                 // diagonals the loader looks ahead of the slowest wave
+#define PLAND 8                  // stores of diagonal d have landed once the storing wave completed d+PLAND
 #define PSPIN_LIMIT (1 << 22)
 
 // site record, word x
@@ -53,13 +63,14 @@
 struct PipeSmem {
     double sc[PRK][PNT][3];      // X, Y, M
     pg_i4 recL[PRW], recR[PRW];  // x: state | flags | n_edges | span, y: dist0 | dist1 << 16, z/w: log-weights 0/1
+    pg_i4 dring[PDR];            // lo, hi, score byte offset (64 bit) of diagonal d at [d % PDR]
     int ebL[PRW], ebR[PRW];      // first bwd edge of the site (edge numbering of the graph)
     int esL[PEC], esR[PEC];
     float ewL[PEC], ewR[PEC];
     float table[256];
-    int progress[PNW];           // last diagonal each compute wave completed
+    int progress[PNW];           // last diagonal each compute wave completed (or sleeps through)
     int arrived[PNW];            // last rendezvous diagonal each compute wave drained for
-    int loaded[2];               // rows / columns staged by the loader
+    int loaded[3];               // rows / columns / diagonal descriptors staged by the loader
     int abort_flag;
 };
 
@@ -72,6 +83,7 @@ namespace {
 
 typedef int pg_i8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(4))) const pg_i8 *cdesc8_p;
+typedef __attribute__((address_space(4))) const int *cint_p;
 
 __device__ __forceinline__ int flag_peek(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -81,22 +93,25 @@ __device__ __forceinline__ void flag_store(int *p, int v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Spin until *p >= need.  Every wait in this kernel is satisfied by a wave that does not wait
-// for the caller (see the header); the spin limit only turns a logic error into an error
-// status instead of a hung GPU.
-__device__ __forceinline__ int poll_ge(const int *p, int need) {
+// Spin until *p >= need.  Every wait in this kernel is for a wave that is not waiting for the
+// caller (see the header); the spin limit only turns a logic error into an error status
+// instead of a hung GPU.
+// `tag` (nonzero) names the wait in the error status: kind | wave << 4 | diagonal << 8.
+__device__ __forceinline__ int poll_ge(const int *p, int need, int tag) {
     int v = flag_load(p);
     int spins = 0;
+#pragma nounroll
     while (v < need) {
-        __builtin_amdgcn_s_sleep(1);
+        if (spins < 64) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(8);
         if (++spins > PSPIN_LIMIT || flag_load(&PM.abort_flag) != 0) {
-            flag_store(&PM.abort_flag, 1);
-            return 0x7fffffff;
+            if (flag_load(&PM.abort_flag) == 0) flag_store(&PM.abort_flag, tag);
+            return 0x7ffffff0;
         }
         v = flag_load(p);
     }
     return v;
 }
+#define PTAG(kind) ((kind) | (wave << 4) | (d << 8))
 
 __device__ __forceinline__ double dpp_shr1(double v, double lane0) {
     // lane n takes lane n-1's v; lane 0 keeps `lane0` (wave_shr:1 leaves the destination of a lane
@@ -139,8 +154,8 @@ __device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_
 }
 
 __device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lane) {
-    int rows = 0, cols = 0;
-    while (rows < J.Lx || cols < J.Ly) {
+    int rows = 0, cols = 0, diags = 0;
+    for (;;) {
         int pmin = flag_load(&PM.progress[0]);
         for (int w = 1; w < PNW; ++w) { const int p = flag_load(&PM.progress[w]); pmin = p < pmin ? p : pmin; }
         if (flag_load(&PM.abort_flag) != 0) return;
@@ -152,11 +167,23 @@ __device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lan
         want_rows = want_rows < J.Lx ? want_rows : J.Lx;
         want_cols = want_cols < J.Ly ? want_cols : J.Ly;
         bool any = false;
+        // descriptors of the diagonals up to da: what a far read needs to find an old cell
+        // (entries older than dcur - PDR + PLOOK are overwritten; readers look back PDR_REACH at most)
+        while (diags <= da) {
+            const int t = diags + lane;
+            if (t <= da) {
+                const pg_i4 v = *((PG_GLOBAL const pg_i4 *)psc + 2 * t);
+                PM.dring[t & (PDR - 1)] = v;
+            }
+            diags = diags + 64 < da + 1 ? diags + 64 : da + 1;
+            any = true;
+        }
         while (rows < want_rows) { load_rec_chunk<true>(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL); rows += 64; any = true; }
         while (cols < want_cols) { load_rec_chunk<false>(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR); cols += 64; any = true; }
         if (any) {
             flag_store(&PM.loaded[0], rows);
             flag_store(&PM.loaded[1], cols);
+            flag_store(&PM.loaded[2], diags);
         } else {
             __builtin_amdgcn_s_sleep(8);
         }
@@ -176,34 +203,76 @@ __device__ __forceinline__ void edge_at(const pg_i4 &rec, int k, int site, int &
     }
 }
 
-// scores of the cell `age` diagonals back in row p (age 1..PAGE-1, diagonal known to be in the ring)
-__device__ __forceinline__ void ring_cell(int slot, int age, int p, double &xs, double &ys, double &ms) {
-    int s = slot - age;
-    s += s < 0 ? PRK : 0;
-    xs = PM.sc[s][p & (PNT - 1)][PG_X];
-    ys = PM.sc[s][p & (PNT - 1)][PG_Y];
-    ms = PM.sc[s][p & (PNT - 1)][PG_M];
-}
-
-// same, for any earlier cell: out of the ring (too old, or its diagonal never went through the
-// lanes) it is read from HBM/L2 -- only on rendezvous diagonals, after every wave drained
-__device__ __forceinline__ void any_cell(gdouble_w sc, cdesc8_p psc, int d, int slot, unsigned resident, int p, int q,
+// Scores of the cell `age` diagonals back in row p.  FAR = false: age is 1..PAGE-1 and that
+// diagonal is in the ring (class 1).  FAR = true: any earlier cell; `resmask` has bit a set when
+// diagonal d-a went through the lanes, everything else is read from L2/HBM -- after the caller
+// made sure it has landed -- through the descriptor window (or the descriptor array itself).
+template <bool FAR>
+__device__ __forceinline__ void old_cell(gdouble_w sc, cdesc8_p psc, int d, int slot, unsigned resmask, int age, int p,
                                          double &xs, double &ys, double &ms) {
-    const int dd = p + q, age = d - dd;
-    int s = slot - age;
-    s += s < 0 ? PRK : 0;
-    if (age < PAGE && ((resident >> s) & 1u)) {
+    if (!FAR || (age < PAGE && ((resmask >> age) & 1u))) {
+        int s = slot - age;
+        s += s < 0 ? PRK : 0;
         xs = PM.sc[s][p & (PNT - 1)][PG_X];
         ys = PM.sc[s][p & (PNT - 1)][PG_Y];
         ms = PM.sc[s][p & (PNT - 1)][PG_M];
     } else {
         const double NI = neg_inf();
         xs = NI; ys = NI; ms = NI;
-        const pg_i4 ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);      // first half of the 32-byte descriptor
+        const int dd = d - age;
+        pg_i4 ds;
+        if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
+        else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
         if (p >= ds.x && p <= ds.y) {
-            const long long ix = (((long long)ds.w << 32) | (unsigned)ds.z) + (p - ds.x);
-            far_cell(sc + 3 * ix, xs, ys, ms);
+            const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p - ds.x);
+            far_cell((gdouble_w)((PG_GLOBAL char *)sc + boff), xs, ys, ms);
         }
+    }
+}
+
+// Item loop of one multi-edge cell (class 1/2: interior, both sites have bwd edges): the (left edge,
+// right edge) pairs row-major, which visits the X candidates in left-list order, the Y candidates
+// in right-list order and the M candidates in the reference's pair order (VA:1396-1433).
+template <bool FAR>
+__device__ __forceinline__ void multi_cell(gdouble_w sc, cdesc8_p psc, int d, int slot, unsigned resmask, const pg_i4 &rL,
+                                           const pg_i4 &cR, int row, int j, bool reduced_terminal, double go, double ge,
+                                           double ng, double tM, double tX, double &bx, double &by, double &bm,
+                                           unsigned &px, unsigned &py, unsigned &pm) {
+    const double NI = neg_inf();
+    bx = NI; by = NI; bm = NI; px = PG_BP_NONE; py = PG_BP_NONE; pm = PG_BP_NONE;
+    const int nL = (rL.x >> PR_NE_SHIFT) & 127, nR = (cR.x >> PR_NE_SHIFT) & 127;
+    const int n_items = nL * nR;
+    int k1 = 0, k2 = 0, dL, dR;
+    double lw, rw;
+    edge_at<true>(rL, 0, row, dL, lw);
+    edge_at<false>(cR, 0, j, dR, rw);
+    for (int t = 0; t < n_items; ++t) {
+        double xs, ys, ms, c;
+        if (k2 == 0) {                                                // X candidates of left edge k1
+            old_cell<FAR>(sc, psc, d, slot, resmask, dL, row - dL, xs, ys, ms);
+            const double open = (reduced_terminal && row == dL) ? 0.0 : go;
+            const unsigned w = pack_bp(0, k1, 0, dL == 1, false);
+            c = xs + ge;            if (c > bx) { bx = c; px = w | PG_X; }
+            c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = w | PG_Y; }
+            c = (ms + ng) + open;   if (c > bx) { bx = c; px = w | PG_M; }
+        }
+        if (k1 == 0) {                                                // Y candidates of right edge k2
+            old_cell<FAR>(sc, psc, d, slot, resmask, dR, row, xs, ys, ms);
+            const double open = (reduced_terminal && j == dR) ? 0.0 : go;
+            const unsigned w = pack_bp(0, 0, k2, false, dR == 1);
+            c = ys + ge;            if (c > by) { by = c; py = w | PG_Y; }
+            c = (xs + 0.0) + go;    if (c > by) { by = c; py = w | PG_X; }
+            c = (ms + ng) + open;   if (c > by) { by = c; py = w | PG_M; }
+        }
+        {                                                             // M candidates of the pair
+            old_cell<FAR>(sc, psc, d, slot, resmask, dL + dR, row - dL, xs, ys, ms);
+            const unsigned w = pack_bp(0, k1, k2, dL == 1, dR == 1);
+            c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_M; }
+            c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_X; }
+            c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_Y; }
+        }
+        if (++k2 == nR) { k2 = 0; ++k1; if (k1 < nL) edge_at<true>(rL, k1, row, dL, lw); }
+        edge_at<false>(cR, k2, j, dR, rw);
     }
 }
 
@@ -220,8 +289,9 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
     const int lane = tid & 63;
     const int S = job->S;
     if (TAB_LDS) for (int k = tid; k < S * S; k += PNT + 64) PM.table[k] = job->table[k];
+    for (int k = tid; k < PRK * PNT * 3; k += PNT + 64) (&PM.sc[0][0][0])[k] = neg_inf();
     if (tid < PNW) { PM.progress[tid] = -1; PM.arrived[tid] = -1; }
-    if (tid == 0) { PM.loaded[0] = 0; PM.loaded[1] = 0; PM.abort_flag = 0; }
+    if (tid == 0) { PM.loaded[0] = 0; PM.loaded[1] = 0; PM.loaded[2] = 0; PM.abort_flag = 0; }
     __syncthreads();
 
     if (tid >= PNT) {
@@ -240,257 +310,226 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
     const float f_go = job->go, f_ge = job->ge, f_gE = job->gE, f_ng = job->ng;
 
     // ================= compute waves =================
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // uniform: keeps the schedule and the step counter in SGPRs
     const int up = (wave + PNW - 1) % PNW, dn = (wave + 1) % PNW;
+    const cint_p sched = (cint_p)job->sched + ((cint_p)job->sched)[wave];     // awake intervals [a,b) of this wave
     const double NI = neg_inf();
     const double go = (double)f_go, ng = (double)f_ng, ge = (double)f_ge;
     const double tng2 = (double)(2 * f_ng), tng1 = (double)(0.0f + f_ng);
     const int bslot = (tid + PNT - 1) & (PNT - 1);                 // ring column of row-1 (lane 0: the upstream wave's lane 63)
+    int rows_ld = 0, cols_ld = 0, diags_ld = 0;
 
-    int row = tid;                                                 // the row this lane is on (or waits for)
-    bool have = false;                                             // rL holds row's record
-    pg_i4 rL = {0, 0, 0, 0}, cR = {0, 0, 0, 0}, cR1 = {0, 0, 0, 0};   // records: own row, column of d, column of d+1
-    float smf = 0.0f;                                              // model score of this lane's cell on d (prefetched)
-    double pX = NI, pY = NI, pM = NI;                              // this lane's cell on d-1: (row, j-1)
-    double cX = NI, cY = NI, cM = NI;                              // (row-1, j-1) on d-2: last step's shift
-    double nbX = NI, nbY = NI, nbM = NI;                           // prefetched lane-0 operand of the next step
-    bool nb_valid = false;
-    int p_up = -1, p_dn = -1, rows_ld = 0, cols_ld = 0;
-    unsigned resident = 0;                                         // bit s: ring row s holds a diagonal the lanes wrote
-    int slot = 0, slot1 = PRK - 1;                                 // d % PRK, (d-1) % PRK
-    pg_i8 nxt = psc[0];
-#ifdef PG_PIPE_STATS
-    int st_rows = 0, st_cols = 0, st_dn = 0, st_up = 0, st_nb = 0, st_sync = 0, st_act = 0;
-    long long st_t0 = __builtin_readcyclecounter(), st_poll = 0;
-#define PSTAT(x) x
-#else
-#define PSTAT(x)
-#endif
+    for (int iv = 0;; iv += 2) {
+        const int wake = sched[iv], sleep = sched[iv + 1];
+        // asleep until `wake`: this wave's ring columns are -inf at every depth, its stores have retired
+        // and it reads nothing
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        flag_store(&PM.arrived[wave], wake - 1);
+        flag_store(&PM.progress[wave], wake - 1);
+        if (wake >= nd) break;
 
-    for (int d = 0; d < nd; ++d) {
-        const pg_i8 cur = nxt;                                     // requested at the bottom of the previous step
-        const int lo = cur.x, hi = cur.y, cls = cur.s4;
-        const long long base = ((long long)cur.w << 32) | (unsigned)cur.z;
-        const unsigned slot_bit = 1u << slot;
+        pg_i8 nxt = psc[wake];
+        int row = nxt.x + ((tid - nxt.x) & (PNT - 1));             // smallest row of this lane's residue inside or below the band
+        bool have = false;                                         // rL holds row's record
+        pg_i4 rL = {0, 0, 0, 0}, cR = {0, 0, 0, 0}, cR1 = {0, 0, 0, 0};   // records: own row, column of d, column of d+1
+        float smf = 0.0f;                                          // model score of this lane's cell on d (prefetched)
+        double pX = NI, pY = NI, pM = NI;                          // this lane's cell on d-1: (row, j-1)
+        double cX = NI, cY = NI, cM = NI;                          // (row-1, j-1) on d-2: last step's shift
+        double nbX = NI, nbY = NI, nbM = NI;                       // prefetched lane-0 operand of the next step
+        bool nb_valid = false;
+        int p_up = -1, p_dn = -1;
+        int ok_until = wake - 1;                                   // flow control holds through this diagonal without re-reading flags
+        int slot = wake % PRK, slot1 = (wake + PRK - 1) % PRK;     // d % PRK, (d-1) % PRK
+        int lo_prev = -1, hi_prev = -1;
 
-        // ---- flow control (cached counters; the polls run only when a cache is stale) ----
-        {
-            int need = hi + 3 < Lx - 1 ? hi + 3 : Lx - 1;
-            PSTAT(const long long pt0 = __builtin_readcyclecounter();)
-            if (rows_ld <= need) { rows_ld = poll_ge(&PM.loaded[0], need + 1); PSTAT(++st_rows;) }
-            need = d + 2 - lo < Ly - 1 ? d + 2 - lo : Ly - 1;
-            if (cols_ld <= need) { cols_ld = poll_ge(&PM.loaded[1], need + 1); PSTAT(++st_cols;) }
-            if (p_dn < d - PLEAD) { p_dn = poll_ge(&PM.progress[dn], d - PLEAD); PSTAT(++st_dn;) }
-            PSTAT(st_poll += __builtin_readcyclecounter() - pt0;)
-        }
-        if (cls >= 2) {
-            // rendezvous: every wave has completed d-1 and its stores have landed
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            flag_store(&PM.arrived[wave], d);
-            for (int w = 0; w < PNW; ++w) poll_ge(&PM.arrived[w], d);
-            p_up = d - 1 > p_up ? d - 1 : p_up;
-            p_dn = d - 1 > p_dn ? d - 1 : p_dn;
-            PSTAT(++st_sync;)
-        } else if (p_up < d - 1 && __any(row <= hi + 1)) {
-            PSTAT(const long long pt1 = __builtin_readcyclecounter();)
-            p_up = poll_ge(&PM.progress[up], d - 1);
-            PSTAT(++st_up; st_poll += __builtin_readcyclecounter() - pt1;)
-        }
-        const int f_up = flag_peek(&PM.progress[up]), f_dn = flag_peek(&PM.progress[dn]);   // consumed at the bottom
-        // next descriptor: requested here, after the step's only LDS wait, so that the scalar load has the
-        // whole step to land (an s_waitcnt on LDS data also waits for scalar loads in flight)
-        nxt = psc[d + 1 < nd ? d + 1 : d];
+        for (int d = wake; d < sleep; ++d) {
+            const pg_i8 cur = nxt;                                 // requested at the top of the previous step
+            const int lo = cur.x, hi = cur.y, cls = cur.s4 & 15;
+            const unsigned resmask = (unsigned)cur.s4 >> 4;
 
-        // ---- (row-1, j) on d-1: lane-1's registers, lane 0 from the ring ----
-        PSTAT(if (__any(row <= hi)) ++st_act;)
-        if (!nb_valid) {
-            PSTAT(++st_nb;)
-            if (p_up >= d - 1 && d > 0) {
-                nbX = PM.sc[slot1][bslot][PG_X]; nbY = PM.sc[slot1][bslot][PG_Y]; nbM = PM.sc[slot1][bslot][PG_M];
-            } else {
-                nbX = NI; nbY = NI; nbM = NI;                      // no lane of this wave can use it (see header)
+            // ---- flow control: flags are read only when the cached ones stop covering this step ----
+            if (d > ok_until) {
+                int need = hi + 3 < Lx - 1 ? hi + 3 : Lx - 1;
+                if (rows_ld <= need) rows_ld = poll_ge(&PM.loaded[0], need + 1, PTAG(1));
+                int margin = rows_ld >= Lx ? nd : rows_ld - 1 - need;
+                need = d + 2 - lo < Ly - 1 ? d + 2 - lo : Ly - 1;
+                if (cols_ld <= need) cols_ld = poll_ge(&PM.loaded[1], need + 1, PTAG(2));
+                const int mc = cols_ld >= Ly ? nd : cols_ld - 1 - need;
+                margin = mc < margin ? mc : margin;
+                if (p_dn < d - PLEAD) p_dn = poll_ge(&PM.progress[dn], d - PLEAD, PTAG(3));
+                if (p_up < d - 1 && __any(row <= hi + 1)) p_up = poll_ge(&PM.progress[up], d - 1, PTAG(4));
+                int until = d + margin;
+                until = p_dn + PLEAD < until ? p_dn + PLEAD : until;
+                until = p_up + 1 < until ? p_up + 1 : until;
+                ok_until = until > d ? until : d;
             }
-        }
-        const double aX = dpp_shr1(pX, nbX), aY = dpp_shr1(pY, nbY), aM = dpp_shr1(pM, nbM);
+            if (cls >= 2) {
+                if (diags_ld < d) diags_ld = poll_ge(&PM.loaded[2], d, PTAG(5));        // descriptor window covers every earlier diagonal
+                if (cls == 2) {
+                    // far reads: the cells are at least PAGE diagonals old; they have landed once every wave
+                    // completed d - PLAND (each wave keeps all but its last 24 stores retired)
+                    int slowest = flag_peek(&PM.progress[0]);
+                    for (int w = 1; w < PNW; ++w) { const int p = flag_peek(&PM.progress[w]); slowest = p < slowest ? p : slowest; }
+                    if (__builtin_amdgcn_readfirstlane(slowest) < d - PLAND)
+                        for (int w = 0; w < PNW; ++w) poll_ge(&PM.progress[w], d - PLAND, PTAG(6));
+                } else {
+                    // rendezvous: every awake wave has completed d-1 and its stores have landed
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    flag_store(&PM.arrived[wave], d);
+                    for (int w = 0; w < PNW; ++w) poll_ge(&PM.arrived[w], d, PTAG(7));
+                    p_up = d - 1 > p_up ? d - 1 : p_up;
+                    p_dn = d - 1 > p_dn ? d - 1 : p_dn;
+                }
+            }
+            // next descriptor: requested here, after the step's LDS wait, so that the scalar load has the
+            // whole step to land (an s_waitcnt on LDS data also waits for scalar loads in flight)
+            nxt = psc[d + 1 < nd ? d + 1 : d];
 
-        // ---- row hand-over: a lane whose row left the band takes the next one of its residue ----
-        if (row < lo) { row += PNT; pX = NI; pY = NI; pM = NI; have = false; }
-        if (!have && row <= hi + 3 && row < Lx) { rL = PM.recL[row & (PRW - 1)]; have = true; }
-        const int j = d - row;
-        const bool active = row <= hi;
-        double bx = NI, by = NI, bm = NI;
-        unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
+            // ---- (row-1, j) on d-1: lane-1's registers, lane 0 from the ring ----
+            if (!nb_valid) {
+                if (p_up >= d - 1 && d > 0) {
+                    nbX = PM.sc[slot1][bslot][PG_X]; nbY = PM.sc[slot1][bslot][PG_Y]; nbM = PM.sc[slot1][bslot][PG_M];
+                } else {
+                    nbX = NI; nbY = NI; nbM = NI;                  // no lane of this wave can use it (see header)
+                }
+            }
+            const double aX = dpp_shr1(pX, nbX), aY = dpp_shr1(pY, nbY), aM = dpp_shr1(pM, nbM);
 
-        if (cls <= 1) {
-            // ---- interior diagonal, every predecessor in registers or in the ring ----
-            const int wi = rL.x, wj = cR.x;
-            if (active) {
-                // straight-line code for simple cells: `+ 0.0` (log_gap_close, unit edge weights) is
-                // omitted -- exact, no score is ever -0.0
-                bx = first_max3(aX + ge, aY + go, (aM + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
-                by = first_max3(pY + ge, pX + go, (pM + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
-                if (!TAB_LDS) smf = far_f32(table + ((rL.x & 0xffff) + (cR.x & 0xffff) * S));
-                const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
-                bm = first_max3(cM + tM, cX + tX, cY + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
-                                PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
-                if (cls == 1 && !(wi & wj & PR_SIMPLE)) {
-                    // ---- multi-edge site: (left edge, right edge) pairs row-major, which visits the X
-                    // candidates in left-list order, the Y candidates in right-list order and the M
-                    // candidates in the reference's pair order (VA:1396-1433) ----
-                    bx = NI; by = NI; bm = NI; px = PG_BP_NONE; py = PG_BP_NONE; pm = PG_BP_NONE;
-                    const int nL = (wi >> PR_NE_SHIFT) & 127, nR = (wj >> PR_NE_SHIFT) & 127;
-                    const int n_items = nL * nR;
-                    int k1 = 0, k2 = 0, dL, dR;
-                    double lw, rw;
-                    edge_at<true>(rL, 0, row, dL, lw);
-                    edge_at<false>(cR, 0, j, dR, rw);
+            // ---- row hand-over: a lane whose row left the band takes the next one of its residue ----
+            if (lo != lo_prev || hi != hi_prev) {
+                if (row < lo) { row += PNT; pX = NI; pY = NI; pM = NI; have = false; }
+                if (!have && row <= hi + 3 && row < Lx) { rL = PM.recL[row & (PRW - 1)]; have = true; }
+                lo_prev = lo; hi_prev = hi;
+            }
+            const int j = d - row;
+            const bool active = row <= hi;
+            double bx = NI, by = NI, bm = NI;
+            unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
+
+            if (cls <= 2) {
+                // ---- interior diagonal ----
+                if (active) {
+                    // straight-line code for simple cells: `+ 0.0` (log_gap_close, unit edge weights) is
+                    // omitted -- exact, no score is ever -0.0
+                    bx = first_max3(aX + ge, aY + go, (aM + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
+                    by = first_max3(pY + ge, pX + go, (pM + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
+                    if (!TAB_LDS) smf = far_f32(table + ((rL.x & 0xffff) + (cR.x & 0xffff) * S));
+                    const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
+                    bm = first_max3(cM + tM, cX + tX, cY + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
+                                    PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
+                    if (cls != 0 && !(rL.x & cR.x & PR_SIMPLE)) {
+                        if (cls == 1)
+                            multi_cell<false>(sc_out, psc, d, slot, resmask, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX,
+                                              bx, by, bm, px, py, pm);
+                        else
+                            multi_cell<true>(sc_out, psc, d, slot, resmask, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX,
+                                             bx, by, bm, px, py, pm);
+                    }
+                }
+            } else if (cls == 3) {
+                // ---- general (first/last rows and columns, sites without predecessors, the two steps after a
+                // wide diagonal): records and edges from the LDS windows, cells from the ring or from HBM ----
+                if (active) {
+                    const pg_i4 gl = PM.recL[row & (PRW - 1)], gr = PM.recR[j & (PRW - 1)];
+                    const int wi = gl.x, wj = gr.x;
+                    int l0 = 0, nL = 0, r0 = 0, nR = 0, n_items = 0;
+                    double tM = 0, tX = 0;
+                    if (row > 0) { l0 = PM.ebL[row & (PRW - 1)]; nL = (wi >> PR_NE_SHIFT) & 127; }
+                    if (j > 0) { r0 = PM.ebR[j & (PRW - 1)]; nR = (wj >> PR_NE_SHIFT) & 127; }
+                    if (row == 0 && j == 0) bm = 0.0;                          // initialise_array_corner, VA:725-736
+                    else n_items = (nL > 0 ? nL : 1) * (nR > 0 ? nR : 1);
+                    if (nL > 0 && nR > 0) {
+                        const int ti = (wi & 0xffff) + (wj & 0xffff) * S;
+                        const float sm = TAB_LDS ? PM.table[ti] : far_f32(table + ti);
+                        tM = tng2 + (double)sm; tX = tng1 + (double)sm;
+                    }
+                    const double extX = (double)(((j == 0 || j == Ly - 1) && !no_terminal_edges) ? f_gE : f_ge);
+                    const double extY = (double)(((row == 0 || row == Lx - 1) && !no_terminal_edges) ? f_gE : f_ge);
+                    const int nRp = nR > 0 ? nR : 1;
+                    int k1 = 0, k2 = 0;
                     for (int t = 0; t < n_items; ++t) {
-                        double xs, ys, ms, c;
-                        if (k2 == 0) {                                                // X candidates of left edge k1
-                            ring_cell(slot, dL, row - dL, xs, ys, ms);
-                            const double open = (reduced_terminal && row == dL) ? 0.0 : go;
-                            const unsigned w = pack_bp(0, k1, 0, dL == 1, false);
-                            c = xs + ge;            if (c > bx) { bx = c; px = w | PG_X; }
-                            c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = w | PG_Y; }
-                            c = (ms + ng) + open;   if (c > bx) { bx = c; px = w | PG_M; }
+                        int p = 0, q = 0;
+                        double lw = 0, rw = 0, xs, ys, ms, c;
+                        if (nL > 0) { p = PM.esL[(l0 + k1) & (PEC - 1)]; lw = (double)PM.ewL[(l0 + k1) & (PEC - 1)]; }
+                        if (nR > 0) { q = PM.esR[(r0 + k2) & (PEC - 1)]; rw = (double)PM.ewR[(r0 + k2) & (PEC - 1)]; }
+                        if (nL > 0 && k2 == 0) {                                     // X candidates of left edge k1
+                            old_cell<true>(sc_out, psc, d, slot, resmask, row - p, p, xs, ys, ms);
+                            const double open = (reduced_terminal && p == 0) ? 0.0 : go;
+                            c = xs + extX;          if (c > bx) { bx = c; px = pack_bp(PG_X, k1, 0, p == row - 1, false); }
+                            c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, k1, 0, p == row - 1, false); }
+                            c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, k1, 0, p == row - 1, false); }
                         }
-                        if (k1 == 0) {                                                // Y candidates of right edge k2
-                            ring_cell(slot, dR, row, xs, ys, ms);
-                            const double open = (reduced_terminal && j == dR) ? 0.0 : go;
-                            const unsigned w = pack_bp(0, 0, k2, false, dR == 1);
-                            c = ys + ge;            if (c > by) { by = c; py = w | PG_Y; }
-                            c = (xs + 0.0) + go;    if (c > by) { by = c; py = w | PG_X; }
-                            c = (ms + ng) + open;   if (c > by) { by = c; py = w | PG_M; }
+                        if (nR > 0 && k1 == 0) {                                     // Y candidates of right edge k2
+                            old_cell<true>(sc_out, psc, d, slot, resmask, j - q, row, xs, ys, ms);
+                            const double open = (reduced_terminal && q == 0) ? 0.0 : go;
+                            c = ys + extY;          if (c > by) { by = c; py = pack_bp(PG_Y, 0, k2, false, q == j - 1); }
+                            c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, k2, false, q == j - 1); }
+                            c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, k2, false, q == j - 1); }
                         }
-                        {                                                             // M candidates of the pair
-                            ring_cell(slot, dL + dR, row - dL, xs, ys, ms);
-                            const unsigned w = pack_bp(0, k1, k2, dL == 1, dR == 1);
-                            c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_M; }
-                            c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_X; }
-                            c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_Y; }
+                        if (nL > 0 && nR > 0) {                                      // M candidates of the pair
+                            old_cell<true>(sc_out, psc, d, slot, resmask, (row - p) + (j - q), p, xs, ys, ms);
+                            c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_M, k1, k2, p == row - 1, q == j - 1); }
+                            c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_X, k1, k2, p == row - 1, q == j - 1); }
+                            c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, k1, k2, p == row - 1, q == j - 1); }
                         }
-                        if (++k2 == nR) { k2 = 0; ++k1; if (k1 < nL) edge_at<true>(rL, k1, row, dL, lw); }
-                        edge_at<false>(cR, k2, j, dR, rw);
+                        if (++k2 == nRp) { k2 = 0; ++k1; }
                     }
                 }
             }
-        } else if (cls == 2) {
-            // ---- general (first/last rows and columns, sites without predecessors, edges reaching past
-            // the ring, the two steps after a wide diagonal): records and edges from the LDS windows,
-            // cells from the ring or from HBM ----
-            if (active) {
-                const pg_i4 gl = PM.recL[row & (PRW - 1)], gr = PM.recR[j & (PRW - 1)];
-                const int wi = gl.x, wj = gr.x;
-                int l0 = 0, nL = 0, r0 = 0, nR = 0, n_items = 0;
-                double tM = 0, tX = 0;
-                if (row > 0) { l0 = PM.ebL[row & (PRW - 1)]; nL = (wi >> PR_NE_SHIFT) & 127; }
-                if (j > 0) { r0 = PM.ebR[j & (PRW - 1)]; nR = (wj >> PR_NE_SHIFT) & 127; }
-                if (row == 0 && j == 0) bm = 0.0;                          // initialise_array_corner, VA:725-736
-                else n_items = (nL > 0 ? nL : 1) * (nR > 0 ? nR : 1);
-                if (nL > 0 && nR > 0) {
-                    const int ti = (wi & 0xffff) + (wj & 0xffff) * S;
-                    const float smf = TAB_LDS ? PM.table[ti] : far_f32(table + ti);
-                    tM = tng2 + (double)smf; tX = tng1 + (double)smf;
-                }
-                const double extX = (double)(((j == 0 || j == Ly - 1) && !no_terminal_edges) ? f_gE : f_ge);
-                const double extY = (double)(((row == 0 || row == Lx - 1) && !no_terminal_edges) ? f_gE : f_ge);
-                const int nRp = nR > 0 ? nR : 1;
-                int k1 = 0, k2 = 0;
-                for (int t = 0; t < n_items; ++t) {
-                    int p = 0, q = 0;
-                    double lw = 0, rw = 0, xs, ys, ms, c;
-                    if (nL > 0) { p = PM.esL[(l0 + k1) & (PEC - 1)]; lw = (double)PM.ewL[(l0 + k1) & (PEC - 1)]; }
-                    if (nR > 0) { q = PM.esR[(r0 + k2) & (PEC - 1)]; rw = (double)PM.ewR[(r0 + k2) & (PEC - 1)]; }
-                    if (nL > 0 && k2 == 0) {                                     // X candidates of left edge k1
-                        any_cell(sc_out, psc, d, slot, resident, p, j, xs, ys, ms);
-                        const double open = (reduced_terminal && p == 0) ? 0.0 : go;
-                        c = xs + extX;          if (c > bx) { bx = c; px = pack_bp(PG_X, k1, 0, p == row - 1, false); }
-                        c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, k1, 0, p == row - 1, false); }
-                        c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, k1, 0, p == row - 1, false); }
-                    }
-                    if (nR > 0 && k1 == 0) {                                     // Y candidates of right edge k2
-                        any_cell(sc_out, psc, d, slot, resident, row, q, xs, ys, ms);
-                        const double open = (reduced_terminal && q == 0) ? 0.0 : go;
-                        c = ys + extY;          if (c > by) { by = c; py = pack_bp(PG_Y, 0, k2, false, q == j - 1); }
-                        c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, k2, false, q == j - 1); }
-                        c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, k2, false, q == j - 1); }
-                    }
-                    if (nL > 0 && nR > 0) {                                      // M candidates of the pair
-                        any_cell(sc_out, psc, d, slot, resident, p, q, xs, ys, ms);
-                        c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_M, k1, k2, p == row - 1, q == j - 1); }
-                        c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_X, k1, k2, p == row - 1, q == j - 1); }
-                        c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, k1, k2, p == row - 1, q == j - 1); }
-                    }
-                    if (++k2 == nRp) { k2 = 0; ++k1; }
-                }
-            }
-        }
 
-        if (cls <= 2) {
-            // ---- commit: EVERY lane writes its column of the ring row (-inf outside the band) ----
-            PM.sc[slot][tid][PG_X] = bx;
-            PM.sc[slot][tid][PG_Y] = by;
-            PM.sc[slot][tid][PG_M] = bm;
-            if (active && !(flags & 0x100u)) {                  // bit 8: timing experiment without the HBM stores
-                typedef double d2 __attribute__((ext_vector_type(2)));
-                typedef unsigned u3 __attribute__((ext_vector_type(3)));
-                PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + 24 * base;
-                PG_GLOBAL char *brow = (PG_GLOBAL char *)bp_out + 12 * base;
-                const unsigned off = (unsigned)(row - lo);
-                d2 xy; xy.x = bx; xy.y = by;
-                *(PG_GLOBAL d2 *)(srow + 24u * off) = xy;
-                *(PG_GLOBAL double *)(srow + 24u * off + 16u) = bm;
-                u3 b3; b3.x = px; b3.y = py; b3.z = pm;
-                *(PG_GLOBAL u3 *)(brow + 12u * off) = b3;
+            if (cls <= 3) {
+                // ---- commit: EVERY lane writes its column of the ring row (-inf outside the band) ----
+                PM.sc[slot][tid][PG_X] = bx;
+                PM.sc[slot][tid][PG_Y] = by;
+                PM.sc[slot][tid][PG_M] = bm;
+                if (active && !(flags & 0x100u)) {                  // bit 8: timing experiment without the HBM stores
+                    typedef double d2 __attribute__((ext_vector_type(2)));
+                    typedef unsigned u3 __attribute__((ext_vector_type(3)));
+                    const long long soff = ((long long)cur.w << 32) | (unsigned)cur.z;     // 24 * first cell of d
+                    PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff;
+                    PG_GLOBAL char *brow = (PG_GLOBAL char *)bp_out + (soff >> 1);
+                    const unsigned off = (unsigned)(row - lo);
+                    d2 xy; xy.x = bx; xy.y = by;
+                    *(PG_GLOBAL d2 *)(srow + 24u * off) = xy;
+                    *(PG_GLOBAL double *)(srow + 24u * off + 16u) = bm;
+                    u3 b3; b3.x = px; b3.y = py; b3.z = pm;
+                    *(PG_GLOBAL u3 *)(brow + 12u * off) = b3;
+                }
+                // all but this wave's last 24 stores (8 steps' worth) have retired: what a far read relies on
+                asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            } else {
+                // ---- wider than the lanes: every cell from HBM/L2 operands (all waves are here, drained) ----
+                const PgDevJob *cold = job;
+                asm volatile("" : "+s"(cold));                     // opaque: keeps these loads inside the branch
+                const View J = load_view(cold);
+                const pg_i8 p1 = psc[d > 0 ? d - 1 : 0], p2 = psc[d > 1 ? d - 2 : 0];
+                const Diag g1 = {p1.x, d > 0 ? p1.y : p1.x - 1, ((long long)p1.s6 << 32) | (unsigned)p1.s5};
+                const Diag g2 = {p2.x, d > 1 ? p2.y : p2.x - 1, ((long long)p2.s6 << 32) | (unsigned)p2.s5};
+                const long long base = ((long long)cur.s6 << 32) | (unsigned)cur.s5;
+                for (int i = lo + tid; i <= hi; i += PNT)
+                    fill_cell_hbm(J, d, g1, g2, i, d - i, base + (i - lo), no_terminal_edges, reduced_terminal);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                have = false;                                      // the record window may have lapped this lane's row
+                hi_prev = -1;
             }
-            resident |= slot_bit;
-        } else {
-            // ---- wider than the lanes: every cell from HBM/L2 operands (all waves are here, drained) ----
-            const PgDevJob *cold = job;
-            asm volatile("" : "+s"(cold));                         // opaque: keeps these loads inside the branch
-            const View J = load_view(cold);
-            const pg_i8 p1 = psc[d > 0 ? d - 1 : 0], p2 = psc[d > 1 ? d - 2 : 0];
-            const Diag g1 = {p1.x, d > 0 ? p1.y : p1.x - 1, ((long long)p1.w << 32) | (unsigned)p1.z};
-            const Diag g2 = {p2.x, d > 1 ? p2.y : p2.x - 1, ((long long)p2.w << 32) | (unsigned)p2.z};
-            for (int i = lo + tid; i <= hi; i += PNT)
-                fill_cell_hbm(J, d, g1, g2, i, d - i, base + (i - lo), no_terminal_edges, reduced_terminal);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            resident &= ~slot_bit;
-            have = false;                                          // the record window may have lapped this lane's row
-        }
 
-        // ---- carry ----
-        cX = aX; cY = aY; cM = aM;
-        pX = bx; pY = by; pM = bm;
-        flag_store(&PM.progress[wave], d);                         // after the ring writes: LDS ops of a wave execute in order
-        // Operand pipeline, so that a step has ONE LDS wait, at its top: the column record two steps
-        // ahead (column d+2-row), the model score one step ahead (a lane's row record is in its
-        // registers at least three steps before the row enters the band), the next descriptor.
-        cR = cR1;
-        cR1 = PM.recR[(d + 2 - row) & (PRW - 1)];
-        {
-            const int ti = (rL.x & 0xffff) + (cR.x & 0xffff) * S;
-            smf = TAB_LDS ? PM.table[ti & 255] : 0.0f;
+            // ---- carry ----
+            cX = aX; cY = aY; cM = aM;
+            pX = bx; pY = by; pM = bm;
+            flag_store(&PM.progress[wave], d);                     // after the ring writes: LDS ops of a wave execute in order
+            // Operand pipeline, so that a step has ONE LDS wait, at its top: the column record two steps
+            // ahead (column d+2-row), the model score one step ahead (a lane's row record is in its
+            // registers at least three steps before the row enters the band).
+            cR = cR1;
+            cR1 = PM.recR[(d + 2 - row) & (PRW - 1)];
+            if (TAB_LDS) smf = PM.table[((rL.x & 0xffff) + (cR.x & 0xffff) * S) & 255];
+            // lane 0's operand of the next step, if the upstream wave has already produced it
+            nb_valid = p_up >= d;
+            if (nb_valid) { nbX = PM.sc[slot][bslot][PG_X]; nbY = PM.sc[slot][bslot][PG_Y]; nbM = PM.sc[slot][bslot][PG_M]; }
+            slot1 = slot;
+            slot = slot + 1 == PRK ? 0 : slot + 1;
         }
-        {
-            const int u = __builtin_amdgcn_readfirstlane(f_up), w = __builtin_amdgcn_readfirstlane(f_dn);
-            p_up = u > p_up ? u : p_up;
-            p_dn = w > p_dn ? w : p_dn;
-        }
-        // lane 0's operand of the next step, if the upstream wave has already produced it
-        nb_valid = p_up >= d;
-        if (nb_valid) { nbX = PM.sc[slot][bslot][PG_X]; nbY = PM.sc[slot][bslot][PG_Y]; nbM = PM.sc[slot][bslot][PG_M]; }
-        slot1 = slot;
-        slot = slot + 1 == PRK ? 0 : slot + 1;
     }
-#ifdef PG_PIPE_STATS
-    if (lane == 0) {
-        PG_GLOBAL int *o = (PG_GLOBAL int *)job->trace + 3 * (Lx + Ly) - 64 + 12 * wave;
-        const long long tot = __builtin_readcyclecounter() - st_t0;
-        o[0] = st_rows; o[1] = st_cols; o[2] = st_dn; o[3] = st_up; o[4] = st_nb; o[5] = st_sync; o[6] = st_act;
-        o[7] = (int)(tot >> 10); o[8] = (int)(st_poll >> 10);
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) *(PG_GLOBAL int *)job->fill_status = flag_load(&PM.abort_flag);
 }
