@@ -359,7 +359,7 @@ void carve_job(Carver &c, const pagan_job &jb, const HostJob &hj, PgDevJob *d) {
     d->table = c.take<float>((size_t)d->S * d->S);
     d->imin = c.take<int>(d->nd); d->imax = c.take<int>(d->nd); d->doff = c.take<long long>(d->nd);
     d->dsc = c.take<int>(4 * (size_t)d->nd);
-    d->psc = hj.cls.empty() ? nullptr : c.take<int>(8 * (size_t)d->nd);
+    d->psc = hj.cls.empty() ? nullptr : c.take<int>(8 * ((size_t)d->nd + 1));     // one entry of padding
     d->sched = hj.cls.empty() ? nullptr : c.take<int>(hj.sched.size());
     d->fill_status = c.take<int>(1);
     d->cells = hj.dx.cells;
@@ -637,7 +637,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             put(stage, d.dsc, packed.data(), packed.size());
         }
         if (!hj.cls.empty()) {
-            std::vector<int> packed(8 * hj.dx.imin.size(), 0);
+            std::vector<int> packed(8 * (hj.dx.imin.size() + 1), 0);
             for (size_t t = 0; t < hj.dx.imin.size(); ++t) {
                 packed[8 * t] = hj.dx.imin[t]; packed[8 * t + 1] = hj.dx.imax[t];
                 const long long boff = 24 * hj.dx.doff[t];
@@ -645,7 +645,8 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
                 unsigned mask = 0;
                 for (int a = 1; a < PG_PIPE_REACH; ++a)
                     if ((long long)t - a >= 0 && hj.cls[t - a] <= 3) mask |= 1u << a;
-                packed[8 * t + 4] = (int)(hj.cls[t] | (mask << 4));
+                const unsigned pair = t + 1 < hj.cls.size() && hj.cls[t + 1] <= 1 ? 1u : 0u;   // the next step is hot too
+                packed[8 * t + 4] = (int)(hj.cls[t] | (pair << 4) | (mask << 5));
                 packed[8 * t + 5] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[8 * t + 6] = (int)(hj.dx.doff[t] >> 32);
             }
             put(stage, d.psc, packed.data(), packed.size());

@@ -208,12 +208,20 @@ __device__ __forceinline__ void lds_barrier() {
 
 // First-wins maximum of three candidates (first_is_bigger, basic_alignment.h:449-462, applied in
 // candidate order to an incumbent of -inf): the value is the plain maximum, the winner is the
-// first candidate equal to it, and nobody wins when all three are -inf.
+// first candidate equal to it, and nobody wins when all three are -inf.  Branch-free: two
+// v_max_f64 for the value, three compares + three selects for the winner (a lone wave pays
+// 5-8 cycles per instruction and ~20 per taken branch).  v_max returns +0 for (+0, -0) whatever
+// the order, where a compare-and-select keeps the incumbent's sign; a score can only be -0.0
+// when an input parameter is -0.0f, and the host keeps such jobs off the kernels using this.
 __device__ __forceinline__ double first_max3(double c1, double c2, double c3, unsigned f1, unsigned f2, unsigned f3,
                                              unsigned &bp) {
-    const double m23 = c2 > c3 ? c2 : c3;
-    const double m = c1 > m23 ? c1 : m23;          // no NaNs on this path, so this is max()
-    bp = (m == neg_inf()) ? PG_BP_NONE : (c1 == m ? f1 : (c2 == m ? f2 : f3));
+    const double m23 = __builtin_fmax(c2, c3);
+    const double m = __builtin_fmax(c1, m23);
+    const bool w3 = c3 > c2;             // a later candidate wins only if strictly greater
+    const bool w23 = m23 > c1;
+    unsigned b = w3 ? f3 : f2;
+    b = w23 ? b : f1;
+    bp = (m > neg_inf()) ? b : PG_BP_NONE;
     return m;
 }
 

@@ -40,6 +40,7 @@
 //   - scores and back-pointers stream to HBM with stores nobody waits for; compute waves
 //     issue no vector-memory load outside class 2-4 diagonals.
 #include "dp_kcommon.h"
+#include <type_traits>
 
 #define PNW 4
 #define PNT (64 * PNW)
@@ -276,7 +277,41 @@ __device__ __forceinline__ void multi_cell(gdouble_w sc, cdesc8_p psc, int d, in
     }
 }
 
+__device__ __forceinline__ double in_vgpr(double x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// Commit of one step: EVERY lane writes its column of the ring row (-inf outside the band); cells
+// inside the band go to HBM, 24 B of scores + 12 B of back-pointers at the diagonal's offset.
+__device__ __forceinline__ void commit_cell(gdouble_w sc_out, gu32_w bp_out, const pg_i8 &cur, int slot, int tid, int off,
+                                            bool active, double bx, double by, double bm, unsigned px, unsigned py, unsigned pm) {
+    PM.sc[slot][tid][PG_X] = bx;
+    PM.sc[slot][tid][PG_Y] = by;
+    PM.sc[slot][tid][PG_M] = bm;
+    if (active) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u3 __attribute__((ext_vector_type(3)));
+        const long long soff = ((long long)cur.w << 32) | (unsigned)cur.z;     // 24 * first cell of the diagonal
+        PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff;
+        PG_GLOBAL char *brow = (PG_GLOBAL char *)bp_out + (soff >> 1);
+        d2 xy; xy.x = bx; xy.y = by;
+        *(PG_GLOBAL d2 *)(srow + 24u * (unsigned)off) = xy;
+        *(PG_GLOBAL double *)(srow + 24u * (unsigned)off + 16u) = bm;
+        u3 b3; b3.x = px; b3.y = py; b3.z = pm;
+        *(PG_GLOBAL u3 *)(brow + 12u * (unsigned)off) = b3;
+    }
+    // all but this wave's last 24 stores (8 steps' worth) have retired: what a far read relies on
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+}
+
 } // namespace
+
+#ifdef PG_PIPE_STATS
+#define PSTAMP(k) do { const long long t_ = __builtin_readcyclecounter(); if (st_on) st_acc[k] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define PSTAMP(k)
+#endif
 
 template <bool TAB_LDS>
 __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restrict__ jobs, const int *__restrict__ which,
@@ -314,10 +349,17 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
     const int up = (wave + PNW - 1) % PNW, dn = (wave + 1) % PNW;
     const cint_p sched = (cint_p)job->sched + ((cint_p)job->sched)[wave];     // awake intervals [a,b) of this wave
     const double NI = neg_inf();
-    const double go = (double)f_go, ng = (double)f_ng, ge = (double)f_ge;
-    const double tng2 = (double)(2 * f_ng), tng1 = (double)(0.0f + f_ng);
+    // the recurrence's constants live in VGPRs: a VALU instruction reads one SGPR operand at most, and the
+    // loop is short of SGPRs, not of VGPRs
+    const double go = in_vgpr((double)f_go), ng = in_vgpr((double)f_ng), ge = in_vgpr((double)f_ge);
+    const double tng2 = in_vgpr((double)(2 * f_ng)), tng1 = in_vgpr((double)(0.0f + f_ng));
     const int bslot = (tid + PNT - 1) & (PNT - 1);                 // ring column of row-1 (lane 0: the upstream wave's lane 63)
     int rows_ld = 0, cols_ld = 0, diags_ld = 0;
+#ifdef PG_PIPE_STATS
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
+    int st_n = 0;
+    bool st_on = false;
+#endif
 
     for (int iv = 0;; iv += 2) {
         const int wake = sched[iv], sleep = sched[iv + 1];
@@ -328,26 +370,32 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
         flag_store(&PM.progress[wave], wake - 1);
         if (wake >= nd) break;
 
-        pg_i8 nxt = psc[wake];
-        int row = nxt.x + ((tid - nxt.x) & (PNT - 1));             // smallest row of this lane's residue inside or below the band
+        cdesc8_p pp = psc + wake;                                  // descriptor last requested
+        pg_i8 dA = *pp, dB = dA;                                   // descriptors of this step / the next one (roles alternate)
+        int row = dA.x + ((tid - dA.x) & (PNT - 1));               // smallest row of this lane's residue inside or below the band
         bool have = false;                                         // rL holds row's record
-        pg_i4 rL = {0, 0, 0, 0}, cR = {0, 0, 0, 0}, cR1 = {0, 0, 0, 0};   // records: own row, column of d, column of d+1
+        pg_i4 rL = {0, 0, 0, 0};
+        pg_i4 ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};                // column records of this step / the next one (roles alternate)
         float smf = 0.0f;                                          // model score of this lane's cell on d (prefetched)
-        double pX = NI, pY = NI, pM = NI;                          // this lane's cell on d-1: (row, j-1)
-        double cX = NI, cY = NI, cM = NI;                          // (row-1, j-1) on d-2: last step's shift
-        double nbX = NI, nbY = NI, nbM = NI;                       // prefetched lane-0 operand of the next step
+        // four register sets whose roles rotate with period 2 (no copies in the steady state):
+        //   P  this lane's cell on d-1, (row, j-1)          C  (row-1, j-1) on d-2: last step's shift
+        //   A  in: lane 0's operand if prefetched, out: (row-1, j) on d-1          R  out: this step's cell
+        double r1x = NI, r1y = NI, r1m = NI, r2x = NI, r2y = NI, r2m = NI;
+        double r3x = NI, r3y = NI, r3m = NI, r4x = NI, r4y = NI, r4m = NI;
         bool nb_valid = false;
-        int p_up = -1, p_dn = -1;
-        int ok_until = wake - 1;                                   // flow control holds through this diagonal without re-reading flags
+        int p_up = -1, p_dn = -1;                                  // cached progress of the neighbours
+        int ok_until = wake - 1;                                   // flow control holds through this diagonal without reading a flag
         int slot = wake % PRK, slot1 = (wake + PRK - 1) % PRK;     // d % PRK, (d-1) % PRK
         int lo_prev = -1, hi_prev = -1;
 
-        for (int d = wake; d < sleep; ++d) {
-            const pg_i8 cur = nxt;                                 // requested at the top of the previous step
+        // One diagonal.  HOT (a tag type): the class is 0 or 1 and the step runs as one half of a pair.
+        auto step = [&](auto hot_tag, const int d, const pg_i8 &cur, pg_i8 &oth, double &PX, double &PY, double &PM_,
+                        double &CX, double &CY, double &CM, double &AX, double &AY, double &AM, double &RX, double &RY,
+                        double &RM, pg_i4 &cra, const pg_i4 &crb) {
+            constexpr bool HOT = decltype(hot_tag)::value;
             const int lo = cur.x, hi = cur.y, cls = cur.s4 & 15;
-            const unsigned resmask = (unsigned)cur.s4 >> 4;
-
-            // ---- flow control: flags are read only when the cached ones stop covering this step ----
+            PSTAMP(6);
+            // ---- flow control: flags are read only when the cached values stop covering this step ----
             if (d > ok_until) {
                 int need = hi + 3 < Lx - 1 ? hi + 3 : Lx - 1;
                 if (rows_ld <= need) rows_ld = poll_ge(&PM.loaded[0], need + 1, PTAG(1));
@@ -356,15 +404,18 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                 if (cols_ld <= need) cols_ld = poll_ge(&PM.loaded[1], need + 1, PTAG(2));
                 const int mc = cols_ld >= Ly ? nd : cols_ld - 1 - need;
                 margin = mc < margin ? mc : margin;
-                if (p_dn < d - PLEAD) p_dn = poll_ge(&PM.progress[dn], d - PLEAD, PTAG(3));
-                if (p_up < d - 1 && __any(row <= hi + 1)) p_up = poll_ge(&PM.progress[up], d - 1, PTAG(4));
-                int until = d + margin;
-                until = p_dn + PLEAD < until ? p_dn + PLEAD : until;
-                until = p_up + 1 < until ? p_up + 1 : until;
+                {   // downstream neighbour: take what it has published, wait only for what this step needs
+                    const int w = flag_load(&PM.progress[dn]);
+                    p_dn = w > p_dn ? w : p_dn;
+                }
+                if (d - PLEAD > p_dn) p_dn = poll_ge(&PM.progress[dn], d - PLEAD, PTAG(3));
+                const int until = p_dn + PLEAD < d + margin ? p_dn + PLEAD : d + margin;
                 ok_until = until > d ? until : d;
             }
-            if (cls >= 2) {
-                if (diags_ld < d) diags_ld = poll_ge(&PM.loaded[2], d, PTAG(5));        // descriptor window covers every earlier diagonal
+            // upstream neighbour: only a wave with a row about to use (row-1, .) has to wait for it
+            if (d - 1 > p_up && __any(row <= hi + 1)) p_up = poll_ge(&PM.progress[up], d - 1, PTAG(4));
+            if (!HOT && cls >= 2) {
+                if (diags_ld < d) diags_ld = poll_ge(&PM.loaded[2], d, PTAG(5));      // descriptor window covers every earlier diagonal
                 if (cls == 2) {
                     // far reads: the cells are at least PAGE diagonals old; they have landed once every wave
                     // completed d - PLAND (each wave keeps all but its last 24 stores retired)
@@ -381,55 +432,76 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                     p_dn = d - 1 > p_dn ? d - 1 : p_dn;
                 }
             }
-            // next descriptor: requested here, after the step's LDS wait, so that the scalar load has the
-            // whole step to land (an s_waitcnt on LDS data also waits for scalar loads in flight)
-            nxt = psc[d + 1 < nd ? d + 1 : d];
+            PSTAMP(0);
 
-            // ---- (row-1, j) on d-1: lane-1's registers, lane 0 from the ring ----
+            // ---- (row-1, j) on d-1: lane-1's registers, lane 0 from the ring (prefetched into A) ----
             if (!nb_valid) {
                 if (p_up >= d - 1 && d > 0) {
-                    nbX = PM.sc[slot1][bslot][PG_X]; nbY = PM.sc[slot1][bslot][PG_Y]; nbM = PM.sc[slot1][bslot][PG_M];
+                    AX = PM.sc[slot1][bslot][PG_X]; AY = PM.sc[slot1][bslot][PG_Y]; AM = PM.sc[slot1][bslot][PG_M];
                 } else {
-                    nbX = NI; nbY = NI; nbM = NI;                  // no lane of this wave can use it (see header)
+                    AX = NI; AY = NI; AM = NI;                     // no lane of this wave can use it (see header)
                 }
             }
-            const double aX = dpp_shr1(pX, nbX), aY = dpp_shr1(pY, nbY), aM = dpp_shr1(pM, nbM);
+            AX = dpp_shr1(PX, AX); AY = dpp_shr1(PY, AY); AM = dpp_shr1(PM_, AM);
+            PSTAMP(1);
+            // next descriptor: requested here, after the step's LDS wait, so that the scalar load has the
+            // whole step to land (an s_waitcnt on LDS data also waits for scalar loads in flight); the
+            // array carries one entry of padding
+            ++pp;
+            oth = *pp;
 
             // ---- row hand-over: a lane whose row left the band takes the next one of its residue ----
-            if (lo != lo_prev || hi != hi_prev) {
-                if (row < lo) { row += PNT; pX = NI; pY = NI; pM = NI; have = false; }
-                if (!have && row <= hi + 3 && row < Lx) { rL = PM.recL[row & (PRW - 1)]; have = true; }
-                lo_prev = lo; hi_prev = hi;
+            if (lo != lo_prev) {
+                lo_prev = lo;
+                if (row < lo) { row += PNT; PX = NI; PY = NI; PM_ = NI; have = false; }
+                hi_prev = -2;
             }
+            if (hi != hi_prev) {
+                hi_prev = hi;
+                if (!have && row <= hi + 3) { rL = PM.recL[row & (PRW - 1)]; have = true; }
+            }
+            PSTAMP(2);
             const int j = d - row;
             const bool active = row <= hi;
             double bx = NI, by = NI, bm = NI;
             unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
 
-            if (cls <= 2) {
-                // ---- interior diagonal ----
+            if (HOT || cls <= 1) {
+                // ================= interior diagonal, every predecessor in registers or in the ring =================
                 if (active) {
                     // straight-line code for simple cells: `+ 0.0` (log_gap_close, unit edge weights) is
                     // omitted -- exact, no score is ever -0.0
-                    bx = first_max3(aX + ge, aY + go, (aM + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
-                    by = first_max3(pY + ge, pX + go, (pM + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
-                    if (!TAB_LDS) smf = far_f32(table + ((rL.x & 0xffff) + (cR.x & 0xffff) * S));
+                    bx = first_max3(AX + ge, AY + go, (AM + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
+                    by = first_max3(PY + ge, PX + go, (PM_ + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
+                    if (!TAB_LDS) smf = far_f32(table + ((rL.x & 0xffff) + (cra.x & 0xffff) * S));
                     const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
-                    bm = first_max3(cM + tM, cX + tX, cY + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
+                    bm = first_max3(CM + tM, CX + tX, CY + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
                                     PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
-                    if (cls != 0 && !(rL.x & cR.x & PR_SIMPLE)) {
-                        if (cls == 1)
-                            multi_cell<false>(sc_out, psc, d, slot, resmask, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX,
-                                              bx, by, bm, px, py, pm);
-                        else
-                            multi_cell<true>(sc_out, psc, d, slot, resmask, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX,
+                    if (cls != 0 && !(rL.x & cra.x & PR_SIMPLE))
+                        multi_cell<false>(sc_out, psc, d, slot, 0u, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX,
+                                          bx, by, bm, px, py, pm);
+                }
+                PSTAMP(3);
+                commit_cell(sc_out, bp_out, cur, slot, tid, row - lo, active, bx, by, bm, px, py, pm);
+                PSTAMP(4);
+            } else if (cls <= 3) {
+                const unsigned resmask = (unsigned)cur.s4 >> 5;
+                if (cls == 2) {
+                    // ---- interior, some edges reach past the ring ----
+                    if (active) {
+                        bx = first_max3(AX + ge, AY + go, (AM + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
+                        by = first_max3(PY + ge, PX + go, (PM_ + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
+                        if (!TAB_LDS) smf = far_f32(table + ((rL.x & 0xffff) + (cra.x & 0xffff) * S));
+                        const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
+                        bm = first_max3(CM + tM, CX + tX, CY + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
+                                        PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
+                        if (!(rL.x & cra.x & PR_SIMPLE))
+                            multi_cell<true>(sc_out, psc, d, slot, resmask, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX,
                                              bx, by, bm, px, py, pm);
                     }
-                }
-            } else if (cls == 3) {
-                // ---- general (first/last rows and columns, sites without predecessors, the two steps after a
-                // wide diagonal): records and edges from the LDS windows, cells from the ring or from HBM ----
-                if (active) {
+                } else if (active) {
+                    // ---- general (first/last rows and columns, sites without predecessors, the steps after a wide
+                    // diagonal): records and edges from the LDS windows, cells from the ring or from HBM ----
                     const pg_i4 gl = PM.recL[row & (PRW - 1)], gr = PM.recR[j & (PRW - 1)];
                     const int wi = gl.x, wj = gr.x;
                     int l0 = 0, nL = 0, r0 = 0, nR = 0, n_items = 0;
@@ -475,28 +547,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                         if (++k2 == nRp) { k2 = 0; ++k1; }
                     }
                 }
-            }
-
-            if (cls <= 3) {
-                // ---- commit: EVERY lane writes its column of the ring row (-inf outside the band) ----
-                PM.sc[slot][tid][PG_X] = bx;
-                PM.sc[slot][tid][PG_Y] = by;
-                PM.sc[slot][tid][PG_M] = bm;
-                if (active && !(flags & 0x100u)) {                  // bit 8: timing experiment without the HBM stores
-                    typedef double d2 __attribute__((ext_vector_type(2)));
-                    typedef unsigned u3 __attribute__((ext_vector_type(3)));
-                    const long long soff = ((long long)cur.w << 32) | (unsigned)cur.z;     // 24 * first cell of d
-                    PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff;
-                    PG_GLOBAL char *brow = (PG_GLOBAL char *)bp_out + (soff >> 1);
-                    const unsigned off = (unsigned)(row - lo);
-                    d2 xy; xy.x = bx; xy.y = by;
-                    *(PG_GLOBAL d2 *)(srow + 24u * off) = xy;
-                    *(PG_GLOBAL double *)(srow + 24u * off + 16u) = bm;
-                    u3 b3; b3.x = px; b3.y = py; b3.z = pm;
-                    *(PG_GLOBAL u3 *)(brow + 12u * off) = b3;
-                }
-                // all but this wave's last 24 stores (8 steps' worth) have retired: what a far read relies on
-                asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                commit_cell(sc_out, bp_out, cur, slot, tid, row - lo, active, bx, by, bm, px, py, pm);
             } else {
                 // ---- wider than the lanes: every cell from HBM/L2 operands (all waves are here, drained) ----
                 const PgDevJob *cold = job;
@@ -510,26 +561,57 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                     fill_cell_hbm(J, d, g1, g2, i, d - i, base + (i - lo), no_terminal_edges, reduced_terminal);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 have = false;                                      // the record window may have lapped this lane's row
-                hi_prev = -1;
+                hi_prev = -2;
             }
 
-            // ---- carry ----
-            cX = aX; cY = aY; cM = aM;
-            pX = bx; pY = by; pM = bm;
+            // ---- hand the step over: R is the lane's cell, A the shift; both are read by the next step ----
+            RX = bx; RY = by; RM = bm;
             flag_store(&PM.progress[wave], d);                     // after the ring writes: LDS ops of a wave execute in order
             // Operand pipeline, so that a step has ONE LDS wait, at its top: the column record two steps
-            // ahead (column d+2-row), the model score one step ahead (a lane's row record is in its
-            // registers at least three steps before the row enters the band).
-            cR = cR1;
-            cR1 = PM.recR[(d + 2 - row) & (PRW - 1)];
-            if (TAB_LDS) smf = PM.table[((rL.x & 0xffff) + (cR.x & 0xffff) * S) & 255];
-            // lane 0's operand of the next step, if the upstream wave has already produced it
+            // ahead (column d+2-row) replaces this step's, the model score one step ahead (a lane's row
+            // record is in its registers at least three steps before the row enters the band).
+            cra = PM.recR[(d + 2 - row) & (PRW - 1)];
+            if (TAB_LDS) smf = PM.table[((rL.x & 0xffff) + (crb.x & 0xffff) * S) & 255];
+            // lane 0's operand of the next step, if the upstream wave has already produced it: into the set
+            // that was C here and is A there
             nb_valid = p_up >= d;
-            if (nb_valid) { nbX = PM.sc[slot][bslot][PG_X]; nbY = PM.sc[slot][bslot][PG_Y]; nbM = PM.sc[slot][bslot][PG_M]; }
+            if (nb_valid) { CX = PM.sc[slot][bslot][PG_X]; CY = PM.sc[slot][bslot][PG_Y]; CM = PM.sc[slot][bslot][PG_M]; }
             slot1 = slot;
             slot = slot + 1 == PRK ? 0 : slot + 1;
+            PSTAMP(5);
+        };
+
+        int d = wake;
+        while (d < sleep) {
+#ifdef PG_PIPE_STATS
+            st_on = (dA.s4 & 15) == 0 && __any(row <= dA.y && row >= dA.x);
+            st_t = __builtin_readcyclecounter();
+            if (st_on) st_n += 2;
+#endif
+            if ((dA.s4 & 0x1e) == 0x10 && d + 1 < sleep) {
+                // two hot steps: the register sets swap roles and are back in place afterwards
+                step(std::true_type(), d, dA, dB, r1x, r1y, r1m, r2x, r2y, r2m, r3x, r3y, r3m, r4x, r4y, r4m, ca, cb);
+                step(std::true_type(), d + 1, dB, dA, r4x, r4y, r4m, r3x, r3y, r3m, r2x, r2y, r2m, r1x, r1y, r1m, cb, ca);
+                d += 2;
+            } else {
+                step(std::false_type(), d, dA, dB, r1x, r1y, r1m, r2x, r2y, r2m, r3x, r3y, r3m, r4x, r4y, r4m, ca, cb);
+                // a single step leaves the sets rotated by one: put them back
+                { const pg_i8 t = dA; dA = dB; dB = t; }
+                { const pg_i4 t = ca; ca = cb; cb = t; }
+                double t;
+                t = r1x; r1x = r4x; r4x = t;  t = r1y; r1y = r4y; r4y = t;  t = r1m; r1m = r4m; r4m = t;
+                t = r2x; r2x = r3x; r3x = t;  t = r2y; r2y = r3y; r3y = t;  t = r2m; r2m = r3m; r3m = t;
+                d += 1;
+            }
         }
     }
+#ifdef PG_PIPE_STATS
+    if (lane == 0) {
+        PG_GLOBAL int *o = (PG_GLOBAL int *)job->trace + 3 * (Lx + Ly) - 200 + 12 * wave;
+        o[0] = st_n;
+        for (int k = 0; k < 7; ++k) o[1 + k] = (int)(st_acc[k] >> 4);
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) *(PG_GLOBAL int *)job->fill_status = flag_load(&PM.abort_flag);
 }

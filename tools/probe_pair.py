@@ -10,7 +10,11 @@ from pagan2_msa_amd import synth, host, abi
 
 leaves = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 names, seqs, nwk = synth.evolve_balanced(leaves, 100000, branch=0.01, sub=0.008, indel_start=0.0008, mean_len=4.0, seed=5)
+if os.environ.get("PG_ALIGN_RING"):
+    os.environ["PAGAN_DP_FILL"] = "ring"      # tree walk on the reference kernel; only the timed batch uses the experiment
 msa = host.Msa(names, seqs, nwk, use_anchors=1).align()
+if os.environ.get("PG_ALIGN_RING"):
+    os.environ["PAGAN_DP_FILL"] = "pipe"
 if os.environ.get("PG_NOSTORE"):
     os.environ["PAGAN_DP_DEBUG_FLAGS"] = "0x100"
 print("timing", msa.timing())
@@ -24,11 +28,12 @@ if os.environ.get("PG_STAMPS"):
     n_int = 3 * (l.n_sites + r.n_sites - 2)
     raw = np.zeros(n_int, np.int32)
     pg.lib().pagan_batch_debug_trace(batch._h, 0, raw.ctypes.data_as(C.c_void_p), raw.nbytes)
-    a = raw[n_int - 64:]
+    a = raw[n_int - 200:]
+    names = ("flow control", "lds wait + dpp", "descriptor request + hand-over", "compute", "commit", "carry + prefetch", "loop edge")
     for w in range(4):
-        row = a[12 * w: 12 * w + 9]
-        print("wave %d polls: rows %d cols %d down %d up %d | sync boundary reads %d rendezvous %d active steps %d | "
-              "kcycles total %d in polls %d" % ((w,) + tuple(int(x) for x in row)))
+        n = max(int(a[12 * w]), 1)
+        print("wave %d: %d class-0 steps with cells; cycles/step: " % (w, n) +
+              ", ".join("%s %.0f" % (names[k], 16.0 * a[12 * w + 1 + k] / n) for k in range(7)))
 if os.environ.get("PG_CHECK"):
     import oracle
     bad = 0
