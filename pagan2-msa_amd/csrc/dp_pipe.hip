@@ -69,6 +69,7 @@ struct PipeSmem {
     int esL[PEC], esR[PEC];
     float ewL[PEC], ewR[PEC];
     float table[256];
+    double null_cell[4];         // -inf, -inf, -inf: what a missing second edge reads
     int progress[PNW];           // last diagonal each compute wave completed (or sleeps through)
     int arrived[PNW];            // last rendezvous diagonal each compute wave drained for
     int loaded[3];               // rows / columns / diagonal descriptors staged by the loader
@@ -277,6 +278,74 @@ __device__ __forceinline__ void multi_cell(gdouble_w sc, cdesc8_p psc, int d, in
     }
 }
 
+// One candidate of a cell state: replaces the incumbent only if strictly greater (first wins).
+__device__ __forceinline__ void cand(double c, unsigned f, double &best, unsigned &bp) {
+    const bool gt = c > best;
+    bp = gt ? f : bp;
+    best = __builtin_fmax(best, c);
+}
+
+// Multi-edge cell whose sites have at most two bwd edges each (nearly all of them: a site after a gap has
+// the edge from its predecessor and the one that skips the gap), every predecessor in the ring: the up
+// to 2 + 2 + 4 cells are read at once and the up to 24 candidates evaluated in the reference's order
+// (X by left edge, Y by right edge, M by (left, right) pair, row-major) as straight-line code -- one
+// LDS latency and independent instruction streams instead of one dependent loop iteration per pair.
+// A missing second edge reads the all -inf null cell, whose candidates can never win.
+__device__ __forceinline__ void multi2_cell(int slot, const pg_i4 &rL, const pg_i4 &cR, int row, int j, bool reduced_terminal,
+                                            double go, double ge, double ng, double tM, double tX, double &bx, double &by,
+                                            double &bm, unsigned &px, unsigned &py, unsigned &pm) {
+    const double NI = neg_inf();
+    const bool l1 = ((rL.x >> PR_NE_SHIFT) & 127) > 1, r1 = ((cR.x >> PR_NE_SHIFT) & 127) > 1;
+    const int dL0 = rL.y & 0xffff, dL1 = (int)((unsigned)rL.y >> 16), dR0 = cR.y & 0xffff, dR1 = (int)((unsigned)cR.y >> 16);
+    const double lw0 = (double)__int_as_float(rL.z), lw1 = (double)__int_as_float(rL.w);
+    const double rw0 = (double)__int_as_float(cR.z), rw1 = (double)__int_as_float(cR.w);
+    auto cell = [&](int age, int p, bool present, double &xs, double &ys, double &ms) {
+        int s = slot - age;
+        s += s < 0 ? PRK : 0;
+        const double *c = present ? &PM.sc[s][p & (PNT - 1)][0] : &PM.null_cell[0];
+        xs = c[PG_X]; ys = c[PG_Y]; ms = c[PG_M];
+    };
+    double xa_x, xa_y, xa_m, xb_x, xb_y, xb_m, ya_x, ya_y, ya_m, yb_x, yb_y, yb_m;
+    double m00x, m00y, m00m, m01x, m01y, m01m, m10x, m10y, m10m, m11x, m11y, m11m;
+    cell(dL0, row - dL0, true, xa_x, xa_y, xa_m);
+    cell(dL1, row - dL1, l1, xb_x, xb_y, xb_m);
+    cell(dR0, row, true, ya_x, ya_y, ya_m);
+    cell(dR1, row, r1, yb_x, yb_y, yb_m);
+    cell(dL0 + dR0, row - dL0, true, m00x, m00y, m00m);
+    cell(dL0 + dR1, row - dL0, r1, m01x, m01y, m01m);
+    cell(dL1 + dR0, row - dL1, l1, m10x, m10y, m10m);
+    cell(dL1 + dR1, row - dL1, l1 && r1, m11x, m11y, m11m);
+    const unsigned aL0 = dL0 == 1 ? PG_BP_ADJL : 0u, aL1 = dL1 == 1 ? PG_BP_ADJL : 0u;
+    const unsigned aR0 = dR0 == 1 ? PG_BP_ADJR : 0u, aR1 = dR1 == 1 ? PG_BP_ADJR : 0u;
+    bx = NI; by = NI; bm = NI; px = PG_BP_NONE; py = PG_BP_NONE; pm = PG_BP_NONE;
+    {   // X: gap in the right sequence, candidates per left edge (VA:898-915)
+        const double o0 = (reduced_terminal && row == dL0) ? 0.0 : go, o1 = (reduced_terminal && row == dL1) ? 0.0 : go;
+        cand(xa_x + ge, aL0 | PG_X, bx, px); cand((xa_y + 0.0) + go, aL0 | PG_Y, bx, px); cand((xa_m + ng) + o0, aL0 | PG_M, bx, px);
+        const unsigned w1 = aL1 | (1u << 4);
+        cand(xb_x + ge, w1 | PG_X, bx, px); cand((xb_y + 0.0) + go, w1 | PG_Y, bx, px); cand((xb_m + ng) + o1, w1 | PG_M, bx, px);
+    }
+    {   // Y: gap in the left sequence, candidates per right edge (VA:927-944)
+        const double o0 = (reduced_terminal && j == dR0) ? 0.0 : go, o1 = (reduced_terminal && j == dR1) ? 0.0 : go;
+        cand(ya_y + ge, aR0 | PG_Y, by, py); cand((ya_x + 0.0) + go, aR0 | PG_X, by, py); cand((ya_m + ng) + o0, aR0 | PG_M, by, py);
+        const unsigned w1 = aR1 | (1u << 18);
+        cand(yb_y + ge, w1 | PG_Y, by, py); cand((yb_x + 0.0) + go, w1 | PG_X, by, py); cand((yb_m + ng) + o1, w1 | PG_M, by, py);
+    }
+    {   // M: (left edge, right edge) pairs row-major (VA:1396-1433)
+        unsigned w = aL0 | aR0;
+        cand(((m00m + tM) + lw0) + rw0, w | PG_M, bm, pm); cand(((m00x + tX) + lw0) + rw0, w | PG_X, bm, pm);
+        cand(((m00y + tX) + lw0) + rw0, w | PG_Y, bm, pm);
+        w = aL0 | aR1 | (1u << 18);
+        cand(((m01m + tM) + lw0) + rw1, w | PG_M, bm, pm); cand(((m01x + tX) + lw0) + rw1, w | PG_X, bm, pm);
+        cand(((m01y + tX) + lw0) + rw1, w | PG_Y, bm, pm);
+        w = aL1 | aR0 | (1u << 4);
+        cand(((m10m + tM) + lw1) + rw0, w | PG_M, bm, pm); cand(((m10x + tX) + lw1) + rw0, w | PG_X, bm, pm);
+        cand(((m10y + tX) + lw1) + rw0, w | PG_Y, bm, pm);
+        w = aL1 | aR1 | (1u << 4) | (1u << 18);
+        cand(((m11m + tM) + lw1) + rw1, w | PG_M, bm, pm); cand(((m11x + tX) + lw1) + rw1, w | PG_X, bm, pm);
+        cand(((m11y + tX) + lw1) + rw1, w | PG_Y, bm, pm);
+    }
+}
+
 __device__ __forceinline__ double in_vgpr(double x) {
     asm volatile("" : "+v"(x));
     return x;
@@ -325,6 +394,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
     const int S = job->S;
     if (TAB_LDS) for (int k = tid; k < S * S; k += PNT + 64) PM.table[k] = job->table[k];
     for (int k = tid; k < PRK * PNT * 3; k += PNT + 64) (&PM.sc[0][0][0])[k] = neg_inf();
+    if (tid < 4) PM.null_cell[tid] = neg_inf();
     if (tid < PNW) { PM.progress[tid] = -1; PM.arrived[tid] = -1; }
     if (tid == 0) { PM.loaded[0] = 0; PM.loaded[1] = 0; PM.loaded[2] = 0; PM.abort_flag = 0; }
     __syncthreads();
@@ -356,7 +426,8 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
     const int bslot = (tid + PNT - 1) & (PNT - 1);                 // ring column of row-1 (lane 0: the upstream wave's lane 63)
     int rows_ld = 0, cols_ld = 0, diags_ld = 0;
 #ifdef PG_PIPE_STATS
-    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_cls_t[5] = {0, 0, 0, 0, 0};
+    int st_cls_n[5] = {0, 0, 0, 0, 0};
     int st_n = 0;
     bool st_on = false;
 #endif
@@ -395,6 +466,10 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
             constexpr bool HOT = decltype(hot_tag)::value;
             const int lo = cur.x, hi = cur.y, cls = cur.s4 & 15;
             PSTAMP(6);
+#ifdef PG_PIPE_STATS
+            const long long st_step0 = __builtin_readcyclecounter();
+            const bool st_has = __any(row <= hi && row >= lo);
+#endif
             // ---- flow control: flags are read only when the cached values stop covering this step ----
             if (d > ok_until) {
                 int need = hi + 3 < Lx - 1 ? hi + 3 : Lx - 1;
@@ -447,7 +522,12 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
             // next descriptor: requested here, after the step's LDS wait, so that the scalar load has the
             // whole step to land (an s_waitcnt on LDS data also waits for scalar loads in flight); the
             // array carries one entry of padding
-            ++pp;
+            {   // (the empty asm ties the address to the shift's result: without it the compiler hoists the load
+                //  above the LDS wait)
+                unsigned long long pv = (unsigned long long)(pp + 1);
+                asm volatile("" : "+s"(pv) : "v"(AX), "v"(AY), "v"(AM));
+                pp = (cdesc8_p)pv;
+            }
             oth = *pp;
 
             // ---- row hand-over: a lane whose row left the band takes the next one of its residue ----
@@ -477,9 +557,15 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                     const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
                     bm = first_max3(CM + tM, CX + tX, CY + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
                                     PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
-                    if (cls != 0 && !(rL.x & cra.x & PR_SIMPLE))
-                        multi_cell<false>(sc_out, psc, d, slot, 0u, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX,
-                                          bx, by, bm, px, py, pm);
+                    if (cls != 0 && !(rL.x & cra.x & PR_SIMPLE)) {
+                        // sites with at most two bwd edges each: straight-line; more: the item loop
+                        const int nl = (rL.x >> PR_NE_SHIFT) & 127, nr = (cra.x >> PR_NE_SHIFT) & 127;
+                        if ((unsigned)(nl - 1) < 2u && (unsigned)(nr - 1) < 2u)
+                            multi2_cell(slot, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX, bx, by, bm, px, py, pm);
+                        else
+                            multi_cell<false>(sc_out, psc, d, slot, 0u, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX,
+                                              bx, by, bm, px, py, pm);
+                    }
                 }
                 PSTAMP(3);
                 commit_cell(sc_out, bp_out, cur, slot, tid, row - lo, active, bx, by, bm, px, py, pm);
@@ -579,6 +665,12 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
             slot1 = slot;
             slot = slot + 1 == PRK ? 0 : slot + 1;
             PSTAMP(5);
+#ifdef PG_PIPE_STATS
+            if (st_has) {
+                const long long dt = __builtin_readcyclecounter() - st_step0;
+                for (int c = 0; c < 5; ++c) if (c == cls) { st_cls_t[c] += dt; ++st_cls_n[c]; }
+            }
+#endif
         };
 
         int d = wake;
@@ -610,6 +702,8 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
         PG_GLOBAL int *o = (PG_GLOBAL int *)job->trace + 3 * (Lx + Ly) - 200 + 12 * wave;
         o[0] = st_n;
         for (int k = 0; k < 7; ++k) o[1 + k] = (int)(st_acc[k] >> 4);
+        PG_GLOBAL int *q = (PG_GLOBAL int *)job->trace + 3 * (Lx + Ly) - 400 + 12 * wave;
+        for (int c = 0; c < 5; ++c) { q[c] = st_cls_n[c]; q[5 + c] = (int)(st_cls_t[c] >> 8); }
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

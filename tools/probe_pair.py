@@ -34,6 +34,12 @@ if os.environ.get("PG_STAMPS"):
         n = max(int(a[12 * w]), 1)
         print("wave %d: %d class-0 steps with cells; cycles/step: " % (w, n) +
               ", ".join("%s %.0f" % (names[k], 16.0 * a[12 * w + 1 + k] / n) for k in range(7)))
+if os.environ.get("PG_STAMPS"):
+    b2 = raw[n_int - 400:]
+    for w in range(4):
+        n = b2[12 * w: 12 * w + 5].astype(np.int64); t = b2[12 * w + 5: 12 * w + 10].astype(np.int64) * 256
+        print("wave %d steps with cells by class (n, Mcycles, cycles/step): " % w +
+              "  ".join("c%d %d %.0fM %.0f" % (c, n[c], t[c] / 1e6, t[c] / max(n[c], 1)) for c in range(5)))
 if os.environ.get("PG_CHECK"):
     import oracle
     bad = 0
