@@ -175,6 +175,11 @@ int64_t pagan_batch_cells(const pagan_batch *b);
 void pagan_batch_destroy(pagan_batch *b);
 /* diagnostic builds only: raw bytes of job k's device trace buffer                    */
 int  pagan_batch_debug_trace(pagan_batch *b, int32_t k, void *dst, int64_t bytes);
+/* diagnostic, host only (no device needed): the plan the banded fill kernel would get for a job --
+ * cls[Lx+Ly-1] = class of every anti-diagonal (0 simple, 1 multi-edge, 2 multi-edge with far edges,
+ * 3 general, 4 wide) and the four compute waves' awake intervals (layout: dp_device.h, sched)      */
+int  pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, const pagan_band *band,
+                         uint8_t *cls, int32_t n_cls, int32_t *sched, int32_t sched_cap, int32_t *sched_len);
 /* diagnostic: job k's scores, [cells][3] doubles (X, Y, M), diagonal-major                */
 int  pagan_batch_debug_scores(pagan_batch *b, int32_t k, double *dst, int64_t count);
 /* diagnostic: overwrite all device outputs with 0xFF (NaN scores) before a run           */

@@ -85,6 +85,30 @@ def align(left, right, model, band=None, flags=0, device=-1):
         L.pagan_result_free(C.byref(res))
 
 
+def debug_plan(left, right, band=None):
+    """Diagnostic (host only): (classes[Lx+Ly-1] uint8, [awake intervals of wave 0..3]) the banded fill kernel
+    would be given for this job."""
+    import numpy as np
+    L = lib()
+    nd = left.n_sites + right.n_sites - 3
+    cls = np.zeros(nd, np.uint8)
+    cap = 8 * nd + 64
+    sched = np.zeros(cap, np.int32)
+    n = C.c_int32()
+    _check(L.pagan_dp_debug_plan(C.byref(left.c), C.byref(right.c), C.byref(band.c) if band is not None else None,
+                                 cls.ctypes.data_as(C.POINTER(C.c_uint8)), nd, sched.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 cap, C.byref(n)), "pagan_dp_debug_plan")
+    waves = []
+    for w in range(4):
+        k = int(sched[w])
+        iv = []
+        while sched[k] < nd:
+            iv.append((int(sched[k]), int(sched[k + 1])))
+            k += 2
+        waves.append(iv)
+    return cls, waves
+
+
 class Batch:
     """Jobs uploaded once and kept resident in HBM; run() replays the hot path on them."""
 

@@ -142,6 +142,16 @@ bool edges_fit_ring(const pagan_graph *g, int rows, int cap = PG_RING_EDGE_CAP, 
     return true;
 }
 
+bool has_negative_zero(const pagan_job &jb) {
+    auto neg0 = [](float f) { return f == 0.0f && std::signbit(f); };
+    const pagan_model *m = jb.model;
+    if (neg0(m->log_gap_open) || neg0(m->log_gap_ext) || neg0(m->log_gap_end_ext) || neg0(m->log_non_gap)) return true;
+    for (int k = 0; k < m->n_states * m->n_states; ++k) if (neg0(m->log_score[k])) return true;
+    for (const pagan_graph *g : {jb.left, jb.right})
+        for (int k = 0; k < g->bwd_off[g->n_sites]; ++k) if (neg0(g->bwd_logw[k])) return true;
+    return false;
+}
+
 // What the fill kernel may assume about a site without looking at its edge list.
 struct SiteFeat {
     std::vector<int> span;            // farthest bwd edge, in sites (0: no bwd edge)
@@ -320,7 +330,11 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
             hj->tb.assign(2, 0);
         }
     }
-    const bool narrow = hj->dx.cells <= (long long)PG_RING_MAX_WIDTH * hj->dx.imin.size() / 2;
+    bool narrow = hj->dx.cells <= (long long)PG_RING_MAX_WIDTH * hj->dx.imin.size() / 2;
+    // The LDS kernels take maxima with v_max_f64, which returns +0 for (+0, -0) in either order where the
+    // reference's compare keeps the incumbent's sign: a job with a negative zero among its parameters
+    // runs on the HBM wavefront kernel, which compares.
+    if (has_negative_zero(jb)) narrow = false;
     if (use_pipe) {
         hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES) &&
                       edges_fit_ring(jb.right, hj->Ly, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES);
@@ -543,6 +557,31 @@ int pagan_dp_device_count(void) {
 
 int pagan_dp_select_device(int32_t device) {
     HIP_TRY(hipSetDevice(device));
+    return PAGAN_OK;
+}
+
+// Host-only: the per-diagonal classes and the wave schedule pg_fill_pipe would be given for this job
+// (what validate_job computes); lets the planner be tested without a device.
+int pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, const pagan_band *band, uint8_t *cls_out,
+                        int32_t n_cls, int32_t *sched_out, int32_t sched_cap, int32_t *sched_len) {
+    if (!left || !right || !cls_out || !sched_out || !sched_len) return PAGAN_E_ARG;
+    int rc;
+    if ((rc = check_graph(left)) != PAGAN_OK) return rc;
+    if ((rc = check_graph(right)) != PAGAN_OK) return rc;
+    const int Lx = left->n_sites - 1, Ly = right->n_sites - 1;
+    if (n_cls != Lx + Ly - 1) return PAGAN_E_ARG;
+    RowBand rb;
+    if ((rc = rb.build(Lx, Ly, band)) != PAGAN_OK) return rc;
+    DiagIndex dx;
+    dx.build(Lx, Ly, rb);
+    std::vector<uint8_t> cls;
+    std::vector<int> sched;
+    classify_diagonals(left, right, Lx, Ly, rb, dx, &cls);
+    schedule_waves(dx, cls, &sched);
+    std::memcpy(cls_out, cls.data(), cls.size());
+    *sched_len = (int32_t)sched.size();
+    if ((int)sched.size() > sched_cap) return PAGAN_E_ARG;
+    std::memcpy(sched_out, sched.data(), sizeof(int) * sched.size());
     return PAGAN_OK;
 }
 

@@ -1,0 +1,79 @@
+"""GPU parity of the register-wavefront fill kernel (dp_pipe.hip) on the code paths the tree workloads
+reach rarely: far edges (class 2), general steps (3), wide boxes (4), waves waking and sleeping; plus the
+older LDS ring kernel behind its switch and the negative-zero route."""
+import numpy as np
+import pytest
+
+from pagan2_msa_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b, what=""):
+    assert a.status == b.status, what
+    assert np.float64(a.score).tobytes() == np.float64(b.score).tobytes(), what + " score %r != %r" % (a.score, b.score)
+    assert a.end == b.end, what
+    assert np.array_equal(a.cols, b.cols), what + " columns differ"
+    assert np.array_equal(a.left_used, b.left_used) and np.array_equal(a.right_used, b.right_used), what
+
+
+def banded_job(seed, n=700, max_span=40, box=True):
+    rng = np.random.default_rng(seed)
+    left = synth.random_graph(n, 15, 10 + seed, p_extra=0.08, p_dead=0.0, max_span=max_span)
+    right = synth.random_graph(n + 30, 15, 20 + seed, p_extra=0.08, p_dead=0.0, max_span=max_span)
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    half = rng.integers(8, 40, Lx)
+    centre = np.arange(Lx) * (Ly - 1) // max(Lx - 1, 1)
+    upper = np.maximum.accumulate(np.maximum(centre - half, 0))
+    lower = np.maximum.accumulate(np.minimum(centre + half, Ly - 1))
+    upper[0] = 0
+    lower[-1] = Ly - 1
+    if box:
+        upper[300:560] = upper[300]
+        lower[300:560] = np.minimum(lower[559] + 300, Ly - 1)
+        lower = np.maximum.accumulate(lower)
+        upper = np.maximum.accumulate(upper)
+    return left, right, synth.random_model(15, seed), abi.Band(upper, lower)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_far_edges_general_steps_and_a_wide_box(pg, oracle, seed):
+    left, right, model, band = banded_job(seed, max_span=40 if seed < 2 else 8)
+    cls, waves = pg.debug_plan(left, right, band)
+    assert set(np.unique(cls)) >= ({2, 3, 4} if seed < 2 else {1, 3, 4}), "the job is meant to reach these classes"
+    assert sum(len(w) for w in waves) >= 4, "waves are meant to sleep and wake"
+    same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band), "seed %d" % seed)
+
+
+@pytest.mark.parametrize("flags", [abi.OPT_NO_TERMINAL_EDGES, abi.OPT_NO_REDUCED_TERMINAL_PEN])
+def test_option_bits_on_a_banded_job(pg, oracle, flags):
+    left, right, model, band = banded_job(7, n=400, box=False)
+    same(pg.align(left, right, model, band, flags=flags), oracle.dp_align(left, right, model, band, flags=flags))
+
+
+def test_ring_kernel_behind_its_switch(pg, oracle, monkeypatch):
+    left, right, model, band = banded_job(3)
+    monkeypatch.setenv("PAGAN_DP_FILL", "ring")
+    same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band))
+
+
+def test_pipe_and_ring_store_identical_scores(pg, monkeypatch):
+    job = banded_job(5)
+    scores = {}
+    for kernel in ("ring", "pipe"):
+        monkeypatch.setenv("PAGAN_DP_FILL", kernel)
+        b = pg.Batch([job])
+        b.run(); b.sync()
+        scores[kernel] = b.debug_scores(0)
+        b.close()
+    assert np.array_equal(scores["ring"].view(np.int64), scores["pipe"].view(np.int64))
+
+
+def test_negative_zero_parameter_keeps_the_comparing_kernel(pg, oracle):
+    left, right, model, band = banded_job(2, n=300, box=False)
+    t = model.log_score.copy()
+    t[3, 3] = np.float32(-0.0)
+    m2 = abi.Model(t, *model.params)
+    cls, _ = pg.debug_plan(left, right, band)        # the planner itself does not look at the model
+    assert cls.size == left.n_sites + right.n_sites - 3
+    same(pg.align(left, right, m2, band), oracle.dp_align(left, right, m2, band))

@@ -1,0 +1,109 @@
+"""Host-side planner of the banded fill kernel (dp_abi.hip: classify_diagonals, schedule_waves) against a
+brute-force restatement of its rules.  No GPU: pagan_dp_debug_plan is host code."""
+import numpy as np
+import pytest
+
+import pagan2_msa_amd as pg
+from pagan2_msa_amd import abi, synth
+
+REACH, WIDTH, RING, WAKE = 16, 240, 20, 6
+
+
+def site_features(g, n):
+    span = np.zeros(n, np.int64); simple = np.zeros(n, bool); nopred = np.zeros(n, bool)
+    for s in range(n):
+        a, b = g.bwd_off[s], g.bwd_off[s + 1]
+        if b > a:
+            span[s] = s - g.bwd_src[a:b].min()
+        nopred[s] = b == a
+        simple[s] = s > 0 and b - a == 1 and g.bwd_src[a] == s - 1 and g.bwd_logw[a] == 0.0
+    return span, simple, nopred
+
+
+def brute_plan(left, right, band):
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    lo = np.zeros(Lx, np.int64); hi = np.full(Lx, Ly - 1, np.int64)
+    if band is not None:
+        lo = np.maximum(band.upper[:Lx].astype(np.int64), 0); hi = np.minimum(band.lower[:Lx].astype(np.int64), Ly - 1)
+    nd = Lx + Ly - 1
+    sl, simL, npL = site_features(left, Lx)
+    sr, simR, npR = site_features(right, Ly)
+    cls = np.zeros(nd, np.uint8)
+    rows_of = [[] for _ in range(nd)]
+    for i in range(Lx):
+        for j in range(lo[i], hi[i] + 1):
+            rows_of[i + j].append(i)
+    last_wide = -1000
+    for d in range(nd):
+        rows = rows_of[d]
+        imin, imax = (rows[0], rows[-1]) if rows else (0, -1)
+        cols = [d - i for i in rows]
+        if len(rows) > WIDTH:
+            c = 4; last_wide = d
+        elif d - last_wide < REACH:
+            c = 3
+        elif not (imin >= 2 and imax <= Lx - 2 and d - imax >= 2 and d - imin <= Ly - 2):
+            c = 3
+        elif any(npL[i] for i in rows) or any(npR[j] for j in cols):
+            c = 3
+        elif any(sl[i] + sr[d - i] >= REACH for i in rows):
+            c = 2
+        elif any(not simL[i] for i in rows) or any(not simR[j] for j in cols):
+            c = 1
+        else:
+            c = 0
+        cls[d] = c
+    active = np.zeros((4, nd), bool)
+    for d in range(nd):
+        for w in range(4):
+            active[w, d] = cls[d] == 4 or any((i % 256) // 64 == w for i in rows_of[d])
+    return cls, active
+
+
+def check(left, right, band):
+    cls, waves = pg.debug_plan(left, right, band)
+    want, active = brute_plan(left, right, band)
+    assert np.array_equal(cls, want), "classes differ at %s" % np.nonzero(cls != want)[0][:10]
+    nd = cls.size
+    for w in range(4):
+        awake = np.zeros(nd, bool)
+        last = -1
+        for a, b in waves[w]:
+            assert last < a < b <= nd
+            awake[a:b] = True
+            last = b
+        # awake from WAKE steps before a row of the wave is in the band until RING steps after the last one left
+        need = np.zeros(nd, bool)
+        for d in np.nonzero(active[w])[0]:
+            need[max(0, d - WAKE): min(nd, d + RING + 1)] = True
+        assert np.array_equal(awake, need), "wave %d schedule differs" % w
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_plan_random_graphs_full_matrix(seed):
+    left = synth.random_graph(60 + 40 * seed, 15, seed, p_extra=0.3, p_dead=0.02 * (seed % 2))
+    right = synth.random_graph(90 + 25 * seed, 15, 50 + seed, p_extra=0.3, p_dead=0.0)
+    check(left, right, None)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_plan_banded_with_long_edges(seed):
+    rng = np.random.default_rng(seed)
+    n = 700
+    span = 40 if seed < 2 else 8
+    left = synth.random_graph(n, 15, 10 + seed, p_extra=0.08, p_dead=0.0, max_span=span)
+    right = synth.random_graph(n + 30, 15, 20 + seed, p_extra=0.08, p_dead=0.0, max_span=span)
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    half = rng.integers(8, 40, Lx)
+    centre = np.arange(Lx) * (Ly - 1) // max(Lx - 1, 1)
+    upper = np.maximum.accumulate(np.maximum(centre - half, 0))
+    lower = np.maximum.accumulate(np.minimum(centre + half, Ly - 1))
+    upper[0] = 0
+    lower[-1] = Ly - 1
+    # one box wider than the lanes in both directions, to get class 4 and the class-3 steps after it
+    upper[300:560] = upper[300]
+    lower[300:560] = np.minimum(lower[559] + 300, Ly - 1)
+    lower = np.maximum.accumulate(lower); upper = np.maximum.accumulate(upper)
+    check(left, right, abi.Band(upper, lower))
+    cls, _ = pg.debug_plan(left, right, abi.Band(upper, lower))
+    assert set(np.unique(cls)) >= ({2, 3, 4} if seed < 2 else {1, 3, 4})
