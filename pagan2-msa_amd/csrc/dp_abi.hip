@@ -40,6 +40,7 @@ unsigned pg_ring_lds_bytes();
 #define PG_PIPE_EDGE_CAP 1024
 #define PG_PIPE_SITE_EDGES 126
 #define PG_PIPE_RING 20
+#define PG_PIPE_WINDOW 352            // widest diagonal the kernel's site-record windows still cover
 #define PG_PIPE_WAKE 6
 unsigned pg_pipe_lds_bytes();
 
@@ -172,7 +173,7 @@ struct SiteFeat {
 };
 
 // Class of every anti-diagonal for dp_pipe.hip (its header explains the five code paths):
-//   4  wider than PG_PIPE_WIDTH cells;
+//   5  wider than PG_PIPE_WINDOW cells;   4  wider than PG_PIPE_WIDTH cells;
 //   3  touches the first/last two rows or columns, holds a site without bwd edges, or follows a wide
 //      diagonal within the ring's reach;
 //   2  holds a cell (i,j) whose farthest predecessor pair lies span(i) + span(j) >= PG_PIPE_REACH
@@ -209,7 +210,7 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
         run += far[d];
         const int lo = dx.imin[d], hi = dx.imax[d];
         uint8_t c;
-        if (hi - lo + 1 > PG_PIPE_WIDTH) { c = 4; last_wide = d; }
+        if (hi - lo + 1 > PG_PIPE_WIDTH) { c = hi - lo + 1 > PG_PIPE_WINDOW ? 5 : 4; last_wide = d; }
         else if (d - last_wide < PG_PIPE_REACH) c = 3;
         else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c = 3;
         else if (fl.no_pred[hi + 1] - fl.no_pred[lo] > 0 || fr.no_pred[d - lo + 1] - fr.no_pred[d - hi] > 0) c = 3;
@@ -230,7 +231,7 @@ void schedule_waves(const DiagIndex &dx, const std::vector<uint8_t> &cls, std::v
     std::vector<int> next_active(nd + 1);
     for (int w = 0; w < 4; ++w) {
         auto active = [&](int d) {
-            if (cls[d] == 4) return true;
+            if (cls[d] >= 4) return true;
             const int lo = dx.imin[d], hi = dx.imax[d];
             if (hi < lo) return false;
             const int a = (lo - 64 * w) & 255;                 // lo's position relative to the wave's block

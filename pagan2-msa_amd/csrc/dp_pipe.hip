@@ -33,8 +33,8 @@
 //     with edges reaching past the ring (those cells come from L2; every wave keeps all but
 //     its last 24 stores retired, so a diagonal 8 steps behind every wave has landed), 3 =
 //     general (first/last rows and columns, sites without predecessors, the steps after a wide
-//     diagonal: all awake waves rendezvous and drain), 4 = wider than the lanes (computed
-//     from HBM operands like the wide kernel);
+//     diagonal: all awake waves rendezvous and drain), 4 = wider than the lanes (every lane takes
+//     several rows, cells come from L2), 5 = wider than the record windows (graph arrays from HBM too);
 //   - a loader wave stages 16-byte site records (state, flags, first two bwd edges), the bwd
 //     edge lists and the recent diagonal descriptors in LDS windows ahead of the slowest wave;
 //   - scores and back-pointers stream to HBM with stores nobody waits for; compute waves
@@ -232,6 +232,52 @@ __device__ __forceinline__ void old_cell(gdouble_w sc, cdesc8_p psc, int d, int 
     }
 }
 
+// A cell's 24 bytes requested from L2 without waiting; far_wait3 is the wait (and the point after which
+// the compiler may use the registers).
+typedef double pg_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void far_cell_issue(PG_GLOBAL const double *p, pg_d2 &xy, double &m) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %2, off offset:16 sc1"
+                 : "=&v"(xy), "=&v"(m) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void far_wait3(pg_d2 &a, double &am, pg_d2 &b, double &bm, pg_d2 &c, double &cm) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(am), "+v"(b), "+v"(bm), "+v"(c), "+v"(cm) : : "memory");
+}
+
+// Up to three earlier cells at once (the X, Y and M operands of one (left edge, right edge) item): cells in
+// the ring are LDS reads; the others are requested from L2 together and waited for once.
+struct CellAsk { bool need; int age, p; };
+template <bool FAR>
+__device__ __forceinline__ void old_cells3(gdouble_w sc, cdesc8_p psc, int d, int slot, unsigned resmask, const CellAsk &a0,
+                                           const CellAsk &a1, const CellAsk &a2, double (&v)[3][3]) {
+    const double NI = neg_inf();
+    pg_d2 xy0 = {NI, NI}, xy1 = {NI, NI}, xy2 = {NI, NI};
+    double m0 = NI, m1 = NI, m2 = NI;
+    auto fetch = [&](const CellAsk &a, pg_d2 &xy, double &m) {
+        if (!a.need) return;
+        if (!FAR || (a.age < PAGE && ((resmask >> a.age) & 1u))) {
+            int s = slot - a.age;
+            s += s < 0 ? PRK : 0;
+            xy.x = PM.sc[s][a.p & (PNT - 1)][PG_X];
+            xy.y = PM.sc[s][a.p & (PNT - 1)][PG_Y];
+            m = PM.sc[s][a.p & (PNT - 1)][PG_M];
+        } else {
+            const int dd = d - a.age;
+            pg_i4 ds;
+            if (a.age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
+            else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
+            if (a.p >= ds.x && a.p <= ds.y) {
+                const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (a.p - ds.x);
+                far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc + boff), xy, m);
+            }
+        }
+    };
+    fetch(a0, xy0, m0); fetch(a1, xy1, m1); fetch(a2, xy2, m2);
+    if (FAR) far_wait3(xy0, m0, xy1, m1, xy2, m2);
+    v[0][0] = xy0.x; v[0][1] = xy0.y; v[0][2] = m0;
+    v[1][0] = xy1.x; v[1][1] = xy1.y; v[1][2] = m1;
+    v[2][0] = xy2.x; v[2][1] = xy2.y; v[2][2] = m2;
+}
+
 // Item loop of one multi-edge cell (class 1/2: interior, both sites have bwd edges): the (left edge,
 // right edge) pairs row-major, which visits the X candidates in left-list order, the Y candidates
 // in right-list order and the M candidates in the reference's pair order (VA:1396-1433).
@@ -249,29 +295,28 @@ __device__ __forceinline__ void multi_cell(gdouble_w sc, cdesc8_p psc, int d, in
     edge_at<true>(rL, 0, row, dL, lw);
     edge_at<false>(cR, 0, j, dR, rw);
     for (int t = 0; t < n_items; ++t) {
-        double xs, ys, ms, c;
+        double v[3][3], c;
+        const CellAsk ax = {k2 == 0, dL, row - dL}, ay = {k1 == 0, dR, row}, am = {true, dL + dR, row - dL};
+        old_cells3<FAR>(sc, psc, d, slot, resmask, ax, ay, am, v);
         if (k2 == 0) {                                                // X candidates of left edge k1
-            old_cell<FAR>(sc, psc, d, slot, resmask, dL, row - dL, xs, ys, ms);
             const double open = (reduced_terminal && row == dL) ? 0.0 : go;
             const unsigned w = pack_bp(0, k1, 0, dL == 1, false);
-            c = xs + ge;            if (c > bx) { bx = c; px = w | PG_X; }
-            c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = w | PG_Y; }
-            c = (ms + ng) + open;   if (c > bx) { bx = c; px = w | PG_M; }
+            c = v[0][0] + ge;            if (c > bx) { bx = c; px = w | PG_X; }
+            c = (v[0][1] + 0.0) + go;    if (c > bx) { bx = c; px = w | PG_Y; }
+            c = (v[0][2] + ng) + open;   if (c > bx) { bx = c; px = w | PG_M; }
         }
         if (k1 == 0) {                                                // Y candidates of right edge k2
-            old_cell<FAR>(sc, psc, d, slot, resmask, dR, row, xs, ys, ms);
             const double open = (reduced_terminal && j == dR) ? 0.0 : go;
             const unsigned w = pack_bp(0, 0, k2, false, dR == 1);
-            c = ys + ge;            if (c > by) { by = c; py = w | PG_Y; }
-            c = (xs + 0.0) + go;    if (c > by) { by = c; py = w | PG_X; }
-            c = (ms + ng) + open;   if (c > by) { by = c; py = w | PG_M; }
+            c = v[1][1] + ge;            if (c > by) { by = c; py = w | PG_Y; }
+            c = (v[1][0] + 0.0) + go;    if (c > by) { by = c; py = w | PG_X; }
+            c = (v[1][2] + ng) + open;   if (c > by) { by = c; py = w | PG_M; }
         }
         {                                                             // M candidates of the pair
-            old_cell<FAR>(sc, psc, d, slot, resmask, dL + dR, row - dL, xs, ys, ms);
             const unsigned w = pack_bp(0, k1, k2, dL == 1, dR == 1);
-            c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_M; }
-            c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_X; }
-            c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_Y; }
+            c = ((v[2][2] + tM) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_M; }
+            c = ((v[2][0] + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_X; }
+            c = ((v[2][1] + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_Y; }
         }
         if (++k2 == nR) { k2 = 0; ++k1; if (k1 < nL) edge_at<true>(rL, k1, row, dL, lw); }
         edge_at<false>(cR, k2, j, dR, rw);
@@ -291,7 +336,9 @@ __device__ __forceinline__ void cand(double c, unsigned f, double &best, unsigne
 // (X by left edge, Y by right edge, M by (left, right) pair, row-major) as straight-line code -- one
 // LDS latency and independent instruction streams instead of one dependent loop iteration per pair.
 // A missing second edge reads the all -inf null cell, whose candidates can never win.
-__device__ __forceinline__ void multi2_cell(int slot, const pg_i4 &rL, const pg_i4 &cR, int row, int j, bool reduced_terminal,
+template <bool FAR>
+__device__ __forceinline__ void multi2_cell(gdouble_w sc, cdesc8_p psc, int d, unsigned resmask, int slot, const pg_i4 &rL,
+                                            const pg_i4 &cR, int row, int j, bool reduced_terminal,
                                             double go, double ge, double ng, double tM, double tX, double &bx, double &by,
                                             double &bm, unsigned &px, unsigned &py, unsigned &pm) {
     const double NI = neg_inf();
@@ -299,22 +346,62 @@ __device__ __forceinline__ void multi2_cell(int slot, const pg_i4 &rL, const pg_
     const int dL0 = rL.y & 0xffff, dL1 = (int)((unsigned)rL.y >> 16), dR0 = cR.y & 0xffff, dR1 = (int)((unsigned)cR.y >> 16);
     const double lw0 = (double)__int_as_float(rL.z), lw1 = (double)__int_as_float(rL.w);
     const double rw0 = (double)__int_as_float(cR.z), rw1 = (double)__int_as_float(cR.w);
-    auto cell = [&](int age, int p, bool present, double &xs, double &ys, double &ms) {
-        int s = slot - age;
-        s += s < 0 ? PRK : 0;
-        const double *c = present ? &PM.sc[s][p & (PNT - 1)][0] : &PM.null_cell[0];
-        xs = c[PG_X]; ys = c[PG_Y]; ms = c[PG_M];
-    };
     double xa_x, xa_y, xa_m, xb_x, xb_y, xb_m, ya_x, ya_y, ya_m, yb_x, yb_y, yb_m;
     double m00x, m00y, m00m, m01x, m01y, m01m, m10x, m10y, m10m, m11x, m11y, m11m;
-    cell(dL0, row - dL0, true, xa_x, xa_y, xa_m);
-    cell(dL1, row - dL1, l1, xb_x, xb_y, xb_m);
-    cell(dR0, row, true, ya_x, ya_y, ya_m);
-    cell(dR1, row, r1, yb_x, yb_y, yb_m);
-    cell(dL0 + dR0, row - dL0, true, m00x, m00y, m00m);
-    cell(dL0 + dR1, row - dL0, r1, m01x, m01y, m01m);
-    cell(dL1 + dR0, row - dL1, l1, m10x, m10y, m10m);
-    cell(dL1 + dR1, row - dL1, l1 && r1, m11x, m11y, m11m);
+    if (!FAR) {
+        // every cell is in the ring: branch-free reads, a missing edge reads the null cell
+        auto cell = [&](int age, int p, bool present, double &xs, double &ys, double &ms) {
+            int s = slot - age;
+            s += s < 0 ? PRK : 0;
+            const double *c = present ? &PM.sc[s][p & (PNT - 1)][0] : &PM.null_cell[0];
+            xs = c[PG_X]; ys = c[PG_Y]; ms = c[PG_M];
+        };
+        cell(dL0, row - dL0, true, xa_x, xa_y, xa_m);
+        cell(dL1, row - dL1, l1, xb_x, xb_y, xb_m);
+        cell(dR0, row, true, ya_x, ya_y, ya_m);
+        cell(dR1, row, r1, yb_x, yb_y, yb_m);
+        cell(dL0 + dR0, row - dL0, true, m00x, m00y, m00m);
+        cell(dL0 + dR1, row - dL0, r1, m01x, m01y, m01m);
+        cell(dL1 + dR0, row - dL1, l1, m10x, m10y, m10m);
+        cell(dL1 + dR1, row - dL1, l1 && r1, m11x, m11y, m11m);
+    } else {
+        // some cells have left the ring: those are requested from L2 together and waited for once
+        pg_d2 q[8];
+        double qm[8];
+        auto cell = [&](int k, int age, int p, bool present) {
+            q[k].x = NI; q[k].y = NI; qm[k] = NI;
+            if (!present) return;
+            if (age < PAGE && ((resmask >> age) & 1u)) {
+                int s = slot - age;
+                s += s < 0 ? PRK : 0;
+                q[k].x = PM.sc[s][p & (PNT - 1)][PG_X]; q[k].y = PM.sc[s][p & (PNT - 1)][PG_Y]; qm[k] = PM.sc[s][p & (PNT - 1)][PG_M];
+            } else {
+                const int dd = d - age;
+                pg_i4 ds;
+                if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
+                else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
+                if (p >= ds.x && p <= ds.y) {
+                    const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p - ds.x);
+                    far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc + boff), q[k], qm[k]);
+                }
+            }
+        };
+        cell(0, dL0, row - dL0, true);
+        cell(1, dL1, row - dL1, l1);
+        cell(2, dR0, row, true);
+        cell(3, dR1, row, r1);
+        cell(4, dL0 + dR0, row - dL0, true);
+        cell(5, dL0 + dR1, row - dL0, r1);
+        cell(6, dL1 + dR0, row - dL1, l1);
+        cell(7, dL1 + dR1, row - dL1, l1 && r1);
+        far_wait3(q[0], qm[0], q[1], qm[1], q[2], qm[2]);
+        far_wait3(q[3], qm[3], q[4], qm[4], q[5], qm[5]);
+        { pg_d2 dq = {NI, NI}; double dm = NI; far_wait3(q[6], qm[6], q[7], qm[7], dq, dm); }
+        xa_x = q[0].x; xa_y = q[0].y; xa_m = qm[0];  xb_x = q[1].x; xb_y = q[1].y; xb_m = qm[1];
+        ya_x = q[2].x; ya_y = q[2].y; ya_m = qm[2];  yb_x = q[3].x; yb_y = q[3].y; yb_m = qm[3];
+        m00x = q[4].x; m00y = q[4].y; m00m = qm[4];  m01x = q[5].x; m01y = q[5].y; m01m = qm[5];
+        m10x = q[6].x; m10y = q[6].y; m10m = qm[6];  m11x = q[7].x; m11y = q[7].y; m11m = qm[7];
+    }
     const unsigned aL0 = dL0 == 1 ? PG_BP_ADJL : 0u, aL1 = dL1 == 1 ? PG_BP_ADJL : 0u;
     const unsigned aR0 = dR0 == 1 ? PG_BP_ADJR : 0u, aR1 = dR1 == 1 ? PG_BP_ADJR : 0u;
     bx = NI; by = NI; bm = NI; px = PG_BP_NONE; py = PG_BP_NONE; pm = PG_BP_NONE;
@@ -428,6 +515,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
 #ifdef PG_PIPE_STATS
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_cls_t[5] = {0, 0, 0, 0, 0};
     int st_cls_n[5] = {0, 0, 0, 0, 0};
+    long long st_w[4] = {0, 0, 0, 0};
     int st_n = 0;
     bool st_on = false;
 #endif
@@ -458,6 +546,57 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
         int ok_until = wake - 1;                                   // flow control holds through this diagonal without reading a flag
         int slot = wake % PRK, slot1 = (wake + PRK - 1) % PRK;     // d % PRK, (d-1) % PRK
         int lo_prev = -1, hi_prev = -1;
+
+        // One cell by the general rules (first/last rows and columns, sites without predecessors, any edge
+        // list): records and edges from the LDS windows, earlier cells from the ring or from L2/HBM.
+        auto gen_cell = [&](const int d, const int slot_, const unsigned resmask, const int r, const int j, double &bx,
+                            double &by, double &bm, unsigned &px, unsigned &py, unsigned &pm) {
+            const pg_i4 gl = PM.recL[r & (PRW - 1)], gr = PM.recR[j & (PRW - 1)];
+            const int wi = gl.x, wj = gr.x;
+            int l0 = 0, nL = 0, r0 = 0, nR = 0, n_items = 0;
+            double tM = 0, tX = 0;
+            if (r > 0) { l0 = PM.ebL[r & (PRW - 1)]; nL = (wi >> PR_NE_SHIFT) & 127; }
+            if (j > 0) { r0 = PM.ebR[j & (PRW - 1)]; nR = (wj >> PR_NE_SHIFT) & 127; }
+            if (r == 0 && j == 0) bm = 0.0;                                    // initialise_array_corner, VA:725-736
+            else n_items = (nL > 0 ? nL : 1) * (nR > 0 ? nR : 1);
+            if (nL > 0 && nR > 0) {
+                const int ti = (wi & 0xffff) + (wj & 0xffff) * S;
+                const float sm = TAB_LDS ? PM.table[ti] : far_f32(table + ti);
+                tM = tng2 + (double)sm; tX = tng1 + (double)sm;
+            }
+            const double extX = (double)(((j == 0 || j == Ly - 1) && !no_terminal_edges) ? f_gE : f_ge);
+            const double extY = (double)(((r == 0 || r == Lx - 1) && !no_terminal_edges) ? f_gE : f_ge);
+            const int nRp = nR > 0 ? nR : 1;
+            int k1 = 0, k2 = 0;
+            for (int t = 0; t < n_items; ++t) {
+                int p = 0, q = 0;
+                double lw = 0, rw = 0, c;
+                if (nL > 0) { p = PM.esL[(l0 + k1) & (PEC - 1)]; lw = (double)PM.ewL[(l0 + k1) & (PEC - 1)]; }
+                if (nR > 0) { q = PM.esR[(r0 + k2) & (PEC - 1)]; rw = (double)PM.ewR[(r0 + k2) & (PEC - 1)]; }
+                double v[3][3];
+                const CellAsk ax = {nL > 0 && k2 == 0, r - p, p}, ay = {nR > 0 && k1 == 0, j - q, r};
+                const CellAsk am = {nL > 0 && nR > 0, (r - p) + (j - q), p};
+                old_cells3<true>(sc_out, psc, d, slot_, resmask, ax, ay, am, v);
+                if (nL > 0 && k2 == 0) {                                       // X candidates of left edge k1
+                    const double open = (reduced_terminal && p == 0) ? 0.0 : go;
+                    c = v[0][0] + extX;          if (c > bx) { bx = c; px = pack_bp(PG_X, k1, 0, p == r - 1, false); }
+                    c = (v[0][1] + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, k1, 0, p == r - 1, false); }
+                    c = (v[0][2] + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, k1, 0, p == r - 1, false); }
+                }
+                if (nR > 0 && k1 == 0) {                                       // Y candidates of right edge k2
+                    const double open = (reduced_terminal && q == 0) ? 0.0 : go;
+                    c = v[1][1] + extY;          if (c > by) { by = c; py = pack_bp(PG_Y, 0, k2, false, q == j - 1); }
+                    c = (v[1][0] + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, k2, false, q == j - 1); }
+                    c = (v[1][2] + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, k2, false, q == j - 1); }
+                }
+                if (nL > 0 && nR > 0) {                                        // M candidates of the pair
+                    c = ((v[2][2] + tM) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_M, k1, k2, p == r - 1, q == j - 1); }
+                    c = ((v[2][0] + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_X, k1, k2, p == r - 1, q == j - 1); }
+                    c = ((v[2][1] + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, k1, k2, p == r - 1, q == j - 1); }
+                }
+                if (++k2 == nRp) { k2 = 0; ++k1; }
+            }
+        };
 
         // One diagonal.  HOT (a tag type): the class is 0 or 1 and the step runs as one half of a pair.
         auto step = [&](auto hot_tag, const int d, const pg_i8 &cur, pg_i8 &oth, double &PX, double &PY, double &PM_,
@@ -500,9 +639,18 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                         for (int w = 0; w < PNW; ++w) poll_ge(&PM.progress[w], d - PLAND, PTAG(6));
                 } else {
                     // rendezvous: every awake wave has completed d-1 and its stores have landed
+#ifdef PG_PIPE_STATS
+                    const long long w0 = __builtin_readcyclecounter();
+#endif
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PG_PIPE_STATS
+                    const long long w1 = __builtin_readcyclecounter();
+#endif
                     flag_store(&PM.arrived[wave], d);
                     for (int w = 0; w < PNW; ++w) poll_ge(&PM.arrived[w], d, PTAG(7));
+#ifdef PG_PIPE_STATS
+                    if (cls == 4) { st_w[0] += w1 - w0; st_w[1] += __builtin_readcyclecounter() - w1; }
+#endif
                     p_up = d - 1 > p_up ? d - 1 : p_up;
                     p_dn = d - 1 > p_dn ? d - 1 : p_dn;
                 }
@@ -561,7 +709,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                         // sites with at most two bwd edges each: straight-line; more: the item loop
                         const int nl = (rL.x >> PR_NE_SHIFT) & 127, nr = (cra.x >> PR_NE_SHIFT) & 127;
                         if ((unsigned)(nl - 1) < 2u && (unsigned)(nr - 1) < 2u)
-                            multi2_cell(slot, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX, bx, by, bm, px, py, pm);
+                            multi2_cell<false>(sc_out, psc, d, 0u, slot, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX, bx, by, bm, px, py, pm);
                         else
                             multi_cell<false>(sc_out, psc, d, slot, 0u, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX,
                                               bx, by, bm, px, py, pm);
@@ -581,61 +729,83 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                         const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
                         bm = first_max3(CM + tM, CX + tX, CY + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
                                         PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
-                        if (!(rL.x & cra.x & PR_SIMPLE))
-                            multi_cell<true>(sc_out, psc, d, slot, resmask, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX,
-                                             bx, by, bm, px, py, pm);
+                        if (!(rL.x & cra.x & PR_SIMPLE)) {
+                            const int nl = (rL.x >> PR_NE_SHIFT) & 127, nr = (cra.x >> PR_NE_SHIFT) & 127;
+                            if ((unsigned)(nl - 1) < 2u && (unsigned)(nr - 1) < 2u)
+                                multi2_cell<true>(sc_out, psc, d, resmask, slot, rL, cra, row, j, reduced_terminal, go, ge, ng, tM,
+                                                  tX, bx, by, bm, px, py, pm);
+                            else
+                                multi_cell<true>(sc_out, psc, d, slot, resmask, rL, cra, row, j, reduced_terminal, go, ge, ng, tM,
+                                                 tX, bx, by, bm, px, py, pm);
+                        }
                     }
                 } else if (active) {
-                    // ---- general (first/last rows and columns, sites without predecessors, the steps after a wide
-                    // diagonal): records and edges from the LDS windows, cells from the ring or from HBM ----
-                    const pg_i4 gl = PM.recL[row & (PRW - 1)], gr = PM.recR[j & (PRW - 1)];
-                    const int wi = gl.x, wj = gr.x;
-                    int l0 = 0, nL = 0, r0 = 0, nR = 0, n_items = 0;
-                    double tM = 0, tX = 0;
-                    if (row > 0) { l0 = PM.ebL[row & (PRW - 1)]; nL = (wi >> PR_NE_SHIFT) & 127; }
-                    if (j > 0) { r0 = PM.ebR[j & (PRW - 1)]; nR = (wj >> PR_NE_SHIFT) & 127; }
-                    if (row == 0 && j == 0) bm = 0.0;                          // initialise_array_corner, VA:725-736
-                    else n_items = (nL > 0 ? nL : 1) * (nR > 0 ? nR : 1);
-                    if (nL > 0 && nR > 0) {
-                        const int ti = (wi & 0xffff) + (wj & 0xffff) * S;
-                        const float sm = TAB_LDS ? PM.table[ti] : far_f32(table + ti);
-                        tM = tng2 + (double)sm; tX = tng1 + (double)sm;
-                    }
-                    const double extX = (double)(((j == 0 || j == Ly - 1) && !no_terminal_edges) ? f_gE : f_ge);
-                    const double extY = (double)(((row == 0 || row == Lx - 1) && !no_terminal_edges) ? f_gE : f_ge);
-                    const int nRp = nR > 0 ? nR : 1;
-                    int k1 = 0, k2 = 0;
-                    for (int t = 0; t < n_items; ++t) {
-                        int p = 0, q = 0;
-                        double lw = 0, rw = 0, xs, ys, ms, c;
-                        if (nL > 0) { p = PM.esL[(l0 + k1) & (PEC - 1)]; lw = (double)PM.ewL[(l0 + k1) & (PEC - 1)]; }
-                        if (nR > 0) { q = PM.esR[(r0 + k2) & (PEC - 1)]; rw = (double)PM.ewR[(r0 + k2) & (PEC - 1)]; }
-                        if (nL > 0 && k2 == 0) {                                     // X candidates of left edge k1
-                            old_cell<true>(sc_out, psc, d, slot, resmask, row - p, p, xs, ys, ms);
-                            const double open = (reduced_terminal && p == 0) ? 0.0 : go;
-                            c = xs + extX;          if (c > bx) { bx = c; px = pack_bp(PG_X, k1, 0, p == row - 1, false); }
-                            c = (ys + 0.0) + go;    if (c > bx) { bx = c; px = pack_bp(PG_Y, k1, 0, p == row - 1, false); }
-                            c = (ms + ng) + open;   if (c > bx) { bx = c; px = pack_bp(PG_M, k1, 0, p == row - 1, false); }
-                        }
-                        if (nR > 0 && k1 == 0) {                                     // Y candidates of right edge k2
-                            old_cell<true>(sc_out, psc, d, slot, resmask, j - q, row, xs, ys, ms);
-                            const double open = (reduced_terminal && q == 0) ? 0.0 : go;
-                            c = ys + extY;          if (c > by) { by = c; py = pack_bp(PG_Y, 0, k2, false, q == j - 1); }
-                            c = (xs + 0.0) + go;    if (c > by) { by = c; py = pack_bp(PG_X, 0, k2, false, q == j - 1); }
-                            c = (ms + ng) + open;   if (c > by) { by = c; py = pack_bp(PG_M, 0, k2, false, q == j - 1); }
-                        }
-                        if (nL > 0 && nR > 0) {                                      // M candidates of the pair
-                            old_cell<true>(sc_out, psc, d, slot, resmask, (row - p) + (j - q), p, xs, ys, ms);
-                            c = ((ms + tM) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_M, k1, k2, p == row - 1, q == j - 1); }
-                            c = ((xs + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_X, k1, k2, p == row - 1, q == j - 1); }
-                            c = ((ys + tX) + lw) + rw;  if (c > bm) { bm = c; pm = pack_bp(PG_Y, k1, k2, p == row - 1, q == j - 1); }
-                        }
-                        if (++k2 == nRp) { k2 = 0; ++k1; }
-                    }
+                    gen_cell(d, slot, resmask, row, j, bx, by, bm, px, py, pm);
                 }
                 commit_cell(sc_out, bp_out, cur, slot, tid, row - lo, active, bx, by, bm, px, py, pm);
+            } else if (cls == 4) {
+                // ---- wider than the lanes, but inside the record windows: every lane takes its rows row, row+256,
+                // ...; cells come from L2 (all waves are here and drained), simple interior cells with their
+                // three predecessors requested together, the others by the general rules; nothing enters the ring ----
+                const unsigned resmask = (unsigned)cur.s4 >> 5;
+#ifdef PG_PIPE_STATS
+                const long long w2 = __builtin_readcyclecounter();
+#endif
+                const pg_i8 p1 = psc[d - 1], p2 = psc[d - 2];              // a wide diagonal has d > 240
+                const long long off1 = ((long long)p1.w << 32) | (unsigned)p1.z, off2 = ((long long)p2.w << 32) | (unsigned)p2.z;
+                const long long soff = ((long long)cur.w << 32) | (unsigned)cur.z;
+                PG_GLOBAL char *s1 = (PG_GLOBAL char *)sc_out + off1, *s2 = (PG_GLOBAL char *)sc_out + off2;
+                PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff, *brow = (PG_GLOBAL char *)bp_out + (soff >> 1);
+                for (int r = row; r <= hi; r += PNT) {
+                    const int jj = d - r;
+                    double wx = NI, wy = NI, wm = NI;
+                    unsigned qx = PG_BP_NONE, qy = PG_BP_NONE, qm = PG_BP_NONE;
+                    const pg_i4 gl = PM.recL[r & (PRW - 1)], gr = PM.recR[jj & (PRW - 1)];
+                    if ((gl.x & gr.x & PR_SIMPLE) && r >= 2 && r <= Lx - 2 && jj >= 2 && jj <= Ly - 2) {
+                        // (r-1, jj) and (r, jj-1) on d-1, (r-1, jj-1) on d-2; outside the band: -inf
+                        const int pa = r - 1;
+                        const bool inA = pa >= p1.x && pa <= p1.y, inB = r <= p1.y, inC = pa >= p2.x && pa <= p2.y;
+                        const int ca_ = pa < p1.x ? p1.x : (pa > p1.y ? p1.y : pa), cb_ = r > p1.y ? p1.y : r;
+                        const int cc_ = pa < p2.x ? p2.x : (pa > p2.y ? p2.y : pa);
+                        pg_d2 axy, bxy, cxy;
+                        double am, bmm, cm;
+                        far_cell_issue((gdouble_w)(s1 + 24u * (unsigned)(ca_ - p1.x)), axy, am);
+                        far_cell_issue((gdouble_w)(s1 + 24u * (unsigned)(cb_ - p1.x)), bxy, bmm);
+                        far_cell_issue((gdouble_w)(s2 + 24u * (unsigned)(cc_ - p2.x)), cxy, cm);
+                        const int ti = (gl.x & 0xffff) + (gr.x & 0xffff) * S;
+                        const float sm = TAB_LDS ? PM.table[ti & 255] : 0.0f;
+                        far_wait3(axy, am, bxy, bmm, cxy, cm);
+                        const float smv = TAB_LDS ? sm : far_f32(table + ti);
+                        const double tM = tng2 + (double)smv, tX = tng1 + (double)smv;
+                        const double ax = inA ? axy.x : NI, ay = inA ? axy.y : NI, amv = inA ? am : NI;
+                        const double bxv = inB ? bxy.x : NI, byv = inB ? bxy.y : NI, bmv = inB ? bmm : NI;
+                        const double cxv = inC ? cxy.x : NI, cyv = inC ? cxy.y : NI, cmv = inC ? cm : NI;
+                        wx = first_max3(ax + ge, ay + go, (amv + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, qx);
+                        wy = first_max3(byv + ge, bxv + go, (bmv + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, qy);
+                        wm = first_max3(cmv + tM, cxv + tX, cyv + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
+                                        PG_Y | PG_BP_ADJL | PG_BP_ADJR, qm);
+                    } else {
+                        gen_cell(d, slot, resmask, r, jj, wx, wy, wm, qx, qy, qm);
+                    }
+                    typedef unsigned u3 __attribute__((ext_vector_type(3)));
+                    const unsigned off = (unsigned)(r - lo);
+                    pg_d2 xy; xy.x = wx; xy.y = wy;
+                    *(PG_GLOBAL pg_d2 *)(srow + 24u * off) = xy;
+                    *(PG_GLOBAL double *)(srow + 24u * off + 16u) = wm;
+                    u3 b3; b3.x = qx; b3.y = qy; b3.z = qm;
+                    *(PG_GLOBAL u3 *)(brow + 12u * off) = b3;
+                }
+#ifdef PG_PIPE_STATS
+                const long long w3 = __builtin_readcyclecounter();
+#endif
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PG_PIPE_STATS
+                st_w[2] += w3 - w2; st_w[3] += __builtin_readcyclecounter() - w3;
+#endif
+                have = false;
+                hi_prev = -2;
             } else {
-                // ---- wider than the lanes: every cell from HBM/L2 operands (all waves are here, drained) ----
+                // ---- wider than the record windows: every cell from HBM/L2 operands, graph arrays included ----
                 const PgDevJob *cold = job;
                 asm volatile("" : "+s"(cold));                     // opaque: keeps these loads inside the branch
                 const View J = load_view(cold);
@@ -704,6 +874,8 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
         for (int k = 0; k < 7; ++k) o[1 + k] = (int)(st_acc[k] >> 4);
         PG_GLOBAL int *q = (PG_GLOBAL int *)job->trace + 3 * (Lx + Ly) - 400 + 12 * wave;
         for (int c = 0; c < 5; ++c) { q[c] = st_cls_n[c]; q[5 + c] = (int)(st_cls_t[c] >> 8); }
+        PG_GLOBAL int *u = (PG_GLOBAL int *)job->trace + 3 * (Lx + Ly) - 600 + 4 * wave;
+        for (int c = 0; c < 4; ++c) u[c] = (int)(st_w[c] >> 8);
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -29,8 +29,9 @@ def banded_job(seed, n=700, max_span=40, box=True):
     upper[0] = 0
     lower[-1] = Ly - 1
     if box:
-        upper[300:560] = upper[300]
-        lower[300:560] = np.minimum(lower[559] + 300, Ly - 1)
+        rows, jump = (260, 300) if seed != 1 else (390, 420)      # seed 1: wider than the record windows too (class 5)
+        upper[300:300 + rows] = upper[300]
+        lower[300:300 + rows] = np.minimum(lower[299 + rows] + jump, Ly - 1)
         lower = np.maximum.accumulate(lower)
         upper = np.maximum.accumulate(upper)
     return left, right, synth.random_model(15, seed), abi.Band(upper, lower)

@@ -6,7 +6,7 @@ import pytest
 import pagan2_msa_amd as pg
 from pagan2_msa_amd import abi, synth
 
-REACH, WIDTH, RING, WAKE = 16, 240, 20, 6
+REACH, WIDTH, WINDOW, RING, WAKE = 16, 240, 352, 20, 6
 
 
 def site_features(g, n):
@@ -39,7 +39,7 @@ def brute_plan(left, right, band):
         imin, imax = (rows[0], rows[-1]) if rows else (0, -1)
         cols = [d - i for i in rows]
         if len(rows) > WIDTH:
-            c = 4; last_wide = d
+            c = 5 if len(rows) > WINDOW else 4; last_wide = d
         elif d - last_wide < REACH:
             c = 3
         elif not (imin >= 2 and imax <= Lx - 2 and d - imax >= 2 and d - imin <= Ly - 2):
@@ -56,7 +56,7 @@ def brute_plan(left, right, band):
     active = np.zeros((4, nd), bool)
     for d in range(nd):
         for w in range(4):
-            active[w, d] = cls[d] == 4 or any((i % 256) // 64 == w for i in rows_of[d])
+            active[w, d] = cls[d] >= 4 or any((i % 256) // 64 == w for i in rows_of[d])
     return cls, active
 
 
@@ -101,9 +101,11 @@ def test_plan_banded_with_long_edges(seed):
     upper[0] = 0
     lower[-1] = Ly - 1
     # one box wider than the lanes in both directions, to get class 4 and the class-3 steps after it
-    upper[300:560] = upper[300]
-    lower[300:560] = np.minimum(lower[559] + 300, Ly - 1)
+    rows, jump = (260, 300) if seed != 1 else (390, 420)          # seed 1: wider than the record windows too (class 5)
+    upper[300:300 + rows] = upper[300]
+    lower[300:300 + rows] = np.minimum(lower[299 + rows] + jump, Ly - 1)
     lower = np.maximum.accumulate(lower); upper = np.maximum.accumulate(upper)
     check(left, right, abi.Band(upper, lower))
     cls, _ = pg.debug_plan(left, right, abi.Band(upper, lower))
     assert set(np.unique(cls)) >= ({2, 3, 4} if seed < 2 else {1, 3, 4})
+    assert (5 in cls) == (seed == 1)

@@ -40,6 +40,11 @@ if os.environ.get("PG_STAMPS"):
         n = b2[12 * w: 12 * w + 5].astype(np.int64); t = b2[12 * w + 5: 12 * w + 10].astype(np.int64) * 256
         print("wave %d steps with cells by class (n, Mcycles, cycles/step): " % w +
               "  ".join("c%d %d %.0fM %.0f" % (c, n[c], t[c] / 1e6, t[c] / max(n[c], 1)) for c in range(5)))
+if os.environ.get("PG_STAMPS"):
+    b3 = raw[n_int - 600:]
+    for w in range(4):
+        t = b3[4 * w: 4 * w + 4].astype(np.int64) * 256
+        print("wave %d wide steps, Mcycles: drain before %.0f, rendezvous %.0f, cells %.0f, drain after %.0f" % ((w,) + tuple(t / 1e6)))
 if os.environ.get("PG_CHECK"):
     import oracle
     bad = 0
