@@ -140,7 +140,7 @@ def main():
                        "cells_per_step_per_gpu": int(cells), "parallelism": "independent node alignments per GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, cells),
-                         "kernel": "pg_fill_ring" if anchors else "pg_fill_wavefront", "avg_launch_ms": fill_avg_ms,
+                         "kernel": fill_kernel(anchors), "avg_launch_ms": fill_avg_ms,
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL,
                          "algorithmic_bytes_per_launch": BYTES_PER_CELL * int(cells)},
             "kernels_ms": {"fill": fill_avg_ms, "end_and_trace": float(np.mean(trace_ms))},
@@ -156,16 +156,25 @@ def main():
         dist.destroy_process_group()
 
 
+def fill_kernel(anchors):
+    """Name of the kernel the timed fill launches: the banded workloads run the register-wavefront kernel
+    (or the older LDS ring kernel behind PAGAN_DP_FILL=ring), full matrices the HBM wavefront."""
+    if not anchors:
+        return "pg_fill_wavefront"
+    return "pg_fill_ring" if os.environ.get("PAGAN_DP_FILL") == "ring" else "pg_fill_pipe"
+
+
 def pmc_traffic(workload, cells):
     """HBM bytes per launch of the fill kernel from the committed rocprofv3 --pmc passes of this same
     command (WRITE_SIZE and FETCH_SIZE need separate passes and cannot be collected from inside
-    the bench); None when the profile is for another workload or cell count."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fill_ring.json")
+    the bench); None when the profile is for another workload, kernel or cell count."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fill.json")
     try:
         prof = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if prof.get("workload") != workload or prof.get("cells_per_launch") != int(cells):
+    if (prof.get("workload") != workload or prof.get("cells_per_launch") != int(cells) or
+            prof.get("kernel") != fill_kernel(WORKLOADS[workload][6])):
         return None
     return prof["hbm_bytes_per_launch"]
 
