@@ -16,9 +16,12 @@ def main():
     c = sqlite3.connect(path)
     kd, ks = table(c, "rocpd_kernel_dispatch"), table(c, "rocpd_info_kernel_symbol")
     if mode == "stats":
+        # one row per (kernel, grid): the bench's timed launches (all node alignments in one grid) are told
+        # apart from the smaller per-level launches of the untimed tree walk
         rows = collections.defaultdict(list)
-        for name, start, end in c.execute(f"select k.kernel_name, d.start, d.end from {kd} d join {ks} k on d.kernel_id = k.id"):
-            rows[name].append(end - start)
+        for name, gx, wx, start, end in c.execute(
+                f"select k.kernel_name, d.grid_size_x, d.workgroup_size_x, d.start, d.end from {kd} d join {ks} k on d.kernel_id = k.id"):
+            rows["%s [grid %d x wg %d]" % (name, gx // max(wx, 1), wx)].append(end - start)
         total = sum(sum(v) for v in rows.values())
         with open(sys.argv[3], "w", newline="") as f:
             w = csv.writer(f)
