@@ -9,6 +9,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -254,6 +257,19 @@ void schedule_waves(const DiagIndex &dx, const std::vector<uint8_t> &cls, std::v
         (*out)[w] = (int)out->size();
         out->insert(out->end(), lists[w].begin(), lists[w].end());
     }
+}
+
+// Independent per-job host work (validation, diagonal index, plan, staging) over a few threads: a batch
+// is a guide-tree level, up to hundreds of 1e5-site jobs.
+template <class F> void parallel_jobs(int n, F f) {
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nt = std::max(1, std::min({n, hw > 0 ? hw : 1, 16}));
+    if (nt == 1) { for (int k = 0; k < n; ++k) f(k); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t)
+        pool.emplace_back([&] { for (int k = next++; k < n; k = next++) f(k); });
+    for (auto &th : pool) th.join();
 }
 
 struct Arena {
@@ -623,9 +639,13 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     if (const char *f = std::getenv("PAGAN_DP_FILL")) b->use_pipe = std::strcmp(f, "ring") != 0;
     if (const char *f = std::getenv("PAGAN_DP_DEBUG_FLAGS")) b->flags |= (uint32_t)std::strtoul(f, nullptr, 0) & 0xff00u;
     std::vector<int> which_ring, which_ring_big, which_wide;
-    for (int k = 0; k < n; ++k) {
+    std::vector<int> job_rc(n, PAGAN_OK);
+    parallel_jobs(n, [&](int k) {
         RowBand rb;
-        int rc = validate_job(jobs[k], &b->jobs[k], &rb, b->use_pipe);
+        job_rc[k] = validate_job(jobs[k], &b->jobs[k], &rb, b->use_pipe);
+    });
+    for (int k = 0; k < n; ++k) {
+        const int rc = job_rc[k];
         if (rc != PAGAN_OK) return rc;
         b->cells += b->jobs[k].dx.cells;
         if (b->jobs[k].n_bound > b->max_bound) b->max_bound = b->jobs[k].n_bound;
@@ -655,7 +675,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
 
     // pass 2: stage inputs (offsets from pass 1 index the staging buffer), then rebase.
     std::vector<char> stage(in_bytes);
-    for (int k = 0; k < n; ++k) {
+    parallel_jobs(n, [&](int k) {
         const pagan_job &jb = jobs[k];
         const HostJob &hj = b->jobs[k];
         const PgDevJob &d = b->dj[k];
@@ -693,7 +713,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             put(stage, d.sched, hj.sched.data(), hj.sched.size());
         }
         put(stage, d.tb, hj.tb.data(), hj.tb.size());
-    }
+    });
     b->trace_off.resize(n); b->end_off.resize(n); b->score_off.resize(n);
     char *base = b->arena.dev;
     auto rebase = [&](auto *&p) { p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(base + reinterpret_cast<size_t>(p)); };
@@ -820,11 +840,21 @@ void pagan_batch_destroy(pagan_batch *b) {
 int pagan_dp_align_batch(int32_t n, const pagan_job *jobs, const pagan_opts *opts, pagan_result *out) {
     if (!out) return PAGAN_E_ARG;
     pagan_batch *b = nullptr;
+    const bool verbose = std::getenv("PAGAN_DP_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     int rc = pagan_batch_create(n, jobs, opts, &b);
     if (rc != PAGAN_OK) return rc;
+    const double t1 = now();
     rc = pagan_batch_run(b);
+    if (rc == PAGAN_OK) rc = pagan_batch_sync(b);
+    const double t2 = now();
     if (rc == PAGAN_OK) rc = pagan_batch_fetch(b, out);
+    const double t3 = now();
     pagan_batch_destroy(b);
+    if (verbose)
+        std::fprintf(stderr, "pagan_dp: batch of %d: create %.1f ms, kernels %.1f ms, fetch+replay %.1f ms, destroy %.1f ms\n", n,
+                     1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (now() - t3));
     return rc;
 }
 
