@@ -80,6 +80,10 @@ int  pagan_msa_timing_get(const pagan_msa *m, pagan_msa_timing *out);
 int  pagan_msa_alignment_length(const pagan_msa *m);
 /* Row of leaf `leaf` (input order) of the final alignment, '-' for gaps; buf >= length+1. */
 int  pagan_msa_alignment_row(const pagan_msa *m, int32_t leaf, char *buf);
+/* The leaf rows as FASTA, leaves in guide-tree order, `>name` + the row cut into lines of chars_by_line
+ * characters (<= 0: 60): Fasta_reader::write_fasta over Node::get_alignment
+ * (src/utils/fasta_reader.cpp:596-629, src/main/node.cpp:537-575).                            */
+int  pagan_msa_write_fasta(const pagan_msa *m, const char *path, int32_t chars_by_line);
 void *pagan_msa_node_graph(const pagan_msa *m, int32_t node);   /* a pagan_hgraph (borrowed)  */
 void pagan_msa_destroy(pagan_msa *m);
 

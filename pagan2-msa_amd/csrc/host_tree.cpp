@@ -464,6 +464,31 @@ int pagan_msa_alignment_row(const pagan_msa *m, int32_t leaf, char *buf) {
     return PAGAN_OK;
 }
 
+// Fasta_reader::write_fasta (src/utils/fasta_reader.cpp:596-629) over Node::get_alignment's leaf rows
+// (src/main/node.cpp:537-575): one entry per leaf in guide-tree order (left to right, as get_leaf_nodes
+// collects them), `>name`, the aligned row cut into lines of chars_by_line characters (60 by default).
+int pagan_msa_write_fasta(const pagan_msa *m, const char *path, int32_t chars_by_line) {
+    if (!m || !m->aligned || !path) return PAGAN_E_ARG;
+    const size_t width = chars_by_line > 0 ? (size_t)chars_by_line : 60;
+    std::FILE *f = std::fopen(path, "w");
+    if (!f) return PAGAN_E_ARG;
+    std::vector<int> stack{m->root}, order;
+    while (!stack.empty()) {                                   // leaves left to right
+        const int t = stack.back();
+        stack.pop_back();
+        const TreeNode &n = m->tree[t];
+        if (n.left < 0) { order.push_back(m->id_of_tree[t]); continue; }
+        stack.push_back(n.right);
+        stack.push_back(n.left);
+    }
+    for (int leaf : order) {
+        std::fprintf(f, ">%s\n", m->names[leaf].c_str());
+        const std::string &row = m->rows[leaf];
+        for (size_t at = 0; at < row.size(); at += width) std::fprintf(f, "%.*s\n", (int)std::min(width, row.size() - at), row.c_str() + at);
+    }
+    return std::fclose(f) == 0 ? PAGAN_OK : PAGAN_E_ARG;
+}
+
 void *pagan_msa_node_graph(const pagan_msa *m, int32_t node) {
     if (!m || node < 0 || node >= (int)m->graph.size()) return nullptr;
     return m->graph[node].get();

@@ -63,6 +63,8 @@ def _lib():
         L.pagan_msa_alignment_length.restype = C.c_int
         L.pagan_msa_alignment_row.argtypes = [vp, C.c_int32, C.c_char_p]
         L.pagan_msa_alignment_row.restype = C.c_int
+        L.pagan_msa_write_fasta.argtypes = [vp, C.c_char_p, C.c_int32]
+        L.pagan_msa_write_fasta.restype = C.c_int
         L.pagan_msa_node_graph.argtypes = [vp, C.c_int32]
         L.pagan_msa_node_graph.restype = vp
         L.pagan_msa_destroy.argtypes = [vp]
@@ -95,7 +97,7 @@ def _lib():
 
 HOST_EXPORTED = ["pagan_assign_units", "pagan_msa_default_opts", "pagan_msa_create", "pagan_msa_align", "pagan_msa_n_internal",
                  "pagan_msa_node_info", "pagan_msa_node_job", "pagan_msa_node_result", "pagan_msa_timing_get",
-                 "pagan_msa_alignment_length", "pagan_msa_alignment_row", "pagan_msa_node_graph",
+                 "pagan_msa_alignment_length", "pagan_msa_alignment_row", "pagan_msa_write_fasta", "pagan_msa_node_graph",
                  "pagan_msa_destroy", "pagan_hgraph_leaf", "pagan_hgraph_parent", "pagan_hgraph_view",
                  "pagan_hgraph_attrs", "pagan_hgraph_fwd", "pagan_hgraph_string", "pagan_hgraph_free",
                  "pagan_define_tunnel", "pagan_dna_model"]
@@ -299,6 +301,13 @@ class Msa:
             self._L.pagan_msa_alignment_row(self._h, k, buf)
             rows.append(buf.raw[:n].decode())
         return rows
+
+    def write_fasta(self, path, chars_by_line=60):
+        """The leaf rows as FASTA in guide-tree order (Fasta_reader::write_fasta over Node::get_alignment)."""
+        rc = self._L.pagan_msa_write_fasta(self._h, str(path).encode(), chars_by_line)
+        if rc != 0:
+            from . import PaganError
+            raise PaganError(rc, "pagan_msa_write_fasta")
 
     def close(self):
         if self._h:

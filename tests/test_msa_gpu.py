@@ -64,3 +64,27 @@ def test_tree_errors(pg):
     assert e.value.code == host.PAGAN_E_TREE
     with pytest.raises(pg.PaganError):
         host.Msa(["a", "b"], ["ACGT", "ACGT"], "(a:0.1,x:0.1);")
+
+
+def test_fasta_output_in_tree_order(pg, tmp_path):
+    """pagan_msa_write_fasta: Fasta_reader::write_fasta over the leaf rows, leaves left to right."""
+    names, seqs, _ = synth.evolve_balanced(4, 200, branch=0.02, sub=0.02, indel_start=0.01, mean_len=3, seed=5)
+    nwk = "((%s:0.02,%s:0.02):0.02,(%s:0.02,%s:0.02):0.02);" % (names[2], names[0], names[3], names[1])
+    msa = host.Msa(names, seqs, nwk, use_anchors=0).align()
+    out = tmp_path / "aligned.fas"
+    msa.write_fasta(out, chars_by_line=50)
+    rows = msa.alignment()
+    lines = out.read_text().split("\n")
+    assert lines[-1] == ""
+    entries, name = {}, None
+    order = []
+    for ln in lines[:-1]:
+        if ln.startswith(">"):
+            name = ln[1:]; order.append(name); entries[name] = []
+        else:
+            assert 0 < len(ln) <= 50
+            entries[name].append(ln)
+    assert order == [names[2], names[0], names[3], names[1]]
+    for k, nm in enumerate(names):
+        assert "".join(entries[nm]) == rows[k]
+        assert all(len(x) == 50 for x in entries[nm][:-1])
