@@ -49,3 +49,19 @@ for k in range(msa.n_internal):
         anyd = ((cl[imax + 1] - cl[imin]) + (cr[jhi + 1] - cr[jlo])) > 0
         line += " | d:%s %.4f" % (name, anyd.mean())
     print(line, flush=True)
+
+# ---- shapes of the non-simple sites (what a register-carried skip-edge step would have to cover) ----
+for k in (msa.n_internal - 1, msa.n_internal - 2, msa.n_internal // 2):
+    l, r, m, b = msa.node_job(k)
+    for side, g in (("L", l), ("R", r)):
+        off = g.bwd_off.astype(np.int64); n = g.n_sites - 1
+        ne = off[1:n + 1] - off[:n]
+        two = np.nonzero(ne == 2)[0]
+        d0 = two - g.bwd_src[off[two]]; d1 = two - g.bwd_src[off[two] + 1]
+        w0 = g.bwd_logw[off[two]]; w1 = g.bwd_logw[off[two] + 1]
+        one = np.nonzero(ne == 1)[0]
+        one_d = one - g.bwd_src[off[one]]; one_w = g.bwd_logw[off[one]]
+        print("node %d %s: sites %d | ne==1 %d (of which dist>1 %d, weight!=0 %d) | ne==2 %d: adjacent first %d, adjacent second %d, "
+              "no adjacent %d, both weights 0 %d | ne>2 %d" % (k, side, n, one.size, int((one_d > 1).sum()), int((one_w != 0).sum()),
+              two.size, int((d0 == 1).sum()), int(((d1 == 1) & (d0 != 1)).sum()), int(((d0 != 1) & (d1 != 1)).sum()),
+              int(((w0 == 0) & (w1 == 0)).sum()), int((ne > 2).sum())), flush=True)

@@ -6,10 +6,12 @@ __global__ void k(long long *out, double *buf, int n_iter, int stores_per_iter, 
     double v = threadIdx.x;
     long long t0 = __builtin_readcyclecounter();
     double *p = buf + threadIdx.x * 3;
+    const double *end = buf + ((size_t)1 << 26) - 4096;        // stay inside the buffer whatever the stride
     for (int i = 0; i < n_iter; ++i) {
         for (int s = 0; s < stores_per_iter; ++s) {
             asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory");
             p += stride;
+            if (p >= end) p = buf + threadIdx.x * 3;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -21,6 +23,7 @@ __global__ void k(long long *out, double *buf, int n_iter, int stores_per_iter, 
         double x;
         asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(buf + threadIdx.x) : "memory");
         acc += x; p += stride;
+        if (p >= end) p = buf + threadIdx.x * 3;
     }
     long long t2 = __builtin_readcyclecounter();
     // load alone
