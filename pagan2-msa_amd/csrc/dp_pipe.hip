@@ -785,7 +785,16 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                         wm = first_max3(cmv + tM, cxv + tX, cyv + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
                                         PG_Y | PG_BP_ADJL | PG_BP_ADJR, qm);
                     } else {
-                        gen_cell(d, slot, resmask, r, jj, wx, wy, wm, qx, qy, qm);
+                        const int nl = (gl.x >> PR_NE_SHIFT) & 127, nr = (gr.x >> PR_NE_SHIFT) & 127;
+                        if ((unsigned)(nl - 1) < 2u && (unsigned)(nr - 1) < 2u && r >= 2 && r <= Lx - 2 && jj >= 2 && jj <= Ly - 2) {
+                            // interior cell, at most two bwd edges per site: its eight operands in one round trip
+                            const int ti = (gl.x & 0xffff) + (gr.x & 0xffff) * S;
+                            const float smv = TAB_LDS ? PM.table[ti & 255] : far_f32(table + ti);
+                            multi2_cell<true>(sc_out, psc, d, resmask, slot, gl, gr, r, jj, reduced_terminal, go, ge, ng,
+                                              tng2 + (double)smv, tng1 + (double)smv, wx, wy, wm, qx, qy, qm);
+                        } else {
+                            gen_cell(d, slot, resmask, r, jj, wx, wy, wm, qx, qy, qm);
+                        }
                     }
                     typedef unsigned u3 __attribute__((ext_vector_type(3)));
                     const unsigned off = (unsigned)(r - lo);
