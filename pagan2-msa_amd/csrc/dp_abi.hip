@@ -413,8 +413,10 @@ template <class T> void put(std::vector<char> &stage, const void *devptr_as_off,
 
 int launch_fill(pagan_batch *b) {
     if (b->n_ring > 0) {
-        static bool lds_set = false;      // > 64 KB of dynamic LDS has to be opted into once per process
-        if (!lds_set) {
+        // > 64 KB of dynamic LDS has to be opted into once per device (a process may drive several)
+        static std::atomic<bool> lds_set_dev[64];
+        std::atomic<bool> &lds_set = lds_set_dev[b->device & 63];
+        if (!lds_set.load()) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_ring<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_ring_lds_bytes()));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_ring<false>),
@@ -423,7 +425,7 @@ int launch_fill(pagan_batch *b) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_pipe_lds_bytes()));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_pipe<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_pipe_lds_bytes()));
-            lds_set = true;
+            lds_set.store(true);
         }
         // model tables of <= 16 states (DNA: 15) are cached in LDS; larger ones stay in HBM/L2
         const int n_small = b->n_ring_small, n_big = b->n_ring - b->n_ring_small;

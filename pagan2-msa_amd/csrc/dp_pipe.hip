@@ -54,7 +54,7 @@
 #define PDR_REACH 60             // oldest diagonal looked up in it
 #define PLOOK 64                 // diagonals the loader looks ahead of the slowest wave
 #define PLAND 8                  // stores of diagonal d have landed once the storing wave completed d+PLAND
-#define PSPIN_LIMIT (1 << 22)
+#define PSPIN_LIMIT (1 << 25)     // ~10 s of polling: far beyond any legitimate wait (a wave sleeping through a long gap)
 
 // site record, word x
 #define PR_SIMPLE 0x10000        // one bwd edge, from the previous site, log-weight 0
