@@ -464,6 +464,9 @@ __device__ __forceinline__ void commit_cell(gdouble_w sc_out, gu32_w bp_out, con
 } // namespace
 
 #ifdef PG_PIPE_STATS
+#ifndef PG_STAT_CLASS
+#define PG_STAT_CLASS 0      // the class whose steps the phase stamps cover (-DPG_STAT_CLASS=1 for multi-edge steps)
+#endif
 #define PSTAMP(k) do { const long long t_ = __builtin_readcyclecounter(); if (st_on) st_acc[k] += t_ - st_t; st_t = t_; } while (0)
 #else
 #define PSTAMP(k)
@@ -855,7 +858,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
         int d = wake;
         while (d < sleep) {
 #ifdef PG_PIPE_STATS
-            st_on = (dA.s4 & 15) == 0 && __any(row <= dA.y && row >= dA.x);
+            st_on = (dA.s4 & 15) == PG_STAT_CLASS && __any(row <= dA.y && row >= dA.x);
             st_t = __builtin_readcyclecounter();
             if (st_on) st_n += 2;
 #endif
