@@ -401,7 +401,7 @@ void carve_outputs(Carver &c, const HostJob &hj, PgDevJob *d) {
     d->sc = c.take<double>(3 * (size_t)hj.dx.cells);
     d->bp = c.take<unsigned>(3 * (size_t)hj.dx.cells);
     d->trace = c.take<int>(3 * (size_t)(hj.Lx + hj.Ly));
-    d->ttab = c.take<int>(4 * (size_t)hj.tb.back());
+    d->ttab = c.take<int>(8 * (size_t)hj.tb.back());
     d->segs = c.take<int>(6 * (size_t)(2 * hj.n_bound + 8));
     d->endcell = c.take<int>(8);
     d->endscore = c.take<double>(1);

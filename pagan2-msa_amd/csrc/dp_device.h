@@ -64,6 +64,7 @@ struct PgDevJob {
     // segmented traceback
     int n_bound;             // K: boundaries k = 1..K at diagonals k*PG_SEG
     const int *tb;           // [K+2] first table entry of boundary k (tb[K+1] = total)
-    int *ttab;               // [total][4]: exit i, exit j, exit matrix | kind<<2, cells visited (-1: dead entry)
+    int *ttab;               // [total][8]: exit i, exit j, exit matrix | kind<<2, cells visited (-1: dead entry),
+                             //             the exit cell's own entry (absolute index, -1: none), 3 x pad
     int *segs;               // [2K+8][6]: start i, j, matrix, cells, output offset, pad
 };

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(128) void pg_trace_spec(const PgDevJob *__restrict_
     const int mnB = J.imin[D - 1], wB = max(J.imax[D - 1] - mnB + 1, 0);
     const int n_entries = 3 * (wA + wB);
     const int low = (k - 1) * PG_SEG;                // next lower boundary pair {low, low-1}; k == 1: run to the start
-    gint_w tab = J.ttab + 4 * (long long)J.tb[k];
+    gint_w tab = J.ttab + 8 * (long long)J.tb[k];
     for (int e = threadIdx.x; e < n_entries; e += blockDim.x) {
         TNode n;
         if (e < 3 * wA) { n.i = mnA + e / 3; n.j = D - n.i; } else { n.i = mnB + (e - 3 * wA) / 3; n.j = D - 1 - n.i; }
@@ -575,7 +575,18 @@ __global__ __launch_bounds__(128) void pg_trace_spec(const PgDevJob *__restrict_
             if (steps > 4 * PG_SEG || !trace_step(J, n, w)) { ok = false; break; }
             ++steps;
         }
-        tab[4 * e] = n.i; tab[4 * e + 1] = n.j; tab[4 * e + 2] = (n.vit & 3) | (kind << 2); tab[4 * e + 3] = ok ? steps : -1;
+        // where the chase arrived, and -- when that is a cell of the next lower boundary -- its entry there,
+        // so that pg_trace_compose hops with one dependent read per boundary
+        int next = -1;
+        if (ok && kind == EXIT_ENTRY && n.vit >= 0 && n.vit <= 2) {
+            const int dd = n.i + n.j, mn = J.imin[dd], mx = J.imax[dd];
+            if (n.i >= mn && n.i <= mx) next = J.tb[k - 1] + entry_index(J, k - 1, n);
+        }
+        typedef int i4 __attribute__((ext_vector_type(4)));
+        i4 a; a.x = n.i; a.y = n.j; a.z = (n.vit & 3) | (kind << 2); a.w = ok ? steps : -1;
+        i4 b; b.x = next; b.y = 0; b.z = 0; b.w = 0;
+        *(PG_GLOBAL i4 *)(tab + 8 * e) = a;
+        *(PG_GLOBAL i4 *)(tab + 8 * e + 4) = b;
     }
 }
 
@@ -588,19 +599,28 @@ __global__ void pg_trace_compose(const PgDevJob *__restrict__ jobs) {
     const int cap = J.Lx + J.Ly, seg_cap = 2 * J.n_bound + 8;
     int off = 0, nseg = 0, status = 0;
     gint_w tr = J.trace;
+    long long cur = -1;                 // table entry of node n, when the previous hop delivered it
     while (!trace_done(n)) {
         if (off >= cap) { status = 2; break; }
-        const int k = boundary_of(n.i + n.j, J.n_bound);
-        if (k > 0) {
-            const int mnD = J.imin[n.i + n.j], mxD = J.imax[n.i + n.j];
-            if (n.i < mnD || n.i > mxD || n.vit < 0 || n.vit > 2) { status = 2; break; }
-            PG_GLOBAL const int *e = J.ttab + 4 * ((long long)J.tb[k] + entry_index(J, k, n));
-            const int steps = e[3];
+        if (cur < 0) {
+            const int k = boundary_of(n.i + n.j, J.n_bound);
+            if (k > 0) {
+                const int mnD = J.imin[n.i + n.j], mxD = J.imax[n.i + n.j];
+                if (n.i < mnD || n.i > mxD || n.vit < 0 || n.vit > 2) { status = 2; break; }
+                cur = (long long)J.tb[k] + entry_index(J, k, n);
+            }
+        }
+        if (cur >= 0) {
+            typedef int i4 __attribute__((ext_vector_type(4)));
+            PG_GLOBAL const i4 *e = (PG_GLOBAL const i4 *)(J.ttab + 8 * cur);
+            const i4 a = e[0], b = e[1];
+            const int steps = a.w;
             if (steps <= 0 || nseg >= seg_cap || off + steps > cap) { status = 2; break; }
             gint_w sg = J.segs + 6 * nseg++;
             sg[0] = n.i; sg[1] = n.j; sg[2] = n.vit; sg[3] = steps; sg[4] = off;
             off += steps;
-            n.i = e[0]; n.j = e[1]; n.vit = e[2] & 3;
+            n.i = a.x; n.j = a.y; n.vit = a.z & 3;
+            cur = b.x;                  // -1: a long edge jumped over the next boundary, or the path ended
         } else {
             // not on a boundary pair (the first cells below the end corner, or a long edge that
             // jumped over a pair): chase serially until one is reached
