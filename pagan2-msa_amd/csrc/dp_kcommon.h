@@ -166,16 +166,6 @@ __device__ __forceinline__ void fill_cell_hbm(const View &J, int d, const Diag &
 // Loads the COMPUTE waves need only on rare paths (an edge reaching past the ring).  Issued as
 // inline asm with their own wait so that the compiler's waitcnt insertion never places a
 // vmcnt(0) -- which would also wait for every store in flight -- on the common path.
-__device__ __forceinline__ double far_f64(PG_GLOBAL const double *p) {
-    double v;
-    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ int far_i32(PG_GLOBAL const int *p) {
-    int v;
-    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-    return v;
-}
 __device__ __forceinline__ float far_f32(PG_GLOBAL const float *p) {
     float v;
     asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
@@ -193,11 +183,6 @@ __device__ __forceinline__ void far_cell(PG_GLOBAL const double *p, double &xs, 
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(xy), "=&v"(m) : "v"(p) : "memory");
     xs = xy.x; ys = xy.y; ms = m;
-}
-__device__ __forceinline__ long long far_i64(PG_GLOBAL const long long *p) {
-    long long v;
-    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-    return v;
 }
 
 // Workgroup barrier that orders LDS traffic only.  (__syncthreads() also waits for vmcnt(0),

@@ -44,7 +44,7 @@
 
 #define PNW 4
 #define PNT (64 * PNW)
-#define PNTW (PNT - 16)          // widest diagonal handled in registers
+#define PNTW (PNT - 16)          // widest diagonal handled in registers (the host's PG_PIPE_WIDTH)
 #define PRK 20                   // ring depth in diagonals
 #define PAGE 16                  // a reader may reach PAGE-1 diagonals back
 #define PLEAD (PRK - PAGE + 1)   // a wave computes D only when its downstream neighbour completed D-PLEAD
@@ -205,33 +205,6 @@ __device__ __forceinline__ void edge_at(const pg_i4 &rec, int k, int site, int &
     }
 }
 
-// Scores of the cell `age` diagonals back in row p.  FAR = false: age is 1..PAGE-1 and that
-// diagonal is in the ring (class 1).  FAR = true: any earlier cell; `resmask` has bit a set when
-// diagonal d-a went through the lanes, everything else is read from L2/HBM -- after the caller
-// made sure it has landed -- through the descriptor window (or the descriptor array itself).
-template <bool FAR>
-__device__ __forceinline__ void old_cell(gdouble_w sc, cdesc8_p psc, int d, int slot, unsigned resmask, int age, int p,
-                                         double &xs, double &ys, double &ms) {
-    if (!FAR || (age < PAGE && ((resmask >> age) & 1u))) {
-        int s = slot - age;
-        s += s < 0 ? PRK : 0;
-        xs = PM.sc[s][p & (PNT - 1)][PG_X];
-        ys = PM.sc[s][p & (PNT - 1)][PG_Y];
-        ms = PM.sc[s][p & (PNT - 1)][PG_M];
-    } else {
-        const double NI = neg_inf();
-        xs = NI; ys = NI; ms = NI;
-        const int dd = d - age;
-        pg_i4 ds;
-        if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
-        else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
-        if (p >= ds.x && p <= ds.y) {
-            const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p - ds.x);
-            far_cell((gdouble_w)((PG_GLOBAL char *)sc + boff), xs, ys, ms);
-        }
-    }
-}
-
 // A cell's 24 bytes requested from L2 without waiting; far_wait3 is the wait (and the point after which
 // the compiler may use the registers).
 typedef double pg_d2 __attribute__((ext_vector_type(2)));
@@ -243,8 +216,11 @@ __device__ __forceinline__ void far_wait3(pg_d2 &a, double &am, pg_d2 &b, double
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(am), "+v"(b), "+v"(bm), "+v"(c), "+v"(cm) : : "memory");
 }
 
-// Up to three earlier cells at once (the X, Y and M operands of one (left edge, right edge) item): cells in
-// the ring are LDS reads; the others are requested from L2 together and waited for once.
+// Up to three earlier cells at once (the X, Y and M operands of one (left edge, right edge) item), each `age`
+// diagonals back in row p.  FAR = false: every age is 1..PAGE-1 and those diagonals are in the ring (class 1).
+// FAR = true: any earlier cell; `resmask` has bit a set when diagonal d-a went through the lanes, the others are
+// requested from L2/HBM together -- after the caller made sure they have landed -- through the descriptor
+// window (or the descriptor array itself) and waited for once.
 struct CellAsk { bool need; int age, p; };
 template <bool FAR>
 __device__ __forceinline__ void old_cells3(gdouble_w sc, cdesc8_p psc, int d, int slot, unsigned resmask, const CellAsk &a0,
