@@ -37,14 +37,7 @@ __global__ void pg_trace_emit(const PgDevJob *jobs);
 #define PG_RING_SITE_SPAN 576
 #define PG_RING_EDGE_CAP 2048
 unsigned pg_ring_lds_bytes();
-// limits of the register-wavefront kernel (dp_pipe.hip: PNTW lanes, PAGE ring reach, PEC edge window)
-#define PG_PIPE_WIDTH 240
-#define PG_PIPE_REACH 16
-#define PG_PIPE_EDGE_CAP 1024
-#define PG_PIPE_SITE_EDGES 126
-#define PG_PIPE_RING 20
-#define PG_PIPE_WINDOW 352            // widest diagonal the kernel's site-record windows still cover
-#define PG_PIPE_WAKE 6
+// limits of the register-wavefront kernel: PG_PIPE_* in dp_device.h, shared with dp_pipe.hip
 unsigned pg_pipe_lds_bytes();
 
 namespace {

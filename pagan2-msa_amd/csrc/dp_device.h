@@ -35,6 +35,16 @@
 #define PG_MAX_SLOT 16383
 #define PG_SEG 256           // diagonals per traceback segment
 
+// Geometry of the banded fill kernel (dp_pipe.hip) that the host-side planner (dp_abi.hip:
+// classify_diagonals, schedule_waves) has to agree with.
+#define PG_PIPE_WIDTH 240        // widest diagonal computed in the lanes' registers (256 lanes - PG_PIPE_REACH)
+#define PG_PIPE_REACH 16         // a cell may read PG_PIPE_REACH-1 diagonals back in the LDS ring
+#define PG_PIPE_RING 20          // ring depth in diagonals: a wave stays awake this long after its last cell
+#define PG_PIPE_WAKE 6           // ... and wakes this many diagonals before its first one (operand prefetch pipeline)
+#define PG_PIPE_WINDOW 352       // widest diagonal the kernel's site-record windows (512 sites) still cover
+#define PG_PIPE_EDGE_CAP 1024    // bwd edges of any PG_RING_SITE_SPAN consecutive sites must fit the LDS edge window
+#define PG_PIPE_SITE_EDGES 126   // bwd edges per site (7-bit count in the site record)
+
 struct PgDevJob {
     int Lx, Ly;              // matrix dimensions (sites minus the stop site)
     int nd;                  // number of anti-diagonals = Lx + Ly - 1

@@ -44,16 +44,17 @@
 
 #define PNW 4
 #define PNT (64 * PNW)
-#define PNTW (PNT - 16)          // widest diagonal handled in registers (the host's PG_PIPE_WIDTH)
-#define PRK 20                   // ring depth in diagonals
-#define PAGE 16                  // a reader may reach PAGE-1 diagonals back
+#define PNTW PG_PIPE_WIDTH       // widest diagonal handled in registers
+#define PRK PG_PIPE_RING         // ring depth in diagonals
+#define PAGE PG_PIPE_REACH       // a reader may reach PAGE-1 diagonals back
 #define PLEAD (PRK - PAGE + 1)   // a wave computes D only when its downstream neighbour completed D-PLEAD
 #define PRW 512                  // site-record window (sites)
-#define PEC 1024                 // bwd-edge window (edges)
+#define PEC PG_PIPE_EDGE_CAP     // bwd-edge window (edges)
 #define PDR 128                  // descriptor window (diagonals)
 #define PDR_REACH 60             // oldest diagonal looked up in it
 #define PLOOK 64                 // diagonals the loader looks ahead of the slowest wave
 #define PLAND 8                  // stores of diagonal d have landed once the storing wave completed d+PLAND
+static_assert(PNTW == PNT - PAGE && PRK > PAGE && PG_PIPE_WINDOW + 160 <= PRW, "kernel geometry out of step with dp_device.h");
 #define PSPIN_LIMIT (1 << 25)     // ~10 s of polling: far beyond any legitimate wait (a wave sleeping through a long gap)
 
 // site record, word x
