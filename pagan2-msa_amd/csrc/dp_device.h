@@ -37,8 +37,10 @@
 
 // Geometry of the banded fill kernel (dp_pipe.hip) that the host-side planner (dp_abi.hip:
 // classify_diagonals, schedule_waves) has to agree with.
-#define PG_PIPE_WIDTH 240        // widest diagonal computed in the lanes' registers (256 lanes - PG_PIPE_REACH)
-#define PG_PIPE_REACH 16         // a cell may read PG_PIPE_REACH-1 diagonals back in the LDS ring
+#define PG_PIPE_WIDTH 237        // widest diagonal computed in the lanes' registers (256 lanes - PG_PIPE_REACH)
+#define PG_PIPE_REACH 19         // a cell may read PG_PIPE_REACH-1 diagonals back in the LDS ring.  Measured on the
+                                 // root of cfg4: 12 -> 408 ms, 16 -> 355, 18 -> 348, 19 -> 344, 20 -> 358: a longer reach
+                                 // turns far steps into ring steps, a shorter one gives the wave pipeline more slack
 #define PG_PIPE_RING 20          // ring depth in diagonals: a wave stays awake this long after its last cell
 #define PG_PIPE_WAKE 6           // ... and wakes this many diagonals before its first one (operand prefetch pipeline)
 #define PG_PIPE_WINDOW 352       // widest diagonal the kernel's site-record windows (512 sites) still cover

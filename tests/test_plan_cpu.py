@@ -6,7 +6,7 @@ import pytest
 import pagan2_msa_amd as pg
 from pagan2_msa_amd import abi, synth
 
-REACH, WIDTH, WINDOW, RING, WAKE = 16, 240, 352, 20, 6
+REACH, WIDTH, WINDOW, RING, WAKE = 19, 237, 352, 20, 6      # dp_device.h: PG_PIPE_*
 
 
 def site_features(g, n):
