@@ -179,7 +179,9 @@ int  pagan_batch_debug_trace(pagan_batch *b, int32_t k, void *dst, int64_t bytes
  * cls[Lx+Ly-1] = class of every anti-diagonal (0 simple, 1 multi-edge, 2 multi-edge with far edges,
  * 3 general, 4 wide) and the four compute waves' awake intervals (layout: dp_device.h, sched)      */
 int  pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, const pagan_band *band,
-                         uint8_t *cls, int32_t n_cls, int32_t *sched, int32_t sched_cap, int32_t *sched_len);
+                         uint8_t *cls, int32_t n_cls, int32_t *sched, int32_t sched_cap, int32_t *sched_len,
+                         int32_t *lead_req /* [n_cls] or NULL: diagonal the downstream wave must have completed
+                                              before diagonal d may overwrite its row of the LDS ring, -1 none */);
 /* diagnostic: job k's scores, [cells][3] doubles (X, Y, M), diagonal-major                */
 int  pagan_batch_debug_scores(pagan_batch *b, int32_t k, double *dst, int64_t count);
 /* diagnostic: overwrite all device outputs with 0xFF (NaN scores) before a run           */

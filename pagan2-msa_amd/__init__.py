@@ -85,9 +85,9 @@ def align(left, right, model, band=None, flags=0, device=-1):
         L.pagan_result_free(C.byref(res))
 
 
-def debug_plan(left, right, band=None):
+def debug_plan(left, right, band=None, with_lead=False):
     """Diagnostic (host only): (classes[Lx+Ly-1] uint8, [awake intervals of wave 0..3]) the banded fill kernel
-    would be given for this job."""
+    would be given for this job; with_lead adds the per-diagonal downstream-progress requirement."""
     import numpy as np
     L = lib()
     nd = left.n_sites + right.n_sites - 3
@@ -95,9 +95,10 @@ def debug_plan(left, right, band=None):
     cap = 8 * nd + 64
     sched = np.zeros(cap, np.int32)
     n = C.c_int32()
+    lead = np.zeros(nd, np.int32)
     _check(L.pagan_dp_debug_plan(C.byref(left.c), C.byref(right.c), C.byref(band.c) if band is not None else None,
                                  cls.ctypes.data_as(C.POINTER(C.c_uint8)), nd, sched.ctypes.data_as(C.POINTER(C.c_int32)),
-                                 cap, C.byref(n)), "pagan_dp_debug_plan")
+                                 cap, C.byref(n), lead.ctypes.data_as(C.POINTER(C.c_int32))), "pagan_dp_debug_plan")
     waves = []
     for w in range(4):
         k = int(sched[w])
@@ -106,6 +107,8 @@ def debug_plan(left, right, band=None):
             iv.append((int(sched[k]), int(sched[k + 1])))
             k += 2
         waves.append(iv)
+    if with_lead:
+        return cls, waves, lead
     return cls, waves
 
 

@@ -175,7 +175,7 @@ def declare(lib):
     lib.pagan_batch_destroy.restype = None
     lib.pagan_batch_debug_trace.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
     lib.pagan_batch_debug_trace.restype = C.c_int
-    lib.pagan_dp_debug_plan.argtypes = [gp, gp, bp, C.POINTER(C.c_uint8), C.c_int32, _i32p, C.c_int32, _i32p]
+    lib.pagan_dp_debug_plan.argtypes = [gp, gp, bp, C.POINTER(C.c_uint8), C.c_int32, _i32p, C.c_int32, _i32p, _i32p]
     lib.pagan_dp_debug_plan.restype = C.c_int
     lib.pagan_batch_debug_scores.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_int64]
     lib.pagan_batch_debug_scores.restype = C.c_int

@@ -125,6 +125,7 @@ struct HostJob {
     bool ring_ok = false;        // fits the LDS-staged narrow-band kernel
     std::vector<uint8_t> cls;    // per diagonal: how dp_pipe.hip computes it (empty: not a pipe job)
     std::vector<int> sched;      // dp_pipe.hip: awake intervals of the four compute waves (dp_device.h)
+    std::vector<int> lead_req;   // dp_pipe.hip: per diagonal, what the downstream wave must have completed first
     int n_bound = 0;             // traceback boundaries (dp_device.h)
     std::vector<int> tb;         // [n_bound + 2] table offsets
 };
@@ -176,7 +177,7 @@ struct SiteFeat {
 //      diagonals back;
 //   1  holds a site that is not simple;   0  otherwise.
 void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, const RowBand &rb,
-                        const DiagIndex &dx, std::vector<uint8_t> *out) {
+                        const DiagIndex &dx, std::vector<uint8_t> *out, std::vector<int> *lead_req) {
     const int nd = Lx + Ly - 1;
     SiteFeat fl, fr;
     fl.build(L, Lx); fr.build(R, Ly);
@@ -214,6 +215,37 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
         else if (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0) c = 1;
         else c = 0;
         (*out)[d] = c;
+    }
+    // How far back in the LDS ring the cells of a diagonal read: 2 for simple cells, span(i) + span(j) for a
+    // multi-edge cell (bounded here by the largest spans among the diagonal's rows and columns: sliding-window
+    // maxima, both windows only move forward), the full reach for the other classes.  From that, the diagonal
+    // the downstream wave must have completed before a wave may overwrite ring row D % PG_PIPE_RING with
+    // diagonal D: the last diagonal that still reads D - PG_PIPE_RING.
+    std::vector<int> need(nd, PG_PIPE_REACH - 1);
+    {
+        std::vector<int> ql, qr;                       // candidate indices, spans decreasing
+        size_t hl = 0, hr = 0;
+        int nextl = 0, nextr = 0;
+        for (int d = 0; d < nd; ++d) {
+            const int lo = dx.imin[d], hi = dx.imax[d];
+            if (hi < lo) continue;
+            for (; nextl <= hi; ++nextl) { while (ql.size() > hl && fl.span[ql.back()] <= fl.span[nextl]) ql.pop_back(); ql.push_back(nextl); }
+            while (hl < ql.size() && ql[hl] < lo) ++hl;
+            const int jlo = d - hi, jhi = d - lo;
+            for (; nextr <= jhi; ++nextr) { while (qr.size() > hr && fr.span[qr.back()] <= fr.span[nextr]) qr.pop_back(); qr.push_back(nextr); }
+            while (hr < qr.size() && qr[hr] < jlo) ++hr;
+            if ((*out)[d] <= 1) {
+                const int m = (hl < ql.size() ? fl.span[ql[hl]] : 1) + (hr < qr.size() ? fr.span[qr[hr]] : 1);
+                need[d] = (*out)[d] == 0 ? 2 : std::min(std::max(m, 2), PG_PIPE_REACH - 1);
+            }
+        }
+    }
+    lead_req->assign(nd, -1);
+    for (int D = PG_PIPE_RING; D < nd; ++D) {
+        int req = -1;
+        for (int t = D - PG_PIPE_RING + 1; t <= D - PG_PIPE_RING + PG_PIPE_REACH - 1 && t < nd; ++t)
+            if (t - need[t] <= D - PG_PIPE_RING) req = t;
+        (*lead_req)[D] = req;
     }
 }
 
@@ -349,7 +381,7 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
         hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES) &&
                       edges_fit_ring(jb.right, hj->Ly, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES);
         if (hj->ring_ok) {
-            classify_diagonals(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, &hj->cls);
+            classify_diagonals(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, &hj->cls, &hj->lead_req);
             schedule_waves(hj->dx, hj->cls, &hj->sched);
         }
     } else {
@@ -575,7 +607,7 @@ int pagan_dp_select_device(int32_t device) {
 // Host-only: the per-diagonal classes and the wave schedule pg_fill_pipe would be given for this job
 // (what validate_job computes); lets the planner be tested without a device.
 int pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, const pagan_band *band, uint8_t *cls_out,
-                        int32_t n_cls, int32_t *sched_out, int32_t sched_cap, int32_t *sched_len) {
+                        int32_t n_cls, int32_t *sched_out, int32_t sched_cap, int32_t *sched_len, int32_t *lead_req_out) {
     if (!left || !right || !cls_out || !sched_out || !sched_len) return PAGAN_E_ARG;
     int rc;
     if ((rc = check_graph(left)) != PAGAN_OK) return rc;
@@ -587,10 +619,11 @@ int pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, const
     DiagIndex dx;
     dx.build(Lx, Ly, rb);
     std::vector<uint8_t> cls;
-    std::vector<int> sched;
-    classify_diagonals(left, right, Lx, Ly, rb, dx, &cls);
+    std::vector<int> sched, lead_req;
+    classify_diagonals(left, right, Lx, Ly, rb, dx, &cls, &lead_req);
     schedule_waves(dx, cls, &sched);
     std::memcpy(cls_out, cls.data(), cls.size());
+    if (lead_req_out) std::memcpy(lead_req_out, lead_req.data(), sizeof(int) * lead_req.size());
     *sched_len = (int32_t)sched.size();
     if ((int)sched.size() > sched_cap) return PAGAN_E_ARG;
     std::memcpy(sched_out, sched.data(), sizeof(int) * sched.size());
@@ -703,6 +736,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
                 const unsigned pair = t + 1 < hj.cls.size() && hj.cls[t + 1] <= 1 ? 1u : 0u;   // the next step is hot too
                 packed[8 * t + 4] = (int)(hj.cls[t] | (pair << 4) | (mask << 5));
                 packed[8 * t + 5] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[8 * t + 6] = (int)(hj.dx.doff[t] >> 32);
+                packed[8 * t + 7] = hj.lead_req[t];
             }
             put(stage, d.psc, packed.data(), packed.size());
             put(stage, d.sched, hj.sched.data(), hj.sched.size());

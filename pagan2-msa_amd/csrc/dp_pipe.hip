@@ -47,7 +47,6 @@
 #define PNTW PG_PIPE_WIDTH       // widest diagonal handled in registers
 #define PRK PG_PIPE_RING         // ring depth in diagonals
 #define PAGE PG_PIPE_REACH       // a reader may reach PAGE-1 diagonals back
-#define PLEAD (PRK - PAGE + 1)   // a wave computes D only when its downstream neighbour completed D-PLEAD
 #define PRW 512                  // site-record window (sites)
 #define PEC PG_PIPE_EDGE_CAP     // bwd-edge window (edges)
 #define PDR 128                  // descriptor window (diagonals)
@@ -598,14 +597,12 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                 if (cols_ld <= need) cols_ld = poll_ge(&PM.loaded[1], need + 1, PTAG(2));
                 const int mc = cols_ld >= Ly ? nd : cols_ld - 1 - need;
                 margin = mc < margin ? mc : margin;
-                {   // downstream neighbour: take what it has published, wait only for what this step needs
-                    const int w = flag_load(&PM.progress[dn]);
-                    p_dn = w > p_dn ? w : p_dn;
-                }
-                if (d - PLEAD > p_dn) p_dn = poll_ge(&PM.progress[dn], d - PLEAD, PTAG(3));
-                const int until = p_dn + PLEAD < d + margin ? p_dn + PLEAD : d + margin;
-                ok_until = until > d ? until : d;
+                ok_until = d + margin;
             }
+            // downstream neighbour: this step overwrites the ring row of diagonal d - PRK; the host worked out the
+            // last diagonal whose cells still read that one (cur.s7; 2 diagonals back in simple stretches, up to
+            // PAGE-1 where long edges are about)
+            if (cur.s7 > p_dn) p_dn = poll_ge(&PM.progress[dn], cur.s7, PTAG(3));
             // upstream neighbour: only a wave with a row about to use (row-1, .) has to wait for it
             if (d - 1 > p_up && __any(row <= hi + 1)) p_up = poll_ge(&PM.progress[up], d - 1, PTAG(4));
             if (!HOT && cls >= 2) {

@@ -29,6 +29,7 @@ def brute_plan(left, right, band):
     sl, simL, npL = site_features(left, Lx)
     sr, simR, npR = site_features(right, Ly)
     cls = np.zeros(nd, np.uint8)
+    need = np.zeros(nd, np.int64)
     rows_of = [[] for _ in range(nd)]
     for i in range(Lx):
         for j in range(lo[i], hi[i] + 1):
@@ -53,18 +54,36 @@ def brute_plan(left, right, band):
         else:
             c = 0
         cls[d] = c
+        if c == 0:
+            need[d] = 2
+        elif c == 1:
+            need[d] = min(REACH - 1, max(2, max(sl[i] + sr[d - i] for i in rows)))
+        else:
+            need[d] = REACH - 1
     active = np.zeros((4, nd), bool)
     for d in range(nd):
         for w in range(4):
             active[w, d] = cls[d] >= 4 or any((i % 256) // 64 == w for i in rows_of[d])
-    return cls, active
+    lead = np.full(nd, -1, np.int64)
+    for D in range(RING, nd):
+        for t in range(D - RING + 1, min(D - RING + REACH, nd)):
+            if t - need[t] <= D - RING:
+                lead[D] = t
+    return cls, active, lead
 
 
 def check(left, right, band):
-    cls, waves = pg.debug_plan(left, right, band)
-    want, active = brute_plan(left, right, band)
+    cls, waves, lead = pg.debug_plan(left, right, band, with_lead=True)
+    want, active, lead_exact = brute_plan(left, right, band)
     assert np.array_equal(cls, want), "classes differ at %s" % np.nonzero(cls != want)[0][:10]
     nd = cls.size
+    # the downstream wave must have completed at least what the exact rule asks (the planner bounds a multi-edge
+    # diagonal's reach from above), never the diagonal being computed or its predecessor, and in simple stretches
+    # exactly RING - 2 diagonals back
+    assert (lead >= lead_exact).all() and (lead <= np.maximum(np.arange(nd) - 2, -1)).all()
+    simple_run = np.convolve((cls == 0).astype(int), np.ones(RING, int), 'full')[:nd] == RING
+    d_idx = np.nonzero(simple_run)[0]
+    assert (lead[d_idx] == d_idx - RING + 2).all()
     for w in range(4):
         awake = np.zeros(nd, bool)
         last = -1
