@@ -60,9 +60,10 @@ struct PgDevJob {
     const int *imin, *imax;
     const long long *doff;
     const int *dsc;          // [nd][4] = imin, imax, doff low, doff high: one 16-byte scalar load per diagonal
-    const int *psc;          // [nd][8] (dp_pipe.hip; null for jobs of the other kernels): imin, imax, byte offset of the
+    const int *psc;          // [nd+1][8] (dp_pipe.hip; null for jobs of the other kernels): imin, imax, byte offset of the
                              //   diagonal's first score (= 24 * doff; low, high), class | next-is-class-0/1 << 4 | resident-mask << 5, doff low,
-                             //   doff high, 0.  class: 0 simple, 1 multi-edge, 2 multi-edge with far edges, 3 general,
+                             //   doff high, diagonal the downstream wave must have completed before this one
+                             //   overwrites its ring row.  class: 0 simple, 1 multi-edge, 2 multi-edge with far edges, 3 general,
                              //   4 wide; bit a of the mask: diagonal d-a was computed by the lanes (is in the LDS ring)
     const int *sched;        // dp_pipe.hip: [4] offsets, then per compute wave its awake intervals a0,b0,a1,b1,...,nd,nd
     int *fill_status;        // [1] 0 = filled; nonzero = the fill kernel abandoned a wait (internal error)

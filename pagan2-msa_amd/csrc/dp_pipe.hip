@@ -18,9 +18,10 @@
 //     the band), and that multi-edge sites read their older predecessors from;
 //   - there is NO workgroup barrier.  Each wave publishes the last diagonal it completed in
 //     LDS; a wave with cells on diagonal d waits (cached flag, re-read only when stale) until
-//     its upstream neighbour has completed d-1, and no wave runs more than PLEAD diagonals
-//     ahead of its downstream neighbour, which keeps the last PAGE diagonals of the ring
-//     intact for it.  The band is a diagonal stripe, so the waves form a pipeline: the wave
+//     its upstream neighbour has completed d-1, and before a wave overwrites a ring row it
+//     waits until its downstream neighbour has completed the last diagonal that still reads
+//     that row (worked out by the host per diagonal: 18 steps of slack in simple stretches, 2
+//     where long edges are about).  The band is a diagonal stripe, so the waves form a pipeline: the wave
 //     holding the top of the band leads, the others follow a step behind;
 //   - a wave whose 64 rows are nowhere near the band SLEEPS: the host lists, per wave, the
 //     diagonal intervals in which it must be awake (rows within reach of the band, plus PRK
