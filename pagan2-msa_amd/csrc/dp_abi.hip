@@ -153,15 +153,20 @@ bool has_negative_zero(const pagan_job &jb) {
 // What the fill kernel may assume about a site without looking at its edge list.
 struct SiteFeat {
     std::vector<int> span;            // farthest bwd edge, in sites (0: no bwd edge)
+    std::vector<int> span_ring;       // farthest bwd edge that reaches fewer than PG_PIPE_REACH sites back (>= 1)
     std::vector<int> not_simple;      // prefix count of sites that are not "one edge from the previous site, weight 1"
     std::vector<int> no_pred;         // prefix count of sites without bwd edges
     void build(const pagan_graph *g, int n) {
-        span.assign(n, 0); not_simple.assign(n + 1, 0); no_pred.assign(n + 1, 0);
+        span.assign(n, 0); span_ring.assign(n, 1); not_simple.assign(n + 1, 0); no_pred.assign(n + 1, 0);
         for (int s = 0; s < n; ++s) {
             const int a = g->bwd_off[s], b = g->bwd_off[s + 1];
-            int sp = 0;
-            for (int k = a; k < b; ++k) sp = std::max(sp, s - g->bwd_src[k]);
-            span[s] = sp;
+            int sp = 0, spr = 1;
+            for (int k = a; k < b; ++k) {
+                const int dist = s - g->bwd_src[k];
+                sp = std::max(sp, dist);
+                if (dist < PG_PIPE_REACH) spr = std::max(spr, dist);
+            }
+            span[s] = sp; span_ring[s] = spr;
             const bool simple = s > 0 && b - a == 1 && g->bwd_src[a] == s - 1 && g->bwd_logw[a] == 0.0f;
             not_simple[s + 1] = not_simple[s] + (simple ? 0 : 1);
             no_pred[s + 1] = no_pred[s] + (b == a ? 1 : 0);
@@ -223,19 +228,21 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
     // diagonal D: the last diagonal that still reads D - PG_PIPE_RING.
     std::vector<int> need(nd, PG_PIPE_REACH - 1);
     {
+        // classes 1 and 2: a cell reads the ring at ages dL, dR and dL + dR below the reach (older operands
+        // come from L2), so the largest ring-reaching spans among the diagonal's rows and columns bound it
         std::vector<int> ql, qr;                       // candidate indices, spans decreasing
         size_t hl = 0, hr = 0;
         int nextl = 0, nextr = 0;
         for (int d = 0; d < nd; ++d) {
             const int lo = dx.imin[d], hi = dx.imax[d];
             if (hi < lo) continue;
-            for (; nextl <= hi; ++nextl) { while (ql.size() > hl && fl.span[ql.back()] <= fl.span[nextl]) ql.pop_back(); ql.push_back(nextl); }
+            for (; nextl <= hi; ++nextl) { while (ql.size() > hl && fl.span_ring[ql.back()] <= fl.span_ring[nextl]) ql.pop_back(); ql.push_back(nextl); }
             while (hl < ql.size() && ql[hl] < lo) ++hl;
             const int jlo = d - hi, jhi = d - lo;
-            for (; nextr <= jhi; ++nextr) { while (qr.size() > hr && fr.span[qr.back()] <= fr.span[nextr]) qr.pop_back(); qr.push_back(nextr); }
+            for (; nextr <= jhi; ++nextr) { while (qr.size() > hr && fr.span_ring[qr.back()] <= fr.span_ring[nextr]) qr.pop_back(); qr.push_back(nextr); }
             while (hr < qr.size() && qr[hr] < jlo) ++hr;
-            if ((*out)[d] <= 1) {
-                const int m = (hl < ql.size() ? fl.span[ql[hl]] : 1) + (hr < qr.size() ? fr.span[qr[hr]] : 1);
+            if ((*out)[d] <= 2) {
+                const int m = (hl < ql.size() ? fl.span_ring[ql[hl]] : 1) + (hr < qr.size() ? fr.span_ring[qr[hr]] : 1);
                 need[d] = (*out)[d] == 0 ? 2 : std::min(std::max(m, 2), PG_PIPE_REACH - 1);
             }
         }

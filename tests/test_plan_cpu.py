@@ -28,6 +28,8 @@ def brute_plan(left, right, band):
     nd = Lx + Ly - 1
     sl, simL, npL = site_features(left, Lx)
     sr, simR, npR = site_features(right, Ly)
+    distL = [[s - p for p in left.bwd_src[left.bwd_off[s]:left.bwd_off[s + 1]]] or [1] for s in range(Lx)]
+    distR = [[s - p for p in right.bwd_src[right.bwd_off[s]:right.bwd_off[s + 1]]] or [1] for s in range(Ly)]
     cls = np.zeros(nd, np.uint8)
     need = np.zeros(nd, np.int64)
     rows_of = [[] for _ in range(nd)]
@@ -56,8 +58,13 @@ def brute_plan(left, right, band):
         cls[d] = c
         if c == 0:
             need[d] = 2
-        elif c == 1:
-            need[d] = min(REACH - 1, max(2, max(sl[i] + sr[d - i] for i in rows)))
+        elif c in (1, 2):
+            ages = [2]
+            for i in rows:
+                for dl in distL[i]:
+                    for dr in distR[d - i]:
+                        ages += [a for a in (dl, dr, dl + dr) if a < REACH]
+            need[d] = max(ages)
         else:
             need[d] = REACH - 1
     active = np.zeros((4, nd), bool)
