@@ -115,6 +115,11 @@ __device__ __forceinline__ int poll_ge(const int *p, int need, int tag) {
     return v;
 }
 #define PTAG(kind) ((kind) | (wave << 4) | (d << 8))
+#ifdef PG_PIPE_STATS
+#define POLL(p, need, kind) ([&] { const long long t0_ = __builtin_readcyclecounter(); const int v_ = poll_ge(p, need, PTAG(kind)); st_poll_t[kind] += __builtin_readcyclecounter() - t0_; ++st_poll_n[kind]; return v_; }())
+#else
+#define POLL(p, need, kind) poll_ge(p, need, PTAG(kind))
+#endif
 
 __device__ __forceinline__ double dpp_shr1(double v, double lane0) {
     // lane n takes lane n-1's v; lane 0 keeps `lane0` (wave_shr:1 leaves the destination of a lane
@@ -496,6 +501,8 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_cls_t[5] = {0, 0, 0, 0, 0};
     int st_cls_n[5] = {0, 0, 0, 0, 0};
     long long st_w[4] = {0, 0, 0, 0};
+    long long st_poll_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int st_poll_n[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int st_n = 0;
     bool st_on = false;
 #endif
@@ -592,10 +599,10 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
             // ---- flow control: flags are read only when the cached values stop covering this step ----
             if (d > ok_until) {
                 int need = hi + 3 < Lx - 1 ? hi + 3 : Lx - 1;
-                if (rows_ld <= need) rows_ld = poll_ge(&PM.loaded[0], need + 1, PTAG(1));
+                if (rows_ld <= need) rows_ld = POLL(&PM.loaded[0], need + 1, 1);
                 int margin = rows_ld >= Lx ? nd : rows_ld - 1 - need;
                 need = d + 2 - lo < Ly - 1 ? d + 2 - lo : Ly - 1;
-                if (cols_ld <= need) cols_ld = poll_ge(&PM.loaded[1], need + 1, PTAG(2));
+                if (cols_ld <= need) cols_ld = POLL(&PM.loaded[1], need + 1, 2);
                 const int mc = cols_ld >= Ly ? nd : cols_ld - 1 - need;
                 margin = mc < margin ? mc : margin;
                 ok_until = d + margin;
@@ -603,18 +610,18 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
             // downstream neighbour: this step overwrites the ring row of diagonal d - PRK; the host worked out the
             // last diagonal whose cells still read that one (cur.s7; 2 diagonals back in simple stretches, up to
             // PAGE-1 where long edges are about)
-            if (cur.s7 > p_dn) p_dn = poll_ge(&PM.progress[dn], cur.s7, PTAG(3));
+            if (cur.s7 > p_dn) p_dn = POLL(&PM.progress[dn], cur.s7, 3);
             // upstream neighbour: only a wave with a row about to use (row-1, .) has to wait for it
-            if (d - 1 > p_up && __any(row <= hi + 1)) p_up = poll_ge(&PM.progress[up], d - 1, PTAG(4));
+            if (d - 1 > p_up && __any(row <= hi + 1)) p_up = POLL(&PM.progress[up], d - 1, 4);
             if (!HOT && cls >= 2) {
-                if (diags_ld < d) diags_ld = poll_ge(&PM.loaded[2], d, PTAG(5));      // descriptor window covers every earlier diagonal
+                if (diags_ld < d) diags_ld = POLL(&PM.loaded[2], d, 5);      // descriptor window covers every earlier diagonal
                 if (cls == 2) {
                     // far reads: the cells are at least PAGE diagonals old; they have landed once every wave
                     // completed d - PLAND (each wave keeps all but its last 24 stores retired)
                     int slowest = flag_peek(&PM.progress[0]);
                     for (int w = 1; w < PNW; ++w) { const int p = flag_peek(&PM.progress[w]); slowest = p < slowest ? p : slowest; }
                     if (__builtin_amdgcn_readfirstlane(slowest) < d - PLAND)
-                        for (int w = 0; w < PNW; ++w) poll_ge(&PM.progress[w], d - PLAND, PTAG(6));
+                        for (int w = 0; w < PNW; ++w) POLL(&PM.progress[w], d - PLAND, 6);
                 } else {
                     // rendezvous: every awake wave has completed d-1 and its stores have landed
 #ifdef PG_PIPE_STATS
@@ -625,7 +632,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                     const long long w1 = __builtin_readcyclecounter();
 #endif
                     flag_store(&PM.arrived[wave], d);
-                    for (int w = 0; w < PNW; ++w) poll_ge(&PM.arrived[w], d, PTAG(7));
+                    for (int w = 0; w < PNW; ++w) POLL(&PM.arrived[w], d, 7);
 #ifdef PG_PIPE_STATS
                     if (cls == 4) { st_w[0] += w1 - w0; st_w[1] += __builtin_readcyclecounter() - w1; }
 #endif
@@ -863,6 +870,8 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
         for (int c = 0; c < 5; ++c) { q[c] = st_cls_n[c]; q[5 + c] = (int)(st_cls_t[c] >> 8); }
         PG_GLOBAL int *u = (PG_GLOBAL int *)job->trace + 3 * (Lx + Ly) - 600 + 4 * wave;
         for (int c = 0; c < 4; ++c) u[c] = (int)(st_w[c] >> 8);
+        PG_GLOBAL int *v = (PG_GLOBAL int *)job->trace + 3 * (Lx + Ly) - 800 + 20 * wave;
+        for (int c = 0; c < 10; ++c) { v[c] = st_poll_n[c]; v[10 + c] = (int)(st_poll_t[c] >> 8); }
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -45,6 +45,13 @@ if os.environ.get("PG_STAMPS"):
     for w in range(4):
         t = b3[4 * w: 4 * w + 4].astype(np.int64) * 256
         print("wave %d wide steps, Mcycles: drain before %.0f, rendezvous %.0f, cells %.0f, drain after %.0f" % ((w,) + tuple(t / 1e6)))
+if os.environ.get("PG_STAMPS"):
+    b4 = raw[n_int - 800:]
+    kinds = {1: "loader rows", 2: "loader cols", 3: "downstream (ring row reuse)", 4: "upstream (row above)", 5: "descriptor window",
+             6: "far: all waves 8 steps behind", 7: "rendezvous"}
+    for w in range(4):
+        n = b4[20 * w: 20 * w + 10].astype(np.int64); t = b4[20 * w + 10: 20 * w + 20].astype(np.int64) * 256
+        print("wave %d waits (count, Mcycles): " % w + "; ".join("%s %d %.0fM" % (kinds[k], n[k], t[k] / 1e6) for k in sorted(kinds)))
 if os.environ.get("PG_CHECK"):
     import oracle
     bad = 0
