@@ -645,13 +645,15 @@ int64_t pagan_dp_count_cells(int32_t left_sites, int32_t right_sites, const paga
     return rb.cells();
 }
 
-// Device bytes for one alignment: 36 B per in-band cell (3 x (f64 score + u32 back-pointer))
-// plus the per-diagonal index and the trace buffer.  Graph/model inputs are negligible.
+// Device bytes for one alignment (an upper bound of what carve_job / carve_outputs lay out): 36 B per in-band
+// cell (3 x (f64 score + u32 back-pointer)) + < 1 B per cell of traceback tables (32 B per state of the two
+// boundary diagonals in every 256) + per diagonal 64 B of band index, descriptors and plan + per site 12 B of
+// trace buffer and ~20 B of graph arrays (one to two bwd edges per site), all 256-byte aligned.
 int64_t pagan_dp_predict_bytes(int32_t left_sites, int32_t right_sites, const pagan_band *band) {
     int64_t cells = pagan_dp_count_cells(left_sites, right_sites, band);
     if (cells < 0) return cells;
-    const int64_t nd = (int64_t)left_sites + right_sites - 3;
-    return cells * 36 + nd * 16 + (nd + 1) * 12 + 64 * 1024;
+    const int64_t nd = (int64_t)left_sites + right_sites - 3, sites = (int64_t)left_sites + right_sites;
+    return cells * 37 + nd * 64 + sites * 40 + 128 * 1024;
 }
 
 int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts, pagan_batch **out) {
