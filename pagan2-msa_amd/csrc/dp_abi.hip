@@ -228,23 +228,27 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
     // diagonal D: the last diagonal that still reads D - PG_PIPE_RING.
     std::vector<int> need(nd, PG_PIPE_REACH - 1);
     {
-        // classes 1 and 2: a cell reads the ring at ages dL, dR and dL + dR below the reach (older operands
-        // come from L2), so the largest ring-reaching spans among the diagonal's rows and columns bound it
-        std::vector<int> ql, qr;                       // candidate indices, spans decreasing
-        size_t hl = 0, hr = 0;
-        int nextl = 0, nextr = 0;
+        // classes 1 and 2: a cell reads the ring at the ages dL, dR and dL + dR below the reach (older operands
+        // come from L2), i.e. at most span_ring(i) + span_ring(j) back; only cells on a row or a column with a
+        // ring-reaching skip edge exceed 2, and a diagonal holds a handful of those: two sliding windows over the
+        // sorted lists of such rows and columns give the exact maximum per diagonal.
+        std::vector<int> rowsL, colsR;
+        for (int i = 0; i < Lx; ++i) if (fl.span_ring[i] >= 2) rowsL.push_back(i);
+        for (int j = 0; j < Ly; ++j) if (fr.span_ring[j] >= 2) colsR.push_back(j);
+        size_t la = 0, lb = 0, ra = 0, rb2 = 0;
         for (int d = 0; d < nd; ++d) {
             const int lo = dx.imin[d], hi = dx.imax[d];
-            if (hi < lo) continue;
-            for (; nextl <= hi; ++nextl) { while (ql.size() > hl && fl.span_ring[ql.back()] <= fl.span_ring[nextl]) ql.pop_back(); ql.push_back(nextl); }
-            while (hl < ql.size() && ql[hl] < lo) ++hl;
+            if (hi < lo || (*out)[d] > 2) continue;
+            if ((*out)[d] == 0) { need[d] = 2; continue; }
             const int jlo = d - hi, jhi = d - lo;
-            for (; nextr <= jhi; ++nextr) { while (qr.size() > hr && fr.span_ring[qr.back()] <= fr.span_ring[nextr]) qr.pop_back(); qr.push_back(nextr); }
-            while (hr < qr.size() && qr[hr] < jlo) ++hr;
-            if ((*out)[d] <= 2) {
-                const int m = (hl < ql.size() ? fl.span_ring[ql[hl]] : 1) + (hr < qr.size() ? fr.span_ring[qr[hr]] : 1);
-                need[d] = (*out)[d] == 0 ? 2 : std::min(std::max(m, 2), PG_PIPE_REACH - 1);
-            }
+            while (lb < rowsL.size() && rowsL[lb] <= hi) ++lb;
+            while (la < lb && rowsL[la] < lo) ++la;
+            while (rb2 < colsR.size() && colsR[rb2] <= jhi) ++rb2;
+            while (ra < rb2 && colsR[ra] < jlo) ++ra;
+            int m = 2;
+            for (size_t k = la; k < lb; ++k) m = std::max(m, fl.span_ring[rowsL[k]] + fr.span_ring[d - rowsL[k]]);
+            for (size_t k = ra; k < rb2; ++k) m = std::max(m, fl.span_ring[d - colsR[k]] + fr.span_ring[colsR[k]]);
+            need[d] = std::min(m, PG_PIPE_REACH - 1);
         }
     }
     lead_req->assign(nd, -1);
