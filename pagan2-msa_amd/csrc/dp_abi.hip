@@ -179,7 +179,8 @@ struct SiteFeat {
 //   3  touches the first/last two rows or columns, holds a site without bwd edges, or follows a wide
 //      diagonal within the ring's reach;
 //   2  holds a cell (i,j) whose farthest predecessor pair lies span(i) + span(j) >= PG_PIPE_REACH
-//      diagonals back;
+//      diagonals back, or a multi-edge site within PG_PIPE_REACH rows/columns of the matrix's first (an edge
+//      in reach may start at site 0, where the gap-open term differs);
 //   1  holds a site that is not simple;   0  otherwise.
 void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, const RowBand &rb,
                         const DiagIndex &dx, std::vector<uint8_t> *out, std::vector<int> *lead_req) {
@@ -217,6 +218,8 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
         else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c = 3;
         else if (fl.no_pred[hi + 1] - fl.no_pred[lo] > 0 || fr.no_pred[d - lo + 1] - fr.no_pred[d - hi] > 0) c = 3;
         else if (run > 0) c = 2;
+        else if ((lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH) &&
+                 (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)) c = 2;
         else if (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0) c = 1;
         else c = 0;
         (*out)[d] = c;

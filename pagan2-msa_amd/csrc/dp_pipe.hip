@@ -388,13 +388,14 @@ __device__ __forceinline__ void multi2_cell(gdouble_w sc, cdesc8_p psc, int d, u
     const unsigned aR0 = dR0 == 1 ? PG_BP_ADJR : 0u, aR1 = dR1 == 1 ? PG_BP_ADJR : 0u;
     bx = NI; by = NI; bm = NI; px = PG_BP_NONE; py = PG_BP_NONE; pm = PG_BP_NONE;
     {   // X: gap in the right sequence, candidates per left edge (VA:898-915)
-        const double o0 = (reduced_terminal && row == dL0) ? 0.0 : go, o1 = (reduced_terminal && row == dL1) ? 0.0 : go;
+        // (a class 1 diagonal lies PAGE rows and columns inside the matrix: no edge in reach starts at site 0)
+        const double o0 = (FAR && reduced_terminal && row == dL0) ? 0.0 : go, o1 = (FAR && reduced_terminal && row == dL1) ? 0.0 : go;
         cand(xa_x + ge, aL0 | PG_X, bx, px); cand((xa_y + 0.0) + go, aL0 | PG_Y, bx, px); cand((xa_m + ng) + o0, aL0 | PG_M, bx, px);
         const unsigned w1 = aL1 | (1u << 4);
         cand(xb_x + ge, w1 | PG_X, bx, px); cand((xb_y + 0.0) + go, w1 | PG_Y, bx, px); cand((xb_m + ng) + o1, w1 | PG_M, bx, px);
     }
     {   // Y: gap in the left sequence, candidates per right edge (VA:927-944)
-        const double o0 = (reduced_terminal && j == dR0) ? 0.0 : go, o1 = (reduced_terminal && j == dR1) ? 0.0 : go;
+        const double o0 = (FAR && reduced_terminal && j == dR0) ? 0.0 : go, o1 = (FAR && reduced_terminal && j == dR1) ? 0.0 : go;
         cand(ya_y + ge, aR0 | PG_Y, by, py); cand((ya_x + 0.0) + go, aR0 | PG_X, by, py); cand((ya_m + ng) + o0, aR0 | PG_M, by, py);
         const unsigned w1 = aR1 | (1u << 18);
         cand(yb_y + ge, w1 | PG_Y, by, py); cand((yb_x + 0.0) + go, w1 | PG_X, by, py); cand((yb_m + ng) + o1, w1 | PG_M, by, py);

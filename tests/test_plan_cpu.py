@@ -51,6 +51,8 @@ def brute_plan(left, right, band):
             c = 3
         elif any(sl[i] + sr[d - i] >= REACH for i in rows):
             c = 2
+        elif (imin < REACH or d - imax < REACH) and (any(not simL[i] for i in rows) or any(not simR[j] for j in cols)):
+            c = 2
         elif any(not simL[i] for i in rows) or any(not simR[j] for j in cols):
             c = 1
         else:
