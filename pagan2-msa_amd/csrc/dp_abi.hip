@@ -231,26 +231,27 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
     // diagonal D: the last diagonal that still reads D - PG_PIPE_RING.
     std::vector<int> need(nd, PG_PIPE_REACH - 1);
     {
-        // classes 1 and 2: a cell reads the ring at the ages dL, dR and dL + dR below the reach (older operands
-        // come from L2), i.e. at most span_ring(i) + span_ring(j) back; only cells on a row or a column with a
-        // ring-reaching skip edge exceed 2, and a diagonal holds a handful of those: two sliding windows over the
-        // sorted lists of such rows and columns give the exact maximum per diagonal.
-        std::vector<int> rowsL, colsR;
+        // What matters for the reuse of a ring row is how far back the cells of a diagonal read IN ANOTHER
+        // WAVE'S ROWS (a wave's reads of its own rows are ordered with its own writes).  A cell (i,j) reads rows
+        // down to i - dL, so it crosses into the block of 64 rows above only if span_ring(i) > i % 64 -- lane 0
+        // always does (row i-1: its shift operand at age 1 and the M operands at ages 1 + dR).  Such a cell
+        // reaches at most span_ring(i) + span_ring(j) diagonals back in the ring (classes 1 and 2; older operands
+        // come from L2).  Candidates per diagonal: the rows with a ring-reaching skip edge (sliding window over
+        // their sorted list) and the at most four rows with i % 64 == 0.
+        std::vector<int> rowsL;
         for (int i = 0; i < Lx; ++i) if (fl.span_ring[i] >= 2) rowsL.push_back(i);
-        for (int j = 0; j < Ly; ++j) if (fr.span_ring[j] >= 2) colsR.push_back(j);
-        size_t la = 0, lb = 0, ra = 0, rb2 = 0;
+        size_t la = 0, lb = 0;
         for (int d = 0; d < nd; ++d) {
             const int lo = dx.imin[d], hi = dx.imax[d];
             if (hi < lo || (*out)[d] > 2) continue;
-            if ((*out)[d] == 0) { need[d] = 2; continue; }
-            const int jlo = d - hi, jhi = d - lo;
             while (lb < rowsL.size() && rowsL[lb] <= hi) ++lb;
             while (la < lb && rowsL[la] < lo) ++la;
-            while (rb2 < colsR.size() && colsR[rb2] <= jhi) ++rb2;
-            while (ra < rb2 && colsR[ra] < jlo) ++ra;
             int m = 2;
-            for (size_t k = la; k < lb; ++k) m = std::max(m, fl.span_ring[rowsL[k]] + fr.span_ring[d - rowsL[k]]);
-            for (size_t k = ra; k < rb2; ++k) m = std::max(m, fl.span_ring[d - colsR[k]] + fr.span_ring[colsR[k]]);
+            for (size_t k = la; k < lb; ++k) {
+                const int i = rowsL[k];
+                if (fl.span_ring[i] > (i & 63)) m = std::max(m, fl.span_ring[i] + fr.span_ring[d - i]);
+            }
+            for (int i = (lo + 63) & ~63; i <= hi; i += 64) m = std::max(m, fl.span_ring[i] + fr.span_ring[d - i]);
             need[d] = std::min(m, PG_PIPE_REACH - 1);
         }
     }

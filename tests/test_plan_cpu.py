@@ -58,14 +58,14 @@ def brute_plan(left, right, band):
         else:
             c = 0
         cls[d] = c
-        if c == 0:
-            need[d] = 2
-        elif c in (1, 2):
+        # how far back the cells of d read in the rows of the wave above (what bounds the reuse of a ring row)
+        if c <= 2:
             ages = [2]
             for i in rows:
                 for dl in distL[i]:
-                    for dr in distR[d - i]:
-                        ages += [a for a in (dl, dr, dl + dr) if a < REACH]
+                    if dl > i % 64 and dl < REACH:        # this edge leaves the lane's block of 64 rows
+                        ages.append(dl)
+                        ages += [dl + dr for dr in distR[d - i] if dl + dr < REACH]
             need[d] = max(ages)
         else:
             need[d] = REACH - 1
