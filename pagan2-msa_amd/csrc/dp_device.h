@@ -37,10 +37,12 @@
 
 // Geometry of the banded fill kernel (dp_pipe.hip) that the host-side planner (dp_abi.hip:
 // classify_diagonals, schedule_waves) has to agree with.
-#define PG_PIPE_WIDTH 237        // widest diagonal computed in the lanes' registers (256 lanes - PG_PIPE_REACH)
-#define PG_PIPE_REACH 19         // a cell may read PG_PIPE_REACH-1 diagonals back in the LDS ring.  Measured on the
-                                 // root of cfg4: 12 -> 408 ms, 16 -> 355, 18 -> 348, 19 -> 344, 20 -> 358: a longer reach
-                                 // turns far steps into ring steps, a shorter one gives the wave pipeline more slack
+#define PG_PIPE_WIDTH 236        // widest diagonal computed in the lanes' registers (256 lanes - PG_PIPE_REACH)
+#define PG_PIPE_REACH 20         // a cell may read PG_PIPE_REACH-1 diagonals back in the LDS ring: the whole ring but the
+                                 // row being written.  A longer reach turns far steps into ring steps; what it costs in
+                                 // pipeline slack is paid only where a cell near a wave boundary really reaches that far
+                                 // (per-diagonal lead requirement from the planner).  Root of cfg4: 16 -> 19 -> 20 =
+                                 // 355 -> 344 -> 358 ms with a fixed lead, 336 -> 322 -> 317 ms with the planned one.
 #define PG_PIPE_RING 20          // ring depth in diagonals: a wave stays awake this long after its last cell
 #define PG_PIPE_WAKE 6           // ... and wakes this many diagonals before its first one (operand prefetch pipeline)
 #define PG_PIPE_WINDOW 352       // widest diagonal the kernel's site-record windows (512 sites) still cover

@@ -54,7 +54,7 @@
 #define PDR_REACH 60             // oldest diagonal looked up in it
 #define PLOOK 64                 // diagonals the loader looks ahead of the slowest wave
 #define PLAND 8                  // stores of diagonal d have landed once the storing wave completed d+PLAND
-static_assert(PNTW == PNT - PAGE && PRK > PAGE && PG_PIPE_WINDOW + 160 <= PRW, "kernel geometry out of step with dp_device.h");
+static_assert(PNTW == PNT - PAGE && PRK >= PAGE && PG_PIPE_WINDOW + 160 <= PRW, "kernel geometry out of step with dp_device.h");
 #define PSPIN_LIMIT (1 << 25)     // ~10 s of polling: far beyond any legitimate wait (a wave sleeping through a long gap)
 
 // site record, word x
