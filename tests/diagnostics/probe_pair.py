@@ -3,7 +3,7 @@ the library (tools/build_stamps.sh) the per-path step counts and cycle shares of
 import ctypes as C
 import os
 import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import pagan2_msa_amd as pg
 from pagan2_msa_amd import synth, host, abi

@@ -2,7 +2,7 @@
 buffers and compare every run with the oracle (hunts nondeterminism in the kernels)."""
 import os
 import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import pagan2_msa_amd as pg
 from pagan2_msa_amd import synth, host

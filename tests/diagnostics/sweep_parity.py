@@ -2,7 +2,7 @@
 (random graphs with long edges, random bands with boxes of varying size, option bits) against the oracle."""
 import os
 import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import pagan2_msa_amd as pg
 from pagan2_msa_amd import abi, synth
