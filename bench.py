@@ -28,6 +28,8 @@ WORKLOADS = {
     "cfg4_32x100kb_dna_anchored": (32, 100000, 0.01, 0.008, 0.0008, 4.0, 1),
     "cfg2_16x2kb_dna_full": (16, 2000, 0.05, 0.04, 0.004, 4.0, 0),
     "smoke_8x3kb_dna_anchored": (8, 3000, 0.01, 0.008, 0.0008, 4.0, 1),
+    # BASELINE.json configs[4] on one GPU: 511 node alignments, up to 256 of them side by side
+    "cfg5_512x10kb_dna_anchored": (512, 10000, 0.01, 0.008, 0.0008, 4.0, 1),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_CELL = 36            # 3 states x (f64 score + u32 back-pointer), SURVEY.md s.8(d)
@@ -160,9 +162,10 @@ def main():
 
 def fill_kernel(anchors):
     """Name of the kernel the timed fill launches: the banded workloads run the register-wavefront kernel
-    (or the older LDS ring kernel behind PAGAN_DP_FILL=ring), full matrices the HBM wavefront."""
+    (or the older LDS ring kernel behind PAGAN_DP_FILL=ring), full matrices the tiled kernel (one launch per
+    tile anti-diagonal; or the one-workgroup HBM wavefront behind PAGAN_DP_WIDE=wavefront)."""
     if not anchors:
-        return "pg_fill_wavefront"
+        return "pg_fill_wavefront" if os.environ.get("PAGAN_DP_WIDE") == "wavefront" else "pg_fill_tiles"
     return "pg_fill_ring" if os.environ.get("PAGAN_DP_FILL") == "ring" else "pg_fill_pipe"
 
 

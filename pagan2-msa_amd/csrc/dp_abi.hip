@@ -27,6 +27,7 @@
 template <int BLOCK> __global__ void pg_fill_wavefront(const PgDevJob *jobs, const int *which, unsigned flags);
 template <bool TAB_LDS> __global__ void pg_fill_ring(const PgDevJob *jobs, const int *which, unsigned flags);
 template <bool TAB_LDS> __global__ void pg_fill_pipe(const PgDevJob *jobs, const int *which, unsigned flags);
+__global__ void pg_fill_tiles(const PgDevJob *jobs, const int *tiles, unsigned flags);
 __global__ void pg_end_corner(const PgDevJob *jobs);
 __global__ void pg_trace_spec(const PgDevJob *jobs);
 __global__ void pg_trace_compose(const PgDevJob *jobs);
@@ -39,6 +40,7 @@ __global__ void pg_trace_emit(const PgDevJob *jobs);
 unsigned pg_ring_lds_bytes();
 // limits of the register-wavefront kernel: PG_PIPE_* in dp_device.h, shared with dp_pipe.hip
 unsigned pg_pipe_lds_bytes();
+unsigned pg_tiles_lds_bytes();
 
 namespace {
 
@@ -126,6 +128,7 @@ struct HostJob {
     std::vector<uint8_t> cls;    // per diagonal: how dp_pipe.hip computes it (empty: not a pipe job)
     std::vector<int> sched;      // dp_pipe.hip: awake intervals of the four compute waves (dp_device.h)
     std::vector<int> lead_req;   // dp_pipe.hip: per diagonal, what the downstream wave must have completed first
+    std::vector<int> tiles;      // dp_tiles.hip (jobs that are not ring_ok): tile row, tile column of every tile that may hold a cell
     int n_bound = 0;             // traceback boundaries (dp_device.h)
     std::vector<int> tb;         // [n_bound + 2] table offsets
 };
@@ -299,6 +302,19 @@ void schedule_waves(const DiagIndex &dx, const std::vector<uint8_t> &cls, std::v
     }
 }
 
+// Tiles of dp_tiles.hip: PG_TILE x PG_TILE squares of the matrix that the band touches.  The band is monotone,
+// so the columns of a block of rows run from the first row's lower bound to the last row's upper bound.
+void list_tiles(int Lx, const RowBand &rb, std::vector<int> *out) {
+    out->clear();
+    for (int a = 0; a * PG_TILE < Lx; ++a) {
+        const int i1 = std::min(Lx, (a + 1) * PG_TILE);
+        int cmin = 1 << 30, cmax = -1;
+        for (int i = a * PG_TILE; i < i1; ++i)
+            if (rb.hi[i] >= rb.lo[i]) { cmin = std::min(cmin, rb.lo[i]); cmax = std::max(cmax, rb.hi[i]); }
+        for (int b = cmin / PG_TILE; cmax >= 0 && b <= cmax / PG_TILE; ++b) { out->push_back(a); out->push_back(b); }
+    }
+}
+
 // Independent per-job host work (validation, diagonal index, plan, staging) over a few threads: a batch
 // is a guide-tree level, up to hundreds of 1e5-site jobs.
 template <class F> void parallel_jobs(int n, F f) {
@@ -328,8 +344,12 @@ struct pagan_batch {
     std::vector<PgDevJob> dj;
     Arena arena;
     PgDevJob *d_jobs = nullptr;
-    int *d_which = nullptr;      // [n]: ring-kernel jobs first, then the wide ones
+    int *d_which = nullptr;      // [n]: ring-kernel jobs first, then the ones of the HBM wavefront kernel
     int n_ring = 0, n_wide = 0;
+    int *d_tiles = nullptr;      // dp_tiles.hip: {job, tile row, tile column, 0} of all tiled jobs, ordered by row + column
+    std::vector<int> tile_off;   // first tile of launch t (tile_off.back() = total)
+    hipStream_t stream2 = nullptr;   // the tile launches, when the batch also has jobs of the other kernels
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_ring_small = 0;        // ring jobs whose model table fits the LDS cache (listed first)
     bool use_pipe = true;        // LDS-staged jobs run pg_fill_pipe (default) or the older pg_fill_ring
     int max_bound = 0;           // largest traceback boundary count of any job
@@ -392,6 +412,7 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
     // reference's compare keeps the incumbent's sign: a job with a negative zero among its parameters
     // runs on the HBM wavefront kernel, which compares.
     if (has_negative_zero(jb)) narrow = false;
+    if (const char *f = std::getenv("PAGAN_DP_FILL")) if (std::strcmp(f, "tiles") == 0) narrow = false;   // A/B switch
     if (use_pipe) {
         hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES) &&
                       edges_fit_ring(jb.right, hj->Ly, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES);
@@ -401,6 +422,15 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
         }
     } else {
         hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx) && edges_fit_ring(jb.right, hj->Ly);
+    }
+    if (!hj->ring_ok) {
+        // dp_tiles.hip stages the bwd edges of a tile's 64 rows and 64 columns in LDS windows of PG_TILE_EDGES entries
+        auto fits = [](const pagan_graph *g, int n) {
+            for (int a = 0; a < n; a += PG_TILE)
+                if (g->bwd_off[std::min(n, a + PG_TILE)] - g->bwd_off[a] > PG_TILE_EDGES) return false;
+            return true;
+        };
+        if (fits(jb.left, hj->Lx) && fits(jb.right, hj->Ly)) list_tiles(hj->Lx, *rb, &hj->tiles);
     }
     return PAGAN_OK;
 }
@@ -452,6 +482,28 @@ template <class T> void put(std::vector<char> &stage, const void *devptr_as_off,
 }
 
 int launch_fill(pagan_batch *b) {
+    if (b->tile_off.size() > 1) {
+        static std::atomic<bool> tiles_set_dev[64];
+        std::atomic<bool> &tiles_set = tiles_set_dev[b->device & 63];
+        if (!tiles_set.load()) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_tiles),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_tiles_lds_bytes()));
+            tiles_set.store(true);
+        }
+        // one launch per tile anti-diagonal, all tiled jobs of the batch together; beside the other kernels
+        hipStream_t st = b->stream;
+        if (b->stream2) {
+            HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
+            HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
+            st = b->stream2;
+        }
+        for (size_t t = 0; t + 1 < b->tile_off.size(); ++t) {
+            const int cnt = b->tile_off[t + 1] - b->tile_off[t];
+            if (cnt > 0)
+                hipLaunchKernelGGL(pg_fill_tiles, dim3(cnt), dim3(64), pg_tiles_lds_bytes(), st, b->d_jobs,
+                                   b->d_tiles + 4 * (size_t)b->tile_off[t], b->flags);
+        }
+    }
     if (b->n_ring > 0) {
         // > 64 KB of dynamic LDS has to be opted into once per device (a process may drive several)
         static std::atomic<bool> lds_set_dev[64];
@@ -493,6 +545,10 @@ int launch_fill(pagan_batch *b) {
         case 256: hipLaunchKernelGGL(pg_fill_wavefront<256>, grid, dim3(256), 0, b->stream, b->d_jobs, which, b->flags); break;
         default: hipLaunchKernelGGL(pg_fill_wavefront<1024>, grid, dim3(1024), 0, b->stream, b->d_jobs, which, b->flags); break;
         }
+    }
+    if (b->tile_off.size() > 1 && b->stream2) {
+        HIP_TRY(hipEventRecord(b->ev_join, b->stream2));
+        HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
     }
     HIP_TRY(hipGetLastError());
     return PAGAN_OK;
@@ -683,7 +739,10 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     // A/B switch: PAGAN_DP_FILL=ring runs the barrier-per-diagonal LDS kernel instead of the register wavefront
     if (const char *f = std::getenv("PAGAN_DP_FILL")) b->use_pipe = std::strcmp(f, "ring") != 0;
     if (const char *f = std::getenv("PAGAN_DP_DEBUG_FLAGS")) b->flags |= (uint32_t)std::strtoul(f, nullptr, 0) & 0xff00u;
-    std::vector<int> which_ring, which_ring_big, which_wide;
+    // A/B switch: PAGAN_DP_WIDE=wavefront sends the wide jobs to the one-workgroup HBM wavefront instead of the tiles
+    const char *wide_env = std::getenv("PAGAN_DP_WIDE");
+    const bool use_tiles = !force_v1 && !(wide_env && std::strcmp(wide_env, "wavefront") == 0);
+    std::vector<int> which_ring, which_ring_big, which_wide, which_tiled;
     std::vector<int> job_rc(n, PAGAN_OK);
     parallel_jobs(n, [&](int k) {
         RowBand rb;
@@ -698,19 +757,46 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             (jobs[k].model->n_states <= 16 ? which_ring : which_ring_big).push_back(k);
             continue;
         }
+        if (use_tiles && !b->jobs[k].ring_ok && !b->jobs[k].tiles.empty()) { which_tiled.push_back(k); continue; }
         which_wide.push_back(k);
         if (b->jobs[k].dx.max_width > max_w) max_w = b->jobs[k].dx.max_width;
+    }
+    // tile launches: launch t takes the tiles with row + column = t of every tiled job
+    std::vector<int> tile_list;
+    if (!which_tiled.empty()) {
+        int T = 0;
+        for (int k : which_tiled) {
+            const std::vector<int> &tl = b->jobs[k].tiles;
+            for (size_t q = 0; q < tl.size(); q += 2) T = std::max(T, tl[q] + tl[q + 1] + 1);
+        }
+        b->tile_off.assign(T + 1, 0);
+        for (int k : which_tiled) {
+            const std::vector<int> &tl = b->jobs[k].tiles;
+            for (size_t q = 0; q < tl.size(); q += 2) ++b->tile_off[tl[q] + tl[q + 1] + 1];
+        }
+        for (int t = 0; t < T; ++t) b->tile_off[t + 1] += b->tile_off[t];
+        tile_list.assign(4 * (size_t)b->tile_off[T] + 4, 0);
+        std::vector<int> cur(b->tile_off.begin(), b->tile_off.end() - 1);
+        for (int k : which_tiled) {
+            const std::vector<int> &tl = b->jobs[k].tiles;
+            for (size_t q = 0; q < tl.size(); q += 2) {
+                const size_t at = 4 * (size_t)cur[tl[q] + tl[q + 1]]++;
+                tile_list[at] = k; tile_list[at + 1] = tl[q]; tile_list[at + 2] = tl[q + 1];
+            }
+        }
     }
     b->n_ring_small = (int)which_ring.size();
     which_ring.insert(which_ring.end(), which_ring_big.begin(), which_ring_big.end());
     b->n_ring = (int)which_ring.size(); b->n_wide = (int)which_wide.size();
     which_ring.insert(which_ring.end(), which_wide.begin(), which_wide.end());
+    which_ring.resize(n, 0);      // tiled jobs are reached through the tile list
     b->block = max_w <= 64 ? 64 : (max_w <= 512 ? 256 : 1024);
 
     // pass 1: sizes.  Inputs first (one contiguous upload), outputs after.
     Carver sizer;
     PgDevJob *jobs_off = sizer.take<PgDevJob>(n);
     int *which_off = sizer.take<int>(n);
+    int *tiles_off = sizer.take<int>(tile_list.size());
     for (int k = 0; k < n; ++k) carve_job(sizer, jobs[k], b->jobs[k], &b->dj[k]);
     const size_t in_bytes = sizer.cur;
     b->out_begin = in_bytes;
@@ -778,8 +864,15 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     std::memcpy(stage.data() + reinterpret_cast<size_t>(which_off), which_ring.data(), sizeof(int) * n);
     b->d_jobs = reinterpret_cast<PgDevJob *>(base + reinterpret_cast<size_t>(jobs_off));
     b->d_which = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(which_off));
+    if (!tile_list.empty()) std::memcpy(stage.data() + reinterpret_cast<size_t>(tiles_off), tile_list.data(), sizeof(int) * tile_list.size());
+    b->d_tiles = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(tiles_off));
     HIP_TRY(hipStreamCreate(&b->stream));
     for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+    if (!which_tiled.empty() && b->n_ring + b->n_wide > 0) {
+        HIP_TRY(hipStreamCreate(&b->stream2));
+        HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+    }
     HIP_TRY(hipMemcpyAsync(base, stage.data(), in_bytes, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     guard.b = nullptr;
@@ -879,6 +972,9 @@ void pagan_batch_destroy(pagan_batch *b) {
     if (!b) return;
     if (b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
     for (auto &e : b->ev) if (e) hipEventDestroy(e);
+    if (b->stream2) { hipStreamSynchronize(b->stream2); hipStreamDestroy(b->stream2); }
+    if (b->ev_fork) hipEventDestroy(b->ev_fork);
+    if (b->ev_join) hipEventDestroy(b->ev_join);
     if (b->arena.dev) hipFree(b->arena.dev);
     delete b;
 }

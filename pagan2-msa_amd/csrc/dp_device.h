@@ -49,6 +49,9 @@
 #define PG_PIPE_EDGE_CAP 1024    // bwd edges of any PG_RING_SITE_SPAN consecutive sites must fit the LDS edge window
 #define PG_PIPE_SITE_EDGES 126   // bwd edges per site (7-bit count in the site record)
 
+#define PG_TILE 64               // dp_tiles.hip: side of the square tiles a wide matrix is cut into (one wave each)
+#define PG_TILE_EDGES 1024       // ... and how many bwd edges the sites of one tile row / tile column may have together
+
 struct PgDevJob {
     int Lx, Ly;              // matrix dimensions (sites minus the stop site)
     int nd;                  // number of anti-diagonals = Lx + Ly - 1

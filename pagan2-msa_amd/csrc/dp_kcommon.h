@@ -86,82 +86,105 @@ __device__ __forceinline__ long long hbm_index(const View &J, int d, const Diag 
     return (p >= mn && p <= mx) ? off + (p - mn) : -1;
 }
 
-// One DP cell with every operand in HBM/L2: the three states of (i,j), written at `at`.
-__device__ __forceinline__ void fill_cell_hbm(const View &J, int d, const Diag &d1, const Diag &d2, int i, int j,
-                                              long long at, bool no_terminal_edges, bool reduced_terminal) {
+// One DP cell, the three states of (i,j) and their back-pointers, in the reference's candidate order.
+// Where the operands live is the caller's business:
+//   fetch(p, q, xs, ys, ms)   scores of cell (p,q), -inf outside the band
+//   edge_l(k, p, lw)          k-th bwd edge of left site i: start site and log weight (as double)
+//   edge_r(k, q, rw)          the same for right site j
+// nl / nr = number of bwd edges of the two sites, sm = the model's log score of the two states
+// (used only when i > 0 && j > 0 and both sites have edges).
+template <class Fetch, class EdgeL, class EdgeR>
+__device__ __forceinline__ void cell_any(const View &J, int i, int j, int nl, int nr, float sm, bool no_terminal_edges,
+                                         bool reduced_terminal, Fetch fetch, EdgeL edge_l, EdgeR edge_r, double &bx,
+                                         double &by, double &bm, unsigned &px, unsigned &py, unsigned &pm) {
     const double NI = neg_inf();
-    double bx = NI, by = NI, bm = NI;
-    unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
+    bx = NI; by = NI; bm = NI;
+    px = PG_BP_NONE; py = PG_BP_NONE; pm = PG_BP_NONE;
     if (i == 0 && j == 0) {
         bm = 0.0;                                   // initialise_array_corner, VA:725-736
-    } else {
-        const double go = (double)J.go, ng = (double)J.ng;
-        int l0 = 0, l1 = 0, r0 = 0, r1 = 0;
-        if (i > 0) { l0 = J.offL[i]; l1 = J.offL[i + 1]; }
-        if (j > 0) { r0 = J.offR[j]; r1 = J.offR[j + 1]; }
-        // ---- X: gap in the right sequence, consumes left site i (VA:898-915) ----
-        if (i > 0) {
-            const bool end_gap = (j == 0 || j == J.Ly - 1) && !no_terminal_edges;   // VA:864-868
-            const double ext = (double)(end_gap ? J.gE : J.ge);
-            for (int e = l0; e < l1; ++e) {
-                const int p = J.srcL[e];
-                const long long ix = hbm_index(J, d, d1, d2, p, j);
-                double xs = NI, ys = NI, ms = NI;
-                if (ix >= 0) { xs = J.sc[3 * ix + PG_X]; ys = J.sc[3 * ix + PG_Y]; ms = J.sc[3 * ix + PG_M]; }
-                const double open = (reduced_terminal && p == 0) ? 0.0 : go;        // BA.h:490-513
-                double c = xs + ext;                                                 // score_gap_ext
-                if (c > bx) { bx = c; px = pack_bp(PG_X, e - l0, 0, p == i - 1, false); }
-                c = (ys + 0.0) + go;                                                 // score_gap_double
-                if (c > bx) { bx = c; px = pack_bp(PG_Y, e - l0, 0, p == i - 1, false); }
-                c = (ms + ng) + open;                                                // score_gap_open
-                if (c > bx) { bx = c; px = pack_bp(PG_M, e - l0, 0, p == i - 1, false); }
-            }
+        return;
+    }
+    const double go = (double)J.go, ng = (double)J.ng;
+    // ---- X: gap in the right sequence, consumes left site i (VA:898-915) ----
+    if (i > 0) {
+        const bool end_gap = (j == 0 || j == J.Ly - 1) && !no_terminal_edges;   // VA:864-868
+        const double ext = (double)(end_gap ? J.gE : J.ge);
+        for (int k = 0; k < nl; ++k) {
+            int p; double lw;
+            edge_l(k, p, lw);
+            double xs, ys, ms;
+            fetch(p, j, xs, ys, ms);
+            const double open = (reduced_terminal && p == 0) ? 0.0 : go;        // BA.h:490-513
+            double c = xs + ext;                                                 // score_gap_ext
+            if (c > bx) { bx = c; px = pack_bp(PG_X, k, 0, p == i - 1, false); }
+            c = (ys + 0.0) + go;                                                 // score_gap_double
+            if (c > bx) { bx = c; px = pack_bp(PG_Y, k, 0, p == i - 1, false); }
+            c = (ms + ng) + open;                                                // score_gap_open
+            if (c > bx) { bx = c; px = pack_bp(PG_M, k, 0, p == i - 1, false); }
         }
-        // ---- Y: gap in the left sequence, consumes right site j (VA:927-944) ----
-        if (j > 0) {
-            const bool end_gap = (i == 0 || i == J.Lx - 1) && !no_terminal_edges;   // VA:875-879
-            const double ext = (double)(end_gap ? J.gE : J.ge);
-            for (int e = r0; e < r1; ++e) {
-                const int q = J.srcR[e];
-                const long long ix = hbm_index(J, d, d1, d2, i, q);
-                double xs = NI, ys = NI, ms = NI;
-                if (ix >= 0) { xs = J.sc[3 * ix + PG_X]; ys = J.sc[3 * ix + PG_Y]; ms = J.sc[3 * ix + PG_M]; }
-                const double open = (reduced_terminal && q == 0) ? 0.0 : go;
-                double c = ys + ext;
-                if (c > by) { by = c; py = pack_bp(PG_Y, 0, e - r0, false, q == j - 1); }
-                c = (xs + 0.0) + go;
-                if (c > by) { by = c; py = pack_bp(PG_X, 0, e - r0, false, q == j - 1); }
-                c = (ms + ng) + open;
-                if (c > by) { by = c; py = pack_bp(PG_M, 0, e - r0, false, q == j - 1); }
-            }
+    }
+    // ---- Y: gap in the left sequence, consumes right site j (VA:927-944) ----
+    if (j > 0) {
+        const bool end_gap = (i == 0 || i == J.Lx - 1) && !no_terminal_edges;   // VA:875-879
+        const double ext = (double)(end_gap ? J.gE : J.ge);
+        for (int k = 0; k < nr; ++k) {
+            int q; double rw;
+            edge_r(k, q, rw);
+            double xs, ys, ms;
+            fetch(i, q, xs, ys, ms);
+            const double open = (reduced_terminal && q == 0) ? 0.0 : go;
+            double c = ys + ext;
+            if (c > by) { by = c; py = pack_bp(PG_Y, 0, k, false, q == j - 1); }
+            c = (xs + 0.0) + go;
+            if (c > by) { by = c; py = pack_bp(PG_X, 0, k, false, q == j - 1); }
+            c = (ms + ng) + open;
+            if (c > by) { by = c; py = pack_bp(PG_M, 0, k, false, q == j - 1); }
         }
-        // ---- M: both sites consumed (VA:956-963, 1353-1436) ----
-        if (i > 0 && j > 0 && l1 > l0 && r1 > r0) {
-            const float sm = J.table[J.stL[i] + J.stR[j] * J.S];                    // VA:1363
-            const double tM = (double)(2 * J.ng) + (double)sm;                      // VA:1364
-            const double tX = (double)(0.0f + J.ng) + (double)sm;                   // VA:1366-1367
-            for (int e1 = l0; e1 < l1; ++e1) {
-                const int p = J.srcL[e1];
-                const double lw = (double)J.lwL[e1];
-                for (int e2 = r0; e2 < r1; ++e2) {
-                    const int q = J.srcR[e2];
-                    const double rw = (double)J.lwR[e2];
-                    const long long ix = hbm_index(J, d, d1, d2, p, q);
-                    double xs = NI, ys = NI, ms = NI;
-                    if (ix >= 0) { xs = J.sc[3 * ix + PG_X]; ys = J.sc[3 * ix + PG_Y]; ms = J.sc[3 * ix + PG_M]; }
-                    double c = ((ms + tM) + lw) + rw;                                // score_m_match
-                    if (c > bm) { bm = c; pm = pack_bp(PG_M, e1 - l0, e2 - r0, p == i - 1, q == j - 1); }
-                    c = ((xs + tX) + lw) + rw;                                       // score_x_match
-                    if (c > bm) { bm = c; pm = pack_bp(PG_X, e1 - l0, e2 - r0, p == i - 1, q == j - 1); }
-                    c = ((ys + tX) + lw) + rw;                                       // score_y_match
-                    if (c > bm) { bm = c; pm = pack_bp(PG_Y, e1 - l0, e2 - r0, p == i - 1, q == j - 1); }
-                }
+    }
+    // ---- M: both sites consumed (VA:956-963, 1353-1436) ----
+    if (i > 0 && j > 0 && nl > 0 && nr > 0) {
+        const double tM = (double)(2 * J.ng) + (double)sm;                      // VA:1364
+        const double tX = (double)(0.0f + J.ng) + (double)sm;                   // VA:1366-1367
+        for (int k1 = 0; k1 < nl; ++k1) {
+            int p; double lw;
+            edge_l(k1, p, lw);
+            for (int k2 = 0; k2 < nr; ++k2) {
+                int q; double rw;
+                edge_r(k2, q, rw);
+                double xs, ys, ms;
+                fetch(p, q, xs, ys, ms);
+                double c = ((ms + tM) + lw) + rw;                                // score_m_match
+                if (c > bm) { bm = c; pm = pack_bp(PG_M, k1, k2, p == i - 1, q == j - 1); }
+                c = ((xs + tX) + lw) + rw;                                       // score_x_match
+                if (c > bm) { bm = c; pm = pack_bp(PG_X, k1, k2, p == i - 1, q == j - 1); }
+                c = ((ys + tX) + lw) + rw;                                       // score_y_match
+                if (c > bm) { bm = c; pm = pack_bp(PG_Y, k1, k2, p == i - 1, q == j - 1); }
             }
         }
     }
-    store_cell(J.sc, J.bp, at, bx, by, bm, px, py, pm);
 }
 
+// The same with every operand in HBM/L2 (graph arrays, model table, scores), written at `at`.
+__device__ __forceinline__ void fill_cell_hbm(const View &J, int d, const Diag &d1, const Diag &d2, int i, int j,
+                                              long long at, bool no_terminal_edges, bool reduced_terminal) {
+    int l0 = 0, l1 = 0, r0 = 0, r1 = 0;
+    if (i > 0) { l0 = J.offL[i]; l1 = J.offL[i + 1]; }
+    if (j > 0) { r0 = J.offR[j]; r1 = J.offR[j + 1]; }
+    float sm = 0.0f;
+    if (i > 0 && j > 0 && l1 > l0 && r1 > r0) sm = J.table[J.stL[i] + J.stR[j] * J.S];       // VA:1363
+    double bx, by, bm;
+    unsigned px, py, pm;
+    cell_any(J, i, j, l1 - l0, r1 - r0, sm, no_terminal_edges, reduced_terminal,
+             [&](int p, int q, double &xs, double &ys, double &ms) {
+                 const long long ix = hbm_index(J, d, d1, d2, p, q);
+                 xs = ys = ms = neg_inf();
+                 if (ix >= 0) { xs = J.sc[3 * ix + PG_X]; ys = J.sc[3 * ix + PG_Y]; ms = J.sc[3 * ix + PG_M]; }
+             },
+             [&](int k, int &p, double &lw) { p = J.srcL[l0 + k]; lw = (double)J.lwL[l0 + k]; },
+             [&](int k, int &q, double &rw) { q = J.srcR[r0 + k]; rw = (double)J.lwR[r0 + k]; },
+             bx, by, bm, px, py, pm);
+    store_cell(J.sc, J.bp, at, bx, by, bm, px, py, pm);
+}
 
 // Loads the COMPUTE waves need only on rare paths (an edge reaching past the ring).  Issued as
 // inline asm with their own wait so that the compiler's waitcnt insertion never places a

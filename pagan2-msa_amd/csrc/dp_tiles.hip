@@ -1,0 +1,405 @@
+// dp_tiles.hip -- gfx950 fill kernel for wide matrices (no band, or a band wider than dp_pipe.hip takes):
+// the matrix is cut into PG_TILE x PG_TILE tiles, one wave per tile, one launch per tile anti-diagonal.
+//
+// Why: an anti-diagonal of a full matrix is thousands of cells wide -- more than one compute unit can
+// take per step (2,000 cells x ~200 instructions is ~2.7 us of one CU's ALU time) -- while the matrix as a
+// whole has work for every CU of the chip.  Tile (a,b) needs tiles (a',b') with a' <= a, b' <= b only
+// (bwd edges point to earlier sites), so all tiles with the same a+b are independent: launch t runs
+// them concurrently, one wave each, for all wide alignments of the batch at once.  Kernel boundaries
+// order the launches, so there is no spinning between workgroups and nothing to get visibility wrong.
+//
+// Inside a tile the wave sweeps the tile's own anti-diagonals: lane r owns row i0 + r, step s handles
+// column j0 + s - r.  The scores of the WHOLE tile plus a halo of eight rows above and eight columns left
+// of it (loaded from HBM at the start) live in LDS, so every predecessor inside the tile or within eight
+// sites of it is an LDS read; a bwd edge that reaches further back reads HBM (written by an earlier launch).  Results go
+// to HBM in the batch's diagonal-major layout (dp_device.h) as they are produced; the wave never waits
+// for them.
+//
+// Code paths per step, chosen wave-uniformly:
+//   simple   every active cell's two sites have exactly one bwd edge, from the previous site: three LDS
+//            cells, nine candidates, straight-line;
+//   near     otherwise: cells whose sites have at most two bwd edges each, all starting inside the tile or
+//            its halo -- eight LDS cells, 24 candidates, straight-line (an absent edge reads a -inf cell);
+//   general  the remaining cells (a site with three or more bwd edges, an edge from before the halo):
+//            cell_any (dp_kcommon.h) with the edges in registers / LDS, operands from LDS or HBM.
+// Maxima are taken by compare-and-select in candidate order (first_is_bigger, basic_alignment.h:449-462),
+// so jobs with negative-zero parameters are exact here as well.
+//
+// LDS: (72 x 72 + 1) cells x 24 B = 124,440 B + column records 2 KB + descriptors 6 KB + edge windows 17 KB +
+// model table 1 KB = 151 KB -> one tile per CU.
+// The row pitch of 72 cells makes the lanes of a step (stride 71 cells = 213 x 8 B, odd) hit distinct banks.
+#include <hip/hip_runtime.h>
+#include "dp_device.h"
+
+#include "dp_kcommon.h"
+
+#define TS PG_TILE
+#define TH 8                       // halo depth: rows above / columns left of the tile kept in LDS
+#define TP (PG_TILE + TH)          // row pitch in cells; (TP - 1) * 3 is odd: the lanes of a step hit distinct 8-byte banks
+#define TNULL ((TS + TH) * TP)     // a cell that stays -inf: stands in for the operand of an absent edge
+#define TEC PG_TILE_EDGES           // bwd edges of the tile's 64 rows / of its 64 columns (the host keeps other jobs off this kernel)
+#define TDB 128                    // descriptors kept for this many diagonals before the tile's first
+#define THALO (TH * (TS + TH) + TH * TS)
+#define THC 9                      // halo cells a lane has in flight at a time
+
+namespace {
+
+struct TileSmem {
+    double sc[(TS + TH) * TP + 1][3];   // cell (p,q) at (q - j0 + TH) * TP + (p - i0 + TH); TNULL: a cell that stays -inf
+    pg_i4 col[TS];                      // column j0 + k: state, first bwd edge (CSR index), edge count | flags, unused
+    pg_i4 cole[TS];                     // its first two bwd edges: start site, log weight (float bits), start site, log weight
+    pg_i4 dsc[TDB + 2 * TS];            // descriptors of anti-diagonals i0 + j0 - TDB ...: imin, imax, doff low, doff high
+    int eL[TEC + 64][2], eR[TEC + 64][2];   // bwd edges of the tile's rows / columns: start site, log weight (float bits)
+    float table[256];                   // model table when S <= 16
+};
+
+// Loads inside the step loop are inline asm with their own wait (dp_kcommon.h: far_*): a load the compiler
+// can see makes its waitcnt insertion put a vmcnt(0) -- a wait for every store in flight -- at the loop header.
+__device__ __forceinline__ int far_i32(PG_GLOBAL const int *p) {
+    int v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// What a lane keeps about a site: x = state, y = CSR index of its first bwd edge, z = number of bwd
+// edges | SITE_SIMPLE (exactly one, from the previous site) | SITE_TWO (at most two) | SITE_FAR0/1 (edge
+// 0 / 1 starts before the tile's halo); e = first two edges (start site, float bits of the log weight).
+#define SITE_SIMPLE (1 << 30)
+#define SITE_TWO (1 << 29)
+#define SITE_FAR0 (1 << 28)           // the first / second bwd edge starts outside the LDS window (tile + halo)
+#define SITE_FAR1 (1 << 27)
+#define SITE_COUNT 0xffff             // PG_MAX_SLOT < 65536
+struct SiteRec { pg_i4 r, e; };
+
+__device__ __forceinline__ SiteRec site_rec(gint_p st, gint_p off, gint_p src, gfloat_p lw, int s, int n, int first) {
+    SiteRec o;
+    o.r = pg_i4{0, 0, 0, 0};
+    o.e = pg_i4{0, 0, 0, 0};
+    if (s >= 0 && s < n) {
+        const int a = off[s], b = off[s + 1];
+        o.r.x = st[s]; o.r.y = a; o.r.z = b - a;
+        if (b - a >= 1) { o.e.x = src[a]; o.e.y = __float_as_int(lw[a]); }
+        if (b - a >= 2) { o.e.z = src[a + 1]; o.e.w = __float_as_int(lw[a + 1]); }
+        if (b - a == 1 && o.e.x == s - 1) o.r.z |= SITE_SIMPLE;
+        if (b - a <= 2) o.r.z |= SITE_TWO;
+        if (b - a >= 1 && o.e.x < first - TH) o.r.z |= SITE_FAR0;
+        if (b - a >= 2 && o.e.z < first - TH) o.r.z |= SITE_FAR1;
+    }
+    return o;
+}
+
+// strict-greater update in candidate order
+#define PG_TAKE(best, bp, c, code) do { const double c__ = (c); if (c__ > best) { best = c__; bp = (code); } } while (0)
+
+} // namespace
+
+unsigned pg_tiles_lds_bytes() { return (unsigned)sizeof(TileSmem); }
+
+extern __shared__ __attribute__((aligned(16))) char pg_tiles_lds[];
+#define TM (*reinterpret_cast<TileSmem *>(pg_tiles_lds))
+#define TAT(p, q) (((q) - j0 + TH) * TP + ((p) - i0 + TH))
+
+// tiles[blockIdx.x] = {job, tile row a, tile column b, -}
+__global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__ jobs, const int *__restrict__ tiles,
+                                                    unsigned flags) {
+    const bool no_terminal_edges = flags & 1u;
+    const bool reduced_terminal = !(flags & 2u);
+    const pg_i4 T = ((cdesc_p)tiles)[blockIdx.x];
+    const View J = load_view(jobs + T.x);
+    const int i0 = T.y * TS, j0 = T.z * TS;
+    const int r = (int)threadIdx.x;
+    const int i = i0 + r;
+#ifdef PG_TILE_STATS
+    // diagnostic build (tools/build_stamps.sh): cycles and step counts summed over all tiles of the job at the
+    // tail of its trace buffer: [0] tiles, [1] prologue, [2..4] steps simple / near / near + general, [5..7] their cycles
+    unsigned long long st_n[3] = {0, 0, 0}, st_t[3] = {0, 0, 0};
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
+    const double NI = neg_inf();
+    const bool tab_lds = J.S <= 16;      // DNA: 15 states; a protein table (211 x 211) stays in HBM/L2
+
+    for (int k = r; k < (TS + TH) * TP + 1; k += 64) { TM.sc[k][0] = NI; TM.sc[k][1] = NI; TM.sc[k][2] = NI; }
+    if (tab_lds)
+        for (int k = r; k < J.S * J.S; k += 64) TM.table[k] = J.table[k];
+    for (int k = r; k < TDB + 2 * TS; k += 64) {
+        const int d = i0 + j0 - TDB + k;
+        TM.dsc[k] = d >= 0 && d < J.nd ? ((PG_GLOBAL const pg_i4 *)(unsigned long long)J.dsc)[d] : pg_i4{0, -1, 0, 0};
+    }
+    {
+        const SiteRec c = site_rec(J.stR, J.offR, J.srcR, J.lwR, j0 + r, J.Ly, j0);
+        TM.col[r] = c.r; TM.cole[r] = c.e;
+    }
+    const SiteRec row = site_rec(J.stL, J.offL, J.srcL, J.lwL, i, J.Lx, i0);
+    // halo: TH rows above the tile (with the corner), then TH columns left of it.  Two dependent rounds of
+    // loads (descriptor of the cell's diagonal, then its scores), each round in flight together: after a
+    // kernel boundary every first touch goes to memory.
+    {
+        PG_GLOBAL const pg_i4 *gdsc = (PG_GLOBAL const pg_i4 *)(unsigned long long)J.dsc;
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        for (int k0 = 0; k0 < THALO; k0 += 64 * THC) {
+        int hp[THC], hat[THC];
+        bool hv[THC];
+        pg_i4 hd[THC];
+#pragma unroll
+        for (int u = 0; u < THC; ++u) {
+            const int k = k0 + r + 64 * u;
+            int p, q;
+            if (k < TH * (TS + TH)) { p = i0 - TH + k / (TS + TH); q = j0 - TH + k % (TS + TH); }
+            else { const int k2 = k - TH * (TS + TH); q = j0 - TH + k2 / TS; p = i0 + k2 % TS; }
+            hv[u] = k < THALO && p >= 0 && q >= 0 && p < J.Lx && q < J.Ly;
+            hp[u] = p; hat[u] = hv[u] ? TAT(p, q) : TNULL;
+            hd[u] = gdsc[hv[u] ? p + q : 0];
+        }
+        d2 hxy[THC];
+        double hm[THC];
+#pragma unroll
+        for (int u = 0; u < THC; ++u) {
+            hv[u] = hv[u] && hp[u] >= hd[u].x && hp[u] <= hd[u].y;
+            const long long ix = hv[u] ? (((long long)hd[u].w << 32) | (unsigned)hd[u].z) + (hp[u] - hd[u].x) : 0;
+            hxy[u] = *(PG_GLOBAL const d2 *)(J.sc + 3 * ix);
+            hm[u] = J.sc[3 * ix + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < THC; ++u)
+            if (hv[u]) { TM.sc[hat[u]][0] = hxy[u].x; TM.sc[hat[u]][1] = hxy[u].y; TM.sc[hat[u]][2] = hm[u]; }
+        }
+    }
+    // bwd edge lists of the tile's rows and columns
+    const int eL0 = __builtin_amdgcn_readfirstlane(row.r.y), eR0 = __builtin_amdgcn_readfirstlane(TM.col[0].y);
+    {
+        const int nL = J.offL[i0 + TS < J.Lx ? i0 + TS : J.Lx] - eL0, nR = J.offR[j0 + TS < J.Ly ? j0 + TS : J.Ly] - eR0;
+        for (int k = r; k < nL && k < TEC; k += 64) { TM.eL[k][0] = J.srcL[eL0 + k]; TM.eL[k][1] = __float_as_int(J.lwL[eL0 + k]); }
+        for (int k = r; k < nR && k < TEC; k += 64) { TM.eR[k][0] = J.srcR[eR0 + k]; TM.eR[k][1] = __float_as_int(J.lwR[eR0 + k]); }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    const double go = (double)J.go, ng = (double)J.ng;
+    const int nl = row.r.z & SITE_COUNT;
+    const int p0 = row.e.x, p1 = row.e.z;
+    const double lw0 = (double)__int_as_float(row.e.y), lw1 = (double)__int_as_float(row.e.w);
+    const double extY = (double)(((i == 0 || i == J.Lx - 1) && !no_terminal_edges) ? J.gE : J.ge);   // VA:875-879
+    const double openX0 = (reduced_terminal && p0 == 0) ? 0.0 : go, openX1 = (reduced_terminal && p1 == 0) ? 0.0 : go;  // BA.h:490-513
+    const int dbase = i0 + j0;
+    const int s_last = (2 * TS - 2 < J.nd - 1 - dbase) ? 2 * TS - 2 : J.nd - 1 - dbase;
+    // operands of a step are fetched one step ahead: the diagonal's descriptor and the column's record
+    pg_i4 D = TM.dsc[TDB];
+    pg_i4 c = pg_i4{0, 0, 0, 0}, ce = pg_i4{0, 0, 0, 0};
+    if (r == 0) { c = TM.col[0]; ce = TM.cole[0]; }
+#ifdef PG_TILE_STATS
+    const unsigned long long st_loop = __builtin_amdgcn_s_memtime();
+#endif
+    for (int s = 0; s <= s_last; ++s) {
+#ifdef PG_TILE_STATS
+        const unsigned long long st_a = __builtin_amdgcn_s_memtime();
+        int st_kind = -1;
+#endif
+        const pg_i4 Dn = TM.dsc[TDB + s + 1];
+        const int jj = s - r;
+        pg_i4 cn = pg_i4{0, 0, 0, 0}, cen = pg_i4{0, 0, 0, 0};
+        if (jj + 1 >= 0 && jj + 1 < TS) { cn = TM.col[jj + 1]; cen = TM.cole[jj + 1]; }
+        const int mn = D.x, mx = D.y;
+        const bool active = jj >= 0 && jj < TS && i >= mn && i <= mx;
+        if (__builtin_amdgcn_ballot_w64(active) != 0) {
+            const long long off = ((long long)D.w << 32) | (unsigned)D.z;
+            const int j = j0 + jj;
+            const bool simple = (row.r.z & c.z & SITE_SIMPLE) != 0;
+            const bool two = (row.r.z & c.z & SITE_TWO) != 0;
+            const bool anyfar = ((row.r.z | c.z) & (SITE_FAR0 | SITE_FAR1)) != 0;
+            double bx = NI, by = NI, bm = NI;
+            unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
+#ifdef PG_TILE_STATS
+            st_kind = __builtin_amdgcn_ballot_w64(active && !simple) == 0 ? 0 : (__builtin_amdgcn_ballot_w64(active && !(two && !anyfar)) == 0 ? 1 : 2);
+#endif
+            if (__builtin_amdgcn_ballot_w64(active && !simple) == 0) {
+                if (active) {
+                    // (i-1,j), (i,j-1), (i-1,j-1)
+                    const int a_up = TAT(i - 1, j), a_left = TAT(i, j - 1), a_diag = TAT(i - 1, j - 1);
+                    const double ux = TM.sc[a_up][0], uy = TM.sc[a_up][1], um = TM.sc[a_up][2];
+                    const double lx = TM.sc[a_left][0], ly = TM.sc[a_left][1], lm = TM.sc[a_left][2];
+                    const double gx = TM.sc[a_diag][0], gy = TM.sc[a_diag][1], gm = TM.sc[a_diag][2];
+                    const float sm = tab_lds ? TM.table[row.r.x + c.x * J.S] : far_f32(J.table + (row.r.x + c.x * J.S));   // VA:1363
+                    const double rw = (double)__int_as_float(ce.y);
+                    {
+                        const bool end_gap = (j == J.Ly - 1) && !no_terminal_edges;          // VA:864-868 (j > 0 here)
+                        const double ext = (double)(end_gap ? J.gE : J.ge);
+                        PG_TAKE(bx, px, ux + ext, pack_bp(PG_X, 0, 0, true, false));
+                        PG_TAKE(bx, px, (uy + 0.0) + go, pack_bp(PG_Y, 0, 0, true, false));
+                        PG_TAKE(bx, px, (um + ng) + openX0, pack_bp(PG_M, 0, 0, true, false));
+                    }
+                    {
+                        const double open = (reduced_terminal && j == 1) ? 0.0 : go;
+                        PG_TAKE(by, py, ly + extY, pack_bp(PG_Y, 0, 0, false, true));
+                        PG_TAKE(by, py, (lx + 0.0) + go, pack_bp(PG_X, 0, 0, false, true));
+                        PG_TAKE(by, py, (lm + ng) + open, pack_bp(PG_M, 0, 0, false, true));
+                    }
+                    {
+                        const double tM = (double)(2 * J.ng) + (double)sm;                   // VA:1364
+                        const double tX = (double)(0.0f + J.ng) + (double)sm;                // VA:1366-1367
+                        PG_TAKE(bm, pm, ((gm + tM) + lw0) + rw, pack_bp(PG_M, 0, 0, true, true));
+                        PG_TAKE(bm, pm, ((gx + tX) + lw0) + rw, pack_bp(PG_X, 0, 0, true, true));
+                        PG_TAKE(bm, pm, ((gy + tX) + lw0) + rw, pack_bp(PG_Y, 0, 0, true, true));
+                    }
+                }
+            } else {
+                const int nr = c.z & SITE_COUNT;
+                const int q0 = ce.x, q1 = ce.z;
+                const bool l0 = nl >= 1, l1 = nl >= 2, r0 = nr >= 1, r1 = nr >= 2;
+                // one lane that needs the loops takes the whole step there: the loops cost what their longest trip
+                // costs, the straight-line block would come on top
+                const bool near = __builtin_amdgcn_ballot_w64(active && !(two && !anyfar)) == 0;
+                if (active && near) {
+                    // At most two bwd edges per site, all eight operand cells in LDS: straight-line, the cell of an
+                    // absent edge is the -inf cell (its candidates never win).  Order: SURVEY.md Appendix A.
+                    const double rw0 = (double)__int_as_float(ce.y), rw1 = (double)__int_as_float(ce.w);
+                    const int aX0 = l0 ? TAT(p0, j) : TNULL, aX1 = l1 ? TAT(p1, j) : TNULL;
+                    const int aY0 = r0 ? TAT(i, q0) : TNULL, aY1 = r1 ? TAT(i, q1) : TNULL;
+                    const int aM00 = (l0 && r0) ? TAT(p0, q0) : TNULL, aM01 = (l0 && r1) ? TAT(p0, q1) : TNULL;
+                    const int aM10 = (l1 && r0) ? TAT(p1, q0) : TNULL, aM11 = (l1 && r1) ? TAT(p1, q1) : TNULL;
+                    float sm = 0.0f;
+                    if (l0 && r0 && i > 0 && j > 0) sm = tab_lds ? TM.table[row.r.x + c.x * J.S] : far_f32(J.table + (row.r.x + c.x * J.S));
+                    {
+                        const double x0 = TM.sc[aX0][0], y0 = TM.sc[aX0][1], m0 = TM.sc[aX0][2];
+                        const double x1 = TM.sc[aX1][0], y1 = TM.sc[aX1][1], m1 = TM.sc[aX1][2];
+                        const bool end_gap = (j == 0 || j == J.Ly - 1) && !no_terminal_edges;    // VA:864-868
+                        const double ext = (double)(end_gap ? J.gE : J.ge);
+                        PG_TAKE(bx, px, x0 + ext, pack_bp(PG_X, 0, 0, p0 == i - 1, false));
+                        PG_TAKE(bx, px, (y0 + 0.0) + go, pack_bp(PG_Y, 0, 0, p0 == i - 1, false));
+                        PG_TAKE(bx, px, (m0 + ng) + openX0, pack_bp(PG_M, 0, 0, p0 == i - 1, false));
+                        PG_TAKE(bx, px, x1 + ext, pack_bp(PG_X, 1, 0, p1 == i - 1, false));
+                        PG_TAKE(bx, px, (y1 + 0.0) + go, pack_bp(PG_Y, 1, 0, p1 == i - 1, false));
+                        PG_TAKE(bx, px, (m1 + ng) + openX1, pack_bp(PG_M, 1, 0, p1 == i - 1, false));
+                    }
+                    {
+                        const double x0 = TM.sc[aY0][0], y0 = TM.sc[aY0][1], m0 = TM.sc[aY0][2];
+                        const double x1 = TM.sc[aY1][0], y1 = TM.sc[aY1][1], m1 = TM.sc[aY1][2];
+                        const double open0 = (reduced_terminal && q0 == 0) ? 0.0 : go, open1 = (reduced_terminal && q1 == 0) ? 0.0 : go;
+                        PG_TAKE(by, py, y0 + extY, pack_bp(PG_Y, 0, 0, false, q0 == j - 1));
+                        PG_TAKE(by, py, (x0 + 0.0) + go, pack_bp(PG_X, 0, 0, false, q0 == j - 1));
+                        PG_TAKE(by, py, (m0 + ng) + open0, pack_bp(PG_M, 0, 0, false, q0 == j - 1));
+                        PG_TAKE(by, py, y1 + extY, pack_bp(PG_Y, 0, 1, false, q1 == j - 1));
+                        PG_TAKE(by, py, (x1 + 0.0) + go, pack_bp(PG_X, 0, 1, false, q1 == j - 1));
+                        PG_TAKE(by, py, (m1 + ng) + open1, pack_bp(PG_M, 0, 1, false, q1 == j - 1));
+                    }
+                    {
+                        const double tM = (double)(2 * J.ng) + (double)sm;                   // VA:1364
+                        const double tX = (double)(0.0f + J.ng) + (double)sm;                // VA:1366-1367
+#define PG_PAIR(a, k1, k2, lw, rw, pp, qq)                                                                          \
+                        {                                                                                           \
+                            const double x_ = TM.sc[a][0], y_ = TM.sc[a][1], m_ = TM.sc[a][2];                      \
+                            PG_TAKE(bm, pm, ((m_ + tM) + lw) + rw, pack_bp(PG_M, k1, k2, pp == i - 1, qq == j - 1)); \
+                            PG_TAKE(bm, pm, ((x_ + tX) + lw) + rw, pack_bp(PG_X, k1, k2, pp == i - 1, qq == j - 1)); \
+                            PG_TAKE(bm, pm, ((y_ + tX) + lw) + rw, pack_bp(PG_Y, k1, k2, pp == i - 1, qq == j - 1)); \
+                        }
+                        PG_PAIR(aM00, 0, 0, lw0, rw0, p0, q0)
+                        PG_PAIR(aM01, 0, 1, lw0, rw1, p0, q1)
+                        PG_PAIR(aM10, 1, 0, lw1, rw0, p1, q0)
+                        PG_PAIR(aM11, 1, 1, lw1, rw1, p1, q1)
+#undef PG_PAIR
+                    }
+                    if (i == 0 && j == 0) bm = 0.0;                                          // initialise_array_corner, VA:725-736
+                }
+                if (!near) {
+                    if (active) {
+                        // Any number of bwd edges, anywhere: the reference's loops, edges from the
+                        // LDS windows (the next one requested while the current one is worked on), operand cells from
+                        // the LDS window or, before the halo, from HBM.
+                        auto fetch = [&](int p, int q, double &xs, double &ys, double &ms) {
+                            if (p >= i0 - TH && q >= j0 - TH) {
+                                const int at = TAT(p, q);
+                                xs = TM.sc[at][0]; ys = TM.sc[at][1]; ms = TM.sc[at][2];
+                            } else {
+                                const int w = p + q - (dbase - TDB);
+                                const pg_i4 F = w >= 0 ? TM.dsc[w] : far_desc(((PG_GLOBAL const pg_i4 *)(unsigned long long)J.dsc) + (p + q));
+                                xs = ys = ms = NI;
+                                if (p >= F.x && p <= F.y) {
+                                    const long long ix = (((long long)F.w << 32) | (unsigned)F.z) + (p - F.x);
+                                    far_cell(J.sc + 3 * ix, xs, ys, ms);
+                                }
+                            }
+                        };
+                        typedef int i2 __attribute__((ext_vector_type(2)));
+                        const int eLi = row.r.y - eL0, eRi = c.y - eR0;
+                        if (i == 0 && j == 0) bm = 0.0;                                      // initialise_array_corner, VA:725-736
+                        if (nl > 0) {                                                        // X (VA:898-915); nl > 0 implies i > 0
+                            const bool end_gap = (j == 0 || j == J.Ly - 1) && !no_terminal_edges;
+                            const double ext = (double)(end_gap ? J.gE : J.ge);
+                            i2 e = *(const i2 *)TM.eL[eLi];
+                            for (int k = 0; k < nl; ++k) {
+                                const int p = e.x;
+                                e = *(const i2 *)TM.eL[eLi + k + 1];
+                                double xs, ys, ms;
+                                fetch(p, j, xs, ys, ms);
+                                const double open = (reduced_terminal && p == 0) ? 0.0 : go;
+                                const unsigned base = ((unsigned)k << 4) | (p == i - 1 ? PG_BP_ADJL : 0u);
+                                PG_TAKE(bx, px, xs + ext, base | PG_X);
+                                PG_TAKE(bx, px, (ys + 0.0) + go, base | PG_Y);
+                                PG_TAKE(bx, px, (ms + ng) + open, base | PG_M);
+                            }
+                        }
+                        if (nr > 0) {                                                        // Y (VA:927-944)
+                            i2 e = *(const i2 *)TM.eR[eRi];
+                            for (int k = 0; k < nr; ++k) {
+                                const int q = e.x;
+                                e = *(const i2 *)TM.eR[eRi + k + 1];
+                                double xs, ys, ms;
+                                fetch(i, q, xs, ys, ms);
+                                const double open = (reduced_terminal && q == 0) ? 0.0 : go;
+                                const unsigned base = ((unsigned)k << 18) | (q == j - 1 ? PG_BP_ADJR : 0u);
+                                PG_TAKE(by, py, ys + extY, base | PG_Y);
+                                PG_TAKE(by, py, (xs + 0.0) + go, base | PG_X);
+                                PG_TAKE(by, py, (ms + ng) + open, base | PG_M);
+                            }
+                        }
+                        if (nl > 0 && nr > 0) {                                              // M (VA:956-963, 1353-1436)
+                            const float sm = tab_lds ? TM.table[row.r.x + c.x * J.S] : far_f32(J.table + (row.r.x + c.x * J.S));
+                            const double tM = (double)(2 * J.ng) + (double)sm;               // VA:1364
+                            const double tX = (double)(0.0f + J.ng) + (double)sm;            // VA:1366-1367
+                            i2 e1 = *(const i2 *)TM.eL[eLi];
+                            for (int k1 = 0; k1 < nl; ++k1) {
+                                const int p = e1.x;
+                                const double lw = (double)__int_as_float(e1.y);
+                                e1 = *(const i2 *)TM.eL[eLi + k1 + 1];
+                                const unsigned base1 = ((unsigned)k1 << 4) | (p == i - 1 ? PG_BP_ADJL : 0u);
+                                i2 e2 = *(const i2 *)TM.eR[eRi];
+                                for (int k2 = 0; k2 < nr; ++k2) {
+                                    const int q = e2.x;
+                                    const double rw = (double)__int_as_float(e2.y);
+                                    e2 = *(const i2 *)TM.eR[eRi + k2 + 1];
+                                    double xs, ys, ms;
+                                    fetch(p, q, xs, ys, ms);
+                                    const unsigned base = base1 | ((unsigned)k2 << 18) | (q == j - 1 ? PG_BP_ADJR : 0u);
+                                    PG_TAKE(bm, pm, ((ms + tM) + lw) + rw, base | PG_M);
+                                    PG_TAKE(bm, pm, ((xs + tX) + lw) + rw, base | PG_X);
+                                    PG_TAKE(bm, pm, ((ys + tX) + lw) + rw, base | PG_Y);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (active) {
+                const int at = TAT(i, j);
+                TM.sc[at][0] = bx; TM.sc[at][1] = by; TM.sc[at][2] = bm;
+                store_cell(J.sc, J.bp, off + (i - mn), bx, by, bm, px, py, pm);
+            }
+        }
+        D = Dn; c = cn; ce = cen;
+        asm volatile("" ::: "memory");
+#ifdef PG_TILE_STATS
+        if (st_kind >= 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - st_a;
+            if (st_kind == 0) { ++st_n[0]; st_t[0] += dt; } else if (st_kind == 1) { ++st_n[1]; st_t[1] += dt; } else { ++st_n[2]; st_t[2] += dt; }
+        }
+#endif
+    }
+#ifdef PG_TILE_STATS
+    if (r == 0) {
+        unsigned long long *out = (unsigned long long *)(jobs[T.x].trace + ((3 * (J.Lx + J.Ly) - 64) & ~1));
+        atomicAdd(out + 0, 1ull);
+        atomicAdd(out + 1, st_loop - st_begin);
+        for (int k = 0; k < 3; ++k) { atomicAdd(out + 2 + k, st_n[k]); atomicAdd(out + 5 + k, st_t[k]); }
+        atomicAdd(out + 8, __builtin_amdgcn_s_memtime() - st_begin);
+    }
+#endif
+}

@@ -3,5 +3,5 @@
 # pagan2-msa_amd/libpagan_dp.so in place; rebuild normally afterwards (python __graft_entry__.py).
 set -e
 cd "$(dirname "$0")/../pagan2-msa_amd/csrc"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -pthread -DPG_PIPE_STATS -Wno-unused-result \
-  -o ../libpagan_dp.so dp_abi.hip dp_kernels.hip dp_pipe.hip host_model.cpp host_graph.cpp host_anchors.cpp host_tree.cpp
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -pthread -DPG_PIPE_STATS -DPG_TILE_STATS -Wno-unused-result \
+  -o ../libpagan_dp.so dp_abi.hip dp_kernels.hip dp_pipe.hip dp_tiles.hip host_model.cpp host_graph.cpp host_anchors.cpp host_tree.cpp
