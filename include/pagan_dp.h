@@ -182,6 +182,11 @@ int  pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, cons
                          uint8_t *cls, int32_t n_cls, int32_t *sched, int32_t sched_cap, int32_t *sched_len,
                          int32_t *lead_req /* [n_cls] or NULL: diagonal the downstream wave must have completed
                                               before diagonal d may overwrite its row of the LDS ring, -1 none */);
+/* diagnostic, host only: the tiles the wide-matrix kernel (dp_tiles.hip) would be launched over for this
+ * job, as (tile row, tile column) pairs of side *tile_side; returns the number of tiles (pairs written:
+ * min(count, cap)), 0 when the job cannot be tiled (a tile's sites have too many bwd edges), < 0 on error */
+int  pagan_dp_debug_tiles(const pagan_graph *left, const pagan_graph *right, const pagan_band *band,
+                          int32_t *tiles /* [2 * cap] */, int32_t cap, int32_t *tile_side);
 /* diagnostic: job k's scores, [cells][3] doubles (X, Y, M), diagonal-major                */
 int  pagan_batch_debug_scores(pagan_batch *b, int32_t k, double *dst, int64_t count);
 /* diagnostic: overwrite all device outputs with 0xFF (NaN scores) before a run           */

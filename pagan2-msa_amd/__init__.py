@@ -85,6 +85,20 @@ def align(left, right, model, band=None, flags=0, device=-1):
         L.pagan_result_free(C.byref(res))
 
 
+def debug_tiles(left, right, band=None):
+    """Diagnostic (host only): (tile side, [(tile row, tile column), ...]) the wide-matrix fill kernel would be
+    launched over for this job; an empty list when the job cannot be tiled."""
+    import numpy as np
+    L = lib()
+    cap = ((left.n_sites + 62) // 64 + 1) * ((right.n_sites + 62) // 64 + 1)
+    out = np.zeros(2 * cap, np.int32)
+    side = C.c_int32()
+    n = L.pagan_dp_debug_tiles(C.byref(left.c), C.byref(right.c), C.byref(band.c) if band is not None else None,
+                               out.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(side))
+    _check(min(n, 0), "pagan_dp_debug_tiles")
+    return side.value, [tuple(int(v) for v in out[2 * k: 2 * k + 2]) for k in range(min(n, cap))]
+
+
 def debug_plan(left, right, band=None, with_lead=False):
     """Diagnostic (host only): (classes[Lx+Ly-1] uint8, [awake intervals of wave 0..3]) the banded fill kernel
     would be given for this job; with_lead adds the per-diagonal downstream-progress requirement."""

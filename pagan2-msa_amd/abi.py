@@ -177,6 +177,8 @@ def declare(lib):
     lib.pagan_batch_debug_trace.restype = C.c_int
     lib.pagan_dp_debug_plan.argtypes = [gp, gp, bp, C.POINTER(C.c_uint8), C.c_int32, _i32p, C.c_int32, _i32p, _i32p]
     lib.pagan_dp_debug_plan.restype = C.c_int
+    lib.pagan_dp_debug_tiles.argtypes = [gp, gp, bp, _i32p, C.c_int32, _i32p]
+    lib.pagan_dp_debug_tiles.restype = C.c_int
     lib.pagan_batch_debug_scores.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_int64]
     lib.pagan_batch_debug_scores.restype = C.c_int
     lib.pagan_batch_debug_poison.argtypes = [C.c_void_p]
@@ -189,5 +191,5 @@ def declare(lib):
 EXPORTED = ["pagan_dp_align", "pagan_dp_align_batch", "pagan_result_free", "pagan_dp_predict_bytes",
             "pagan_dp_count_cells", "pagan_dp_device_count", "pagan_dp_select_device", "pagan_batch_create",
             "pagan_batch_run", "pagan_batch_sync", "pagan_batch_fetch", "pagan_batch_last_ms",
-            "pagan_batch_cells", "pagan_batch_destroy", "pagan_batch_debug_trace", "pagan_dp_debug_plan", "pagan_batch_debug_scores", "pagan_batch_debug_poison",
+            "pagan_batch_cells", "pagan_batch_destroy", "pagan_batch_debug_trace", "pagan_dp_debug_plan", "pagan_dp_debug_tiles", "pagan_batch_debug_scores", "pagan_batch_debug_poison",
             "pagan_dp_version"]

@@ -315,6 +315,13 @@ void list_tiles(int Lx, const RowBand &rb, std::vector<int> *out) {
     }
 }
 
+// dp_tiles.hip stages the bwd edges of a tile's 64 rows and 64 columns in LDS windows of PG_TILE_EDGES entries
+bool edges_fit_tiles(const pagan_graph *g, int n) {
+    for (int a = 0; a < n; a += PG_TILE)
+        if (g->bwd_off[std::min(n, a + PG_TILE)] - g->bwd_off[a] > PG_TILE_EDGES) return false;
+    return true;
+}
+
 // Independent per-job host work (validation, diagonal index, plan, staging) over a few threads: a batch
 // is a guide-tree level, up to hundreds of 1e5-site jobs.
 template <class F> void parallel_jobs(int n, F f) {
@@ -423,15 +430,7 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
     } else {
         hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx) && edges_fit_ring(jb.right, hj->Ly);
     }
-    if (!hj->ring_ok) {
-        // dp_tiles.hip stages the bwd edges of a tile's 64 rows and 64 columns in LDS windows of PG_TILE_EDGES entries
-        auto fits = [](const pagan_graph *g, int n) {
-            for (int a = 0; a < n; a += PG_TILE)
-                if (g->bwd_off[std::min(n, a + PG_TILE)] - g->bwd_off[a] > PG_TILE_EDGES) return false;
-            return true;
-        };
-        if (fits(jb.left, hj->Lx) && fits(jb.right, hj->Ly)) list_tiles(hj->Lx, *rb, &hj->tiles);
-    }
+    if (!hj->ring_ok && edges_fit_tiles(jb.left, hj->Lx) && edges_fit_tiles(jb.right, hj->Ly)) list_tiles(hj->Lx, *rb, &hj->tiles);
     return PAGAN_OK;
 }
 
@@ -699,6 +698,24 @@ int pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, const
     if ((int)sched.size() > sched_cap) return PAGAN_E_ARG;
     std::memcpy(sched_out, sched.data(), sizeof(int) * sched.size());
     return PAGAN_OK;
+}
+
+int pagan_dp_debug_tiles(const pagan_graph *left, const pagan_graph *right, const pagan_band *band, int32_t *tiles,
+                         int32_t cap, int32_t *tile_side) {
+    if (!left || !right || !tiles || cap < 0) return PAGAN_E_ARG;
+    int rc;
+    if ((rc = check_graph(left)) != PAGAN_OK) return rc;
+    if ((rc = check_graph(right)) != PAGAN_OK) return rc;
+    const int Lx = left->n_sites - 1, Ly = right->n_sites - 1;
+    RowBand rb;
+    if ((rc = rb.build(Lx, Ly, band)) != PAGAN_OK) return rc;
+    if (tile_side) *tile_side = PG_TILE;
+    if (!edges_fit_tiles(left, Lx) || !edges_fit_tiles(right, Ly)) return 0;
+    std::vector<int> list;
+    list_tiles(Lx, rb, &list);
+    const int n = (int)(list.size() / 2);
+    std::memcpy(tiles, list.data(), sizeof(int) * 2 * (size_t)std::min(n, (int)cap));
+    return n;
 }
 
 int64_t pagan_dp_count_cells(int32_t left_sites, int32_t right_sites, const pagan_band *band) {

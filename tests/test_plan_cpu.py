@@ -137,3 +137,44 @@ def test_plan_banded_with_long_edges(seed):
     cls, _ = pg.debug_plan(left, right, abi.Band(upper, lower))
     assert set(np.unique(cls)) >= ({2, 3, 4} if seed < 2 else {1, 3, 4})
     assert (5 in cls) == (seed == 1)
+
+
+def test_tile_list_covers_exactly_the_tiles_the_band_touches():
+    """dp_tiles.hip is launched over the tiles listed by the host: every in-band cell must lie in a listed tile,
+    every listed tile's row block must reach its column block, and a tile row lists its columns contiguously."""
+    import pagan2_msa_amd as pg
+    rng = np.random.default_rng(5)
+    left = synth.random_graph(700, 15, 1, p_extra=0.05)
+    right = synth.random_graph(640, 15, 2, p_extra=0.05)
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    for case in range(4):
+        if case == 0:
+            band, lo, hi = None, np.zeros(Lx, np.int64), np.full(Lx, Ly - 1)
+        else:
+            centre = np.arange(Lx) * (Ly - 1) // (Lx - 1)
+            h = rng.integers(10, 60 * case, Lx)
+            lo = np.maximum.accumulate(np.maximum(centre - h, 0)); hi = np.maximum.accumulate(np.minimum(centre + h, Ly - 1))
+            lo[0] = 0; hi[-1] = Ly - 1
+            band = abi.Band(lo, hi)
+        side, tiles = pg.debug_tiles(left, right, band)
+        assert side == 64
+        want = set()
+        for i in range(Lx):
+            for b in range(lo[i] // side, hi[i] // side + 1):
+                want.add((i // side, int(b)))
+        assert want <= set(tiles)
+        rows = {}
+        for a, b in tiles:
+            rows.setdefault(a, []).append(b)
+        for a, bs in rows.items():
+            assert bs == list(range(bs[0], bs[-1] + 1))
+            assert bs[0] == lo[a * side: (a + 1) * side].min() // side and bs[-1] == hi[a * side: (a + 1) * side].max() // side
+        assert len(tiles) == len(set(tiles))
+
+
+def test_a_tile_with_too_many_edges_is_not_tiled():
+    import pagan2_msa_amd as pg
+    left = synth.random_graph(200, 15, 3, p_extra=1.0, max_deg=40, max_span=60)      # ~20 extra edges per site
+    right = synth.random_graph(200, 15, 4, p_extra=0.0)
+    side, tiles = pg.debug_tiles(left, right)
+    assert tiles == []

@@ -1,0 +1,114 @@
+"""GPU parity of the tiled wide-matrix fill kernel (dp_tiles.hip): full matrices and wide bands spanning
+several tiles, with the graph shapes each of its code paths is for -- plain sequences (simple steps), skip
+edges inside the halo (straight-line two-edge cells), sites with three and more bwd edges, edges that start
+before the halo or several tiles back (operands from HBM), predecessor-less sites -- plus the switch back to
+the one-workgroup wavefront, a protein-sized table (not cached in LDS) and negative-zero parameters."""
+import numpy as np
+import pytest
+
+from pagan2_msa_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b, what=""):
+    assert a.status == b.status, what
+    assert np.float64(a.score).tobytes() == np.float64(b.score).tobytes(), what + " score %r != %r" % (a.score, b.score)
+    assert a.end == b.end, what
+    assert np.array_equal(a.cols, b.cols), what + " columns differ"
+    assert np.array_equal(a.left_used, b.left_used) and np.array_equal(a.right_used, b.right_used), what
+
+
+def wide_band(Lx, Ly, half, seed):
+    """A monotone band a few hundred cells wide: too wide for the banded kernel, so it is tiled."""
+    rng = np.random.default_rng(seed)
+    centre = np.arange(Lx) * (Ly - 1) // max(Lx - 1, 1)
+    h = rng.integers(half // 2, half, Lx)
+    upper = np.maximum.accumulate(np.maximum(centre - h, 0))
+    lower = np.maximum.accumulate(np.minimum(centre + h, Ly - 1))
+    upper[0] = 0
+    lower[-1] = Ly - 1
+    return abi.Band(upper, lower)
+
+
+CASES = {
+    # name: (left sites, right sites, p_extra, max_deg, max_span, p_dead, states)
+    "plain": (300, 330, 0.0, 2, 2, 0.0, 15),
+    "skip_edges_in_halo": (280, 260, 0.10, 2, 6, 0.0, 15),
+    "three_and_more_edges": (260, 300, 0.15, 5, 7, 0.0, 15),
+    "edges_from_before_the_halo": (270, 250, 0.08, 3, 40, 0.0, 15),
+    "edges_across_tiles": (330, 300, 0.05, 4, 200, 0.0, 15),
+    "dead_sites": (250, 270, 0.10, 3, 12, 0.03, 15),
+    "protein_table": (200, 230, 0.08, 3, 10, 0.0, 211),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_full_matrix_over_several_tiles(pg, oracle, name):
+    nl, nr, p_extra, max_deg, max_span, p_dead, states = CASES[name]
+    left = synth.random_graph(nl, states, 101, p_extra=p_extra, max_deg=max_deg, max_span=max_span, p_dead=p_dead)
+    right = synth.random_graph(nr, states, 202, p_extra=p_extra, max_deg=max_deg, max_span=max_span, p_dead=p_dead)
+    model = synth.random_model(states, 7)
+    side, tiles = pg.debug_tiles(left, right)
+    assert len(tiles) >= 16, "the job is meant to span several tiles in both directions"
+    same(pg.align(left, right, model), oracle.dp_align(left, right, model), name)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_wide_band_is_tiled(pg, oracle, seed):
+    left = synth.random_graph(900, 15, 10 + seed, p_extra=0.08, max_deg=4, max_span=30)
+    right = synth.random_graph(860, 15, 20 + seed, p_extra=0.08, max_deg=4, max_span=30)
+    band = wide_band(left.n_sites - 1, right.n_sites - 1, 400, seed)
+    side, tiles = pg.debug_tiles(left, right, band)
+    full = ((left.n_sites + side - 2) // side) * ((right.n_sites + side - 2) // side)
+    assert 0 < len(tiles) < full, "tiles outside the band are not launched"
+    model = synth.random_model(15, seed)
+    same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band), "seed %d" % seed)
+
+
+@pytest.mark.parametrize("flags", [abi.OPT_NO_TERMINAL_EDGES, abi.OPT_NO_REDUCED_TERMINAL_PEN])
+def test_option_bits(pg, oracle, flags):
+    left = synth.random_graph(200, 15, 5, p_extra=0.1, max_deg=3, max_span=9)
+    right = synth.random_graph(170, 15, 6, p_extra=0.1, max_deg=3, max_span=9)
+    model = synth.random_model(15, 3)
+    same(pg.align(left, right, model, flags=flags), oracle.dp_align(left, right, model, flags=flags))
+
+
+def test_tiles_and_wavefront_store_identical_scores(pg, monkeypatch):
+    left = synth.random_graph(260, 15, 31, p_extra=0.12, max_deg=4, max_span=50)
+    right = synth.random_graph(240, 15, 32, p_extra=0.12, max_deg=4, max_span=50)
+    job = (left, right, synth.random_model(15, 9), None)
+    scores = {}
+    for kernel in ("tiles", "wavefront"):
+        monkeypatch.setenv("PAGAN_DP_WIDE", kernel)
+        b = pg.Batch([job])
+        b.run(); b.sync()
+        scores[kernel] = b.debug_scores(0)
+        b.close()
+    assert np.array_equal(scores["tiles"].view(np.int64), scores["wavefront"].view(np.int64))
+
+
+def test_negative_zero_parameters(pg, oracle):
+    left = synth.random_graph(150, 15, 41, p_extra=0.1, max_deg=3, max_span=9)
+    right = synth.random_graph(140, 15, 42, p_extra=0.1, max_deg=3, max_span=9)
+    model = synth.random_model(15, 4)
+    t = model.log_score.copy()
+    t[2, 5] = t[5, 2] = np.float32(-0.0)
+    m2 = abi.Model(t, *model.params)
+    same(pg.align(left, right, m2), oracle.dp_align(left, right, m2))
+
+
+def test_banded_and_tiled_jobs_share_a_batch(pg, oracle):
+    """One launch sequence: the banded kernel on the batch's stream, the tile launches beside it."""
+    a = synth.random_graph(500, 15, 51, p_extra=0.05, max_deg=3, max_span=8)
+    b = synth.random_graph(520, 15, 52, p_extra=0.05, max_deg=3, max_span=8)
+    Lx, Ly = a.n_sites - 1, b.n_sites - 1
+    centre = np.arange(Lx) * (Ly - 1) // (Lx - 1)
+    upper = np.maximum.accumulate(np.maximum(centre - 20, 0)); lower = np.maximum.accumulate(np.minimum(centre + 20, Ly - 1))
+    upper[0] = 0; lower[-1] = Ly - 1
+    narrow = abi.Band(upper, lower)
+    model = synth.random_model(15, 5)
+    jobs = [(a, b, model, narrow), (a, b, model, None), (b, a, model, None)]
+    got = pg.align_batch(jobs)
+    for k, (l, r, m, band) in enumerate(jobs):
+        same(got[k], oracle.dp_align(l, r, m, band), "job %d" % k)
