@@ -50,7 +50,7 @@
 #define PG_PIPE_SITE_EDGES 126   // bwd edges per site (7-bit count in the site record)
 
 #define PG_TILE 64               // dp_tiles.hip: side of the square tiles a wide matrix is cut into (one wave each)
-#define PG_TILE_EDGES 1024       // ... and how many bwd edges the sites of one tile row / tile column may have together
+#define PG_TILE_EDGES 512        // ... and how many bwd edges the sites of one tile row / tile column may have together
 
 struct PgDevJob {
     int Lx, Ly;              // matrix dimensions (sites minus the stop site)

@@ -25,8 +25,8 @@
 // Maxima are taken by compare-and-select in candidate order (first_is_bigger, basic_alignment.h:449-462),
 // so jobs with negative-zero parameters are exact here as well.
 //
-// LDS: (72 x 72 + 1) cells x 24 B = 124,440 B + column records 2 KB + descriptors 6 KB + edge windows 17 KB +
-// model table 1 KB = 151 KB -> one tile per CU.
+// LDS: (72 x 72 + 1) cells x 24 B = 124,440 B + column records 2 KB + descriptors 4 KB + edge windows 9 KB +
+// model scores 16 KB + table 1 KB = 157 KB of 160 -> one tile per CU.
 // The row pitch of 72 cells makes the lanes of a step (stride 71 cells = 213 x 8 B, odd) hit distinct banks.
 #include <hip/hip_runtime.h>
 #include "dp_device.h"
@@ -50,7 +50,8 @@ struct TileSmem {
     pg_i4 cole[TS];                     // its first two bwd edges: start site, log weight (float bits), start site, log weight
     pg_i4 dsc[TDB + 2 * TS];            // descriptors of anti-diagonals i0 + j0 - TDB ...: imin, imax, doff low, doff high
     int eL[TEC + 64][2], eR[TEC + 64][2];   // bwd edges of the tile's rows / columns: start site, log weight (float bits)
-    float table[256];                   // model table when S <= 16
+    float sm[TS][TS];                   // model log score of row i0 + r's state against column j0 + k's: sm[r][k]
+    float table[256];                   // the model table while sm[][] is built (S <= 16)
 };
 
 // Loads inside the step loop are inline asm with their own wait (dp_kcommon.h: far_*): a load the compiler
@@ -130,6 +131,28 @@ __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__
         TM.col[r] = c.r; TM.cole[r] = c.e;
     }
     const SiteRec row = site_rec(J.stL, J.offL, J.srcL, J.lwL, i, J.Lx, i0);
+    // the model's scores for the tile's 64 x 64 state pairs (VA:1363): from the table's LDS copy, or -- a
+    // protein table is 211 x 211 floats -- from HBM/L2, sixteen loads in flight per lane
+    {
+        const bool rv = i > 0 && i < J.Lx;
+        if (tab_lds) {
+            for (int k = 0; k < TS; ++k) {
+                const bool v = rv && j0 + k > 0 && j0 + k < J.Ly;
+                TM.sm[r][k] = v ? TM.table[row.r.x + TM.col[k].x * J.S] : 0.0f;
+            }
+        } else {
+            for (int k0 = 0; k0 < TS; k0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const bool ok = rv && j0 + k0 + u > 0 && j0 + k0 + u < J.Ly;
+                    v[u] = J.table[ok ? row.r.x + TM.col[k0 + u].x * J.S : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) TM.sm[r][k0 + u] = v[u];
+            }
+        }
+    }
     // halo: TH rows above the tile (with the corner), then TH columns left of it.  Two dependent rounds of
     // loads (descriptor of the cell's diagonal, then its scores), each round in flight together: after a
     // kernel boundary every first touch goes to memory.
@@ -217,7 +240,7 @@ __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__
                     const double ux = TM.sc[a_up][0], uy = TM.sc[a_up][1], um = TM.sc[a_up][2];
                     const double lx = TM.sc[a_left][0], ly = TM.sc[a_left][1], lm = TM.sc[a_left][2];
                     const double gx = TM.sc[a_diag][0], gy = TM.sc[a_diag][1], gm = TM.sc[a_diag][2];
-                    const float sm = tab_lds ? TM.table[row.r.x + c.x * J.S] : far_f32(J.table + (row.r.x + c.x * J.S));   // VA:1363
+                    const float sm = TM.sm[r][jj];   // VA:1363
                     const double rw = (double)__int_as_float(ce.y);
                     {
                         const bool end_gap = (j == J.Ly - 1) && !no_terminal_edges;          // VA:864-868 (j > 0 here)
@@ -256,7 +279,7 @@ __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__
                     const int aM00 = (l0 && r0) ? TAT(p0, q0) : TNULL, aM01 = (l0 && r1) ? TAT(p0, q1) : TNULL;
                     const int aM10 = (l1 && r0) ? TAT(p1, q0) : TNULL, aM11 = (l1 && r1) ? TAT(p1, q1) : TNULL;
                     float sm = 0.0f;
-                    if (l0 && r0 && i > 0 && j > 0) sm = tab_lds ? TM.table[row.r.x + c.x * J.S] : far_f32(J.table + (row.r.x + c.x * J.S));
+                    if (l0 && r0 && i > 0 && j > 0) sm = TM.sm[r][jj];
                     {
                         const double x0 = TM.sc[aX0][0], y0 = TM.sc[aX0][1], m0 = TM.sc[aX0][2];
                         const double x1 = TM.sc[aX1][0], y1 = TM.sc[aX1][1], m1 = TM.sc[aX1][2];
@@ -351,7 +374,7 @@ __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__
                             }
                         }
                         if (nl > 0 && nr > 0) {                                              // M (VA:956-963, 1353-1436)
-                            const float sm = tab_lds ? TM.table[row.r.x + c.x * J.S] : far_f32(J.table + (row.r.x + c.x * J.S));
+                            const float sm = TM.sm[r][jj];
                             const double tM = (double)(2 * J.ng) + (double)sm;               // VA:1364
                             const double tX = (double)(0.0f + J.ng) + (double)sm;            // VA:1366-1367
                             i2 e1 = *(const i2 *)TM.eL[eLi];
