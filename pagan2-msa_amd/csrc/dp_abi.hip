@@ -219,7 +219,6 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
         if (hi - lo + 1 > PG_PIPE_WIDTH) { c = hi - lo + 1 > PG_PIPE_WINDOW ? 5 : 4; last_wide = d; }
         else if (d - last_wide < PG_PIPE_REACH) c = 3;
         else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c = 3;
-        else if (fl.no_pred[hi + 1] - fl.no_pred[lo] > 0 || fr.no_pred[d - lo + 1] - fr.no_pred[d - hi] > 0) c = 3;
         else if (run > 0) c = 2;
         else if ((lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH) &&
                  (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)) c = 2;

@@ -17,10 +17,10 @@ def same(a, b, what=""):
     assert np.array_equal(a.left_used, b.left_used) and np.array_equal(a.right_used, b.right_used), what
 
 
-def banded_job(seed, n=700, max_span=40, box=True):
+def banded_job(seed, n=700, max_span=40, box=True, p_dead=0.0):
     rng = np.random.default_rng(seed)
-    left = synth.random_graph(n, 15, 10 + seed, p_extra=0.08, p_dead=0.0, max_span=max_span)
-    right = synth.random_graph(n + 30, 15, 20 + seed, p_extra=0.08, p_dead=0.0, max_span=max_span)
+    left = synth.random_graph(n, 15, 10 + seed, p_extra=0.08, p_dead=p_dead, max_span=max_span)
+    right = synth.random_graph(n + 30, 15, 20 + seed, p_extra=0.08, p_dead=p_dead, max_span=max_span)
     Lx, Ly = left.n_sites - 1, right.n_sites - 1
     half = rng.integers(8, 40, Lx)
     centre = np.arange(Lx) * (Ly - 1) // max(Lx - 1, 1)
@@ -43,6 +43,16 @@ def test_far_edges_general_steps_and_a_wide_box(pg, oracle, seed):
     cls, waves = pg.debug_plan(left, right, band)
     assert set(np.unique(cls)) >= ({2, 3, 4} if seed < 2 else {1, 3, 4}), "the job is meant to reach these classes"
     assert sum(len(w) for w in waves) >= 4, "waves are meant to sleep and wake"
+    same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band), "seed %d" % seed)
+
+
+@pytest.mark.parametrize("seed,p_dead,max_span", [(11, 0.05, 6), (12, 0.2, 6), (13, 0.4, 30), (14, 0.1, 40)])
+def test_sites_without_bwd_edges_stay_on_the_multi_edge_paths(pg, oracle, seed, p_dead, max_span):
+    """Upper levels of deep trees: 18-40 % of the sites have no bwd edge (tools/probe_plan.py on cfg5); their
+    cells take the item loop of the multi-edge steps instead of sending the whole diagonal to the general path."""
+    left, right, model, band = banded_job(seed, n=500, max_span=max_span, box=False, p_dead=p_dead)
+    cls, _ = pg.debug_plan(left, right, band)
+    assert (cls == 3).sum() < 100 and ((cls == 1) | (cls == 2)).sum() > 800
     same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band), "seed %d" % seed)
 
 

@@ -47,9 +47,7 @@ def brute_plan(left, right, band):
             c = 3
         elif not (imin >= 2 and imax <= Lx - 2 and d - imax >= 2 and d - imin <= Ly - 2):
             c = 3
-        elif any(npL[i] for i in rows) or any(npR[j] for j in cols):
-            c = 3
-        elif any(sl[i] + sr[d - i] >= REACH for i in rows):
+        elif any(max(sl[i], 1) + max(sr[d - i], 1) >= REACH for i in rows):      # a site without bwd edges counts as span 1
             c = 2
         elif (imin < REACH or d - imax < REACH) and (any(not simL[i] for i in rows) or any(not simR[j] for j in cols)):
             c = 2
@@ -112,6 +110,19 @@ def test_plan_random_graphs_full_matrix(seed):
     left = synth.random_graph(60 + 40 * seed, 15, seed, p_extra=0.3, p_dead=0.02 * (seed % 2))
     right = synth.random_graph(90 + 25 * seed, 15, 50 + seed, p_extra=0.3, p_dead=0.0)
     check(left, right, None)
+
+
+@pytest.mark.parametrize("seed,p_dead", [(0, 0.05), (1, 0.3)])
+def test_plan_banded_with_sites_without_bwd_edges(seed, p_dead):
+    rng = np.random.default_rng(seed)
+    left = synth.random_graph(400, 15, 70 + seed, p_extra=0.08, p_dead=p_dead, max_span=25)
+    right = synth.random_graph(420, 15, 80 + seed, p_extra=0.08, p_dead=p_dead, max_span=25)
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    half = rng.integers(8, 40, Lx)
+    centre = np.arange(Lx) * (Ly - 1) // (Lx - 1)
+    upper = np.maximum.accumulate(np.maximum(centre - half, 0)); lower = np.maximum.accumulate(np.minimum(centre + half, Ly - 1))
+    upper[0] = 0; lower[-1] = Ly - 1
+    check(left, right, abi.Band(upper, lower))
 
 
 @pytest.mark.parametrize("seed", range(4))
