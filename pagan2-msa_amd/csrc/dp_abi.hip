@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -475,7 +476,43 @@ void carve_outputs(Carver &c, const HostJob &hj, PgDevJob *d) {
     d->endscore = c.take<double>(1);
 }
 
-template <class T> void put(std::vector<char> &stage, const void *devptr_as_off, const T *src, size_t count) {
+// Host staging buffers are reused across batches: a level's upload is hundreds of MB, and fresh zeroed pages
+// for it every time cost more than filling them (46 -> 20 ms for the 244 MB of cfg4's leaf level).
+struct StagePool {
+    std::mutex m;
+    std::vector<std::pair<char *, size_t>> idle;
+    char *take(size_t n, size_t *cap) {
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (size_t k = 0; k < idle.size(); ++k)
+                if (idle[k].second >= n) {
+                    char *p = idle[k].first; *cap = idle[k].second;
+                    idle.erase(idle.begin() + k);
+                    return p;
+                }
+            if (idle.size() >= 4) { std::free(idle.front().first); idle.erase(idle.begin()); }
+        }
+        *cap = n + n / 8 + 4096;
+        return (char *)std::malloc(*cap);
+    }
+    void give(char *p, size_t cap) {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(m);
+        idle.emplace_back(p, cap);
+    }
+};
+StagePool stage_pool;
+struct Stage {
+    char *p = nullptr;
+    size_t cap = 0;
+    explicit Stage(size_t n) { p = stage_pool.take(n, &cap); }
+    ~Stage() { stage_pool.give(p, cap); }
+    Stage(const Stage &) = delete;
+    Stage &operator=(const Stage &) = delete;
+    char *data() { return p; }
+};
+
+template <class T> void put(Stage &stage, const void *devptr_as_off, const T *src, size_t count) {
     if (count) std::memcpy(stage.data() + reinterpret_cast<size_t>(devptr_as_off), src, sizeof(T) * count);
 }
 
@@ -760,6 +797,9 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     const bool use_tiles = !force_v1 && !(wide_env && std::strcmp(wide_env, "wavefront") == 0);
     std::vector<int> which_ring, which_ring_big, which_wide, which_tiled;
     std::vector<int> job_rc(n, PAGAN_OK);
+    const bool verbose = std::getenv("PAGAN_DP_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tc0 = now();
     parallel_jobs(n, [&](int k) {
         RowBand rb;
         job_rc[k] = validate_job(jobs[k], &b->jobs[k], &rb, b->use_pipe);
@@ -808,6 +848,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     which_ring.resize(n, 0);      // tiled jobs are reached through the tile list
     b->block = max_w <= 64 ? 64 : (max_w <= 512 ? 256 : 1024);
 
+    const double tc1 = now();
     // pass 1: sizes.  Inputs first (one contiguous upload), outputs after.
     Carver sizer;
     PgDevJob *jobs_off = sizer.take<PgDevJob>(n);
@@ -819,9 +860,11 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     for (int k = 0; k < n; ++k) carve_outputs(sizer, b->jobs[k], &b->dj[k]);
     b->arena.size = sizer.cur;
     HIP_TRY(hipMalloc((void **)&b->arena.dev, b->arena.size));
+    const double tc2 = now();
 
     // pass 2: stage inputs (offsets from pass 1 index the staging buffer), then rebase.
-    std::vector<char> stage(in_bytes);
+    Stage stage(in_bytes);
+    if (!stage.data()) return PAGAN_E_NOMEM;
     parallel_jobs(n, [&](int k) {
         const pagan_job &jb = jobs[k];
         const HostJob &hj = b->jobs[k];
@@ -836,32 +879,33 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         put(stage, d.imax, hj.dx.imax.data(), hj.dx.imax.size());
         put(stage, d.doff, hj.dx.doff.data(), hj.dx.doff.size());
         {
-            std::vector<int> packed(4 * hj.dx.imin.size());
+            int *packed = reinterpret_cast<int *>(stage.data() + reinterpret_cast<size_t>(d.dsc));     // written in place
             for (size_t t = 0; t < hj.dx.imin.size(); ++t) {
                 packed[4 * t] = hj.dx.imin[t]; packed[4 * t + 1] = hj.dx.imax[t];
                 packed[4 * t + 2] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[4 * t + 3] = (int)(hj.dx.doff[t] >> 32);
             }
-            put(stage, d.dsc, packed.data(), packed.size());
         }
         if (!hj.cls.empty()) {
-            std::vector<int> packed(8 * (hj.dx.imin.size() + 1), 0);
+            int *packed = reinterpret_cast<int *>(stage.data() + reinterpret_cast<size_t>(d.psc));
+            std::memset(packed + 8 * hj.dx.imin.size(), 0, 8 * sizeof(int));                             // the entry of padding
+            unsigned mask = 0;             // bit a: diagonal t-a was computed by the lanes (class <= 3), a = 1 .. REACH-1
             for (size_t t = 0; t < hj.dx.imin.size(); ++t) {
                 packed[8 * t] = hj.dx.imin[t]; packed[8 * t + 1] = hj.dx.imax[t];
                 const long long boff = 24 * hj.dx.doff[t];
                 packed[8 * t + 2] = (int)(boff & 0xffffffffLL); packed[8 * t + 3] = (int)(boff >> 32);
-                unsigned mask = 0;
-                for (int a = 1; a < PG_PIPE_REACH; ++a)
-                    if ((long long)t - a >= 0 && hj.cls[t - a] <= 3) mask |= 1u << a;
+                mask = ((mask << 1) | (t >= 1 && hj.cls[t - 1] <= 3 ? 2u : 0u)) & (((1u << PG_PIPE_REACH) - 1u) & ~1u);
                 const unsigned pair = t + 1 < hj.cls.size() && hj.cls[t + 1] <= 1 ? 1u : 0u;   // the next step is hot too
                 packed[8 * t + 4] = (int)(hj.cls[t] | (pair << 4) | (mask << 5));
                 packed[8 * t + 5] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[8 * t + 6] = (int)(hj.dx.doff[t] >> 32);
                 packed[8 * t + 7] = hj.lead_req[t];
             }
-            put(stage, d.psc, packed.data(), packed.size());
             put(stage, d.sched, hj.sched.data(), hj.sched.size());
         }
         put(stage, d.tb, hj.tb.data(), hj.tb.size());
+        const int zero = 0;
+        put(stage, d.fill_status, &zero, 1);          // the staging buffer is reused, not zeroed
     });
+    const double tc3 = now();
     b->trace_off.resize(n); b->end_off.resize(n); b->score_off.resize(n);
     char *base = b->arena.dev;
     auto rebase = [&](auto *&p) { p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(base + reinterpret_cast<size_t>(p)); };
@@ -891,6 +935,10 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     }
     HIP_TRY(hipMemcpyAsync(base, stage.data(), in_bytes, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
+    if (verbose)
+        std::fprintf(stderr, "pagan_dp: create: plan %.1f ms, hipMalloc of %.0f MB %.1f ms, staging %.0f MB %.1f ms, upload %.1f ms\n",
+                     1e3 * (tc1 - tc0), b->arena.size / 1048576.0, 1e3 * (tc2 - tc1), in_bytes / 1048576.0, 1e3 * (tc3 - tc2),
+                     1e3 * (now() - tc3));
     guard.b = nullptr;
     *out = b;
     return PAGAN_OK;
