@@ -416,6 +416,59 @@ __device__ __forceinline__ void multi2_cell(gdouble_w sc, cdesc8_p psc, int d, u
     }
 }
 
+// Multi-edge cell with ONE multi-edge site (at most two bwd edges) opposite a simple site -- what a wave
+// usually holds: two such cells in one lane need both sites after a gap.  Half of multi2_cell's work: the
+// gap state of the simple side is the straight-line result the caller already has; the gap state of the
+// multi-edge side reads two cells, M two cells (the simple side's edge is the adjacent one, weight 0).  Which
+// side is which differs between lanes, so the operands are selected per lane and the arithmetic is
+// multi2_cell's (minus additions of the simple side's zero weight): G = X with the cells (i - dL, j) for a left multi-edge site, Y with
+// (i, j - dR) for a right one; M pairs (l_k, r_0) or (l_0, r_k), k = 0, 1, in list order.
+__device__ __forceinline__ void multi1_cell(int slot, const pg_i4 &rL, const pg_i4 &cR, int row, double go, double ge, double ng,
+                                            double tM, double tX, double &bx, double &by, double &bm, unsigned &px,
+                                            unsigned &py, unsigned &pm) {
+    const double NI = neg_inf();
+    const bool left = !(rL.x & PR_SIMPLE);                  // the multi-edge site is the left one
+    const pg_i4 m = left ? rL : cR;
+    const bool has1 = ((m.x >> PR_NE_SHIFT) & 127) > 1;
+    const int d0 = m.y & 0xffff, d1 = (int)((unsigned)m.y >> 16);
+    const double w0 = (double)__int_as_float(m.z), w1 = (double)__int_as_float(m.w);
+    // The simple side's edge weight is 0, and `+ 0.0` changes nothing but the sign of a zero, which no score
+    // of a job on this kernel has (has_negative_zero, dp_abi.hip): ((s + t) + lw) + rw = (s + t) + w either way.
+    auto cell = [&](int age, int p, bool present, double &xs, double &ys, double &ms) {
+        int s = slot - age;
+        s += s < 0 ? PRK : 0;
+        const double *c = present ? &PM.sc[s][p & (PNT - 1)][0] : &PM.null_cell[0];
+        xs = c[PG_X]; ys = c[PG_Y]; ms = c[PG_M];
+    };
+    const int pa0 = left ? row - d0 : row, pa1 = left ? row - d1 : row;         // gap operands: (i - dL, j) or (i, j - dR)
+    const int pb0 = left ? row - d0 : row - 1, pb1 = left ? row - d1 : row - 1; // M operands: (i - dL, j - 1) or (i - 1, j - dR)
+    double a0x, a0y, a0m, a1x, a1y, a1m, b0x, b0y, b0m, b1x, b1y, b1m;
+    cell(d0, pa0, true, a0x, a0y, a0m);
+    cell(d1, pa1, has1, a1x, a1y, a1m);
+    cell(d0 + 1, pb0, true, b0x, b0y, b0m);
+    cell(d1 + 1, pb1, has1, b1x, b1y, b1m);
+    const unsigned adj = left ? PG_BP_ADJL : PG_BP_ADJR, other = left ? PG_BP_ADJR : PG_BP_ADJL;
+    const unsigned k1 = left ? (1u << 4) : (1u << 18);
+    const unsigned e0 = d0 == 1 ? adj : 0u, e1 = (d1 == 1 ? adj : 0u) | k1;
+    const unsigned self = left ? PG_X : PG_Y, cross = left ? PG_Y : PG_X;
+    {   // the multi-edge side's gap state: per edge own state, the other gap state, M (VA:898-915 / 927-944)
+        double g = NI;
+        unsigned pg = PG_BP_NONE;
+        const double s0 = left ? a0x : a0y, c0 = left ? a0y : a0x, s1 = left ? a1x : a1y, c1 = left ? a1y : a1x;
+        cand(s0 + ge, e0 | self, g, pg); cand(c0 + go, e0 | cross, g, pg); cand((a0m + ng) + go, e0 | PG_M, g, pg);
+        cand(s1 + ge, e1 | self, g, pg); cand(c1 + go, e1 | cross, g, pg); cand((a1m + ng) + go, e1 | PG_M, g, pg);
+        bx = left ? g : bx; px = left ? pg : px;
+        by = left ? by : g; py = left ? py : pg;
+    }
+    {   // M: the two (left edge, right edge) pairs in list order (VA:1396-1433)
+        bm = NI; pm = PG_BP_NONE;
+        unsigned w = e0 | other;
+        cand((b0m + tM) + w0, w | PG_M, bm, pm); cand((b0x + tX) + w0, w | PG_X, bm, pm); cand((b0y + tX) + w0, w | PG_Y, bm, pm);
+        w = e1 | other;
+        cand((b1m + tM) + w1, w | PG_M, bm, pm); cand((b1x + tX) + w1, w | PG_X, bm, pm); cand((b1y + tX) + w1, w | PG_Y, bm, pm);
+    }
+}
+
 __device__ __forceinline__ double in_vgpr(double x) {
     asm volatile("" : "+v"(x));
     return x;
@@ -692,9 +745,18 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                     bm = first_max3(CM + tM, CX + tX, CY + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
                                     PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
                     if (cls != 0 && !(rL.x & cra.x & PR_SIMPLE)) {
-                        // sites with at most two bwd edges each: straight-line; more: the item loop
+                        // sites with at most two bwd edges each: straight-line -- the half-size block when no cell of
+                        // the wave has two multi-edge sites; more edges: the item loop
                         const int nl = (rL.x >> PR_NE_SHIFT) & 127, nr = (cra.x >> PR_NE_SHIFT) & 127;
-                        if ((unsigned)(nl - 1) < 2u && (unsigned)(nr - 1) < 2u)
+                        const bool two = (unsigned)(nl - 1) < 2u && (unsigned)(nr - 1) < 2u;
+                        const bool one = two && ((rL.x | cra.x) & PR_SIMPLE);
+                        if (__builtin_amdgcn_ballot_w64(two && !one) == 0) {
+                            if (one)
+                                multi1_cell(slot, rL, cra, row, go, ge, ng, tM, tX, bx, by, bm, px, py, pm);
+                            else
+                                multi_cell<false>(sc_out, psc, d, slot, 0u, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX,
+                                                  bx, by, bm, px, py, pm);
+                        } else if (two)
                             multi2_cell<false>(sc_out, psc, d, 0u, slot, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX, bx, by, bm, px, py, pm);
                         else
                             multi_cell<false>(sc_out, psc, d, slot, 0u, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX,
