@@ -3,7 +3,8 @@
 
 Workload (BASELINE.json configs[3], the headline): 32 x 100 kb synthetic DNA on a balanced
 guide tree (branch 0.01), prefix anchors with --anchors-offset 15.  Untimed setup runs the
-whole progressive alignment once on the GPU (its wall-clock is reported as e2e_wall_s) and
+whole progressive alignment on the GPU (twice; the wall-clock of the second walk is reported as
+e2e_wall_s, of the process's first as e2e_wall_first_in_process_s) and
 keeps every internal node's aligner inputs -- child graphs, model table, band -- resident in
 HBM.  A timed "step" is one pass of the hot path (matrix fill + end corner + traceback) over
 that batch of 31 node alignments.  value = in-band DP cells per second over all ranks.
@@ -69,6 +70,13 @@ def main():
                                                 mean_len=mean_len, seed=seed)
 
     # ---- untimed setup: whole progressive alignment on the GPU, inputs stay resident ----
+    # (twice: the first walk also pays the process's one-off costs -- code object load, first hipMalloc,
+    # staging buffers; the second is what a tree costs in a running process)
+    t0 = time.time()
+    msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=local_rank, n_devices=1)
+    msa.align()
+    e2e_wall_cold = time.time() - t0
+    del msa
     t0 = time.time()
     msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=local_rank, n_devices=1)
     msa.align()
@@ -149,6 +157,7 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_CELL * int(cells)},
             "kernels_ms": {"fill": fill_avg_ms, "end_and_trace": float(np.mean(trace_ms))},
             "e2e_wall_s": e2e_wall,
+            "e2e_wall_first_in_process_s": e2e_wall_cold,
             "e2e_breakdown_s": tm,
             "parity_self_check": bool(ok),
         }
