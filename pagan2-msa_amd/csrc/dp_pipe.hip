@@ -30,10 +30,12 @@
 //     one or two waves carry the step and nobody waits for idle ones;
 //   - the host classifies every diagonal (dp_abi.hip, classify_diagonals): 0 = all cells
 //     simple (straight-line code), 1 = multi-edge sites whose predecessors are all in the
-//     ring (straight-line code for the simple lanes, an item loop for the others), 2 = same
+//     ring (straight-line code for the simple lanes, straight-line blocks for cells with at most two bwd
+//     edges per site -- half size when no cell of the wave has two multi-edge sites --, an item loop for
+//     the others), 2 = same
 //     with edges reaching past the ring (those cells come from L2; every wave keeps all but
 //     its last 24 stores retired, so a diagonal 8 steps behind every wave has landed), 3 =
-//     general (first/last rows and columns, sites without predecessors, the steps after a wide
+//     general (first/last rows and columns, the steps after a wide
 //     diagonal: all awake waves rendezvous and drain), 4 = wider than the lanes (every lane takes
 //     several rows, cells come from L2), 5 = wider than the record windows (graph arrays from HBM too);
 //   - a loader wave stages 16-byte site records (state, flags, first two bwd edges), the bwd
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
         int slot = wake % PRK, slot1 = (wake + PRK - 1) % PRK;     // d % PRK, (d-1) % PRK
         int lo_prev = -1, hi_prev = -1;
 
-        // One cell by the general rules (first/last rows and columns, sites without predecessors, any edge
+        // One cell by the general rules (first/last rows and columns, any edge
         // list): records and edges from the LDS windows, earlier cells from the ring or from L2/HBM.
         auto gen_cell = [&](const int d, const int slot_, const unsigned resmask, const int r, const int j, double &bx,
                             double &by, double &bm, unsigned &px, unsigned &py, unsigned &pm) {
