@@ -119,81 +119,150 @@ __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__
     const double NI = neg_inf();
     const bool tab_lds = J.S <= 16;      // DNA: 15 states; a protein table (211 x 211) stays in HBM/L2
 
+    // ---- prologue: after a kernel boundary every first touch goes to memory (~1 us), so the loads are issued in
+    // three dependent rounds, each round's in flight together, with the LDS-only work between issue and use ----
+    PG_GLOBAL const pg_i4 *gdsc = (PG_GLOBAL const pg_i4 *)(unsigned long long)J.dsc;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int dbase = i0 + j0;
+    // which halo cell a lane loads in slot u of chunk k0: TH rows above the tile (with the corner), then TH columns left
+    auto halo_cell = [&](int k, int &p, int &q) {
+        if (k < TH * (TS + TH)) { p = i0 - TH + k / (TS + TH); q = j0 - TH + k % (TS + TH); }
+        else { const int k2 = k - TH * (TS + TH); q = j0 - TH + k2 / TS; p = i0 + k2 % TS; }
+        return k < THALO && p >= 0 && q >= 0 && p < J.Lx && q < J.Ly;
+    };
+    // round 1: descriptors of the tile's diagonals, model table, the sites' CSR offsets and states, first halo descriptors
+    pg_i4 dv[(TDB + 2 * TS) / 64];
+#pragma unroll
+    for (int u = 0; u < (TDB + 2 * TS) / 64; ++u) {
+        const int d = dbase - TDB + r + 64 * u;
+        dv[u] = gdsc[d >= 0 && d < J.nd ? d : 0];
+    }
+    float tv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tv[u] = J.table[tab_lds && r + 64 * u < J.S * J.S ? r + 64 * u : 0];
+    const int jc = j0 + r;
+    const bool cv = jc < J.Ly, rv = i < J.Lx;
+    const int ca = J.offR[cv ? jc : 0], cb = J.offR[cv ? jc + 1 : 0], cst = J.stR[cv ? jc : 0];
+    const int ra = J.offL[rv ? i : 0], rb = J.offL[rv ? i + 1 : 0], rst = J.stL[rv ? i : 0];
+    const int eLend = J.offL[i0 + TS < J.Lx ? i0 + TS : J.Lx], eRend = J.offR[j0 + TS < J.Ly ? j0 + TS : J.Ly];
+    int hp[THC], hat[THC];
+    bool hv[THC];
+    pg_i4 hd[THC];
+#pragma unroll
+    for (int u = 0; u < THC; ++u) {
+        int q;
+        hv[u] = halo_cell(r + 64 * u, hp[u], q);
+        hat[u] = hv[u] ? TAT(hp[u], q) : TNULL;
+        hd[u] = gdsc[hv[u] ? hp[u] + q : 0];
+    }
     for (int k = r; k < (TS + TH) * TP + 1; k += 64) { TM.sc[k][0] = NI; TM.sc[k][1] = NI; TM.sc[k][2] = NI; }
-    if (tab_lds)
-        for (int k = r; k < J.S * J.S; k += 64) TM.table[k] = J.table[k];
-    for (int k = r; k < TDB + 2 * TS; k += 64) {
-        const int d = i0 + j0 - TDB + k;
-        TM.dsc[k] = d >= 0 && d < J.nd ? ((PG_GLOBAL const pg_i4 *)(unsigned long long)J.dsc)[d] : pg_i4{0, -1, 0, 0};
+#pragma unroll
+    for (int u = 0; u < (TDB + 2 * TS) / 64; ++u) {
+        const int d = dbase - TDB + r + 64 * u;
+        TM.dsc[r + 64 * u] = d >= 0 && d < J.nd ? dv[u] : pg_i4{0, -1, 0, 0};
     }
-    {
-        const SiteRec c = site_rec(J.stR, J.offR, J.srcR, J.lwR, j0 + r, J.Ly, j0);
-        TM.col[r] = c.r; TM.cole[r] = c.e;
+    if (tab_lds) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (r + 64 * u < J.S * J.S) TM.table[r + 64 * u] = tv[u];
     }
-    const SiteRec row = site_rec(J.stL, J.offL, J.srcL, J.lwL, i, J.Lx, i0);
+    // round 2: the sites' first two bwd edges, the bwd edge windows, the first halo cells, the remaining halo descriptors
+    SiteRec row, col;
+    auto rec_issue = [&](SiteRec &o, bool valid, int a, int b, int st, gint_p src, gfloat_p lw) {
+        o.r = pg_i4{valid ? st : 0, valid ? a : 0, valid ? b - a : 0, 0};
+        const int n = o.r.z;
+        o.e.x = src[n >= 1 ? a : 0]; o.e.y = __float_as_int(lw[n >= 1 ? a : 0]);
+        o.e.z = src[n >= 2 ? a + 1 : 0]; o.e.w = __float_as_int(lw[n >= 2 ? a + 1 : 0]);
+    };
+    rec_issue(col, cv, ca, cb, cst, J.srcR, J.lwR);
+    rec_issue(row, rv, ra, rb, rst, J.srcL, J.lwL);
+    const int eL0 = __builtin_amdgcn_readfirstlane(ra), eR0 = __builtin_amdgcn_readfirstlane(ca);
+    const int nL = eLend - eL0, nR = eRend - eR0;
+    int es[4];
+    float ew[4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int k = r + 64 * u;
+        es[u] = J.srcL[k < nL ? eL0 + k : 0]; ew[u] = J.lwL[k < nL ? eL0 + k : 0];
+        es[2 + u] = J.srcR[k < nR ? eR0 + k : 0]; ew[2 + u] = J.lwR[k < nR ? eR0 + k : 0];
+    }
+    d2 hxy[THC];
+    double hm[THC];
+#pragma unroll
+    for (int u = 0; u < THC; ++u) {
+        hv[u] = hv[u] && hp[u] >= hd[u].x && hp[u] <= hd[u].y;
+        const long long ix = hv[u] ? (((long long)hd[u].w << 32) | (unsigned)hd[u].z) + (hp[u] - hd[u].x) : 0;
+        hxy[u] = *(PG_GLOBAL const d2 *)(J.sc + 3 * ix);
+        hm[u] = J.sc[3 * ix + 2];
+    }
+    int gp[THC], gat[THC];
+    bool gv[THC];
+    pg_i4 gd[THC];
+#pragma unroll
+    for (int u = 0; u < THC; ++u) {
+        int q;
+        gv[u] = halo_cell(64 * THC + r + 64 * u, gp[u], q);
+        gat[u] = gv[u] ? TAT(gp[u], q) : TNULL;
+        gd[u] = gdsc[gv[u] ? gp[u] + q : 0];
+    }
+    // consume round 2
+    auto rec_flags = [&](SiteRec &o, int s, int first) {
+        const int n = o.r.z;
+        if (n < 1) { o.e.x = 0; o.e.y = 0; }
+        if (n < 2) { o.e.z = 0; o.e.w = 0; }
+        if (n == 1 && o.e.x == s - 1) o.r.z |= SITE_SIMPLE;
+        if (n <= 2) o.r.z |= SITE_TWO;
+        if (n >= 1 && o.e.x < first - TH) o.r.z |= SITE_FAR0;
+        if (n >= 2 && o.e.z < first - TH) o.r.z |= SITE_FAR1;
+    };
+    rec_flags(col, jc, j0);
+    rec_flags(row, i, i0);
+    if (!cv) col.r.z = 0;
+    if (!rv) row.r.z = 0;
+    TM.col[r] = col.r; TM.cole[r] = col.e;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int k = r + 64 * u;
+        if (k < nL) { TM.eL[k][0] = es[u]; TM.eL[k][1] = __float_as_int(ew[u]); }
+        if (k < nR) { TM.eR[k][0] = es[2 + u]; TM.eR[k][1] = __float_as_int(ew[2 + u]); }
+    }
+    for (int k = r + 128; k < nL && k < TEC; k += 64) { TM.eL[k][0] = J.srcL[eL0 + k]; TM.eL[k][1] = __float_as_int(J.lwL[eL0 + k]); }
+    for (int k = r + 128; k < nR && k < TEC; k += 64) { TM.eR[k][0] = J.srcR[eR0 + k]; TM.eR[k][1] = __float_as_int(J.lwR[eR0 + k]); }
+#pragma unroll
+    for (int u = 0; u < THC; ++u)
+        if (hv[u]) { TM.sc[hat[u]][0] = hxy[u].x; TM.sc[hat[u]][1] = hxy[u].y; TM.sc[hat[u]][2] = hm[u]; }
+    // round 3: the remaining halo cells (and, for a table too large for LDS, the tile's model scores)
+#pragma unroll
+    for (int u = 0; u < THC; ++u) {
+        gv[u] = gv[u] && gp[u] >= gd[u].x && gp[u] <= gd[u].y;
+        const long long ix = gv[u] ? (((long long)gd[u].w << 32) | (unsigned)gd[u].z) + (gp[u] - gd[u].x) : 0;
+        hxy[u] = *(PG_GLOBAL const d2 *)(J.sc + 3 * ix);
+        hm[u] = J.sc[3 * ix + 2];
+    }
     // the model's scores for the tile's 64 x 64 state pairs (VA:1363): from the table's LDS copy, or -- a
     // protein table is 211 x 211 floats -- from HBM/L2, sixteen loads in flight per lane
     {
-        const bool rv = i > 0 && i < J.Lx;
-        if (tab_lds) {
-            for (int k = 0; k < TS; ++k) {
-                const bool v = rv && j0 + k > 0 && j0 + k < J.Ly;
-                TM.sm[r][k] = v ? TM.table[row.r.x + TM.col[k].x * J.S] : 0.0f;
+        const bool sv = i > 0 && i < J.Lx;
+        for (int k0 = 0; k0 < TS; k0 += 16) {
+            int at[16];
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) at[u] = TM.col[k0 + u].x;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) at[u] = (sv && j0 + k0 + u > 0 && j0 + k0 + u < J.Ly) ? row.r.x + at[u] * J.S : 0;
+            if (tab_lds) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = TM.table[at[u]];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = J.table[at[u]];
             }
-        } else {
-            for (int k0 = 0; k0 < TS; k0 += 16) {
-                float v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const bool ok = rv && j0 + k0 + u > 0 && j0 + k0 + u < J.Ly;
-                    v[u] = J.table[ok ? row.r.x + TM.col[k0 + u].x * J.S : 0];
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) TM.sm[r][k0 + u] = v[u];
-            }
+            for (int u = 0; u < 16; ++u) TM.sm[r][k0 + u] = v[u];
         }
     }
-    // halo: TH rows above the tile (with the corner), then TH columns left of it.  Two dependent rounds of
-    // loads (descriptor of the cell's diagonal, then its scores), each round in flight together: after a
-    // kernel boundary every first touch goes to memory.
-    {
-        PG_GLOBAL const pg_i4 *gdsc = (PG_GLOBAL const pg_i4 *)(unsigned long long)J.dsc;
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        for (int k0 = 0; k0 < THALO; k0 += 64 * THC) {
-        int hp[THC], hat[THC];
-        bool hv[THC];
-        pg_i4 hd[THC];
 #pragma unroll
-        for (int u = 0; u < THC; ++u) {
-            const int k = k0 + r + 64 * u;
-            int p, q;
-            if (k < TH * (TS + TH)) { p = i0 - TH + k / (TS + TH); q = j0 - TH + k % (TS + TH); }
-            else { const int k2 = k - TH * (TS + TH); q = j0 - TH + k2 / TS; p = i0 + k2 % TS; }
-            hv[u] = k < THALO && p >= 0 && q >= 0 && p < J.Lx && q < J.Ly;
-            hp[u] = p; hat[u] = hv[u] ? TAT(p, q) : TNULL;
-            hd[u] = gdsc[hv[u] ? p + q : 0];
-        }
-        d2 hxy[THC];
-        double hm[THC];
-#pragma unroll
-        for (int u = 0; u < THC; ++u) {
-            hv[u] = hv[u] && hp[u] >= hd[u].x && hp[u] <= hd[u].y;
-            const long long ix = hv[u] ? (((long long)hd[u].w << 32) | (unsigned)hd[u].z) + (hp[u] - hd[u].x) : 0;
-            hxy[u] = *(PG_GLOBAL const d2 *)(J.sc + 3 * ix);
-            hm[u] = J.sc[3 * ix + 2];
-        }
-#pragma unroll
-        for (int u = 0; u < THC; ++u)
-            if (hv[u]) { TM.sc[hat[u]][0] = hxy[u].x; TM.sc[hat[u]][1] = hxy[u].y; TM.sc[hat[u]][2] = hm[u]; }
-        }
-    }
-    // bwd edge lists of the tile's rows and columns
-    const int eL0 = __builtin_amdgcn_readfirstlane(row.r.y), eR0 = __builtin_amdgcn_readfirstlane(TM.col[0].y);
-    {
-        const int nL = J.offL[i0 + TS < J.Lx ? i0 + TS : J.Lx] - eL0, nR = J.offR[j0 + TS < J.Ly ? j0 + TS : J.Ly] - eR0;
-        for (int k = r; k < nL && k < TEC; k += 64) { TM.eL[k][0] = J.srcL[eL0 + k]; TM.eL[k][1] = __float_as_int(J.lwL[eL0 + k]); }
-        for (int k = r; k < nR && k < TEC; k += 64) { TM.eR[k][0] = J.srcR[eR0 + k]; TM.eR[k][1] = __float_as_int(J.lwR[eR0 + k]); }
-    }
+    for (int u = 0; u < THC; ++u)
+        if (gv[u]) { TM.sc[gat[u]][0] = hxy[u].x; TM.sc[gat[u]][1] = hxy[u].y; TM.sc[gat[u]][2] = hm[u]; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
     const double go = (double)J.go, ng = (double)J.ng;
@@ -202,7 +271,6 @@ __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__
     const double lw0 = (double)__int_as_float(row.e.y), lw1 = (double)__int_as_float(row.e.w);
     const double extY = (double)(((i == 0 || i == J.Lx - 1) && !no_terminal_edges) ? J.gE : J.ge);   // VA:875-879
     const double openX0 = (reduced_terminal && p0 == 0) ? 0.0 : go, openX1 = (reduced_terminal && p1 == 0) ? 0.0 : go;  // BA.h:490-513
-    const int dbase = i0 + j0;
     const int s_last = (2 * TS - 2 < J.nd - 1 - dbase) ? 2 * TS - 2 : J.nd - 1 - dbase;
     // operands of a step are fetched one step ahead: the diagonal's descriptor and the column's record
     pg_i4 D = TM.dsc[TDB];
@@ -346,55 +414,66 @@ __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__
                         if (nl > 0) {                                                        // X (VA:898-915); nl > 0 implies i > 0
                             const bool end_gap = (j == 0 || j == J.Ly - 1) && !no_terminal_edges;
                             const double ext = (double)(end_gap ? J.gE : J.ge);
-                            i2 e = *(const i2 *)TM.eL[eLi];
+                            // two stages: while the candidates of edge k are taken, the cell of edge k+1 is on its way
+                            i2 en = *(const i2 *)TM.eL[eLi + 1];
+                            int p = TM.eL[eLi][0];
+                            double xs, ys, ms;
+                            fetch(p, j, xs, ys, ms);
                             for (int k = 0; k < nl; ++k) {
-                                const int p = e.x;
-                                e = *(const i2 *)TM.eL[eLi + k + 1];
-                                double xs, ys, ms;
-                                fetch(p, j, xs, ys, ms);
+                                const int pn = en.x;
+                                double nx = NI, ny = NI, nm = NI;
+                                if (k + 1 < nl) fetch(pn, j, nx, ny, nm);
+                                en = *(const i2 *)TM.eL[eLi + k + 2];
                                 const double open = (reduced_terminal && p == 0) ? 0.0 : go;
                                 const unsigned base = ((unsigned)k << 4) | (p == i - 1 ? PG_BP_ADJL : 0u);
                                 PG_TAKE(bx, px, xs + ext, base | PG_X);
                                 PG_TAKE(bx, px, (ys + 0.0) + go, base | PG_Y);
                                 PG_TAKE(bx, px, (ms + ng) + open, base | PG_M);
+                                p = pn; xs = nx; ys = ny; ms = nm;
                             }
                         }
                         if (nr > 0) {                                                        // Y (VA:927-944)
-                            i2 e = *(const i2 *)TM.eR[eRi];
+                            i2 en = *(const i2 *)TM.eR[eRi + 1];
+                            int q = TM.eR[eRi][0];
+                            double xs, ys, ms;
+                            fetch(i, q, xs, ys, ms);
                             for (int k = 0; k < nr; ++k) {
-                                const int q = e.x;
-                                e = *(const i2 *)TM.eR[eRi + k + 1];
-                                double xs, ys, ms;
-                                fetch(i, q, xs, ys, ms);
+                                const int qn = en.x;
+                                double nx = NI, ny = NI, nm = NI;
+                                if (k + 1 < nr) fetch(i, qn, nx, ny, nm);
+                                en = *(const i2 *)TM.eR[eRi + k + 2];
                                 const double open = (reduced_terminal && q == 0) ? 0.0 : go;
                                 const unsigned base = ((unsigned)k << 18) | (q == j - 1 ? PG_BP_ADJR : 0u);
                                 PG_TAKE(by, py, ys + extY, base | PG_Y);
                                 PG_TAKE(by, py, (xs + 0.0) + go, base | PG_X);
                                 PG_TAKE(by, py, (ms + ng) + open, base | PG_M);
+                                q = qn; xs = nx; ys = ny; ms = nm;
                             }
                         }
                         if (nl > 0 && nr > 0) {                                              // M (VA:956-963, 1353-1436)
                             const float sm = TM.sm[r][jj];
                             const double tM = (double)(2 * J.ng) + (double)sm;               // VA:1364
                             const double tX = (double)(0.0f + J.ng) + (double)sm;            // VA:1366-1367
-                            i2 e1 = *(const i2 *)TM.eL[eLi];
-                            for (int k1 = 0; k1 < nl; ++k1) {
-                                const int p = e1.x;
-                                const double lw = (double)__int_as_float(e1.y);
-                                e1 = *(const i2 *)TM.eL[eLi + k1 + 1];
-                                const unsigned base1 = ((unsigned)k1 << 4) | (p == i - 1 ? PG_BP_ADJL : 0u);
-                                i2 e2 = *(const i2 *)TM.eR[eRi];
-                                for (int k2 = 0; k2 < nr; ++k2) {
-                                    const int q = e2.x;
-                                    const double rw = (double)__int_as_float(e2.y);
-                                    e2 = *(const i2 *)TM.eR[eRi + k2 + 1];
-                                    double xs, ys, ms;
-                                    fetch(p, q, xs, ys, ms);
-                                    const unsigned base = base1 | ((unsigned)k2 << 18) | (q == j - 1 ? PG_BP_ADJR : 0u);
-                                    PG_TAKE(bm, pm, ((ms + tM) + lw) + rw, base | PG_M);
-                                    PG_TAKE(bm, pm, ((xs + tX) + lw) + rw, base | PG_X);
-                                    PG_TAKE(bm, pm, ((ys + tX) + lw) + rw, base | PG_Y);
-                                }
+                            // the (left edge, right edge) pairs row-major as ONE loop: the next pair's edges are requested
+                            // before the current pair's cell
+                            const int pairs = nl * nr;
+                            int k1 = 0, k2 = 0;
+                            i2 e1 = *(const i2 *)TM.eL[eLi], e2 = *(const i2 *)TM.eR[eRi];
+                            for (int t = 0; t < pairs; ++t) {
+                                const int p = e1.x, q = e2.x;
+                                const double lw = (double)__int_as_float(e1.y), rw = (double)__int_as_float(e2.y);
+                                const unsigned base = ((unsigned)k1 << 4) | ((unsigned)k2 << 18) | (p == i - 1 ? PG_BP_ADJL : 0u) |
+                                                      (q == j - 1 ? PG_BP_ADJR : 0u);
+                                const bool wrap = k2 + 1 == nr;
+                                k2 = wrap ? 0 : k2 + 1;
+                                k1 = wrap ? k1 + 1 : k1;
+                                e1 = *(const i2 *)TM.eL[eLi + k1];
+                                e2 = *(const i2 *)TM.eR[eRi + k2];
+                                double xs, ys, ms;
+                                fetch(p, q, xs, ys, ms);
+                                PG_TAKE(bm, pm, ((ms + tM) + lw) + rw, base | PG_M);
+                                PG_TAKE(bm, pm, ((xs + tX) + lw) + rw, base | PG_X);
+                                PG_TAKE(bm, pm, ((ys + tX) + lw) + rw, base | PG_Y);
                             }
                         }
                     }
