@@ -192,6 +192,13 @@ int  pagan_batch_debug_scores(pagan_batch *b, int32_t k, double *dst, int64_t co
 /* diagnostic: overwrite all device outputs with 0xFF (NaN scores) before a run           */
 int  pagan_batch_debug_poison(pagan_batch *b);
 
+/* The library keeps up to two idle device arenas per device and a few host staging buffers for the next
+ * batch (a level of a tree walk is followed by the next; freeing and re-allocating GBs costs tens of ms).
+ * pagan_dp_release_cache frees them; pagan_dp_cached_device_bytes says how much of a device's memory they hold
+ * (memory a caller sizing batches from hipMemGetInfo may count as free). */
+void    pagan_dp_release_cache(void);
+int64_t pagan_dp_cached_device_bytes(int32_t device);
+
 const char *pagan_dp_version(void);
 
 #ifdef __cplusplus

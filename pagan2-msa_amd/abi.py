@@ -183,6 +183,10 @@ def declare(lib):
     lib.pagan_batch_debug_scores.restype = C.c_int
     lib.pagan_batch_debug_poison.argtypes = [C.c_void_p]
     lib.pagan_batch_debug_poison.restype = C.c_int
+    lib.pagan_dp_release_cache.argtypes = []
+    lib.pagan_dp_release_cache.restype = None
+    lib.pagan_dp_cached_device_bytes.argtypes = [C.c_int32]
+    lib.pagan_dp_cached_device_bytes.restype = C.c_int64
     lib.pagan_dp_version.argtypes = []
     lib.pagan_dp_version.restype = C.c_char_p
     return lib
@@ -191,5 +195,5 @@ def declare(lib):
 EXPORTED = ["pagan_dp_align", "pagan_dp_align_batch", "pagan_result_free", "pagan_dp_predict_bytes",
             "pagan_dp_count_cells", "pagan_dp_device_count", "pagan_dp_select_device", "pagan_batch_create",
             "pagan_batch_run", "pagan_batch_sync", "pagan_batch_fetch", "pagan_batch_last_ms",
-            "pagan_batch_cells", "pagan_batch_destroy", "pagan_batch_debug_trace", "pagan_dp_debug_plan", "pagan_dp_debug_tiles", "pagan_batch_debug_scores", "pagan_batch_debug_poison",
+            "pagan_batch_cells", "pagan_batch_destroy", "pagan_batch_debug_trace", "pagan_dp_debug_plan", "pagan_dp_debug_tiles", "pagan_dp_release_cache", "pagan_dp_cached_device_bytes", "pagan_batch_debug_scores", "pagan_batch_debug_poison",
             "pagan_dp_version"]

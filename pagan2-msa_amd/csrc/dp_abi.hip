@@ -337,8 +337,61 @@ template <class F> void parallel_jobs(int n, F f) {
 
 struct Arena {
     char *dev = nullptr;
-    size_t size = 0;
+    size_t size = 0;         // bytes the batch uses
+    size_t cap = 0;          // bytes allocated (an arena taken from the pool may be larger)
 };
+
+// Device arenas are reused by the next batch on the same device: hipFree of a few GB costs 10-30 ms, and a level
+// of a tree walk is followed by the next.  At most two idle arenas per device; pagan_dp_release_cache() frees them.
+struct ArenaPool {
+    struct Slot { char *p; size_t cap; int device; };
+    std::mutex m;
+    std::vector<Slot> idle;
+    char *take(int device, size_t n, size_t *cap) {
+        std::lock_guard<std::mutex> g(m);
+        int best = -1;
+        for (size_t k = 0; k < idle.size(); ++k)
+            if (idle[k].device == device && idle[k].cap >= n && (best < 0 || idle[k].cap < idle[best].cap)) best = (int)k;
+        if (best < 0) return nullptr;
+        char *p = idle[best].p;
+        *cap = idle[best].cap;
+        idle.erase(idle.begin() + best);
+        return p;
+    }
+    void give(int device, char *p, size_t cap) {
+        std::vector<char *> drop;
+        {
+            std::lock_guard<std::mutex> g(m);
+            idle.push_back({p, cap, device});
+            for (;;) {
+                int count = 0, smallest = -1;
+                for (size_t k = 0; k < idle.size(); ++k)
+                    if (idle[k].device == device) { ++count; if (smallest < 0 || idle[k].cap < idle[smallest].cap) smallest = (int)k; }
+                if (count <= 2) break;
+                drop.push_back(idle[smallest].p);
+                idle.erase(idle.begin() + smallest);
+            }
+        }
+        for (char *q : drop) (void)hipFree(q);
+    }
+    // frees the idle arenas of one device (-1: all)
+    void clear(int device) {
+        std::vector<char *> drop;
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (size_t k = 0; k < idle.size();)
+                if (device < 0 || idle[k].device == device) { drop.push_back(idle[k].p); idle.erase(idle.begin() + k); } else ++k;
+        }
+        for (char *q : drop) (void)hipFree(q);
+    }
+    size_t idle_bytes(int device) {
+        std::lock_guard<std::mutex> g(m);
+        size_t n = 0;
+        for (const Slot &s : idle) if (s.device == device) n += s.cap;
+        return n;
+    }
+};
+ArenaPool arena_pool;
 
 } // namespace
 
@@ -859,7 +912,16 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     b->out_begin = in_bytes;
     for (int k = 0; k < n; ++k) carve_outputs(sizer, b->jobs[k], &b->dj[k]);
     b->arena.size = sizer.cur;
-    HIP_TRY(hipMalloc((void **)&b->arena.dev, b->arena.size));
+    b->arena.dev = arena_pool.take(b->device, b->arena.size, &b->arena.cap);
+    if (!b->arena.dev) {
+        b->arena.cap = b->arena.size;
+        if (hipMalloc((void **)&b->arena.dev, b->arena.size) != hipSuccess) {
+            (void)hipGetLastError();
+            b->arena.dev = nullptr;
+            arena_pool.clear(b->device);                 // the idle arenas may be what is in the way
+            HIP_TRY(hipMalloc((void **)&b->arena.dev, b->arena.size));
+        }
+    }
     const double tc2 = now();
 
     // pass 2: stage inputs (offsets from pass 1 index the staging buffer), then rebase.
@@ -987,23 +1049,27 @@ int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
     double ms[2] = {0, 0};
     pagan_batch_last_ms(b, ms);
     for (int k = 0; k < b->n; ++k) std::memset(&out[k], 0, sizeof(pagan_result));
-    int first_err = PAGAN_OK;
-    std::vector<int> trace;
+    // copies first (one device queue), then the path replays of the jobs side by side on the host
+    struct Fetched { int endcell[8]; double endscore; std::vector<int> trace; };
+    std::vector<Fetched> got(b->n);
     for (int k = 0; k < b->n; ++k) {
-        const HostJob &hj = b->jobs[k];
-        int endcell[8];
-        double endscore;
-        HIP_TRY(hipMemcpy(endcell, b->arena.dev + b->end_off[k], sizeof(endcell), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&endscore, b->arena.dev + b->score_off[k], sizeof(double), hipMemcpyDeviceToHost));
-        const int nt = endcell[0] == 0 ? endcell[6] : 0;
-        trace.resize(3 * (size_t)nt + 3);
+        Fetched &f = got[k];
+        HIP_TRY(hipMemcpy(f.endcell, b->arena.dev + b->end_off[k], sizeof(f.endcell), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&f.endscore, b->arena.dev + b->score_off[k], sizeof(double), hipMemcpyDeviceToHost));
+        const int nt = f.endcell[0] == 0 ? f.endcell[6] : 0;
+        f.trace.resize(3 * (size_t)nt + 3);
         if (nt > 0)
-            HIP_TRY(hipMemcpy(trace.data(), b->arena.dev + b->trace_off[k], sizeof(int) * 3 * (size_t)nt, hipMemcpyDeviceToHost));
-        int rc = replay(hj, endcell, endscore, trace.data(), &out[k]);
+            HIP_TRY(hipMemcpy(f.trace.data(), b->arena.dev + b->trace_off[k], sizeof(int) * 3 * (size_t)nt, hipMemcpyDeviceToHost));
+    }
+    std::vector<int> rcs(b->n, PAGAN_OK);
+    parallel_jobs(b->n, [&](int k) {
+        rcs[k] = replay(b->jobs[k], got[k].endcell, got[k].endscore, got[k].trace.data(), &out[k]);
         out[k].fill_ms = ms[0];
         out[k].trace_ms = ms[1];
-        if (rc != PAGAN_OK && first_err == PAGAN_OK) first_err = rc;
-    }
+    });
+    int first_err = PAGAN_OK;
+    for (int k = 0; k < b->n; ++k)
+        if (rcs[k] != PAGAN_OK && first_err == PAGAN_OK) first_err = rcs[k];
     return first_err;
 }
 
@@ -1039,7 +1105,7 @@ void pagan_batch_destroy(pagan_batch *b) {
     if (b->stream2) { hipStreamSynchronize(b->stream2); hipStreamDestroy(b->stream2); }
     if (b->ev_fork) hipEventDestroy(b->ev_fork);
     if (b->ev_join) hipEventDestroy(b->ev_join);
-    if (b->arena.dev) hipFree(b->arena.dev);
+    if (b->arena.dev) arena_pool.give(b->device, b->arena.dev, b->arena.cap);
     delete b;
 }
 
@@ -1069,6 +1135,15 @@ int pagan_dp_align(const pagan_graph *left, const pagan_graph *right, const paga
     pagan_job jb{left, right, model, band};
     return pagan_dp_align_batch(1, &jb, opts, out);
 }
+
+void pagan_dp_release_cache(void) {
+    arena_pool.clear(-1);
+    std::lock_guard<std::mutex> g(stage_pool.m);
+    for (auto &s : stage_pool.idle) std::free(s.first);
+    stage_pool.idle.clear();
+}
+
+int64_t pagan_dp_cached_device_bytes(int32_t device) { return (int64_t)arena_pool.idle_bytes(device); }
 
 void pagan_result_free(pagan_result *r) {
     if (!r) return;

@@ -147,7 +147,7 @@ int device_budget(const pagan_msa_opts &o, int dev, int64_t *bytes) {
     if (hipSetDevice(dev) != hipSuccess) return PAGAN_E_NODEVICE;
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return PAGAN_E_NODEVICE;
-    *bytes = (int64_t)(0.8 * (double)fr);
+    *bytes = (int64_t)(0.8 * (double)(fr + (size_t)pagan_dp_cached_device_bytes(dev)));   // idle arenas are reused or dropped
     return PAGAN_OK;
 }
 

@@ -209,3 +209,19 @@ def test_ring_kernel_wide_boxes_inside_a_band(pg, oracle):
         batch.run()
         assert_same(batch.fetch()[0], want, "rep %d" % rep)
     batch.close()
+
+
+def test_idle_arenas_are_kept_for_the_next_batch_and_can_be_released(pg, oracle):
+    left, right, _ = pair_of_leaves(300, 5, sub=0.1, indel_start=0.03)
+    model = synth.jc_like_dna_model(0.1)
+    L = pg.lib()
+    L.pagan_dp_release_cache()
+    assert L.pagan_dp_cached_device_bytes(0) == 0
+    want = oracle.dp_align(left, right, model)
+    assert_same(pg.align(left, right, model), want)
+    held = L.pagan_dp_cached_device_bytes(0)
+    assert held > 0
+    assert_same(pg.align(left, right, model), want)            # runs in the arena the first call left behind
+    assert L.pagan_dp_cached_device_bytes(0) == held
+    L.pagan_dp_release_cache()
+    assert L.pagan_dp_cached_device_bytes(0) == 0
