@@ -11,17 +11,23 @@
 // Inside a tile the wave sweeps the tile's own anti-diagonals: lane r owns row i0 + r, step s handles
 // column j0 + s - r.  The scores of the WHOLE tile plus a halo of eight rows above and eight columns left
 // of it (loaded from HBM at the start) live in LDS, so every predecessor inside the tile or within eight
-// sites of it is an LDS read; a bwd edge that reaches further back reads HBM (written by an earlier launch).  Results go
+// sites of it is an LDS read; a bwd edge that reaches further back reads HBM (written by an earlier
+// launch).  The prologue issues its loads in three dependent rounds, each in flight together (after a kernel
+// boundary every first touch goes to memory).  Results go
 // to HBM in the batch's diagonal-major layout (dp_device.h) as they are produced; the wave never waits
-// for them.
+// for them: the only loads inside the step loop (operands from before the halo) are inline asm with their own
+// wait (dp_kcommon.h: far_*) -- a load the compiler can see makes its waitcnt insertion put a vmcnt(0), a wait
+// for every store in flight, at the loop header.
 //
 // Code paths per step, chosen wave-uniformly:
 //   simple   every active cell's two sites have exactly one bwd edge, from the previous site: three LDS
 //            cells, nine candidates, straight-line;
 //   near     otherwise: cells whose sites have at most two bwd edges each, all starting inside the tile or
 //            its halo -- eight LDS cells, 24 candidates, straight-line (an absent edge reads a -inf cell);
-//   general  the remaining cells (a site with three or more bwd edges, an edge from before the halo):
-//            cell_any (dp_kcommon.h) with the edges in registers / LDS, operands from LDS or HBM.
+//   loops    a site with three or more bwd edges, or an edge from before the halo, anywhere in the wave: all
+//            active lanes run the reference's loops (the straight-line block would come on top of them, the
+//            loops cost what their longest trip costs): edges from LDS windows, the next one requested ahead,
+//            (left, right) pairs as one flattened loop, operands from LDS or HBM.
 // Maxima are taken by compare-and-select in candidate order (first_is_bigger, basic_alignment.h:449-462),
 // so jobs with negative-zero parameters are exact here as well.
 //
@@ -54,14 +60,6 @@ struct TileSmem {
     float table[256];                   // the model table while sm[][] is built (S <= 16)
 };
 
-// Loads inside the step loop are inline asm with their own wait (dp_kcommon.h: far_*): a load the compiler
-// can see makes its waitcnt insertion put a vmcnt(0) -- a wait for every store in flight -- at the loop header.
-__device__ __forceinline__ int far_i32(PG_GLOBAL const int *p) {
-    int v;
-    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-    return v;
-}
-
 // What a lane keeps about a site: x = state, y = CSR index of its first bwd edge, z = number of bwd
 // edges | SITE_SIMPLE (exactly one, from the previous site) | SITE_TWO (at most two) | SITE_FAR0/1 (edge
 // 0 / 1 starts before the tile's halo); e = first two edges (start site, float bits of the log weight).
@@ -71,23 +69,6 @@ __device__ __forceinline__ int far_i32(PG_GLOBAL const int *p) {
 #define SITE_FAR1 (1 << 27)
 #define SITE_COUNT 0xffff             // PG_MAX_SLOT < 65536
 struct SiteRec { pg_i4 r, e; };
-
-__device__ __forceinline__ SiteRec site_rec(gint_p st, gint_p off, gint_p src, gfloat_p lw, int s, int n, int first) {
-    SiteRec o;
-    o.r = pg_i4{0, 0, 0, 0};
-    o.e = pg_i4{0, 0, 0, 0};
-    if (s >= 0 && s < n) {
-        const int a = off[s], b = off[s + 1];
-        o.r.x = st[s]; o.r.y = a; o.r.z = b - a;
-        if (b - a >= 1) { o.e.x = src[a]; o.e.y = __float_as_int(lw[a]); }
-        if (b - a >= 2) { o.e.z = src[a + 1]; o.e.w = __float_as_int(lw[a + 1]); }
-        if (b - a == 1 && o.e.x == s - 1) o.r.z |= SITE_SIMPLE;
-        if (b - a <= 2) o.r.z |= SITE_TWO;
-        if (b - a >= 1 && o.e.x < first - TH) o.r.z |= SITE_FAR0;
-        if (b - a >= 2 && o.e.z < first - TH) o.r.z |= SITE_FAR1;
-    }
-    return o;
-}
 
 // strict-greater update in candidate order
 #define PG_TAKE(best, bp, c, code) do { const double c__ = (c); if (c__ > best) { best = c__; bp = (code); } } while (0)
