@@ -26,6 +26,11 @@ struct Chains {
         const size_t n = g.state.size();
         bhead.assign(n, -1); btail.assign(n, -1); fhead.assign(n, -1); ftail.assign(n, -1);
     }
+    void reserve_edges(size_t n) {
+        g.e_start.reserve(n); g.e_end.reserve(n); g.e_w.reserve(n); g.e_logw.reserve(n);
+        g.e_count_since_used.reserve(n); g.e_count_as_skipped.reserve(n); g.e_dist_since_used.reserve(n); g.e_used.reserve(n);
+        bnext.reserve(n); fnext.reserve(n);
+    }
     int new_edge(int s, int e, float w, float logw) {
         const int id = (int)g.e_start.size();
         g.e_start.push_back(s); g.e_end.push_back(e); g.e_w.push_back(w); g.e_logw.push_back(logw);
@@ -80,6 +85,11 @@ struct Chains {
     }
 };
 
+void reserve_sites(SeqGraph &g, size_t n) {
+    g.state.reserve(n); g.site_type.reserve(n); g.path_state.reserve(n); g.child_l.reserve(n); g.child_r.reserve(n);
+    g.count_since_used.reserve(n); g.dist_since_used.reserve(n); g.ambiguous.reserve(n);
+}
+
 void push_site(SeqGraph &g, int state, int type, int pstate, int cl, int cr) {
     g.state.push_back(state); g.site_type.push_back((int8_t)type); g.path_state.push_back((int8_t)pstate);
     g.child_l.push_back(cl); g.child_r.push_back(cr);
@@ -91,6 +101,8 @@ void push_site(SeqGraph &g, int state, int type, int pstate, int cl, int cr) {
 SeqGraph make_leaf(const std::string &residues, const std::string &alphabet, int flags) {
     SeqGraph g;
     g.terminal = true;
+    reserve_sites(g, residues.size() + 2);
+    g.symbols.reserve(residues.size());
     push_site(g, -1, kStartSite, kEnds, -1, -1);
     for (char c : residues) {
         if (c == '0') continue;                                   // sequence.cpp:173-176
@@ -100,6 +112,7 @@ SeqGraph make_leaf(const std::string &residues, const std::string &alphabet, int
     push_site(g, -1, kStopSite, kEnds, -1, -1);
     const int n = g.n_sites();
     Chains ch(g);
+    ch.reserve_edges((size_t)n + 8);      // plain leaves: one edge per site (the 454 / homopolymer modes add a few)
     // Edge 0 is created but never linked (sequence.cpp:164-165); it keeps Edge::index of the
     // chain edge into site k equal to k for plain leaves.
     ch.new_edge(-1, 0, 1.0f, 0.0f);
