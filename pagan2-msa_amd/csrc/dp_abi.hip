@@ -471,7 +471,8 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
     // The LDS kernels take maxima with v_max_f64, which returns +0 for (+0, -0) in either order where the
     // reference's compare keeps the incumbent's sign: a job with a negative zero among its parameters
     // runs on the HBM wavefront kernel, which compares.
-    if (has_negative_zero(jb)) narrow = false;
+    const bool neg0 = has_negative_zero(jb);
+    if (neg0) narrow = false;
     if (const char *f = std::getenv("PAGAN_DP_FILL")) if (std::strcmp(f, "tiles") == 0) narrow = false;   // A/B switch
     if (use_pipe) {
         hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES) &&
@@ -483,7 +484,8 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
     } else {
         hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx) && edges_fit_ring(jb.right, hj->Ly);
     }
-    if (!hj->ring_ok && edges_fit_tiles(jb.left, hj->Lx) && edges_fit_tiles(jb.right, hj->Ly)) list_tiles(hj->Lx, *rb, &hj->tiles);
+    if (!hj->ring_ok && !neg0 && edges_fit_tiles(jb.left, hj->Lx) && edges_fit_tiles(jb.right, hj->Ly))
+        list_tiles(hj->Lx, *rb, &hj->tiles);
     return PAGAN_OK;
 }
 

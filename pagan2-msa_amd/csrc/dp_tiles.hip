@@ -28,8 +28,8 @@
 //            active lanes run the reference's loops (the straight-line block would come on top of them, the
 //            loops cost what their longest trip costs): edges from LDS windows, the next one requested ahead,
 //            (left, right) pairs as one flattened loop, operands from LDS or HBM.
-// Maxima are taken by compare-and-select in candidate order (first_is_bigger, basic_alignment.h:449-462),
-// so jobs with negative-zero parameters are exact here as well.
+// Back-pointers follow strict-greater in candidate order (first_is_bigger, basic_alignment.h:449-462); values
+// are v_max_f64 maxima, which is why jobs with negative-zero parameters go to the comparing HBM wavefront.
 //
 // LDS: (72 x 72 + 1) cells x 24 B = 124,440 B + column records 2 KB + descriptors 4 KB + edge windows 9 KB +
 // model scores 16 KB + table 1 KB = 157 KB of 160 -> one tile per CU.
@@ -70,8 +70,11 @@ struct TileSmem {
 #define SITE_COUNT 0xffff             // PG_MAX_SLOT < 65536
 struct SiteRec { pg_i4 r, e; };
 
-// strict-greater update in candidate order
-#define PG_TAKE(best, bp, c, code) do { const double c__ = (c); if (c__ > best) { best = c__; bp = (code); } } while (0)
+// One candidate, in candidate order: it takes the back-pointer only if strictly greater (first_is_bigger,
+// basic_alignment.h:449-462); the value is the maximum either way (v_max_f64: one instruction where a
+// compare-and-select of a double costs two more).  v_max_f64 may flip the sign of a zero, so the host keeps jobs
+// with a negative zero among their parameters off this kernel (dp_abi.hip: has_negative_zero).
+#define PG_TAKE(best, bp, c, code) do { const double c__ = (c); bp = c__ > best ? (code) : bp; best = __builtin_fmax(best, c__); } while (0)
 
 } // namespace
 

@@ -2,7 +2,8 @@
 several tiles, with the graph shapes each of its code paths is for -- plain sequences (simple steps), skip
 edges inside the halo (straight-line two-edge cells), sites with three and more bwd edges, edges that start
 before the halo or several tiles back (operands from HBM), predecessor-less sites -- plus the switch back to
-the one-workgroup wavefront, a protein-sized table (not cached in LDS) and negative-zero parameters."""
+the one-workgroup wavefront, a protein-sized table (not cached in LDS) and negative-zero parameters (which the
+comparing wavefront kernel takes)."""
 import numpy as np
 import pytest
 
@@ -88,7 +89,7 @@ def test_tiles_and_wavefront_store_identical_scores(pg, monkeypatch):
     assert np.array_equal(scores["tiles"].view(np.int64), scores["wavefront"].view(np.int64))
 
 
-def test_negative_zero_parameters(pg, oracle):
+def test_negative_zero_parameters_keep_the_comparing_kernel(pg, oracle):
     left = synth.random_graph(150, 15, 41, p_extra=0.1, max_deg=3, max_span=9)
     right = synth.random_graph(140, 15, 42, p_extra=0.1, max_deg=3, max_span=9)
     model = synth.random_model(15, 4)
