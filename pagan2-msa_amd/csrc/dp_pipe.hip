@@ -425,8 +425,12 @@ __device__ __forceinline__ void multi2_cell(gdouble_w sc, cdesc8_p psc, int d, u
 // side is which differs between lanes, so the operands are selected per lane and the arithmetic is
 // multi2_cell's (minus additions of the simple side's zero weight): G = X with the cells (i - dL, j) for a left multi-edge site, Y with
 // (i, j - dR) for a right one; M pairs (l_k, r_0) or (l_0, r_k), k = 0, 1, in list order.
-__device__ __forceinline__ void multi1_cell(int slot, const pg_i4 &rL, const pg_i4 &cR, int row, double go, double ge, double ng,
-                                            double tM, double tX, double &bx, double &by, double &bm, unsigned &px,
+// FAR (class 2): cells that have left the ring come from L2, requested together, as in multi2_cell<true>, and an
+// edge of the multi-edge site may start at site 0, where the gap-open term differs.
+template <bool FAR>
+__device__ __forceinline__ void multi1_cell(gdouble_w sc, cdesc8_p psc, int d, unsigned resmask, int slot, const pg_i4 &rL,
+                                            const pg_i4 &cR, int row, int j, bool reduced_terminal, double go, double ge,
+                                            double ng, double tM, double tX, double &bx, double &by, double &bm, unsigned &px,
                                             unsigned &py, unsigned &pm) {
     const double NI = neg_inf();
     const bool left = !(rL.x & PR_SIMPLE);                  // the multi-edge site is the left one
@@ -436,19 +440,54 @@ __device__ __forceinline__ void multi1_cell(int slot, const pg_i4 &rL, const pg_
     const double w0 = (double)__int_as_float(m.z), w1 = (double)__int_as_float(m.w);
     // The simple side's edge weight is 0, and `+ 0.0` changes nothing but the sign of a zero, which no score
     // of a job on this kernel has (has_negative_zero, dp_abi.hip): ((s + t) + lw) + rw = (s + t) + w either way.
-    auto cell = [&](int age, int p, bool present, double &xs, double &ys, double &ms) {
-        int s = slot - age;
-        s += s < 0 ? PRK : 0;
-        const double *c = present ? &PM.sc[s][p & (PNT - 1)][0] : &PM.null_cell[0];
-        xs = c[PG_X]; ys = c[PG_Y]; ms = c[PG_M];
-    };
     const int pa0 = left ? row - d0 : row, pa1 = left ? row - d1 : row;         // gap operands: (i - dL, j) or (i, j - dR)
     const int pb0 = left ? row - d0 : row - 1, pb1 = left ? row - d1 : row - 1; // M operands: (i - dL, j - 1) or (i - 1, j - dR)
     double a0x, a0y, a0m, a1x, a1y, a1m, b0x, b0y, b0m, b1x, b1y, b1m;
-    cell(d0, pa0, true, a0x, a0y, a0m);
-    cell(d1, pa1, has1, a1x, a1y, a1m);
-    cell(d0 + 1, pb0, true, b0x, b0y, b0m);
-    cell(d1 + 1, pb1, has1, b1x, b1y, b1m);
+    if (!FAR) {
+        auto cell = [&](int age, int p, bool present, double &xs, double &ys, double &ms) {
+            int s = slot - age;
+            s += s < 0 ? PRK : 0;
+            const double *c = present ? &PM.sc[s][p & (PNT - 1)][0] : &PM.null_cell[0];
+            xs = c[PG_X]; ys = c[PG_Y]; ms = c[PG_M];
+        };
+        cell(d0, pa0, true, a0x, a0y, a0m);
+        cell(d1, pa1, has1, a1x, a1y, a1m);
+        cell(d0 + 1, pb0, true, b0x, b0y, b0m);
+        cell(d1 + 1, pb1, has1, b1x, b1y, b1m);
+    } else {
+        pg_d2 q[4];
+        double qm[4];
+        auto cell = [&](int k, int age, int p, bool present) {
+            q[k].x = NI; q[k].y = NI; qm[k] = NI;
+            if (!present) return;
+            if (age < PAGE && ((resmask >> age) & 1u)) {
+                int s = slot - age;
+                s += s < 0 ? PRK : 0;
+                q[k].x = PM.sc[s][p & (PNT - 1)][PG_X]; q[k].y = PM.sc[s][p & (PNT - 1)][PG_Y]; qm[k] = PM.sc[s][p & (PNT - 1)][PG_M];
+            } else {
+                const int dd = d - age;
+                pg_i4 ds;
+                if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
+                else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
+                if (p >= ds.x && p <= ds.y) {
+                    const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p - ds.x);
+                    far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc + boff), q[k], qm[k]);
+                }
+            }
+        };
+        cell(0, d0, pa0, true);
+        cell(1, d1, pa1, has1);
+        cell(2, d0 + 1, pb0, true);
+        cell(3, d1 + 1, pb1, has1);
+        far_wait3(q[0], qm[0], q[1], qm[1], q[2], qm[2]);
+        { pg_d2 dq = {NI, NI}; double dm = NI; pg_d2 dq2 = {NI, NI}; double dm2 = NI; far_wait3(q[3], qm[3], dq, dm, dq2, dm2); }
+        a0x = q[0].x; a0y = q[0].y; a0m = qm[0];  a1x = q[1].x; a1y = q[1].y; a1m = qm[1];
+        b0x = q[2].x; b0y = q[2].y; b0m = qm[2];  b1x = q[3].x; b1y = q[3].y; b1m = qm[3];
+    }
+    // an edge of the multi-edge site that starts at site 0 opens a gap for free (BA.h:490-513); class 1 diagonals lie
+    // PAGE rows and columns inside the matrix
+    const int at = left ? row : j;
+    const double o0 = (FAR && reduced_terminal && at == d0) ? 0.0 : go, o1 = (FAR && reduced_terminal && at == d1) ? 0.0 : go;
     const unsigned adj = left ? PG_BP_ADJL : PG_BP_ADJR, other = left ? PG_BP_ADJR : PG_BP_ADJL;
     const unsigned k1 = left ? (1u << 4) : (1u << 18);
     const unsigned e0 = d0 == 1 ? adj : 0u, e1 = (d1 == 1 ? adj : 0u) | k1;
@@ -457,8 +496,8 @@ __device__ __forceinline__ void multi1_cell(int slot, const pg_i4 &rL, const pg_
         double g = NI;
         unsigned pg = PG_BP_NONE;
         const double s0 = left ? a0x : a0y, c0 = left ? a0y : a0x, s1 = left ? a1x : a1y, c1 = left ? a1y : a1x;
-        cand(s0 + ge, e0 | self, g, pg); cand(c0 + go, e0 | cross, g, pg); cand((a0m + ng) + go, e0 | PG_M, g, pg);
-        cand(s1 + ge, e1 | self, g, pg); cand(c1 + go, e1 | cross, g, pg); cand((a1m + ng) + go, e1 | PG_M, g, pg);
+        cand(s0 + ge, e0 | self, g, pg); cand(c0 + go, e0 | cross, g, pg); cand((a0m + ng) + o0, e0 | PG_M, g, pg);
+        cand(s1 + ge, e1 | self, g, pg); cand(c1 + go, e1 | cross, g, pg); cand((a1m + ng) + o1, e1 | PG_M, g, pg);
         bx = left ? g : bx; px = left ? pg : px;
         by = left ? by : g; py = left ? py : pg;
     }
@@ -754,7 +793,8 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                         const bool one = two && ((rL.x | cra.x) & PR_SIMPLE);
                         if (__builtin_amdgcn_ballot_w64(two && !one) == 0) {
                             if (one)
-                                multi1_cell(slot, rL, cra, row, go, ge, ng, tM, tX, bx, by, bm, px, py, pm);
+                                multi1_cell<false>(sc_out, psc, d, 0u, slot, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX,
+                                                   bx, by, bm, px, py, pm);
                             else
                                 multi_cell<false>(sc_out, psc, d, slot, 0u, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX,
                                                   bx, by, bm, px, py, pm);
@@ -781,7 +821,16 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                                         PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
                         if (!(rL.x & cra.x & PR_SIMPLE)) {
                             const int nl = (rL.x >> PR_NE_SHIFT) & 127, nr = (cra.x >> PR_NE_SHIFT) & 127;
-                            if ((unsigned)(nl - 1) < 2u && (unsigned)(nr - 1) < 2u)
+                            const bool two = (unsigned)(nl - 1) < 2u && (unsigned)(nr - 1) < 2u;
+                            const bool one = two && ((rL.x | cra.x) & PR_SIMPLE);
+                            if (__builtin_amdgcn_ballot_w64(two && !one) == 0) {
+                                if (one)
+                                    multi1_cell<true>(sc_out, psc, d, resmask, slot, rL, cra, row, j, reduced_terminal, go, ge, ng,
+                                                      tM, tX, bx, by, bm, px, py, pm);
+                                else
+                                    multi_cell<true>(sc_out, psc, d, slot, resmask, rL, cra, row, j, reduced_terminal, go, ge, ng,
+                                                     tM, tX, bx, by, bm, px, py, pm);
+                            } else if (two)
                                 multi2_cell<true>(sc_out, psc, d, resmask, slot, rL, cra, row, j, reduced_terminal, go, ge, ng, tM,
                                                   tX, bx, by, bm, px, py, pm);
                             else
