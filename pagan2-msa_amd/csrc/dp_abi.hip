@@ -458,7 +458,7 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
         }
         hj->tb[hj->n_bound + 1] = run;
         // The segmented traceback chases from EVERY cell of every boundary: worth it for a narrow
-        // band over a long path (2 x 100 kb: 1.3e5 chases of 256 cells against one chase of 2e5),
+        // band over a long path (2 x 100 kb: 2.6e5 chases of 128 cells against one chase of 2e5),
         // wasteful for a short path through a full matrix (thousands of cells per boundary).  Fall
         // back to the single serial chase (pg_trace_compose with no boundaries) in that case.
         const long long speculative = (long long)run / 3 * PG_SEG, serial = (long long)hj->Lx + hj->Ly;
@@ -818,14 +818,14 @@ int64_t pagan_dp_count_cells(int32_t left_sites, int32_t right_sites, const paga
 }
 
 // Device bytes for one alignment (an upper bound of what carve_job / carve_outputs lay out): 36 B per in-band
-// cell (3 x (f64 score + u32 back-pointer)) + < 1 B per cell of traceback tables (32 B per state of the two
-// boundary diagonals in every 256) + per diagonal 64 B of band index, descriptors and plan + per site 12 B of
+// cell (3 x (f64 score + u32 back-pointer)) + 1.5 B per cell of traceback tables (32 B per state of the two
+// boundary diagonals in every PG_SEG = 128) + per diagonal 64 B of band index, descriptors and plan + per site 12 B of
 // trace buffer and ~20 B of graph arrays (one to two bwd edges per site), all 256-byte aligned.
 int64_t pagan_dp_predict_bytes(int32_t left_sites, int32_t right_sites, const pagan_band *band) {
     int64_t cells = pagan_dp_count_cells(left_sites, right_sites, band);
     if (cells < 0) return cells;
     const int64_t nd = (int64_t)left_sites + right_sites - 3, sites = (int64_t)left_sites + right_sites;
-    return cells * 37 + nd * 64 + sites * 40 + 128 * 1024;
+    return cells * 38 + nd * 64 + sites * 40 + 128 * 1024;
 }
 
 int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts, pagan_batch **out) {

@@ -33,7 +33,7 @@
 #define PG_BP_ADJL 4u
 #define PG_BP_ADJR 8u
 #define PG_MAX_SLOT 16383
-#define PG_SEG 256           // diagonals per traceback segment
+#define PG_SEG 128           // diagonals per traceback segment
 
 // Geometry of the banded fill kernel (dp_pipe.hip) that the host-side planner (dp_abi.hip:
 // classify_diagonals, schedule_waves) has to agree with.
