@@ -113,3 +113,29 @@ def test_banded_and_tiled_jobs_share_a_batch(pg, oracle):
     got = pg.align_batch(jobs)
     for k, (l, r, m, band) in enumerate(jobs):
         same(got[k], oracle.dp_align(l, r, m, band), "job %d" % k)
+
+
+@pytest.mark.parametrize("nl,nr", [(1, 700), (700, 1), (3, 500), (62, 62), (63, 64), (64, 65), (65, 127), (128, 129), (2, 2)])
+def test_shapes_around_the_tile_size(pg, oracle, nl, nr):
+    """Matrices of 1 x many tiles, and sides just below / at / above multiples of the tile side (the matrix has
+    nl + 1 by nr + 1 cells: start site included)."""
+    left = synth.random_graph(nl, 15, 300 + nl, p_extra=0.2, max_deg=4, max_span=12, p_dead=0.02)
+    right = synth.random_graph(nr, 15, 400 + nr, p_extra=0.2, max_deg=4, max_span=12, p_dead=0.02)
+    model = synth.random_model(15, nl + nr)
+    same(pg.align(left, right, model), oracle.dp_align(left, right, model), "%d x %d" % (nl, nr))
+
+
+def test_band_with_boxes_on_the_matrix_edges(pg, oracle):
+    left = synth.random_graph(600, 15, 71, p_extra=0.1, max_deg=3, max_span=20)
+    right = synth.random_graph(640, 15, 72, p_extra=0.1, max_deg=3, max_span=20)
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    centre = np.arange(Lx) * (Ly - 1) // (Lx - 1)
+    upper = np.maximum(centre - 150, 0); lower = np.minimum(centre + 150, Ly - 1)
+    upper[:200] = 0; lower[:200] = np.maximum(lower[:200], 400)          # a box in the start corner
+    upper[-150:] = upper[-150]; lower[-150:] = Ly - 1                      # and one in the end corner
+    upper = np.maximum.accumulate(upper); lower = np.maximum.accumulate(lower)
+    band = abi.Band(upper, lower)
+    side, tiles = pg.debug_tiles(left, right, band)
+    assert len(tiles) > 30
+    model = synth.random_model(15, 11)
+    same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band))
