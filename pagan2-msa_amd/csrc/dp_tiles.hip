@@ -322,7 +322,71 @@ __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__
                 // one lane that needs the loops takes the whole step there: the loops cost what their longest trip
                 // costs, the straight-line block would come on top
                 const bool near = __builtin_amdgcn_ballot_w64(active && !(two && !anyfar)) == 0;
-                if (active && near) {
+                // a simple site on at least one side of every cell of the wave (the usual case: two multi-edge sites in one
+                // cell need a gap on both sides): the half-size block
+                const bool one = ((row.r.z | c.z) & SITE_SIMPLE) != 0;
+                const bool half = near && __builtin_amdgcn_ballot_w64(active && !one) == 0;
+                if (active && half) {
+                    // The simple side's gap state comes from its one (adjacent) edge; the other side's gap state and M from
+                    // that side's at most two edges, paired with the simple side's one.  Which side is which differs between
+                    // lanes: operands are selected per lane, the sums associate as in the full block below.
+                    const bool left = !(row.r.z & SITE_SIMPLE);                      // the (possibly) multi-edge site is the left one
+                    const double rw0 = (double)__int_as_float(ce.y), rw1 = (double)__int_as_float(ce.w);
+                    const int g0 = left ? p0 : q0, g1 = left ? p1 : q1;              // where that site's edges start
+                    const bool h0 = left ? l0 : r0, h1 = left ? l1 : r1;
+                    const double gw0 = left ? lw0 : rw0, gw1 = left ? lw1 : rw1, sw = left ? rw0 : lw0;
+                    const int aS = left ? TAT(i, j - 1) : TAT(i - 1, j);
+                    const int aA0 = h0 ? (left ? TAT(g0, j) : TAT(i, g0)) : TNULL, aA1 = h1 ? (left ? TAT(g1, j) : TAT(i, g1)) : TNULL;
+                    const int aB0 = h0 ? (left ? TAT(g0, j - 1) : TAT(i - 1, g0)) : TNULL;
+                    const int aB1 = h1 ? (left ? TAT(g1, j - 1) : TAT(i - 1, g1)) : TNULL;
+                    const double sx = TM.sc[aS][0], sy = TM.sc[aS][1], ss = TM.sc[aS][2];
+                    const double a0x = TM.sc[aA0][0], a0y = TM.sc[aA0][1], a0m = TM.sc[aA0][2];
+                    const double a1x = TM.sc[aA1][0], a1y = TM.sc[aA1][1], a1m = TM.sc[aA1][2];
+                    const double b0x = TM.sc[aB0][0], b0y = TM.sc[aB0][1], b0m = TM.sc[aB0][2];
+                    const double b1x = TM.sc[aB1][0], b1y = TM.sc[aB1][1], b1m = TM.sc[aB1][2];
+                    const float sm = (i > 0 && j > 0) ? TM.sm[r][jj] : 0.0f;
+                    const double extX = (double)(((j == 0 || j == J.Ly - 1) && !no_terminal_edges) ? J.gE : J.ge);   // VA:864-868
+                    const unsigned adjG = left ? PG_BP_ADJL : PG_BP_ADJR, adjS = left ? PG_BP_ADJR : PG_BP_ADJL;
+                    const unsigned selfG = left ? PG_X : PG_Y, crossG = left ? PG_Y : PG_X;
+                    const int kshift = left ? 4 : 18;
+                    const int nearG = left ? i - 1 : j - 1;                          // the site an adjacent edge of that side starts at
+                    double gs = NI, ssb = NI;
+                    unsigned pg = PG_BP_NONE, ps = PG_BP_NONE;
+                    {   // the simple side's gap state: one operand, own state first (VA:898-915 / 927-944)
+                        const double extS = left ? extY : extX;
+                        const int srcS = left ? j - 1 : i - 1;
+                        const double open = (reduced_terminal && srcS == 0) ? 0.0 : go;
+                        PG_TAKE(ssb, ps, (left ? sy : sx) + extS, crossG | adjS);
+                        PG_TAKE(ssb, ps, ((left ? sx : sy) + 0.0) + go, selfG | adjS);
+                        PG_TAKE(ssb, ps, (ss + ng) + open, PG_M | adjS);
+                    }
+                    {   // the other side's gap state: per edge own state, the other gap state, M
+                        const double extG = left ? extX : extY;
+                        const unsigned e0 = g0 == nearG ? adjG : 0u, e1 = (g1 == nearG ? adjG : 0u) | (1u << kshift);
+                        const double o0 = (reduced_terminal && g0 == 0) ? 0.0 : go, o1 = (reduced_terminal && g1 == 0) ? 0.0 : go;
+                        PG_TAKE(gs, pg, (left ? a0x : a0y) + extG, e0 | selfG);
+                        PG_TAKE(gs, pg, ((left ? a0y : a0x) + 0.0) + go, e0 | crossG);
+                        PG_TAKE(gs, pg, (a0m + ng) + o0, e0 | PG_M);
+                        PG_TAKE(gs, pg, (left ? a1x : a1y) + extG, e1 | selfG);
+                        PG_TAKE(gs, pg, ((left ? a1y : a1x) + 0.0) + go, e1 | crossG);
+                        PG_TAKE(gs, pg, (a1m + ng) + o1, e1 | PG_M);
+                    }
+                    {   // M: the (left edge, right edge) pairs in list order (VA:1396-1433)
+                        const double tM = (double)(2 * J.ng) + (double)sm;                   // VA:1364
+                        const double tX = (double)(0.0f + J.ng) + (double)sm;                // VA:1366-1367
+                        const double lwA0 = left ? gw0 : sw, rwA0 = left ? sw : gw0, lwA1 = left ? gw1 : sw, rwA1 = left ? sw : gw1;
+                        const unsigned e0 = (g0 == nearG ? adjG : 0u) | adjS, e1 = (g1 == nearG ? adjG : 0u) | (1u << kshift) | adjS;
+                        PG_TAKE(bm, pm, ((b0m + tM) + lwA0) + rwA0, e0 | PG_M);
+                        PG_TAKE(bm, pm, ((b0x + tX) + lwA0) + rwA0, e0 | PG_X);
+                        PG_TAKE(bm, pm, ((b0y + tX) + lwA0) + rwA0, e0 | PG_Y);
+                        PG_TAKE(bm, pm, ((b1m + tM) + lwA1) + rwA1, e1 | PG_M);
+                        PG_TAKE(bm, pm, ((b1x + tX) + lwA1) + rwA1, e1 | PG_X);
+                        PG_TAKE(bm, pm, ((b1y + tX) + lwA1) + rwA1, e1 | PG_Y);
+                    }
+                    bx = left ? gs : ssb; px = left ? pg : ps;
+                    by = left ? ssb : gs; py = left ? ps : pg;
+                }
+                if (active && near && !half) {
                     // At most two bwd edges per site, all eight operand cells in LDS: straight-line, the cell of an
                     // absent edge is the -inf cell (its candidates never win).  Order: SURVEY.md Appendix A.
                     const double rw0 = (double)__int_as_float(ce.y), rw1 = (double)__int_as_float(ce.w);
