@@ -540,6 +540,20 @@ __device__ __forceinline__ void commit_cell(gdouble_w sc_out, gu32_w bp_out, con
 
 } // namespace
 
+// A class 5 step: out of line -- it is rare, and the kernel is as large as the instruction cache.
+__device__ __attribute__((noinline)) void widest_step(const PgDevJob *job, cdesc8_p psc, int d, int lo, int hi, int tid,
+                                                      bool no_terminal_edges, bool reduced_terminal) {
+    const View J = load_view(job);
+    const pg_i8 cur = psc[d];
+    const pg_i8 p1 = psc[d > 0 ? d - 1 : 0], p2 = psc[d > 1 ? d - 2 : 0];
+    const Diag g1 = {p1.x, d > 0 ? p1.y : p1.x - 1, ((long long)p1.s6 << 32) | (unsigned)p1.s5};
+    const Diag g2 = {p2.x, d > 1 ? p2.y : p2.x - 1, ((long long)p2.s6 << 32) | (unsigned)p2.s5};
+    const long long base = ((long long)cur.s6 << 32) | (unsigned)cur.s5;
+    for (int i = lo + tid; i <= hi; i += PNT)
+        fill_cell_hbm(J, d, g1, g2, i, d - i, base + (i - lo), no_terminal_edges, reduced_terminal);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 #ifdef PG_PIPE_STATS
 #ifndef PG_STAT_CLASS
 #define PG_STAT_CLASS 0      // the class whose steps the phase stamps cover (-DPG_STAT_CLASS=1 for multi-edge steps)
@@ -914,16 +928,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                 hi_prev = -2;
             } else {
                 // ---- wider than the record windows: every cell from HBM/L2 operands, graph arrays included ----
-                const PgDevJob *cold = job;
-                asm volatile("" : "+s"(cold));                     // opaque: keeps these loads inside the branch
-                const View J = load_view(cold);
-                const pg_i8 p1 = psc[d > 0 ? d - 1 : 0], p2 = psc[d > 1 ? d - 2 : 0];
-                const Diag g1 = {p1.x, d > 0 ? p1.y : p1.x - 1, ((long long)p1.s6 << 32) | (unsigned)p1.s5};
-                const Diag g2 = {p2.x, d > 1 ? p2.y : p2.x - 1, ((long long)p2.s6 << 32) | (unsigned)p2.s5};
-                const long long base = ((long long)cur.s6 << 32) | (unsigned)cur.s5;
-                for (int i = lo + tid; i <= hi; i += PNT)
-                    fill_cell_hbm(J, d, g1, g2, i, d - i, base + (i - lo), no_terminal_edges, reduced_terminal);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                widest_step(job, psc, d, lo, hi, tid, no_terminal_edges, reduced_terminal);
                 have = false;                                      // the record window may have lapped this lane's row
                 hi_prev = -2;
             }
