@@ -98,6 +98,7 @@ __device__ __forceinline__ int flag_peek(const int *p) {
 }
 __device__ __forceinline__ int flag_load(const int *p) { return __builtin_amdgcn_readfirstlane(flag_peek(p)); }
 __device__ __forceinline__ void flag_store(int *p, int v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // LDS only: the writes a flag publishes stay above its store
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
