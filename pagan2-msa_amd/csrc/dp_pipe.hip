@@ -91,8 +91,9 @@ typedef __attribute__((address_space(4))) const pg_i8 *cdesc8_p;
 typedef __attribute__((address_space(4))) const int *cint_p;
 
 // Acquire, so that the compiler keeps the LDS reads a flag guards (ring cells, records, descriptors) below the read
-// of the flag; in hardware a wave's LDS operations execute in order anyway.  The stores are relaxed on purpose: a
-// release would wait for the wave's HBM stores, which the flags do not cover (the far reads have their own rule).
+// of the flag; in hardware a wave's LDS operations execute in order anyway.  The stores sit behind a release fence
+// restricted to LDS: an unrestricted release would also wait for the wave's HBM stores, which the flags do not
+// cover (the far reads have their own rule).
 __device__ __forceinline__ int flag_peek(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
