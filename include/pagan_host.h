@@ -7,7 +7,8 @@
  * tree; at every internal node build the Evol_model for dist = d_left + d_right, define the
  * tunnel from anchors, call the pairwise aligner (GPU), build the parent Sequence graph.
  * Nodes whose children are finished are independent and are aligned as one batch
- * (node.cpp:227-285), optionally spread over several devices (no collectives).
+ * (node.cpp:227-285), optionally spread over several devices or ranks (no collectives in the
+ * data path: what ranks exchange is the finished path of a node, host bytes).
  *
  * Also exposes the host graph builder on its own (pagan_hgraph_*), the counterpart of
  * Sequence construction (src/main/sequence.cpp:152-303) and
@@ -41,6 +42,11 @@ typedef struct pagan_msa_opts {
     int32_t  host_threads;       /* threads for anchors / graph building; 0 = hardware           */
     float    truncate_branches;  /* --truncate-branches, default 0.2 (settings.cpp:228)          */
     int64_t  device_mem_budget;  /* bytes of HBM one batch may use; 0 = 80% of free memory       */
+    int32_t  data_type;          /* 0 = guess (Fasta_reader::check_sequence_data_type,
+                                    fasta_reader.cpp:1303-1336), 1 = DNA, 2 = protein (WAG,
+                                    211-letter alphabet, model_factory.cpp:304-632,1478-1595)     */
+    int32_t  pileup_rates;       /* ins = del = 0.25: --454/--homopolymer with --pileup-alignment
+                                    (model_factory.cpp:1901-1905)                                  */
 } pagan_msa_opts;
 
 void pagan_msa_default_opts(pagan_msa_opts *o);
@@ -68,8 +74,35 @@ typedef struct pagan_msa_timing {
 
 int  pagan_msa_create(int32_t n_seqs, const char *const *names, const char *const *seqs,
                       const char *newick, const pagan_msa_opts *opts, pagan_msa **out);
-/* Progressive alignment of every internal node; the DP runs on the GPU(s).               */
+/* Progressive alignment of every internal node; the DP runs on the GPU(s).  With n_devices > 1 the
+ * ready nodes are a work queue over the devices (Node::start_threaded_alignment, node.cpp:196-223,
+ * 289-345): a parent is ready the moment its two children are done, idle devices take what is
+ * ready.  No collective: parents are built on the host.                                          */
 int  pagan_msa_align(pagan_msa *m);
+
+/* ---- the same walk, one step at a time (one process per GPU: tree replicated, DP sharded) -------
+ * Every rank holds the whole tree.  Per round: pagan_msa_ready lists the nodes whose children are
+ * done (build_queues, node.cpp:273-285; the same list on every rank), the ranks split it with
+ * pagan_assign_units over pagan_msa_node_cost, each aligns its share (pagan_msa_align_nodes:
+ * model, anchors, DP on this rank's device(s), parent graph), exports what the alignment left behind
+ * (pagan_msa_export_result: path columns + used child edges + max_end, a few bytes per column) and
+ * imports the other ranks' results (pagan_msa_import_result builds those parents locally).
+ * pagan_msa_finish after the last round.  pagan_msa_align is this loop with one rank.           */
+int     pagan_msa_ready(const pagan_msa *m, int32_t *ids, int32_t cap);    /* count (may exceed cap) */
+int     pagan_msa_remaining(const pagan_msa *m);                           /* internal nodes not yet done */
+int64_t pagan_msa_node_cost(const pagan_msa *m, int32_t node);             /* cells estimate of a ready node */
+int     pagan_msa_align_nodes(pagan_msa *m, int32_t n, const int32_t *nodes);
+int64_t pagan_msa_export_result(const pagan_msa *m, int32_t node, void *buf, int64_t cap);  /* bytes needed/written */
+int     pagan_msa_import_result(pagan_msa *m, const void *buf, int64_t bytes);
+int     pagan_msa_finish(pagan_msa *m);
+int     pagan_msa_data_type(const pagan_msa *m);                           /* 1 DNA, 2 protein */
+int     pagan_msa_node_device(const pagan_msa *m, int32_t k);              /* device internal node k ran on; -1: another rank */
+/* TEST SEAM, never set by the product: replaces pagan_dp_align_batch as the thing the work queue hands its
+ * batches to, so that the queue (dealing, feeder threads, retries, result exchange) can be exercised on a
+ * machine without a GPU.  fn has pagan_dp_align_batch's contract (results released with free()); the device a
+ * batch was dealt to arrives in opts->device.  NULL restores the HIP path.                                    */
+typedef int (*pagan_batch_fn)(int32_t n, const pagan_job *jobs, const pagan_opts *opts, pagan_result *out, void *user);
+int     pagan_msa_set_batch_backend(pagan_msa *m, pagan_batch_fn fn, void *user);
 int  pagan_msa_n_internal(const pagan_msa *m);
 int  pagan_msa_node_info(const pagan_msa *m, int32_t k, pagan_node_info *out);
 /* Borrowed views (valid until pagan_msa_destroy) of what node k's alignment consumed and
@@ -114,6 +147,16 @@ int  pagan_define_tunnel(const char *s1, const char *s2, const char *gapped1, co
  * log_gap_open, log_gap_ext, log_gap_end_ext, log_non_gap; parsimony [i + j*15].          */
 int  pagan_dna_model(const float base_freq[4], double distance, float *table, float *params,
                      int32_t *parsimony);
+/* Protein (WAG) Evol_model for a distance: table [a + b*211] (211x211 floats), params as above,
+ * parsimony [i + j*211] (model_factory.cpp:304-541, 1478-1595, 1871-1960, 2155-2219).              */
+int  pagan_protein_model(double distance, float *table, float *params, int32_t *parsimony);
+/* Alphabets of a data type (1 DNA, 2 protein): leaf_alphabet (state = position of the residue,
+ * Sequence::full_char_alphabet) and ancestral_alphabet (the character an internal state prints as,
+ * Model_factory::ancestral_character_alphabet); both >= 212 bytes.  Returns the number of states.  */
+int  pagan_model_alphabets(int32_t data_type, char *leaf_alphabet, char *ancestral_alphabet);
+/* Eigen::eigenQREV (src/utils/eigen.cpp:48-128) for a row-major n x n reversible rate matrix:
+ * Q = U diag(root) V.  Exposed for the tests.                                                     */
+int  pagan_eigen_qrev(const double *Q, const double *pi, int32_t n, double *root, double *U, double *V);
 
 #ifdef __cplusplus
 }

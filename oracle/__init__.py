@@ -19,7 +19,7 @@ DNA_ALPHABET = "ACGTRYMKWSBDHVN"      # Model_factory::dna_full_char_alphabet, m
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_dp.cpp", "oracle_host.cpp", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_dp.cpp", "oracle_host.cpp", "oracle_model.cpp", "wag_data.h", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "pagan_dp.h"))
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
@@ -66,6 +66,13 @@ def lib():
         L.oracle_define_tunnel.restype = C.c_int
         L.oracle_dna_parsimony.argtypes = [i32p]
         L.oracle_dna_parsimony.restype = None
+        L.oracle_dna_model.argtypes = [f32p, C.c_double, C.c_int, f32p, f32p]
+        L.oracle_dna_model.restype = C.c_int
+        L.oracle_protein_model.argtypes = [C.c_double, f32p, f32p, i32p]
+        L.oracle_protein_model.restype = C.c_int
+        f64p = C.POINTER(C.c_double)
+        L.oracle_eigen_qrev.argtypes = [f64p, f64p, C.c_int, f64p, f64p, f64p]
+        L.oracle_eigen_qrev.restype = C.c_int
         _lib = L
     return _lib
 
@@ -164,6 +171,46 @@ def dna_parsimony():
     t = np.zeros(225, np.int32)
     lib().oracle_dna_parsimony(_ip(t))
     return t
+
+
+PROTEIN_ALPHABET = "ARNDCQEGHILKMFPSTWYV"      # Model_factory::protein_char_alphabet, model_factory.cpp:104
+
+
+def protein_leaf_alphabet():
+    """Model_factory::get_protein_full_char_alphabet (model_factory.h:144-155): 20 residues, X, then the 190
+    pair codes written as the lower-case first residue."""
+    a = PROTEIN_ALPHABET
+    return a + "X" + "".join(a[i].lower() for i in range(19) for _ in range(i + 1, 20))
+
+
+def dna_model(base_freq, dist, pileup=False):
+    """(abi.Model, params) of Model_factory::dna_model + alignment_model, restated in oracle_model.cpp."""
+    bf = np.ascontiguousarray(base_freq, np.float32)
+    table = np.zeros(225, np.float32)
+    params = np.zeros(4, np.float32)
+    lib().oracle_dna_model(_fp(bf), float(dist), 1 if pileup else 0, _fp(table), _fp(params))
+    return abi.Model(table.reshape(15, 15).T, *params)
+
+
+def protein_model(dist):
+    """(abi.Model, parsimony[211*211]) of Model_factory::protein_model (WAG) + alignment_model."""
+    table = np.zeros(211 * 211, np.float32)
+    params = np.zeros(4, np.float32)
+    pars = np.zeros(211 * 211, np.int32)
+    lib().oracle_protein_model(float(dist), _fp(table), _fp(params), _ip(pars))
+    return abi.Model(table.reshape(211, 211).T, *params), pars
+
+
+def eigen_qrev(Q, pi):
+    """Eigen::eigenQREV restated: (root, U, V) with Q = U diag(root) V."""
+    Q = np.ascontiguousarray(Q, np.float64)
+    pi = np.ascontiguousarray(pi, np.float64)
+    n = pi.shape[0]
+    root, U, V = np.zeros(n), np.zeros((n, n)), np.zeros((n, n))
+    dp = C.POINTER(C.c_double)
+    lib().oracle_eigen_qrev(Q.ctypes.data_as(dp), pi.ctypes.data_as(dp), n, root.ctypes.data_as(dp),
+                            U.ctypes.data_as(dp), V.ctypes.data_as(dp))
+    return root, U, V
 
 
 def define_tunnel(left, right, min_length=30, trim=5, width=15, alphabet=DNA_ALPHABET):

@@ -1,0 +1,445 @@
+// oracle_model.cpp -- TEST INFRASTRUCTURE ONLY (see oracle_dp.cpp header; PARITY UNPINNED).
+//
+// CPU restatement of the scoring-model producer, function by function:
+//
+//   pi_sqrt / qrev()        <- Eigen::getpi_sqrt, Eigen::eigenQREV          src/utils/eigen.cpp:39-128
+//   real_sym()              <- Eigen::eigenRealSym                          eigen.cpp:135-149
+//   sort_roots()            <- Eigen::EigenSort                             eigen.cpp:152-174
+//   householder()           <- Eigen::HouseholderRealSym                    eigen.cpp:177-245
+//   tridiag_ql()            <- Eigen::EigenTridagQLImplicit                 eigen.cpp:249-318
+//   p_matrix()              <- Eigen::computePMatrix                        eigen.cpp:330-358
+//   Factory::dna()          <- Model_factory::dna_model                     src/utils/model_factory.cpp:1344-1474
+//   Factory::protein()      <- Model_factory::define_protein_alphabet       model_factory.cpp:304-632
+//                              Model_factory::protein_model                 model_factory.cpp:1502-1595
+//   Factory::alignment()    <- Model_factory::alignment_model               model_factory.cpp:1871-2230
+//
+// The product's producer (pagan2-msa_amd/csrc/host_model.cpp) is written differently (one
+// solver object, dense index maps for the pi == 0 case); tests compare the two bit for bit and
+// both against numpy/scipy (expm) within a tolerance.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "wag_data.h"
+
+namespace {
+
+// ---- eigen.cpp ------------------------------------------------------------------------------------
+// row-major element (r, c) of an n x n matrix held in a flat array
+inline double &el(double *m, int n, int r, int c) { return m[r * n + c]; }
+void householder(double a[], int n, double d[], double e[]) {
+    int m, k, j, i;
+    double scale, hh, h, g, f;
+    for (i = n - 1; i >= 1; i--) {
+        m = i - 1;
+        h = scale = 0;
+        if (m > 0) {
+            for (k = 0; k <= m; k++) scale += fabs(el(a, n, i, k));
+            if (scale == 0) e[i] = el(a, n, i, m);
+            else {
+                for (k = 0; k <= m; k++) { el(a, n, i, k) /= scale; h += el(a, n, i, k) * el(a, n, i, k); }
+                f = el(a, n, i, m);
+                g = (f >= 0 ? -sqrt(h) : sqrt(h));
+                e[i] = scale * g;
+                h -= f * g;
+                el(a, n, i, m) = f - g;
+                f = 0;
+                for (j = 0; j <= m; j++) {
+                    el(a, n, j, i) = el(a, n, i, j) / h;
+                    g = 0;
+                    for (k = 0; k <= j; k++) g += el(a, n, j, k) * el(a, n, i, k);
+                    for (k = j + 1; k <= m; k++) g += el(a, n, k, j) * el(a, n, i, k);
+                    e[j] = g / h;
+                    f += e[j] * el(a, n, i, j);
+                }
+                hh = f / (h * 2);
+                for (j = 0; j <= m; j++) {
+                    f = el(a, n, i, j);
+                    e[j] = g = e[j] - hh * f;
+                    for (k = 0; k <= j; k++) el(a, n, j, k) -= (f * e[k] + g * el(a, n, i, k));
+                }
+            }
+        } else
+            e[i] = el(a, n, i, m);
+        d[i] = h;
+    }
+    d[0] = e[0] = 0;
+    for (i = 0; i < n; i++) {
+        m = i - 1;
+        if (d[i]) {
+            for (j = 0; j <= m; j++) {
+                g = 0;
+                for (k = 0; k <= m; k++) g += el(a, n, i, k) * el(a, n, k, j);
+                for (k = 0; k <= m; k++) el(a, n, k, j) -= g * el(a, n, k, i);
+            }
+        }
+        d[i] = el(a, n, i, i);
+        el(a, n, i, i) = 1;
+        for (j = 0; j <= m; j++) el(a, n, j, i) = el(a, n, i, j) = 0;
+    }
+}
+
+inline double sign_of(double a, double b) { return b >= 0.0 ? fabs(a) : -fabs(a); }
+
+int tridiag_ql(double d[], double e[], int n, double z[]) {
+    int m, j, iter, niter = 30, status = 0, i, k;
+    double s, r, p, g, f, dd, c, b, aa, bb;
+    for (i = 1; i < n; i++) e[i - 1] = e[i];
+    e[n - 1] = 0;
+    for (j = 0; j < n; j++) {
+        iter = 0;
+        do {
+            for (m = j; m < n - 1; m++) {
+                dd = fabs(d[m]) + fabs(d[m + 1]);
+                if (fabs(e[m]) + dd == dd) break;
+            }
+            if (m != j) {
+                if (iter++ == niter) { status = -1; break; }
+                g = (d[j + 1] - d[j]) / (2 * e[j]);
+                if ((aa = fabs(g)) > 1) r = aa * sqrt(1 + 1 / (g * g));
+                else r = sqrt(1 + g * g);
+                g = d[m] - d[j] + e[j] / (g + sign_of(r, g));
+                s = c = 1;
+                p = 0;
+                for (i = m - 1; i >= j; i--) {
+                    f = s * e[i];
+                    b = c * e[i];
+                    aa = fabs(f); bb = fabs(g);
+                    if (aa > bb) { bb /= aa; r = aa * sqrt(1 + bb * bb); }
+                    else if (bb == 0) r = 0;
+                    else { aa /= bb; r = bb * sqrt(1 + aa * aa); }
+                    e[i + 1] = r;
+                    if (r == 0) { d[i + 1] -= p; e[m] = 0; break; }
+                    s = f / r;
+                    c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2 * c * b;
+                    d[i + 1] = g + (p = s * r);
+                    g = c * r - b;
+                    for (k = 0; k < n; k++) {
+                        f = el(z, n, k, i + 1);
+                        el(z, n, k, i + 1) = s * el(z, n, k, i) + c * f;
+                        el(z, n, k, i) = c * el(z, n, k, i) - s * f;
+                    }
+                }
+                if (r == 0 && i >= j) continue;
+                d[j] -= p; e[j] = g; e[m] = 0;
+            }
+        } while (m != j);
+    }
+    return status;
+}
+
+void sort_roots(double d[], double U[], int n) {
+    int k, j, i;
+    double p;
+    for (i = 0; i < n - 1; i++) {
+        p = d[k = i];
+        for (j = i + 1; j < n; j++) if (d[j] >= p) p = d[k = j];
+        if (k != i) {
+            d[k] = d[i]; d[i] = p;
+            for (j = 0; j < n; j++) { p = el(U, n, j, i); el(U, n, j, i) = el(U, n, j, k); el(U, n, j, k) = p; }
+        }
+    }
+}
+
+int real_sym(double A[], int n, double Root[], double work[]) {
+    householder(A, n, Root, work);
+    int status = tridiag_ql(Root, work, n, A);
+    sort_roots(Root, A, n);
+    return status;
+}
+
+int qrev(double Q[], double pi[], int n, double Root[], double U[], double V[]) {
+    std::vector<double> pi_sqrt(n);
+    int npi0 = 0, j, i, inew, jnew;
+    for (j = 0, npi0 = 0; j < n; j++) if (pi[j]) pi_sqrt[npi0++] = sqrt(pi[j]);
+    npi0 = n - npi0;
+    int nnew = n - npi0, status;
+    if (npi0 == 0) {
+        for (i = 0; i < n; i++)
+            for (j = 0, el(U, n, i, i) = el(Q, n, i, i); j < i; j++)
+                el(U, n, i, j) = el(U, n, j, i) = (el(Q, n, i, j) * pi_sqrt[i] / pi_sqrt[j]);
+        status = real_sym(U, n, Root, V);
+        for (i = 0; i < n; i++) for (j = 0; j < n; j++) el(V, n, i, j) = el(U, n, j, i) * pi_sqrt[j];
+        for (i = 0; i < n; i++) for (j = 0; j < n; j++) el(U, n, i, j) /= pi_sqrt[i];
+    } else {
+        for (i = 0, inew = 0; i < n; i++) {
+            if (pi[i]) {
+                for (j = 0, jnew = 0; j < i; j++)
+                    if (pi[j]) {
+                        el(U, nnew, inew, jnew) = el(U, nnew, jnew, inew) = el(Q, n, i, j) * pi_sqrt[inew] / pi_sqrt[jnew];
+                        jnew++;
+                    }
+                el(U, nnew, inew, inew) = el(Q, n, i, i);
+                inew++;
+            }
+        }
+        status = real_sym(U, nnew, Root, V);
+        for (i = n - 1, inew = nnew - 1; i >= 0; i--) Root[i] = (pi[i] ? Root[inew--] : 0);
+        for (i = n - 1, inew = nnew - 1; i >= 0; i--) {
+            if (pi[i]) {
+                for (j = n - 1, jnew = nnew - 1; j >= 0; j--)
+                    if (pi[j]) { el(V, n, i, j) = el(U, nnew, jnew, inew) * pi_sqrt[jnew]; jnew--; }
+                    else el(V, n, i, j) = (i == j);
+                inew--;
+            } else
+                for (j = 0; j < n; j++) el(V, n, i, j) = (i == j);
+        }
+        for (i = n - 1, inew = nnew - 1; i >= 0; i--) {
+            if (pi[i]) {
+                for (j = n - 1, jnew = nnew - 1; j >= 0; j--)
+                    if (pi[j]) { el(U, n, i, j) = el(U, nnew, inew, jnew) / pi_sqrt[inew]; jnew--; }
+                    else el(U, n, i, j) = (i == j);
+                inew--;
+            } else
+                for (j = 0; j < n; j++) el(U, n, i, j) = (i == j);
+        }
+    }
+    Root[0] = 0;
+    return status;
+}
+
+void p_matrix(int n, double *pMat, double *U, double *V, double *Root, double time) {
+    double *P = pMat;
+    for (int i = 0; i < n * n; i++) *(P++) = 0;
+    double *pdV, *pdU, e1, e2;
+    for (int k = 0; k < n; k++) {
+        P = pMat;
+        pdU = &U[k];
+        e1 = exp(time * Root[k]);
+        for (int i = 0; i < n; i++) {
+            e2 = *pdU * e1;
+            pdV = &V[k * n];
+            pdU += n;
+            for (int j = 0; j < n; j++) *P++ += (e2 * *(pdV++));
+        }
+    }
+}
+
+// ---- model_factory.cpp ----------------------------------------------------------------------------
+struct Symbol { int index, n_units, first_residue, second_residue; std::string residues; };
+
+struct Factory {
+    int char_as = 0, char_fas = 0;
+    bool is_protein = false;
+    std::vector<double> charPi, charU, charV, charRoot;       // [i*char_as + j]
+    std::vector<int> parsimony;                               // g(i,j) = [i + j*char_fas]
+    std::vector<Symbol> symbols;
+    float ins_rate, del_rate, ext_prob, end_ext_prob;
+
+    void build(std::vector<double> &q) {                      // Model_factory::build_model, :1809-1866
+        charU.assign(char_as * char_as, 0); charV.assign(char_as * char_as, 0); charRoot.assign(char_as, 0);
+        std::vector<double> tpi(charPi.begin(), charPi.begin() + char_as);
+        qrev(q.data(), tpi.data(), char_as, charRoot.data(), charU.data(), charV.data());
+    }
+
+    void dna(const float *pi, float kappa, float rho) {       // :1344-1458 + define_dna_alphabet :118-227
+        is_protein = false; char_as = 4; char_fas = 15;
+        ins_rate = 0.01f; del_rate = 0.01f; ext_prob = 0.8f; end_ext_prob = 0.95f;
+        charPi.assign(15, 0);
+        for (int i = 0; i < 4; i++) charPi[i] = pi[i];
+        float ka = kappa / 2.0;
+        float piR = pi[0] + pi[2];
+        float piY = pi[1] + pi[3];
+        float beta = 1 / (2 * piR * piY * (1 + ka));
+        float alfaY = (piR * piY * ka - pi[0] * pi[2] - pi[1] * pi[3]) /
+                      ((2 + 2 * ka) * (piY * pi[0] * pi[2] * rho + piR * pi[1] * pi[3]));
+        float alfaR = rho * alfaY;
+        std::vector<double> Q(16, 0.0);
+        auto s = [&](double v, int i, int j) { Q[i * 4 + j] = v; };
+        auto g = [&](int i, int j) { return Q[i * 4 + j]; };
+        double t;
+        /*AC*/ t = beta * pi[1]; s(t, 0, 1);
+        /*AG*/ t = alfaR * pi[2] / piR + beta * pi[2]; s(t, 0, 2);
+        /*AT*/ t = beta * pi[3]; s(t, 0, 3);
+        /*AA*/ s(0 - g(0, 1) - g(0, 2) - g(0, 3), 0, 0);
+        /*CA*/ t = beta * pi[0]; s(t, 1, 0);
+        /*CG*/ t = beta * pi[2]; s(t, 1, 2);
+        /*CT*/ t = alfaY * pi[3] / piY + beta * pi[3]; s(t, 1, 3);
+        /*CC*/ s(0 - g(1, 0) - g(1, 2) - g(1, 3), 1, 1);
+        /*GA*/ t = alfaR * pi[0] / piR + beta * pi[0]; s(t, 2, 0);
+        /*GC*/ t = beta * pi[1]; s(t, 2, 1);
+        /*GT*/ t = beta * pi[3]; s(t, 2, 3);
+        /*GG*/ s(0 - g(2, 0) - g(2, 1) - g(2, 3), 2, 2);
+        /*TA*/ t = beta * pi[0]; s(t, 3, 0);
+        /*TC*/ t = alfaY * pi[1] / piY + beta * pi[1]; s(t, 3, 1);
+        /*TG*/ t = beta * pi[2]; s(t, 3, 2);
+        /*TT*/ s(0 - g(3, 0) - g(3, 1) - g(3, 2), 3, 3);
+        build(Q);
+        symbols.clear();
+        const int n_residues[] = {1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 4};
+        const char *ambiguity[] = {"A", "C", "G", "T", "AG", "CT", "AC", "GT", "AT", "CG", "CGT", "AGT", "ACT", "ACG", "ACGT"};
+        for (int i = 0; i < 15; i++) symbols.push_back({i, n_residues[i], -1, -1, ambiguity[i]});
+    }
+
+    void protein() {
+        is_protein = true; char_as = 20;
+        ins_rate = 0.05f; del_rate = 0.05f; ext_prob = 0.5f; end_ext_prob = 0.75f;
+        const std::string alphabet = "ARNDCQEGHILKMFPSTWYV";
+        symbols.clear();
+        int count = 0;
+        for (int i = 0; i < char_as; i++) { symbols.push_back({i, 1, i, -1, std::string(1, alphabet[i])}); count++; }
+        symbols.push_back({count, 20, count, -1, alphabet});
+        count++;
+        for (int i = 0; i < char_as - 1; i++)
+            for (int j = i + 1; j < char_as; j++) {
+                symbols.push_back({count, 2, i, j, std::string(1, alphabet[i]) + alphabet[j]});
+                count++;
+            }
+        char_fas = (int)symbols.size();
+        const double *tmp_pi = oracle_wag::kWagPi, *tmp_q = oracle_wag::kWagQ;
+        auto cQ = [&](int j, int i) { return tmp_q[j * char_as + i]; };
+        parsimony.assign(char_fas * char_fas, 0);
+        auto set = [&](int v, int i, int j) { parsimony[i + j * char_fas] = v; };
+        for (int i = 0; i < char_fas; i++) {
+            for (int j = 0; j < char_fas; j++) {
+                if (i == j) { set(i, i, j); continue; }
+                Symbol *letter1 = &symbols.at(i), *letter2 = &symbols.at(j);
+                if (letter1->index == char_as) set(j, i, j);
+                else if (letter2->index == char_as) set(i, i, j);
+                else if (letter1->n_units == 1 && letter2->n_units == 1) {
+                    for (int k = char_as; k < char_fas; k++) {
+                        Symbol *x = &symbols.at(k);
+                        if ((x->first_residue == letter1->first_residue && x->second_residue == letter2->first_residue) ||
+                            (x->first_residue == letter2->first_residue && x->second_residue == letter1->first_residue))
+                            set(k, i, j);
+                    }
+                } else if (letter1->n_units == 1 && letter2->n_units == 2 &&
+                           (letter1->first_residue == letter2->first_residue || letter1->first_residue == letter2->second_residue))
+                    set(letter1->first_residue, i, j);
+                else if (letter2->n_units == 1 && letter1->n_units == 2 &&
+                         (letter2->first_residue == letter1->first_residue || letter2->first_residue == letter1->second_residue))
+                    set(letter2->first_residue, i, j);
+                else {
+                    float maxQ = -1; char maxl1 = 0; char maxl2 = 0;
+                    int m = letter1->first_residue, n = letter2->first_residue;
+                    if (cQ(m, n) > maxQ) { maxQ = cQ(m, n); maxl1 = letter1->first_residue; maxl2 = letter2->first_residue; }
+                    if (letter2->n_units == 2) {
+                        m = letter1->first_residue; n = letter2->second_residue;
+                        if (cQ(m, n) > maxQ) { maxQ = cQ(m, n); maxl1 = letter1->first_residue; maxl2 = letter2->second_residue; }
+                    }
+                    if (letter1->n_units == 2) {
+                        m = letter1->second_residue; n = letter2->first_residue;
+                        if (cQ(m, n) > maxQ) { maxQ = cQ(m, n); maxl1 = letter1->second_residue; maxl2 = letter2->first_residue; }
+                    }
+                    if (letter1->n_units == 2 && letter2->n_units == 2) {
+                        m = letter1->second_residue; n = letter2->second_residue;
+                        if (cQ(m, n) > maxQ) { maxQ = cQ(m, n); maxl1 = letter1->second_residue; maxl2 = letter2->second_residue; }
+                    }
+                    for (int k = 20; k < char_fas; k++) {
+                        Symbol *x = &symbols.at(k);
+                        if ((x->first_residue == maxl1 && x->second_residue == maxl2) ||
+                            (x->second_residue == maxl1 && x->first_residue == maxl2))
+                            set(k, i, j);
+                    }
+                }
+            }
+        }
+        charPi.assign(char_fas, 0);
+        for (int j = 0; j < char_as; j++) charPi[j] = tmp_pi[j];
+        std::vector<double> Q(tmp_q, tmp_q + 400);
+        build(Q);
+    }
+
+    // alignment_model: table[a + b*char_fas] as floats (Evol_model::log_score returns float), params[4]
+    void alignment(double distance, bool pileup, float *table, float *params) const {
+        const int as = char_as, fas = char_fas;
+        std::vector<double> tmr(as * as), twr(charRoot), twu(charU), twv(charV);
+        p_matrix(as, tmr.data(), twu.data(), twv.data(), twr.data(), distance);
+        float char_ins_rate = ins_rate, char_del_rate = del_rate;
+        float log_ext_prob = log(ext_prob);
+        if (pileup) { char_ins_rate = 0.25; char_del_rate = 0.25; }
+        double t = (1.0 - exp(-0.5 * (char_ins_rate + char_del_rate) * distance));
+        float log_id_prob = log(t);
+        float log_match_prob = log(1.0 - 2 * t);
+        float log_end_ext_prob = log(end_ext_prob);
+        params[0] = log_id_prob; params[1] = log_ext_prob; params[2] = log_end_ext_prob; params[3] = log_match_prob;
+        std::vector<double> charPr(fas * fas, 0.0), logCharPr(fas * fas, 0.0);
+        auto PR = [&](int i, int j) -> double & { return charPr[i + j * fas]; };
+        auto LPR = [&](int i, int j) -> double & { return logCharPr[i + j * fas]; };
+        for (int i = 0; i < as; i++)
+            for (int j = 0; j < as; j++) {
+                float sp = tmr[i * as + j];
+                float lo = 0.5 * (charPi[i] + charPi[j]) * sp / (charPi[i] * charPi[j]);
+                PR(i, j) = lo;
+                LPR(i, j) = std::log(lo);                          // `using namespace std`: log(float) is logf
+            }
+        if (!is_protein) {
+            std::vector<double> amb(4 * fas, 0.0);                // char_ambiguity(at, ai), ambiguity_factor 1
+            const std::string alpha = "ACGT";
+            for (unsigned ai = 0; ai < symbols.size(); ai++) {
+                const Symbol *a = &symbols.at(ai);
+                float probability = pow(1.0f, a->n_units);
+                for (int aj = 0; aj < a->n_units; aj++) amb[alpha.find(a->residues.at(aj)) + 4 * ai] = probability;
+            }
+            for (int i = 0; i < fas; i++)
+                for (int j = 0; j < fas; j++) {
+                    if (i < as && j < as) continue;
+                    double max = 0;
+                    for (int n = 0; n < as; n++)
+                        for (int m = 0; m < as; m++) {
+                            double tt = PR(n, m) * amb[m + 4 * j] * amb[n + 4 * i];
+                            if (max < tt) max = tt;
+                        }
+                    PR(i, j) = max;
+                    LPR(i, j) = log(max);
+                }
+        } else {
+            for (int i = 0; i < fas; i++)
+                for (int j = 0; j < fas; j++) {
+                    if (i < as && j < as) continue;
+                    double max = 0, tt;
+                    if (i == as) { for (int n = 0; n < as; n++) { double v = PR(n, j); if (max < v) max = v; } }
+                    else if (j == as) { for (int m = 0; m < as; m++) { double v = PR(i, m); if (max < v) max = v; } }
+                    else {
+                        const Symbol *l1 = &symbols.at(i), *l2 = &symbols.at(j);
+                        if (l1->n_units == 1 && l2->n_units == 2) {
+                            max = PR(l1->first_residue, l2->first_residue);
+                            tt = PR(l1->first_residue, l2->second_residue); if (max < tt) max = tt;
+                        } else if (l1->n_units == 2 && l2->n_units == 1) {
+                            max = PR(l1->first_residue, l2->first_residue);
+                            tt = PR(l1->second_residue, l2->first_residue); if (max < tt) max = tt;
+                        } else if (l1->n_units == 2 && l2->n_units == 2) {
+                            max = PR(l1->first_residue, l2->first_residue);
+                            tt = PR(l1->first_residue, l2->second_residue); if (max < tt) max = tt;
+                            tt = PR(l1->second_residue, l2->first_residue); if (max < tt) max = tt;
+                            tt = PR(l1->second_residue, l2->second_residue); if (max < tt) max = tt;
+                        }
+                    }
+                    PR(i, j) = max;
+                    LPR(i, j) = log(max);
+                }
+        }
+        for (int k = 0; k < fas * fas; k++) table[k] = (float)logCharPr[k];
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+int oracle_dna_model(const float bf[4], double distance, int pileup, float *table, float *params) {
+    Factory f;
+    f.dna(bf, 2.0f, 1.0f);
+    f.alignment(distance, pileup != 0, table, params);
+    return 0;
+}
+
+int oracle_protein_model(double distance, float *table, float *params, int32_t *parsimony) {
+    static Factory *f = nullptr;
+    if (!f) { f = new Factory(); f->protein(); }
+    f->alignment(distance, false, table, params);
+    if (parsimony) for (size_t k = 0; k < f->parsimony.size(); k++) parsimony[k] = f->parsimony[k];
+    return 0;
+}
+
+int oracle_eigen_qrev(const double *Q, const double *pi, int n, double *root, double *U, double *V) {
+    std::vector<double> q(Q, Q + n * n), p(pi, pi + n);
+    return qrev(q.data(), p.data(), n, root, U, V);
+}
+
+} // extern "C"

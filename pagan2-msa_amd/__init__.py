@@ -17,7 +17,8 @@ from . import abi
 from .abi import Band, Graph, Model, Result  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpagan_dp.so")
+# PAGAN_DP_LIB: a diagnostic build (tools/build_stamps.sh writes libpagan_dp_stats.so) instead of the product library
+LIB_PATH = os.environ.get("PAGAN_DP_LIB") or os.path.join(_HERE, "libpagan_dp.so")
 _lib = None
 
 

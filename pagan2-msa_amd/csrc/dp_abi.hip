@@ -527,8 +527,16 @@ void carve_outputs(Carver &c, const HostJob &hj, PgDevJob *d) {
     d->trace = c.take<int>(3 * (size_t)(hj.Lx + hj.Ly));
     d->ttab = c.take<int>(8 * (size_t)hj.tb.back());
     d->segs = c.take<int>(6 * (size_t)(2 * hj.n_bound + 8));
-    d->endcell = c.take<int>(8);
-    d->endscore = c.take<double>(1);
+}
+// max_end of every job of the batch in one block, 64 B per job (endcell[8] at +0, endscore at +32): one copy
+// brings all of them back (cfg5: 511 node alignments per walk)
+constexpr size_t kEndStride = 64;
+void carve_ends(Carver &c, int n, PgDevJob *dj) {
+    char *ends = c.take<char>(kEndStride * (size_t)n);
+    for (int k = 0; k < n; ++k) {
+        dj[k].endcell = reinterpret_cast<int *>(ends + kEndStride * (size_t)k);
+        dj[k].endscore = reinterpret_cast<double *>(ends + kEndStride * (size_t)k + 32);
+    }
 }
 
 // Host staging buffers are reused across batches: a level's upload is hundreds of MB, and fresh zeroed pages
@@ -655,15 +663,20 @@ int replay(const HostJob &hj, const int *endcell, double endscore, const int *tr
     std::memset(out, 0, sizeof(*out));
     out->cells = hj.dx.cells;
     out->score = endscore;
+    // nothing the device wrote is used as an index before it has been checked against the graphs
+    if (endcell[0] != 0 && endcell[0] != 1) {
+        if (std::getenv("PAGAN_DP_VERBOSE")) std::fprintf(stderr, "pagan_dp: device status %d\n", endcell[0]);
+        return PAGAN_E_INTERNAL;
+    }
+    const int degL = L->bwd_off[Lx + 1] - L->bwd_off[Lx], degR = R->bwd_off[Ly + 1] - R->bwd_off[Ly];
+    if (endcell[4] >= degL || endcell[5] >= degR) return PAGAN_E_INTERNAL;
     out->end_matrix = endcell[1]; out->end_x = endcell[2]; out->end_y = endcell[3];
     out->end_x_edge = endcell[4] >= 0 ? L->bwd_eid[L->bwd_off[Lx] + endcell[4]] : -1;
     out->end_y_edge = endcell[5] >= 0 ? R->bwd_eid[R->bwd_off[Ly] + endcell[5]] : -1;
     if (endcell[0] == 1) { out->status = PAGAN_DP_UNREACHABLE; return PAGAN_OK; }
-    if (endcell[0] != 0) {
-        if (std::getenv("PAGAN_DP_VERBOSE")) std::fprintf(stderr, "pagan_dp: device status %d\n", endcell[0]);
-        return PAGAN_E_INTERNAL;
-    }
     const int n = endcell[6];
+    if (out->end_matrix < PAGAN_X_MAT || out->end_matrix > PAGAN_M_MAT || out->end_x < 0 || out->end_x >= Lx ||
+        out->end_y < 0 || out->end_y >= Ly || n < 0 || n > Lx + Ly) return PAGAN_E_INTERNAL;
 
     std::vector<char> lused(L->n_edges, 0), rused(R->n_edges, 0);
     struct Step { int8_t matrix; int8_t real; };
@@ -690,7 +703,9 @@ int replay(const HostJob &hj, const int *endcell, double endscore, const int *tr
         const int ci = trace[3 * t], cj = trace[3 * t + 1];
         const unsigned w = (unsigned)trace[3 * t + 2];
         const int vit = (int)(w & 3u), k1 = (int)((w >> 4) & 16383u), k2 = (int)(w >> 18);
-        if (ci != i || cj != j) return PAGAN_E_INTERNAL;
+        if (ci != i || cj != j || i < 0 || j < 0) return PAGAN_E_INTERNAL;
+        if ((vit != PAGAN_Y_MAT && (i < 1 || k1 >= L->bwd_off[i + 1] - L->bwd_off[i])) ||
+            (vit != PAGAN_X_MAT && (j < 1 || k2 >= R->bwd_off[j + 1] - R->bwd_off[j]))) return PAGAN_E_INTERNAL;
         // the cell's `from` label is the matrix of the next visited cell; for the last one
         // it is never pushed (i<1 && j<1 after it), so any value does
         const int from = (t + 1 < n) ? (int)((unsigned)trace[3 * (t + 1) + 2] & 3u) : PAGAN_M_MAT;
@@ -913,6 +928,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     const size_t in_bytes = sizer.cur;
     b->out_begin = in_bytes;
     for (int k = 0; k < n; ++k) carve_outputs(sizer, b->jobs[k], &b->dj[k]);
+    carve_ends(sizer, n, b->dj.data());
     b->arena.size = sizer.cur;
     b->arena.dev = arena_pool.take(b->device, b->arena.size, &b->arena.cap);
     if (!b->arena.dev) {
@@ -1054,11 +1070,14 @@ int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
     // copies first (one device queue), then the path replays of the jobs side by side on the host
     struct Fetched { int endcell[8]; double endscore; std::vector<int> trace; };
     std::vector<Fetched> got(b->n);
+    std::vector<char> ends(kEndStride * (size_t)b->n);
+    if (b->n > 0) HIP_TRY(hipMemcpy(ends.data(), b->arena.dev + b->end_off[0], ends.size(), hipMemcpyDeviceToHost));
     for (int k = 0; k < b->n; ++k) {
         Fetched &f = got[k];
-        HIP_TRY(hipMemcpy(f.endcell, b->arena.dev + b->end_off[k], sizeof(f.endcell), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&f.endscore, b->arena.dev + b->score_off[k], sizeof(double), hipMemcpyDeviceToHost));
+        std::memcpy(f.endcell, ends.data() + kEndStride * (size_t)k, sizeof(f.endcell));
+        std::memcpy(&f.endscore, ends.data() + kEndStride * (size_t)k + 32, sizeof(double));
         const int nt = f.endcell[0] == 0 ? f.endcell[6] : 0;
+        if (nt < 0 || nt > b->jobs[k].Lx + b->jobs[k].Ly) return PAGAN_E_INTERNAL;
         f.trace.resize(3 * (size_t)nt + 3);
         if (nt > 0)
             HIP_TRY(hipMemcpy(f.trace.data(), b->arena.dev + b->trace_off[k], sizeof(int) * 3 * (size_t)nt, hipMemcpyDeviceToHost));
@@ -1112,7 +1131,8 @@ void pagan_batch_destroy(pagan_batch *b) {
 }
 
 int pagan_dp_align_batch(int32_t n, const pagan_job *jobs, const pagan_opts *opts, pagan_result *out) {
-    if (!out) return PAGAN_E_ARG;
+    if (!out || n < 0) return PAGAN_E_ARG;
+    for (int k = 0; k < n; ++k) std::memset(&out[k], 0, sizeof(pagan_result));
     pagan_batch *b = nullptr;
     const bool verbose = std::getenv("PAGAN_DP_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1125,6 +1145,7 @@ int pagan_dp_align_batch(int32_t n, const pagan_job *jobs, const pagan_opts *opt
     const double t2 = now();
     if (rc == PAGAN_OK) rc = pagan_batch_fetch(b, out);
     const double t3 = now();
+    if (rc != PAGAN_OK) for (int k = 0; k < n; ++k) pagan_result_free(&out[k]);   // a failed batch hands back nothing
     pagan_batch_destroy(b);
     if (verbose)
         std::fprintf(stderr, "pagan_dp: batch of %d: create %.1f ms, kernels %.1f ms, fetch+replay %.1f ms, destroy %.1f ms\n", n,

@@ -986,7 +986,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
         }
     }
 #ifdef PG_PIPE_STATS
-    if (lane == 0) {
+    if (lane == 0 && 3 * (Lx + Ly) >= 4096) {     // the counters borrow the tail of the trace buffer: long jobs only
         PG_GLOBAL int *o = (PG_GLOBAL int *)job->trace + 3 * (Lx + Ly) - 200 + 12 * wave;
         o[0] = st_n;
         for (int k = 0; k < 7; ++k) o[1 + k] = (int)(st_acc[k] >> 4);
@@ -999,7 +999,13 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) *(PG_GLOBAL int *)job->fill_status = flag_load(&PM.abort_flag);
+    // every wave reports an abort it sees when it leaves (the host staged 0): wave 0 may be done long before a
+    // later wave's wait runs into its spin limit, and after an abort every wait passes, so a wave that continued
+    // on unsynchronised operands still ends here with the flag set
+    if (lane == 0) {
+        const int aborted = flag_load(&PM.abort_flag);
+        if (aborted != 0) *(PG_GLOBAL int *)job->fill_status = aborted;
+    }
 }
 
 template __global__ void pg_fill_pipe<true>(const PgDevJob *, const int *, unsigned);

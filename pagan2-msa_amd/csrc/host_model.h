@@ -1,14 +1,17 @@
-// host_model.h -- per-alignment scoring model (the reference's Evol_model) for DNA.
+// host_model.h -- per-alignment scoring model (the reference's Evol_model) for DNA and protein.
 //
-// DnaModelFactory restates Model_factory::dna_model (src/utils/model_factory.cpp:1299-1474) and
-// Model_factory::alignment_model (model_factory.cpp:1871-2016): Q from base frequencies
-// (kappa 2, rho 1, float arithmetic as written there), P(t) = U exp(t Lambda) V, log-odds
-// table with the 15-letter ambiguity extension, and the indel parameters.  The symmetric
-// eigenproblem is solved with cyclic Jacobi rotations instead of the reference's PAML
-// Householder/QL routine (src/utils/eigen.cpp:132-330), so P(t) can differ from the
-// reference's in the last bits of a double; the table is an INPUT of the aligner ABI.
+// ModelFactory restates Model_factory::dna_model / protein_model
+// (src/utils/model_factory.cpp:1299-1474, 1478-1595), the alphabets and parsimony tables
+// (model_factory.cpp:118-227 DNA, 304-541 protein) and Model_factory::alignment_model
+// (model_factory.cpp:1871-2230): Q and pi, the time-reversible eigen solution
+// (Eigen::eigenQREV -> Householder tridiagonalisation -> implicit QL, src/utils/eigen.cpp:39-295,
+// same operation order, so U, V and the roots carry the same doubles), P(t) = U exp(t Lambda) V
+// (eigen.cpp:330-358), the log-odds table with its ambiguity extension, and the indel parameters.
+// The table is an INPUT of the aligner ABI (pagan_model); this is the producer the stand-alone
+// tree walk uses.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "../../include/pagan_dp.h"
@@ -28,18 +31,34 @@ struct EvolModel {
     }
 };
 
-struct DnaModelFactory {
-    static const char *full_alphabet() { return "ACGTRYMKWSBDHVN"; }   // model_factory.cpp:103
-    float ins_rate = 0.01f, del_rate = 0.01f, ext_prob = 0.8f, end_ext_prob = 0.95f;   // :1303-1306
-    double pi[4];
-    double U[16], V[16], root[4];
-    std::vector<int32_t> parsimony;      // 15x15, [i + j*15] (model_factory.cpp:147-227)
+enum DataType { kDna = 0, kProtein = 1 };                 // Model_factory::dna / ::protein
 
+struct ModelFactory {
+    int type = kDna;
+    int S = 15, char_as = 4;                              // char_fas, char_as
+    std::string leaf_alphabet;                            // Sequence::full_char_alphabet: state = find(residue)
+    std::string ancestral_alphabet;                       // Model_factory::ancestral_character_alphabet, one char per state
+    float ins_rate = 0.01f, del_rate = 0.01f, ext_prob = 0.8f, end_ext_prob = 0.95f;
+    std::vector<double> pi, U, V, root;
+    std::vector<int32_t> parsimony;                       // [i + j*S]
+    std::vector<int32_t> mostcommon;                      // [i + j*mc_dim] (--mostcommon)
+    int mc_dim = 0;
+    std::vector<int16_t> res1, res2;                      // protein: Char_symbol::first_residue / second_residue
+
+    static const char *dna_full_alphabet() { return "ACGTRYMKWSBDHVN"; }          // model_factory.cpp:103
+    static const char *protein_alphabet() { return "ARNDCQEGHILKMFPSTWYV"; }      // model_factory.cpp:104
+    // Fasta_reader::check_sequence_data_type, fasta_reader.cpp:1303-1336
+    static int guess_type(const std::vector<std::string> &raw_upper);
     // Empirical base frequencies the way Fasta_reader::check_alphabet counts them
     // (src/utils/fasta_reader.cpp:1196-1255): float counters over all input sequences.
     static void base_frequencies(const std::vector<std::string> &seqs, float out[4]);
-    void init(const float base_freq[4], float kappa = 2.0f, float rho = 1.0f);
-    EvolModel alignment_model(double distance) const;
+    void init_dna(const float base_freq[4], float kappa = 2.0f, float rho = 1.0f);
+    void init_protein();
+    // ins = del = 0.25 for --454/--homopolymer with --pileup-alignment (model_factory.cpp:1901-1905)
+    EvolModel alignment_model(double distance, bool pileup_rates = false) const;
 };
+
+// Eigen::eigenQREV (eigen.cpp:48-128) on a row-major n x n rate matrix; exposed for the tests.
+int eigen_qrev(const double *Q, const double *pi, int n, double *root, double *U, double *V);
 
 } // namespace pagan

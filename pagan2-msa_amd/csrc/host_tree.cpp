@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -118,7 +119,9 @@ struct NodeWork {                // everything one internal node's alignment con
     pagan_band pb;
     bool banded = false;
     pagan_result res;
-    bool has_res = false;
+    bool has_res = false;        // res is valid (aligned here, or imported from the rank that aligned it)
+    bool has_job = false;        // gl/gr/pm/pb are valid: this process prepared and aligned the node
+    int  device = -1;            // device the alignment ran on (-1: another rank)
 };
 
 } // namespace
@@ -132,18 +135,27 @@ struct pagan_msa {
     std::vector<int> tree_of_id;         // public id -> tree index
     std::vector<std::unique_ptr<pagan_hgraph>> graph;    // by public node id
     std::vector<NodeWork> work;          // by internal order k (public id = n_leaves + k)
-    DnaModelFactory mf;
+    ModelFactory mf;
     pagan_msa_timing tm;
     bool aligned = false;
     int n_leaves = 0;
     std::vector<std::string> rows;
+    // walk state (pagan_msa_ready / align_nodes / import_result)
+    std::vector<char> done;              // by public node id
+    int remaining = 0, rounds = 0;
+    std::map<double, std::shared_ptr<EvolModel>> model_cache;    // one table per distinct distance
+    std::mutex mu;                       // model cache, timing sums
+    pagan_batch_fn backend = nullptr;    // test seam (pagan_msa_set_batch_backend); null = pagan_dp_align_batch
+    void *backend_user = nullptr;
     ~pagan_msa() { for (auto &w : work) if (w.has_res) pagan_result_free(&w.res); }
 };
 
 namespace {
 
-int device_budget(const pagan_msa_opts &o, int dev, int64_t *bytes) {
+int device_budget(const pagan_msa *m, int dev, int64_t *bytes) {
+    const pagan_msa_opts &o = m->opts;
     if (o.device_mem_budget > 0) { *bytes = o.device_mem_budget; return PAGAN_OK; }
+    if (m->backend) { *bytes = (int64_t)1 << 40; return PAGAN_OK; }
     if (hipSetDevice(dev) != hipSuccess) return PAGAN_E_NODEVICE;
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return PAGAN_E_NODEVICE;
@@ -155,7 +167,7 @@ int device_budget(const pagan_msa_opts &o, int dev, int64_t *bytes) {
 // fit the memory budget.
 int align_on_device(pagan_msa *m, const std::vector<int> &ks, int dev, double *fill_ms, double *trace_ms) {
     int64_t budget = 0;
-    int rc = device_budget(m->opts, dev, &budget);
+    int rc = device_budget(m, dev, &budget);
     if (rc != PAGAN_OK) return rc;
     pagan_opts po;
     po.flags = m->opts.dp_flags; po.device = dev;
@@ -175,9 +187,10 @@ int align_on_device(pagan_msa *m, const std::vector<int> &ks, int dev, double *f
             jobs.push_back(jb); which.push_back(ks[at]); ++at;
         }
         std::vector<pagan_result> res(jobs.size());
-        rc = pagan_dp_align_batch((int32_t)jobs.size(), jobs.data(), &po, res.data());
+        rc = m->backend ? m->backend((int32_t)jobs.size(), jobs.data(), &po, res.data(), m->backend_user)
+                        : pagan_dp_align_batch((int32_t)jobs.size(), jobs.data(), &po, res.data());
+        if (rc != PAGAN_OK) return rc;            // nothing in res[] is valid then (the library released it)
         for (size_t k = 0; k < jobs.size(); ++k) { m->work[which[k]].res = res[k]; m->work[which[k]].has_res = true; }
-        if (rc != PAGAN_OK) return rc;
         if (!res.empty()) { *fill_ms += res[0].fill_ms; *trace_ms += res[0].trace_ms; }
     }
     return PAGAN_OK;
@@ -259,12 +272,24 @@ int pagan_msa_create(int32_t n_seqs, const char *const *names, const char *const
         for (int t = 0; t < nt; ++t) pool.emplace_back([&] { for (int k = next++; k < n_seqs; k = next++) f(k); });
         for (auto &th : pool) th.join();
     };
+    // fasta_reader.cpp:138-160: upper case, no gaps, no line ends
     over_leaves([&](int k) {
         std::string s;
-        for (const char *p = seqs[k]; *p; ++p) {             // fasta_reader.cpp:138-160,1206: upper case, U->T,
-            char c = (char)std::toupper((unsigned char)*p);  // drop what is outside the DNA alphabet
-            if (c == 'U') c = 'T';
-            if (std::strchr(DnaModelFactory::full_alphabet(), c)) s.push_back(c);
+        for (const char *p = seqs[k]; *p; ++p) {
+            const char c = (char)std::toupper((unsigned char)*p);
+            if (c != '-' && c != '\r' && c != '\n') s.push_back(c);
+        }
+        m->seqs[k].swap(s);
+    });
+    int type = m->opts.data_type == 1 ? kDna : m->opts.data_type == 2 ? kProtein : ModelFactory::guess_type(m->seqs);
+    // Fasta_reader::check_alphabet, fasta_reader.cpp:1180-1297: DNA U->T; protein U->X; what is outside the
+    // full alphabet is dropped
+    over_leaves([&](int k) {
+        std::string s;
+        const char *keep = type == kDna ? ModelFactory::dna_full_alphabet() : ModelFactory::protein_alphabet();
+        for (char c : m->seqs[k]) {
+            if (type == kDna) { if (c == 'U') c = 'T'; if (std::strchr(keep, c)) s.push_back(c); }
+            else { if (c == 'U') c = 'X'; if (c == 'X' || std::strchr(keep, c)) s.push_back(c); }
         }
         m->seqs[k].swap(s);
     });
@@ -294,142 +319,366 @@ int pagan_msa_create(int32_t n_seqs, const char *const *names, const char *const
         m->id_of_tree[t] = id; m->tree_of_id[id] = (int)t;
     }
     m->graph.resize(m->tree.size());
-    float bf[4];
-    DnaModelFactory::base_frequencies(m->seqs, bf);
-    m->mf.init(bf);
-    const std::string alpha = DnaModelFactory::full_alphabet();
+    if (type == kDna) {
+        float bf[4];
+        ModelFactory::base_frequencies(m->seqs, bf);
+        m->mf.init_dna(bf);
+    } else {
+        m->mf.init_protein();
+    }
     over_leaves([&](int k) {
         m->graph[k].reset(new pagan_hgraph());
-        m->graph[k]->g = make_leaf(m->seqs[k], alpha, m->opts.leaf_flags);
+        m->graph[k]->g = make_leaf(m->seqs[k], m->mf.leaf_alphabet, m->opts.leaf_flags);
     });
     m->work.resize(n_seqs - 1);
+    m->done.assign(2 * n_seqs - 1, 0);
+    for (int k = 0; k < n_seqs; ++k) m->done[k] = 1;
+    m->remaining = n_seqs - 1;
     std::memset(&m->tm, 0, sizeof(m->tm));
     *out = m.release();
     return PAGAN_OK;
 }
 
-int pagan_msa_align(pagan_msa *m) {
-    if (!m || m->aligned) return PAGAN_E_ARG;
-    const double t_start = now_s();
-    const int n = m->n_leaves;
+} // extern "C"
+
+namespace {
+
+int host_threads_of(const pagan_msa *m) {
     int threads = m->opts.host_threads > 0 ? m->opts.host_threads : (int)std::thread::hardware_concurrency();
-    if (threads < 1) threads = 1;
-    int ndev = m->opts.n_devices;
-    if (ndev <= 0) ndev = 1;
-    int first_dev = m->opts.first_device;
-    if (m->opts.n_devices <= 0) { if (hipGetDevice(&first_dev) != hipSuccess) return PAGAN_E_NODEVICE; }
-    const std::string alpha = DnaModelFactory::full_alphabet();
+    return threads < 1 ? 1 : threads;
+}
+
+bool node_ready(const pagan_msa *m, int id) {
+    if (m->done[id]) return false;
+    const TreeNode &t = m->tree[m->tree_of_id[id]];
+    return m->done[m->id_of_tree[t.left]] && m->done[m->id_of_tree[t.right]];
+}
+
+// What align_sequences_this_node does before the aligner is called (node.cpp:70-152): the model for
+// dist = d_left + d_right (serialised in the reference too: omp critical, node.cpp:415-416), the
+// child graphs' views, anchors -> tunnel.
+void prepare_node(pagan_msa *m, int id, int round) {
+    const int n = m->n_leaves;
+    NodeWork &w = m->work[id - n];
+    const TreeNode &t = m->tree[m->tree_of_id[id]];
+    const double dist = m->tree[t.left].dist + m->tree[t.right].dist;         // node.cpp:70
+    const bool pileup_rates = m->opts.pileup_rates != 0;
+    {
+        std::lock_guard<std::mutex> g(m->mu);
+        auto it = m->model_cache.find(dist);
+        if (it == m->model_cache.end())
+            it = m->model_cache.emplace(dist, std::make_shared<EvolModel>(m->mf.alignment_model(dist, pileup_rates))).first;
+        w.model = it->second;
+    }
+    w.node = id; w.level = round;
+    const SeqGraph &gl = m->graph[m->id_of_tree[t.left]]->g, &gr = m->graph[m->id_of_tree[t.right]]->g;
+    w.gl = gl.view(); w.gr = gr.view(); w.pm = w.model->view();
+    w.banded = false;
+    if (m->opts.use_anchors) {
+        AnchorSettings as;
+        as.offset = m->opts.anchors_offset; as.prefix_hit_length = m->opts.prefix_hit_length; as.hit_trim = m->opts.hit_trim;
+        const std::string &alpha = m->mf.ancestral_alphabet;
+        w.n_hits = define_tunnel(sequence_string(gl, false, alpha), sequence_string(gr, false, alpha),
+                                 sequence_string(gl, true, alpha), sequence_string(gr, true, alpha), as,
+                                 &w.upper, &w.lower);
+        w.pb.n = (int32_t)w.upper.size(); w.pb.upper = w.upper.data(); w.pb.lower = w.lower.data();
+        w.banded = true;
+    }
+    w.has_job = true;
+}
+
+// add_ancestral_sequence(va.get_simple_sequence()) (node.cpp:166): the parent graph from the path.
+int build_parent(pagan_msa *m, int id) {
+    NodeWork &w = m->work[id - m->n_leaves];
+    if (!w.has_res || w.res.status != PAGAN_DP_REACHED) return PAGAN_E_INTERNAL;
     BuildSettings bs;
     if (m->opts.keep_all_edges) bs.reads_mode();
     if (m->opts.dp_flags & PAGAN_OPT_NO_REDUCED_TERMINAL_PEN) bs.reduced_terminal = false;
-    AnchorSettings as;
-    as.offset = m->opts.anchors_offset; as.prefix_hit_length = m->opts.prefix_hit_length; as.hit_trim = m->opts.hit_trim;
-    std::map<double, std::shared_ptr<EvolModel>> model_cache;    // one table per distinct distance
-    std::vector<char> done(2 * n - 1, 0);
-    for (int k = 0; k < n; ++k) done[k] = 1;
-    int remaining = n - 1, level = 0;
-    while (remaining > 0) {
-        // build_queues, node.cpp:273-285
-        std::vector<int> ready;
-        for (int id = n; id < 2 * n - 1; ++id) {
-            if (done[id]) continue;
-            const TreeNode &t = m->tree[m->tree_of_id[id]];
-            if (done[m->id_of_tree[t.left]] && done[m->id_of_tree[t.right]]) ready.push_back(id);
-        }
-        if (ready.empty()) return PAGAN_E_INTERNAL;
-        // models (serialised in the reference too: omp critical, node.cpp:415-416)
-        double t0 = now_s();
-        for (int id : ready) {
-            NodeWork &w = m->work[id - n];
-            const TreeNode &t = m->tree[m->tree_of_id[id]];
-            const double dist = m->tree[t.left].dist + m->tree[t.right].dist;         // node.cpp:70
-            auto it = model_cache.find(dist);
-            if (it == model_cache.end())
-                it = model_cache.emplace(dist, std::make_shared<EvolModel>(m->mf.alignment_model(dist))).first;
-            w.model = it->second; w.node = id; w.level = level;
-        }
-        m->tm.model_s += now_s() - t0;
-        // anchors -> band, per node in parallel
-        t0 = now_s();
-        parallel_for((int)ready.size(), threads, [&](int r) {
-            const int id = ready[r];
-            NodeWork &w = m->work[id - n];
-            const TreeNode &t = m->tree[m->tree_of_id[id]];
-            const SeqGraph &gl = m->graph[m->id_of_tree[t.left]]->g, &gr = m->graph[m->id_of_tree[t.right]]->g;
-            w.gl = gl.view(); w.gr = gr.view(); w.pm = w.model->view();
-            w.banded = false;
-            if (m->opts.use_anchors) {
-                w.n_hits = define_tunnel(sequence_string(gl, false, alpha), sequence_string(gr, false, alpha),
-                                         sequence_string(gl, true, alpha), sequence_string(gr, true, alpha), as,
-                                         &w.upper, &w.lower);
-                w.pb.n = (int32_t)w.upper.size(); w.pb.upper = w.upper.data(); w.pb.lower = w.lower.data();
-                w.banded = true;
-            }
-        });
-        m->tm.anchors_s += now_s() - t0;
-        // DP on the device(s): ready nodes dealt round-robin, largest first, one thread per device
-        t0 = now_s();
-        std::vector<int> order(ready.size());
-        for (size_t r = 0; r < ready.size(); ++r) order[r] = ready[r] - n;
-        std::vector<int64_t> cost(m->work.size(), 0);
-        for (int k : order) {
-            NodeWork &w = m->work[k];
-            cost[k] = pagan_dp_count_cells(w.gl.n_sites, w.gr.n_sites, w.banded ? &w.pb : nullptr);
-            if (cost[k] < 0) return (int)cost[k];
-        }
-        std::vector<int64_t> oc(order.size());
-        for (size_t r = 0; r < order.size(); ++r) oc[r] = cost[order[r]];
-        std::vector<int32_t> owner(order.size());
-        pagan_assign_units((int32_t)order.size(), oc.data(), ndev, owner.data());
-        std::vector<std::vector<int>> per_dev(ndev);
-        for (size_t r = 0; r < order.size(); ++r) per_dev[owner[r]].push_back(order[r]);
-        for (auto &v : per_dev) std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-        std::vector<int> rcs(ndev, PAGAN_OK);
-        std::vector<double> fms(ndev, 0), tms(ndev, 0);
-        {
-            std::vector<std::thread> feeders;
-            for (int d = 0; d < ndev; ++d)
-                if (!per_dev[d].empty())
-                    feeders.emplace_back([&, d] { rcs[d] = align_on_device(m, per_dev[d], first_dev + d, &fms[d], &tms[d]); });
-            for (auto &th : feeders) th.join();
-        }
-        for (int d = 0; d < ndev; ++d) if (rcs[d] != PAGAN_OK) return rcs[d];
-        // "anchored alignment failed: trying again" (viterbi_alignment.cpp:298-317): a node whose
-        // end corner is unreachable inside its tunnel is re-aligned over the full matrix.
-        std::vector<int> retry;
-        for (int k : order)
-            if (m->work[k].banded && m->work[k].res.status == PAGAN_DP_UNREACHABLE) retry.push_back(k);
-        if (!retry.empty()) {
-            for (int k : retry) { m->work[k].banded = false; pagan_result_free(&m->work[k].res); m->work[k].has_res = false; }
-            double f = 0, t = 0;
-            const int rc = align_on_device(m, retry, first_dev, &f, &t);
-            if (rc != PAGAN_OK) return rc;
-            fms[0] += f; tms[0] += t;
-        }
-        m->tm.dp_wall_s += now_s() - t0;
-        m->tm.dp_fill_dev_s += *std::max_element(fms.begin(), fms.end()) / 1e3;
-        m->tm.dp_trace_dev_s += *std::max_element(tms.begin(), tms.end()) / 1e3;
-        // parents
-        t0 = now_s();
-        std::atomic<int> bad(0);
-        parallel_for((int)ready.size(), threads, [&](int r) {
-            const int id = ready[r];
-            NodeWork &w = m->work[id - n];
-            if (w.res.status != PAGAN_DP_REACHED) { bad = 1; return; }
-            const TreeNode &t = m->tree[m->tree_of_id[id]];
-            SeqGraph &gl = m->graph[m->id_of_tree[t.left]]->g, &gr = m->graph[m->id_of_tree[t.right]]->g;
-            m->graph[id].reset(new pagan_hgraph());
-            m->graph[id]->g = make_parent(gl, gr, w.res, (float)m->tree[t.left].dist, (float)m->tree[t.right].dist,
-                                          m->mf.parsimony.data(), 15, 4, bs);
-        });
-        m->tm.build_s += now_s() - t0;
-        if (bad) return PAGAN_E_INTERNAL;     // unreachable end corner: caller may retry with use_anchors = 0
-        for (int id : ready) { done[id] = 1; --remaining; }
-        ++level;
+    const TreeNode &t = m->tree[m->tree_of_id[id]];
+    SeqGraph &gl = m->graph[m->id_of_tree[t.left]]->g, &gr = m->graph[m->id_of_tree[t.right]]->g;
+    m->graph[id].reset(new pagan_hgraph());
+    m->graph[id]->g = make_parent(gl, gr, w.res, (float)m->tree[t.left].dist, (float)m->tree[t.right].dist,
+                                  m->mf.parsimony.data(), m->mf.S, m->mf.char_as, bs);
+    return PAGAN_OK;
+}
+
+// One unit of the work queue: the nodes `ids` (all ready) prepared, aligned on device `dev`, their parents
+// built.  Runs on the calling thread (+ the host thread pool); several of these run side by side on
+// different devices.  "anchored alignment failed: trying again" (viterbi_alignment.cpp:298-317): a node
+// whose end corner is unreachable inside its tunnel is re-aligned over the full matrix.
+int run_unit(pagan_msa *m, const std::vector<int> &ids, int dev, int round, int threads) {
+    const int n = m->n_leaves;
+    double t0 = now_s();
+    parallel_for((int)ids.size(), threads, [&](int r) { prepare_node(m, ids[r], round); });
+    const double t_prep = now_s() - t0;
+    t0 = now_s();
+    std::vector<int> ks(ids.size());
+    std::vector<int64_t> cost(ids.size());
+    for (size_t r = 0; r < ids.size(); ++r) {
+        NodeWork &w = m->work[ids[r] - n];
+        cost[r] = pagan_dp_count_cells(w.gl.n_sites, w.gr.n_sites, w.banded ? &w.pb : nullptr);
+        if (cost[r] < 0) return (int)cost[r];
+        w.device = dev;
     }
+    std::vector<int> order(ids.size());
+    for (size_t r = 0; r < ids.size(); ++r) order[r] = (int)r;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    for (size_t r = 0; r < ids.size(); ++r) ks[r] = ids[order[r]] - n;
+    double fill_ms = 0, trace_ms = 0;
+    int rc = align_on_device(m, ks, dev, &fill_ms, &trace_ms);
+    if (rc != PAGAN_OK) return rc;
+    std::vector<int> retry;
+    for (int k : ks) if (m->work[k].banded && m->work[k].res.status == PAGAN_DP_UNREACHABLE) retry.push_back(k);
+    if (!retry.empty()) {
+        for (int k : retry) { m->work[k].banded = false; pagan_result_free(&m->work[k].res); m->work[k].has_res = false; }
+        rc = align_on_device(m, retry, dev, &fill_ms, &trace_ms);
+        if (rc != PAGAN_OK) return rc;
+    }
+    const double t_dp = now_s() - t0;
+    t0 = now_s();
+    std::atomic<int> bad(0);
+    parallel_for((int)ids.size(), threads, [&](int r) { if (build_parent(m, ids[r]) != PAGAN_OK) bad = 1; });
+    const double t_build = now_s() - t0;
+    {
+        std::lock_guard<std::mutex> g(m->mu);
+        m->tm.anchors_s += t_prep; m->tm.dp_wall_s += t_dp; m->tm.build_s += t_build;
+        m->tm.dp_fill_dev_s += fill_ms / 1e3; m->tm.dp_trace_dev_s += trace_ms / 1e3;
+    }
+    return bad ? PAGAN_E_INTERNAL : PAGAN_OK;     // unreachable end corner: caller may retry with use_anchors = 0
+}
+
+int64_t node_cost_estimate(const pagan_msa *m, int id) {
+    const TreeNode &t = m->tree[m->tree_of_id[id]];
+    const int64_t lx = m->graph[m->id_of_tree[t.left]]->g.n_sites(), ly = m->graph[m->id_of_tree[t.right]]->g.n_sites();
+    // before the anchors are known: a tunnel is ~ (2 * offset + a few) cells per row, a full matrix Lx * Ly
+    return m->opts.use_anchors ? (lx + ly) * (int64_t)(2 * m->opts.anchors_offset + 16) : lx * ly;
+}
+
+} // namespace
+
+extern "C" {
+
+int pagan_msa_ready(const pagan_msa *m, int32_t *ids, int32_t cap) {
+    if (!m) return PAGAN_E_ARG;
+    int cnt = 0;
+    for (int id = m->n_leaves; id < 2 * m->n_leaves - 1; ++id)
+        if (node_ready(m, id)) { if (ids && cnt < cap) ids[cnt] = id; ++cnt; }
+    return cnt;
+}
+
+int pagan_msa_remaining(const pagan_msa *m) { return m ? m->remaining : PAGAN_E_ARG; }
+
+int64_t pagan_msa_node_cost(const pagan_msa *m, int32_t id) {
+    if (!m || id < m->n_leaves || id >= 2 * m->n_leaves - 1 || !node_ready(m, id)) return PAGAN_E_ARG;
+    return node_cost_estimate(m, id);
+}
+
+// The in-process work queue (Node::start_threaded_alignment, node.cpp:196-223,289-345, with devices in the
+// place of threads): whenever devices are idle and nodes are ready, the ready nodes are dealt over the idle
+// devices (largest first, least-loaded device) and each device's share becomes one unit on its own feeder
+// thread.  A parent becomes ready the moment its two children are done, whichever devices they ran on; a
+// device that finishes early picks up what is ready without waiting for the others.
+int pagan_msa_align_nodes(pagan_msa *m, int32_t n_ids, const int32_t *ids) {
+    if (!m || m->aligned || n_ids < 0 || (n_ids > 0 && !ids)) return PAGAN_E_ARG;
+    for (int k = 0; k < n_ids; ++k)
+        if (ids[k] < m->n_leaves || ids[k] >= 2 * m->n_leaves - 1 || !node_ready(m, ids[k])) return PAGAN_E_ARG;
+    if (n_ids == 0) return PAGAN_OK;
+    const double t_start = now_s();
+    int ndev = m->opts.n_devices;
+    int first_dev = m->opts.first_device;
+    if (ndev <= 0) { ndev = 1; if (!m->backend && hipGetDevice(&first_dev) != hipSuccess) return PAGAN_E_NODEVICE; }
+    const int threads = host_threads_of(m);
+    std::vector<int64_t> cost(n_ids);
+    for (int k = 0; k < n_ids; ++k) cost[k] = node_cost_estimate(m, ids[k]);
+    std::vector<int32_t> owner(n_ids);
+    const int workers = std::min(ndev, (int)n_ids);
+    pagan_assign_units(n_ids, cost.data(), workers, owner.data());
+    std::vector<std::vector<int>> share(workers);
+    for (int k = 0; k < n_ids; ++k) share[owner[k]].push_back(ids[k]);
+    std::vector<int> rcs(workers, PAGAN_OK);
+    const int round = m->rounds++;
+    if (workers == 1) {
+        rcs[0] = run_unit(m, share[0], first_dev, round, threads);
+    } else {
+        std::vector<std::thread> feeders;
+        const int per = std::max(1, threads / workers);
+        for (int d = 0; d < workers; ++d)
+            feeders.emplace_back([&, d] { rcs[d] = run_unit(m, share[d], first_dev + d, round, per); });
+        for (auto &th : feeders) th.join();
+    }
+    for (int rc : rcs) if (rc != PAGAN_OK) return rc;
+    for (int k = 0; k < n_ids; ++k) { m->done[ids[k]] = 1; --m->remaining; }
+    m->tm.total_s += now_s() - t_start;
+    return PAGAN_OK;
+}
+
+int pagan_msa_finish(pagan_msa *m) {
+    if (!m || m->aligned || m->remaining != 0) return PAGAN_E_ARG;
+    const double t0 = now_s();
     build_rows(m);
-    m->tm.total_s = now_s() - t_start;
+    m->tm.total_s += now_s() - t0;
     m->aligned = true;
+    return PAGAN_OK;
+}
+
+int pagan_msa_align(pagan_msa *m) {
+    if (!m || m->aligned) return PAGAN_E_ARG;
+    int ndev = m->opts.n_devices;
+    int first_dev = m->opts.first_device;
+    if (ndev <= 0) { ndev = 1; if (!m->backend && hipGetDevice(&first_dev) != hipSuccess) return PAGAN_E_NODEVICE; }
+    const int threads = host_threads_of(m);
+    if (ndev == 1) {
+        // one device: every round takes all ready nodes as one batch (the guide tree's levels)
+        std::vector<int32_t> ids(m->n_leaves);
+        while (m->remaining > 0) {
+            const int cnt = pagan_msa_ready(m, ids.data(), (int32_t)ids.size());
+            if (cnt <= 0) return PAGAN_E_INTERNAL;
+            const int rc = pagan_msa_align_nodes(m, cnt, ids.data());
+            if (rc != PAGAN_OK) return rc;
+        }
+        return pagan_msa_finish(m);
+    }
+    // several devices: dynamic ready queue
+    const double t_start = now_s();
+    std::mutex qm;
+    std::condition_variable cv;
+    std::vector<char> queued(m->done.size(), 0), busy(ndev, 0);
+    std::vector<std::thread> running(ndev);
+    std::vector<int> finished;           // devices whose unit has ended and whose thread can be joined
+    int in_flight = 0, err = PAGAN_OK;
+    const int per = std::max(1, threads / ndev);
+    std::unique_lock<std::mutex> lk(qm);
+    for (;;) {
+        for (int d : finished) { running[d].join(); busy[d] = 0; }
+        finished.clear();
+        if (err != PAGAN_OK || (m->remaining == 0 && in_flight == 0)) break;
+        std::vector<int> ready, idle;
+        for (int id = m->n_leaves; id < 2 * m->n_leaves - 1; ++id) if (!queued[id] && node_ready(m, id)) ready.push_back(id);
+        for (int d = 0; d < ndev; ++d) if (!busy[d]) idle.push_back(d);
+        if (!ready.empty() && !idle.empty()) {
+            std::vector<int64_t> cost(ready.size());
+            for (size_t k = 0; k < ready.size(); ++k) cost[k] = node_cost_estimate(m, ready[k]);
+            const int workers = (int)std::min(idle.size(), ready.size());
+            std::vector<int32_t> owner(ready.size());
+            pagan_assign_units((int32_t)ready.size(), cost.data(), workers, owner.data());
+            const int round = m->rounds++;
+            for (int w = 0; w < workers; ++w) {
+                std::vector<int> mine;
+                for (size_t k = 0; k < ready.size(); ++k) if (owner[k] == w) { mine.push_back(ready[k]); queued[ready[k]] = 1; }
+                const int d = idle[w];
+                busy[d] = 1; ++in_flight;
+                running[d] = std::thread([&, d, mine, round] {
+                    const int rc = run_unit(m, mine, first_dev + d, round, per);
+                    std::lock_guard<std::mutex> g(qm);
+                    if (rc != PAGAN_OK && err == PAGAN_OK) err = rc;
+                    if (rc == PAGAN_OK) for (int id : mine) { m->done[id] = 1; --m->remaining; }
+                    --in_flight; finished.push_back(d);
+                    cv.notify_all();
+                });
+            }
+            continue;
+        }
+        if (in_flight == 0) { err = PAGAN_E_INTERNAL; break; }
+        cv.wait(lk);
+    }
+    while (in_flight > 0) cv.wait(lk);
+    for (int d : finished) running[d].join();
+    lk.unlock();
+    if (err != PAGAN_OK) return err;
+    m->tm.total_s += now_s() - t_start;
+    return pagan_msa_finish(m);
+}
+
+// ---- results across processes (one rank per GPU): what a node's alignment left behind, as bytes ------------
+// Layout: int32 magic, node, status, end_matrix, end_x, end_y, end_x_edge, end_y_edge, n_cols, n_left_used,
+// n_right_used, packed; int64 cells; double score; then the columns -- packed: one byte of path_state per column
+// (the child indices are running counters, basic_alignment.cpp:73-165), else int32 triples -- and the used edge ids.
+static const int32_t kResultMagic = 0x50475232;   // "PGR2"
+
+int64_t pagan_msa_export_result(const pagan_msa *m, int32_t id, void *buf, int64_t cap) {
+    if (!m || id < m->n_leaves || id >= 2 * m->n_leaves - 1) return PAGAN_E_ARG;
+    const NodeWork &w = m->work[id - m->n_leaves];
+    if (!w.has_res) return PAGAN_E_ARG;
+    const pagan_result &r = w.res;
+    bool packed = true;
+    {
+        int l = 1, rr = 1;
+        for (int k = 0; k < r.n_cols && packed; ++k) {
+            const pagan_col &c = r.cols[k];
+            const bool hl = c.path_state == PAGAN_MATCHED || c.path_state == PAGAN_XGAPPED || c.path_state == PAGAN_XSKIPPED;
+            const bool hr = c.path_state == PAGAN_MATCHED || c.path_state == PAGAN_YGAPPED || c.path_state == PAGAN_YSKIPPED;
+            if ((hl ? c.left != l : c.left != -1) || (hr ? c.right != rr : c.right != -1)) packed = false;
+            l += hl; rr += hr;
+        }
+    }
+    const int64_t need = 12 * 4 + 8 + 8 + (packed ? (int64_t)r.n_cols : 12 * (int64_t)r.n_cols) + 4 * ((int64_t)r.n_left_used + r.n_right_used);
+    if (!buf || cap < need) return need;
+    char *p = (char *)buf;
+    const int32_t head[12] = {kResultMagic, id, r.status, r.end_matrix, r.end_x, r.end_y, r.end_x_edge, r.end_y_edge,
+                              r.n_cols, r.n_left_used, r.n_right_used, packed ? 1 : 0};
+    std::memcpy(p, head, sizeof(head)); p += sizeof(head);
+    std::memcpy(p, &r.cells, 8); p += 8;
+    std::memcpy(p, &r.score, 8); p += 8;
+    if (packed) for (int k = 0; k < r.n_cols; ++k) *p++ = (char)r.cols[k].path_state;
+    else { std::memcpy(p, r.cols, 12 * (size_t)r.n_cols); p += 12 * (size_t)r.n_cols; }
+    if (r.n_left_used) std::memcpy(p, r.left_used, 4 * (size_t)r.n_left_used);
+    p += 4 * (size_t)r.n_left_used;
+    if (r.n_right_used) std::memcpy(p, r.right_used, 4 * (size_t)r.n_right_used);
+    return need;
+}
+
+// Takes over a node aligned by another rank: stores the result, builds the parent graph, marks the node done.
+int pagan_msa_import_result(pagan_msa *m, const void *buf, int64_t bytes) {
+    if (!m || !buf || bytes < 12 * 4 + 16) return PAGAN_E_ARG;
+    const char *p = (const char *)buf;
+    int32_t head[12];
+    std::memcpy(head, p, sizeof(head)); p += sizeof(head);
+    if (head[0] != kResultMagic) return PAGAN_E_ARG;
+    const int id = head[1];
+    if (id < m->n_leaves || id >= 2 * m->n_leaves - 1 || !node_ready(m, id)) return PAGAN_E_ARG;
+    const int n_cols = head[8], nl = head[9], nr = head[10], packed = head[11];
+    if (n_cols < 0 || nl < 0 || nr < 0) return PAGAN_E_ARG;
+    const int64_t need = 12 * 4 + 16 + (packed ? (int64_t)n_cols : 12 * (int64_t)n_cols) + 4 * ((int64_t)nl + nr);
+    if (bytes < need) return PAGAN_E_ARG;
+    NodeWork &w = m->work[id - m->n_leaves];
+    if (w.has_res) { pagan_result_free(&w.res); w.has_res = false; }
+    pagan_result &r = w.res;
+    std::memset(&r, 0, sizeof(r));
+    r.status = head[2]; r.end_matrix = head[3]; r.end_x = head[4]; r.end_y = head[5]; r.end_x_edge = head[6]; r.end_y_edge = head[7];
+    r.n_cols = n_cols; r.n_left_used = nl; r.n_right_used = nr;
+    std::memcpy(&r.cells, p, 8); p += 8;
+    std::memcpy(&r.score, p, 8); p += 8;
+    // pagan_result_free releases these with free()
+    r.cols = (pagan_col *)std::malloc(sizeof(pagan_col) * (size_t)std::max(n_cols, 1));
+    r.left_used = (int32_t *)std::malloc(4 * (size_t)std::max(nl, 1));
+    r.right_used = (int32_t *)std::malloc(4 * (size_t)std::max(nr, 1));
+    if (!r.cols || !r.left_used || !r.right_used) { std::free(r.cols); std::free(r.left_used); std::free(r.right_used); return PAGAN_E_NOMEM; }
+    if (packed) {
+        int l = 1, rr = 1;
+        for (int k = 0; k < n_cols; ++k) {
+            const int ps = (unsigned char)*p++;
+            const bool hl = ps == PAGAN_MATCHED || ps == PAGAN_XGAPPED || ps == PAGAN_XSKIPPED;
+            const bool hr = ps == PAGAN_MATCHED || ps == PAGAN_YGAPPED || ps == PAGAN_YSKIPPED;
+            r.cols[k].path_state = ps; r.cols[k].left = hl ? l++ : -1; r.cols[k].right = hr ? rr++ : -1;
+        }
+    } else { std::memcpy(r.cols, p, 12 * (size_t)n_cols); p += 12 * (size_t)n_cols; }
+    if (nl) std::memcpy(r.left_used, p, 4 * (size_t)nl);
+    p += 4 * (size_t)nl;
+    if (nr) std::memcpy(r.right_used, p, 4 * (size_t)nr);
+    w.has_res = true; w.has_job = false; w.device = -1; w.node = id; w.level = m->rounds;
+    const TreeNode &t = m->tree[m->tree_of_id[id]];
+    const SeqGraph &gl = m->graph[m->id_of_tree[t.left]]->g, &gr = m->graph[m->id_of_tree[t.right]]->g;
+    for (int k = 0; k < n_cols; ++k) {
+        const pagan_col &c = r.cols[k];
+        if (c.path_state < PAGAN_MATCHED || c.path_state > PAGAN_YSKIPPED || c.left >= gl.n_sites() - 1 || c.right >= gr.n_sites() - 1) return PAGAN_E_ARG;
+    }
+    for (int k = 0; k < nl; ++k) if (r.left_used[k] < 0 || r.left_used[k] >= gl.n_edges()) return PAGAN_E_ARG;
+    for (int k = 0; k < nr; ++k) if (r.right_used[k] < 0 || r.right_used[k] >= gr.n_edges()) return PAGAN_E_ARG;
+    const double t0 = now_s();
+    const int rc = build_parent(m, id);
+    m->tm.build_s += now_s() - t0;
+    if (rc != PAGAN_OK) return rc;
+    m->done[id] = 1; --m->remaining;
     return PAGAN_OK;
 }
 
@@ -453,7 +702,7 @@ int pagan_msa_node_info(const pagan_msa *m, int32_t k, pagan_node_info *o) {
 }
 
 int pagan_msa_node_job(const pagan_msa *m, int32_t k, pagan_job *o) {
-    if (!m || !o || k < 0 || k >= m->n_leaves - 1 || !m->work[k].has_res) return PAGAN_E_ARG;
+    if (!m || !o || k < 0 || k >= m->n_leaves - 1 || !m->work[k].has_res || !m->work[k].has_job) return PAGAN_E_ARG;
     const NodeWork &w = m->work[k];
     o->left = &w.gl; o->right = &w.gr; o->model = &w.pm; o->band = w.banded ? &w.pb : nullptr;
     return PAGAN_OK;
@@ -573,13 +822,53 @@ int pagan_define_tunnel(const char *s1, const char *s2, const char *g1, const ch
 }
 
 int pagan_dna_model(const float bf[4], double distance, float *table, float *params, int32_t *parsimony) {
-    DnaModelFactory mf;
-    mf.init(bf);
+    if (!bf || !table || !params) return PAGAN_E_ARG;
+    ModelFactory mf;
+    mf.init_dna(bf);
     const EvolModel em = mf.alignment_model(distance);
     std::memcpy(table, em.log_score.data(), sizeof(float) * 225);
     params[0] = em.log_gap_open; params[1] = em.log_gap_ext; params[2] = em.log_gap_end_ext; params[3] = em.log_non_gap;
     if (parsimony) std::memcpy(parsimony, mf.parsimony.data(), sizeof(int32_t) * 225);
     return PAGAN_OK;
 }
+
+int pagan_protein_model(double distance, float *table, float *params, int32_t *parsimony) {
+    if (!table || !params) return PAGAN_E_ARG;
+    static ModelFactory mf;                       // the WAG eigen solution does not depend on the input
+    static std::once_flag once;
+    std::call_once(once, [] { mf.init_protein(); });
+    const EvolModel em = mf.alignment_model(distance);
+    std::memcpy(table, em.log_score.data(), sizeof(float) * em.log_score.size());
+    params[0] = em.log_gap_open; params[1] = em.log_gap_ext; params[2] = em.log_gap_end_ext; params[3] = em.log_non_gap;
+    if (parsimony) std::memcpy(parsimony, mf.parsimony.data(), sizeof(int32_t) * mf.parsimony.size());
+    return PAGAN_OK;
+}
+
+int pagan_model_alphabets(int32_t data_type, char *leaf_alphabet, char *ancestral_alphabet) {
+    ModelFactory mf;
+    if (data_type == 2) mf.init_protein();
+    else { const float bf[4] = {0.25f, 0.25f, 0.25f, 0.25f}; mf.init_dna(bf); }
+    if (leaf_alphabet) std::memcpy(leaf_alphabet, mf.leaf_alphabet.c_str(), mf.leaf_alphabet.size() + 1);
+    if (ancestral_alphabet) std::memcpy(ancestral_alphabet, mf.ancestral_alphabet.c_str(), mf.ancestral_alphabet.size() + 1);
+    return mf.S;
+}
+
+int pagan_eigen_qrev(const double *Q, const double *pi, int32_t n, double *root, double *U, double *V) {
+    if (!Q || !pi || n < 1 || !root || !U || !V) return PAGAN_E_ARG;
+    return eigen_qrev(Q, pi, n, root, U, V);
+}
+
+int pagan_msa_set_batch_backend(pagan_msa *m, pagan_batch_fn fn, void *user) {
+    if (!m) return PAGAN_E_ARG;
+    m->backend = fn; m->backend_user = user;
+    return PAGAN_OK;
+}
+
+int pagan_msa_node_device(const pagan_msa *m, int32_t k) {
+    if (!m || k < 0 || k >= m->n_leaves - 1) return PAGAN_E_ARG;
+    return m->work[k].device;
+}
+
+int pagan_msa_data_type(const pagan_msa *m) { return m ? (m->mf.type == kProtein ? 2 : 1) : PAGAN_E_ARG; }
 
 } // extern "C"

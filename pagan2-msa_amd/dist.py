@@ -1,6 +1,22 @@
-"""One-process-per-GPU plumbing for bench.py (torch.distributed; backend "nccl" = RCCL on the GPU
-box, "gloo" in the CPU tests).  The data path has no collective: ranks only meet at the barrier
-and to reduce the timing."""
+"""One-process-per-GPU plumbing (torch.distributed; backend "nccl" = RCCL on the GPU box, "gloo" in
+the CPU tests).
+
+The path shards by independent units -- guide-tree nodes whose two children are finished
+(Node::start_openmp_alignment / build_queues, src/main/node.cpp:227-285) -- and the reference runs
+them from a shared-memory queue.  With one process per GPU there is no shared memory, so every rank
+holds the whole (small) tree state and the queue is replayed in rounds:
+
+    ready = msa.ready()                      the same list on every rank
+    mine  = the units the work-queue rule (pagan_assign_units, largest first) gives this rank
+    msa.align_nodes(mine)                    model, anchors, DP on this rank's GPU, parent graphs
+    all_gather(exported results of `mine`)   the one exchange: path columns + used child edges of the
+                                             nodes a rank aligned, ~1 byte per alignment column
+    msa.import_result(...) for the others'   builds those parents locally
+
+The DP itself has no collective; what travels is the finished path of each node, because the next
+round's inputs (the parents' graphs) are built from it on every rank.
+"""
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -32,3 +48,66 @@ def my_units(costs, assign):
     """Indices of the units this rank owns under the work-queue rule `assign(costs, n_workers)`."""
     owner = assign(costs, world())
     return [k for k, o in enumerate(owner) if int(o) == rank()]
+
+
+def all_gather_bytes(chunks, device="cpu"):
+    """chunks: list of uint8 numpy arrays of this rank.  Returns, per rank, its list of chunks.
+    Two collectives: the chunk sizes (fixed shape), then the padded payloads."""
+    w = world()
+    if w == 1:
+        return [list(chunks)]
+    sizes = torch.tensor([len(chunks)] + [int(c.shape[0]) for c in chunks], dtype=torch.int64, device=device)
+    n_max = torch.tensor([sizes.shape[0]], dtype=torch.int64, device=device)
+    dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
+    pad = torch.zeros(int(n_max.item()), dtype=torch.int64, device=device)
+    pad[:sizes.shape[0]] = sizes
+    all_sizes = [torch.zeros_like(pad) for _ in range(w)]
+    dist.all_gather(all_sizes, pad)
+    all_sizes = [s.cpu().numpy() for s in all_sizes]
+    totals = [int(s[1:1 + int(s[0])].sum()) for s in all_sizes]
+    cap = max(max(totals), 1)
+    payload = torch.zeros(cap, dtype=torch.uint8, device=device)
+    if chunks:
+        flat = np.concatenate(chunks) if len(chunks) > 1 else chunks[0]
+        payload[:flat.shape[0]] = torch.from_numpy(np.ascontiguousarray(flat)).to(device)
+    gathered = [torch.zeros_like(payload) for _ in range(w)]
+    dist.all_gather(gathered, payload)
+    out = []
+    for r in range(w):
+        buf = gathered[r].cpu().numpy()
+        cnt = int(all_sizes[r][0])
+        lens = all_sizes[r][1:1 + cnt]
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        out.append([buf[int(offs[k]):int(offs[k + 1])] for k in range(cnt)])
+    return out
+
+
+def align_sharded(msa, assign, device="cpu", on_round=None):
+    """The whole progressive alignment of `msa` (a host.Msa, created identically on every rank) with the
+    ready nodes of each round dealt over the ranks.  `assign(costs, n_workers)` is the work-queue rule
+    (host.assign_units).  Returns per-round records [(n_ready, n_mine, bytes exchanged)]."""
+    w, r = world(), rank()
+    rounds = []
+    while msa.remaining > 0:
+        ready = msa.ready()
+        if not ready:
+            raise RuntimeError("no ready node although %d remain" % msa.remaining)
+        costs = [msa.node_cost(n) for n in ready]
+        owner = assign(costs, min(w, len(ready)))
+        mine = [n for n, o in zip(ready, owner) if int(o) == r]
+        if mine:
+            msa.align_nodes(mine)
+        chunks = [msa.export_result(n) for n in mine]
+        moved = 0
+        if w > 1:
+            for src, theirs in enumerate(all_gather_bytes(chunks, device=device)):
+                if src == r:
+                    continue
+                for c in theirs:
+                    msa.import_result(c)
+                    moved += int(c.shape[0])
+        rounds.append((len(ready), len(mine), moved))
+        if on_round:
+            on_round(len(rounds) - 1, ready, mine)
+    msa.finish()
+    return rounds

@@ -19,7 +19,8 @@ class CMsaOpts(C.Structure):
     _fields_ = [("use_anchors", C.c_int32), ("anchors_offset", C.c_int32), ("prefix_hit_length", C.c_int32),
                 ("hit_trim", C.c_int32), ("dp_flags", C.c_uint32), ("leaf_flags", C.c_int32),
                 ("keep_all_edges", C.c_int32), ("n_devices", C.c_int32), ("first_device", C.c_int32),
-                ("host_threads", C.c_int32), ("truncate_branches", C.c_float), ("device_mem_budget", C.c_int64)]
+                ("host_threads", C.c_int32), ("truncate_branches", C.c_float), ("device_mem_budget", C.c_int64),
+                ("data_type", C.c_int32), ("pileup_rates", C.c_int32)]
 
 
 class CNodeInfo(C.Structure):
@@ -32,6 +33,9 @@ class CTiming(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("total_s", "model_s", "anchors_s", "dp_wall_s", "dp_fill_dev_s",
                                            "dp_trace_dev_s", "build_s")]
 
+
+# pagan_batch_fn (include/pagan_host.h): the test seam's callback type
+BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_int32, C.POINTER(abi.CJob), C.POINTER(abi.COpts), C.POINTER(abi.CResult), C.c_void_p)
 
 _declared = False
 
@@ -91,6 +95,33 @@ def _lib():
         L.pagan_assign_units.restype = None
         L.pagan_dna_model.argtypes = [_f32p, C.c_double, _f32p, _f32p, _i32p]
         L.pagan_dna_model.restype = C.c_int
+        L.pagan_protein_model.argtypes = [C.c_double, _f32p, _f32p, _i32p]
+        L.pagan_protein_model.restype = C.c_int
+        L.pagan_model_alphabets.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
+        L.pagan_model_alphabets.restype = C.c_int
+        f64p = C.POINTER(C.c_double)
+        L.pagan_eigen_qrev.argtypes = [f64p, f64p, C.c_int32, f64p, f64p, f64p]
+        L.pagan_eigen_qrev.restype = C.c_int
+        L.pagan_msa_ready.argtypes = [vp, _i32p, C.c_int32]
+        L.pagan_msa_ready.restype = C.c_int
+        L.pagan_msa_remaining.argtypes = [vp]
+        L.pagan_msa_remaining.restype = C.c_int
+        L.pagan_msa_node_cost.argtypes = [vp, C.c_int32]
+        L.pagan_msa_node_cost.restype = C.c_int64
+        L.pagan_msa_align_nodes.argtypes = [vp, C.c_int32, _i32p]
+        L.pagan_msa_align_nodes.restype = C.c_int
+        L.pagan_msa_export_result.argtypes = [vp, C.c_int32, C.c_void_p, C.c_int64]
+        L.pagan_msa_export_result.restype = C.c_int64
+        L.pagan_msa_import_result.argtypes = [vp, C.c_void_p, C.c_int64]
+        L.pagan_msa_import_result.restype = C.c_int
+        L.pagan_msa_finish.argtypes = [vp]
+        L.pagan_msa_finish.restype = C.c_int
+        L.pagan_msa_data_type.argtypes = [vp]
+        L.pagan_msa_data_type.restype = C.c_int
+        L.pagan_msa_node_device.argtypes = [vp, C.c_int32]
+        L.pagan_msa_node_device.restype = C.c_int
+        L.pagan_msa_set_batch_backend.argtypes = [vp, BATCH_FN, C.c_void_p]
+        L.pagan_msa_set_batch_backend.restype = C.c_int
         _declared = True
     return L
 
@@ -100,7 +131,10 @@ HOST_EXPORTED = ["pagan_assign_units", "pagan_msa_default_opts", "pagan_msa_crea
                  "pagan_msa_alignment_length", "pagan_msa_alignment_row", "pagan_msa_write_fasta", "pagan_msa_node_graph",
                  "pagan_msa_destroy", "pagan_hgraph_leaf", "pagan_hgraph_parent", "pagan_hgraph_view",
                  "pagan_hgraph_attrs", "pagan_hgraph_fwd", "pagan_hgraph_string", "pagan_hgraph_free",
-                 "pagan_define_tunnel", "pagan_dna_model"]
+                 "pagan_define_tunnel", "pagan_dna_model", "pagan_protein_model", "pagan_model_alphabets",
+                 "pagan_eigen_qrev", "pagan_msa_ready", "pagan_msa_remaining", "pagan_msa_node_cost",
+                 "pagan_msa_align_nodes", "pagan_msa_export_result", "pagan_msa_import_result", "pagan_msa_finish",
+                 "pagan_msa_data_type", "pagan_msa_node_device", "pagan_msa_set_batch_backend"]
 
 
 def _ip(a):
@@ -218,6 +252,38 @@ def dna_model(base_freq, dist):
     return abi.Model(table.reshape(15, 15).T, *params), pars
 
 
+def protein_model(dist):
+    """(abi.Model, parsimony[211*211]) for a protein (WAG) alignment at distance `dist`."""
+    table = np.zeros(211 * 211, np.float32)
+    params = np.zeros(4, np.float32)
+    pars = np.zeros(211 * 211, np.int32)
+    rc = _lib().pagan_protein_model(float(dist), _fp(table), _fp(params), _ip(pars))
+    if rc != 0:
+        raise RuntimeError("pagan_protein_model failed: %d" % rc)
+    return abi.Model(table.reshape(211, 211).T, *params), pars
+
+
+def alphabets(data_type):
+    """(leaf alphabet, ancestral alphabet) of a data type: 1 DNA, 2 protein."""
+    a, b = C.create_string_buffer(256), C.create_string_buffer(256)
+    _lib().pagan_model_alphabets(int(data_type), a, b)
+    return a.value.decode(), b.value.decode()
+
+
+def eigen_qrev(Q, pi):
+    """Eigen::eigenQREV as the library restates it: (root, U, V) with Q = U diag(root) V."""
+    Q = np.ascontiguousarray(Q, np.float64)
+    pi = np.ascontiguousarray(pi, np.float64)
+    n = pi.shape[0]
+    root, U, V = np.zeros(n), np.zeros((n, n)), np.zeros((n, n))
+    dp = C.POINTER(C.c_double)
+    rc = _lib().pagan_eigen_qrev(Q.ctypes.data_as(dp), pi.ctypes.data_as(dp), n, root.ctypes.data_as(dp),
+                                 U.ctypes.data_as(dp), V.ctypes.data_as(dp))
+    if rc != 0:
+        raise RuntimeError("pagan_eigen_qrev failed: %d" % rc)
+    return root, U, V
+
+
 class Msa:
     """Progressive alignment of sequences on a rooted binary guide tree (Node mirror)."""
 
@@ -249,6 +315,61 @@ class Msa:
     @property
     def n_internal(self):
         return self._L.pagan_msa_n_internal(self._h)
+
+    @property
+    def data_type(self):
+        return self._L.pagan_msa_data_type(self._h)
+
+    # ---- the walk one round at a time (one process per GPU; see dist.align_sharded) ----
+    def ready(self):
+        ids = np.zeros(max(self.n, 1), np.int32)
+        cnt = self._L.pagan_msa_ready(self._h, _ip(ids), int(ids.shape[0]))
+        return [int(x) for x in ids[:cnt]]
+
+    @property
+    def remaining(self):
+        return self._L.pagan_msa_remaining(self._h)
+
+    def node_cost(self, node):
+        return int(self._L.pagan_msa_node_cost(self._h, node))
+
+    def align_nodes(self, nodes):
+        ids = np.ascontiguousarray(nodes, np.int32)
+        rc = self._L.pagan_msa_align_nodes(self._h, int(ids.shape[0]), _ip(ids))
+        if rc != 0:
+            from . import PaganError
+            raise PaganError(rc, "pagan_msa_align_nodes")
+
+    def export_result(self, node):
+        need = self._L.pagan_msa_export_result(self._h, node, None, 0)
+        if need < 0:
+            from . import PaganError
+            raise PaganError(int(need), "pagan_msa_export_result")
+        buf = np.zeros(need, np.uint8)
+        self._L.pagan_msa_export_result(self._h, node, buf.ctypes.data_as(C.c_void_p), need)
+        return buf
+
+    def import_result(self, buf):
+        b = np.ascontiguousarray(buf, np.uint8)
+        rc = self._L.pagan_msa_import_result(self._h, b.ctypes.data_as(C.c_void_p), int(b.shape[0]))
+        if rc != 0:
+            from . import PaganError
+            raise PaganError(rc, "pagan_msa_import_result")
+
+    def node_device(self, k):
+        return self._L.pagan_msa_node_device(self._h, k)
+
+    def set_batch_backend(self, fn):
+        """TEST SEAM: `fn(n, jobs, opts, out, user) -> rc` stands in for pagan_dp_align_batch (None: the HIP path)."""
+        self._backend = BATCH_FN(fn) if fn is not None else C.cast(None, BATCH_FN)
+        self._L.pagan_msa_set_batch_backend(self._h, self._backend, None)
+
+    def finish(self):
+        rc = self._L.pagan_msa_finish(self._h)
+        if rc != 0:
+            from . import PaganError
+            raise PaganError(rc, "pagan_msa_finish")
+        return self
 
     def node_info(self, k):
         info = CNodeInfo()

@@ -27,27 +27,38 @@ def test_leaf_graphs(oracle, pg, flags):
         same_graph(host.HGraph.leaf(s, flags=flags), oracle.OGraph.leaf(s, flags=flags), "leaf %s/%d" % (s[:8], flags))
 
 
-def walk(tree, seqs_by_name, oracle, bf, flags=0, check=None, band=False):
+def walk(tree, seqs_by_name, oracle, bf, flags=0, check=None, band=False, protein=False):
     """Post-order progressive alignment with the oracle DP; both graph builders in lockstep."""
-    stats = {"nodes": 0, "skips": 0, "nonreal": 0, "multi": 0}
+    stats = {"nodes": 0, "skips": 0, "nonreal": 0, "multi": 0, "states": set()}
+    leaf_alpha, anc_alpha = host.alphabets(2 if protein else 1)
+    o_leaf_alpha = oracle.protein_leaf_alphabet() if protein else oracle.DNA_ALPHABET
+    char_as = 20 if protein else 4
 
     def rec(t):
         if t[0] == "leaf":
             s = seqs_by_name[t[1]]
-            return host.HGraph.leaf(s), oracle.OGraph.leaf(s), min(max(t[2], 0.001), 0.2) if t[2] > 0 else 0.001
+            return (host.HGraph.leaf(s, leaf_alpha), oracle.OGraph.leaf(s, o_leaf_alpha),
+                    min(max(t[2], 0.001), 0.2) if t[2] > 0 else 0.001)
         hl, ol, dl = rec(t[1])
         hr, orr, dr = rec(t[2])
-        model, pars = host.dna_model(bf, dl + dr)
+        if protein:
+            model, pars = host.protein_model(dl + dr)
+            opars = oracle.protein_model(dl + dr)[1]
+        else:
+            model, pars = host.dna_model(bf, dl + dr)
+            opars = oracle.dna_parsimony()
         gl, gr = hl.flatten(), hr.flatten()
         b = None
         if band:
-            b, _ = host.define_tunnel(hl.string(False), hr.string(False), hl.string(True), hr.string(True))
-            ob, _ = oracle.define_tunnel(ol, orr)
+            b, _ = host.define_tunnel(hl.string(False, anc_alpha), hr.string(False, anc_alpha),
+                                      hl.string(True, anc_alpha), hr.string(True, anc_alpha))
+            ob, _ = oracle.define_tunnel(ol, orr, alphabet=anc_alpha)
             assert np.array_equal(b.upper, ob.upper) and np.array_equal(b.lower, ob.lower)
         res = oracle.dp_align(gl, gr, model, b)
         assert res.status == 0
-        hp = host.HGraph.parent(hl, hr, res, dl, dr, pars, 4, flags)
-        op = oracle.OGraph.parent(ol, orr, res, dl, dr, oracle.dna_parsimony(), 4, flags)
+        hp = host.HGraph.parent(hl, hr, res, dl, dr, pars, char_as, flags)
+        op = oracle.OGraph.parent(ol, orr, res, dl, dr, opars, char_as, flags)
+        stats["states"].update(hp.flatten().state.tolist())
         same_graph(hp, op, "node %d" % stats["nodes"])
         stats["nodes"] += 1
         sa = hp.attrs()[0]
@@ -85,6 +96,19 @@ def test_progressive_graphs_caterpillar_deletes_ranges(oracle, pg):
     names, seqs, nwk = synth.evolve_caterpillar(14, 150, seed=2)
     st = walk(synth.parse_newick(nwk), dict(zip(names, seqs)), oracle, base_freq(seqs))
     assert st["nodes"] == 13 and st["nonreal"] > 0
+
+
+def test_progressive_graphs_protein(oracle, pg):
+    """WAG / 211-letter alphabet: upper nodes carry X and pair codes from the parsimony table."""
+    aa = "ARNDCQEGHILKMFPSTWYV"
+    names, seqs, nwk = synth.evolve_balanced(16, 120, branch=0.05, sub=0.08, indel_start=0.012, mean_len=4, seed=9,
+                                             alphabet=aa)
+    seqs[3] = seqs[3][:40] + "X" + seqs[3][41:]
+    st = walk(synth.parse_newick(nwk), dict(zip(names, seqs)), oracle, None, protein=True)
+    assert st["nodes"] == 15 and st["skips"] > 5
+    assert max(st["states"]) > 20                                # pair codes reached internal nodes (X yields to a residue)
+    st = walk(synth.parse_newick(nwk), dict(zip(names, seqs)), oracle, None, protein=True, band=True)
+    assert st["nodes"] == 15
 
 
 def test_define_tunnel_matches_oracle_on_leaves(oracle, pg):

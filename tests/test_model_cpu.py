@@ -1,0 +1,136 @@
+"""CPU tests of the scoring-model producer (DNA HKY-like and protein WAG): the product's
+restatement (csrc/host_model.cpp) against the oracle's literal one (oracle/oracle_model.cpp) bit
+for bit, and both against an independent numpy/scipy computation within a tolerance."""
+import re
+
+import numpy as np
+import pytest
+from scipy.linalg import expm
+
+from pagan2_msa_amd import host
+
+AA = "ARNDCQEGHILKMFPSTWYV"
+
+
+def wag():
+    src = open(__import__("os").path.join(__import__("os").path.dirname(__file__), "..", "oracle", "wag_data.h")).read()
+    nums = [float(x) for x in re.findall(r"-?\d+\.\d+(?:e-?\d+)?", src.split("kWagPi")[1])]
+    return np.array(nums[:20]), np.array(nums[20:420]).reshape(20, 20)
+
+
+def test_wag_constants_are_a_reversible_rate_matrix():
+    pi, Q = wag()
+    assert abs(pi.sum() - 1) < 1e-6
+    assert np.abs(Q.sum(1)).max() < 1e-12
+    assert np.abs(pi[:, None] * Q - (pi[:, None] * Q).T).max() < 1e-12      # detailed balance
+    assert open("oracle/wag_data.h").read().split("namespace")[1].split("{", 1)[1] == \
+        open("pagan2-msa_amd/csrc/wag_data.h").read().split("namespace")[1].split("{", 1)[1]
+
+
+def test_eigen_qrev_bits_match_oracle_and_reconstruct_q(oracle, pg):
+    pi, Q = wag()
+    r1, U1, V1 = host.eigen_qrev(Q, pi)
+    r2, U2, V2 = oracle.eigen_qrev(Q, pi)
+    assert r1.tobytes() == r2.tobytes() and U1.tobytes() == U2.tobytes() and V1.tobytes() == V2.tobytes()
+    assert r1[0] == 0 and np.all(np.diff(r1) <= 0)
+    assert np.abs(U1 @ np.diag(r1) @ V1 - Q).max() < 1e-13
+    assert np.abs(U1 @ V1 - np.eye(20)).max() < 1e-13
+    w = np.sort(np.linalg.eigvals(Q).real)[::-1]
+    assert np.abs(w - r1).max() < 1e-12
+    # a state with pi == 0 is cut out of the eigenproblem and embedded again (eigen.cpp:83-123)
+    rng = np.random.default_rng(1)
+    p4 = np.array([0.3, 0.0, 0.5, 0.2])
+    S = rng.random((4, 4)); S = S + S.T
+    Q4 = S * p4[None, :]
+    Q4[1, :] = 0; Q4[:, 1] = 0
+    np.fill_diagonal(Q4, 0)
+    Q4 -= np.diag(Q4.sum(1))
+    a, b = host.eigen_qrev(Q4, p4), oracle.eigen_qrev(Q4, p4)
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()
+    assert np.abs(a[1] @ np.diag(a[0]) @ a[2] - Q4).max() < 1e-13
+
+
+@pytest.mark.parametrize("dist", [0.002, 0.05, 0.1, 0.4])
+def test_protein_model_bits_match_oracle_and_scipy(oracle, pg, dist):
+    m1, p1 = host.protein_model(dist)
+    m2, p2 = oracle.protein_model(dist)
+    assert m1.table.tobytes() == m2.table.tobytes(), "211x211 log-odds tables differ in some bit"
+    assert np.array(m1.params).tobytes() == np.array(m2.params).tobytes()
+    assert np.array_equal(p1, p2)
+    pi, Q = wag()
+    P = expm(Q * dist)
+    lo = np.log(0.5 * (pi[:, None] + pi[None, :]) * P / (pi[:, None] * pi[None, :]))
+    T = m1.log_score
+    assert np.allclose(T[:20, :20], lo, rtol=0, atol=3e-6)
+    t = 1 - np.exp(-0.5 * 0.1 * dist)
+    assert np.allclose(m1.params, [np.log(t), np.log(0.5), np.log(0.75), np.log(1 - 2 * t)], atol=1e-6)
+    # ambiguity codes: X = best over all residues; a pair code = best of its two members (model_factory.cpp:2155-2219)
+    code = {}
+    k = 21
+    for i in range(19):
+        for j in range(i + 1, 20):
+            code[(i, j)] = k
+            k += 1
+    assert k == 211
+    assert T[20, 3] == T[:20, 3].max() and T[5, 20] == T[5, :20].max() and T[20, 20] == T[:20, :20].max()
+    c = code[(2, 7)]
+    assert T[c, 4] == max(T[2, 4], T[7, 4]) and T[4, c] == max(T[4, 2], T[4, 7])
+    c2 = code[(0, 19)]
+    assert T[c, c2] == max(T[2, 0], T[2, 19], T[7, 0], T[7, 19])
+    assert np.isfinite(T).all()
+
+
+def test_protein_parsimony_table_rules(pg):
+    _, pars = host.protein_model(0.1)
+    P = pars.reshape(211, 211).T          # P[i, j] = table(i, j)
+    pi, Q = wag()
+    code, members = {}, {}
+    k = 21
+    for i in range(19):
+        for j in range(i + 1, 20):
+            code[(i, j)] = code[(j, i)] = k
+            members[k] = (i, j)
+            k += 1
+    for i in range(211):
+        assert P[i, i] == i and P[20, i] == i and P[i, 20] == i           # X yields to anything
+    for i in range(20):
+        for j in range(20):
+            if i != j:
+                assert P[i, j] == code[(i, j)]                            # two residues -> their pair code
+    for c, (a, b) in members.items():
+        assert P[a, c] == a and P[c, b] == b                              # residue inside a pair -> the residue
+    # disjoint cases: the member pair with the largest WAG rate (float running maximum, strict >)
+    for (i, j) in [(3, code[(5, 9)]), (code[(0, 1)], code[(2, 3)]), (code[(4, 7)], code[(7, 11)]), (code[(10, 12)], 6)]:
+        mi = members.get(i, (i,))
+        mj = members.get(j, (j,))
+        order = [(mi[0], mj[0])] + ([(mi[0], mj[1])] if len(mj) == 2 else []) + ([(mi[1], mj[0])] if len(mi) == 2 else []) \
+            + ([(mi[1], mj[1])] if len(mi) == 2 and len(mj) == 2 else [])
+        best, pick = np.float32(-1), None
+        for (a, b) in order:
+            if Q[a, b] > best:
+                best, pick = np.float32(Q[a, b]), (a, b)
+        assert P[i, j] == code[pick]
+
+
+def test_alphabets(pg, oracle):
+    leaf, anc = host.alphabets(2)
+    assert leaf == oracle.protein_leaf_alphabet() and len(leaf) == 211 and leaf.find("X") == 20
+    pi, _ = wag()
+    assert anc[:21] == AA + "X" and len(anc) == 211
+    k = 21
+    for i in range(19):
+        for j in range(i + 1, 20):
+            assert anc[k] == (AA[i] if pi[i] > pi[j] else AA[j])
+            k += 1
+    leaf, anc = host.alphabets(1)
+    assert leaf == anc == "ACGTRYMKWSBDHVN"
+
+
+@pytest.mark.parametrize("dist", [0.002, 0.1, 0.4])
+def test_dna_model_bits_match_oracle(oracle, pg, dist):
+    for bf in ([0.31, 0.19, 0.22, 0.28], [0.25, 0.25, 0.25, 0.25], [0.4, 0.1, 0.1, 0.4]):
+        bf = np.array(bf, np.float32)
+        m1, _ = host.dna_model(bf, dist)
+        m2 = oracle.dna_model(bf, dist)
+        assert m1.table.tobytes() == m2.table.tobytes() and np.array(m1.params).tobytes() == np.array(m2.params).tobytes()

@@ -1,0 +1,166 @@
+"""CPU tests of the multi-device / multi-rank work queue of the tree walk (host_tree.cpp,
+pagan2-msa_amd/dist.py).  There is no GPU here, so the queue's batches go to a stand-in for
+pagan_dp_align_batch installed through the test seam pagan_msa_set_batch_backend: the oracle's DP,
+called per job.  Everything else is the product's code: dealing by cost, feeder threads per device,
+the dynamic ready queue, the tunnel retry, parent building, result export/import, the all-gather."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from pagan2_msa_amd import host, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_backend(oracle, log):
+    """fn(n, jobs, opts, out, user) with pagan_dp_align_batch's contract, backed by oracle_dp_align."""
+    L = oracle.lib()
+
+    def fn(n, jobs, opts, out, user):
+        log.append((int(opts.contents.device), int(n)))
+        for k in range(n):
+            j = jobs[k]
+            rc = L.oracle_dp_align(j.left, j.right, j.model, j.band if j.band else None, opts, C.byref(out[k]))
+            if rc != 0:
+                return rc
+        return 0
+    return fn
+
+
+def walk(oracle, names, seqs, nwk, log=None, **opts):
+    msa = host.Msa(names, seqs, nwk, **opts)
+    msa.set_batch_backend(oracle_backend(oracle, log if log is not None else []))
+    return msa
+
+
+def snapshot(msa):
+    out = {"rows": msa.alignment(), "scores": [], "cols": []}
+    for k in range(msa.n_internal):
+        r = msa.node_result(k)
+        out["scores"].append(r.score)
+        out["cols"].append(r.cols.copy())
+    return out
+
+
+def same(a, b):
+    assert a["rows"] == b["rows"]
+    assert a["scores"] == b["scores"]
+    for x, y in zip(a["cols"], b["cols"]):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("shape", ["balanced", "caterpillar"])
+def test_in_process_queue_over_devices_matches_one_device(oracle, pg, shape):
+    if shape == "balanced":
+        names, seqs, nwk = synth.evolve_balanced(16, 220, branch=0.03, sub=0.03, indel_start=0.01, mean_len=4, seed=11)
+    else:
+        names, seqs, nwk = synth.evolve_caterpillar(9, 180, seed=4)
+    base = walk(oracle, names, seqs, nwk, use_anchors=0, n_devices=1, first_device=0).align()
+    want = snapshot(base)
+    for ndev in (2, 3):
+        log = []
+        msa = walk(oracle, names, seqs, nwk, log=log, use_anchors=0, n_devices=ndev, first_device=0).align()
+        same(snapshot(msa), want)
+        devs = {msa.node_device(k) for k in range(msa.n_internal)}
+        assert devs <= set(range(ndev))
+        if shape == "balanced":
+            assert devs == set(range(ndev))                 # a 8-wide first level reaches every device
+            assert sum(n for _, n in log) == msa.n_internal
+        for r, s in zip(msa.alignment(), seqs):
+            assert r.replace("-", "") == s
+
+
+def test_queue_deals_largest_first_and_retries_failed_tunnels(oracle, pg):
+    names, seqs, nwk = synth.evolve_balanced(8, 600, branch=0.02, sub=0.02, indel_start=0.004, mean_len=4, seed=12)
+    log = []
+    msa = walk(oracle, names, seqs, nwk, log=log, use_anchors=1, n_devices=2, first_device=3).align()
+    assert {d for d, _ in log} == {3, 4}                    # first_device is honoured
+    one = walk(oracle, names, seqs, nwk, use_anchors=1, n_devices=1, first_device=0).align()
+    same(snapshot(msa), snapshot(one))
+    # every node's recorded job reproduces its result (bands included)
+    for k in range(msa.n_internal):
+        left, right, model, band = msa.node_job(k)
+        assert oracle.dp_align(left, right, model, band).same_alignment(msa.node_result(k))
+
+
+def test_export_import_rebuilds_the_same_parents(oracle, pg):
+    names, seqs, nwk = synth.evolve_balanced(8, 300, branch=0.04, sub=0.04, indel_start=0.012, mean_len=5, seed=13)
+    a = walk(oracle, names, seqs, nwk, use_anchors=0).align()
+    b = host.Msa(names, seqs, nwk, use_anchors=0)            # never aligns anything itself
+    n = len(names)
+    total = 0
+    while b.remaining > 0:
+        ready = b.ready()
+        assert ready
+        for node in ready:
+            buf = a.export_result(node)
+            total += buf.shape[0]
+            b.import_result(buf)
+    b.finish()
+    assert b.alignment() == a.alignment()
+    cols = sum(a.node_result(k).cols.shape[0] for k in range(a.n_internal))
+    assert total < 64 * a.n_internal + cols + 4 * sum(
+        a.node_result(k).left_used.shape[0] + a.node_result(k).right_used.shape[0] for k in range(a.n_internal)) + 8
+    for node in range(n, 2 * n - 1):
+        ga, gb = a.node_graph(node), b.node_graph(node)
+        fa, fb = ga.flatten(), gb.flatten()
+        for f in ("state", "bwd_off", "bwd_src", "bwd_eid"):
+            assert np.array_equal(getattr(fa, f), getattr(fb, f))
+        assert fa.bwd_logw.tobytes() == fb.bwd_logw.tobytes()
+        for x, y in zip(ga.attrs(), gb.attrs()):
+            assert x.tobytes() == y.tobytes()
+    with pytest.raises(Exception):
+        b.import_result(a.export_result(n))                  # already done: refused
+    with pytest.raises(Exception):
+        host.Msa(names, seqs, nwk, use_anchors=0).import_result(a.export_result(2 * n - 2))   # root before its children
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pagan2_msa_amd import dist as pdist, host as h, synth as sy
+    import oracle
+    oracle.build()
+    names, seqs, nwk = sy.evolve_balanced(16, 260, branch=0.02, sub=0.02, indel_start=0.006, mean_len=4, seed=14)
+    log = []
+    msa = h.Msa(names, seqs, nwk, use_anchors=1, prefix_hit_length=20)
+    msa.set_batch_backend(oracle_backend(oracle, log))
+    rounds = pdist.align_sharded(msa, h.assign_units)
+    mine = [k for k in range(msa.n_internal) if msa.node_device(k) >= 0]
+    np.save(os.path.join(out_dir, "rows%d.npy" % rank), np.array(msa.alignment()))
+    np.save(os.path.join(out_dir, "scores%d.npy" % rank), np.array([msa.node_info(k).score for k in range(msa.n_internal)]))
+    np.save(os.path.join(out_dir, "mine%d.npy" % rank), np.array(mine))
+    np.save(os.path.join(out_dir, "rounds%d.npy" % rank), np.array(rounds))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_shard_one_tree_and_exchange_paths(tmp_path, oracle, pg, world):
+    mp.spawn(_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    names, seqs, nwk = synth.evolve_balanced(16, 260, branch=0.02, sub=0.02, indel_start=0.006, mean_len=4, seed=14)
+    one = walk(oracle, names, seqs, nwk, use_anchors=1, prefix_hit_length=20).align()
+    want_rows = np.array(one.alignment())
+    want_scores = np.array([one.node_info(k).score for k in range(one.n_internal)])
+    owned = []
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("rows%d.npy" % r)), want_rows)          # every rank ends with the whole MSA
+        assert np.array_equal(np.load(tmp_path / ("scores%d.npy" % r)), want_scores)
+        owned += np.load(tmp_path / ("mine%d.npy" % r)).tolist()
+        rounds = np.load(tmp_path / ("rounds%d.npy" % r))
+        assert rounds[:, 0].tolist() == [8, 4, 2, 1]                                       # the tree's levels
+        assert rounds[0, 1] in (8 // world, 8 // world + 1)                                # level 1 is split
+    assert sorted(owned) == list(range(15))                                                # every node aligned exactly once
