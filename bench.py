@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- DP cells/s of the pairwise graph-vs-graph Viterbi aligner on MI355X.
 
-Workload (BASELINE.json configs[3], the headline): 32 x 100 kb synthetic DNA on a balanced
-guide tree (branch 0.01), prefix anchors with --anchors-offset 15.  Untimed setup runs the
-whole progressive alignment on the GPU (twice; the wall-clock of the second walk is reported as
-e2e_wall_s, of the process's first as e2e_wall_first_in_process_s) and
-keeps every internal node's aligner inputs -- child graphs, model table, band -- resident in
-HBM.  A timed "step" is one pass of the hot path (matrix fill + end corner + traceback) over
-that batch of 31 node alignments.  value = in-band DP cells per second over all ranks.
+    python bench.py [--gpus 1] --steps K --warmup W [--workload NAME]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+One GPU (the default; workload = BASELINE.json configs[3], the headline: 32 x 100 kb synthetic DNA on
+a balanced guide tree, branch 0.01, prefix anchors, --anchors-offset 15).  Untimed setup walks the
+tree on the GPU (twice; the second walk's wall-clock is e2e_wall_s) and keeps every internal node's
+aligner inputs -- child graphs, model table, band -- resident in HBM, one resident batch per guide-tree
+level.  A timed "step" is one pass of the hot path (matrix fill + end corner + traceback) over the whole
+tree IN DEPENDENCY ORDER: the level batches run one after the other, each waiting for the one before,
+exactly as a progressive alignment has to (a parent's inputs come from its children).
+value = in-band DP cells of the tree / time of that pass.  The same nodes launched side by side as one
+batch (no dependency order; the round-1 headline) are reported as value_resident_batch.
 
-With N > 1 every rank runs the same-sized workload (its own seed) on its own GPU: the path
-shards by independent node alignments, there is no collective in the data path ("weak").
+N > 1 GPUs (workload = configs[4]: 512 x 10 kb, branch 0.02, anchored): ONE tree, its ready nodes dealt
+over the N ranks round by round (pagan2_msa_amd.dist.align_sharded: each rank runs model + anchors + DP +
+parent graph for its share on its own GPU, the finished paths are all-gathered, every rank rebuilds the
+other ranks' parents).  A step is one whole progressive alignment; value = cells of the tree / wall-clock
+of the walk (max over ranks): "strong" scaling.  Rank 0 also times the same walk alone on its GPU
+(value_one_gpu_same_workload) so that a speed-up can be read off one line.  Without torchrun,
+`--gpus N` runs the in-process work queue over N devices of this process instead (one feeder thread
+per device, pagan_msa_align with n_devices = N).
 """
 import argparse
 import json
@@ -25,15 +33,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (leaves, length, branch, sub, indel_start, mean_len, anchors)
-    "cfg4_32x100kb_dna_anchored": (32, 100000, 0.01, 0.008, 0.0008, 4.0, 1),
-    "cfg2_16x2kb_dna_full": (16, 2000, 0.05, 0.04, 0.004, 4.0, 0),
-    "smoke_8x3kb_dna_anchored": (8, 3000, 0.01, 0.008, 0.0008, 4.0, 1),
-    # BASELINE.json configs[4] on one GPU: 511 node alignments, up to 256 of them side by side
-    "cfg5_512x10kb_dna_anchored": (512, 10000, 0.01, 0.008, 0.0008, 4.0, 1),
+    # name: (config index, leaves, length, branch, sub, indel_start, mean_len, anchors, alphabet)
+    "cfg4_32x100kb_dna_anchored": (4, 32, 100000, 0.01, 0.008, 0.0008, 4.0, 1, "ACGT"),
+    "cfg2_16x2kb_dna_full": (2, 16, 2000, 0.05, 0.04, 0.004, 4.0, 0, "ACGT"),
+    "cfg3_64x500aa_protein_full": (3, 64, 500, 0.05, 0.04, 0.004, 4.0, 0, "ARNDCQEGHILKMFPSTWYV"),
+    "cfg5_512x10kb_dna_anchored": (5, 512, 10000, 0.02, 0.016, 0.0016, 4.0, 1, "ACGT"),
+    "smoke_8x3kb_dna_anchored": (0, 8, 3000, 0.01, 0.008, 0.0008, 4.0, 1, "ACGT"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_CELL = 36            # 3 states x (f64 score + u32 back-pointer), SURVEY.md s.8(d)
+STEP_FLOOR_US = 0.25           # a lone wave's ~100 straight-line instructions per diagonal x 5.5 cycles at 2.4 GHz
+                               # (tools/ubench/issue_rate.hip)
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_fill.json")
+
+
+def make_inputs(workload):
+    from pagan2_msa_amd import synth
+    cfg, leaves, length, branch, sub, indel, mean_len, anchors, alphabet = WORKLOADS[workload]
+    return synth.evolve_balanced(leaves, length, branch=branch, sub=sub, indel_start=indel, mean_len=mean_len,
+                                 seed=20240807 + cfg, alphabet=alphabet)
 
 
 def main():
@@ -41,131 +59,268 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg4_32x100kb_dna_anchored", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-stale-traffic", action="store_true",
+                    help="report roofline.traffic = null instead of failing when %s does not match this run" % PMC_PROFILE)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
-    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the aligner has no CPU path")
+    if world == 1 and args.gpus > torch.cuda.device_count():
+        raise SystemExit("bench.py: --gpus %d but %d device(s) visible; start one rank per GPU with torch.distributed.run"
+                         % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus > 1:
+        return bench_work_queue(args, rank, local_rank, world)
+    return bench_one_gpu(args, local_rank)
 
-    import numpy as np
-    import pagan2_msa_amd as pg
-    from pagan2_msa_amd import abi, host, synth
+
+# ---------------------------------------------------------------------------------------------------------------
+def bench_one_gpu(args, device):
     import ctypes as C
+    import numpy as np
+    import torch
+    import pagan2_msa_amd as pg
+    from pagan2_msa_amd import abi, host
 
-    pg.lib().pagan_dp_select_device(local_rank)
-    leaves, length, branch, sub, indel, mean_len, anchors = WORKLOADS[args.workload]
-    seed = 20240807 + 4 + 1000 * rank
-    names, seqs, newick = synth.evolve_balanced(leaves, length, branch=branch, sub=sub, indel_start=indel,
-                                                mean_len=mean_len, seed=seed)
+    workload = args.workload or "cfg4_32x100kb_dna_anchored"
+    cfg, leaves, length, branch, sub, indel, mean_len, anchors, alphabet = WORKLOADS[workload]
+    L = pg.lib()
+    L.pagan_dp_select_device(device)
+    names, seqs, newick = make_inputs(workload)
 
-    # ---- untimed setup: whole progressive alignment on the GPU, inputs stay resident ----
-    # (twice: the first walk also pays the process's one-off costs -- code object load, first hipMalloc,
-    # staging buffers; the second is what a tree costs in a running process)
+    # ---- untimed setup: whole progressive alignment on the GPU (twice: the first walk also pays the process's
+    # one-off costs -- code object load, first hipMalloc, staging buffers) ----
     t0 = time.time()
-    msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=local_rank, n_devices=1)
+    msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=device, n_devices=1)
     msa.align()
     e2e_wall_cold = time.time() - t0
     del msa
     t0 = time.time()
-    msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=local_rank, n_devices=1)
+    msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=device, n_devices=1)
     msa.align()
     e2e_wall = time.time() - t0
     tm = msa.timing()
     n_nodes = msa.n_internal
-    cjobs = (abi.CJob * n_nodes)()
-    for k in range(n_nodes):
-        cjobs[k] = msa.node_cjob(k)
-    opts = abi.COpts(0, local_rank)
-    L = pg.lib()
-    hb = C.c_void_p()
-    rc = L.pagan_batch_create(n_nodes, cjobs, C.byref(opts), C.byref(hb))
-    if rc != 0:
-        raise SystemExit("pagan_batch_create failed: %d" % rc)
-    cells = L.pagan_batch_cells(hb)
+    infos = [msa.node_info(k) for k in range(n_nodes)]
+    levels = sorted({i.level for i in infos})
+    opts = abi.COpts(0, device)
 
-    def step():
+    def resident(ks):
+        cjobs = (abi.CJob * len(ks))()
+        for a, k in enumerate(ks):
+            cjobs[a] = msa.node_cjob(k)
+        hb = C.c_void_p()
+        rc = L.pagan_batch_create(len(ks), cjobs, C.byref(opts), C.byref(hb))
+        if rc != 0:
+            raise SystemExit("pagan_batch_create failed: %d" % rc)
+        return hb
+
+    by_level = [[k for k in range(n_nodes) if infos[k].level == lv] for lv in levels]
+    batches = [resident(ks) for ks in by_level]
+    cells_level = [int(L.pagan_batch_cells(hb)) for hb in batches]
+    cells = sum(cells_level)
+    steps_level = [max(infos[k].left_sites + infos[k].right_sites - 3 for k in ks) for ks in by_level]   # diagonals
+
+    def run(hb):
         rc = L.pagan_batch_run(hb)
+        if rc == 0:
+            rc = L.pagan_batch_sync(hb)          # the next level's inputs depend on this one's results
         if rc != 0:
             raise SystemExit("pagan_batch_run failed: %d" % rc)
 
-    def fence():
-        L.pagan_batch_sync(hb)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+    def step():
+        for hb in batches:
+            run(hb)
 
     for _ in range(args.warmup):
         step()
-    fence()
-    fill_ms, trace_ms = [], []
+    torch.cuda.synchronize()
+    fill_ms = np.zeros((args.steps, len(batches)))
+    trace_ms = np.zeros((args.steps, len(batches)))
     ms = (C.c_double * 2)()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # HIP events on the library's own stream bracket each kernel of the step
-        L.pagan_batch_last_ms(hb, ms)
-        fill_ms.append(ms[0])
-        trace_ms.append(ms[1])
-    fence()
+    for s in range(args.steps):
+        for b, hb in enumerate(batches):
+            run(hb)
+            L.pagan_batch_last_ms(hb, ms)        # HIP events on the library's own stream bracket each kernel
+            fill_ms[s, b], trace_ms[s, b] = ms[0], ms[1]
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    from pagan2_msa_amd import dist as pdist
-    elapsed_max, total_cells = pdist.reduce_step(elapsed, cells, device="cuda")
 
-    # parity spot check of the resident batch against what the tree walk produced
-    res = (abi.CResult * n_nodes)()
-    rc = L.pagan_batch_fetch(hb, res)
-    ok = rc == 0 and all(abi.Result(res[k]).same_alignment(msa.node_result(k)) for k in range(n_nodes))
-    for k in range(n_nodes):
-        L.pagan_result_free(C.byref(res[k]))
+    # parity of the resident batches against what the tree walk produced
+    ok = True
+    for ks, hb in zip(by_level, batches):
+        res = (abi.CResult * len(ks))()
+        rc = L.pagan_batch_fetch(hb, res)
+        ok = ok and rc == 0 and all(abi.Result(res[a]).same_alignment(msa.node_result(k)) for a, k in enumerate(ks))
+        for a in range(len(ks)):
+            L.pagan_result_free(C.byref(res[a]))
+    for hb in batches:
+        L.pagan_batch_destroy(hb)
 
+    # the same nodes side by side, no dependency order (what round 1 reported as the headline)
+    hb_all = resident(list(range(n_nodes)))
+    run(hb_all)
+    t1 = time.perf_counter()
+    for _ in range(max(2, args.steps // 2)):
+        run(hb_all)
+    side_by_side = cells * max(2, args.steps // 2) / (time.perf_counter() - t1)
+    L.pagan_batch_destroy(hb_all)
+
+    fill_launch_ms = fill_ms.mean(axis=0)                      # per level launch
+    fill_step_ms = float(fill_launch_ms.sum())
+    achieved = BYTES_PER_CELL * cells / (fill_step_ms * 1e-3) / 1e9
+    crit_steps = int(sum(steps_level))
+    us_per_step = 1e3 * fill_step_ms / crit_steps
+    out = {
+        "metric": ("DP cells/sec, 32x100 kb DNA progressive align (hot path in dependency order: fill + traceback per tree level)"
+                   if workload.startswith("cfg4") else
+                   "DP cells/sec, %s (hot path in dependency order; not the headline workload)" % workload),
+        "value": cells * args.steps / elapsed,
+        "unit": "cells/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": workload, "leaves": leaves, "length": length, "branch": branch,
+                   "data_type": "protein" if len(alphabet) == 20 else "dna",
+                   "anchors": "prefix, offset 15" if anchors else "none", "node_alignments": n_nodes,
+                   "levels": [len(ks) for ks in by_level], "cells_per_step": int(cells),
+                   "order": "guide-tree levels one after the other (a parent needs its children)"},
+        "value_resident_batch": side_by_side,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "kernel": fill_kernel(anchors), "launches_per_step": len(batches),
+                     "avg_launch_ms": float(fill_launch_ms.mean()), "launch_ms_by_level": [float(x) for x in fill_launch_ms],
+                     "cells_by_level": cells_level,
+                     "algorithmic_bytes_per_cell": BYTES_PER_CELL,
+                     "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells / len(batches),
+                     "latency": {"steps": crit_steps, "us_per_step": us_per_step, "floor_us_per_step": STEP_FLOOR_US,
+                                 "frac_of_floor": STEP_FLOOR_US / us_per_step,
+                                 "note": "steps = anti-diagonals on the critical path (longest alignment of every level); "
+                                         "floor from tools/ubench/issue_rate.hip"}},
+        "kernels_ms": {"fill": fill_step_ms, "end_and_trace": float(trace_ms.mean(axis=0).sum())},
+        "e2e_wall_s": e2e_wall,
+        "e2e_wall_first_in_process_s": e2e_wall_cold,
+        "e2e_cells_per_s": cells / e2e_wall,
+        "e2e_breakdown_s": tm,
+        "parity_self_check": bool(ok),
+    }
+    out["roofline"].update(pmc_traffic(workload, cells, fill_kernel(anchors), len(batches), args.allow_stale_traffic))
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(msa, n_nodes, args.cpu_seconds)
+        ok = ok and out["cpu_baseline"]["matches_gpu"]
+    print(json.dumps(out))
+    if not ok:
+        raise SystemExit("bench.py: parity self-check FAILED")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def bench_work_queue(args, rank, local_rank, world):
+    import torch
+    import torch.distributed as dist
+    import pagan2_msa_amd as pg
+    from pagan2_msa_amd import dist as pdist, host
+
+    workload = args.workload or "cfg5_512x10kb_dna_anchored"
+    cfg, leaves, length, branch, sub, indel, mean_len, anchors, alphabet = WORKLOADS[workload]
+    in_process = world == 1                      # no torchrun: one process feeds args.gpus devices
+    pg.lib().pagan_dp_select_device(local_rank)
+    if not in_process:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    names, seqs, newick = make_inputs(workload)  # the same tree on every rank
+
+    def walk(sharded):
+        """One progressive alignment.  Returns (wall seconds of the alignment, msa)."""
+        if in_process:
+            msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=0, n_devices=args.gpus if sharded else 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            msa.align()
+            return time.perf_counter() - t0, msa
+        msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=local_rank, n_devices=1)
+        if sharded:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if sharded:
+            pdist.align_sharded(msa, host.assign_units, device="cuda")
+            torch.cuda.synchronize()
+            dist.barrier()
+        else:
+            msa.align()
+        return time.perf_counter() - t0, msa
+
+    # rank 0 alone first: the one-GPU time of the same workload (and the reference alignment for the check below)
+    solo_s, solo = None, None
     if rank == 0:
-        fill_avg_ms = float(np.mean(fill_ms))
-        achieved = BYTES_PER_CELL * cells / (fill_avg_ms * 1e-3) / 1e9
+        walk(False)
+        solo_s, solo = walk(False)
+    for _ in range(args.warmup):
+        walk(True)
+    elapsed, msa = 0.0, None
+    for _ in range(args.steps):
+        dt, msa = walk(True)
+        elapsed += dt
+    if in_process:
+        elapsed_max = elapsed
+    else:
+        elapsed_max, _ = pdist.reduce_step(elapsed, 0, device="cuda")
+    if rank == 0:
+        n_nodes = msa.n_internal
+        cells = sum(int(msa.node_info(k).cells) for k in range(n_nodes))
+        same = msa.alignment() == solo.alignment() and all(
+            msa.node_info(k).score == solo.node_info(k).score and msa.node_info(k).cells == solo.node_info(k).cells
+            for k in range(n_nodes))
+        mine = sum(1 for k in range(n_nodes) if msa.node_device(k) >= 0)
         out = {
-            "metric": ("DP cells/sec, 32x100 kb DNA progressive align (hot path: fill + traceback)"
-                       if args.workload.startswith("cfg4") else
-                       "DP cells/sec, %s (hot path: fill + traceback; not the headline workload)" % args.workload),
-            "value": total_cells * args.steps / elapsed_max,
+            "metric": "DP cells/sec, %s, one guide tree farmed over %d GPUs as a work queue (end-to-end walk)" % (workload, args.gpus),
+            "value": cells * args.steps / elapsed_max,
             "unit": "cells/s",
-            "n_gpus": world,
+            "n_gpus": args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed_max / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": args.workload, "leaves": leaves, "length": length, "branch": branch,
+            "config": {"workload": workload, "leaves": leaves, "length": length, "branch": branch,
                        "anchors": "prefix, offset 15" if anchors else "none", "node_alignments": n_nodes,
-                       "cells_per_step_per_gpu": int(cells), "parallelism": "independent node alignments per GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, cells),
-                         "kernel": fill_kernel(anchors), "avg_launch_ms": fill_avg_ms,
-                         "algorithmic_bytes_per_cell": BYTES_PER_CELL,
-                         "algorithmic_bytes_per_launch": BYTES_PER_CELL * int(cells)},
-            "kernels_ms": {"fill": fill_avg_ms, "end_and_trace": float(np.mean(trace_ms))},
-            "e2e_wall_s": e2e_wall,
-            "e2e_wall_first_in_process_s": e2e_wall_cold,
-            "e2e_breakdown_s": tm,
-            "parity_self_check": bool(ok),
+                       "cells_per_step": int(cells),
+                       "parallelism": ("in-process work queue over %d devices" % args.gpus) if in_process else
+                                      ("one rank per GPU, ready nodes dealt per round, paths all-gathered (RCCL); "
+                                       "rank 0 aligned %d of %d nodes" % (mine, n_nodes)),
+                       "step": "one whole progressive alignment: model + anchors + DP + parent graphs, host work included"},
+            "value_one_gpu_same_workload": cells / solo_s,
+            "one_gpu_wall_s": solo_s,
+            "speedup_vs_one_gpu": solo_s / (elapsed_max / args.steps),
+            "e2e_breakdown_s_rank0": msa.timing(),
+            "parity_self_check": bool(same),
+            "roofline": None, "cpu_baseline": None,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(msa, n_nodes, args.cpu_seconds)
         print(json.dumps(out))
-    L.pagan_batch_destroy(hb)
-    if world > 1:
+        if not same:
+            if not in_process:
+                dist.destroy_process_group()
+            raise SystemExit("bench.py: the sharded walk differs from the one-GPU walk")
+    if not in_process:
         dist.destroy_process_group()
 
 
@@ -178,19 +333,30 @@ def fill_kernel(anchors):
     return "pg_fill_ring" if os.environ.get("PAGAN_DP_FILL") == "ring" else "pg_fill_pipe"
 
 
-def pmc_traffic(workload, cells):
-    """HBM bytes per launch of the fill kernel from the committed rocprofv3 --pmc passes of this same
-    command (WRITE_SIZE and FETCH_SIZE need separate passes and cannot be collected from inside
-    the bench); None when the profile is for another workload, kernel or cell count."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fill.json")
+def pmc_traffic(workload, cells, kernel, launches, allow_stale):
+    """HBM bytes per launch of the fill kernel from the committed rocprofv3 --pmc passes of this same command
+    (WRITE_SIZE and FETCH_SIZE need separate profiler passes, they cannot be read from inside the bench).  The
+    profile names its workload, kernel and cells; a mismatch means it was taken on something else and is an error
+    (--allow-stale-traffic turns that into traffic = null)."""
+    path = os.path.join(ROOT, PMC_PROFILE)
     try:
         prof = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    if (prof.get("workload") != workload or prof.get("cells_per_launch") != int(cells) or
-            prof.get("kernel") != fill_kernel(WORKLOADS[workload][6])):
-        return None
-    return prof["hbm_bytes_per_launch"]
+        why = None
+        if prof.get("workload") != workload:
+            why = "profile is for workload %r" % prof.get("workload")
+        elif prof.get("kernel") != kernel:
+            why = "profile is for kernel %r, this run launches %r" % (prof.get("kernel"), kernel)
+        elif prof.get("cells_per_step") != int(cells):
+            why = "profile covers %r cells per step, this run %d" % (prof.get("cells_per_step"), cells)
+    except (OSError, ValueError) as e:
+        prof, why = None, "cannot read it: %s" % e
+    if why is None:
+        return {"traffic": prof["hbm_bytes_per_step"] / launches, "traffic_source": PMC_PROFILE,
+                "traffic_over_algorithmic": prof["hbm_bytes_per_step"] / (BYTES_PER_CELL * cells)}
+    if workload.startswith("cfg4") and not allow_stale:
+        raise SystemExit("bench.py: %s does not describe this run (%s); re-collect it (DESIGN.md s.4) or pass "
+                         "--allow-stale-traffic" % (PMC_PROFILE, why))
+    return {"traffic": None, "traffic_source": "%s not applicable: %s" % (PMC_PROFILE, why)}
 
 
 def cpu_baseline(msa, n_nodes, budget_s):

@@ -1,4 +1,10 @@
-"""Builds libpagan_dp.so (HIP, gfx950) in-tree with hipcc.  Cross-compiles without a GPU."""
+"""Builds libpagan_dp.so (HIP, gfx950) in-tree with hipcc.  Cross-compiles without a GPU.
+
+The library is rebuilt whenever the digest of its inputs (compiler flags + every source and header it is made
+from) differs from the one recorded beside it at the last build, so a stale or differently-flagged binary
+(tools/build_stamps.sh writes its diagnostic build to another file for the same reason) is never taken for
+the product."""
+import hashlib
 import os
 import shutil
 import subprocess
@@ -6,10 +12,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpagan_dp.so")
-SOURCES = ["dp_abi.hip", "dp_kernels.hip", "dp_pipe.hip", "dp_tiles.hip", "host_model.cpp", "host_graph.cpp", "host_anchors.cpp",
-           "host_tree.cpp"]
+SOURCES = ["dp_abi.hip", "dp_kernels.hip", "dp_pipe.hip", "dp_tiles.hip", "dp_fb.hip", "host_model.cpp", "host_graph.cpp",
+           "host_anchors.cpp", "host_tree.cpp", "host_pileup.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-result", "-pthread"]
+         "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-pthread"]
 
 
 def _hipcc():
@@ -23,23 +29,39 @@ def sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
-def stale():
-    if not os.path.exists(LIB):
+def inputs():
+    inc = os.path.join(HERE, "..", "include")
+    return (sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) +
+            sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")))
+
+
+def digest():
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for p in inputs():
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def stale(lib=LIB):
+    if not os.path.exists(lib) or not os.path.exists(lib + ".digest"):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    deps.append(os.path.join(HERE, "..", "include", "pagan_dp.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(lib + ".digest") as f:
+        return f.read().strip() != digest()
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
-        return LIB
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB] + sources()
+def build(force=False, verbose=False, out=LIB):
+    """Compiles every source into `out`.  Returns the path."""
+    if not force and not stale(out):
+        return out
+    cmd = [_hipcc()] + FLAGS + ["-o", out] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB
+    with open(out + ".digest", "w") as f:
+        f.write(digest() + "\n")
+    return out
 
 
 if __name__ == "__main__":

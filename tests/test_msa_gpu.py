@@ -88,3 +88,61 @@ def test_fasta_output_in_tree_order(pg, tmp_path):
     for k, nm in enumerate(names):
         assert "".join(entries[nm]) == rows[k]
         assert all(len(x) == 50 for x in entries[nm][:-1])
+
+
+AA = "ARNDCQEGHILKMFPSTWYV"
+
+
+def check_graphs(msa, seqs, oracle, leaf_alpha, char_as):
+    """Every node's graph as the product built it against the oracle's builder fed the same paths.  The two
+    branches under a node have the same length in these synthetic trees, so each is half the node's dist."""
+    n = len(seqs)
+    og = [oracle.OGraph.leaf(s, leaf_alpha) for s in seqs] + [None] * (n - 1)
+    for k in range(msa.n_internal):
+        info = msa.node_info(k)
+        pars = oracle.protein_model(info.dist)[1] if char_as == 20 else oracle.dna_parsimony()
+        og[info.node] = oracle.OGraph.parent(og[info.left], og[info.right], msa.node_result(k), info.dist / 2,
+                                             info.dist / 2, pars, char_as)
+        a, b = msa.node_graph(info.node).flatten(), og[info.node].flatten()
+        for f in ("state", "bwd_off", "bwd_src", "bwd_eid"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), "node %d: %s" % (info.node, f)
+        assert a.bwd_logw.tobytes() == b.bwd_logw.tobytes()
+
+
+def test_protein_tree_16x200(pg, oracle):
+    """BASELINE config 3 scaled down: WAG, 211-letter alphabet, no anchors -> full matrices (tiled kernel)."""
+    names, seqs, nwk = synth.evolve_balanced(16, 200, branch=0.05, sub=0.08, indel_start=0.01, mean_len=4, seed=31,
+                                             alphabet=AA)
+    msa = host.Msa(names, seqs, nwk, use_anchors=0).align()          # data type guessed from the residues
+    assert msa.data_type == 2
+    check_tree(msa, seqs, oracle)
+    left, right, model, band = msa.node_job(msa.n_internal - 1)
+    assert model.n_states == 211 and band is None
+    assert max(left.state.max(), right.state.max()) > 20              # pair codes enter the upper DPs
+    want, _ = oracle.protein_model(msa.node_info(0).dist)
+    assert msa.node_job(0)[2].table.tobytes() == want.table.tobytes()
+    check_graphs(msa, seqs, oracle, oracle.protein_leaf_alphabet(), 20)
+
+
+def test_protein_tree_banded_large_table_on_the_banded_kernel(pg, oracle):
+    names, seqs, nwk = synth.evolve_balanced(8, 700, branch=0.02, sub=0.03, indel_start=0.004, mean_len=4, seed=32,
+                                             alphabet=AA)
+    msa = host.Msa(names, seqs, nwk, use_anchors=1, data_type=2, prefix_hit_length=12).align()
+    check_tree(msa, seqs, oracle)
+    assert all(msa.node_job(k)[3] is not None for k in range(msa.n_internal))
+
+
+def test_work_queue_over_devices_cfg5_reduced(pg, oracle):
+    """BASELINE config 5 scaled down (64 x 1 kb, anchored): the ready-queue walk over min(2, #GPUs) devices."""
+    ndev = min(2, pg.device_count())
+    names, seqs, nwk = synth.evolve_balanced(64, 1000, branch=0.02, sub=0.016, indel_start=0.0016, mean_len=4, seed=33)
+    msa = host.Msa(names, seqs, nwk, use_anchors=1, n_devices=ndev, first_device=0).align()
+    check_tree(msa, seqs, oracle)
+    assert {msa.node_device(k) for k in range(msa.n_internal)} == set(range(ndev))
+    # the round-at-a-time API (one process per GPU drives it through dist.align_sharded) gives the same walk
+    from pagan2_msa_amd import dist as pdist
+    again = host.Msa(names, seqs, nwk, use_anchors=1)
+    rounds = pdist.align_sharded(again, host.assign_units)
+    assert [r[0] for r in rounds] == [32, 16, 8, 4, 2, 1]
+    assert again.alignment() == msa.alignment()
+    assert all(again.node_result(k).same_alignment(msa.node_result(k)) for k in range(63))
