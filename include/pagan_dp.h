@@ -199,6 +199,38 @@ int  pagan_batch_debug_poison(pagan_batch *b);
 void    pagan_dp_release_cache(void);
 int64_t pagan_dp_cached_device_bytes(int32_t device);
 
+/* ---- forward/backward full probability, posteriors, path sampling -----------------------------
+ * The reference's compute_full_score pass (--full-probability, --sample-path; basic_alignment.h:621-625,
+ * viterbi_alignment.cpp:329-371, 740-854, 975-1034, 1571-1662, 2259-2305; sampling :1193-1322), in log
+ * space on the GPU: the reference multiplies raw probabilities and under/overflows on long inputs.      */
+typedef struct pagan_model_prob {   /* Evol_model's probability-space accessors (evol_model.h:70-88)       */
+    int32_t      n_states;
+    const float *score;             /* [S*S] Evol_model::score(a,b) = score[a + b*S] (charPr as float)     */
+    float        gap_open;          /* Evol_model::gap_open()  = id_prob                                   */
+    float        gap_ext;           /* Evol_model::gap_ext()   = ext_prob                                  */
+    float        non_gap;           /* Evol_model::non_gap()   = match_prob;  gap_close() is 1             */
+} pagan_model_prob;
+
+typedef struct pagan_fb pagan_fb;   /* forward and backward matrices of one alignment, resident in HBM     */
+
+/* Runs both passes.  left/right must stay valid until pagan_fb_destroy (sample_path reads them).          */
+int  pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_model_prob *model,
+                  const pagan_band *band, const pagan_opts *opts, pagan_fb **out);
+/* log of max_end.fwd_score ("full probability", VA:1562-1563) and of match[0][0].bwd_score (VA:345-349);
+ * the reference checks their ratio (VA:351-355).                                                          */
+int  pagan_fb_totals(const pagan_fb *fb, double *log_fwd, double *log_bwd, int64_t *cells);
+/* which: 0 log forward, 1 log backward, 2 posterior (compute_posterior_score, VA:1029-1034);
+ * dst [Lx][Ly][3] row-major, states X, Y, M; outside the tunnel -inf / 0.                                  */
+int  pagan_fb_dump(pagan_fb *fb, int32_t which, double *dst);
+/* posterior of n cells given as (state, i, j) triples                                                     */
+int  pagan_fb_posterior_cells(pagan_fb *fb, int32_t n, const int32_t *cells, double *post);
+/* sample_new_path (VA:1193-1322): u[k] in [0,1) replaces rand()/(RAND_MAX+1), one per step, the end corner
+ * first (at most Lx+Ly+1 are consumed).  `out` has the shape of a Viterbi result (free with
+ * pagan_result_free); visited (optional, 3*(Lx+Ly) ints): the path's cells end -> start as (i, j, state).  */
+int  pagan_fb_sample_path(pagan_fb *fb, const double *u, int32_t n_u, pagan_result *out,
+                          int32_t *visited, int32_t *n_visited);
+void pagan_fb_destroy(pagan_fb *fb);
+
 const char *pagan_dp_version(void);
 
 #ifdef __cplusplus

@@ -150,6 +150,9 @@ int  pagan_dna_model(const float base_freq[4], double distance, float *table, fl
 /* Protein (WAG) Evol_model for a distance: table [a + b*211] (211x211 floats), params as above,
  * parsimony [i + j*211] (model_factory.cpp:304-541, 1478-1595, 1871-1960, 2155-2219).              */
 int  pagan_protein_model(double distance, float *table, float *params, int32_t *parsimony);
+/* The same model in probability space, what the forward/backward pass takes (pagan_model_prob):
+ * score [a + b*S] = Evol_model::score, params[3] = gap_open, gap_ext, non_gap.  data_type 1 DNA, 2 protein. */
+int  pagan_model_prob_table(int32_t data_type, const float *base_freq, double distance, float *score, float *params);
 /* Alphabets of a data type (1 DNA, 2 protein): leaf_alphabet (state = position of the residue,
  * Sequence::full_char_alphabet) and ancestral_alphabet (the character an internal state prints as,
  * Model_factory::ancestral_character_alphabet); both >= 212 bytes.  Returns the number of states.  */

@@ -19,7 +19,7 @@ DNA_ALPHABET = "ACGTRYMKWSBDHVN"      # Model_factory::dna_full_char_alphabet, m
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_dp.cpp", "oracle_host.cpp", "oracle_model.cpp", "wag_data.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_dp.cpp", "oracle_host.cpp", "oracle_model.cpp", "oracle_fb.cpp", "wag_data.h", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "pagan_dp.h"))
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
@@ -36,7 +36,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         gp, mp, bp, op, rp = (C.POINTER(abi.CGraph), C.POINTER(abi.CModel), C.POINTER(abi.CBand),
                               C.POINTER(abi.COpts), C.POINTER(abi.CResult))
-        i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        i32p, f32p, f64p = C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_double)
         L.oracle_dp_align.argtypes = [gp, gp, mp, bp, op, rp]
         L.oracle_dp_align.restype = C.c_int
         L.oracle_result_free.argtypes = [rp]
@@ -70,9 +70,15 @@ def lib():
         L.oracle_dna_model.restype = C.c_int
         L.oracle_protein_model.argtypes = [C.c_double, f32p, f32p, i32p]
         L.oracle_protein_model.restype = C.c_int
-        f64p = C.POINTER(C.c_double)
         L.oracle_eigen_qrev.argtypes = [f64p, f64p, C.c_int, f64p, f64p, f64p]
         L.oracle_eigen_qrev.restype = C.c_int
+        L.oracle_model_prob.argtypes = [C.c_int, f32p, C.c_double, f32p, f32p]
+        L.oracle_model_prob.restype = C.c_int
+        L.oracle_fb.argtypes = [gp, gp, C.c_int32, f32p, C.c_float, C.c_float, C.c_float, bp, C.c_int, f64p, f64p, f64p, f64p]
+        L.oracle_fb.restype = C.c_int
+        L.oracle_sample_path.argtypes = [gp, gp, C.c_int32, f32p, C.c_float, C.c_float, C.c_float, f64p, f64p, C.c_int,
+                                         i32p, i32p]
+        L.oracle_sample_path.restype = C.c_int
         _lib = L
     return _lib
 
@@ -199,6 +205,46 @@ def protein_model(dist):
     pars = np.zeros(211 * 211, np.int32)
     lib().oracle_protein_model(float(dist), _fp(table), _fp(params), _ip(pars))
     return abi.Model(table.reshape(211, 211).T, *params), pars
+
+
+def model_prob(data_type, dist, base_freq=None):
+    """abi.ModelProb (Evol_model::score / gap_open / gap_ext / non_gap) restated in oracle_model.cpp."""
+    S = 211 if data_type == 2 else 15
+    score = np.zeros(S * S, np.float32)
+    params = np.zeros(3, np.float32)
+    bf = np.ascontiguousarray(base_freq if base_freq is not None else [0.25] * 4, np.float32)
+    lib().oracle_model_prob(int(data_type), _fp(bf), float(dist), _fp(score), _fp(params))
+    return abi.ModelProb(score.reshape(S, S).T, *params)
+
+
+def fb(left, right, mp, band=None, log_space=True, matrices=True):
+    """Forward/backward restated (oracle_fb.cpp).  Returns (log_fwd, log_bwd, posterior[Lx,Ly,3], log_f[Lx,Ly,3])."""
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    lf, lb = C.c_double(), C.c_double()
+    post = np.zeros((Lx, Ly, 3)) if matrices else None
+    logf = np.zeros((Lx, Ly, 3)) if matrices else None
+    dp = C.POINTER(C.c_double)
+    rc = lib().oracle_fb(C.byref(left.c), C.byref(right.c), mp.n_states, _fp(mp.table), mp.gap_open, mp.gap_ext, mp.non_gap,
+                         C.byref(band.c) if band is not None else None, 1 if log_space else 0, C.byref(lf), C.byref(lb),
+                         post.ctypes.data_as(dp) if matrices else None, logf.ctypes.data_as(dp) if matrices else None)
+    if rc != 0:
+        raise RuntimeError("oracle_fb failed: %d" % rc)
+    return lf.value, lb.value, post, logf
+
+
+def sample_path(left, right, mp, log_f, u):
+    """sample_new_path restated: visited cells end -> start as rows (i, j, state), and the end pick (state, i, j)."""
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    cells = np.zeros((Lx + Ly + 2, 3), np.int32)
+    end = np.zeros(3, np.int32)
+    lf = np.ascontiguousarray(log_f, np.float64)
+    uu = np.ascontiguousarray(u, np.float64)
+    dp = C.POINTER(C.c_double)
+    n = lib().oracle_sample_path(C.byref(left.c), C.byref(right.c), mp.n_states, _fp(mp.table), mp.gap_open, mp.gap_ext,
+                                 mp.non_gap, lf.ctypes.data_as(dp), uu.ctypes.data_as(dp), int(uu.shape[0]), _ip(cells), _ip(end))
+    if n < 0:
+        raise RuntimeError("oracle_sample_path failed")
+    return cells[:n], end
 
 
 def eigen_qrev(Q, pi):

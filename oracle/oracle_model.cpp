@@ -346,7 +346,7 @@ struct Factory {
     }
 
     // alignment_model: table[a + b*char_fas] as floats (Evol_model::log_score returns float), params[4]
-    void alignment(double distance, bool pileup, float *table, float *params) const {
+    void alignment(double distance, bool pileup, float *table, float *params, float *prob = nullptr, float *prob_params = nullptr) const {
         const int as = char_as, fas = char_fas;
         std::vector<double> tmr(as * as), twr(charRoot), twu(charU), twv(charV);
         p_matrix(as, tmr.data(), twu.data(), twv.data(), twr.data(), distance);
@@ -415,6 +415,8 @@ struct Factory {
                 }
         }
         for (int k = 0; k < fas * fas; k++) table[k] = (float)logCharPr[k];
+        if (prob) for (int k = 0; k < fas * fas; k++) prob[k] = (float)charPr[k];          // Evol_model::score, evol_model.h:88
+        if (prob_params) { float id_prob = t, match_prob = 1.0 - 2 * t; prob_params[0] = id_prob; prob_params[1] = ext_prob; prob_params[2] = match_prob; }
     }
 };
 
@@ -434,6 +436,13 @@ int oracle_protein_model(double distance, float *table, float *params, int32_t *
     if (!f) { f = new Factory(); f->protein(); }
     f->alignment(distance, false, table, params);
     if (parsimony) for (size_t k = 0; k < f->parsimony.size(); k++) parsimony[k] = f->parsimony[k];
+    return 0;
+}
+
+int oracle_model_prob(int data_type, const float *bf, double distance, float *score, float *params) {
+    std::vector<float> table(211 * 211), lp(4);
+    if (data_type == 2) { Factory f; f.protein(); f.alignment(distance, false, table.data(), lp.data(), score, params); }
+    else { Factory f; f.dna(bf, 2.0f, 1.0f); f.alignment(distance, false, table.data(), lp.data(), score, params); }
     return 0;
 }
 

@@ -14,7 +14,7 @@ import ctypes as C
 import os
 
 from . import abi
-from .abi import Band, Graph, Model, Result  # noqa: F401
+from .abi import Band, Graph, Model, ModelProb, Result  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PAGAN_DP_LIB: a diagnostic build (tools/build_stamps.sh writes libpagan_dp_stats.so) instead of the product library
@@ -84,6 +84,78 @@ def align(left, right, model, band=None, flags=0, device=-1):
         return Result(res)
     finally:
         L.pagan_result_free(C.byref(res))
+
+
+class FullProbability:
+    """Forward/backward matrices of one alignment on the GPU (the reference's compute_full_score pass:
+    --full-probability, posteriors, --sample-path), in log space.
+
+        fb = FullProbability(left, right, model_prob, band)
+        fb.log_fwd, fb.log_bwd          log max_end.fwd_score, log match[0][0].bwd_score
+        fb.posterior()                  [Lx, Ly, 3] (X, Y, M), compute_posterior_score
+        fb.sample_path(u)               Result with the shape of a Viterbi result
+    """
+
+    def __init__(self, left, right, model_prob, band=None, device=-1):
+        import numpy as np
+        self._np = np
+        self._L = lib()
+        self.left, self.right, self.model, self.band = left, right, model_prob, band     # keep the arrays alive
+        opts = abi.COpts(0, device)
+        self._h = C.c_void_p()
+        _check(self._L.pagan_fb_run(C.byref(left.c), C.byref(right.c), C.byref(model_prob.c),
+                                    C.byref(band.c) if band is not None else None, C.byref(opts), C.byref(self._h)),
+               "pagan_fb_run")
+        a, b, c = C.c_double(), C.c_double(), C.c_int64()
+        _check(self._L.pagan_fb_totals(self._h, C.byref(a), C.byref(b), C.byref(c)), "pagan_fb_totals")
+        self.log_fwd, self.log_bwd, self.cells = a.value, b.value, c.value
+        self.shape = (left.n_sites - 1, right.n_sites - 1, 3)
+
+    def _dump(self, which):
+        out = self._np.zeros(self.shape, self._np.float64)
+        _check(self._L.pagan_fb_dump(self._h, which, out.ctypes.data_as(C.POINTER(C.c_double))), "pagan_fb_dump")
+        return out
+
+    def log_forward(self):
+        return self._dump(0)
+
+    def log_backward(self):
+        return self._dump(1)
+
+    def posterior(self):
+        return self._dump(2)
+
+    def posterior_cells(self, cells):
+        c = self._np.ascontiguousarray(cells, self._np.int32).reshape(-1, 3)
+        out = self._np.zeros(c.shape[0], self._np.float64)
+        _check(self._L.pagan_fb_posterior_cells(self._h, c.shape[0], c.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                out.ctypes.data_as(C.POINTER(C.c_double))), "pagan_fb_posterior_cells")
+        return out
+
+    def sample_path(self, u):
+        """(Result, visited cells end -> start as rows (i, j, state))."""
+        uu = self._np.ascontiguousarray(u, self._np.float64)
+        res = abi.CResult()
+        vis = self._np.zeros((self.shape[0] + self.shape[1] + 2, 3), self._np.int32)
+        n = C.c_int32()
+        rc = self._L.pagan_fb_sample_path(self._h, uu.ctypes.data_as(C.POINTER(C.c_double)), int(uu.shape[0]), C.byref(res),
+                                          vis.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n))
+        try:
+            _check(rc, "pagan_fb_sample_path")
+            return Result(res), vis[:n.value].copy()
+        finally:
+            self._L.pagan_result_free(C.byref(res))
+
+    def close(self):
+        if self._h:
+            self._L.pagan_fb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def debug_tiles(left, right, band=None):

@@ -103,6 +103,24 @@ class Model:
         self.c = CModel(self.n_states, _p(self.table, _f32p), *[float(x) for x in self.params])
 
 
+class CModelProb(C.Structure):
+    _fields_ = [("n_states", C.c_int32), ("score", _f32p), ("gap_open", C.c_float), ("gap_ext", C.c_float),
+                ("non_gap", C.c_float)]
+
+
+class ModelProb:
+    """pagan_model_prob: the model in probability space (forward/backward pass)."""
+
+    def __init__(self, score, gap_open, gap_ext, non_gap):
+        t = np.asarray(score, dtype=np.float32)
+        assert t.ndim == 2 and t.shape[0] == t.shape[1]
+        self.n_states = int(t.shape[0])
+        self.table = np.ascontiguousarray(t.T.reshape(-1))       # score(a,b) = table[a + b*S]
+        self.score = t
+        self.gap_open, self.gap_ext, self.non_gap = (float(np.float32(x)) for x in (gap_open, gap_ext, non_gap))
+        self.c = CModelProb(self.n_states, _p(self.table, _f32p), self.gap_open, self.gap_ext, self.non_gap)
+
+
 class Band:
     def __init__(self, upper, lower):
         self.upper = np.ascontiguousarray(upper, dtype=np.int32)
@@ -187,6 +205,19 @@ def declare(lib):
     lib.pagan_dp_release_cache.restype = None
     lib.pagan_dp_cached_device_bytes.argtypes = [C.c_int32]
     lib.pagan_dp_cached_device_bytes.restype = C.c_int64
+    mpp, f64p = C.POINTER(CModelProb), C.POINTER(C.c_double)
+    lib.pagan_fb_run.argtypes = [gp, gp, mpp, bp, op, C.POINTER(C.c_void_p)]
+    lib.pagan_fb_run.restype = C.c_int
+    lib.pagan_fb_totals.argtypes = [C.c_void_p, f64p, f64p, C.POINTER(C.c_int64)]
+    lib.pagan_fb_totals.restype = C.c_int
+    lib.pagan_fb_dump.argtypes = [C.c_void_p, C.c_int32, f64p]
+    lib.pagan_fb_dump.restype = C.c_int
+    lib.pagan_fb_posterior_cells.argtypes = [C.c_void_p, C.c_int32, _i32p, f64p]
+    lib.pagan_fb_posterior_cells.restype = C.c_int
+    lib.pagan_fb_sample_path.argtypes = [C.c_void_p, f64p, C.c_int32, rp, _i32p, _i32p]
+    lib.pagan_fb_sample_path.restype = C.c_int
+    lib.pagan_fb_destroy.argtypes = [C.c_void_p]
+    lib.pagan_fb_destroy.restype = None
     lib.pagan_dp_version.argtypes = []
     lib.pagan_dp_version.restype = C.c_char_p
     return lib
@@ -196,4 +227,5 @@ EXPORTED = ["pagan_dp_align", "pagan_dp_align_batch", "pagan_result_free", "paga
             "pagan_dp_count_cells", "pagan_dp_device_count", "pagan_dp_select_device", "pagan_batch_create",
             "pagan_batch_run", "pagan_batch_sync", "pagan_batch_fetch", "pagan_batch_last_ms",
             "pagan_batch_cells", "pagan_batch_destroy", "pagan_batch_debug_trace", "pagan_dp_debug_plan", "pagan_dp_debug_tiles", "pagan_dp_release_cache", "pagan_dp_cached_device_bytes", "pagan_batch_debug_scores", "pagan_batch_debug_poison",
-            "pagan_dp_version"]
+            "pagan_fb_run", "pagan_fb_totals", "pagan_fb_dump", "pagan_fb_posterior_cells", "pagan_fb_sample_path",
+            "pagan_fb_destroy", "pagan_dp_version"]

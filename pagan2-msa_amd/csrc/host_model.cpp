@@ -387,6 +387,9 @@ EvolModel ModelFactory::alignment_model(double distance, bool pileup_rates) cons
     }
     m.log_score.resize((size_t)S * S);
     for (size_t k = 0; k < m.log_score.size(); ++k) m.log_score[k] = (float)logpr[k];
+    m.score.resize((size_t)S * S);
+    for (size_t k = 0; k < m.score.size(); ++k) m.score[k] = (float)pr[k];      // Evol_model::score returns float
+    m.gap_open = (float)t; m.non_gap = (float)(1.0 - 2 * t); m.gap_ext = ext_prob;          // :1917-1918, 1899
     return m;
 }
 

@@ -22,6 +22,15 @@ struct EvolModel {
     int S = 0, char_as = 0;
     std::vector<float> log_score;        // [a + b*S]  (Evol_model::log_score, evol_model.h:87)
     float log_gap_open = 0, log_gap_ext = 0, log_gap_end_ext = 0, log_non_gap = 0;
+    // probability-space accessors (Evol_model::score / gap_open / gap_ext / non_gap, evol_model.h:70-88): the
+    // forward/backward pass works on these
+    std::vector<float> score;            // [a + b*S]
+    float gap_open = 0, gap_ext = 0, non_gap = 0;
+    pagan_model_prob prob_view() const {
+        pagan_model_prob m;
+        m.n_states = S; m.score = score.data(); m.gap_open = gap_open; m.gap_ext = gap_ext; m.non_gap = non_gap;
+        return m;
+    }
     pagan_model view() const {
         pagan_model m;
         m.n_states = S; m.log_score = log_score.data();

@@ -844,6 +844,18 @@ int pagan_protein_model(double distance, float *table, float *params, int32_t *p
     return PAGAN_OK;
 }
 
+// Probability-space view of the same model (Evol_model::score / gap_open / gap_ext / non_gap): score [a + b*S],
+// params[3] = gap_open, gap_ext, non_gap.  data_type 1: DNA (base_freq needed), 2: protein.
+int pagan_model_prob_table(int32_t data_type, const float *base_freq, double distance, float *score, float *params) {
+    if (!score || !params || (data_type != 2 && !base_freq)) return PAGAN_E_ARG;
+    ModelFactory mf;
+    if (data_type == 2) mf.init_protein(); else mf.init_dna(base_freq);
+    const EvolModel em = mf.alignment_model(distance);
+    std::memcpy(score, em.score.data(), sizeof(float) * em.score.size());
+    params[0] = em.gap_open; params[1] = em.gap_ext; params[2] = em.non_gap;
+    return PAGAN_OK;
+}
+
 int pagan_model_alphabets(int32_t data_type, char *leaf_alphabet, char *ancestral_alphabet) {
     ModelFactory mf;
     if (data_type == 2) mf.init_protein();

@@ -97,6 +97,8 @@ def _lib():
         L.pagan_dna_model.restype = C.c_int
         L.pagan_protein_model.argtypes = [C.c_double, _f32p, _f32p, _i32p]
         L.pagan_protein_model.restype = C.c_int
+        L.pagan_model_prob_table.argtypes = [C.c_int32, _f32p, C.c_double, _f32p, _f32p]
+        L.pagan_model_prob_table.restype = C.c_int
         L.pagan_model_alphabets.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
         L.pagan_model_alphabets.restype = C.c_int
         f64p = C.POINTER(C.c_double)
@@ -131,7 +133,7 @@ HOST_EXPORTED = ["pagan_assign_units", "pagan_msa_default_opts", "pagan_msa_crea
                  "pagan_msa_alignment_length", "pagan_msa_alignment_row", "pagan_msa_write_fasta", "pagan_msa_node_graph",
                  "pagan_msa_destroy", "pagan_hgraph_leaf", "pagan_hgraph_parent", "pagan_hgraph_view",
                  "pagan_hgraph_attrs", "pagan_hgraph_fwd", "pagan_hgraph_string", "pagan_hgraph_free",
-                 "pagan_define_tunnel", "pagan_dna_model", "pagan_protein_model", "pagan_model_alphabets",
+                 "pagan_define_tunnel", "pagan_dna_model", "pagan_protein_model", "pagan_model_prob_table", "pagan_model_alphabets",
                  "pagan_eigen_qrev", "pagan_msa_ready", "pagan_msa_remaining", "pagan_msa_node_cost",
                  "pagan_msa_align_nodes", "pagan_msa_export_result", "pagan_msa_import_result", "pagan_msa_finish",
                  "pagan_msa_data_type", "pagan_msa_node_device", "pagan_msa_set_batch_backend"]
@@ -261,6 +263,18 @@ def protein_model(dist):
     if rc != 0:
         raise RuntimeError("pagan_protein_model failed: %d" % rc)
     return abi.Model(table.reshape(211, 211).T, *params), pars
+
+
+def model_prob(data_type, dist, base_freq=None):
+    """abi.ModelProb for a distance: the probability-space view (Evol_model::score, gap_open, gap_ext, non_gap)."""
+    S = 211 if data_type == 2 else 15
+    score = np.zeros(S * S, np.float32)
+    params = np.zeros(3, np.float32)
+    bf = np.ascontiguousarray(base_freq if base_freq is not None else [0.25] * 4, np.float32)
+    rc = _lib().pagan_model_prob_table(int(data_type), _fp(bf), float(dist), _fp(score), _fp(params))
+    if rc != 0:
+        raise RuntimeError("pagan_model_prob_table failed: %d" % rc)
+    return abi.ModelProb(score.reshape(S, S).T, *params)
 
 
 def alphabets(data_type):

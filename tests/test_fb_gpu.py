@@ -1,0 +1,96 @@
+"""GPU: forward/backward full probability, posteriors and path sampling (dp_fb.hip) against the oracle's log-space
+restatement (oracle/oracle_fb.cpp).  Sums are log-sum-exp in fp64 on both sides, the device's exp/log1p differ from
+glibc's in the last bits, so the comparison is a tolerance: 1e-9 on logs (north_star asks 1e-6 for log-probability
+scores), 1e-7 relative on posteriors."""
+import numpy as np
+import pytest
+
+import pagan2_msa_amd as pgm
+from pagan2_msa_amd import abi, host, synth
+
+pytestmark = pytest.mark.gpu
+LOG_TOL = 1e-9
+
+
+def close_logs(a, b):
+    fa, fb = np.isfinite(a), np.isfinite(b)
+    return np.array_equal(fa, fb) and np.allclose(a[fa], b[fb], rtol=LOG_TOL, atol=LOG_TOL)
+
+
+def check_pair(oracle, gl, gr, mp, band=None):
+    fb = pgm.FullProbability(gl, gr, mp, band)
+    lf, lb, post, logf = oracle.fb(gl, gr, mp, band=band)
+    assert abs(fb.log_fwd - lf) <= LOG_TOL * max(1, abs(lf)), (fb.log_fwd, lf)
+    assert abs(fb.log_bwd - lb) <= LOG_TOL * max(1, abs(lb)), (fb.log_bwd, lb)
+    assert close_logs(fb.log_forward(), logf)
+    assert np.allclose(fb.posterior(), post, rtol=1e-7, atol=1e-12)
+    return fb, post, logf
+
+
+def test_leaf_pairs_dna_and_protein(pg, oracle):
+    _, seqs, _ = synth.evolve_balanced(2, 300, branch=0.05, sub=0.06, indel_start=0.01, mean_len=3, seed=41)
+    gl, gr = (host.HGraph.leaf(s).flatten() for s in seqs)
+    mp = host.model_prob(1, 0.1, base_freq=[0.3, 0.2, 0.2, 0.3])
+    fb, post, _ = check_pair(oracle, gl, gr, mp)
+    assert abs(np.exp(fb.log_fwd - fb.log_bwd) - 1) < 1e-9              # the reference's own check, VA:351-355
+    cells = np.array([[2, 0, 0], [2, 10, 11], [0, 5, 4], [1, 299, 300], [2, 1000, 3]], np.int32)
+    want = [post[0, 0, 2], post[10, 11, 2], post[5, 4, 0], post[299, 300, 1] if post.shape[1] > 300 else 0.0, 0.0]
+    assert np.allclose(fb.posterior_cells(cells), want, rtol=1e-7, atol=1e-12)
+    aa = "ARNDCQEGHILKMFPSTWYV"
+    _, ps, _ = synth.evolve_balanced(2, 200, branch=0.05, sub=0.08, indel_start=0.01, mean_len=3, seed=42, alphabet=aa)
+    leaf_alpha, _ = host.alphabets(2)
+    pl, pr = (host.HGraph.leaf(s, leaf_alpha).flatten() for s in ps)
+    check_pair(oracle, pl, pr, host.model_prob(2, 0.2))
+
+
+def test_long_input_stays_in_range(pg, oracle):
+    """2 x 3 kb: the reference's probability-space products are far below the smallest double here."""
+    _, seqs, _ = synth.evolve_balanced(2, 3000, branch=0.02, sub=0.02, indel_start=0.004, mean_len=4, seed=43)
+    gl, gr = (host.HGraph.leaf(s).flatten() for s in seqs)
+    band, _ = host.define_tunnel(seqs[0], seqs[1], seqs[0], seqs[1])
+    mp = host.model_prob(1, 0.04, base_freq=[0.25] * 4)
+    fb = pgm.FullProbability(gl, gr, mp, band)
+    lf, lb, _, _ = oracle.fb(gl, gr, mp, band=band, matrices=False)
+    assert fb.log_fwd < -2000 and abs(fb.log_fwd - lf) <= LOG_TOL * abs(lf) and abs(fb.log_bwd - lb) <= LOG_TOL * abs(lb)
+    assert abs(fb.log_fwd - fb.log_bwd) < 1e-7
+
+
+def test_graph_vs_graph_with_tunnel_and_sampling(pg, oracle):
+    """Internal nodes of a small tree (multi-edge sites, skipped sites), inside their tunnels; sampled paths."""
+    names, seqs, nwk = synth.evolve_balanced(8, 250, branch=0.03, sub=0.03, indel_start=0.01, mean_len=4, seed=44)
+    msa = host.Msa(names, seqs, nwk, use_anchors=1, prefix_hit_length=15).align()
+    bf = np.array([sum(s.count(x) for s in seqs) for x in "ACGT"], np.float32)
+    bf /= bf.sum()
+    rng = np.random.default_rng(5)
+    multi = 0
+    for k in (4, 5, 6):                                   # the two level-2 nodes and the root
+        left, right, model, band = msa.node_job(k)
+        multi += int((np.diff(left.bwd_off) > 1).sum() + (np.diff(right.bwd_off) > 1).sum())
+        mp = host.model_prob(1, msa.node_info(k).dist, base_freq=bf)
+        fb, post, logf = check_pair(oracle, left, right, mp, band)
+        for _ in range(3):
+            u = rng.random(left.n_sites + right.n_sites)
+            res, visited = fb.sample_path(u)
+            want, end = oracle.sample_path(left, right, mp, logf, u)
+            assert np.array_equal(visited, want)
+            assert res.status == 0 and res.score == fb.log_fwd
+            # the columns consume every site of both children once, in order
+            assert [c for c in res.cols[:, 0] if c >= 0] == list(range(1, left.n_sites - 1))
+            assert [c for c in res.cols[:, 1] if c >= 0] == list(range(1, right.n_sites - 1))
+            # matched / gapped columns are exactly the visited cells
+            real = res.cols[res.cols[:, 2] <= 4]
+            assert real.shape[0] == visited.shape[0] + (0 if (visited[-1][0] > 0 or visited[-1][1] > 0) else 0)
+        # a parent graph can be built from a sampled path like from a Viterbi path
+        info = msa.node_info(k)
+        hp = host.HGraph.parent(msa.node_graph(info.left), msa.node_graph(info.right), res, info.dist / 2, info.dist / 2,
+                                oracle.dna_parsimony(), 4)
+        assert hp.flatten().n_sites == res.cols.shape[0] + 2
+    assert multi > 0
+
+
+def test_errors(pg):
+    g = host.HGraph.leaf("ACGT").flatten()
+    bad = abi.ModelProb(np.ones((15, 15), np.float32), 0.0, 0.5, 0.9)
+    with pytest.raises(pgm.PaganError) as e:
+        pgm.FullProbability(g, g, bad)
+    assert e.value.code == abi.PAGAN_E_MODEL
