@@ -47,6 +47,16 @@ typedef struct pagan_msa_opts {
                                     211-letter alphabet, model_factory.cpp:304-632,1478-1595)     */
     int32_t  pileup_rates;       /* ins = del = 0.25: --454/--homopolymer with --pileup-alignment
                                     (model_factory.cpp:1901-1905)                                  */
+    int32_t  anchor_mode;        /* 0 = order-conflict filter + Find_anchors::define_tunnel
+                                    (viterbi_alignment.cpp:159-164); 1 = eliminate_bad_hits +
+                                    define_tunnel_with_overlapping_hits (:148-157, the BLAST branch;
+                                    the hits here are the prefix anchors)                          */
+    int32_t  overlap_total;      /* --ncbi-threshold-overlap-total, default 50 (settings.cpp:180)  */
+    int32_t  overlap_partly;     /* --ncbi-threshold-overlap-partly, default 400 (settings.cpp:181) */
+    int32_t  force_gap;          /* --force-gap (node.cpp:124-141): over the memory budget, replace the
+                                    largest empty tunnel block by a gap until the node fits         */
+    int32_t  force_gap_threshold;/* --force-gap-threshold, default 40000 (settings.cpp:189)        */
+    int32_t  force_gap_wide;     /* --force-gap-wide-tunnel                                        */
 } pagan_msa_opts;
 
 void pagan_msa_default_opts(pagan_msa_opts *o);
@@ -66,6 +76,7 @@ typedef struct pagan_node_info {
     double  dist;                /* d_left + d_right after truncation (node.cpp:70)               */
     double  score;
     int32_t status;
+    int32_t n_forced_gaps;       /* empty tunnel blocks replaced by a gap (--force-gap)             */
 } pagan_node_info;
 
 typedef struct pagan_msa_timing {
@@ -142,6 +153,22 @@ void pagan_hgraph_free(pagan_hgraph *g);
 int  pagan_define_tunnel(const char *s1, const char *s2, const char *gapped1, const char *gapped2,
                          int32_t prefix_hit_length, int32_t hit_trim, int32_t offset,
                          int32_t *upper, int32_t *lower);
+
+/* The tunnel from a list of possibly overlapping hits, the reference's BLAST branch from the hit list onwards.
+ * hits: n x 4 ints (start in sequence 1, start in sequence 2, length, score), positions in the UNGAPPED strings.
+ * pagan_prefix_hits: Find_anchors::find_long_substrings (find_anchors.cpp:35-127); returns the number of hits.
+ * pagan_drop_bad_hits: Find_anchors::eliminate_bad_hits (find_anchors.cpp:497-545), in place, returns the count.
+ * pagan_define_tunnel_overlapping: Find_anchors::define_tunnel_with_overlapping_hits (find_anchors.cpp:643-843);
+ *   upper/lower hold strlen(gapped1)+1 entries; blocks (cap x 4 ints: start x, start y, end x, end y) are the empty
+ *   tunnel blocks ascending by size; returns their number.
+ * pagan_force_gap: Viterbi_alignment::replace_largest_tunnel_block_with_gap_tunnel (viterbi_alignment.cpp:467-553)
+ *   on the last (largest) block; returns 1 if it was replaced, 0 if no block of at least `threshold` cells is left. */
+int  pagan_prefix_hits(const char *s1, const char *s2, int32_t min_length, int32_t *hits, int32_t cap);
+int  pagan_drop_bad_hits(int32_t *hits, int32_t n, int32_t thr_total, int32_t thr_partly);
+int  pagan_define_tunnel_overlapping(const int32_t *hits, int32_t n, const char *gapped1, const char *gapped2, int32_t width,
+                                     int32_t *upper, int32_t *lower, int32_t *blocks, int32_t cap);
+int  pagan_force_gap(int32_t *upper, int32_t *lower, int32_t n, const int32_t *blocks, int32_t n_blocks, int32_t threshold,
+                     int32_t width, int32_t wide);
 
 /* DNA Evol_model for a distance: table [a + b*15] (15x15 floats), params[4] =
  * log_gap_open, log_gap_ext, log_gap_end_ext, log_non_gap; parsimony [i + j*15].          */

@@ -64,6 +64,12 @@ def lib():
         L.oracle_define_tunnel.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int,
                                            C.c_int, i32p, i32p]
         L.oracle_define_tunnel.restype = C.c_int
+        L.oracle_eliminate_bad_hits.argtypes = [i32p, C.c_int, C.c_int, C.c_int]
+        L.oracle_eliminate_bad_hits.restype = C.c_int
+        L.oracle_tunnel_overlapping.argtypes = [i32p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, i32p, i32p, i32p, C.c_int]
+        L.oracle_tunnel_overlapping.restype = C.c_int
+        L.oracle_force_gap.argtypes = [i32p, i32p, C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.oracle_force_gap.restype = C.c_int
         L.oracle_dna_parsimony.argtypes = [i32p]
         L.oracle_dna_parsimony.restype = None
         L.oracle_dna_model.argtypes = [f32p, C.c_double, C.c_int, f32p, f32p]
@@ -257,6 +263,29 @@ def eigen_qrev(Q, pi):
     lib().oracle_eigen_qrev(Q.ctypes.data_as(dp), pi.ctypes.data_as(dp), n, root.ctypes.data_as(dp),
                             U.ctypes.data_as(dp), V.ctypes.data_as(dp))
     return root, U, V
+
+
+def eliminate_bad_hits(hits, thr_total=50, thr_partly=400):
+    h = np.ascontiguousarray(hits, np.int32).reshape(-1, 4).copy()
+    n = lib().oracle_eliminate_bad_hits(_ip(h), int(h.shape[0]), thr_total, thr_partly)
+    return h[:n].copy()
+
+
+def tunnel_overlapping(hits, g1, g2, width=15):
+    h = np.ascontiguousarray(hits, np.int32).reshape(-1, 4)
+    up = np.zeros(len(g1) + 1, np.int32)
+    lo = np.zeros(len(g1) + 1, np.int32)
+    cap = len(g1) + 2
+    blocks = np.zeros((cap, 4), np.int32)
+    n = lib().oracle_tunnel_overlapping(_ip(h), int(h.shape[0]), g1.encode(), g2.encode(), width, _ip(up), _ip(lo), _ip(blocks), cap)
+    return abi.Band(up, lo), blocks[:n].copy()
+
+
+def force_gap(band, blocks, threshold=40000, width=15, wide=False):
+    up, lo = band.upper.copy(), band.lower.copy()
+    b = np.ascontiguousarray(blocks, np.int32).reshape(-1, 4)
+    done = lib().oracle_force_gap(_ip(up), _ip(lo), int(up.shape[0]), _ip(b), int(b.shape[0]), threshold, width, 1 if wide else 0)
+    return bool(done), abi.Band(up, lo), (b[:-1].copy() if done else b.copy())
 
 
 def define_tunnel(left, right, min_length=30, trim=5, width=15, alphabet=DNA_ALPHABET):

@@ -40,6 +40,7 @@ namespace {
 struct Prob {
     double v = 0.0;
     static Prob of(double p) { Prob x; x.v = p; return x; }
+    static Prob from_log(double l) { return of(std::exp(l)); }
     static Prob zero() { return of(0.0); }
     Prob operator*(Prob o) const { return of(v * o.v); }
     void operator+=(Prob o) { v += o.v; }
@@ -50,6 +51,7 @@ struct Prob {
 struct LogProb {
     double v = -HUGE_VAL;
     static LogProb of(double p) { LogProb x; x.v = std::log(p); return x; }
+    static LogProb from_log(double l) { LogProb x; x.v = l; return x; }
     static LogProb zero() { return LogProb(); }
     LogProb operator*(LogProb o) const { LogProb x; x.v = v + o.v; return x; }
     void operator+=(LogProb o) {
@@ -66,13 +68,13 @@ struct ProbModel {          // Evol_model's probability-space accessors (src/uti
     int S; const float *score; float gap_open, gap_ext, non_gap;
 };
 
-struct Fwd { std::vector<int> off, dst, eid; std::vector<float> w; };      // fwd lists, creation order
+struct Fwd { std::vector<int> off, dst, eid; std::vector<float> w; };      // fwd lists, creation order; w = log weight
 
 Fwd forward_lists(const pagan_graph *g) {
     struct E { int src, dst, eid; float w; };
     std::vector<E> es;
     for (int s = 0; s < g->n_sites; s++)
-        for (int k = g->bwd_off[s]; k < g->bwd_off[s + 1]; k++) es.push_back({g->bwd_src[k], s, g->bwd_eid[k], std::exp(g->bwd_logw[k])});
+        for (int k = g->bwd_off[s]; k < g->bwd_off[s + 1]; k++) es.push_back({g->bwd_src[k], s, g->bwd_eid[k], g->bwd_logw[k]});
     std::stable_sort(es.begin(), es.end(), [](const E &a, const E &b) { return a.src != b.src ? a.src < b.src : a.eid < b.eid; });
     Fwd f;
     f.off.assign(g->n_sites + 1, 0);
@@ -95,9 +97,10 @@ template <class P> struct Pass {
     P B(int s, int i, int j) const { return in(i, j) ? bw[((size_t)i * Ly + j) * 3 + s] : P::zero(); }
     P &Fw(int s, int i, int j) { return fw[((size_t)i * Ly + j) * 3 + s]; }
     P &Bw(int s, int i, int j) { return bw[((size_t)i * Ly + j) * 3 + s]; }
-    // get_edge_weight (probability space): the float posterior weight; the CSR carries its logf
-    P lw(int k) const { return P::of((double)std::exp(L->bwd_logw[k])); }
-    P rw(int k) const { return P::of((double)std::exp(R->bwd_logw[k])); }
+    // get_edge_weight (probability space) is the float posterior weight w; the CSR carries logf(w), so the weight
+    // used here is exp((double) logf(w)) = w (1 +- 6e-8) for the few edges with w != 1 (w = 1 is exact)
+    P lw(int k) const { return P::from_log((double)L->bwd_logw[k]); }
+    P rw(int k) const { return P::from_log((double)R->bwd_logw[k]); }
     P emit(int i, int j) const { return P::of((double)m.score[L->state[i] + (size_t)R->state[j] * m.S]); }
 
     Pass(const pagan_graph *l, const pagan_graph *r, const ProbModel &pm, const pagan_band *band) : L(l), R(r), m(pm) {
@@ -199,7 +202,7 @@ template <class P> struct Pass {
                     for (int k2 = fr.off[j]; k2 < fr.off[j + 1]; k2++) {
                         const int t = fl.dst[k1], u = fr.dst[k2];
                         if (t >= Lx || u >= Ly) continue;
-                        const P thru = B(2, t, u) * emit(t, u) * P::of((double)fl.w[k1]) * P::of((double)fr.w[k2]);   // :2269-2271
+                        const P thru = B(2, t, u) * emit(t, u) * P::from_log((double)fl.w[k1]) * P::from_log((double)fr.w[k2]);   // :2269-2271
                         bx += thru * (close * ng); by += thru * (close * ng); bm += thru * (ng * ng);
                     }
                 Bw(0, i, j) = bx; Bw(1, i, j) = by; Bw(2, i, j) = bm;

@@ -524,6 +524,173 @@ void tunnel(const std::vector<Hit> &hits, const std::string &str1, const std::st
     *lower = low;
 }
 
+
+// ---- the tunnel from overlapping hits + forced gaps ---------------------------------------------------------------
+// find_anchors.cpp:497-632 (eliminate_bad_hits and its predicates), :643-843 (define_tunnel_with_overlapping_hits),
+// find_anchors.h:38-70 (Coord, Tunnel_block), viterbi_alignment.cpp:467-553 (replace_largest_tunnel_block_with_gap_tunnel).
+struct Coord { int x = -1, y = -1; };
+struct Tunnel_block {
+    Coord start, end;
+    long long size() const { return (long long)(end.x - start.x) * (long long)(end.y - start.y); }
+};
+
+int overlapsAtBegin(Hit &hit, Hit &subject) {
+    int overlap = 0;
+    if (hit.s1 >= subject.s1 && hit.s1 + hit.len > subject.s1 + subject.len) overlap = std::max(overlap, subject.s1 + subject.len - hit.s1);
+    if (hit.s2 >= subject.s2 && hit.s2 + hit.len > subject.s2 + subject.len) overlap = std::max(overlap, subject.s2 + subject.len - hit.s2);
+    return std::max(0, overlap);
+}
+unsigned int hit_distance(Hit &hit, Hit &subject) { return abs((subject.s1 - subject.s2) - (hit.s1 - hit.s2)); }
+bool probaplyBadHit(Hit &hit, Hit &subject) {
+    if (hit.s1 < subject.s1 && hit.s2 > subject.s2 && hit.s1 + hit.len < subject.s1 + subject.len) return true;
+    if (hit.s1 > subject.s1 && hit.s2 < subject.s2 && hit.s2 + hit.len < subject.s2 + subject.len) return true;
+    return false;
+}
+bool totallyOverlappingHit(Hit &hit, Hit &subject) {
+    if (hit.s1 >= subject.s1 && hit.s1 + hit.len <= subject.s1 + subject.len) return true;
+    if (hit.s2 >= subject.s2 && hit.s2 + hit.len <= subject.s2 + subject.len) return true;
+    return false;
+}
+bool partlyOverlappingHit(Hit &hit, Hit &subject) { return overlapsAtBegin(hit, subject) || overlapsAtBegin(subject, hit); }
+
+// The reference keeps pointers to the good hits inside the vector it erases from; the good hits always lie before the
+// erased position, so they stay put.  Indices here.
+void eliminate_bad_hits(std::vector<Hit> &hits, unsigned int threshold_totally_overlapping, unsigned int threshold_partly_overlapping) {
+    std::vector<size_t> good_hits;
+    size_t hit = 0;
+    while (hit < hits.size()) {
+        bool bad_hit = false, decent_hit = false;
+        for (size_t s : good_hits) {
+            if (probaplyBadHit(hits[hit], hits[s]) || totallyOverlappingHit(hits[hit], hits[s])) {
+                if (hit_distance(hits[hit], hits[s]) > threshold_totally_overlapping) { bad_hit = true; break; }
+                else decent_hit = true;
+            } else if (partlyOverlappingHit(hits[hit], hits[s])) {
+                if (hit_distance(hits[hit], hits[s]) > threshold_partly_overlapping) { bad_hit = true; break; }
+            }
+        }
+        if (bad_hit) hits.erase(hits.begin() + hit);
+        else { if (!decent_hit) good_hits.push_back(hit); ++hit; }
+    }
+}
+
+void define_tunnel_with_overlapping_hits(std::vector<Hit> &hits, std::vector<int> &upper, std::vector<int> &lower,
+                                         const std::string &sequence1, const std::string &sequence2, int width,
+                                         std::vector<Tunnel_block> &empty_blocks) {
+    int l1 = sequence1.length(), l2 = sequence2.length();
+    std::vector<int> i1, i2;
+    for (int i = 0; i < l1; i++) if (sequence1.at(i) != '-') i1.push_back(i + 1);
+    for (int i = 0; i < l2; i++) if (sequence2.at(i) != '-') i2.push_back(i + 1);
+    std::vector<int> lowest_points(l1 + 1), highest_points(l1 + 1);
+    int min_height = 0, max_height = l2;
+    for (int i = 0; i <= l1; i++) { lowest_points[i] = max_height + 1; highest_points[i] = min_height - 1; }
+    for (auto hit = hits.begin(); hit != hits.end(); ++hit)
+        for (int a = 0; a < hit->len; a++) {
+            if (i2.at(hit->s2 + a) < lowest_points[i1.at(hit->s1 + a)]) lowest_points[i1.at(hit->s1 + a)] = std::max(i2.at(hit->s2 + a), min_height);
+            if (i2.at(hit->s2 + a) > highest_points[i1.at(hit->s1 + a)]) highest_points[i1.at(hit->s1 + a)] = std::min(i2.at(hit->s2 + a), max_height);
+        }
+    int previous_lowest = min_height, previous_highest = max_height;
+    previous_highest = highest_points[0];
+    for (int i = 0; i <= l1; i++)
+        if (highest_points[i] > min_height) {
+            if (highest_points[i] < previous_highest) highest_points[i] = previous_highest;
+            previous_highest = highest_points[i];
+        }
+    previous_lowest = lowest_points[l1];
+    for (int i = l1; i >= 0; i--)
+        if (lowest_points[i] < max_height) {
+            if (lowest_points[i] > previous_lowest) lowest_points[i] = previous_lowest;
+            previous_lowest = lowest_points[i];
+        }
+    Tunnel_block current_block;
+    current_block.start.x = 0; current_block.start.y = 0;
+    for (int i = 1; i <= l1; i++) {
+        if (highest_points[i - 1] >= min_height && highest_points[i] < min_height) {
+            current_block.start.x = i; current_block.start.y = highest_points[i - 1];
+        } else if (highest_points[i] >= min_height && highest_points[i - 1] < min_height) {
+            if (lowest_points[i] > current_block.start.y) {
+                current_block.end.x = i; current_block.end.y = lowest_points[i];
+                if (current_block.size() > 10) empty_blocks.push_back(current_block);
+            }
+        } else if (i == l1 && highest_points[i] < min_height) {
+            if (max_height > current_block.start.y) {
+                current_block.end.x = i; current_block.end.y = max_height;
+                if (current_block.size() > 10) empty_blocks.push_back(current_block);
+            }
+        }
+    }
+    // std::sort in the reference; blocks of equal size have no defined order there -- stable here
+    std::stable_sort(empty_blocks.begin(), empty_blocks.end(), [](const Tunnel_block &a, const Tunnel_block &b) { return a.size() < b.size(); });
+    previous_lowest = min_height; previous_highest = max_height;
+    for (int i = 0; i <= l1; i++) { if (lowest_points[i] >= max_height) lowest_points[i] = previous_lowest; previous_lowest = lowest_points[i]; }
+    for (int i = l1; i >= 0; i--) { if (highest_points[i] <= min_height) highest_points[i] = previous_highest; previous_highest = highest_points[i]; }
+    lowest_points[0] = min_height;
+    highest_points[l1] = max_height;
+    for (int i = 0; i <= l1; i++) if (highest_points[i] >= min_height) highest_points[i] = std::min(max_height, highest_points[i] + width);
+    for (int i = 0; i <= l1; i++) if (lowest_points[i] <= max_height) lowest_points[i] = std::max(min_height, lowest_points[i] - width);
+    std::vector<std::pair<int, bool>> overflow_highest;
+    for (int i = 1; i <= l1; i++) {
+        if ((i + 1 > l1 || highest_points[i] == highest_points[i + 1]) && highest_points[i - 1] < highest_points[i] - 1) overflow_highest.push_back({i, true});
+        else if (highest_points[i - 1] < highest_points[i] - 1) overflow_highest.push_back({i, false});
+    }
+    for (int a = 0; a < (int)overflow_highest.size(); a++) {
+        int i = overflow_highest.at(a).first;
+        if (overflow_highest.at(a).second) {
+            for (int x = i - 1; x >= i - width && x >= 0 && highest_points[x] >= min_height; x--) highest_points[x] = std::max(highest_points[x], highest_points[i]);
+        } else {
+            for (int x = i - 1; x >= i - width && x >= 0 && highest_points[x] >= min_height; x--) highest_points[x] = std::max(highest_points[x], highest_points[x + 1] - 1);
+        }
+    }
+    std::vector<std::pair<int, bool>> overflow_lowest;
+    for (int i = l1 - 1; i >= 0; i--) {
+        if ((i - 1 < 0 || lowest_points[i] == lowest_points[i - 1]) && lowest_points[i + 1] > lowest_points[i] + 1) overflow_lowest.push_back({i, true});
+        else if (lowest_points[i + 1] > lowest_points[i] + 1) overflow_lowest.push_back({i, false});
+    }
+    for (int a = 0; a < (int)overflow_lowest.size(); a++) {
+        int i = overflow_lowest.at(a).first;
+        if (overflow_lowest.at(a).second) {
+            for (int x = i + 1; x <= i + width && x <= l1 && lowest_points[x] <= max_height; x++) lowest_points[x] = std::min(lowest_points[x], lowest_points[i]);
+        } else {
+            for (int x = i + 1; x <= i + width && x <= l1 && lowest_points[x] <= max_height; x++) lowest_points[x] = std::min(lowest_points[x], lowest_points[x - 1] + 1);
+        }
+    }
+    for (int i = 0; i <= l1; i++) { upper.push_back(lowest_points[i]); lower.push_back(highest_points[i]); }
+}
+
+bool replace_largest_tunnel_block_with_gap_tunnel(std::vector<int> &upper_bound, std::vector<int> &lower_bound,
+                                                  std::vector<Tunnel_block> &empty_tunnel_blocks, int remove_threshold,
+                                                  int tunnel_width, bool wide_tunnel) {
+    int tunnel_end = (int)lower_bound.size() - 1;
+    if (empty_tunnel_blocks.size() < 1 || empty_tunnel_blocks.back().size() < remove_threshold) return false;
+    Tunnel_block &largest_block = empty_tunnel_blocks.back();
+    if (wide_tunnel) {
+        for (int i = largest_block.start.x; i < largest_block.end.x - tunnel_width; i++) lower_bound.at(i) = largest_block.start.y + tunnel_width;
+        for (int i = largest_block.start.x - 1; i >= 0; i--) {
+            if (lower_bound.at(i) > lower_bound.at(i + 1)) lower_bound.at(i) = lower_bound.at(i + 1);
+            else break;
+        }
+    } else {
+        int a = 0;
+        for (int i = largest_block.start.x; i < largest_block.end.x; i++) {
+            lower_bound.at(i) = largest_block.start.y;
+            upper_bound.at(i) = std::min(largest_block.start.y, upper_bound.at(i) + a);
+            a++;
+        }
+        upper_bound.at(largest_block.end.x) = largest_block.start.y;
+        for (int i = largest_block.start.x - 1; i >= 0; i--) {
+            if (lower_bound.at(i) > lower_bound.at(i + 1)) lower_bound.at(i) = lower_bound.at(i + 1);
+            else break;
+        }
+        int last_i = std::min(largest_block.end.x + tunnel_width + 1, tunnel_end);
+        int b = 0;
+        for (int i = last_i; i >= largest_block.end.x + 1; i--) {
+            upper_bound.at(i) = std::max(upper_bound.at(last_i) - b, largest_block.start.y);
+            b++;
+        }
+    }
+    empty_tunnel_blocks.pop_back();
+    return true;
+}
+
 } // namespace
 
 extern "C" {
@@ -622,6 +789,39 @@ int oracle_define_tunnel(const char *s1, const char *s2, const char *g1, const c
     tunnel(hits, g1, g2, width, &up, &lo);
     for (size_t i = 0; i < up.size(); i++) { upper[i] = up[i]; lower[i] = lo[i]; }
     return (int)hits.size();
+}
+
+
+// hits: n x 4 ints (start 1, start 2, length, score) in processing order.  Returns the surviving count (compacted in place).
+int oracle_eliminate_bad_hits(int32_t *hits, int n, int thr_total, int thr_partly) {
+    std::vector<Hit> v;
+    for (int k = 0; k < n; k++) v.push_back({hits[4 * k], hits[4 * k + 1], hits[4 * k + 2], hits[4 * k + 3]});
+    eliminate_bad_hits(v, thr_total, thr_partly);
+    for (size_t k = 0; k < v.size(); k++) { hits[4 * k] = v[k].s1; hits[4 * k + 1] = v[k].s2; hits[4 * k + 2] = v[k].len; hits[4 * k + 3] = v[k].score; }
+    return (int)v.size();
+}
+
+// upper/lower: strlen(g1)+1 entries; blocks: cap x 4 ints (start x, start y, end x, end y), ascending by size.  Returns the block count.
+int oracle_tunnel_overlapping(const int32_t *hits, int n, const char *g1, const char *g2, int width, int32_t *upper, int32_t *lower,
+                              int32_t *blocks, int cap) {
+    std::vector<Hit> v;
+    for (int k = 0; k < n; k++) v.push_back({hits[4 * k], hits[4 * k + 1], hits[4 * k + 2], hits[4 * k + 3]});
+    std::vector<int> up, lo;
+    std::vector<Tunnel_block> eb;
+    define_tunnel_with_overlapping_hits(v, up, lo, g1, g2, width, eb);
+    for (size_t i = 0; i < up.size(); i++) { upper[i] = up[i]; lower[i] = lo[i]; }
+    for (size_t k = 0; k < eb.size() && (int)k < cap; k++) { blocks[4 * k] = eb[k].start.x; blocks[4 * k + 1] = eb[k].start.y; blocks[4 * k + 2] = eb[k].end.x; blocks[4 * k + 3] = eb[k].end.y; }
+    return (int)eb.size();
+}
+
+// One round of --force-gap on bounds of n entries and n_blocks blocks (ascending); returns 1 if a block was replaced.
+int oracle_force_gap(int32_t *upper, int32_t *lower, int n, const int32_t *blocks, int n_blocks, int threshold, int width, int wide) {
+    std::vector<int> up(upper, upper + n), lo(lower, lower + n);
+    std::vector<Tunnel_block> eb(n_blocks);
+    for (int k = 0; k < n_blocks; k++) { eb[k].start.x = blocks[4 * k]; eb[k].start.y = blocks[4 * k + 1]; eb[k].end.x = blocks[4 * k + 2]; eb[k].end.y = blocks[4 * k + 3]; }
+    const bool done = replace_largest_tunnel_block_with_gap_tunnel(up, lo, eb, threshold, width, wide != 0);
+    for (int i = 0; i < n; i++) { upper[i] = up[i]; lower[i] = lo[i]; }
+    return done ? 1 : 0;
 }
 
 // Model_factory::define_dna_alphabet parsimony table (model_factory.cpp:147-227): 15x15,

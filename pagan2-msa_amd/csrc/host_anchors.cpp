@@ -12,6 +12,7 @@
 #include "host_anchors.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -176,6 +177,146 @@ void hits_to_band(const std::vector<Hit> &hits, const std::string &str1, const s
         if (run && m_count >= width) prev_y = y;
         (*lower)[i] = std::min(std::max(y, prev_y), length2);
     }
+}
+
+// ---- Find_anchors::eliminate_bad_hits and its predicates (find_anchors.cpp:497-632) ----
+namespace {
+inline int end1(const Hit &h) { return h.s1 + h.len; }
+inline int end2(const Hit &h) { return h.s2 + h.len; }
+// length of `h`'s head lying over `o`'s tail on either axis (overlapsAtBegin, :552-565)
+int head_overlap(const Hit &h, const Hit &o) {
+    int ov = 0;
+    if (h.s1 >= o.s1 && end1(h) > end1(o)) ov = std::max(ov, end1(o) - h.s1);
+    if (h.s2 >= o.s2 && end2(h) > end2(o)) ov = std::max(ov, end2(o) - h.s2);
+    return std::max(0, ov);
+}
+unsigned diagonal_distance(const Hit &h, const Hit &o) { return (unsigned)std::abs((o.s1 - o.s2) - (h.s1 - h.s2)); }   // :573-575
+bool crosses(const Hit &h, const Hit &o) {                                                                              // probaplyBadHit, :583-591
+    if (h.s1 < o.s1 && h.s2 > o.s2 && end1(h) < end1(o)) return true;
+    if (h.s1 > o.s1 && h.s2 < o.s2 && end2(h) < end2(o)) return true;
+    return false;
+}
+bool inside(const Hit &h, const Hit &o) {                                                                               // totallyOverlappingHit, :598-606
+    return (h.s1 >= o.s1 && end1(h) <= end1(o)) || (h.s2 >= o.s2 && end2(h) <= end2(o));
+}
+} // namespace
+
+void drop_bad_hits(std::vector<Hit> *hits, unsigned max_inside, unsigned max_partly) {
+    // hits are judged in input order against the hits accepted so far as "good"; a hit that crosses or lies inside
+    // a good hit survives only close to its diagonal (and then is kept without becoming a yardstick itself)
+    std::vector<Hit> good, out;
+    out.reserve(hits->size());
+    for (const Hit &h : *hits) {
+        bool bad = false, tolerated = false;
+        for (const Hit &g : good) {
+            if (crosses(h, g) || inside(h, g)) {
+                if (diagonal_distance(h, g) > max_inside) { bad = true; break; }
+                tolerated = true;
+            } else if (head_overlap(h, g) || head_overlap(g, h)) {                    // partlyOverlappingHit, :616-624
+                if (diagonal_distance(h, g) > max_partly) { bad = true; break; }
+            }
+        }
+        if (bad) continue;
+        if (!tolerated) good.push_back(h);
+        out.push_back(h);
+    }
+    hits->swap(out);
+}
+
+void hits_to_band_overlapping(const std::vector<Hit> &hits, const std::string &g1, const std::string &g2, int width,
+                              std::vector<int32_t> *upper, std::vector<int32_t> *lower, std::vector<TunnelBlock> *blocks) {
+    const int l1 = (int)g1.size(), l2 = (int)g2.size();
+    std::vector<int> pos1, pos2;                                   // 1-based column of every residue in the gapped strings
+    for (int i = 0; i < l1; ++i) if (g1[i] != '-') pos1.push_back(i + 1);
+    for (int i = 0; i < l2; ++i) if (g2[i] != '-') pos2.push_back(i + 1);
+    const int floor_y = 0, top_y = l2;
+    std::vector<int> lo(l1 + 1, top_y + 1), hi(l1 + 1, floor_y - 1);    // per row: lowest / highest anchored column; unset
+    for (const Hit &h : hits)                                           // :683-692
+        for (int a = 0; a < h.len; ++a) {
+            const int x = pos1.at(h.s1 + a), y = pos2.at(h.s2 + a);
+            if (y < lo[x]) lo[x] = std::max(y, floor_y);
+            if (y > hi[x]) hi[x] = std::min(y, top_y);
+        }
+    {   // monotone: the upper envelope never falls, the lower never rises (:699-717); unset rows are skipped
+        int run = hi[0];
+        for (int i = 0; i <= l1; ++i) if (hi[i] > floor_y) { if (hi[i] < run) hi[i] = run; run = hi[i]; }
+        run = lo[l1];
+        for (int i = l1; i >= 0; --i) if (lo[i] < top_y) { if (lo[i] > run) lo[i] = run; run = lo[i]; }
+    }
+    {   // empty blocks between anchored stretches (:720-748)
+        TunnelBlock cur;
+        cur.sx = 0; cur.sy = 0;
+        for (int i = 1; i <= l1; ++i) {
+            const bool here = hi[i] >= floor_y, before = hi[i - 1] >= floor_y;
+            if (before && !here) { cur.sx = i; cur.sy = hi[i - 1]; }
+            else if (here && !before) {
+                if (lo[i] > cur.sy) { cur.ex = i; cur.ey = lo[i]; if (cur.size() > 10) blocks->push_back(cur); }
+            } else if (i == l1 && !here) {
+                if (top_y > cur.sy) { cur.ex = i; cur.ey = top_y; if (cur.size() > 10) blocks->push_back(cur); }
+            }
+        }
+        // ascending by size (std::sort over Tunnel_block::operator<, :750); stable here so that equal sizes keep their order
+        std::stable_sort(blocks->begin(), blocks->end(), [](const TunnelBlock &a, const TunnelBlock &b) { return a.size() < b.size(); });
+    }
+    {   // unset rows take their neighbour's bound (:757-771), corners pinned (:774-775)
+        int run = floor_y;
+        for (int i = 0; i <= l1; ++i) { if (lo[i] >= top_y) lo[i] = run; run = lo[i]; }
+        run = top_y;
+        for (int i = l1; i >= 0; --i) { if (hi[i] <= floor_y) hi[i] = run; run = hi[i]; }
+        lo[0] = floor_y; hi[l1] = top_y;
+    }
+    for (int i = 0; i <= l1; ++i) if (hi[i] >= floor_y) hi[i] = std::min(top_y, hi[i] + width);      // :780-789
+    for (int i = 0; i <= l1; ++i) if (lo[i] <= top_y) lo[i] = std::max(floor_y, lo[i] - width);
+    {   // the same margin along the other axis (:793-827): where a bound jumps by more than one, the rows before (after) the
+        // jump are lifted -- to the jump's level across a gap, along a unit-slope ramp otherwise
+        std::vector<std::pair<int, bool>> jumps;
+        for (int i = 1; i <= l1; ++i) {
+            if ((i + 1 > l1 || hi[i] == hi[i + 1]) && hi[i - 1] < hi[i] - 1) jumps.emplace_back(i, true);
+            else if (hi[i - 1] < hi[i] - 1) jumps.emplace_back(i, false);
+        }
+        for (const auto &jp : jumps) {
+            const int i = jp.first;
+            for (int x = i - 1; x >= i - width && x >= 0 && hi[x] >= floor_y; --x)
+                hi[x] = std::max(hi[x], jp.second ? hi[i] : hi[x + 1] - 1);
+        }
+        jumps.clear();
+        for (int i = l1 - 1; i >= 0; --i) {
+            if ((i - 1 < 0 || lo[i] == lo[i - 1]) && lo[i + 1] > lo[i] + 1) jumps.emplace_back(i, true);
+            else if (lo[i + 1] > lo[i] + 1) jumps.emplace_back(i, false);
+        }
+        for (const auto &jp : jumps) {
+            const int i = jp.first;
+            for (int x = i + 1; x <= i + width && x <= l1 && lo[x] <= top_y; ++x)
+                lo[x] = std::min(lo[x], jp.second ? lo[i] : lo[x - 1] + 1);
+        }
+    }
+    upper->assign(lo.begin(), lo.end());                                                              // :839-842
+    lower->assign(hi.begin(), hi.end());
+}
+
+bool force_gap(std::vector<int32_t> *upper, std::vector<int32_t> *lower, std::vector<TunnelBlock> *blocks, int min_size,
+               int width, bool wide) {
+    if (blocks->empty() || blocks->back().size() < min_size) return false;                            // :481-486
+    const TunnelBlock b = blocks->back();
+    std::vector<int32_t> &up = *upper, &lo = *lower;
+    const int last = (int)lo.size() - 1;
+    auto pull_down_before = [&](int from) {                    // keep the lower bound monotone below the block (:499-506, 519-526)
+        for (int i = from; i >= 0; --i) { if (lo.at(i) > lo.at(i + 1)) lo.at(i) = lo.at(i + 1); else break; }
+    };
+    if (wide) {                                                                                       // :490-506
+        for (int i = b.sx; i < b.ex - width; ++i) lo.at(i) = b.sy + width;
+        pull_down_before(b.sx - 1);
+    } else {                                                                                          // :508-541
+        int a = 0;
+        for (int i = b.sx; i < b.ex; ++i, ++a) { lo.at(i) = b.sy; up.at(i) = std::min(b.sy, up.at(i) + a); }
+        up.at(b.ex) = b.sy;
+        pull_down_before(b.sx - 1);
+        const int last_i = std::min(b.ex + width + 1, last);
+        int back = 0;
+        for (int i = last_i; i >= b.ex + 1; --i, ++back) up.at(i) = std::max(up.at(last_i) - back, b.sy);
+    }
+    blocks->pop_back();
+    return true;
 }
 
 int define_tunnel(const std::string &s1, const std::string &s2, const std::string &g1, const std::string &g2,

@@ -27,6 +27,24 @@ void resolve_conflicts(int len1, int len2, int trim, std::vector<Hit> *hits);
 void hits_to_band(const std::vector<Hit> &hits, const std::string &gapped1, const std::string &gapped2, int width,
                   std::vector<int32_t> *upper, std::vector<int32_t> *lower);
 
+// ---- the tunnel from possibly overlapping hits (the reference's BLAST branch) and the --force-gap rescue ----
+//   drop_bad_hits       <- Find_anchors::eliminate_bad_hits                    find_anchors.cpp:497-545 (+ predicates :552-632)
+//   hits_to_band_overlapping <- Find_anchors::define_tunnel_with_overlapping_hits   find_anchors.cpp:643-843
+//   force_gap           <- Viterbi_alignment::replace_largest_tunnel_block_with_gap_tunnel  viterbi_alignment.cpp:467-553
+// The hits themselves come from NCBI BLAST in the reference (outside its tree: unpinned); everything from the hit
+// list onwards is restated here.
+struct TunnelBlock {                   // find_anchors.h:51-70: an empty rectangle between two anchored stretches
+    int sx = -1, sy = -1, ex = -1, ey = -1;
+    long long size() const { return (long long)(ex - sx) * (long long)(ey - sy); }
+};
+void drop_bad_hits(std::vector<Hit> *hits, unsigned max_dist_inside, unsigned max_dist_partly);
+void hits_to_band_overlapping(const std::vector<Hit> &hits, const std::string &gapped1, const std::string &gapped2, int width,
+                              std::vector<int32_t> *upper, std::vector<int32_t> *lower, std::vector<TunnelBlock> *empty_blocks);
+// Replaces the largest empty block (blocks sorted ascending by size; the last one) by a gap-shaped tunnel.  Returns false
+// when there is no block of at least `min_size` cells left.
+bool force_gap(std::vector<int32_t> *upper, std::vector<int32_t> *lower, std::vector<TunnelBlock> *blocks, int min_size,
+               int width, bool wide_tunnel);
+
 // define_tunnel end to end: ungapped strings for the hits, gapped strings for the band.
 int define_tunnel(const std::string &s1, const std::string &s2, const std::string &g1, const std::string &g2,
                   const AnchorSettings &as, std::vector<int32_t> *upper, std::vector<int32_t> *lower);

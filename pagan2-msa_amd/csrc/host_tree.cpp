@@ -113,7 +113,8 @@ struct NodeWork {                // everything one internal node's alignment con
     int node = -1, level = 0;
     std::shared_ptr<EvolModel> model;
     std::vector<int32_t> upper, lower;
-    int n_hits = 0;
+    std::vector<TunnelBlock> blocks;     // empty tunnel blocks, ascending by size (anchor_mode 1; --force-gap takes the last)
+    int n_hits = 0, n_forced = 0;
     pagan_graph gl, gr;
     pagan_model pm;
     pagan_band pb;
@@ -246,6 +247,7 @@ void pagan_msa_default_opts(pagan_msa_opts *o) {
     std::memset(o, 0, sizeof(*o));
     o->use_anchors = 1; o->anchors_offset = 15; o->prefix_hit_length = 30; o->hit_trim = 5;
     o->truncate_branches = 0.2f;
+    o->force_gap_threshold = 40000; o->overlap_total = 50; o->overlap_partly = 400;      // settings.cpp:180-189
 }
 
 int pagan_msa_create(int32_t n_seqs, const char *const *names, const char *const *seqs, const char *newick,
@@ -378,9 +380,21 @@ void prepare_node(pagan_msa *m, int id, int round) {
         AnchorSettings as;
         as.offset = m->opts.anchors_offset; as.prefix_hit_length = m->opts.prefix_hit_length; as.hit_trim = m->opts.hit_trim;
         const std::string &alpha = m->mf.ancestral_alphabet;
-        w.n_hits = define_tunnel(sequence_string(gl, false, alpha), sequence_string(gr, false, alpha),
-                                 sequence_string(gl, true, alpha), sequence_string(gr, true, alpha), as,
-                                 &w.upper, &w.lower);
+        if (m->opts.anchor_mode == 1) {
+            // the reference's BLAST branch from the hit list onwards (viterbi_alignment.cpp:148-157): hits here are the
+            // prefix anchors, sorted by length as find_long_substrings leaves them
+            std::vector<Hit> hits;
+            prefix_hits(sequence_string(gl, false, alpha), sequence_string(gr, false, alpha), as.prefix_hit_length, &hits);
+            drop_bad_hits(&hits, (unsigned)m->opts.overlap_total, (unsigned)m->opts.overlap_partly);
+            w.upper.clear(); w.lower.clear(); w.blocks.clear();
+            hits_to_band_overlapping(hits, sequence_string(gl, true, alpha), sequence_string(gr, true, alpha), as.offset,
+                                     &w.upper, &w.lower, &w.blocks);
+            w.n_hits = (int)hits.size();
+        } else {
+            w.n_hits = define_tunnel(sequence_string(gl, false, alpha), sequence_string(gr, false, alpha),
+                                     sequence_string(gl, true, alpha), sequence_string(gr, true, alpha), as,
+                                     &w.upper, &w.lower);
+        }
         w.pb.n = (int32_t)w.upper.size(); w.pb.upper = w.upper.data(); w.pb.lower = w.lower.data();
         w.banded = true;
     }
@@ -414,6 +428,22 @@ int run_unit(pagan_msa *m, const std::vector<int> &ids, int dev, int round, int 
     t0 = now_s();
     std::vector<int> ks(ids.size());
     std::vector<int64_t> cost(ids.size());
+    if (m->opts.force_gap) {
+        // the memory guard of align_sequences_this_node (node.cpp:81-152): while the alignment does not fit the budget,
+        // the largest empty tunnel block is replaced by a gap-shaped tunnel; no block left -> the node fails
+        int64_t budget = 0;
+        int rc = device_budget(m, dev, &budget);
+        if (rc != PAGAN_OK) return rc;
+        for (int id : ids) {
+            NodeWork &w = m->work[id - n];
+            if (!w.banded) continue;
+            while (pagan_dp_predict_bytes(w.gl.n_sites, w.gr.n_sites, &w.pb) > budget) {
+                if (!force_gap(&w.upper, &w.lower, &w.blocks, m->opts.force_gap_threshold, m->opts.anchors_offset, m->opts.force_gap_wide != 0))
+                    return PAGAN_E_MEMCAP;
+                ++w.n_forced;
+            }
+        }
+    }
     for (size_t r = 0; r < ids.size(); ++r) {
         NodeWork &w = m->work[ids[r] - n];
         cost[r] = pagan_dp_count_cells(w.gl.n_sites, w.gr.n_sites, w.banded ? &w.pb : nullptr);
@@ -691,7 +721,7 @@ int pagan_msa_node_info(const pagan_msa *m, int32_t k, pagan_node_info *o) {
     const TreeNode &t = m->tree[m->tree_of_id[id]];
     std::memset(o, 0, sizeof(*o));
     o->node = id; o->left = m->id_of_tree[t.left]; o->right = m->id_of_tree[t.right];
-    o->level = w.level; o->n_hits = w.n_hits;
+    o->level = w.level; o->n_hits = w.n_hits; o->n_forced_gaps = w.n_forced;
     o->dist = m->tree[t.left].dist + m->tree[t.right].dist;
     if (w.has_res) {
         o->left_sites = w.gl.n_sites; o->right_sites = w.gr.n_sites;
@@ -819,6 +849,49 @@ int pagan_define_tunnel(const char *s1, const char *s2, const char *g1, const ch
     std::memcpy(upper, up.data(), sizeof(int32_t) * up.size());
     std::memcpy(lower, lo.data(), sizeof(int32_t) * lo.size());
     return n;
+}
+
+int pagan_prefix_hits(const char *s1, const char *s2, int32_t min_length, int32_t *hits, int32_t cap) {
+    if (!s1 || !s2) return PAGAN_E_ARG;
+    std::vector<Hit> v;
+    prefix_hits(s1, s2, min_length, &v);
+    for (size_t k = 0; k < v.size() && (int)k < cap; ++k) { hits[4 * k] = v[k].s1; hits[4 * k + 1] = v[k].s2; hits[4 * k + 2] = v[k].len; hits[4 * k + 3] = v[k].score; }
+    return (int)v.size();
+}
+
+int pagan_drop_bad_hits(int32_t *hits, int32_t n, int32_t thr_total, int32_t thr_partly) {
+    if (n < 0 || (n > 0 && !hits)) return PAGAN_E_ARG;
+    std::vector<Hit> v(n);
+    for (int k = 0; k < n; ++k) v[k] = Hit{hits[4 * k], hits[4 * k + 1], hits[4 * k + 2], hits[4 * k + 3]};
+    drop_bad_hits(&v, (unsigned)thr_total, (unsigned)thr_partly);
+    for (size_t k = 0; k < v.size(); ++k) { hits[4 * k] = v[k].s1; hits[4 * k + 1] = v[k].s2; hits[4 * k + 2] = v[k].len; hits[4 * k + 3] = v[k].score; }
+    return (int)v.size();
+}
+
+int pagan_define_tunnel_overlapping(const int32_t *hits, int32_t n, const char *g1, const char *g2, int32_t width,
+                                    int32_t *upper, int32_t *lower, int32_t *blocks, int32_t cap) {
+    if (n < 0 || (n > 0 && !hits) || !g1 || !g2 || !upper || !lower) return PAGAN_E_ARG;
+    std::vector<Hit> v(n);
+    for (int k = 0; k < n; ++k) v[k] = Hit{hits[4 * k], hits[4 * k + 1], hits[4 * k + 2], hits[4 * k + 3]};
+    std::vector<int32_t> up, lo;
+    std::vector<TunnelBlock> eb;
+    hits_to_band_overlapping(v, g1, g2, width, &up, &lo, &eb);
+    std::memcpy(upper, up.data(), sizeof(int32_t) * up.size());
+    std::memcpy(lower, lo.data(), sizeof(int32_t) * lo.size());
+    for (size_t k = 0; k < eb.size() && (int)k < cap; ++k) { blocks[4 * k] = eb[k].sx; blocks[4 * k + 1] = eb[k].sy; blocks[4 * k + 2] = eb[k].ex; blocks[4 * k + 3] = eb[k].ey; }
+    return (int)eb.size();
+}
+
+int pagan_force_gap(int32_t *upper, int32_t *lower, int32_t n, const int32_t *blocks, int32_t n_blocks, int32_t threshold,
+                    int32_t width, int32_t wide) {
+    if (!upper || !lower || n < 1 || n_blocks < 0 || (n_blocks > 0 && !blocks)) return PAGAN_E_ARG;
+    std::vector<int32_t> up(upper, upper + n), lo(lower, lower + n);
+    std::vector<TunnelBlock> eb(n_blocks);
+    for (int k = 0; k < n_blocks; ++k) { eb[k].sx = blocks[4 * k]; eb[k].sy = blocks[4 * k + 1]; eb[k].ex = blocks[4 * k + 2]; eb[k].ey = blocks[4 * k + 3]; }
+    const bool done = force_gap(&up, &lo, &eb, threshold, width, wide != 0);
+    std::memcpy(upper, up.data(), sizeof(int32_t) * n);
+    std::memcpy(lower, lo.data(), sizeof(int32_t) * n);
+    return done ? 1 : 0;
 }
 
 int pagan_dna_model(const float bf[4], double distance, float *table, float *params, int32_t *parsimony) {

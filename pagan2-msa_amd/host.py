@@ -20,13 +20,16 @@ class CMsaOpts(C.Structure):
                 ("hit_trim", C.c_int32), ("dp_flags", C.c_uint32), ("leaf_flags", C.c_int32),
                 ("keep_all_edges", C.c_int32), ("n_devices", C.c_int32), ("first_device", C.c_int32),
                 ("host_threads", C.c_int32), ("truncate_branches", C.c_float), ("device_mem_budget", C.c_int64),
-                ("data_type", C.c_int32), ("pileup_rates", C.c_int32)]
+                ("data_type", C.c_int32), ("pileup_rates", C.c_int32), ("anchor_mode", C.c_int32),
+                ("overlap_total", C.c_int32), ("overlap_partly", C.c_int32), ("force_gap", C.c_int32),
+                ("force_gap_threshold", C.c_int32), ("force_gap_wide", C.c_int32)]
 
 
 class CNodeInfo(C.Structure):
     _fields_ = [("node", C.c_int32), ("left", C.c_int32), ("right", C.c_int32), ("level", C.c_int32),
                 ("left_sites", C.c_int32), ("right_sites", C.c_int32), ("sites", C.c_int32), ("n_hits", C.c_int32),
-                ("cells", C.c_int64), ("dist", C.c_double), ("score", C.c_double), ("status", C.c_int32)]
+                ("cells", C.c_int64), ("dist", C.c_double), ("score", C.c_double), ("status", C.c_int32),
+                ("n_forced_gaps", C.c_int32)]
 
 
 class CTiming(C.Structure):
@@ -93,6 +96,15 @@ def _lib():
         L.pagan_define_tunnel.restype = C.c_int
         L.pagan_assign_units.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.c_int32, _i32p]
         L.pagan_assign_units.restype = None
+        L.pagan_prefix_hits.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, _i32p, C.c_int32]
+        L.pagan_prefix_hits.restype = C.c_int
+        L.pagan_drop_bad_hits.argtypes = [_i32p, C.c_int32, C.c_int32, C.c_int32]
+        L.pagan_drop_bad_hits.restype = C.c_int
+        L.pagan_define_tunnel_overlapping.argtypes = [_i32p, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32, _i32p, _i32p,
+                                                      _i32p, C.c_int32]
+        L.pagan_define_tunnel_overlapping.restype = C.c_int
+        L.pagan_force_gap.argtypes = [_i32p, _i32p, C.c_int32, _i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.pagan_force_gap.restype = C.c_int
         L.pagan_dna_model.argtypes = [_f32p, C.c_double, _f32p, _f32p, _i32p]
         L.pagan_dna_model.restype = C.c_int
         L.pagan_protein_model.argtypes = [C.c_double, _f32p, _f32p, _i32p]
@@ -133,7 +145,8 @@ HOST_EXPORTED = ["pagan_assign_units", "pagan_msa_default_opts", "pagan_msa_crea
                  "pagan_msa_alignment_length", "pagan_msa_alignment_row", "pagan_msa_write_fasta", "pagan_msa_node_graph",
                  "pagan_msa_destroy", "pagan_hgraph_leaf", "pagan_hgraph_parent", "pagan_hgraph_view",
                  "pagan_hgraph_attrs", "pagan_hgraph_fwd", "pagan_hgraph_string", "pagan_hgraph_free",
-                 "pagan_define_tunnel", "pagan_dna_model", "pagan_protein_model", "pagan_model_prob_table", "pagan_model_alphabets",
+                 "pagan_define_tunnel", "pagan_prefix_hits", "pagan_drop_bad_hits", "pagan_define_tunnel_overlapping",
+                 "pagan_force_gap", "pagan_dna_model", "pagan_protein_model", "pagan_model_prob_table", "pagan_model_alphabets",
                  "pagan_eigen_qrev", "pagan_msa_ready", "pagan_msa_remaining", "pagan_msa_node_cost",
                  "pagan_msa_align_nodes", "pagan_msa_export_result", "pagan_msa_import_result", "pagan_msa_finish",
                  "pagan_msa_data_type", "pagan_msa_node_device", "pagan_msa_set_batch_backend"]
@@ -240,6 +253,42 @@ def define_tunnel(s1, s2, g1, g2, prefix_hit_length=30, hit_trim=5, offset=15):
     n = _lib().pagan_define_tunnel(s1.encode(), s2.encode(), g1.encode(), g2.encode(), prefix_hit_length, hit_trim,
                                    offset, _ip(up), _ip(lo))
     return abi.Band(up, lo), n
+
+
+def prefix_hits(s1, s2, min_length=30):
+    """Find_anchors::find_long_substrings: [n, 4] int32 rows (start 1, start 2, length, score)."""
+    cap = max(len(s1), 1)
+    out = np.zeros((cap, 4), np.int32)
+    n = _lib().pagan_prefix_hits(s1.encode(), s2.encode(), min_length, _ip(out), cap)
+    return out[:n].copy()
+
+
+def drop_bad_hits(hits, thr_total=50, thr_partly=400):
+    h = np.ascontiguousarray(hits, np.int32).reshape(-1, 4).copy()
+    n = _lib().pagan_drop_bad_hits(_ip(h), int(h.shape[0]), thr_total, thr_partly)
+    return h[:n].copy()
+
+
+def define_tunnel_overlapping(hits, g1, g2, width=15):
+    """(Band, blocks[n, 4]) from possibly overlapping hits (define_tunnel_with_overlapping_hits)."""
+    h = np.ascontiguousarray(hits, np.int32).reshape(-1, 4)
+    up = np.zeros(len(g1) + 1, np.int32)
+    lo = np.zeros(len(g1) + 1, np.int32)
+    cap = len(g1) + 2
+    blocks = np.zeros((cap, 4), np.int32)
+    n = _lib().pagan_define_tunnel_overlapping(_ip(h), int(h.shape[0]), g1.encode(), g2.encode(), width, _ip(up), _ip(lo),
+                                               _ip(blocks), cap)
+    if n < 0:
+        raise RuntimeError("pagan_define_tunnel_overlapping failed: %d" % n)
+    return abi.Band(up, lo), blocks[:n].copy()
+
+
+def force_gap(band, blocks, threshold=40000, width=15, wide=False):
+    """One round of --force-gap: (replaced?, new Band, remaining blocks)."""
+    up, lo = band.upper.copy(), band.lower.copy()
+    b = np.ascontiguousarray(blocks, np.int32).reshape(-1, 4)
+    done = _lib().pagan_force_gap(_ip(up), _ip(lo), int(up.shape[0]), _ip(b), int(b.shape[0]), threshold, width, 1 if wide else 0)
+    return bool(done), abi.Band(up, lo), (b[:-1].copy() if done else b.copy())
 
 
 def dna_model(base_freq, dist):

@@ -44,14 +44,15 @@ def test_leaf_pairs_dna_and_protein(pg, oracle):
 
 
 def test_long_input_stays_in_range(pg, oracle):
-    """2 x 3 kb: the reference's probability-space products are far below the smallest double here."""
+    """2 x 3 kb: the reference's probability-space products (log-odds "probabilities", mostly > 1) leave the range of a
+    double here -- exp(2900) -- where the log-space pass does not care."""
     _, seqs, _ = synth.evolve_balanced(2, 3000, branch=0.02, sub=0.02, indel_start=0.004, mean_len=4, seed=43)
     gl, gr = (host.HGraph.leaf(s).flatten() for s in seqs)
     band, _ = host.define_tunnel(seqs[0], seqs[1], seqs[0], seqs[1])
     mp = host.model_prob(1, 0.04, base_freq=[0.25] * 4)
     fb = pgm.FullProbability(gl, gr, mp, band)
     lf, lb, _, _ = oracle.fb(gl, gr, mp, band=band, matrices=False)
-    assert fb.log_fwd < -2000 and abs(fb.log_fwd - lf) <= LOG_TOL * abs(lf) and abs(fb.log_bwd - lb) <= LOG_TOL * abs(lb)
+    assert abs(fb.log_fwd) > 710 and abs(fb.log_fwd - lf) <= LOG_TOL * abs(lf) and abs(fb.log_bwd - lb) <= LOG_TOL * abs(lb)
     assert abs(fb.log_fwd - fb.log_bwd) < 1e-7
 
 
@@ -79,7 +80,7 @@ def test_graph_vs_graph_with_tunnel_and_sampling(pg, oracle):
             assert [c for c in res.cols[:, 1] if c >= 0] == list(range(1, right.n_sites - 1))
             # matched / gapped columns are exactly the visited cells
             real = res.cols[res.cols[:, 2] <= 4]
-            assert real.shape[0] == visited.shape[0] + (0 if (visited[-1][0] > 0 or visited[-1][1] > 0) else 0)
+            assert real.shape[0] == visited.shape[0]
         # a parent graph can be built from a sampled path like from a Viterbi path
         info = msa.node_info(k)
         hp = host.HGraph.parent(msa.node_graph(info.left), msa.node_graph(info.right), res, info.dist / 2, info.dist / 2,

@@ -146,3 +146,42 @@ def test_work_queue_over_devices_cfg5_reduced(pg, oracle):
     assert [r[0] for r in rounds] == [32, 16, 8, 4, 2, 1]
     assert again.alignment() == msa.alignment()
     assert all(again.node_result(k).same_alignment(msa.node_result(k)) for k in range(63))
+
+
+def test_force_gapped_tunnel(pg, oracle):
+    """--force-gap (node.cpp:124-141 + replace_largest_tunnel_block_with_gap_tunnel): a pair with an unalignable
+    stretch; the tunnel from overlapping hits, then with its largest empty block replaced by a gap -- both aligned on
+    the GPU against the oracle, and the tree walk taking the same route under a small memory budget."""
+    _, seqs, _ = synth.evolve_balanced(2, 5000, branch=0.02, sub=0.02, indel_start=0.002, mean_len=5, seed=51)
+    rng = np.random.default_rng(9)
+    junk = lambda n: "".join(np.array(list("ACGT"))[rng.integers(0, 4, n)])
+    a, b = seqs[0][:2000] + junk(700) + seqs[0][2700:], seqs[1][:2000] + junk(700) + seqs[1][2700:]
+    gl, gr = host.HGraph.leaf(a).flatten(), host.HGraph.leaf(b).flatten()
+    band, blocks = host.define_tunnel_overlapping(host.drop_bad_hits(host.prefix_hits(a, b, 20)), a, b)
+    done, forced, _ = host.force_gap(band, blocks)
+    assert done
+    model, _ = host.dna_model([0.25] * 4, 0.04)
+    cells = []
+    for bd in (band, forced):
+        got, want = pg.align(gl, gr, model, bd), oracle.dp_align(gl, gr, model, bd)
+        assert got.same_alignment(want) and got.status == 0
+        cells.append(got.cells)
+    assert cells[1] < cells[0] - 200000
+    # the forced tunnel aligns the junk as one long gap pair instead of scattered matches
+    names = ["a", "b"]
+    nwk = "(a:0.02,b:0.02);"
+    free = host.Msa(names, [a, b], nwk, anchor_mode=1).align()
+    assert free.node_info(0).n_forced_gaps == 0
+    need = pg.lib().pagan_dp_predict_bytes(gl.n_sites, gr.n_sites, __import__("ctypes").byref(band.c))
+    tight = host.Msa(names, [a, b], nwk, anchor_mode=1, force_gap=1, device_mem_budget=int(need * 0.8)).align()
+    info = tight.node_info(0)
+    assert info.n_forced_gaps == 1 and info.cells == cells[1]
+    left, right, m2, b2 = tight.node_job(0)
+    assert np.array_equal(b2.upper, forced.upper) and np.array_equal(b2.lower, forced.lower)
+    assert tight.node_result(0).same_alignment(oracle.dp_align(left, right, m2, b2))
+    with pytest.raises(pg.PaganError) as e:                       # without --force-gap the node does not fit: the reference exits
+        host.Msa(names, [a, b], nwk, anchor_mode=1, device_mem_budget=int(need * 0.8)).align()
+    assert e.value.code == host.PAGAN_E_MEMCAP
+    with pytest.raises(pg.PaganError) as e:                       # nothing large enough to replace
+        host.Msa(names, [a, b], nwk, anchor_mode=1, force_gap=1, force_gap_threshold=10 ** 9, device_mem_budget=int(need * 0.8)).align()
+    assert e.value.code == host.PAGAN_E_MEMCAP
