@@ -131,6 +131,44 @@ int  pagan_msa_write_fasta(const pagan_msa *m, const char *path, int32_t chars_b
 void *pagan_msa_node_graph(const pagan_msa *m, int32_t node);   /* a pagan_hgraph (borrowed)  */
 void pagan_msa_destroy(pagan_msa *m);
 
+/* ---- pileup chain (BASELINE config 1: --queryfile reads --pileup-alignment --homopolymer) -----------------
+ * Reads_aligner::pileup_alignment (src/main/reads_aligner.cpp:151-264): read 0 is the reference; every further
+ * read is aligned (GPU) against the current root as a temporary two-child node -- root at distance 0.001, read at
+ * query_distance, reads settings (basic_alignment.h:572-586) -- and joins the alignment when
+ * overlap > min_overlap and identity > min_identity (read_alignment_scores, reads_aligner.cpp:3323-3465).      */
+typedef struct pagan_pileup pagan_pileup;
+typedef struct pagan_pileup_opts {
+    int32_t  leaf_flags;         /* 1 = --454, 2 = --homopolymer (default): leaf graphs and ins = del = 0.25 */
+    uint32_t dp_flags;           /* PAGAN_OPT_*                                                           */
+    float    query_distance;     /* --query-distance, default 0.1 (settings.cpp:107)                      */
+    float    min_overlap;        /* --min-query-overlap, default 0.5                                      */
+    float    min_identity;       /* --min-query-identity, default 0.5                                     */
+    int32_t  use_anchors;        /* 0 = full matrices (default), 1 = prefix anchors                       */
+    int32_t  anchors_offset, prefix_hit_length, hit_trim;
+    int32_t  device;             /* HIP device, -1 = current                                              */
+} pagan_pileup_opts;
+typedef struct pagan_pileup_step {
+    int32_t read;                /* index of the read this step tried to add                              */
+    int32_t accepted;
+    float   overlap, identity;   /* aligned / read_length, matched / aligned                              */
+    int32_t aligned, matched, read_length;
+    int32_t left_sites, right_sites, status, n_cols;
+    double  score;
+    int64_t cells;
+} pagan_pileup_step;
+void pagan_pileup_default_opts(pagan_pileup_opts *o);
+int  pagan_pileup_create(int32_t n_reads, const char *const *names, const char *const *seqs,
+                         const pagan_pileup_opts *opts, pagan_pileup **out);
+int  pagan_pileup_align(pagan_pileup *p);
+int  pagan_pileup_n_steps(const pagan_pileup *p);                              /* n_reads - 1 */
+int  pagan_pileup_step_info(const pagan_pileup *p, int32_t k, pagan_pileup_step *out);
+int  pagan_pileup_step_job(const pagan_pileup *p, int32_t k, pagan_job *out);  /* borrowed views */
+int  pagan_pileup_step_result(const pagan_pileup *p, int32_t k, pagan_result *out);
+int  pagan_pileup_alignment_length(const pagan_pileup *p);
+int  pagan_pileup_alignment_row(const pagan_pileup *p, int32_t read, char *buf);   /* "" for a rejected read */
+int  pagan_pileup_set_batch_backend(pagan_pileup *p, pagan_batch_fn fn, void *user);  /* TEST SEAM, as for pagan_msa */
+void pagan_pileup_destroy(pagan_pileup *p);
+
 /* ---- host graphs on their own ---------------------------------------------------------- */
 typedef struct pagan_hgraph pagan_hgraph;
 pagan_hgraph *pagan_hgraph_leaf(const char *residues, const char *full_alphabet, int32_t flags);

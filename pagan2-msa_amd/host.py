@@ -40,6 +40,19 @@ class CTiming(C.Structure):
 # pagan_batch_fn (include/pagan_host.h): the test seam's callback type
 BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_int32, C.POINTER(abi.CJob), C.POINTER(abi.COpts), C.POINTER(abi.CResult), C.c_void_p)
 
+class CPileupOpts(C.Structure):
+    _fields_ = [("leaf_flags", C.c_int32), ("dp_flags", C.c_uint32), ("query_distance", C.c_float), ("min_overlap", C.c_float),
+                ("min_identity", C.c_float), ("use_anchors", C.c_int32), ("anchors_offset", C.c_int32),
+                ("prefix_hit_length", C.c_int32), ("hit_trim", C.c_int32), ("device", C.c_int32)]
+
+
+class CPileupStep(C.Structure):
+    _fields_ = [("read", C.c_int32), ("accepted", C.c_int32), ("overlap", C.c_float), ("identity", C.c_float),
+                ("aligned", C.c_int32), ("matched", C.c_int32), ("read_length", C.c_int32), ("left_sites", C.c_int32),
+                ("right_sites", C.c_int32), ("status", C.c_int32), ("n_cols", C.c_int32), ("score", C.c_double),
+                ("cells", C.c_int64)]
+
+
 _declared = False
 
 
@@ -136,6 +149,28 @@ def _lib():
         L.pagan_msa_node_device.restype = C.c_int
         L.pagan_msa_set_batch_backend.argtypes = [vp, BATCH_FN, C.c_void_p]
         L.pagan_msa_set_batch_backend.restype = C.c_int
+        L.pagan_pileup_default_opts.argtypes = [C.POINTER(CPileupOpts)]
+        L.pagan_pileup_default_opts.restype = None
+        L.pagan_pileup_create.argtypes = [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(CPileupOpts), C.POINTER(vp)]
+        L.pagan_pileup_create.restype = C.c_int
+        L.pagan_pileup_align.argtypes = [vp]
+        L.pagan_pileup_align.restype = C.c_int
+        L.pagan_pileup_n_steps.argtypes = [vp]
+        L.pagan_pileup_n_steps.restype = C.c_int
+        L.pagan_pileup_step_info.argtypes = [vp, C.c_int32, C.POINTER(CPileupStep)]
+        L.pagan_pileup_step_info.restype = C.c_int
+        L.pagan_pileup_step_job.argtypes = [vp, C.c_int32, C.POINTER(abi.CJob)]
+        L.pagan_pileup_step_job.restype = C.c_int
+        L.pagan_pileup_step_result.argtypes = [vp, C.c_int32, C.POINTER(abi.CResult)]
+        L.pagan_pileup_step_result.restype = C.c_int
+        L.pagan_pileup_alignment_length.argtypes = [vp]
+        L.pagan_pileup_alignment_length.restype = C.c_int
+        L.pagan_pileup_alignment_row.argtypes = [vp, C.c_int32, C.c_char_p]
+        L.pagan_pileup_alignment_row.restype = C.c_int
+        L.pagan_pileup_set_batch_backend.argtypes = [vp, BATCH_FN, C.c_void_p]
+        L.pagan_pileup_set_batch_backend.restype = C.c_int
+        L.pagan_pileup_destroy.argtypes = [vp]
+        L.pagan_pileup_destroy.restype = None
         _declared = True
     return L
 
@@ -149,7 +184,11 @@ HOST_EXPORTED = ["pagan_assign_units", "pagan_msa_default_opts", "pagan_msa_crea
                  "pagan_force_gap", "pagan_dna_model", "pagan_protein_model", "pagan_model_prob_table", "pagan_model_alphabets",
                  "pagan_eigen_qrev", "pagan_msa_ready", "pagan_msa_remaining", "pagan_msa_node_cost",
                  "pagan_msa_align_nodes", "pagan_msa_export_result", "pagan_msa_import_result", "pagan_msa_finish",
-                 "pagan_msa_data_type", "pagan_msa_node_device", "pagan_msa_set_batch_backend"]
+                 "pagan_msa_data_type", "pagan_msa_node_device", "pagan_msa_set_batch_backend",
+                 "pagan_pileup_default_opts", "pagan_pileup_create", "pagan_pileup_align", "pagan_pileup_n_steps",
+                 "pagan_pileup_step_info", "pagan_pileup_step_job", "pagan_pileup_step_result",
+                 "pagan_pileup_alignment_length", "pagan_pileup_alignment_row", "pagan_pileup_set_batch_backend",
+                 "pagan_pileup_destroy"]
 
 
 def _ip(a):
@@ -345,6 +384,98 @@ def eigen_qrev(Q, pi):
     if rc != 0:
         raise RuntimeError("pagan_eigen_qrev failed: %d" % rc)
     return root, U, V
+
+
+def _job_copy(j):
+    """(Graph, Graph, Model, Band|None) copies of a borrowed CJob."""
+    left, right = _graph_from_view(j.left.contents), _graph_from_view(j.right.contents)
+    m = j.model.contents
+    S = m.n_states
+    table = np.ctypeslib.as_array(m.log_score, shape=(S * S,)).copy()
+    model = abi.Model(table.reshape(S, S).T, m.log_gap_open, m.log_gap_ext, m.log_gap_end_ext, m.log_non_gap)
+    band = None
+    if j.band:
+        b = j.band.contents
+        band = abi.Band(np.ctypeslib.as_array(b.upper, shape=(b.n,)).copy(), np.ctypeslib.as_array(b.lower, shape=(b.n,)).copy())
+    return left, right, model, band
+
+
+class Pileup:
+    """Reads_aligner::pileup_alignment mirror: read 0 is the reference, every further read is aligned (GPU) against the
+    growing root and joins it when it overlaps well enough."""
+
+    def __init__(self, names, seqs, **opts):
+        L = _lib()
+        o = CPileupOpts()
+        L.pagan_pileup_default_opts(C.byref(o))
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError("unknown option %s" % k)
+            setattr(o, k, v)
+        self.n = len(names)
+        na = (C.c_char_p * self.n)(*[s.encode() for s in names])
+        sa = (C.c_char_p * self.n)(*[s.encode() for s in seqs])
+        self._h = C.c_void_p()
+        rc = L.pagan_pileup_create(self.n, na, sa, C.byref(o), C.byref(self._h))
+        if rc != 0:
+            from . import PaganError
+            raise PaganError(rc, "pagan_pileup_create")
+        self._L = L
+
+    def set_batch_backend(self, fn):
+        """TEST SEAM: `fn` stands in for pagan_dp_align_batch (see Msa.set_batch_backend)."""
+        self._backend = BATCH_FN(fn) if fn is not None else C.cast(None, BATCH_FN)
+        self._L.pagan_pileup_set_batch_backend(self._h, self._backend, None)
+
+    def align(self):
+        rc = self._L.pagan_pileup_align(self._h)
+        if rc != 0:
+            from . import PaganError
+            raise PaganError(rc, "pagan_pileup_align")
+        return self
+
+    @property
+    def n_steps(self):
+        return self._L.pagan_pileup_n_steps(self._h)
+
+    def step(self, k):
+        s = CPileupStep()
+        self._L.pagan_pileup_step_info(self._h, k, C.byref(s))
+        return s
+
+    def step_job(self, k):
+        j = abi.CJob()
+        rc = self._L.pagan_pileup_step_job(self._h, k, C.byref(j))
+        if rc != 0:
+            raise RuntimeError("pagan_pileup_step_job failed: %d" % rc)
+        return _job_copy(j)
+
+    def step_result(self, k):
+        r = abi.CResult()
+        rc = self._L.pagan_pileup_step_result(self._h, k, C.byref(r))
+        if rc != 0:
+            raise RuntimeError("pagan_pileup_step_result failed: %d" % rc)
+        return abi.Result(r)
+
+    def alignment(self):
+        n = self._L.pagan_pileup_alignment_length(self._h)
+        buf = C.create_string_buffer(n + 1)
+        rows = []
+        for k in range(self.n):
+            ln = self._L.pagan_pileup_alignment_row(self._h, k, buf)
+            rows.append(buf.raw[:ln].decode())
+        return rows
+
+    def close(self):
+        if self._h:
+            self._L.pagan_pileup_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Msa:

@@ -170,18 +170,18 @@ def test_force_gapped_tunnel(pg, oracle):
     # the forced tunnel aligns the junk as one long gap pair instead of scattered matches
     names = ["a", "b"]
     nwk = "(a:0.02,b:0.02);"
-    free = host.Msa(names, [a, b], nwk, anchor_mode=1).align()
+    free = host.Msa(names, [a, b], nwk, anchor_mode=1, prefix_hit_length=20).align()
     assert free.node_info(0).n_forced_gaps == 0
     need = pg.lib().pagan_dp_predict_bytes(gl.n_sites, gr.n_sites, __import__("ctypes").byref(band.c))
-    tight = host.Msa(names, [a, b], nwk, anchor_mode=1, force_gap=1, device_mem_budget=int(need * 0.8)).align()
+    tight = host.Msa(names, [a, b], nwk, anchor_mode=1, prefix_hit_length=20, force_gap=1, device_mem_budget=int(need * 0.8)).align()
     info = tight.node_info(0)
     assert info.n_forced_gaps == 1 and info.cells == cells[1]
     left, right, m2, b2 = tight.node_job(0)
     assert np.array_equal(b2.upper, forced.upper) and np.array_equal(b2.lower, forced.lower)
     assert tight.node_result(0).same_alignment(oracle.dp_align(left, right, m2, b2))
     with pytest.raises(pg.PaganError) as e:                       # without --force-gap the node does not fit: the reference exits
-        host.Msa(names, [a, b], nwk, anchor_mode=1, device_mem_budget=int(need * 0.8)).align()
+        host.Msa(names, [a, b], nwk, anchor_mode=1, prefix_hit_length=20, device_mem_budget=int(need * 0.8)).align()
     assert e.value.code == host.PAGAN_E_MEMCAP
     with pytest.raises(pg.PaganError) as e:                       # nothing large enough to replace
-        host.Msa(names, [a, b], nwk, anchor_mode=1, force_gap=1, force_gap_threshold=10 ** 9, device_mem_budget=int(need * 0.8)).align()
+        host.Msa(names, [a, b], nwk, anchor_mode=1, prefix_hit_length=20, force_gap=1, force_gap_threshold=10 ** 9, device_mem_budget=int(need * 0.8)).align()
     assert e.value.code == host.PAGAN_E_MEMCAP
