@@ -57,6 +57,9 @@ typedef struct pagan_msa_opts {
                                     largest empty tunnel block by a gap until the node fits         */
     int32_t  force_gap_threshold;/* --force-gap-threshold, default 40000 (settings.cpp:189)        */
     int32_t  force_gap_wide;     /* --force-gap-wide-tunnel                                        */
+    int32_t  mostcommon;         /* --mostcommon: a matched column's parent state from the most-common table
+                                    (basic_alignment.cpp:146-147) and Node::fix_ambiguous_states
+                                    (node.cpp:1610-1690) after every node                            */
 } pagan_msa_opts;
 
 void pagan_msa_default_opts(pagan_msa_opts *o);
@@ -122,12 +125,17 @@ int  pagan_msa_node_job(const pagan_msa *m, int32_t k, pagan_job *out);
 int  pagan_msa_node_result(const pagan_msa *m, int32_t k, pagan_result *out);
 int  pagan_msa_timing_get(const pagan_msa *m, pagan_msa_timing *out);
 int  pagan_msa_alignment_length(const pagan_msa *m);
-/* Row of leaf `leaf` (input order) of the final alignment, '-' for gaps; buf >= length+1. */
-int  pagan_msa_alignment_row(const pagan_msa *m, int32_t leaf, char *buf);
+/* Row of node `node` of the final alignment, '-' for gaps; buf >= length+1.  Leaves 0..n-1 in input order;
+ * internal nodes n..2n-2 (the ancestors' rows of --output-ancestors: the state's character, a gap where the
+ * site is skipped or deleted; get_alignment_column_at, node.cpp:779-834).                                  */
+int  pagan_msa_alignment_row(const pagan_msa *m, int32_t node, char *buf);
 /* The leaf rows as FASTA, leaves in guide-tree order, `>name` + the row cut into lines of chars_by_line
  * characters (<= 0: 60): Fasta_reader::write_fasta over Node::get_alignment
  * (src/utils/fasta_reader.cpp:596-629, src/main/node.cpp:537-575).                            */
 int  pagan_msa_write_fasta(const pagan_msa *m, const char *path, int32_t chars_by_line);
+/* ... with include_internal != 0 every node, in Node::get_all_nodes order (left subtree, node, right subtree;
+ * node.h:277-290), internal nodes named #k# (node.h:479-495): Node::get_alignment(.., true), node.cpp:537-555. */
+int  pagan_msa_write_fasta_nodes(const pagan_msa *m, const char *path, int32_t chars_by_line, int32_t include_internal);
 void *pagan_msa_node_graph(const pagan_msa *m, int32_t node);   /* a pagan_hgraph (borrowed)  */
 void pagan_msa_destroy(pagan_msa *m);
 

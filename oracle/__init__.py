@@ -43,6 +43,8 @@ def lib():
         L.oracle_result_free.restype = None
         L.oracle_graph_leaf.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         L.oracle_graph_leaf.restype = C.c_void_p
+        L.oracle_graph_set_state.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.oracle_graph_set_state.restype = None
         L.oracle_graph_free.argtypes = [C.c_void_p]
         L.oracle_graph_free.restype = None
         for f in ("oracle_graph_n_sites", "oracle_graph_n_edges", "oracle_graph_n_bwd"):
@@ -155,6 +157,9 @@ class OGraph:
         eid = np.zeros(max(ne, 1), np.int32)
         L.oracle_graph_fwd(self.h, _ip(off), _ip(eid))
         return off, eid[:off[-1]]
+
+    def set_state(self, pos, state):
+        lib().oracle_graph_set_state(self.h, int(pos), int(state))
 
     def mark_used(self, eids):
         e = np.ascontiguousarray(eids, np.int32)

@@ -697,6 +697,8 @@ extern "C" {
 
 void *oracle_graph_leaf(const char *seq, const char *alphabet, int flags) { return Graph::leaf(seq, alphabet, flags); }
 void oracle_graph_free(void *g) { delete (Graph *)g; }
+// Site::set_state, for Node::set_ambiguous_state (node.cpp:1661-1690) driven from the tests
+void oracle_graph_set_state(void *g, int pos, int state) { ((Graph *)g)->sites[pos].state = state; }
 int oracle_graph_n_sites(void *g) { return (int)((Graph *)g)->sites.size(); }
 int oracle_graph_n_edges(void *g) { return (int)((Graph *)g)->edges.size(); }
 int oracle_graph_n_bwd(void *gp) {

@@ -146,6 +146,8 @@ struct pagan_msa {
     int remaining = 0, rounds = 0;
     std::map<double, std::shared_ptr<EvolModel>> model_cache;    // one table per distinct distance
     std::mutex mu;                       // model cache, timing sums
+    std::vector<int32_t> state_table;    // parent state of a matched column: parsimony table, or with --mostcommon the
+                                         // most-common table where it is defined (basic_alignment.cpp:146-149)
     pagan_batch_fn backend = nullptr;    // test seam (pagan_msa_set_batch_backend); null = pagan_dp_align_batch
     void *backend_user = nullptr;
     ~pagan_msa() { for (auto &w : work) if (w.has_res) pagan_result_free(&w.res); }
@@ -204,7 +206,8 @@ void build_rows(pagan_msa *m) {
     std::vector<std::vector<int32_t>> col(m->graph.size());
     col[root_id].resize(width + 2);
     for (int s = 0; s < width + 2; ++s) col[root_id][s] = s - 1;
-    m->rows.assign(n, std::string(width, '-'));
+    m->rows.assign(m->graph.size(), std::string(width, '-'));
+    const std::string &anc = m->mf.ancestral_alphabet;
     // internal ids grow in post-order, so walking them downwards visits parents first
     for (int id = (int)m->graph.size() - 1; id >= n; --id) {
         const TreeNode &t = m->tree[m->tree_of_id[id]];
@@ -215,6 +218,11 @@ void build_rows(pagan_msa *m) {
         for (int s = 1; s < g.n_sites() - 1; ++s) {
             if (g.child_l[s] >= 0) col[lid][g.child_l[s]] = col[id][s];
             if (g.child_r[s] >= 0) col[rid][g.child_r[s]] = col[id][s];
+            // the ancestor's own row (get_alignment_column_at with include_internal_nodes, node.cpp:808-818): its
+            // state's character, a gap where the site is skipped or was deleted
+            const int ps = g.path_state[s];
+            if (!(ps == PAGAN_XSKIPPED || ps == PAGAN_YSKIPPED || g.site_type[s] == kNonReal) && g.state[s] >= 0)
+                m->rows[id][col[id][s]] = anc[g.state[s]];
         }
         col[id].clear(); col[id].shrink_to_fit();
     }
@@ -328,6 +336,10 @@ int pagan_msa_create(int32_t n_seqs, const char *const *names, const char *const
     } else {
         m->mf.init_protein();
     }
+    m->state_table = m->mf.parsimony;
+    if (m->opts.mostcommon)      // Evol_model::mostcommon_state: defined over mc_dim x mc_dim states (20 x 20 residues for protein)
+        for (int i = 0; i < m->mf.mc_dim; ++i)
+            for (int j = 0; j < m->mf.mc_dim; ++j) m->state_table[i + (size_t)j * m->mf.S] = m->mf.mostcommon[i + j * m->mf.mc_dim];
     over_leaves([&](int k) {
         m->graph[k].reset(new pagan_hgraph());
         m->graph[k]->g = make_leaf(m->seqs[k], m->mf.leaf_alphabet, m->opts.leaf_flags);
@@ -401,6 +413,48 @@ void prepare_node(pagan_msa *m, int id, int round) {
     w.has_job = true;
 }
 
+// Node::get_ambiguous_states (node.cpp:1638-1659): the states below an ambiguous site, down to unambiguous ones.
+void ambiguous_states(const pagan_msa *m, int id, int pos, std::vector<int> *out) {
+    const SeqGraph &g = m->graph[id]->g;
+    if (!g.ambiguous[pos]) { out->push_back(g.state[pos]); return; }
+    const TreeNode &t = m->tree[m->tree_of_id[id]];
+    if (t.left < 0) return;                                        // an ambiguous leaf site has nothing below it
+    if (g.child_l[pos] >= 0) ambiguous_states(m, m->id_of_tree[t.left], g.child_l[pos], out);
+    if (g.child_r[pos] >= 0) ambiguous_states(m, m->id_of_tree[t.right], g.child_r[pos], out);
+}
+
+// Node::set_ambiguous_state (node.cpp:1661-1690): pushes a resolved state down the ambiguous sites that carry it.
+bool set_ambiguous_state(pagan_msa *m, int id, int pos, int state) {
+    SeqGraph &g = m->graph[id]->g;
+    if (!g.ambiguous[pos]) return g.state[pos] == state;
+    const TreeNode &t = m->tree[m->tree_of_id[id]];
+    if (t.left < 0) return false;
+    bool cont = true;
+    if (g.child_l[pos] >= 0 && set_ambiguous_state(m, m->id_of_tree[t.left], g.child_l[pos], state)) { g.state[pos] = state; cont = false; }
+    if (g.child_r[pos] >= 0 && cont && set_ambiguous_state(m, m->id_of_tree[t.right], g.child_r[pos], state)) g.state[pos] = state;
+    return false;
+}
+
+// Node::fix_ambiguous_states (node.cpp:1610-1636), --mostcommon only: a site whose two subtrees share exactly one state
+// (and bring more than two states together) takes that state, and so do the ambiguous sites below it.
+void fix_ambiguous_states(pagan_msa *m, int id) {
+    const TreeNode &t = m->tree[m->tree_of_id[id]];
+    const int lid = m->id_of_tree[t.left], rid = m->id_of_tree[t.right];
+    const int n = m->graph[id]->g.n_sites();
+    std::vector<int> ls, rs;
+    for (int j = 1; j < n - 1; ++j) {
+        const SeqGraph &g = m->graph[id]->g;
+        ls.clear(); rs.clear();
+        if (g.child_l[j] >= 0) ambiguous_states(m, lid, g.child_l[j], &ls);
+        if (g.child_r[j] >= 0) ambiguous_states(m, rid, g.child_r[j], &rs);
+        std::sort(ls.begin(), ls.end()); ls.erase(std::unique(ls.begin(), ls.end()), ls.end());       // std::set semantics
+        std::sort(rs.begin(), rs.end()); rs.erase(std::unique(rs.begin(), rs.end()), rs.end());
+        std::vector<int> both;
+        std::set_intersection(ls.begin(), ls.end(), rs.begin(), rs.end(), std::back_inserter(both));
+        if (both.size() == 1 && ls.size() + rs.size() > 2) set_ambiguous_state(m, id, j, both[0]);
+    }
+}
+
 // add_ancestral_sequence(va.get_simple_sequence()) (node.cpp:166): the parent graph from the path.
 int build_parent(pagan_msa *m, int id) {
     NodeWork &w = m->work[id - m->n_leaves];
@@ -412,7 +466,8 @@ int build_parent(pagan_msa *m, int id) {
     SeqGraph &gl = m->graph[m->id_of_tree[t.left]]->g, &gr = m->graph[m->id_of_tree[t.right]]->g;
     m->graph[id].reset(new pagan_hgraph());
     m->graph[id]->g = make_parent(gl, gr, w.res, (float)m->tree[t.left].dist, (float)m->tree[t.right].dist,
-                                  m->mf.parsimony.data(), m->mf.S, m->mf.char_as, bs);
+                                  m->state_table.data(), m->mf.S, m->mf.char_as, bs);
+    if (m->opts.mostcommon) fix_ambiguous_states(m, id);
     return PAGAN_OK;
 }
 
@@ -753,7 +808,7 @@ int pagan_msa_timing_get(const pagan_msa *m, pagan_msa_timing *o) {
 int pagan_msa_alignment_length(const pagan_msa *m) { return (m && m->aligned) ? (int)m->rows[0].size() : PAGAN_E_ARG; }
 
 int pagan_msa_alignment_row(const pagan_msa *m, int32_t leaf, char *buf) {
-    if (!m || !m->aligned || leaf < 0 || leaf >= m->n_leaves || !buf) return PAGAN_E_ARG;
+    if (!m || !m->aligned || leaf < 0 || leaf >= (int)m->rows.size() || !buf) return PAGAN_E_ARG;
     std::memcpy(buf, m->rows[leaf].c_str(), m->rows[leaf].size() + 1);
     return PAGAN_OK;
 }
@@ -762,21 +817,34 @@ int pagan_msa_alignment_row(const pagan_msa *m, int32_t leaf, char *buf) {
 // (src/main/node.cpp:537-575): one entry per leaf in guide-tree order (left to right, as get_leaf_nodes
 // collects them), `>name`, the aligned row cut into lines of chars_by_line characters (60 by default).
 int pagan_msa_write_fasta(const pagan_msa *m, const char *path, int32_t chars_by_line) {
+    return pagan_msa_write_fasta_nodes(m, path, chars_by_line, 0);
+}
+
+// ... with include_internal (--output-ancestors): every node in Node::get_all_nodes order -- left subtree, the node,
+// right subtree (node.h:277-290) -- internal nodes named #k# in alignment order (node.h:479-495).
+int pagan_msa_write_fasta_nodes(const pagan_msa *m, const char *path, int32_t chars_by_line, int32_t include_internal) {
     if (!m || !m->aligned || !path) return PAGAN_E_ARG;
     const size_t width = chars_by_line > 0 ? (size_t)chars_by_line : 60;
     std::FILE *f = std::fopen(path, "w");
     if (!f) return PAGAN_E_ARG;
-    std::vector<int> stack{m->root}, order;
-    while (!stack.empty()) {                                   // leaves left to right
-        const int t = stack.back();
-        stack.pop_back();
-        const TreeNode &n = m->tree[t];
-        if (n.left < 0) { order.push_back(m->id_of_tree[t]); continue; }
-        stack.push_back(n.right);
-        stack.push_back(n.left);
+    std::vector<int> order;
+    {
+        // in-order walk without recursion: (tree index, children done?)
+        std::vector<std::pair<int, bool>> stack{{m->root, false}};
+        while (!stack.empty()) {
+            const auto [t, visited] = stack.back();
+            stack.pop_back();
+            const TreeNode &n = m->tree[t];
+            if (n.left < 0) { order.push_back(m->id_of_tree[t]); continue; }
+            if (visited) { if (include_internal) order.push_back(m->id_of_tree[t]); continue; }
+            stack.push_back({n.right, false});
+            stack.push_back({t, true});
+            stack.push_back({n.left, false});
+        }
     }
     for (int leaf : order) {
-        std::fprintf(f, ">%s\n", m->names[leaf].c_str());
+        if (leaf < m->n_leaves) std::fprintf(f, ">%s\n", m->names[leaf].c_str());
+        else std::fprintf(f, ">#%d#\n", leaf - m->n_leaves + 1);
         const std::string &row = m->rows[leaf];
         for (size_t at = 0; at < row.size(); at += width) std::fprintf(f, "%.*s\n", (int)std::min(width, row.size() - at), row.c_str() + at);
     }

@@ -22,7 +22,7 @@ class CMsaOpts(C.Structure):
                 ("host_threads", C.c_int32), ("truncate_branches", C.c_float), ("device_mem_budget", C.c_int64),
                 ("data_type", C.c_int32), ("pileup_rates", C.c_int32), ("anchor_mode", C.c_int32),
                 ("overlap_total", C.c_int32), ("overlap_partly", C.c_int32), ("force_gap", C.c_int32),
-                ("force_gap_threshold", C.c_int32), ("force_gap_wide", C.c_int32)]
+                ("force_gap_threshold", C.c_int32), ("force_gap_wide", C.c_int32), ("mostcommon", C.c_int32)]
 
 
 class CNodeInfo(C.Structure):
@@ -85,6 +85,8 @@ def _lib():
         L.pagan_msa_alignment_row.restype = C.c_int
         L.pagan_msa_write_fasta.argtypes = [vp, C.c_char_p, C.c_int32]
         L.pagan_msa_write_fasta.restype = C.c_int
+        L.pagan_msa_write_fasta_nodes.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32]
+        L.pagan_msa_write_fasta_nodes.restype = C.c_int
         L.pagan_msa_node_graph.argtypes = [vp, C.c_int32]
         L.pagan_msa_node_graph.restype = vp
         L.pagan_msa_destroy.argtypes = [vp]
@@ -177,7 +179,8 @@ def _lib():
 
 HOST_EXPORTED = ["pagan_assign_units", "pagan_msa_default_opts", "pagan_msa_create", "pagan_msa_align", "pagan_msa_n_internal",
                  "pagan_msa_node_info", "pagan_msa_node_job", "pagan_msa_node_result", "pagan_msa_timing_get",
-                 "pagan_msa_alignment_length", "pagan_msa_alignment_row", "pagan_msa_write_fasta", "pagan_msa_node_graph",
+                 "pagan_msa_alignment_length", "pagan_msa_alignment_row", "pagan_msa_write_fasta", "pagan_msa_write_fasta_nodes",
+                 "pagan_msa_node_graph",
                  "pagan_msa_destroy", "pagan_hgraph_leaf", "pagan_hgraph_parent", "pagan_hgraph_view",
                  "pagan_hgraph_attrs", "pagan_hgraph_fwd", "pagan_hgraph_string", "pagan_hgraph_free",
                  "pagan_define_tunnel", "pagan_prefix_hits", "pagan_drop_bad_hits", "pagan_define_tunnel_overlapping",
@@ -617,9 +620,20 @@ class Msa:
             rows.append(buf.raw[:n].decode())
         return rows
 
-    def write_fasta(self, path, chars_by_line=60):
-        """The leaf rows as FASTA in guide-tree order (Fasta_reader::write_fasta over Node::get_alignment)."""
-        rc = self._L.pagan_msa_write_fasta(self._h, str(path).encode(), chars_by_line)
+    def alignment_all(self):
+        """Rows of every node: leaves 0..n-1, then the internal nodes (ancestors) in alignment order."""
+        n = self._L.pagan_msa_alignment_length(self._h)
+        rows = []
+        buf = C.create_string_buffer(n + 1)
+        for k in range(2 * self.n - 1):
+            self._L.pagan_msa_alignment_row(self._h, k, buf)
+            rows.append(buf.raw[:n].decode())
+        return rows
+
+    def write_fasta(self, path, chars_by_line=60, include_internal=False):
+        """The rows as FASTA in guide-tree order (Fasta_reader::write_fasta over Node::get_alignment); with
+        include_internal the ancestors' rows too, in Node::get_all_nodes order."""
+        rc = self._L.pagan_msa_write_fasta_nodes(self._h, str(path).encode(), chars_by_line, 1 if include_internal else 0)
         if rc != 0:
             from . import PaganError
             raise PaganError(rc, "pagan_msa_write_fasta")
