@@ -62,6 +62,10 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N > 1 under torchrun: nccl (= RCCL, the default) or gloo (rehearsal on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: rank r uses device r %% device_count instead of device r (numbers are meaningless)")
     ap.add_argument("--allow-stale-traffic", action="store_true",
                     help="report roofline.traffic = null instead of failing when %s does not match this run" % PMC_PROFILE)
     args = ap.parse_args()
@@ -78,6 +82,8 @@ def main():
     if world == 1 and args.gpus > torch.cuda.device_count():
         raise SystemExit("bench.py: --gpus %d but %d device(s) visible; start one rank per GPU with torch.distributed.run"
                          % (args.gpus, torch.cuda.device_count()))
+    if args.share_device:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if args.gpus > 1:
         return bench_work_queue(args, rank, local_rank, world)
@@ -241,8 +247,12 @@ def bench_work_queue(args, rank, local_rank, world):
     cfg, leaves, length, branch, sub, indel, mean_len, anchors, alphabet = WORKLOADS[workload]
     in_process = world == 1                      # no torchrun: one process feeds args.gpus devices
     pg.lib().pagan_dp_select_device(local_rank)
+    xdev = "cuda" if args.dist_backend == "nccl" else "cpu"     # where the exchanged bytes live
     if not in_process:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     names, seqs, newick = make_inputs(workload)  # the same tree on every rank
 
     def walk(sharded):
@@ -259,7 +269,7 @@ def bench_work_queue(args, rank, local_rank, world):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if sharded:
-            pdist.align_sharded(msa, host.assign_units, device="cuda")
+            pdist.align_sharded(msa, host.assign_units, device=xdev)
             torch.cuda.synchronize()
             dist.barrier()
         else:
@@ -280,7 +290,7 @@ def bench_work_queue(args, rank, local_rank, world):
     if in_process:
         elapsed_max = elapsed
     else:
-        elapsed_max, _ = pdist.reduce_step(elapsed, 0, device="cuda")
+        elapsed_max, _ = pdist.reduce_step(elapsed, 0, device=xdev)
     if rank == 0:
         n_nodes = msa.n_internal
         cells = sum(int(msa.node_info(k).cells) for k in range(n_nodes))
@@ -305,8 +315,9 @@ def bench_work_queue(args, rank, local_rank, world):
                        "anchors": "prefix, offset 15" if anchors else "none", "node_alignments": n_nodes,
                        "cells_per_step": int(cells),
                        "parallelism": ("in-process work queue over %d devices" % args.gpus) if in_process else
-                                      ("one rank per GPU, ready nodes dealt per round, paths all-gathered (RCCL); "
-                                       "rank 0 aligned %d of %d nodes" % (mine, n_nodes)),
+                                      ("one rank per GPU, ready nodes dealt per round, paths all-gathered (%s); "
+                                       "rank 0 aligned %d of %d nodes%s" % ("RCCL" if args.dist_backend == "nccl" else "gloo", mine, n_nodes,
+                                                                            "; REHEARSAL: ranks share a device" if args.share_device else "")),
                        "step": "one whole progressive alignment: model + anchors + DP + parent graphs, host work included"},
             "value_one_gpu_same_workload": cells / solo_s,
             "one_gpu_wall_s": solo_s,
