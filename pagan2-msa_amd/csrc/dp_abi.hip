@@ -42,6 +42,7 @@ __global__ void pg_trace_emit(const PgDevJob *jobs);
 unsigned pg_ring_lds_bytes();
 // limits of the register-wavefront kernel: PG_PIPE_* in dp_device.h, shared with dp_pipe.hip
 unsigned pg_pipe_lds_bytes();
+unsigned pg_pipe_block();
 unsigned pg_tiles_lds_bytes();
 
 namespace {
@@ -558,10 +559,10 @@ int launch_fill(pagan_batch *b) {
         const int n_small = b->n_ring_small, n_big = b->n_ring - b->n_ring_small;
         if (b->use_pipe) {
             if (n_small > 0)
-                hipLaunchKernelGGL(pg_fill_pipe<true>, dim3(n_small), dim3(320), pg_pipe_lds_bytes(), b->stream,
+                hipLaunchKernelGGL(pg_fill_pipe<true>, dim3(n_small), dim3(pg_pipe_block()), pg_pipe_lds_bytes(), b->stream,
                                    b->d_jobs, b->d_which, b->flags);
             if (n_big > 0)
-                hipLaunchKernelGGL(pg_fill_pipe<false>, dim3(n_big), dim3(320), pg_pipe_lds_bytes(), b->stream,
+                hipLaunchKernelGGL(pg_fill_pipe<false>, dim3(n_big), dim3(pg_pipe_block()), pg_pipe_lds_bytes(), b->stream,
                                    b->d_jobs, b->d_which + n_small, b->flags);
         } else {
             if (n_small > 0)
@@ -921,7 +922,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
                 const long long boff = 24 * hj.dx.doff[t];
                 packed[8 * t + 2] = (int)(boff & 0xffffffffLL); packed[8 * t + 3] = (int)(boff >> 32);
                 mask = ((mask << 1) | (t >= 1 && hj.cls[t - 1] <= 3 ? 2u : 0u)) & (((1u << PG_PIPE_REACH) - 1u) & ~1u);
-                const unsigned pair = t + 1 < hj.cls.size() && hj.cls[t + 1] <= 1 ? 1u : 0u;   // the next step is hot too
+                const unsigned pair = t + 1 < hj.cls.size() && hj.cls[t + 1] <= 2 ? 1u : 0u;   // the next step is hot too
                 packed[8 * t + 4] = (int)(hj.cls[t] | (pair << 4) | (mask << 5));
                 packed[8 * t + 5] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[8 * t + 6] = (int)(hj.dx.doff[t] >> 32);
                 packed[8 * t + 7] = hj.lead_req[t];

@@ -37,13 +37,15 @@
 
 // Geometry of the banded fill kernel (dp_pipe.hip) that the host-side planner (dp_abi.hip:
 // classify_diagonals, schedule_waves) has to agree with.
-#define PG_PIPE_WIDTH 236        // widest diagonal computed in the lanes' registers (256 lanes - PG_PIPE_REACH)
-#define PG_PIPE_REACH 20         // a cell may read PG_PIPE_REACH-1 diagonals back in the LDS ring: the whole ring but the
-                                 // row being written.  A longer reach turns far steps into ring steps; what it costs in
-                                 // pipeline slack is paid only where a cell near a wave boundary really reaches that far
-                                 // (per-diagonal lead requirement from the planner).  Root of cfg4: 16 -> 19 -> 20 =
-                                 // 355 -> 344 -> 358 ms with a fixed lead, 336 -> 322 -> 317 ms with the planned one.
-#define PG_PIPE_RING 20          // ring depth in diagonals: a wave stays awake this long after its last cell
+#define PG_PIPE_WIDTH 241        // widest diagonal computed in the lanes' registers (256 lanes - PG_PIPE_REACH)
+#define PG_PIPE_REACH 15         // a cell may read PG_PIPE_REACH-1 diagonals back in the LDS ring: the whole ring but the
+                                 // row being written.  Older operands come from L2.  Since the multi-edge candidates are
+                                 // evaluated by assist waves ahead of the compute waves (dp_pipe.hip), an L2 read is off the
+                                 // critical path, and five diagonals of the ring (20 in round 1) became the staging slots
+                                 // through which the assist waves hand their results over.
+#define PG_PIPE_RING 15          // ring depth in diagonals: a wave stays awake this long after its last cell
+#define PG_PIPE_ASSIST 3         // assist waves: wave a takes the multi-edge cells of the diagonals d with d % 3 == a
+#define PG_PIPE_STAGE 3          // staging slots (d % 3, one per assist wave): a diagonal is staged at most two ahead of the compute waves
 #define PG_PIPE_WAKE 6           // ... and wakes this many diagonals before its first one (operand prefetch pipeline)
 #define PG_PIPE_WINDOW 352       // widest diagonal the kernel's site-record windows (512 sites) still cover
 #define PG_PIPE_EDGE_CAP 1024    // bwd edges of any PG_RING_SITE_SPAN consecutive sites must fit the LDS edge window

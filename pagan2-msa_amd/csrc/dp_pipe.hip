@@ -56,7 +56,15 @@
 #define PDR_REACH 60             // oldest diagonal looked up in it
 #define PLOOK 64                 // diagonals the loader looks ahead of the slowest wave
 #define PLAND 8                  // stores of diagonal d have landed once the storing wave completed d+PLAND
+#define PNA PG_PIPE_ASSIST       // assist waves
+#define PST PG_PIPE_STAGE        // staging slots
+#define PBLOCK (PNT + 64 * PNA + 64)     // compute waves, assist waves, loader wave
 static_assert(PNTW == PNT - PAGE && PRK >= PAGE && PG_PIPE_WINDOW + 160 <= PRW, "kernel geometry out of step with dp_device.h");
+static_assert(PNA == 3 && PST == 3 && PAGE >= PLAND + 4, "assist wave a stages the diagonals d % 3 == a into slot a, at most two diagonals ahead; far cells have landed");
+// staged back-pointer words: the regular bits of a back-pointer plus what the compute wave needs to merge
+#define PS_ONLY 0x80000000u      // the site has no edge from the previous site: the staged value IS the state's value
+#define PS_FIRST 0x40000000u     // the staged winner precedes the previous-site edge in the list: it wins a tie
+#define PS_BP 0x3fffffffu
 #define PSPIN_LIMIT (1 << 25)     // ~10 s of polling: far beyond any legitimate wait (a wave sleeping through a long gap)
 
 // site record, word x
@@ -77,9 +85,17 @@ struct PipeSmem {
     int arrived[PNW];            // last rendezvous diagonal each compute wave drained for
     int loaded[3];               // rows / columns / diagonal descriptors staged by the loader
     int abort_flag;
+    // what the assist waves hand over, per staging slot (d % PST) and lane of the compute waves (row % 256):
+    // best candidate of X / Y over the bwd edges that do NOT come from the previous site, M over all edge pairs
+    double sx[PST][PNT], sy[PST][PNT], sM[PST][PNT];
+    unsigned spx[PST][PNT], spy[PST][PNT], spm[PST][PNT];
+    float ssm[PST][PNT];         // the model's score of the cell (large tables: gathered from L2 by the assist wave)
+    int assist_done[PNA];        // last diagonal each assist wave has staged
+    int as_list[PNA][64];        // rows of the multi-edge cells of the diagonal an assist wave is working on, compacted
 };
 
 unsigned pg_pipe_lds_bytes() { return (unsigned)sizeof(PipeSmem); }
+unsigned pg_pipe_block() { return PBLOCK; }
 
 extern __shared__ __attribute__((aligned(16))) char pg_pipe_lds[];
 #define PM (*reinterpret_cast<PipeSmem *>(pg_pipe_lds))
@@ -267,49 +283,67 @@ __device__ __forceinline__ void old_cells3(gdouble_w sc, cdesc8_p psc, int d, in
     v[2][0] = xy2.x; v[2][1] = xy2.y; v[2][2] = m2;
 }
 
-// Item loop of one multi-edge cell (class 1/2: interior, both sites have bwd edges): the (left edge,
-// right edge) pairs row-major, which visits the X candidates in left-list order, the Y candidates
-// in right-list order and the M candidates in the reference's pair order (VA:1396-1433).
+// The part of a multi-edge cell (class 1/2: interior) that does not need the previous diagonal, evaluated by an ASSIST
+// wave up to two diagonals ahead of the compute waves:
+//   X: the candidates of every left bwd edge that does NOT start at the previous site (an edge from row-1 reads the
+//      cell (row-1, j) of diagonal d-1: that one stays with the compute wave, whose straight-line code is exactly its
+//      three candidates -- gap candidates ignore edge weights, VA:2116-2219);
+//   Y: the same for the right site;
+//   M: every (left edge, right edge) pair, row-major (VA:1396-1433): all of them read diagonals <= d-2.
+// Candidates in list order, strict > (first wins).  The compute wave merges: X/Y by value, ties by list position
+// (PS_FIRST: the staged winner's edge precedes the previous-site edge; PS_ONLY: there is no previous-site edge, the
+// staged value is the state's value); M is taken as it is.  adjacent-edge slots travel in unused bits of the staged
+// words so that the compute wave's back-pointer names the right list slot.  This is the general form (any number of
+// edges, sites without edges); assist1_cell / assist2_cell are its straight-line special cases.
 template <bool FAR>
-__device__ __forceinline__ void multi_cell(gdouble_w sc, cdesc8_p psc, int d, int slot, unsigned resmask, const pg_i4 &rL,
-                                           const pg_i4 &cR, int row, int j, bool reduced_terminal, double go, double ge,
-                                           double ng, double tM, double tX, double &bx, double &by, double &bm,
-                                           unsigned &px, unsigned &py, unsigned &pm) {
+__device__ __forceinline__ void assist_cell(gdouble_w sc, cdesc8_p psc, int d, int slot, unsigned resmask, const pg_i4 &rL,
+                                            const pg_i4 &cR, int row, int j, bool reduced_terminal, double go, double ge,
+                                            double ng, double tM, double tX, double &ex, double &ey, double &em,
+                                            unsigned &px, unsigned &py, unsigned &pm) {
     const double NI = neg_inf();
-    bx = NI; by = NI; bm = NI; px = PG_BP_NONE; py = PG_BP_NONE; pm = PG_BP_NONE;
+    ex = NI; ey = NI; em = NI; px = PG_BP_NONE; py = PG_BP_NONE; pm = PG_BP_NONE;
     const int nL = (rL.x >> PR_NE_SHIFT) & 127, nR = (cR.x >> PR_NE_SHIFT) & 127;
-    const int n_items = nL * nR;
-    int k1 = 0, k2 = 0, dL, dR;
+    int adjL = -1, adjR = -1, winL = -1, winR = -1, dL, dR;
     double lw, rw;
-    edge_at<true>(rL, 0, row, dL, lw);
-    edge_at<false>(cR, 0, j, dR, rw);
+    for (int k = 0; k < nL; ++k) { edge_at<true>(rL, k, row, dL, lw); if (dL == 1) adjL = k; }
+    for (int k = 0; k < nR; ++k) { edge_at<false>(cR, k, j, dR, rw); if (dR == 1) adjR = k; }
+    const int n_items = nL * nR;
+    int k1 = 0, k2 = 0;
+    if (n_items > 0) { edge_at<true>(rL, 0, row, dL, lw); edge_at<false>(cR, 0, j, dR, rw); }
     for (int t = 0; t < n_items; ++t) {
         double v[3][3], c;
-        const CellAsk ax = {k2 == 0, dL, row - dL}, ay = {k1 == 0, dR, row}, am = {true, dL + dR, row - dL};
+        const bool do_x = k2 == 0 && dL != 1, do_y = k1 == 0 && dR != 1;
+        const CellAsk ax = {do_x, dL, row - dL}, ay = {do_y, dR, row}, am = {true, dL + dR, row - dL};
         old_cells3<FAR>(sc, psc, d, slot, resmask, ax, ay, am, v);
-        if (k2 == 0) {                                                // X candidates of left edge k1
+        if (do_x) {                                                   // X candidates of left edge k1
             const double open = (reduced_terminal && row == dL) ? 0.0 : go;
-            const unsigned w = pack_bp(0, k1, 0, dL == 1, false);
-            c = v[0][0] + ge;            if (c > bx) { bx = c; px = w | PG_X; }
-            c = (v[0][1] + 0.0) + go;    if (c > bx) { bx = c; px = w | PG_Y; }
-            c = (v[0][2] + ng) + open;   if (c > bx) { bx = c; px = w | PG_M; }
+            const unsigned w = pack_bp(0, k1, 0, false, false);
+            c = v[0][0] + ge;            if (c > ex) { ex = c; px = w | PG_X; winL = k1; }
+            c = (v[0][1] + 0.0) + go;    if (c > ex) { ex = c; px = w | PG_Y; winL = k1; }
+            c = (v[0][2] + ng) + open;   if (c > ex) { ex = c; px = w | PG_M; winL = k1; }
         }
-        if (k1 == 0) {                                                // Y candidates of right edge k2
+        if (do_y) {                                                   // Y candidates of right edge k2
             const double open = (reduced_terminal && j == dR) ? 0.0 : go;
-            const unsigned w = pack_bp(0, 0, k2, false, dR == 1);
-            c = v[1][1] + ge;            if (c > by) { by = c; py = w | PG_Y; }
-            c = (v[1][0] + 0.0) + go;    if (c > by) { by = c; py = w | PG_X; }
-            c = (v[1][2] + ng) + open;   if (c > by) { by = c; py = w | PG_M; }
+            const unsigned w = pack_bp(0, 0, k2, false, false);
+            c = v[1][1] + ge;            if (c > ey) { ey = c; py = w | PG_Y; winR = k2; }
+            c = (v[1][0] + 0.0) + go;    if (c > ey) { ey = c; py = w | PG_X; winR = k2; }
+            c = (v[1][2] + ng) + open;   if (c > ey) { ey = c; py = w | PG_M; winR = k2; }
         }
         {                                                             // M candidates of the pair
             const unsigned w = pack_bp(0, k1, k2, dL == 1, dR == 1);
-            c = ((v[2][2] + tM) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_M; }
-            c = ((v[2][0] + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_X; }
-            c = ((v[2][1] + tX) + lw) + rw;  if (c > bm) { bm = c; pm = w | PG_Y; }
+            c = ((v[2][2] + tM) + lw) + rw;  if (c > em) { em = c; pm = w | PG_M; }
+            c = ((v[2][0] + tX) + lw) + rw;  if (c > em) { em = c; pm = w | PG_X; }
+            c = ((v[2][1] + tX) + lw) + rw;  if (c > em) { em = c; pm = w | PG_Y; }
         }
         if (++k2 == nR) { k2 = 0; ++k1; if (k1 < nL) edge_at<true>(rL, k1, row, dL, lw); }
         edge_at<false>(cR, k2, j, dR, rw);
     }
+    // X: regular bits 0-17 (from, k1 << 4), the previous-site edge's slot in bits 18-24; Y: regular bits 0-3 and 18-24
+    // (k2 << 18), the previous-site edge's slot in bits 4-10
+    px |= (unsigned)(adjL < 0 ? 0 : adjL) << 18;
+    py |= (unsigned)(adjR < 0 ? 0 : adjR) << 4;
+    if (adjL < 0) px |= PS_ONLY; else if (winL >= 0 && winL < adjL) px |= PS_FIRST;
+    if (adjR < 0) py |= PS_ONLY; else if (winR >= 0 && winR < adjR) py |= PS_FIRST;
 }
 
 // One candidate of a cell state: replaces the incumbent only if strictly greater (first wins).
@@ -423,98 +457,6 @@ __device__ __forceinline__ void multi2_cell(gdouble_w sc, cdesc8_p psc, int d, u
     }
 }
 
-// Multi-edge cell with ONE multi-edge site (at most two bwd edges) opposite a simple site -- what a wave
-// usually holds: two such cells in one lane need both sites after a gap.  Half of multi2_cell's work: the
-// gap state of the simple side is the straight-line result the caller already has; the gap state of the
-// multi-edge side reads two cells, M two cells (the simple side's edge is the adjacent one, weight 0).  Which
-// side is which differs between lanes, so the operands are selected per lane and the arithmetic is
-// multi2_cell's (minus additions of the simple side's zero weight): G = X with the cells (i - dL, j) for a left multi-edge site, Y with
-// (i, j - dR) for a right one; M pairs (l_k, r_0) or (l_0, r_k), k = 0, 1, in list order.
-// FAR (class 2): cells that have left the ring come from L2, requested together, as in multi2_cell<true>, and an
-// edge of the multi-edge site may start at site 0, where the gap-open term differs.
-template <bool FAR>
-__device__ __forceinline__ void multi1_cell(gdouble_w sc, cdesc8_p psc, int d, unsigned resmask, int slot, const pg_i4 &rL,
-                                            const pg_i4 &cR, int row, int j, bool reduced_terminal, double go, double ge,
-                                            double ng, double tM, double tX, double &bx, double &by, double &bm, unsigned &px,
-                                            unsigned &py, unsigned &pm) {
-    const double NI = neg_inf();
-    const bool left = !(rL.x & PR_SIMPLE);                  // the multi-edge site is the left one
-    const pg_i4 m = left ? rL : cR;
-    const bool has1 = ((m.x >> PR_NE_SHIFT) & 127) > 1;
-    const int d0 = m.y & 0xffff, d1 = (int)((unsigned)m.y >> 16);
-    const double w0 = (double)__int_as_float(m.z), w1 = (double)__int_as_float(m.w);
-    // The simple side's edge weight is 0, and `+ 0.0` changes nothing but the sign of a zero, which no score
-    // of a job on this kernel has (has_negative_zero, dp_abi.hip): ((s + t) + lw) + rw = (s + t) + w either way.
-    const int pa0 = left ? row - d0 : row, pa1 = left ? row - d1 : row;         // gap operands: (i - dL, j) or (i, j - dR)
-    const int pb0 = left ? row - d0 : row - 1, pb1 = left ? row - d1 : row - 1; // M operands: (i - dL, j - 1) or (i - 1, j - dR)
-    double a0x, a0y, a0m, a1x, a1y, a1m, b0x, b0y, b0m, b1x, b1y, b1m;
-    if (!FAR) {
-        auto cell = [&](int age, int p, bool present, double &xs, double &ys, double &ms) {
-            int s = slot - age;
-            s += s < 0 ? PRK : 0;
-            const double *c = present ? &PM.sc[s][p & (PNT - 1)][0] : &PM.null_cell[0];
-            xs = c[PG_X]; ys = c[PG_Y]; ms = c[PG_M];
-        };
-        cell(d0, pa0, true, a0x, a0y, a0m);
-        cell(d1, pa1, has1, a1x, a1y, a1m);
-        cell(d0 + 1, pb0, true, b0x, b0y, b0m);
-        cell(d1 + 1, pb1, has1, b1x, b1y, b1m);
-    } else {
-        pg_d2 q[4];
-        double qm[4];
-        auto cell = [&](int k, int age, int p, bool present) {
-            q[k].x = NI; q[k].y = NI; qm[k] = NI;
-            if (!present) return;
-            if (age < PAGE && ((resmask >> age) & 1u)) {
-                int s = slot - age;
-                s += s < 0 ? PRK : 0;
-                q[k].x = PM.sc[s][p & (PNT - 1)][PG_X]; q[k].y = PM.sc[s][p & (PNT - 1)][PG_Y]; qm[k] = PM.sc[s][p & (PNT - 1)][PG_M];
-            } else {
-                const int dd = d - age;
-                pg_i4 ds;
-                if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
-                else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
-                if (p >= ds.x && p <= ds.y) {
-                    const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p - ds.x);
-                    far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc + boff), q[k], qm[k]);
-                }
-            }
-        };
-        cell(0, d0, pa0, true);
-        cell(1, d1, pa1, has1);
-        cell(2, d0 + 1, pb0, true);
-        cell(3, d1 + 1, pb1, has1);
-        far_wait3(q[0], qm[0], q[1], qm[1], q[2], qm[2]);
-        { pg_d2 dq = {NI, NI}; double dm = NI; pg_d2 dq2 = {NI, NI}; double dm2 = NI; far_wait3(q[3], qm[3], dq, dm, dq2, dm2); }
-        a0x = q[0].x; a0y = q[0].y; a0m = qm[0];  a1x = q[1].x; a1y = q[1].y; a1m = qm[1];
-        b0x = q[2].x; b0y = q[2].y; b0m = qm[2];  b1x = q[3].x; b1y = q[3].y; b1m = qm[3];
-    }
-    // an edge of the multi-edge site that starts at site 0 opens a gap for free (BA.h:490-513); class 1 diagonals lie
-    // PAGE rows and columns inside the matrix
-    const int at = left ? row : j;
-    const double o0 = (FAR && reduced_terminal && at == d0) ? 0.0 : go, o1 = (FAR && reduced_terminal && at == d1) ? 0.0 : go;
-    const unsigned adj = left ? PG_BP_ADJL : PG_BP_ADJR, other = left ? PG_BP_ADJR : PG_BP_ADJL;
-    const unsigned k1 = left ? (1u << 4) : (1u << 18);
-    const unsigned e0 = d0 == 1 ? adj : 0u, e1 = (d1 == 1 ? adj : 0u) | k1;
-    const unsigned self = left ? PG_X : PG_Y, cross = left ? PG_Y : PG_X;
-    {   // the multi-edge side's gap state: per edge own state, the other gap state, M (VA:898-915 / 927-944)
-        double g = NI;
-        unsigned pg = PG_BP_NONE;
-        const double s0 = left ? a0x : a0y, c0 = left ? a0y : a0x, s1 = left ? a1x : a1y, c1 = left ? a1y : a1x;
-        cand(s0 + ge, e0 | self, g, pg); cand(c0 + go, e0 | cross, g, pg); cand((a0m + ng) + o0, e0 | PG_M, g, pg);
-        cand(s1 + ge, e1 | self, g, pg); cand(c1 + go, e1 | cross, g, pg); cand((a1m + ng) + o1, e1 | PG_M, g, pg);
-        bx = left ? g : bx; px = left ? pg : px;
-        by = left ? by : g; py = left ? py : pg;
-    }
-    {   // M: the two (left edge, right edge) pairs in list order (VA:1396-1433)
-        bm = NI; pm = PG_BP_NONE;
-        unsigned w = e0 | other;
-        cand((b0m + tM) + w0, w | PG_M, bm, pm); cand((b0x + tX) + w0, w | PG_X, bm, pm); cand((b0y + tX) + w0, w | PG_Y, bm, pm);
-        w = e1 | other;
-        cand((b1m + tM) + w1, w | PG_M, bm, pm); cand((b1x + tX) + w1, w | PG_X, bm, pm); cand((b1y + tX) + w1, w | PG_Y, bm, pm);
-    }
-}
-
 __device__ __forceinline__ double in_vgpr(double x) {
     asm volatile("" : "+v"(x));
     return x;
@@ -559,6 +501,490 @@ __device__ __attribute__((noinline)) void widest_step(const PgDevJob *job, cdesc
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// assist_cell for sites with one or two bwd edges each (nearly all multi-edge cells: a site after a gap has the edge
+// from its predecessor and the one that skips the gap): the up to 2 + 2 + 4 operand cells are read at once and the
+// candidates evaluated as straight-line code in the reference's order.  An absent operand -- a missing second edge, or
+// a gap candidate of the edge from the previous site, which the compute wave evaluates -- reads the all -inf null cell
+// and cannot win.  With at most two edges the tie rule is simple: the staged X (Y) winner precedes the previous-site
+// edge exactly when that edge is the SECOND one.
+template <bool FAR>
+__device__ __forceinline__ void assist2_cell(gdouble_w sc, cdesc8_p psc, int d, unsigned resmask, int slot, const pg_i4 &rL,
+                                             const pg_i4 &cR, int row, int j, bool reduced_terminal, double go, double ge,
+                                             double ng, double tM, double tX, double &ex, double &ey, double &em,
+                                             unsigned &px, unsigned &py, unsigned &pm) {
+    const double NI = neg_inf();
+    const bool l1 = ((rL.x >> PR_NE_SHIFT) & 127) > 1, r1 = ((cR.x >> PR_NE_SHIFT) & 127) > 1;
+    const int dL0 = rL.y & 0xffff, dL1 = (int)((unsigned)rL.y >> 16), dR0 = cR.y & 0xffff, dR1 = (int)((unsigned)cR.y >> 16);
+    const double lw0 = (double)__int_as_float(rL.z), lw1 = (double)__int_as_float(rL.w);
+    const double rw0 = (double)__int_as_float(cR.z), rw1 = (double)__int_as_float(cR.w);
+    const bool xa_on = dL0 != 1, xb_on = l1 && dL1 != 1, ya_on = dR0 != 1, yb_on = r1 && dR1 != 1;
+    double xa_x, xa_y, xa_m, xb_x, xb_y, xb_m, ya_x, ya_y, ya_m, yb_x, yb_y, yb_m;
+    double m00x, m00y, m00m, m01x, m01y, m01m, m10x, m10y, m10m, m11x, m11y, m11m;
+    if (!FAR) {
+        auto cell = [&](int age, int p, bool present, double &xs, double &ys, double &ms) {
+            int s_ = slot - age;
+            s_ += s_ < 0 ? PRK : 0;
+            const double *c = present ? &PM.sc[s_][p & (PNT - 1)][0] : &PM.null_cell[0];
+            xs = c[PG_X]; ys = c[PG_Y]; ms = c[PG_M];
+        };
+        cell(dL0, row - dL0, xa_on, xa_x, xa_y, xa_m);
+        cell(dL1, row - dL1, xb_on, xb_x, xb_y, xb_m);
+        cell(dR0, row, ya_on, ya_x, ya_y, ya_m);
+        cell(dR1, row, yb_on, yb_x, yb_y, yb_m);
+        cell(dL0 + dR0, row - dL0, true, m00x, m00y, m00m);
+        cell(dL0 + dR1, row - dL0, r1, m01x, m01y, m01m);
+        cell(dL1 + dR0, row - dL1, l1, m10x, m10y, m10m);
+        cell(dL1 + dR1, row - dL1, l1 && r1, m11x, m11y, m11m);
+    } else {
+        pg_d2 q[8];
+        double qm[8];
+        auto cell = [&](int k, int age, int p, bool present) {
+            q[k].x = NI; q[k].y = NI; qm[k] = NI;
+            if (!present) return;
+            if (age < PAGE && ((resmask >> age) & 1u)) {
+                int s_ = slot - age;
+                s_ += s_ < 0 ? PRK : 0;
+                q[k].x = PM.sc[s_][p & (PNT - 1)][PG_X]; q[k].y = PM.sc[s_][p & (PNT - 1)][PG_Y]; qm[k] = PM.sc[s_][p & (PNT - 1)][PG_M];
+            } else {
+                const int dd = d - age;
+                pg_i4 ds;
+                if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
+                else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
+                if (p >= ds.x && p <= ds.y) {
+                    const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p - ds.x);
+                    far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc + boff), q[k], qm[k]);
+                }
+            }
+        };
+        cell(0, dL0, row - dL0, xa_on);
+        cell(1, dL1, row - dL1, xb_on);
+        cell(2, dR0, row, ya_on);
+        cell(3, dR1, row, yb_on);
+        cell(4, dL0 + dR0, row - dL0, true);
+        cell(5, dL0 + dR1, row - dL0, r1);
+        cell(6, dL1 + dR0, row - dL1, l1);
+        cell(7, dL1 + dR1, row - dL1, l1 && r1);
+        far_wait3(q[0], qm[0], q[1], qm[1], q[2], qm[2]);
+        far_wait3(q[3], qm[3], q[4], qm[4], q[5], qm[5]);
+        { pg_d2 dq = {NI, NI}; double dm = NI; far_wait3(q[6], qm[6], q[7], qm[7], dq, dm); }
+        xa_x = q[0].x; xa_y = q[0].y; xa_m = qm[0];  xb_x = q[1].x; xb_y = q[1].y; xb_m = qm[1];
+        ya_x = q[2].x; ya_y = q[2].y; ya_m = qm[2];  yb_x = q[3].x; yb_y = q[3].y; yb_m = qm[3];
+        m00x = q[4].x; m00y = q[4].y; m00m = qm[4];  m01x = q[5].x; m01y = q[5].y; m01m = qm[5];
+        m10x = q[6].x; m10y = q[6].y; m10m = qm[6];  m11x = q[7].x; m11y = q[7].y; m11m = qm[7];
+    }
+    const unsigned aL0 = dL0 == 1 ? PG_BP_ADJL : 0u, aL1 = dL1 == 1 ? PG_BP_ADJL : 0u;
+    const unsigned aR0 = dR0 == 1 ? PG_BP_ADJR : 0u, aR1 = dR1 == 1 ? PG_BP_ADJR : 0u;
+    ex = NI; ey = NI; em = NI; px = PG_BP_NONE; py = PG_BP_NONE; pm = PG_BP_NONE;
+    {   // X: the left edges that do not start at the previous site (VA:898-915); an edge in reach may start at site 0 (class 2)
+        const double o0 = (FAR && reduced_terminal && row == dL0) ? 0.0 : go, o1 = (FAR && reduced_terminal && row == dL1) ? 0.0 : go;
+        cand(xa_x + ge, PG_X, ex, px); cand((xa_y + 0.0) + go, PG_Y, ex, px); cand((xa_m + ng) + o0, PG_M, ex, px);
+        const unsigned w1 = 1u << 4;
+        cand(xb_x + ge, w1 | PG_X, ex, px); cand((xb_y + 0.0) + go, w1 | PG_Y, ex, px); cand((xb_m + ng) + o1, w1 | PG_M, ex, px);
+    }
+    {   // Y: the same for the right edges (VA:927-944)
+        const double o0 = (FAR && reduced_terminal && j == dR0) ? 0.0 : go, o1 = (FAR && reduced_terminal && j == dR1) ? 0.0 : go;
+        cand(ya_y + ge, PG_Y, ey, py); cand((ya_x + 0.0) + go, PG_X, ey, py); cand((ya_m + ng) + o0, PG_M, ey, py);
+        const unsigned w1 = 1u << 18;
+        cand(yb_y + ge, w1 | PG_Y, ey, py); cand((yb_x + 0.0) + go, w1 | PG_X, ey, py); cand((yb_m + ng) + o1, w1 | PG_M, ey, py);
+    }
+    {   // M: (left edge, right edge) pairs row-major (VA:1396-1433)
+        unsigned w = aL0 | aR0;
+        cand(((m00m + tM) + lw0) + rw0, w | PG_M, em, pm); cand(((m00x + tX) + lw0) + rw0, w | PG_X, em, pm);
+        cand(((m00y + tX) + lw0) + rw0, w | PG_Y, em, pm);
+        w = aL0 | aR1 | (1u << 18);
+        cand(((m01m + tM) + lw0) + rw1, w | PG_M, em, pm); cand(((m01x + tX) + lw0) + rw1, w | PG_X, em, pm);
+        cand(((m01y + tX) + lw0) + rw1, w | PG_Y, em, pm);
+        w = aL1 | aR0 | (1u << 4);
+        cand(((m10m + tM) + lw1) + rw0, w | PG_M, em, pm); cand(((m10x + tX) + lw1) + rw0, w | PG_X, em, pm);
+        cand(((m10y + tX) + lw1) + rw0, w | PG_Y, em, pm);
+        w = aL1 | aR1 | (1u << 4) | (1u << 18);
+        cand(((m11m + tM) + lw1) + rw1, w | PG_M, em, pm); cand(((m11x + tX) + lw1) + rw1, w | PG_X, em, pm);
+        cand(((m11y + tX) + lw1) + rw1, w | PG_Y, em, pm);
+    }
+    // `cand` keeps the incumbent's back-pointer while nothing beats -inf: an all -inf state ends as PG_BP_NONE
+    const int adjL = dL0 == 1 ? 0 : ((l1 && dL1 == 1) ? 1 : -1), adjR = dR0 == 1 ? 0 : ((r1 && dR1 == 1) ? 1 : -1);
+    px |= (unsigned)(adjL < 0 ? 0 : adjL) << 18;
+    py |= (unsigned)(adjR < 0 ? 0 : adjR) << 4;
+    px |= adjL < 0 ? PS_ONLY : ((adjL == 1 && ex > NI) ? PS_FIRST : 0u);
+    py |= adjR < 0 ? PS_ONLY : ((adjR == 1 && ey > NI) ? PS_FIRST : 0u);
+}
+
+// assist_cell for a cell with ONE multi-edge site (one to three bwd edges) opposite a simple site -- what a diagonal
+// usually holds: two multi-edge sites in one cell need a gap in both children at the same place.  The simple side's gap
+// state is the compute wave's; staged are the multi-edge side's gap state over its edges that do not start at the
+// previous site (operands (i - dL, j) for a left site, (i, j - dR) for a right one) and M over the pairs (edge k, the
+// simple site's edge), k in list order, operands one diagonal further back.  THREE: some cell of the batch has a third
+// edge (it comes from the LDS edge window, the first two travel in the site record).
+template <bool FAR, bool THREE>
+__device__ __forceinline__ void assist1_cell(gdouble_w sc, cdesc8_p psc, int d, unsigned resmask, int slot, const pg_i4 &rL,
+                                             const pg_i4 &cR, int row, int j, bool reduced_terminal, double go, double ge,
+                                             double ng, double tM, double tX, double &eg, double &em, unsigned &pg,
+                                             unsigned &pm, bool &left) {
+    const double NI = neg_inf();
+    left = !(rL.x & PR_SIMPLE);                             // the multi-edge site is the left one
+    const pg_i4 m = left ? rL : cR;
+    const int site = left ? row : j;
+    const int ne = (m.x >> PR_NE_SHIFT) & 127;
+    const bool has1 = ne > 1, has2 = THREE && ne > 2;
+    const int d0 = m.y & 0xffff, d1 = (int)((unsigned)m.y >> 16);
+    const double w0 = (double)__int_as_float(m.z), w1 = (double)__int_as_float(m.w);
+    int d2 = 2;
+    double w2 = 0.0;
+    if (THREE && has2) {
+        const int e = (left ? PM.ebL : PM.ebR)[site & (PRW - 1)] + 2;
+        d2 = site - (left ? PM.esL : PM.esR)[e & (PEC - 1)];
+        w2 = (double)(left ? PM.ewL : PM.ewR)[e & (PEC - 1)];
+    }
+    // The simple side's edge weight is 0, and `+ 0.0` changes nothing but the sign of a zero, which no score of a job
+    // on this kernel has (has_negative_zero, dp_abi.hip): ((s + t) + lw) + rw = (s + t) + w either way.
+    const int ga0 = left ? row - d0 : row, ga1 = left ? row - d1 : row, ga2 = left ? row - d2 : row;               // gap operands
+    const int mb0 = left ? row - d0 : row - 1, mb1 = left ? row - d1 : row - 1, mb2 = left ? row - d2 : row - 1;   // M operands
+    const bool g0 = d0 != 1, g1 = has1 && d1 != 1, g2 = has2 && d2 != 1;
+    double a0x, a0y, a0m, a1x, a1y, a1m, a2x = NI, a2y = NI, a2m = NI, b0x, b0y, b0m, b1x, b1y, b1m, b2x = NI, b2y = NI, b2m = NI;
+    if (!FAR) {
+        auto cell = [&](int age, int p, bool present, double &xs, double &ys, double &ms) {
+            int s_ = slot - age;
+            s_ += s_ < 0 ? PRK : 0;
+            const double *c = present ? &PM.sc[s_][p & (PNT - 1)][0] : &PM.null_cell[0];
+            xs = c[PG_X]; ys = c[PG_Y]; ms = c[PG_M];
+        };
+        cell(d0, ga0, g0, a0x, a0y, a0m);
+        cell(d1, ga1, g1, a1x, a1y, a1m);
+        cell(d0 + 1, mb0, true, b0x, b0y, b0m);
+        cell(d1 + 1, mb1, has1, b1x, b1y, b1m);
+        if (THREE) { cell(d2, ga2, g2, a2x, a2y, a2m); cell(d2 + 1, mb2, has2, b2x, b2y, b2m); }
+    } else {
+        pg_d2 q[6];
+        double qm[6];
+        auto cell = [&](int k, int age, int p, bool present) {
+            q[k].x = NI; q[k].y = NI; qm[k] = NI;
+            if (!present) return;
+            if (age < PAGE && ((resmask >> age) & 1u)) {
+                int s_ = slot - age;
+                s_ += s_ < 0 ? PRK : 0;
+                q[k].x = PM.sc[s_][p & (PNT - 1)][PG_X]; q[k].y = PM.sc[s_][p & (PNT - 1)][PG_Y]; qm[k] = PM.sc[s_][p & (PNT - 1)][PG_M];
+            } else {
+                const int dd = d - age;
+                pg_i4 ds;
+                if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
+                else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
+                if (p >= ds.x && p <= ds.y) {
+                    const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p - ds.x);
+                    far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc + boff), q[k], qm[k]);
+                }
+            }
+        };
+        cell(0, d0, ga0, g0);
+        cell(1, d1, ga1, g1);
+        cell(2, d0 + 1, mb0, true);
+        cell(3, d1 + 1, mb1, has1);
+        cell(4, d2, ga2, g2);
+        cell(5, d2 + 1, mb2, has2);
+        far_wait3(q[0], qm[0], q[1], qm[1], q[2], qm[2]);
+        far_wait3(q[3], qm[3], q[4], qm[4], q[5], qm[5]);
+        a0x = q[0].x; a0y = q[0].y; a0m = qm[0];  a1x = q[1].x; a1y = q[1].y; a1m = qm[1];
+        b0x = q[2].x; b0y = q[2].y; b0m = qm[2];  b1x = q[3].x; b1y = q[3].y; b1m = qm[3];
+        a2x = q[4].x; a2y = q[4].y; a2m = qm[4];  b2x = q[5].x; b2y = q[5].y; b2m = qm[5];
+    }
+    // an edge of the multi-edge site that starts at site 0 opens a gap for free (BA.h:490-513); class 1 diagonals lie
+    // PAGE rows and columns inside the matrix
+    const double o0 = (FAR && reduced_terminal && site == d0) ? 0.0 : go, o1 = (FAR && reduced_terminal && site == d1) ? 0.0 : go;
+    const double o2 = (FAR && reduced_terminal && site == d2) ? 0.0 : go;
+    const unsigned adj = left ? PG_BP_ADJL : PG_BP_ADJR, other = left ? PG_BP_ADJR : PG_BP_ADJL;
+    const unsigned kk = left ? (1u << 4) : (1u << 18);
+    const unsigned self = left ? PG_X : PG_Y, cross = left ? PG_Y : PG_X;
+    {   // the multi-edge side's gap state: per edge own state, the other gap state, M (VA:898-915 / 927-944)
+        eg = NI; pg = PG_BP_NONE;
+        const double s0 = left ? a0x : a0y, c0 = left ? a0y : a0x, s1 = left ? a1x : a1y, c1 = left ? a1y : a1x;
+        cand(s0 + ge, self, eg, pg); cand(c0 + go, cross, eg, pg); cand((a0m + ng) + o0, PG_M, eg, pg);
+        cand(s1 + ge, kk | self, eg, pg); cand(c1 + go, kk | cross, eg, pg); cand((a1m + ng) + o1, kk | PG_M, eg, pg);
+        if (THREE) {
+            const double s2 = left ? a2x : a2y, c2 = left ? a2y : a2x;
+            cand(s2 + ge, 2 * kk | self, eg, pg); cand(c2 + go, 2 * kk | cross, eg, pg); cand((a2m + ng) + o2, 2 * kk | PG_M, eg, pg);
+        }
+    }
+    {   // M: the (left edge, right edge) pairs in list order (VA:1396-1433)
+        em = NI; pm = PG_BP_NONE;
+        unsigned w = (d0 == 1 ? adj : 0u) | other;
+        cand((b0m + tM) + w0, w | PG_M, em, pm); cand((b0x + tX) + w0, w | PG_X, em, pm); cand((b0y + tX) + w0, w | PG_Y, em, pm);
+        w = (d1 == 1 ? adj : 0u) | kk | other;
+        cand((b1m + tM) + w1, w | PG_M, em, pm); cand((b1x + tX) + w1, w | PG_X, em, pm); cand((b1y + tX) + w1, w | PG_Y, em, pm);
+        if (THREE) {
+            w = (d2 == 1 ? adj : 0u) | 2 * kk | other;
+            cand((b2m + tM) + w2, w | PG_M, em, pm); cand((b2x + tX) + w2, w | PG_X, em, pm); cand((b2y + tX) + w2, w | PG_Y, em, pm);
+        }
+    }
+    // merge information: the previous-site edge's slot, whether the staged winner precedes it, whether it exists at all
+    const int adjs = d0 == 1 ? 0 : ((has1 && d1 == 1) ? 1 : ((has2 && d2 == 1) ? 2 : -1));
+    const int win = (int)((pg >> (left ? 4 : 18)) & 127u);
+    pg |= (unsigned)(adjs < 0 ? 0 : adjs) << (left ? 18 : 4);
+    pg |= adjs < 0 ? PS_ONLY : ((eg > NI && win < adjs) ? PS_FIRST : 0u);
+}
+
+// ---- assist waves ----------------------------------------------------------------------------------------------
+// Assist wave `a` stages, for every interior diagonal d with d % PNA == a (= its staging slot) that holds a multi-edge
+// site (class 1 or 2), what assist_cell computes for the diagonal's multi-edge cells -- compacted, lane = cell -- at the
+// compute lanes' positions (row % 256).  Nothing of it depends on diagonal d-1, so the wave computes d as soon as every
+// compute wave has completed d-2 and is done, as a rule, before the compute waves merge it near the end of their step d:
+// the multi-edge arithmetic, its LDS round trips and -- class 2 -- the L2 reads of cells that have left the ring run on a
+// SIMD of their own.  With a model table too large for LDS the wave also gathers every cell's model score (classes
+// 0..2) from L2, so that the compute waves never issue a load behind their stores.
+// Ring safety: the compute waves cannot pass d before this wave has published d, a cell reads at most PAGE-1
+// diagonals back, and step d' overwrites diagonal d'-PRK only: everything diagonal d reads is still in place.
+template <bool TAB_LDS>
+__device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, bool reduced_terminal) {
+    const int nd = job->nd, S = job->S;
+    const gdouble_w sc_out = (gdouble_w)job->sc;
+    const gfloat_p table = (gfloat_p)job->table;
+    const float f_ng = job->ng;
+    const double go = (double)job->go, ge = (double)job->ge, ng = (double)f_ng;
+    const double tng2 = (double)(2 * f_ng), tng1 = (double)(0.0f + f_ng);
+    const int wave = PNW + a;                                      // names this wave in an abort tag
+    int rows_ld = 0, cols_ld = 0, diags_ld = 0;
+    int pw0 = -1, pw1 = -1, pw2 = -1, pw3 = -1;                   // cached progress of the compute waves
+#ifdef PG_PIPE_STATS
+    long long st_poll_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int st_poll_n[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    int *list = PM.as_list[a];
+    const double NI_ = neg_inf();
+    // Software pipeline: everything a diagonal's batch needs that does NOT come out of the ring -- its descriptor, the scan
+    // of the band for multi-edge cells, their site records, edge data and model scores -- is prepared right after the
+    // previous diagonal has been published, while the compute waves are still steps away.  What is left between "the
+    // compute waves have completed d-2" and "d is staged" is the ring reads, the candidates and the staging stores.
+    int q_d = -1, q_cls = 0, q_lo = 0, q_hi = 0, q_n = 0;          // the prepared diagonal (q_d < 0: none)
+    unsigned q_mask = 0;
+    bool q_big = false;                                            // more than 64 multi-edge cells: not prepared, done in batches
+    int q_row = 0, q_j = 0, q_kind = 0;
+    pg_i4 q_rL = {0, 0, 0, 0}, q_cR = {0, 0, 0, 0};
+    double q_tM = 0, q_tX = 0;
+    // the usual batch (class 1, every cell one multi-edge site with at most two edges) decoded down to LDS offsets of its four
+    // operand cells, weights and back-pointer words: what remains for the critical chain is 12 LDS reads and 12 candidates
+    bool q_fast = false, q_left = true;
+    int q_oa0 = 0, q_oa1 = 0, q_ob0 = 0, q_ob1 = 0, q_adjs = -1;
+    unsigned q_e0 = 0, q_e1 = 0;                                   // ADJ flag / slot bits of the two edges in an M back-pointer
+    double q_w0 = 0, q_w1 = 0;
+    int scan_d = a;                                                // next diagonal whose descriptor has not been looked at
+
+    // classification of one multi-edge cell: 1 one multi-edge site with <= 2 edges, 2 ... with 3, 3 two multi-edge sites
+    // with <= 2 edges each, 4 anything else
+    auto classify = [&](const pg_i4 &rL, const pg_i4 &cR) {
+        const int nl = (rL.x >> PR_NE_SHIFT) & 127, nr = (cR.x >> PR_NE_SHIFT) & 127;
+        const bool sL = rL.x & PR_SIMPLE, sR = cR.x & PR_SIMPLE;
+        const int ne = sL ? nr : nl;
+        if ((sL || sR) && (unsigned)(ne - 1) < 3u) return ne == 3 ? 2 : 1;
+        if ((unsigned)(nl - 1) < 2u && (unsigned)(nr - 1) < 2u) return 3;
+        return 4;
+    };
+    // the ring-dependent part for one batch of cells held in registers
+    auto compute = [&](int d, int cls, unsigned resmask, bool on, int row, int j, int kind, const pg_i4 &rL, const pg_i4 &cR,
+                       double tM, double tX) {
+        const int slot = d % PRK, stg = d % PST, at = row & (PNT - 1);
+        if (__builtin_amdgcn_ballot_w64(on && kind >= 3) == 0) {
+            // the usual batch: one multi-edge site per cell
+            double eg = 0, em = 0;
+            unsigned pg = 0, pm = 0;
+            bool left = true;
+            const bool three = __builtin_amdgcn_ballot_w64(on && kind == 2) != 0;
+            if (on) {
+                if (cls == 2) {
+                    if (three) assist1_cell<true, true>(sc_out, psc, d, resmask, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, eg, em, pg, pm, left);
+                    else assist1_cell<true, false>(sc_out, psc, d, resmask, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, eg, em, pg, pm, left);
+                } else {
+                    if (three) assist1_cell<false, true>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, eg, em, pg, pm, left);
+                    else assist1_cell<false, false>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, eg, em, pg, pm, left);
+                }
+                if (left) { PM.sx[stg][at] = eg; PM.spx[stg][at] = pg; } else { PM.sy[stg][at] = eg; PM.spy[stg][at] = pg; }
+                PM.sM[stg][at] = em; PM.spm[stg][at] = pm;
+            }
+        } else if (on) {
+            double ex, ey, em;
+            unsigned px, py, pm;
+            if (kind == 4) {
+                if (cls == 2) assist_cell<true>(sc_out, psc, d, slot, resmask, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, ex, ey, em, px, py, pm);
+                else assist_cell<false>(sc_out, psc, d, slot, 0u, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, ex, ey, em, px, py, pm);
+            } else if (kind == 2) {
+                bool left;
+                double eg;
+                unsigned pg;
+                if (cls == 2) assist1_cell<true, true>(sc_out, psc, d, resmask, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, eg, em, pg, pm, left);
+                else assist1_cell<false, true>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, eg, em, pg, pm, left);
+                ex = ey = eg; px = py = pg;                        // the compute wave reads the multi-edge side's only
+            } else {
+                if (cls == 2) assist2_cell<true>(sc_out, psc, d, resmask, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, ex, ey, em, px, py, pm);
+                else assist2_cell<false>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, ex, ey, em, px, py, pm);
+            }
+            PM.sx[stg][at] = ex; PM.sy[stg][at] = ey; PM.sM[stg][at] = em;
+            PM.spx[stg][at] = px; PM.spy[stg][at] = py; PM.spm[stg][at] = pm;
+        }
+    };
+    // one batch from the compacted list into registers
+    auto fetch_batch = [&](int d, int stg, int n, bool &on, int &row, int &j, int &kind, pg_i4 &rL, pg_i4 &cR, double &tM, double &tX) {
+        on = lane < n;
+        row = 0; j = 0; kind = 0; tM = 0; tX = 0;
+        if (on) {
+            row = list[lane]; j = d - row;
+            rL = PM.recL[row & (PRW - 1)]; cR = PM.recR[j & (PRW - 1)];
+            const int ti = (rL.x & 0xffff) + (cR.x & 0xffff) * S;
+            const float sm = TAB_LDS ? PM.table[ti & 255] : PM.ssm[stg][row & (PNT - 1)];
+            tM = tng2 + (double)sm; tX = tng1 + (double)sm;
+            kind = classify(rL, cR);
+        }
+    };
+    // scan of a diagonal's band: model scores for large tables, the multi-edge cells compacted into `list`.  Returns their
+    // number; with `flush` batches of 64 are computed as they fill up (the diagonal must be computable then).
+    auto scan = [&](int d, int cls, int lo, int hi, unsigned resmask, bool flush) {
+        const int stg = d % PST;
+        int n_ns = 0, total = 0;
+        for (int base = lo; base <= hi; base += 64) {
+            const int row = base + lane, j = d - row;
+            bool ns = false;
+            if (row <= hi) {
+                const pg_i4 rL = PM.recL[row & (PRW - 1)], cR = PM.recR[j & (PRW - 1)];
+                if (!TAB_LDS) PM.ssm[stg][row & (PNT - 1)] = far_f32(table + ((rL.x & 0xffff) + (cR.x & 0xffff) * S));
+                ns = cls != 0 && !(rL.x & cR.x & PR_SIMPLE);
+            }
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(ns);
+            const int cnt = __builtin_popcountll(mask);
+            if (cnt == 0) continue;
+            total += cnt;
+            if (n_ns + cnt > 64) {
+                if (!flush) return total + 64;                     // too many for the register batch: the caller redoes it with flush
+                bool on; int r_, j_, k_; pg_i4 a_ = {0, 0, 0, 0}, b_ = {0, 0, 0, 0}; double tm_, tx_;
+                fetch_batch(d, stg, n_ns, on, r_, j_, k_, a_, b_, tm_, tx_);
+                compute(d, cls, resmask, on, r_, j_, k_, a_, b_, tm_, tx_);
+                n_ns = 0;
+            }
+            if (ns) list[n_ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = row;
+            n_ns += cnt;
+        }
+        if (flush && n_ns > 0) {
+            bool on; int r_, j_, k_; pg_i4 a_ = {0, 0, 0, 0}, b_ = {0, 0, 0, 0}; double tm_, tx_;
+            fetch_batch(d, stg, n_ns, on, r_, j_, k_, a_, b_, tm_, tx_);
+            compute(d, cls, resmask, on, r_, j_, k_, a_, b_, tm_, tx_);
+        }
+        return flush ? total : n_ns;
+    };
+    // looks for the next diagonal of this wave with work and prepares it
+    auto prepare = [&]() {
+        q_d = -1;
+        while (scan_d < nd) {
+            const int d = scan_d;
+            scan_d += PNA;
+            const pg_i8 cur = psc[d];
+            const int cls = cur.s4 & 15;
+            if (!((cls == 1 || cls == 2) || (!TAB_LDS && cls == 0))) continue;
+            const int lo = cur.x, hi = cur.y;
+            if (rows_ld <= hi) rows_ld = POLL(&PM.loaded[0], hi + 1, 1);
+            if (cols_ld <= d - lo) cols_ld = POLL(&PM.loaded[1], d - lo + 1, 2);
+            q_d = d; q_cls = cls; q_lo = lo; q_hi = hi; q_mask = (unsigned)cur.s4 >> 5;
+            // large tables: the scan writes the model scores into staging slot d % PST, whose previous user, diagonal
+            // d - PST, the compute waves must have completed
+            if (!TAB_LDS) {
+                if (pw0 < d - PST) pw0 = POLL(&PM.progress[0], d - PST, 9);
+                if (pw1 < d - PST) pw1 = POLL(&PM.progress[1], d - PST, 9);
+                if (pw2 < d - PST) pw2 = POLL(&PM.progress[2], d - PST, 9);
+                if (pw3 < d - PST) pw3 = POLL(&PM.progress[3], d - PST, 9);
+            }
+            const int n = scan(d, cls, lo, hi, q_mask, false);
+            q_big = n > 64;
+            q_n = q_big ? 0 : n;
+            q_fast = false;
+            if (!q_big) {
+                bool on;
+                fetch_batch(d, d % PST, q_n, on, q_row, q_j, q_kind, q_rL, q_cR, q_tM, q_tX);
+                q_fast = cls == 1 && q_n > 0 && __builtin_amdgcn_ballot_w64(on && q_kind != 1) == 0;
+                if (q_fast && on) {
+                    // assist1_cell<false, false>'s operand selection, done ahead of time
+                    q_left = !(q_rL.x & PR_SIMPLE);
+                    const pg_i4 m = q_left ? q_rL : q_cR;
+                    const bool has1 = ((m.x >> PR_NE_SHIFT) & 127) > 1;
+                    const int d0 = m.y & 0xffff, d1 = (int)((unsigned)m.y >> 16);
+                    q_w0 = (double)__int_as_float(m.z); q_w1 = (double)__int_as_float(m.w);
+                    const int slot = d % PRK;
+                    auto cell_off = [&](int age, int p, bool present) {
+                        int s_ = slot - age;
+                        s_ += s_ < 0 ? PRK : 0;
+                        const double *c = present ? &PM.sc[s_][p & (PNT - 1)][0] : &PM.null_cell[0];
+                        return (int)((const char *)c - (const char *)&PM);
+                    };
+                    q_oa0 = cell_off(d0, q_left ? q_row - d0 : q_row, d0 != 1);
+                    q_oa1 = cell_off(d1, q_left ? q_row - d1 : q_row, has1 && d1 != 1);
+                    q_ob0 = cell_off(d0 + 1, q_left ? q_row - d0 : q_row - 1, true);
+                    q_ob1 = cell_off(d1 + 1, q_left ? q_row - d1 : q_row - 1, has1);
+                    const unsigned adj = q_left ? PG_BP_ADJL : PG_BP_ADJR, other = q_left ? PG_BP_ADJR : PG_BP_ADJL;
+                    const unsigned kk = q_left ? (1u << 4) : (1u << 18);
+                    q_e0 = (d0 == 1 ? adj : 0u) | other;
+                    q_e1 = (d1 == 1 ? adj : 0u) | kk | other;
+                    q_adjs = d0 == 1 ? 0 : ((has1 && d1 == 1) ? 1 : -1);
+                }
+            }
+            return;
+        }
+    };
+#ifdef PG_PIPE_STATS
+    long long as_t[4] = {0, 0, 0, 0};      // cycles: prepare, waiting for the compute waves, compute, publish
+    int as_n = 0;
+#define ASTAMP(k) do { const long long t_ = __builtin_readcyclecounter(); as_t[k] += t_ - as_t0; as_t0 = t_; } while (0)
+    long long as_t0 = __builtin_readcyclecounter();
+#else
+#define ASTAMP(k)
+#endif
+    prepare();
+    while (q_d >= 0) {
+        const int d = q_d;
+        ASTAMP(0);
+        // every compute wave has completed d-2 (or sleeps through it); a poll that ran into an abort returns "done" and
+        // the wave runs to the end of its list on whatever is in the ring (reads stay inside the arena)
+        if (pw0 < d - 2) pw0 = POLL(&PM.progress[0], d - 2, 9);
+        if (pw1 < d - 2) pw1 = POLL(&PM.progress[1], d - 2, 9);
+        if (pw2 < d - 2) pw2 = POLL(&PM.progress[2], d - 2, 9);
+        if (pw3 < d - 2) pw3 = POLL(&PM.progress[3], d - 2, 9);
+        if (q_cls == 2 && diags_ld < d) diags_ld = POLL(&PM.loaded[2], d, 5);
+        ASTAMP(1);
+        if (q_big) scan(d, q_cls, q_lo, q_hi, q_mask, true);
+        else if (q_fast) {
+            if (lane < q_n) {
+                const char *base = (const char *)&PM;
+                const double *a0 = (const double *)(base + q_oa0), *a1 = (const double *)(base + q_oa1);
+                const double *b0 = (const double *)(base + q_ob0), *b1 = (const double *)(base + q_ob1);
+                const double a0x = a0[PG_X], a0y = a0[PG_Y], a0m = a0[PG_M], a1x = a1[PG_X], a1y = a1[PG_Y], a1m = a1[PG_M];
+                const double b0x = b0[PG_X], b0y = b0[PG_Y], b0m = b0[PG_M], b1x = b1[PG_X], b1y = b1[PG_Y], b1m = b1[PG_M];
+                const unsigned kk = q_left ? (1u << 4) : (1u << 18);
+                const unsigned self = q_left ? PG_X : PG_Y, cross = q_left ? PG_Y : PG_X;
+                double eg = NI_, em = NI_;
+                unsigned pg = PG_BP_NONE, pm = PG_BP_NONE;
+                const double s0 = q_left ? a0x : a0y, c0 = q_left ? a0y : a0x, s1 = q_left ? a1x : a1y, c1 = q_left ? a1y : a1x;
+                cand(s0 + ge, self, eg, pg); cand(c0 + go, cross, eg, pg); cand((a0m + ng) + go, PG_M, eg, pg);
+                cand(s1 + ge, kk | self, eg, pg); cand(c1 + go, kk | cross, eg, pg); cand((a1m + ng) + go, kk | PG_M, eg, pg);
+                cand((b0m + q_tM) + q_w0, q_e0 | PG_M, em, pm); cand((b0x + q_tX) + q_w0, q_e0 | PG_X, em, pm); cand((b0y + q_tX) + q_w0, q_e0 | PG_Y, em, pm);
+                cand((b1m + q_tM) + q_w1, q_e1 | PG_M, em, pm); cand((b1x + q_tX) + q_w1, q_e1 | PG_X, em, pm); cand((b1y + q_tX) + q_w1, q_e1 | PG_Y, em, pm);
+                const int win = (int)((pg >> (q_left ? 4 : 18)) & 127u);
+                pg |= (unsigned)(q_adjs < 0 ? 0 : q_adjs) << (q_left ? 18 : 4);
+                pg |= q_adjs < 0 ? PS_ONLY : ((eg > NI_ && win < q_adjs) ? PS_FIRST : 0u);
+                const int stg = a, at = q_row & (PNT - 1);          // d % PST == d % PNA == a
+                if (q_left) { PM.sx[stg][at] = eg; PM.spx[stg][at] = pg; } else { PM.sy[stg][at] = eg; PM.spy[stg][at] = pg; }
+                PM.sM[stg][at] = em; PM.spm[stg][at] = pm;
+            }
+        }
+        else if (q_n > 0) compute(d, q_cls, q_mask, lane < q_n, q_row, q_j, q_kind, q_rL, q_cR, q_tM, q_tX);
+        ASTAMP(2);
+        flag_store(&PM.assist_done[a], d);
+        ASTAMP(3);
+#ifdef PG_PIPE_STATS
+        ++as_n;
+#endif
+        prepare();
+    }
+#ifdef PG_PIPE_STATS
+    if (lane == 0 && 3 * (job->Lx + job->Ly) >= 4096) {
+        PG_GLOBAL int *o = (PG_GLOBAL int *)job->trace + 3 * (job->Lx + job->Ly) - 1000 + 8 * a;
+        o[0] = as_n;
+        for (int k = 0; k < 4; ++k) o[1 + k] = (int)(as_t[k] >> 8);
+    }
+#endif
+}
+
 #ifdef PG_PIPE_STATS
 #ifndef PG_STAT_CLASS
 #define PG_STAT_CLASS 0      // the class whose steps the phase stamps cover (-DPG_STAT_CLASS=1 for multi-edge steps)
@@ -569,7 +995,7 @@ __device__ __attribute__((noinline)) void widest_step(const PgDevJob *job, cdesc
 #endif
 
 template <bool TAB_LDS>
-__global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restrict__ jobs, const int *__restrict__ which,
+__global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restrict__ jobs, const int *__restrict__ which,
                                                          unsigned flags) {
     const PgDevJob *__restrict__ job = jobs + which[blockIdx.x];
     const cdesc8_p psc = (cdesc8_p)job->psc;
@@ -578,16 +1004,21 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int S = job->S;
-    if (TAB_LDS) for (int k = tid; k < S * S; k += PNT + 64) PM.table[k] = job->table[k];
-    for (int k = tid; k < PRK * PNT * 3; k += PNT + 64) (&PM.sc[0][0][0])[k] = neg_inf();
+    if (TAB_LDS) for (int k = tid; k < S * S; k += PBLOCK) PM.table[k] = job->table[k];
+    for (int k = tid; k < PRK * PNT * 3; k += PBLOCK) (&PM.sc[0][0][0])[k] = neg_inf();
     if (tid < 4) PM.null_cell[tid] = neg_inf();
     if (tid < PNW) { PM.progress[tid] = -1; PM.arrived[tid] = -1; }
     if (tid == 0) { PM.loaded[0] = 0; PM.loaded[1] = 0; PM.loaded[2] = 0; PM.abort_flag = 0; }
+    if (tid < PNA) PM.assist_done[tid] = -1;
     __syncthreads();
 
-    if (tid >= PNT) {
+    if (tid >= PNT + 64 * PNA) {
         const View J = load_view(job);
         pipe_loader(J, psc, lane);
+        return;
+    }
+    if (tid >= PNT) {
+        pipe_assist<TAB_LDS>(job, psc, __builtin_amdgcn_readfirstlane((tid - PNT) >> 6), lane, !(flags & 2u));
         return;
     }
 
@@ -611,6 +1042,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
     const double tng2 = in_vgpr((double)(2 * f_ng)), tng1 = in_vgpr((double)(0.0f + f_ng));
     const int bslot = (tid + PNT - 1) & (PNT - 1);                 // ring column of row-1 (lane 0: the upstream wave's lane 63)
     int rows_ld = 0, cols_ld = 0, diags_ld = 0;
+    int as0 = -1, as1 = -1, as2 = -1;                              // cached progress of the assist waves (wave a: diagonals d % 3 == a)
 #ifdef PG_PIPE_STATS
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_cls_t[5] = {0, 0, 0, 0, 0};
     int st_cls_n[5] = {0, 0, 0, 0, 0};
@@ -646,6 +1078,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
         int p_up = -1, p_dn = -1;                                  // cached progress of the neighbours
         int ok_until = wake - 1;                                   // flow control holds through this diagonal without reading a flag
         int slot = wake % PRK, slot1 = (wake + PRK - 1) % PRK;     // d % PRK, (d-1) % PRK
+        int stg = wake % PST;                                       // d % PST: the staging slot (and assist wave) of this diagonal
         int lo_prev = -1, hi_prev = -1;
 
         // One cell by the general rules (first/last rows and columns, any edge
@@ -727,16 +1160,9 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
             if (cur.s7 > p_dn) p_dn = POLL(&PM.progress[dn], cur.s7, 3);
             // upstream neighbour: only a wave with a row about to use (row-1, .) has to wait for it
             if (d - 1 > p_up && __any(row <= hi + 1)) p_up = POLL(&PM.progress[up], d - 1, 4);
-            if (!HOT && cls >= 2) {
+            if (!HOT && cls >= 3) {
                 if (diags_ld < d) diags_ld = POLL(&PM.loaded[2], d, 5);      // descriptor window covers every earlier diagonal
-                if (cls == 2) {
-                    // far reads: the cells are at least PAGE diagonals old; they have landed once every wave
-                    // completed d - PLAND (each wave keeps all but its last 24 stores retired)
-                    int slowest = flag_peek(&PM.progress[0]);
-                    for (int w = 1; w < PNW; ++w) { const int p = flag_peek(&PM.progress[w]); slowest = p < slowest ? p : slowest; }
-                    if (__builtin_amdgcn_readfirstlane(slowest) < d - PLAND)
-                        for (int w = 0; w < PNW; ++w) POLL(&PM.progress[w], d - PLAND, 6);
-                } else {
+                {
                     // rendezvous: every awake wave has completed d-1 and its stores have landed
 #ifdef PG_PIPE_STATS
                     const long long w0 = __builtin_readcyclecounter();
@@ -753,6 +1179,13 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                     p_up = d - 1 > p_up ? d - 1 : p_up;
                     p_dn = d - 1 > p_dn ? d - 1 : p_dn;
                 }
+            }
+            // ---- large model table: the assist wave of this diagonal gathered the cells' model scores ----
+            if (!TAB_LDS && (HOT || cls <= 2)) {
+                if (stg == 0) { if (as0 < d) as0 = POLL(&PM.assist_done[0], d, 8); }
+                else if (stg == 1) { if (as1 < d) as1 = POLL(&PM.assist_done[1], d, 8); }
+                else { if (as2 < d) as2 = POLL(&PM.assist_done[2], d, 8); }
+                smf = PM.ssm[stg][tid];
             }
             PSTAMP(0);
 
@@ -793,35 +1226,42 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
             double bx = NI, by = NI, bm = NI;
             unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
 
-            if (HOT || cls <= 1) {
-                // ================= interior diagonal, every predecessor in registers or in the ring =================
+            if (HOT || cls <= 2) {
+                // ================= interior diagonal: the previous diagonal in registers, the rest staged =================
                 if (active) {
-                    // straight-line code for simple cells: `+ 0.0` (log_gap_close, unit edge weights) is
-                    // omitted -- exact, no score is ever -0.0
+                    // straight-line code for the edges from the previous sites: `+ 0.0` (log_gap_close, unit edge
+                    // weights) is omitted -- exact, no score is ever -0.0
                     bx = first_max3(AX + ge, AY + go, (AM + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
                     by = first_max3(PY + ge, PX + go, (PM_ + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
-                    if (!TAB_LDS) smf = far_f32(table + ((rL.x & 0xffff) + (cra.x & 0xffff) * S));
                     const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
                     bm = first_max3(CM + tM, CX + tX, CY + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
                                     PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
-                    if (cls != 0 && !(rL.x & cra.x & PR_SIMPLE)) {
-                        // sites with at most two bwd edges each: straight-line -- the half-size block when no cell of
-                        // the wave has two multi-edge sites; more edges: the item loop
-                        const int nl = (rL.x >> PR_NE_SHIFT) & 127, nr = (cra.x >> PR_NE_SHIFT) & 127;
-                        const bool two = (unsigned)(nl - 1) < 2u && (unsigned)(nr - 1) < 2u;
-                        const bool one = two && ((rL.x | cra.x) & PR_SIMPLE);
-                        if (__builtin_amdgcn_ballot_w64(two && !one) == 0) {
-                            if (one)
-                                multi1_cell<false>(sc_out, psc, d, 0u, slot, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX,
-                                                   bx, by, bm, px, py, pm);
-                            else
-                                multi_cell<false>(sc_out, psc, d, slot, 0u, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX,
-                                                  bx, by, bm, px, py, pm);
-                        } else if (two)
-                            multi2_cell<false>(sc_out, psc, d, 0u, slot, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX, bx, by, bm, px, py, pm);
-                        else
-                            multi_cell<false>(sc_out, psc, d, slot, 0u, rL, cra, row, j, reduced_terminal, go, ge, ng, tM, tX,
-                                              bx, by, bm, px, py, pm);
+                }
+                if (cls != 0) {
+                    // ---- what the assist wave of this diagonal staged: the multi-edge candidates that do not need
+                    // diagonal d-1.  As late in the step as possible: the assist wave could only start on d when d-2
+                    // was complete, and everything above ran beside it.  The flag is read only when the cached value
+                    // stops covering d ----
+                    if (stg == 0) { if (as0 < d) as0 = POLL(&PM.assist_done[0], d, 8); }
+                    else if (stg == 1) { if (as1 < d) as1 = POLL(&PM.assist_done[1], d, 8); }
+                    else { if (as2 < d) as2 = POLL(&PM.assist_done[2], d, 8); }
+                    if (active) {
+                        const double ex = PM.sx[stg][tid], ey = PM.sy[stg][tid], em = PM.sM[stg][tid];
+                        const unsigned sfx = PM.spx[stg][tid], sfy = PM.spy[stg][tid], sfm = PM.spm[stg][tid];
+                        // merge (branch-free; simple sites keep what they have).  The previous-site edge's candidates
+                        // sit at that edge's list position: a staged winner takes a tie only if its edge comes first
+                        // (first_is_bigger is strict, basic_alignment.h:449-462).
+                        const bool msL = !(rL.x & PR_SIMPLE), msR = !(cra.x & PR_SIMPLE);
+                        const bool tkx = msL && ((sfx & PS_ONLY) || ex > bx || (ex == bx && (sfx & PS_FIRST)));
+                        const bool tky = msR && ((sfy & PS_ONLY) || ey > by || (ey == by && (sfy & PS_FIRST)));
+                        px |= msL ? ((sfx >> 18) & 127u) << 4 : 0u;            // the previous-site edge's slot in the left list
+                        py |= msR ? ((sfy >> 4) & 127u) << 18 : 0u;            // ... in the right list
+                        px = bx > NI ? px : PG_BP_NONE;
+                        py = by > NI ? py : PG_BP_NONE;
+                        bx = tkx ? ex : bx;  px = tkx ? (sfx & 0x3ffffu) : px;
+                        by = tky ? ey : by;  py = tky ? (sfy & 0x01fc000fu) : py;
+                        const bool tkm = msL || msR;
+                        bm = tkm ? em : bm;  pm = tkm ? sfm : pm;
                     }
                 }
                 PSTAMP(3);
@@ -829,37 +1269,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
                 PSTAMP(4);
             } else if (cls <= 3) {
                 const unsigned resmask = (unsigned)cur.s4 >> 5;
-                if (cls == 2) {
-                    // ---- interior, some edges reach past the ring ----
-                    if (active) {
-                        bx = first_max3(AX + ge, AY + go, (AM + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
-                        by = first_max3(PY + ge, PX + go, (PM_ + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
-                        if (!TAB_LDS) smf = far_f32(table + ((rL.x & 0xffff) + (cra.x & 0xffff) * S));
-                        const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
-                        bm = first_max3(CM + tM, CX + tX, CY + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
-                                        PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
-                        if (!(rL.x & cra.x & PR_SIMPLE)) {
-                            const int nl = (rL.x >> PR_NE_SHIFT) & 127, nr = (cra.x >> PR_NE_SHIFT) & 127;
-                            const bool two = (unsigned)(nl - 1) < 2u && (unsigned)(nr - 1) < 2u;
-                            const bool one = two && ((rL.x | cra.x) & PR_SIMPLE);
-                            if (__builtin_amdgcn_ballot_w64(two && !one) == 0) {
-                                if (one)
-                                    multi1_cell<true>(sc_out, psc, d, resmask, slot, rL, cra, row, j, reduced_terminal, go, ge, ng,
-                                                      tM, tX, bx, by, bm, px, py, pm);
-                                else
-                                    multi_cell<true>(sc_out, psc, d, slot, resmask, rL, cra, row, j, reduced_terminal, go, ge, ng,
-                                                     tM, tX, bx, by, bm, px, py, pm);
-                            } else if (two)
-                                multi2_cell<true>(sc_out, psc, d, resmask, slot, rL, cra, row, j, reduced_terminal, go, ge, ng, tM,
-                                                  tX, bx, by, bm, px, py, pm);
-                            else
-                                multi_cell<true>(sc_out, psc, d, slot, resmask, rL, cra, row, j, reduced_terminal, go, ge, ng, tM,
-                                                 tX, bx, by, bm, px, py, pm);
-                        }
-                    }
-                } else if (active) {
-                    gen_cell(d, slot, resmask, row, j, bx, by, bm, px, py, pm);
-                }
+                if (active) gen_cell(d, slot, resmask, row, j, bx, by, bm, px, py, pm);
                 commit_cell(sc_out, bp_out, cur, slot, tid, row - lo, active, bx, by, bm, px, py, pm);
             } else if (cls == 4) {
                 // ---- wider than the lanes, but inside the record windows: every lane takes its rows row, row+256,
@@ -952,6 +1362,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
             if (nb_valid) { CX = PM.sc[slot][bslot][PG_X]; CY = PM.sc[slot][bslot][PG_Y]; CM = PM.sc[slot][bslot][PG_M]; }
             slot1 = slot;
             slot = slot + 1 == PRK ? 0 : slot + 1;
+            stg = stg + 1 == PST ? 0 : stg + 1;
             PSTAMP(5);
 #ifdef PG_PIPE_STATS
             if (st_has) {
@@ -968,7 +1379,7 @@ __global__ __launch_bounds__(PNT + 64) void pg_fill_pipe(const PgDevJob *__restr
             st_t = __builtin_readcyclecounter();
             if (st_on) st_n += 2;
 #endif
-            if ((dA.s4 & 0x1e) == 0x10 && d + 1 < sleep) {
+            if ((dA.s4 & 0x1c) == 0x10 && (dA.s4 & 3) != 3 && d + 1 < sleep) {      // class 0..2 and the next one too
                 // two hot steps: the register sets swap roles and are back in place afterwards
                 step(std::true_type(), d, dA, dB, r1x, r1y, r1m, r2x, r2y, r2m, r3x, r3y, r3m, r4x, r4y, r4m, ca, cb);
                 step(std::true_type(), d + 1, dB, dA, r4x, r4y, r4m, r3x, r3y, r3m, r2x, r2y, r2m, r1x, r1y, r1m, cb, ca);

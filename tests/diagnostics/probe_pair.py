@@ -48,10 +48,17 @@ if os.environ.get("PG_STAMPS"):
 if os.environ.get("PG_STAMPS"):
     b4 = raw[n_int - 800:]
     kinds = {1: "loader rows", 2: "loader cols", 3: "downstream (ring row reuse)", 4: "upstream (row above)", 5: "descriptor window",
-             6: "far: all waves 8 steps behind", 7: "rendezvous"}
+             6: "far: all waves 8 steps behind", 7: "rendezvous", 8: "assist wave (staged multi-edge candidates)"}
     for w in range(4):
         n = b4[20 * w: 20 * w + 10].astype(np.int64); t = b4[20 * w + 10: 20 * w + 20].astype(np.int64) * 256
         print("wave %d waits (count, Mcycles): " % w + "; ".join("%s %d %.0fM" % (kinds[k], n[k], t[k] / 1e6) for k in sorted(kinds)))
+if os.environ.get("PG_STAMPS"):
+    b5 = raw[n_int - 1000:]
+    for a_ in range(3):
+        n = max(int(b5[8 * a_]), 1)
+        t = b5[8 * a_ + 1: 8 * a_ + 5].astype(np.int64) * 256
+        print("assist %d: %d diagonals; cycles/diagonal: prepare %.0f, wait for compute waves %.0f, compute %.0f, publish %.0f" %
+              ((a_, n) + tuple(t / n)))
 if os.environ.get("PG_CHECK"):
     import oracle
     bad = 0

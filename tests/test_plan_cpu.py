@@ -6,7 +6,7 @@ import pytest
 import pagan2_msa_amd as pg
 from pagan2_msa_amd import abi, synth
 
-REACH, WIDTH, WINDOW, RING, WAKE = 20, 236, 352, 20, 6      # dp_device.h: PG_PIPE_*
+REACH, WIDTH, WINDOW, RING, WAKE = 15, 241, 352, 15, 6      # dp_device.h: PG_PIPE_*
 
 
 def site_features(g, n):
