@@ -917,13 +917,25 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             int *packed = reinterpret_cast<int *>(stage.data() + reinterpret_cast<size_t>(d.psc));
             std::memset(packed + 8 * hj.dx.imin.size(), 0, 8 * sizeof(int));                             // the entry of padding
             unsigned mask = 0;             // bit a: diagonal t-a was computed by the lanes (class <= 3), a = 1 .. REACH-1
+            // hop[t]: how many of its own diagonals (t + PNA, t + 2 PNA, ...) an assist wave may skip after t before the
+            // next one with work for it (a multi-edge cell, or -- model table too large for LDS -- any interior diagonal);
+            // 12 bits, saturating: it looks again after a saturated hop
+            const size_t ndg = hj.dx.imin.size();
+            const bool big_table = d.S * d.S > 256;
+            std::vector<int> hop(ndg, 0);
+            for (size_t t = ndg; t-- > 0;) {
+                const size_t nx = t + PG_PIPE_ASSIST;
+                if (nx >= ndg) { hop[t] = 4095; continue; }
+                const bool work = hj.cls[nx] == 1 || hj.cls[nx] == 2 || (big_table && hj.cls[nx] == 0);
+                hop[t] = work ? 1 : std::min(4095, hop[nx] + 1);
+            }
             for (size_t t = 0; t < hj.dx.imin.size(); ++t) {
                 packed[8 * t] = hj.dx.imin[t]; packed[8 * t + 1] = hj.dx.imax[t];
                 const long long boff = 24 * hj.dx.doff[t];
                 packed[8 * t + 2] = (int)(boff & 0xffffffffLL); packed[8 * t + 3] = (int)(boff >> 32);
                 mask = ((mask << 1) | (t >= 1 && hj.cls[t - 1] <= 3 ? 2u : 0u)) & (((1u << PG_PIPE_REACH) - 1u) & ~1u);
                 const unsigned pair = t + 1 < hj.cls.size() && hj.cls[t + 1] <= 2 ? 1u : 0u;   // the next step is hot too
-                packed[8 * t + 4] = (int)(hj.cls[t] | (pair << 4) | (mask << 5));
+                packed[8 * t + 4] = (int)(hj.cls[t] | (pair << 4) | (mask << 5) | ((unsigned)hop[t] << 20));
                 packed[8 * t + 5] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[8 * t + 6] = (int)(hj.dx.doff[t] >> 32);
                 packed[8 * t + 7] = hj.lead_req[t];
             }

@@ -870,14 +870,14 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
         q_d = -1;
         while (scan_d < nd) {
             const int d = scan_d;
-            scan_d += PNA;
             const pg_i8 cur = psc[d];
+            scan_d += PNA * (int)((unsigned)cur.s4 >> 20);          // the host's hop count: straight to this wave's next diagonal with work
             const int cls = cur.s4 & 15;
             if (!((cls == 1 || cls == 2) || (!TAB_LDS && cls == 0))) continue;
             const int lo = cur.x, hi = cur.y;
             if (rows_ld <= hi) rows_ld = POLL(&PM.loaded[0], hi + 1, 1);
             if (cols_ld <= d - lo) cols_ld = POLL(&PM.loaded[1], d - lo + 1, 2);
-            q_d = d; q_cls = cls; q_lo = lo; q_hi = hi; q_mask = (unsigned)cur.s4 >> 5;
+            q_d = d; q_cls = cls; q_lo = lo; q_hi = hi; q_mask = ((unsigned)cur.s4 >> 5) & 0x7fffu;
             // large tables: the scan writes the model scores into staging slot d % PST, whose previous user, diagonal
             // d - PST, the compute waves must have completed
             if (!TAB_LDS) {
@@ -1268,14 +1268,14 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
                 commit_cell(sc_out, bp_out, cur, slot, tid, row - lo, active, bx, by, bm, px, py, pm);
                 PSTAMP(4);
             } else if (cls <= 3) {
-                const unsigned resmask = (unsigned)cur.s4 >> 5;
+                const unsigned resmask = ((unsigned)cur.s4 >> 5) & 0x7fffu;
                 if (active) gen_cell(d, slot, resmask, row, j, bx, by, bm, px, py, pm);
                 commit_cell(sc_out, bp_out, cur, slot, tid, row - lo, active, bx, by, bm, px, py, pm);
             } else if (cls == 4) {
                 // ---- wider than the lanes, but inside the record windows: every lane takes its rows row, row+256,
                 // ...; cells come from L2 (all waves are here and drained), simple interior cells with their
                 // three predecessors requested together, the others by the general rules; nothing enters the ring ----
-                const unsigned resmask = (unsigned)cur.s4 >> 5;
+                const unsigned resmask = ((unsigned)cur.s4 >> 5) & 0x7fffu;
 #ifdef PG_PIPE_STATS
                 const long long w2 = __builtin_readcyclecounter();
 #endif
