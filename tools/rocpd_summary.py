@@ -31,10 +31,10 @@ def main():
     else:
         pe, ip = table(c, "rocpd_pmc_event"), table(c, "rocpd_info_pmc")
         per = collections.defaultdict(float)
-        q = (f"select k.kernel_name, d.id, e.value from {pe} e join {ip} p on e.pmc_id = p.id "
+        q = (f"select k.kernel_name, d.grid_size_x, d.workgroup_size_x, d.id, e.value from {pe} e join {ip} p on e.pmc_id = p.id "
              f"join {kd} d on e.event_id = d.event_id join {ks} k on d.kernel_id = k.id where p.name = ?")
-        for name, did, value in c.execute(q, (sys.argv[3],)):
-            per[(name, did)] += value
+        for name, gx, wx, did, value in c.execute(q, (sys.argv[3],)):
+            per[("%s [grid %d x wg %d]" % (name, gx // max(wx, 1), wx), did)] += value
         by = collections.defaultdict(list)
         for (name, did), v in sorted(per.items(), key=lambda kv: kv[0][1]):
             by[name].append(v)
