@@ -98,8 +98,10 @@ struct SiteFeat {
     std::vector<int> span_ring;       // farthest bwd edge that reaches fewer than PG_PIPE_REACH sites back (>= 1)
     std::vector<int> not_simple;      // prefix count of sites that are not "one edge from the previous site, weight 1"
     std::vector<int> no_pred;         // prefix count of sites without bwd edges
+    std::vector<int> not_easy;        // prefix count of sites the compute waves of dp_pipe.hip do not evaluate themselves: anything
+                                      // but one edge from the previous site (any weight), alone or beside ONE edge from further back
     void build(const pagan_graph *g, int n) {
-        span.assign(n, 0); span_ring.assign(n, 1); not_simple.assign(n + 1, 0); no_pred.assign(n + 1, 0);
+        span.assign(n, 0); span_ring.assign(n, 1); not_simple.assign(n + 1, 0); no_pred.assign(n + 1, 0); not_easy.assign(n + 1, 0);
         for (int s = 0; s < n; ++s) {
             const int a = g->bwd_off[s], b = g->bwd_off[s + 1];
             int sp = 0, spr = 1;
@@ -112,6 +114,10 @@ struct SiteFeat {
             const bool simple = s > 0 && b - a == 1 && g->bwd_src[a] == s - 1 && g->bwd_logw[a] == 0.0f;
             not_simple[s + 1] = not_simple[s] + (simple ? 0 : 1);
             no_pred[s + 1] = no_pred[s] + (b == a ? 1 : 0);
+            int n_adj = 0;
+            for (int k = a; k < b; ++k) n_adj += g->bwd_src[k] == s - 1;
+            const bool easy = s > 0 && (b - a == 1 || b - a == 2) && n_adj == 1;
+            not_easy[s + 1] = not_easy[s] + (easy ? 0 : 1);
         }
     }
 };
@@ -124,8 +130,11 @@ struct SiteFeat {
 //      diagonals back, or a multi-edge site within PG_PIPE_REACH rows/columns of the matrix's first (an edge
 //      in reach may start at site 0, where the gap-open term differs);
 //   1  holds a site that is not simple;   0  otherwise.
+// `inwave` (model table in LDS): the compute waves evaluate the multi-edge cells of a class 1 diagonal themselves, which
+// covers sites with one edge from the previous site and at most one more ("easy", SiteFeat::not_easy); a diagonal that
+// holds any other multi-edge site is class 2 (the assist waves stage its candidates, ring-resident operands included).
 void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, const RowBand &rb,
-                        const DiagIndex &dx, std::vector<uint8_t> *out, std::vector<int> *lead_req) {
+                        const DiagIndex &dx, bool inwave, std::vector<uint8_t> *out, std::vector<int> *lead_req) {
     const int nd = Lx + Ly - 1;
     SiteFeat fl, fr;
     fl.build(L, Lx); fr.build(R, Ly);
@@ -161,7 +170,8 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
         else if (run > 0) c = 2;
         else if ((lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH) &&
                  (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)) c = 2;
-        else if (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0) c = 1;
+        else if (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)
+            c = (inwave && (fl.not_easy[hi + 1] - fl.not_easy[lo] > 0 || fr.not_easy[d - lo + 1] - fr.not_easy[d - hi] > 0)) ? 2 : 1;
         else c = 0;
         (*out)[d] = c;
     }
@@ -416,7 +426,8 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
         hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES) &&
                       edges_fit_ring(jb.right, hj->Ly, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES);
         if (hj->ring_ok) {
-            classify_diagonals(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, &hj->cls, &hj->lead_req);
+            classify_diagonals(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, jb.model->n_states * jb.model->n_states <= 256,
+                               &hj->cls, &hj->lead_req);
             schedule_waves(hj->dx, hj->cls, &hj->sched);
         }
     } else {
@@ -744,7 +755,7 @@ int pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, const
     dx.build(Lx, Ly, rb);
     std::vector<uint8_t> cls;
     std::vector<int> sched, lead_req;
-    classify_diagonals(left, right, Lx, Ly, rb, dx, &cls, &lead_req);
+    classify_diagonals(left, right, Lx, Ly, rb, dx, true, &cls, &lead_req);      // the plan of a job whose model table fits LDS
     schedule_waves(dx, cls, &sched);
     std::memcpy(cls_out, cls.data(), cls.size());
     if (lead_req_out) std::memcpy(lead_req_out, lead_req.data(), sizeof(int) * lead_req.size());
@@ -926,14 +937,15 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             for (size_t t = ndg; t-- > 0;) {
                 const size_t nx = t + PG_PIPE_ASSIST;
                 if (nx >= ndg) { hop[t] = 4095; continue; }
-                const bool work = hj.cls[nx] == 1 || hj.cls[nx] == 2 || (big_table && hj.cls[nx] == 0);
+                const bool work = hj.cls[nx] == 2 || (big_table && hj.cls[nx] <= 1);     // small tables: class 1 is the compute waves' own
                 hop[t] = work ? 1 : std::min(4095, hop[nx] + 1);
             }
             for (size_t t = 0; t < hj.dx.imin.size(); ++t) {
                 packed[8 * t] = hj.dx.imin[t]; packed[8 * t + 1] = hj.dx.imax[t];
                 const long long boff = 24 * hj.dx.doff[t];
                 packed[8 * t + 2] = (int)(boff & 0xffffffffLL); packed[8 * t + 3] = (int)(boff >> 32);
-                mask = ((mask << 1) | (t >= 1 && hj.cls[t - 1] <= 3 ? 2u : 0u)) & (((1u << PG_PIPE_REACH) - 1u) & ~1u);
+                // (a wide diagonal reuses the ring's memory: nothing older than it is resident afterwards)
+                mask = (t >= 1 && hj.cls[t - 1] <= 3) ? (((mask << 1) | 2u) & (((1u << PG_PIPE_REACH) - 1u) & ~1u)) : 0u;
                 const unsigned pair = t + 1 < hj.cls.size() && hj.cls[t + 1] <= 2 ? 1u : 0u;   // the next step is hot too
                 packed[8 * t + 4] = (int)(hj.cls[t] | (pair << 4) | (mask << 5) | ((unsigned)hop[t] << 20));
                 packed[8 * t + 5] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[8 * t + 6] = (int)(hj.dx.doff[t] >> 32);

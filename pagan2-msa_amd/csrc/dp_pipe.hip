@@ -119,6 +119,14 @@ __device__ __forceinline__ void flag_store(int *p, int v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// The hot loop's flag store: the writes a flag publishes are this wave's own LDS writes, which the hardware executes
+// in order; the inline asm keeps the compiler from moving them across and from waiting for them (the fence above ends
+// up as an s_waitcnt on every LDS operation in flight).
+__device__ __forceinline__ void flag_store_inorder(int *p, int v) {
+    const unsigned a = (unsigned)(unsigned long long)(__attribute__((address_space(3))) int *)p;
+    asm volatile("ds_write_b32 %0, %1" : : "v"(a), "v"(v) : "memory");
+}
+
 // Spin until *p >= need.  Every wait in this kernel is for a wave that is not waiting for the
 // caller (see the header); the spin limit only turns a logic error into an error status
 // instead of a hung GPU.
@@ -137,10 +145,14 @@ __device__ __forceinline__ int poll_ge(const int *p, int need, int tag) {
     }
     return v;
 }
+// the same as a function of its own: the run functions call it only when a cached flag stops covering a step
+__device__ __noinline__ int poll_ge_out(const int *p, int need, int tag) { return poll_ge(p, need, tag); }
 #define PTAG(kind) ((kind) | (wave << 4) | (d << 8))
 #ifdef PG_PIPE_STATS
+#define POLLX(p, need, kind) ([&] { const long long t0_ = __builtin_readcyclecounter(); const int v_ = __builtin_amdgcn_readfirstlane(poll_ge_out(p, need, PTAG(kind))); st_poll_t[kind] += __builtin_readcyclecounter() - t0_; ++st_poll_n[kind]; return v_; }())
 #define POLL(p, need, kind) ([&] { const long long t0_ = __builtin_readcyclecounter(); const int v_ = poll_ge(p, need, PTAG(kind)); st_poll_t[kind] += __builtin_readcyclecounter() - t0_; ++st_poll_n[kind]; return v_; }())
 #else
+#define POLLX(p, need, kind) __builtin_amdgcn_readfirstlane(poll_ge_out(p, need, PTAG(kind)))
 #define POLL(p, need, kind) poll_ge(p, need, PTAG(kind))
 #endif
 
@@ -485,6 +497,45 @@ __device__ __forceinline__ void commit_cell(gdouble_w sc_out, gu32_w bp_out, con
     asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
 }
 
+
+// ---- helpers of the compute waves' own multi-edge arithmetic (hot_run) ----
+// First-wins maximum of three candidates WITHOUT the "-inf means no back-pointer" rule (the caller applies it once per
+// state): value = plain maximum, `from` = the first candidate equal to it.
+__device__ __forceinline__ double fmax3_from(double c1, double c2, double c3, unsigned f1, unsigned f2, unsigned f3, unsigned &from) {
+    const double m23 = __builtin_fmax(c2, c3);
+    const double m = __builtin_fmax(c1, m23);
+    const bool w3 = c3 > c2;
+    const bool w23 = m23 > c1;
+    const unsigned b = w3 ? f3 : f2;
+    from = w23 ? b : f1;
+    return m;
+}
+// (va, pa) against (vb, pb): b replaces a if strictly greater, or equal and listed first (first_is_bigger is strict,
+// basic_alignment.h:449-462, so the earlier candidate keeps a tie)
+__device__ __forceinline__ void take_better(double &va, unsigned &pa, double vb, unsigned pb, bool b_first) {
+    const bool t = (vb > va) | ((vb == va) & b_first);
+    va = t ? vb : va;
+    pa = t ? pb : pa;
+}
+// the three scores of the ring cell at byte offset `off` of the ring (X, Y, M)
+__device__ __forceinline__ void ring_cell(int off, double &x, double &y, double &m) {
+    const double *c = (const double *)((const char *)&PM.sc[0][0][0] + off);
+    x = c[PG_X]; y = c[PG_Y]; m = c[PG_M];
+}
+// wide diagonals (class 4, model table in LDS) reuse the ring's memory as PWK rows of PWPOS positions (row % 512): a lane
+// holds up to two rows of such a diagonal; a cell reads at most PWAGE diagonals back in it, older operands come from L2
+#define PWK 7
+#define PWPOS 512
+#define PWAGE 5
+#define PWROW_BYTES (PWPOS * 24)
+static_assert(PWK * PWROW_BYTES <= PRK * PNT * 24 && PWAGE + 2 <= PWK && PG_PIPE_WINDOW < PWPOS - 64, "wide ring inside the ring");
+#define PRING_BYTES (PRK * PNT * 24)
+#define PROW_BYTES (PNT * 24)
+// byte offset (inside the ring) of the ring row `age` diagonals before the row at `sb`
+__device__ __forceinline__ int ring_back(int sb, int age) {
+    const int x = sb - age * PROW_BYTES;
+    return x < 0 ? x + PRING_BYTES : x;
+}
 } // namespace
 
 // A class 5 step: out of line -- it is rare, and the kernel is as large as the instruction cache.
@@ -873,7 +924,7 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
             const pg_i8 cur = psc[d];
             scan_d += PNA * (int)((unsigned)cur.s4 >> 20);          // the host's hop count: straight to this wave's next diagonal with work
             const int cls = cur.s4 & 15;
-            if (!((cls == 1 || cls == 2) || (!TAB_LDS && cls == 0))) continue;
+            if (!(cls == 2 || (!TAB_LDS && cls <= 1))) continue;   // small tables: class 1 is the compute waves' own (hot_run)
             const int lo = cur.x, hi = cur.y;
             if (rows_ld <= hi) rows_ld = POLL(&PM.loaded[0], hi + 1, 1);
             if (cols_ld <= d - lo) cols_ld = POLL(&PM.loaded[1], d - lo + 1, 2);
@@ -983,6 +1034,481 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
         for (int k = 0; k < 4; ++k) o[1 + k] = (int)(as_t[k] >> 8);
     }
 #endif
+}
+
+
+// ---- the compute waves' state that hot_run / wide_run share with the kernel's step() ----------------------------------
+// Both are functions of their own (not inlined): the register allocation of their loops does not depend on what else the
+// kernel contains, and the kernel's rare paths do not compete with them for SGPRs.  The state travels through this struct
+// (in scratch memory) once per run, not per step.
+struct WaveCtx {
+    // constants of the wave
+    const PgDevJob *job;
+    cdesc8_p psc;
+    gdouble_w sc_out;
+    gu32_w bp_out;
+    double go, ng, ge, tng2, tng1;
+    int Lx, Ly, nd, S, sleep;
+    int tid, wave, up, dn, bslot;
+    unsigned flags;
+    // what a run continues from and hands back
+    int d, row;
+    double px, py, pm, cx, cy, cm;           // this lane's cell on d-1; (row-1, j-1) on d-2
+    pg_i4 ca, cb;                            // records of the columns d - row, d + 1 - row
+    float smf;                               // model score of (row, d - row)
+    pg_i8 dA;                                // descriptor of diagonal d
+    int p_up, p_dn, ok_until, rows_ld, cols_ld, diags_ld, as0, as1, as2;
+#ifdef PG_PIPE_STATS
+    long long st_cls_t[5], st_poll_t[10];
+    int st_cls_n[5], st_poll_n[10];
+#endif
+};
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ pg_i8 uniform_i8(const pg_i8 &v) {
+    pg_i8 r;
+    r.s0 = __builtin_amdgcn_readfirstlane(v.s0); r.s1 = __builtin_amdgcn_readfirstlane(v.s1); r.s2 = __builtin_amdgcn_readfirstlane(v.s2);
+    r.s3 = __builtin_amdgcn_readfirstlane(v.s3); r.s4 = __builtin_amdgcn_readfirstlane(v.s4); r.s5 = __builtin_amdgcn_readfirstlane(v.s5);
+    r.s6 = __builtin_amdgcn_readfirstlane(v.s6); r.s7 = __builtin_amdgcn_readfirstlane(v.s7);
+    return r;
+}
+#define WCTX_IN(c) \
+    const cdesc8_p psc = (cdesc8_p)uniform_u64((unsigned long long)(c).psc); \
+    const gdouble_w sc_out = (gdouble_w)uniform_u64((unsigned long long)(c).sc_out); const gu32_w bp_out = (gu32_w)uniform_u64((unsigned long long)(c).bp_out); \
+    const double go = (c).go, ng = (c).ng, ge = (c).ge, tng2 = (c).tng2, tng1 = (c).tng1; \
+    const int Lx = __builtin_amdgcn_readfirstlane((c).Lx), Ly = __builtin_amdgcn_readfirstlane((c).Ly), nd = __builtin_amdgcn_readfirstlane((c).nd); \
+    const int S = __builtin_amdgcn_readfirstlane((c).S), sleep = __builtin_amdgcn_readfirstlane((c).sleep); \
+    const int tid = (c).tid, wave = __builtin_amdgcn_readfirstlane((c).wave), up = __builtin_amdgcn_readfirstlane((c).up), dn = __builtin_amdgcn_readfirstlane((c).dn), bslot = (c).bslot; \
+    int d = __builtin_amdgcn_readfirstlane((c).d), row = (c).row; \
+    int p_up = __builtin_amdgcn_readfirstlane((c).p_up), p_dn = __builtin_amdgcn_readfirstlane((c).p_dn), ok_until = __builtin_amdgcn_readfirstlane((c).ok_until); \
+    int rows_ld = __builtin_amdgcn_readfirstlane((c).rows_ld), cols_ld = __builtin_amdgcn_readfirstlane((c).cols_ld), diags_ld = __builtin_amdgcn_readfirstlane((c).diags_ld); \
+    int as0 = __builtin_amdgcn_readfirstlane((c).as0), as1 = __builtin_amdgcn_readfirstlane((c).as1), as2 = __builtin_amdgcn_readfirstlane((c).as2); \
+    const double NI = neg_inf(); \
+    (void)Lx; (void)Ly; (void)nd; (void)S; (void)up; (void)dn; (void)bslot; (void)as0; (void)as1; (void)as2; (void)diags_ld; (void)ok_until; (void)go; (void)ng; (void)ge; (void)tng2; (void)tng1; (void)NI
+#define WCTX_OUT(c) \
+    (c).d = d; (c).row = row; (c).p_up = p_up; (c).p_dn = p_dn; (c).ok_until = ok_until; (c).rows_ld = rows_ld; (c).cols_ld = cols_ld; \
+    (c).diags_ld = diags_ld; (c).as0 = as0; (c).as1 = as1; (c).as2 = as2
+#ifdef PG_PIPE_STATS
+#define WCTX_STATS(c) long long (&st_cls_t)[5] = (c).st_cls_t; long long (&st_poll_t)[10] = (c).st_poll_t; int (&st_cls_n)[5] = (c).st_cls_n; int (&st_poll_n)[10] = (c).st_poll_n
+#else
+#define WCTX_STATS(c)
+#endif
+
+// ---- hot run (model table in LDS): the diagonals from d on while their class is 0, 1 or 2 ----
+// One iteration per diagonal.  Across iterations only the lane's cell of the previous diagonal (P), the shifted
+// cell of the diagonal before (C) and the operand pipeline (row record, two column records, model score) live in
+// registers; everything else is recomputed from the lane's row and the diagonal's descriptor, so there is no
+// per-lane state to keep consistent: an out-of-band lane computes on whatever it holds and its results are
+// replaced by -inf.  Class 1: the multi-edge cells are evaluated HERE, by the lanes that own them, in blocks that
+// run only when an active lane of the wave needs them -- sites with one edge from the previous site and at most
+// one more ("easy"; the host sends every other shape to the assist waves as class 2):
+//   X: the previous-site edge's candidates from (row-1, j) as for a simple site, the other edge's from (row-kL, j)
+//      in the ring; Y the same with (row, j-kR); M over the up to four (left edge, right edge) pairs, operands
+//      C, (row-kL, j-1), (row-1, j-kR), (row-kL, j-kR).
+// The reference walks the lists in order and replaces the incumbent on strict > only (VA:1328-1349, 1396-1433,
+// basic_alignment.h:449-462): per edge / pair a first-wins maximum of its three candidates, then the groups
+// combined with "equal: the one listed first" -- the same winner.  Class 2 (any other multi-edge shape, or operands
+// that left the ring): what the diagonal's assist wave staged is merged as in step().
+__device__ __noinline__ void hot_run(WaveCtx &C_) {
+    WCTX_IN(C_);
+    WCTX_STATS(C_);
+    double PX = C_.px, PY = C_.py, PMm = C_.pm, CX = C_.cx, CY = C_.cy, CM = C_.cm;
+    const pg_i4 ca = C_.ca, cb = C_.cb;
+    const float smf = C_.smf;
+    pg_i8 dA = uniform_i8(C_.dA);
+    pg_i8 cur = dA;
+    int sb = (d % PRK) * PROW_BYTES;                        // ring row of diagonal d, as a byte offset
+    int hstg = d % PST;                                     // staging slot (and assist wave) of diagonal d
+    pg_i4 rLc = PM.recL[row & (PRW - 1)];                   // (garbage while the row is beyond the staged ones: inactive)
+    pg_i4 cR0 = ca, cR1 = cb;                               // records of the columns d - row and d + 1 - row
+    float sm = smf;                                         // model score of (row, d - row)
+    const int tid24 = tid * 24, bpos24 = bslot * 24;
+    const int null_off = (int)offsetof(PipeSmem, null_cell);
+    // LDS addresses the class 0 loop below works with
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned lds_ring = (unsigned)(unsigned long long)(lds_char *)&PM.sc[0][0][0];
+    const unsigned a_tid24 = lds_ring + (unsigned)tid24, a_bpos24 = lds_ring + (unsigned)bpos24;
+    const unsigned a_recR = (unsigned)(unsigned long long)(lds_char *)&PM.recR[0], a_recL = (unsigned)(unsigned long long)(lds_char *)&PM.recL[0];
+    const unsigned a_table = (unsigned)(unsigned long long)(lds_char *)&PM.table[0];
+    const unsigned a_fup = (unsigned)(unsigned long long)(lds_char *)&PM.progress[up], a_fme = (unsigned)(unsigned long long)(lds_char *)&PM.progress[wave];
+    const unsigned ni_hi = 0xfff00000u;
+    for (;;) {
+#ifndef PG_NO_HOT_ASM
+        if ((cur.s4 & 15) == 0) {
+            // ---- consecutive class 0 diagonals: hand-scheduled loop (tools/gen_hot_asm.py has the register plan) ----
+            // It runs until a diagonal needs anything but the straight-line step -- another class, the end of the wave's
+            // interval, a flag that has to be polled -- and leaves that diagonal untouched: d, the ring row, the lane's row
+            // and cells come back; the operand pipeline is reloaded below.
+            unsigned long long dptr = (unsigned long long)(psc + d);
+            int colx = cR1.x, rowx = rLc.x;
+            float smv = sm;
+            const unsigned sc_lo = (unsigned)(unsigned long long)sc_out, sc_hi = (unsigned)((unsigned long long)sc_out >> 32);
+            const unsigned bp_lo = (unsigned)(unsigned long long)bp_out, bp_hi = (unsigned)((unsigned long long)bp_out >> 32);
+            const int d_in = d;
+            asm volatile(
+#include "dp_pipe_hot.inc"
+                : [row] "+v"(row), [colx] "+v"(colx), [rowx] "+v"(rowx), [sm] "+v"(smv),
+                  [p0] "+v"(PX), [p1] "+v"(PY), [p2] "+v"(PMm), [c0] "+v"(CX), [c1] "+v"(CY), [c2] "+v"(CM),
+                  [d] "+s"(d), [sb] "+s"(sb), [pup] "+s"(p_up), [dptr] "+s"(dptr)
+                : [ge] "v"(ge), [go] "v"(go), [ng] "v"(ng), [tng2] "v"(tng2), [tng1] "v"(tng1), [ni] "v"(NI), [nihi] "v"(ni_hi),
+                  [tid24] "v"(a_tid24), [bpos24] "v"(a_bpos24), [fup] "v"(a_fup), [fme] "v"(a_fme),
+                  [sleep] "s"(sleep), [okuntil] "s"(ok_until), [pdn] "s"(p_dn), [S] "s"(S),
+                  [bR] "s"(a_recR), [bL] "s"(a_recL), [bT] "s"(a_table),
+                  [sclo] "s"(sc_lo), [schi] "s"(sc_hi), [bplo] "s"(bp_lo), [bphi] "s"(bp_hi)
+                : "memory", "vcc", "scc",
+                  "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193",
+                  "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207",
+                  "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221",
+                  "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235",
+                  "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+                  "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
+                  "s68", "s69", "s70", "s71", "s72");
+            d = __builtin_amdgcn_readfirstlane(d);
+            if (d != d_in) {
+                // the operand pipeline of diagonal d from the LDS windows, the descriptor from memory
+                cur = psc[d];
+                hstg = d % PST;
+                rLc = PM.recL[row & (PRW - 1)];
+                cR0 = PM.recR[(d - row) & (PRW - 1)];
+                cR1 = PM.recR[(d + 1 - row) & (PRW - 1)];
+                sm = PM.table[((rLc.x & 0xffff) + __umul24(cR0.x & 0xffff, S)) & 255];
+                if ((cur.s4 & 15) > 2 || d >= sleep) { dA = cur; break; }
+            }
+        }
+#endif
+        const int lo = cur.x, hi = cur.y, cls = cur.s4 & 15;
+#ifdef PG_PIPE_STATS
+        const long long st_step0 = __builtin_readcyclecounter();
+        const bool st_has = __any(row <= hi && row >= lo);
+#endif
+        // ---- flow control: flags are read only when the cached values stop covering this step (see step()) ----
+        if (d > ok_until) {
+            int need = hi + 3 < Lx - 1 ? hi + 3 : Lx - 1;
+            if (rows_ld <= need) rows_ld = POLLX(&PM.loaded[0], need + 1, 1);
+            int margin = rows_ld >= Lx ? nd : rows_ld - 1 - need;
+            need = d + 2 - lo < Ly - 1 ? d + 2 - lo : Ly - 1;
+            if (cols_ld <= need) cols_ld = POLLX(&PM.loaded[1], need + 1, 2);
+            const int mc = cols_ld >= Ly ? nd : cols_ld - 1 - need;
+            margin = mc < margin ? mc : margin;
+            ok_until = d + margin;
+        }
+        if (cur.s7 > p_dn) p_dn = POLLX(&PM.progress[dn], cur.s7, 3);
+        if (d - 1 > p_up && __any(row <= hi + 1)) p_up = POLLX(&PM.progress[up], d - 1, 4);
+        // ---- (row-1, j) on d-1: lane-1's registers; lane 0 takes the upstream wave's lane 63 from the ring (what it
+        // reads is used only if lane 0's row is in the band, and then the upstream wave was waited for above) ----
+        const int sb1 = sb == 0 ? PRING_BYTES - PROW_BYTES : sb - PROW_BYTES;
+        double AX, AY, AM;
+        ring_cell(sb1 + bpos24, AX, AY, AM);
+        // ---- row hand-over: a lane whose row left the band takes the next one of its residue (far below the band) ----
+        row += row < lo ? PNT : 0;
+        const bool active = row <= hi;
+        const double tM = tng2 + (double)sm, tX = tng1 + (double)sm;
+        double bx, by, bm;
+        unsigned px, py, pm;
+        // candidates that do not need the shift first: the LDS read above is in flight
+        by = fmax3_from(PY + ge, PX + go, (PMm + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
+        if (cls != 1) {
+            bm = fmax3_from(CM + tM, CX + tX, CY + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
+                            PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
+        }
+        AX = dpp_shr1(PX, AX); AY = dpp_shr1(PY, AY); AM = dpp_shr1(PMm, AM);
+        // next descriptor: requested after the step's LDS wait (an s_waitcnt on LDS data also waits for scalar
+        // loads in flight); the array carries one entry of padding
+        pg_i8 nxt;
+        {
+            unsigned long long pv = (unsigned long long)(psc + d + 1);
+            asm volatile("" : "+s"(pv) : "v"(AX), "v"(AY), "v"(AM));
+            nxt = *(cdesc8_p)pv;
+        }
+        bx = fmax3_from(AX + ge, AY + go, (AM + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
+        if (cls == 1) {
+            // ================= class 1: the lanes' own multi-edge cells =================
+            const bool l2 = active && ((rLc.x >> PR_NE_SHIFT) & 127) == 2, r2 = active && ((cR0.x >> PR_NE_SHIFT) & 127) == 2;
+            const bool lA2 = (rLc.y & 0xffff) != 1, rA2 = (cR0.y & 0xffff) != 1;      // (two edges:) the previous-site edge is listed second
+            const double lw0 = (double)__int_as_float(rLc.z), lw1 = (double)__int_as_float(rLc.w);
+            const double rw0 = (double)__int_as_float(cR0.z), rw1 = (double)__int_as_float(cR0.w);
+            const bool lS = l2 && lA2, rS = r2 && rA2;                                 // the other edge comes first in the list
+            const double lwA = lS ? lw1 : lw0, lwS = lS ? lw0 : lw1, rwA = rS ? rw1 : rw0, rwS = rS ? rw0 : rw1;
+            const unsigned lbA = lS ? 1u << 4 : 0u, lbS = lS ? 0u : 1u << 4;           // list slots in a back-pointer
+            const unsigned rbA = rS ? 1u << 18 : 0u, rbS = rS ? 0u : 1u << 18;
+            px |= lbA; py |= rbA;
+            bm = fmax3_from(((CM + tM) + lwA) + rwA, ((CX + tX) + lwA) + rwA, ((CY + tX) + lwA) + rwA, PG_M, PG_X, PG_Y, pm);
+            pm |= PG_BP_ADJL | PG_BP_ADJR | lbA | rbA;
+            const int kL = lA2 ? (rLc.y & 0xffff) : (int)((unsigned)rLc.y >> 16);
+            const int kR = rA2 ? (cR0.y & 0xffff) : (int)((unsigned)cR0.y >> 16);
+            const int posL = ((tid - kL) & (PNT - 1)) * 24;
+            const bool anyL = __any(l2), anyR = __any(r2);
+            if (anyR) {
+                // the right site's other edge: Y from (row, j-kR), the pair (previous-site left edge, it) from (row-1, j-kR)
+                double ux, uy, um, vx, vy, vm;
+                ring_cell(r2 ? ring_back(sb, kR) + tid24 : null_off, ux, uy, um);
+                ring_cell(r2 ? ring_back(sb, kR + 1) + bpos24 : null_off, vx, vy, vm);
+                unsigned f;
+                const double ys = fmax3_from(uy + ge, ux + go, (um + ng) + go, PG_Y, PG_X, PG_M, f);
+                take_better(by, py, ys, f | rbS, rS);
+                const double ms = fmax3_from(((vm + tM) + lwA) + rwS, ((vx + tX) + lwA) + rwS, ((vy + tX) + lwA) + rwS, PG_M, PG_X, PG_Y, f);
+                take_better(bm, pm, ms, f | PG_BP_ADJL | lbA | rbS, rS);
+            }
+            if (anyL) {
+                // the left site's other edge: X from (row-kL, j), the pair (it, previous-site right edge) from (row-kL, j-1)
+                double ux, uy, um, vx, vy, vm;
+                ring_cell(l2 ? ring_back(sb, kL) + posL : null_off, ux, uy, um);
+                ring_cell(l2 ? ring_back(sb, kL + 1) + posL : null_off, vx, vy, vm);
+                unsigned f, f2;
+                const double xs = fmax3_from(ux + ge, uy + go, (um + ng) + go, PG_X, PG_Y, PG_M, f);
+                take_better(bx, px, xs, f | lbS, lS);
+                double m2 = fmax3_from(((vm + tM) + lwS) + rwA, ((vx + tX) + lwS) + rwA, ((vy + tX) + lwS) + rwA, PG_M, PG_X, PG_Y, f2);
+                unsigned p2 = f2 | PG_BP_ADJR | lbS | rbA;
+                if (__any(l2 && r2)) {
+                    // both sites have another edge: the pair of the two, from (row-kL, j-kR)
+                    double wx, wy, wm;
+                    ring_cell((l2 && r2) ? ring_back(sb, kL + kR) + posL : null_off, wx, wy, wm);
+                    const double m3 = fmax3_from(((wm + tM) + lwS) + rwS, ((wx + tX) + lwS) + rwS, ((wy + tX) + lwS) + rwS, PG_M, PG_X, PG_Y, f);
+                    take_better(m2, p2, m3, f | lbS | rbS, rS);
+                }
+                take_better(bm, pm, m2, p2, lS);
+            }
+        }
+#ifndef PG_X_NOC2
+        else if (cls == 2) {
+            // ================= class 2: merge what the assist wave of this diagonal staged (see step()) =================
+            if (hstg == 0) { if (as0 < d) as0 = POLLX(&PM.assist_done[0], d, 8); }
+            else if (hstg == 1) { if (as1 < d) as1 = POLLX(&PM.assist_done[1], d, 8); }
+            else { if (as2 < d) as2 = POLLX(&PM.assist_done[2], d, 8); }
+            const double ex = PM.sx[hstg][tid], ey = PM.sy[hstg][tid], em = PM.sM[hstg][tid];
+            const unsigned sfx = PM.spx[hstg][tid], sfy = PM.spy[hstg][tid], sfm = PM.spm[hstg][tid];
+            const bool msL = !(rLc.x & PR_SIMPLE), msR = !(cR0.x & PR_SIMPLE);
+            const bool tkx = msL && ((sfx & PS_ONLY) || ex > bx || (ex == bx && (sfx & PS_FIRST)));
+            const bool tky = msR && ((sfy & PS_ONLY) || ey > by || (ey == by && (sfy & PS_FIRST)));
+            px |= msL ? ((sfx >> 18) & 127u) << 4 : 0u;            // the previous-site edge's slot in the left list
+            py |= msR ? ((sfy >> 4) & 127u) << 18 : 0u;            // ... in the right list
+            bx = tkx ? ex : bx;  px = tkx ? (sfx & 0x3ffffu) : px;
+            by = tky ? ey : by;  py = tky ? (sfy & 0x01fc000fu) : py;
+            const bool tkm = msL || msR;
+            bm = tkm ? em : bm;  pm = tkm ? sfm : pm;
+        }
+#endif
+        // ---- results: -inf outside the band; a state that stayed -inf has no back-pointer ----
+        bx = active ? bx : NI; by = active ? by : NI; bm = active ? bm : NI;
+        px = bx > NI ? px : PG_BP_NONE; py = by > NI ? py : PG_BP_NONE; pm = bm > NI ? pm : PG_BP_NONE;
+        {
+            double *o = (double *)((char *)&PM.sc[0][0][0] + sb + tid24);
+            o[PG_X] = bx; o[PG_Y] = by; o[PG_M] = bm;
+        }
+        if (active) {
+            typedef unsigned u3 __attribute__((ext_vector_type(3)));
+            const long long soff = ((long long)cur.w << 32) | (unsigned)cur.z;     // 24 * first cell of the diagonal
+            PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff;
+            PG_GLOBAL char *brow = (PG_GLOBAL char *)bp_out + (soff >> 1);
+            const unsigned off = (unsigned)(row - lo);
+            pg_d2 xy; xy.x = bx; xy.y = by;
+            const unsigned off12 = __umul24(off, 12u);
+            *(PG_GLOBAL pg_d2 *)(srow + 2u * off12) = xy;
+            *(PG_GLOBAL double *)(srow + 2u * off12 + 16u) = bm;
+            u3 b3; b3.x = px; b3.y = py; b3.z = pm;
+            *(PG_GLOBAL u3 *)(brow + off12) = b3;
+        }
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // all but the last 8 steps' stores have retired (far reads rely on it)
+#ifdef PG_X_OLDFLAG
+        flag_store(&PM.progress[wave], d);
+#else
+        flag_store_inorder(&PM.progress[wave], d);
+#endif
+        // ---- operand pipeline for the next steps: one LDS wait per step, at its top ----
+        const pg_i4 cR2 = PM.recR[(d + 2 - row) & (PRW - 1)];
+        const float sm1 = PM.table[((rLc.x & 0xffff) + __umul24(cR1.x & 0xffff, S)) & 255];
+        const pg_i4 rLn = PM.recL[row & (PRW - 1)];
+        PX = bx; PY = by; PMm = bm;
+        CX = AX; CY = AY; CM = AM;
+#ifdef PG_PIPE_STATS
+        if (st_has) {
+            const long long dt = __builtin_readcyclecounter() - st_step0;
+            for (int c = 0; c < 5; ++c) if (c == cls) { st_cls_t[c] += dt; ++st_cls_n[c]; }
+        }
+#endif
+        ++d;
+        sb = sb + PROW_BYTES == PRING_BYTES ? 0 : sb + PROW_BYTES;
+        hstg = hstg + 1 == PST ? 0 : hstg + 1;
+        cR0 = cR1; cR1 = cR2; sm = sm1; rLc = rLn;
+        if ((nxt.s4 & 15) > 2 || d >= sleep) { dA = nxt; break; }        // the next diagonal is not class 0..2, or the wave's interval ends
+        cur = nxt;
+    }
+    // hand the state back to step(): the column records and model score of diagonal d (the row records are reloaded there,
+    // nothing of lane 0's operand is prefetched)
+    C_.ca = cR0; C_.cb = cR1; C_.smf = sm;
+    C_.px = PX; C_.py = PY; C_.pm = PMm; C_.cx = CX; C_.cy = CY; C_.cm = CM;
+    C_.dA = dA;
+    WCTX_OUT(C_);
+}
+
+
+// ---- wide run (model table in LDS): consecutive class 4 diagonals, 242 .. PG_PIPE_WINDOW cells ----
+// A lane takes its residue's rows lo + ((tid - lo) & 255) and that + 256.  Nothing lives in registers across steps:
+// a cell's operands come from the WIDE RING -- the ring's memory as PWK rows of 512 positions (row % 512), written
+// by every lane for both its rows, -inf outside the band -- when their diagonal belongs to this run and is at
+// most PWAGE back, and from L2 otherwise (diagonals before the run: everything landed at the rendezvous on entry;
+// older diagonals of the run: every wave keeps all but its last 30 stores, five steps' worth, retired).  Simple
+// interior cells are straight-line code; cells with "easy" multi-edge sites (hot_run) get their up to eight
+// operands in one batch; anything else goes through cell_any with one fetch per operand.  The four waves move in
+// lock step through flags: the wave above has completed d-1, the wave below d-2 (ring row reuse).
+__device__ __noinline__ void wide_run(WaveCtx &C_) {
+    WCTX_IN(C_);
+    WCTX_STATS(C_);
+    const PgDevJob *__restrict__ job = (const PgDevJob *)uniform_u64((unsigned long long)C_.job);
+    const unsigned flags_ = __builtin_amdgcn_readfirstlane(C_.flags);
+    const bool no_terminal_edges = flags_ & 1u, reduced_terminal = !(flags_ & 2u);
+    pg_i8 dA = uniform_i8(C_.dA);
+    const View J = load_view(job);
+    const int d0 = d;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flag_store(&PM.arrived[wave], d0);
+    for (int w = 0; w < PNW; ++w) POLLX(&PM.arrived[w], d0, 7);
+    p_up = d0 - 1 > p_up ? d0 - 1 : p_up;
+    p_dn = d0 - 1 > p_dn ? d0 - 1 : p_dn;
+    pg_i8 cur = dA;
+    const double NIw = neg_inf();
+    for (;;) {
+        const int lo = cur.x, hi = cur.y;
+        {   // records of the diagonal's rows and columns, descriptors of every earlier diagonal
+            const int nr_ = hi + 1 < Lx ? hi + 1 : Lx, nc_ = d - lo + 1 < Ly ? d - lo + 1 : Ly;
+            if (rows_ld < nr_) rows_ld = POLLX(&PM.loaded[0], nr_, 1);
+            if (cols_ld < nc_) cols_ld = POLLX(&PM.loaded[1], nc_, 2);
+            if (diags_ld < d) diags_ld = POLLX(&PM.loaded[2], d, 5);
+        }
+        if (p_up < d - 1) p_up = POLLX(&PM.progress[up], d - 1, 4);
+        if (p_dn < d - 2) p_dn = POLLX(&PM.progress[dn], d - 2, 3);
+        const pg_i8 nxt = psc[d + 1];
+        const int amax = d - d0 < PWAGE ? d - d0 : PWAGE;               // ages 1 .. amax are in the wide ring
+        const int wsb = (d % PWK) * PWROW_BYTES;
+        const long long soff = ((long long)cur.w << 32) | (unsigned)cur.z;
+        PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff, *brow = (PG_GLOBAL char *)bp_out + (soff >> 1);
+        // one operand cell (p, d - age): issued (L2) or read (wide ring); -inf outside the band.  The caller waits.
+        auto wcell = [&](bool need, int age, int p_, pg_d2 &xy, double &m) {
+            xy.x = NIw; xy.y = NIw; m = NIw;
+            if (!need) return;
+            if (age <= amax) {
+                int rb = wsb - age * PWROW_BYTES;
+                rb += rb < 0 ? PWK * PWROW_BYTES : 0;
+                const double *c = (const double *)((const char *)&PM.sc[0][0][0] + rb + (p_ & (PWPOS - 1)) * 24);
+                xy.x = c[PG_X]; xy.y = c[PG_Y]; m = c[PG_M];
+            } else {
+                const int dd = d - age;
+                pg_i4 ds;
+                if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
+                else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
+                if (p_ >= ds.x && p_ <= ds.y) {
+                    const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p_ - ds.x);
+                    far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc_out + boff), xy, m);
+                }
+            }
+        };
+        for (int q = 0; q < 2; ++q) {
+            const int r = lo + ((tid - lo) & (PNT - 1)) + PNT * q, j = d - r;
+            const bool active = r <= hi;
+            double bx = NIw, by = NIw, bm = NIw;
+            unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
+            if (active) {
+                const pg_i4 gl = PM.recL[r & (PRW - 1)], gr = PM.recR[j & (PRW - 1)];
+                const int nl = (gl.x >> PR_NE_SHIFT) & 127, nr = (gr.x >> PR_NE_SHIFT) & 127;
+                const int dl0 = gl.y & 0xffff, dl1 = (int)((unsigned)gl.y >> 16), dr0 = gr.y & 0xffff, dr1 = (int)((unsigned)gr.y >> 16);
+                const bool easyL = nl == 1 ? dl0 == 1 : (nl == 2 && (dl0 == 1) != (dl1 == 1));
+                const bool easyR = nr == 1 ? dr0 == 1 : (nr == 2 && (dr0 == 1) != (dr1 == 1));
+                const bool l2 = nl == 2, r2 = nr == 2;
+                const bool lS = l2 && dl0 != 1, rS = r2 && dr0 != 1;                 // the other edge is listed first
+                const int kL = lS ? dl0 : dl1, kR = rS ? dr0 : dr1;
+                // interior, and no edge in reach starts at site 0 (where the gap-open term differs)
+                const bool inner = r >= 2 && r <= Lx - 2 && j >= 2 && j <= Ly - 2 && (!l2 || r - kL >= 1) && (!r2 || j - kR >= 1);
+                if (easyL && easyR && inner) {
+                    const float smv = PM.table[((gl.x & 0xffff) + __umul24(gr.x & 0xffff, S)) & 255];
+                    const double tM = tng2 + (double)smv, tX = tng1 + (double)smv;
+                    pg_d2 a_, p_, c_, lx_, lm_, ry_, rm_, lr_;
+                    double am, pmm, cm, lxm, lmm, rym, rmm, lrm;
+                    wcell(true, 1, r - 1, a_, am);
+                    wcell(true, 1, r, p_, pmm);
+                    wcell(true, 2, r - 1, c_, cm);
+                    wcell(l2, kL, r - kL, lx_, lxm);
+                    wcell(l2, kL + 1, r - kL, lm_, lmm);
+                    wcell(r2, kR, r, ry_, rym);
+                    wcell(r2, kR + 1, r - 1, rm_, rmm);
+                    wcell(l2 && r2, kL + kR, r - kL, lr_, lrm);
+                    far_wait3(a_, am, p_, pmm, c_, cm);
+                    far_wait3(lx_, lxm, lm_, lmm, ry_, rym);
+                    { pg_d2 dq = {NIw, NIw}; double dm = NIw; far_wait3(rm_, rmm, lr_, lrm, dq, dm); }
+                    const double lw0 = (double)__int_as_float(gl.z), lw1 = (double)__int_as_float(gl.w);
+                    const double rw0 = (double)__int_as_float(gr.z), rw1 = (double)__int_as_float(gr.w);
+                    const double lwA = lS ? lw1 : lw0, lwS = lS ? lw0 : lw1, rwA = rS ? rw1 : rw0, rwS = rS ? rw0 : rw1;
+                    const unsigned lbA = lS ? 1u << 4 : 0u, lbS = lS ? 0u : 1u << 4;
+                    const unsigned rbA = rS ? 1u << 18 : 0u, rbS = rS ? 0u : 1u << 18;
+                    unsigned f;
+                    bx = fmax3_from(a_.x + ge, a_.y + go, (am + ng) + go, PG_X, PG_Y, PG_M, f); px = f | PG_BP_ADJL | lbA;
+                    by = fmax3_from(p_.y + ge, p_.x + go, (pmm + ng) + go, PG_Y, PG_X, PG_M, f); py = f | PG_BP_ADJR | rbA;
+                    bm = fmax3_from(((cm + tM) + lwA) + rwA, ((c_.x + tX) + lwA) + rwA, ((c_.y + tX) + lwA) + rwA, PG_M, PG_X, PG_Y, f);
+                    pm = f | PG_BP_ADJL | PG_BP_ADJR | lbA | rbA;
+                    if (r2) {
+                        const double ys = fmax3_from(ry_.y + ge, ry_.x + go, (rym + ng) + go, PG_Y, PG_X, PG_M, f);
+                        take_better(by, py, ys, f | rbS, rS);
+                        const double ms = fmax3_from(((rmm + tM) + lwA) + rwS, ((rm_.x + tX) + lwA) + rwS, ((rm_.y + tX) + lwA) + rwS, PG_M, PG_X, PG_Y, f);
+                        take_better(bm, pm, ms, f | PG_BP_ADJL | lbA | rbS, rS);
+                    }
+                    if (l2) {
+                        const double xs = fmax3_from(lx_.x + ge, lx_.y + go, (lxm + ng) + go, PG_X, PG_Y, PG_M, f);
+                        take_better(bx, px, xs, f | lbS, lS);
+                        unsigned f2;
+                        double m2 = fmax3_from(((lmm + tM) + lwS) + rwA, ((lm_.x + tX) + lwS) + rwA, ((lm_.y + tX) + lwS) + rwA, PG_M, PG_X, PG_Y, f2);
+                        unsigned p2 = f2 | PG_BP_ADJR | lbS | rbA;
+                        if (r2) {
+                            const double m3 = fmax3_from(((lrm + tM) + lwS) + rwS, ((lr_.x + tX) + lwS) + rwS, ((lr_.y + tX) + lwS) + rwS, PG_M, PG_X, PG_Y, f);
+                            take_better(m2, p2, m3, f | lbS | rbS, rS);
+                        }
+                        take_better(bm, pm, m2, p2, lS);
+                    }
+                    px = bx > NIw ? px : PG_BP_NONE; py = by > NIw ? py : PG_BP_NONE; pm = bm > NIw ? pm : PG_BP_NONE;
+                } else {
+                    // first/last rows and columns, sites without edges, more than two edges, ...: the general rules
+                    float smv = 0.0f;
+                    if (r > 0 && j > 0 && nl > 0 && nr > 0) smv = PM.table[((gl.x & 0xffff) + __umul24(gr.x & 0xffff, S)) & 255];
+                    cell_any(J, r, j, r > 0 ? nl : 0, j > 0 ? nr : 0, smv, no_terminal_edges, reduced_terminal,
+                             [&](int p_, int q_, double &xs, double &ys, double &ms) {
+                                 pg_d2 xy; double m_;
+                                 pg_d2 e1 = {NIw, NIw}, e2 = {NIw, NIw}; double m1 = NIw, m2 = NIw;
+                                 wcell(p_ >= 0 && q_ >= 0, d - (p_ + q_), p_, xy, m_);
+                                 far_wait3(xy, m_, e1, m1, e2, m2);
+                                 xs = xy.x; ys = xy.y; ms = m_;
+                             },
+                             [&](int k, int &p_, double &lw) { int dist; edge_at<true>(gl, k, r, dist, lw); p_ = r - dist; },
+                             [&](int k, int &q_, double &rw) { int dist; edge_at<false>(gr, k, j, dist, rw); q_ = j - dist; },
+                             bx, by, bm, px, py, pm);
+                }
+            }
+            {
+                double *o = (double *)((char *)&PM.sc[0][0][0] + wsb + (r & (PWPOS - 1)) * 24);
+                o[PG_X] = bx; o[PG_Y] = by; o[PG_M] = bm;
+            }
+            if (active) {
+                typedef unsigned u3 __attribute__((ext_vector_type(3)));
+                const unsigned off12 = __umul24((unsigned)(r - lo), 12u);
+                pg_d2 xy; xy.x = bx; xy.y = by;
+                *(PG_GLOBAL pg_d2 *)(srow + 2u * off12) = xy;
+                *(PG_GLOBAL double *)(srow + 2u * off12 + 16u) = bm;
+                u3 b3; b3.x = px; b3.y = py; b3.z = pm;
+                *(PG_GLOBAL u3 *)(brow + off12) = b3;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(30)" ::: "memory");  // the stores of five steps ago have retired (older cells of the run are read from L2)
+        flag_store(&PM.progress[wave], d);
+        ++d;
+        dA = nxt;
+        if ((nxt.s4 & 15) != 4 || d >= sleep) break;
+        cur = nxt;
+    }
+    // back to step(): this lane's row for the narrow diagonals, nothing in registers or prefetched; the ring's
+    // memory holds wide-ring rows now -- the host marks no diagonal up to here as ring-resident (dp_abi.hip)
+    row = dA.x + ((tid - dA.x) & (PNT - 1));
+    ok_until = d - 1;
+    C_.dA = dA;
+    WCTX_OUT(C_);
 }
 
 #ifdef PG_PIPE_STATS
@@ -1372,6 +1898,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
 #endif
         };
 
+
         int d = wake;
         while (d < sleep) {
 #ifdef PG_PIPE_STATS
@@ -1379,7 +1906,38 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
             st_t = __builtin_readcyclecounter();
             if (st_on) st_n += 2;
 #endif
-            if ((dA.s4 & 0x1c) == 0x10 && (dA.s4 & 3) != 3 && d + 1 < sleep) {      // class 0..2 and the next one too
+            if (TAB_LDS && ((dA.s4 & 15) <= 2 || (dA.s4 & 15) == 4)) {           // model table in LDS: classes 0..2 and 4 run as functions of their own
+                WaveCtx C_;
+                C_.job = job; C_.psc = psc; C_.sc_out = sc_out; C_.bp_out = bp_out;
+                C_.go = go; C_.ng = ng; C_.ge = ge; C_.tng2 = tng2; C_.tng1 = tng1;
+                C_.Lx = Lx; C_.Ly = Ly; C_.nd = nd; C_.S = S; C_.sleep = sleep;
+                C_.tid = tid; C_.wave = wave; C_.up = up; C_.dn = dn; C_.bslot = bslot; C_.flags = flags;
+                C_.d = d; C_.row = row;
+                C_.px = r1x; C_.py = r1y; C_.pm = r1m; C_.cx = r2x; C_.cy = r2y; C_.cm = r2m;
+                C_.ca = ca; C_.cb = cb; C_.smf = smf; C_.dA = dA;
+                C_.p_up = p_up; C_.p_dn = p_dn; C_.ok_until = ok_until; C_.rows_ld = rows_ld; C_.cols_ld = cols_ld; C_.diags_ld = diags_ld;
+                C_.as0 = as0; C_.as1 = as1; C_.as2 = as2;
+#ifdef PG_PIPE_STATS
+                for (int k = 0; k < 5; ++k) { C_.st_cls_t[k] = st_cls_t[k]; C_.st_cls_n[k] = st_cls_n[k]; }
+                for (int k = 0; k < 10; ++k) { C_.st_poll_t[k] = st_poll_t[k]; C_.st_poll_n[k] = st_poll_n[k]; }
+#endif
+                if ((dA.s4 & 15) == 4) wide_run(C_); else hot_run(C_);
+#ifdef PG_PIPE_STATS
+                for (int k = 0; k < 5; ++k) { st_cls_t[k] = C_.st_cls_t[k]; st_cls_n[k] = C_.st_cls_n[k]; }
+                for (int k = 0; k < 10; ++k) { st_poll_t[k] = C_.st_poll_t[k]; st_poll_n[k] = C_.st_poll_n[k]; }
+#endif
+                d = __builtin_amdgcn_readfirstlane(C_.d); row = C_.row;
+                r1x = C_.px; r1y = C_.py; r1m = C_.pm; r2x = C_.cx; r2y = C_.cy; r2m = C_.cm;
+                ca = C_.ca; cb = C_.cb; smf = C_.smf; dA = uniform_i8(C_.dA);
+                p_up = __builtin_amdgcn_readfirstlane(C_.p_up); p_dn = __builtin_amdgcn_readfirstlane(C_.p_dn);
+                ok_until = __builtin_amdgcn_readfirstlane(C_.ok_until); rows_ld = __builtin_amdgcn_readfirstlane(C_.rows_ld);
+                cols_ld = __builtin_amdgcn_readfirstlane(C_.cols_ld); diags_ld = __builtin_amdgcn_readfirstlane(C_.diags_ld);
+                as0 = __builtin_amdgcn_readfirstlane(C_.as0); as1 = __builtin_amdgcn_readfirstlane(C_.as1); as2 = __builtin_amdgcn_readfirstlane(C_.as2);
+                // step() reloads the row records; nothing of lane 0's operand is prefetched
+                have = false; lo_prev = -1; hi_prev = -2; nb_valid = false;
+                slot = d % PRK; slot1 = (d + PRK - 1) % PRK; stg = d % PST;
+                pp = psc + d;
+            } else if (!TAB_LDS && (dA.s4 & 0x1c) == 0x10 && (dA.s4 & 3) != 3 && d + 1 < sleep) {      // class 0..2 and the next one too
                 // two hot steps: the register sets swap roles and are back in place afterwards
                 step(std::true_type(), d, dA, dB, r1x, r1y, r1m, r2x, r2y, r2m, r3x, r3y, r3m, r4x, r4y, r4m, ca, cb);
                 step(std::true_type(), d + 1, dB, dA, r4x, r4y, r4m, r3x, r3y, r3m, r2x, r2y, r2m, r1x, r1y, r1m, cb, ca);
