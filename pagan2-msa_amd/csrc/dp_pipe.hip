@@ -1059,7 +1059,7 @@ struct WaveCtx {
     pg_i8 dA;                                // descriptor of diagonal d
     int p_up, p_dn, ok_until, rows_ld, cols_ld, diags_ld, as0, as1, as2;
 #ifdef PG_PIPE_STATS
-    long long st_cls_t[5], st_poll_t[10];
+    long long st_cls_t[5], st_poll_t[10], st_w[4];
     int st_cls_n[5], st_poll_n[10];
 #endif
 };
@@ -1091,7 +1091,7 @@ __device__ __forceinline__ pg_i8 uniform_i8(const pg_i8 &v) {
     (c).d = d; (c).row = row; (c).p_up = p_up; (c).p_dn = p_dn; (c).ok_until = ok_until; (c).rows_ld = rows_ld; (c).cols_ld = cols_ld; \
     (c).diags_ld = diags_ld; (c).as0 = as0; (c).as1 = as1; (c).as2 = as2
 #ifdef PG_PIPE_STATS
-#define WCTX_STATS(c) long long (&st_cls_t)[5] = (c).st_cls_t; long long (&st_poll_t)[10] = (c).st_poll_t; int (&st_cls_n)[5] = (c).st_cls_n; int (&st_poll_n)[10] = (c).st_poll_n
+#define WCTX_STATS(c) long long (&st_cls_t)[5] = (c).st_cls_t; long long (&st_poll_t)[10] = (c).st_poll_t; int (&st_cls_n)[5] = (c).st_cls_n; int (&st_poll_n)[10] = (c).st_poll_n; long long (&st_w)[4] = (c).st_w; (void)st_w
 #else
 #define WCTX_STATS(c)
 #endif
@@ -1134,11 +1134,13 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
     const unsigned a_table = (unsigned)(unsigned long long)(lds_char *)&PM.table[0];
     const unsigned a_fup = (unsigned)(unsigned long long)(lds_char *)&PM.progress[up], a_fme = (unsigned)(unsigned long long)(lds_char *)&PM.progress[wave];
     const unsigned ni_hi = 0xfff00000u;
+    const unsigned a_null = (unsigned)(unsigned long long)(lds_char *)&PM.null_cell[0];
     for (;;) {
 #ifndef PG_NO_HOT_ASM
-        if ((cur.s4 & 15) == 0) {
-            // ---- consecutive class 0 diagonals: hand-scheduled loop (tools/gen_hot_asm.py has the register plan) ----
-            // It runs until a diagonal needs anything but the straight-line step -- another class, the end of the wave's
+        if ((cur.s4 & 15) <= 1) {
+            // ---- consecutive class 0 / class 1 diagonals: hand-scheduled loop (tools/gen_hot_asm.py has the register plan;
+            // the C++ step below states the same arithmetic) ----
+            // It runs until a diagonal needs anything else -- another class, the end of the wave's
             // interval, a flag that has to be polled -- and leaves that diagonal untouched: d, the ring row, the lane's row
             // and cells come back; the operand pipeline is reloaded below.
             unsigned long long dptr = (unsigned long long)(psc + d);
@@ -1154,17 +1156,23 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                   [d] "+s"(d), [sb] "+s"(sb), [pup] "+s"(p_up), [dptr] "+s"(dptr)
                 : [ge] "v"(ge), [go] "v"(go), [ng] "v"(ng), [tng2] "v"(tng2), [tng1] "v"(tng1), [ni] "v"(NI), [nihi] "v"(ni_hi),
                   [tid24] "v"(a_tid24), [bpos24] "v"(a_bpos24), [fup] "v"(a_fup), [fme] "v"(a_fme),
+                  [c18] "v"(1u << 18), [nulla] "v"(a_null), [tid] "v"(tid), [ringb] "s"(lds_ring),
                   [sleep] "s"(sleep), [okuntil] "s"(ok_until), [pdn] "s"(p_dn), [S] "s"(S),
                   [bR] "s"(a_recR), [bL] "s"(a_recL), [bT] "s"(a_table),
                   [sclo] "s"(sc_lo), [schi] "s"(sc_hi), [bplo] "s"(bp_lo), [bphi] "s"(bp_hi)
                 : "memory", "vcc", "scc",
+                  "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173",
+                  "v174", "v175", "v176", "v177", "v178", "v179",
+                  "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250",
+                  "v251", "v252", "v253", "v254", "v255",
+                  "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
                   "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193",
                   "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207",
                   "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221",
                   "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235",
                   "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
                   "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
-                  "s68", "s69", "s70", "s71", "s72");
+                  "s68", "s69", "s70", "s71", "s72", "s73");
             d = __builtin_amdgcn_readfirstlane(d);
             if (d != d_in) {
                 // the operand pipeline of diagonal d from the LDS windows, the descriptor from memory
@@ -1195,12 +1203,22 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
             ok_until = d + margin;
         }
         if (cur.s7 > p_dn) p_dn = POLLX(&PM.progress[dn], cur.s7, 3);
-        if (d - 1 > p_up && __any(row <= hi + 1)) p_up = POLLX(&PM.progress[up], d - 1, 4);
         // ---- (row-1, j) on d-1: lane-1's registers; lane 0 takes the upstream wave's lane 63 from the ring (what it
-        // reads is used only if lane 0's row is in the band, and then the upstream wave was waited for above) ----
+        // reads is used only if lane 0's row is in the band, and then the upstream wave is waited for).  The flag is
+        // read in the same LDS batch, ahead of the cell (LDS executes in order): a follower one step behind its
+        // upstream wave pays no round trip of its own for it ----
         const int sb1 = sb == 0 ? PRING_BYTES - PROW_BYTES : sb - PROW_BYTES;
         double AX, AY, AM;
+        const int upf = flag_peek(&PM.progress[up]);
         ring_cell(sb1 + bpos24, AX, AY, AM);
+        if (d - 1 > p_up) {
+            const int seen = __builtin_amdgcn_readfirstlane(upf);
+            p_up = seen > p_up ? seen : p_up;
+            if (d - 1 > p_up && __any(row <= hi + 1)) {
+                p_up = POLLX(&PM.progress[up], d - 1, 4);
+                ring_cell(sb1 + bpos24, AX, AY, AM);
+            }
+        }
         // ---- row hand-over: a lane whose row left the band takes the next one of its residue (far below the band) ----
         row += row < lo ? PNT : 0;
         const bool active = row <= hi;
@@ -1209,7 +1227,9 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
         unsigned px, py, pm;
         // candidates that do not need the shift first: the LDS read above is in flight
         by = fmax3_from(PY + ge, PX + go, (PMm + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
-        if (cls != 1) {
+        // (a class 1 diagonal none of whose multi-edge cells belongs to this wave is a class 0 diagonal to it)
+        const bool own_multi = cls == 1 && __any(active && !(rLc.x & cR0.x & PR_SIMPLE));
+        if (!own_multi) {
             bm = fmax3_from(CM + tM, CX + tX, CY + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
                             PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
         }
@@ -1223,7 +1243,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
             nxt = *(cdesc8_p)pv;
         }
         bx = fmax3_from(AX + ge, AY + go, (AM + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
-        if (cls == 1) {
+        if (own_multi) {
             // ================= class 1: the lanes' own multi-edge cells =================
             const bool l2 = active && ((rLc.x >> PR_NE_SHIFT) & 127) == 2, r2 = active && ((cR0.x >> PR_NE_SHIFT) & 127) == 2;
             const bool lA2 = (rLc.y & 0xffff) != 1, rA2 = (cR0.y & 0xffff) != 1;      // (two edges:) the previous-site edge is listed second
@@ -1371,48 +1391,72 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
     const double NIw = neg_inf();
     for (;;) {
         const int lo = cur.x, hi = cur.y;
+#ifdef PG_PIPE_STATS
+        const long long st_step0 = __builtin_readcyclecounter();
+#endif
         {   // records of the diagonal's rows and columns, descriptors of every earlier diagonal
             const int nr_ = hi + 1 < Lx ? hi + 1 : Lx, nc_ = d - lo + 1 < Ly ? d - lo + 1 : Ly;
             if (rows_ld < nr_) rows_ld = POLLX(&PM.loaded[0], nr_, 1);
             if (cols_ld < nc_) cols_ld = POLLX(&PM.loaded[1], nc_, 2);
             if (diags_ld < d) diags_ld = POLLX(&PM.loaded[2], d, 5);
         }
-        if (p_up < d - 1) p_up = POLLX(&PM.progress[up], d - 1, 4);
-        if (p_dn < d - 2) p_dn = POLLX(&PM.progress[dn], d - 2, 3);
+        // (inline polls: in lock step a neighbour is, as a rule, a fraction of a step away)
+        if (p_up < d - 1) p_up = __builtin_amdgcn_readfirstlane(POLL(&PM.progress[up], d - 1, 4));
+        if (p_dn < d - 2) p_dn = __builtin_amdgcn_readfirstlane(POLL(&PM.progress[dn], d - 2, 3));
+#ifdef PG_PIPE_STATS
+        const long long st_t1 = __builtin_readcyclecounter();
+#endif
         const pg_i8 nxt = psc[d + 1];
         const int amax = d - d0 < PWAGE ? d - d0 : PWAGE;               // ages 1 .. amax are in the wide ring
         const int wsb = (d % PWK) * PWROW_BYTES;
         const long long soff = ((long long)cur.w << 32) | (unsigned)cur.z;
         PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff, *brow = (PG_GLOBAL char *)bp_out + (soff >> 1);
-        // one operand cell (p, d - age): issued (L2) or read (wide ring); -inf outside the band.  The caller waits.
-        auto wcell = [&](bool need, int age, int p_, pg_d2 &xy, double &m) {
+        // one operand cell (p, d - age): requested from L2 (returns true: the caller waits) or read from the wide ring;
+        // -inf outside the band
+        auto wcell = [&](bool need, int age, int p_, pg_d2 &xy, double &m) -> bool {
             xy.x = NIw; xy.y = NIw; m = NIw;
-            if (!need) return;
+            if (!need) return false;
             if (age <= amax) {
                 int rb = wsb - age * PWROW_BYTES;
                 rb += rb < 0 ? PWK * PWROW_BYTES : 0;
                 const double *c = (const double *)((const char *)&PM.sc[0][0][0] + rb + (p_ & (PWPOS - 1)) * 24);
                 xy.x = c[PG_X]; xy.y = c[PG_Y]; m = c[PG_M];
-            } else {
-                const int dd = d - age;
-                pg_i4 ds;
-                if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
-                else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
-                if (p_ >= ds.x && p_ <= ds.y) {
-                    const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p_ - ds.x);
-                    far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc_out + boff), xy, m);
-                }
+                return false;
             }
+            const int dd = d - age;
+            pg_i4 ds;
+            if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
+            else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
+            if (p_ >= ds.x && p_ <= ds.y) {
+                const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p_ - ds.x);
+                far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc_out + boff), xy, m);
+                return true;
+            }
+            return false;
         };
+        // Both rows of the lane in phases, so that a step pays at most ONE L2 round trip for its batched cells: request /
+        // read every operand, wait once (only if some lane asked L2: a wait also covers the wave's stores in flight),
+        // then the arithmetic; cells outside the batch (general rules) fetch one operand at a time afterwards.
+        int rr[2], kind[2];                                     // kind: 0 outside the band, 1 batched, 2 general rules
+        pg_i4 gl[2], gr[2];
+        pg_d2 o_xy[2][8];
+        double o_m[2][8];
+        bool l2q[2], r2q[2], lSq[2], rSq[2];
+        int kLq[2], kRq[2];
+        bool asked = false;
+#pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int r = lo + ((tid - lo) & (PNT - 1)) + PNT * q, j = d - r;
-            const bool active = r <= hi;
-            double bx = NIw, by = NIw, bm = NIw;
-            unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
-            if (active) {
-                const pg_i4 gl = PM.recL[r & (PRW - 1)], gr = PM.recR[j & (PRW - 1)];
-                const int nl = (gl.x >> PR_NE_SHIFT) & 127, nr = (gr.x >> PR_NE_SHIFT) & 127;
-                const int dl0 = gl.y & 0xffff, dl1 = (int)((unsigned)gl.y >> 16), dr0 = gr.y & 0xffff, dr1 = (int)((unsigned)gr.y >> 16);
+            rr[q] = r; kind[q] = 0;
+            l2q[q] = r2q[q] = lSq[q] = rSq[q] = false;
+            kLq[q] = kRq[q] = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { o_xy[q][t].x = NIw; o_xy[q][t].y = NIw; o_m[q][t] = NIw; }
+            gl[q] = pg_i4{0, 0, 0, 0}; gr[q] = pg_i4{0, 0, 0, 0};
+            if (r <= hi) {
+                gl[q] = PM.recL[r & (PRW - 1)]; gr[q] = PM.recR[j & (PRW - 1)];
+                const int nl = (gl[q].x >> PR_NE_SHIFT) & 127, nr = (gr[q].x >> PR_NE_SHIFT) & 127;
+                const int dl0 = gl[q].y & 0xffff, dl1 = (int)((unsigned)gl[q].y >> 16), dr0 = gr[q].y & 0xffff, dr1 = (int)((unsigned)gr[q].y >> 16);
                 const bool easyL = nl == 1 ? dl0 == 1 : (nl == 2 && (dl0 == 1) != (dl1 == 1));
                 const bool easyR = nr == 1 ? dr0 == 1 : (nr == 2 && (dr0 == 1) != (dr1 == 1));
                 const bool l2 = nl == 2, r2 = nr == 2;
@@ -1420,67 +1464,112 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
                 const int kL = lS ? dl0 : dl1, kR = rS ? dr0 : dr1;
                 // interior, and no edge in reach starts at site 0 (where the gap-open term differs)
                 const bool inner = r >= 2 && r <= Lx - 2 && j >= 2 && j <= Ly - 2 && (!l2 || r - kL >= 1) && (!r2 || j - kR >= 1);
-                if (easyL && easyR && inner) {
-                    const float smv = PM.table[((gl.x & 0xffff) + __umul24(gr.x & 0xffff, S)) & 255];
-                    const double tM = tng2 + (double)smv, tX = tng1 + (double)smv;
-                    pg_d2 a_, p_, c_, lx_, lm_, ry_, rm_, lr_;
-                    double am, pmm, cm, lxm, lmm, rym, rmm, lrm;
-                    wcell(true, 1, r - 1, a_, am);
-                    wcell(true, 1, r, p_, pmm);
-                    wcell(true, 2, r - 1, c_, cm);
-                    wcell(l2, kL, r - kL, lx_, lxm);
-                    wcell(l2, kL + 1, r - kL, lm_, lmm);
-                    wcell(r2, kR, r, ry_, rym);
-                    wcell(r2, kR + 1, r - 1, rm_, rmm);
-                    wcell(l2 && r2, kL + kR, r - kL, lr_, lrm);
-                    far_wait3(a_, am, p_, pmm, c_, cm);
-                    far_wait3(lx_, lxm, lm_, lmm, ry_, rym);
-                    { pg_d2 dq = {NIw, NIw}; double dm = NIw; far_wait3(rm_, rmm, lr_, lrm, dq, dm); }
-                    const double lw0 = (double)__int_as_float(gl.z), lw1 = (double)__int_as_float(gl.w);
-                    const double rw0 = (double)__int_as_float(gr.z), rw1 = (double)__int_as_float(gr.w);
-                    const double lwA = lS ? lw1 : lw0, lwS = lS ? lw0 : lw1, rwA = rS ? rw1 : rw0, rwS = rS ? rw0 : rw1;
-                    const unsigned lbA = lS ? 1u << 4 : 0u, lbS = lS ? 0u : 1u << 4;
-                    const unsigned rbA = rS ? 1u << 18 : 0u, rbS = rS ? 0u : 1u << 18;
-                    unsigned f;
-                    bx = fmax3_from(a_.x + ge, a_.y + go, (am + ng) + go, PG_X, PG_Y, PG_M, f); px = f | PG_BP_ADJL | lbA;
-                    by = fmax3_from(p_.y + ge, p_.x + go, (pmm + ng) + go, PG_Y, PG_X, PG_M, f); py = f | PG_BP_ADJR | rbA;
-                    bm = fmax3_from(((cm + tM) + lwA) + rwA, ((c_.x + tX) + lwA) + rwA, ((c_.y + tX) + lwA) + rwA, PG_M, PG_X, PG_Y, f);
-                    pm = f | PG_BP_ADJL | PG_BP_ADJR | lbA | rbA;
-                    if (r2) {
-                        const double ys = fmax3_from(ry_.y + ge, ry_.x + go, (rym + ng) + go, PG_Y, PG_X, PG_M, f);
-                        take_better(by, py, ys, f | rbS, rS);
-                        const double ms = fmax3_from(((rmm + tM) + lwA) + rwS, ((rm_.x + tX) + lwA) + rwS, ((rm_.y + tX) + lwA) + rwS, PG_M, PG_X, PG_Y, f);
-                        take_better(bm, pm, ms, f | PG_BP_ADJL | lbA | rbS, rS);
-                    }
-                    if (l2) {
-                        const double xs = fmax3_from(lx_.x + ge, lx_.y + go, (lxm + ng) + go, PG_X, PG_Y, PG_M, f);
-                        take_better(bx, px, xs, f | lbS, lS);
-                        unsigned f2;
-                        double m2 = fmax3_from(((lmm + tM) + lwS) + rwA, ((lm_.x + tX) + lwS) + rwA, ((lm_.y + tX) + lwS) + rwA, PG_M, PG_X, PG_Y, f2);
-                        unsigned p2 = f2 | PG_BP_ADJR | lbS | rbA;
-                        if (r2) {
-                            const double m3 = fmax3_from(((lrm + tM) + lwS) + rwS, ((lr_.x + tX) + lwS) + rwS, ((lr_.y + tX) + lwS) + rwS, PG_M, PG_X, PG_Y, f);
-                            take_better(m2, p2, m3, f | lbS | rbS, rS);
-                        }
-                        take_better(bm, pm, m2, p2, lS);
-                    }
-                    px = bx > NIw ? px : PG_BP_NONE; py = by > NIw ? py : PG_BP_NONE; pm = bm > NIw ? pm : PG_BP_NONE;
-                } else {
-                    // first/last rows and columns, sites without edges, more than two edges, ...: the general rules
-                    float smv = 0.0f;
-                    if (r > 0 && j > 0 && nl > 0 && nr > 0) smv = PM.table[((gl.x & 0xffff) + __umul24(gr.x & 0xffff, S)) & 255];
-                    cell_any(J, r, j, r > 0 ? nl : 0, j > 0 ? nr : 0, smv, no_terminal_edges, reduced_terminal,
-                             [&](int p_, int q_, double &xs, double &ys, double &ms) {
-                                 pg_d2 xy; double m_;
-                                 pg_d2 e1 = {NIw, NIw}, e2 = {NIw, NIw}; double m1 = NIw, m2 = NIw;
-                                 wcell(p_ >= 0 && q_ >= 0, d - (p_ + q_), p_, xy, m_);
-                                 far_wait3(xy, m_, e1, m1, e2, m2);
-                                 xs = xy.x; ys = xy.y; ms = m_;
-                             },
-                             [&](int k, int &p_, double &lw) { int dist; edge_at<true>(gl, k, r, dist, lw); p_ = r - dist; },
-                             [&](int k, int &q_, double &rw) { int dist; edge_at<false>(gr, k, j, dist, rw); q_ = j - dist; },
-                             bx, by, bm, px, py, pm);
+                kind[q] = (easyL && easyR && inner) ? 1 : 2;
+                if (kind[q] == 1) { l2q[q] = l2; r2q[q] = r2; lSq[q] = lS; rSq[q] = rS; kLq[q] = kL; kRq[q] = kR; }
+            }
+            // the batched cells' operands.  Wave-uniform shortcuts: an optional operand is skipped when no lane has it, and
+            // while every operand of the wave lies in the wide ring the reads are plain LDS reads (no L2 path, no branches)
+            const bool b1 = kind[q] == 1, l2 = l2q[q], r2 = r2q[q];
+            const int kL = kLq[q], kR = kRq[q];
+            if (!__any(b1)) continue;
+            auto rd = [&](bool need, int age, int p_, pg_d2 &xy, double &m) {
+                int rb = wsb - age * PWROW_BYTES;
+                rb += rb < 0 ? PWK * PWROW_BYTES : 0;
+                const int off = need ? rb + (p_ & (PWPOS - 1)) * 24 : (int)offsetof(PipeSmem, null_cell);
+                const double *c = (const double *)((const char *)&PM.sc[0][0][0] + off);
+                xy.x = c[PG_X]; xy.y = c[PG_Y]; m = c[PG_M];
+            };
+            // one operand of the wave's batched cells: nothing if no lane has it, a plain LDS read while every lane's lies in
+            // the wide ring, the L2-or-ring path otherwise
+            auto fetch = [&](bool need, int age, int p_, pg_d2 &xy, double &m) {
+                if (!__any(need)) return;
+                if (!__any(need && age > amax)) rd(need, age, p_, xy, m);
+                else if (need) asked |= wcell(true, age, p_, xy, m);
+            };
+            fetch(b1, 1, r - 1, o_xy[q][0], o_m[q][0]);
+            fetch(b1, 1, r, o_xy[q][1], o_m[q][1]);
+            fetch(b1, 2, r - 1, o_xy[q][2], o_m[q][2]);
+            fetch(b1 && l2, kL, r - kL, o_xy[q][3], o_m[q][3]);
+            fetch(b1 && l2, kL + 1, r - kL, o_xy[q][4], o_m[q][4]);
+            fetch(b1 && r2, kR, r, o_xy[q][5], o_m[q][5]);
+            fetch(b1 && r2, kR + 1, r - 1, o_xy[q][6], o_m[q][6]);
+            fetch(b1 && l2 && r2, kL + kR, r - kL, o_xy[q][7], o_m[q][7]);
+        }
+#ifdef PG_PIPE_STATS
+        const long long st_t2 = __builtin_readcyclecounter();
+#endif
+        if (__any(asked)) {
+            // one wait; the empty statements keep every possibly-requested register below it
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                far_wait3(o_xy[q][0], o_m[q][0], o_xy[q][1], o_m[q][1], o_xy[q][2], o_m[q][2]);
+                far_wait3(o_xy[q][3], o_m[q][3], o_xy[q][4], o_m[q][4], o_xy[q][5], o_m[q][5]);
+                { pg_d2 dq = {NIw, NIw}; double dm = NIw; far_wait3(o_xy[q][6], o_m[q][6], o_xy[q][7], o_m[q][7], dq, dm); }
+            }
+        }
+#ifdef PG_PIPE_STATS
+        const long long st_t3 = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = rr[q], j = d - r;
+            const bool active = kind[q] != 0;
+            double bx = NIw, by = NIw, bm = NIw;
+            unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
+            if (kind[q] == 1) {
+                const bool l2 = l2q[q], r2 = r2q[q], lS = lSq[q], rS = rSq[q];
+                const float smv = PM.table[((gl[q].x & 0xffff) + __umul24(gr[q].x & 0xffff, S)) & 255];
+                const double tM = tng2 + (double)smv, tX = tng1 + (double)smv;
+                const double lw0 = (double)__int_as_float(gl[q].z), lw1 = (double)__int_as_float(gl[q].w);
+                const double rw0 = (double)__int_as_float(gr[q].z), rw1 = (double)__int_as_float(gr[q].w);
+                const double lwA = lS ? lw1 : lw0, lwS = lS ? lw0 : lw1, rwA = rS ? rw1 : rw0, rwS = rS ? rw0 : rw1;
+                const unsigned lbA = lS ? 1u << 4 : 0u, lbS = lS ? 0u : 1u << 4;
+                const unsigned rbA = rS ? 1u << 18 : 0u, rbS = rS ? 0u : 1u << 18;
+                const pg_d2 a_ = o_xy[q][0], p_ = o_xy[q][1], c_ = o_xy[q][2], lx_ = o_xy[q][3], lm_ = o_xy[q][4], ry_ = o_xy[q][5], rm_ = o_xy[q][6], lr_ = o_xy[q][7];
+                const double am = o_m[q][0], pmm = o_m[q][1], cm = o_m[q][2], lxm = o_m[q][3], lmm = o_m[q][4], rym = o_m[q][5], rmm = o_m[q][6], lrm = o_m[q][7];
+                unsigned f;
+                bx = fmax3_from(a_.x + ge, a_.y + go, (am + ng) + go, PG_X, PG_Y, PG_M, f); px = f | PG_BP_ADJL | lbA;
+                by = fmax3_from(p_.y + ge, p_.x + go, (pmm + ng) + go, PG_Y, PG_X, PG_M, f); py = f | PG_BP_ADJR | rbA;
+                bm = fmax3_from(((cm + tM) + lwA) + rwA, ((c_.x + tX) + lwA) + rwA, ((c_.y + tX) + lwA) + rwA, PG_M, PG_X, PG_Y, f);
+                pm = f | PG_BP_ADJL | PG_BP_ADJR | lbA | rbA;
+                // (absent operands are -inf and cannot win; the blocks are skipped when no lane of the wave has the edge)
+                if (__any(r2)) {
+                    const double ys = fmax3_from(ry_.y + ge, ry_.x + go, (rym + ng) + go, PG_Y, PG_X, PG_M, f);
+                    take_better(by, py, ys, f | rbS, rS);
+                    const double ms = fmax3_from(((rmm + tM) + lwA) + rwS, ((rm_.x + tX) + lwA) + rwS, ((rm_.y + tX) + lwA) + rwS, PG_M, PG_X, PG_Y, f);
+                    take_better(bm, pm, ms, f | PG_BP_ADJL | lbA | rbS, rS);
                 }
+                if (__any(l2)) {
+                    const double xs = fmax3_from(lx_.x + ge, lx_.y + go, (lxm + ng) + go, PG_X, PG_Y, PG_M, f);
+                    take_better(bx, px, xs, f | lbS, lS);
+                    unsigned f2;
+                    double m2 = fmax3_from(((lmm + tM) + lwS) + rwA, ((lm_.x + tX) + lwS) + rwA, ((lm_.y + tX) + lwS) + rwA, PG_M, PG_X, PG_Y, f2);
+                    unsigned p2 = f2 | PG_BP_ADJR | lbS | rbA;
+                    if (__any(l2 && r2)) {
+                        const double m3 = fmax3_from(((lrm + tM) + lwS) + rwS, ((lr_.x + tX) + lwS) + rwS, ((lr_.y + tX) + lwS) + rwS, PG_M, PG_X, PG_Y, f);
+                        take_better(m2, p2, m3, f | lbS | rbS, rS);
+                    }
+                    take_better(bm, pm, m2, p2, lS);
+                }
+                px = bx > NIw ? px : PG_BP_NONE; py = by > NIw ? py : PG_BP_NONE; pm = bm > NIw ? pm : PG_BP_NONE;
+            } else if (kind[q] == 2) {
+                // first/last rows and columns, sites without edges, more than two edges, ...: the general rules
+                const int nl = (gl[q].x >> PR_NE_SHIFT) & 127, nr = (gr[q].x >> PR_NE_SHIFT) & 127;
+                float smv = 0.0f;
+                if (r > 0 && j > 0 && nl > 0 && nr > 0) smv = PM.table[((gl[q].x & 0xffff) + __umul24(gr[q].x & 0xffff, S)) & 255];
+                const pg_i4 gl_ = gl[q], gr_ = gr[q];
+                cell_any(J, r, j, r > 0 ? nl : 0, j > 0 ? nr : 0, smv, no_terminal_edges, reduced_terminal,
+                         [&](int p_, int q_, double &xs, double &ys, double &ms) {
+                             pg_d2 xy; double m_;
+                             if (wcell(p_ >= 0 && q_ >= 0, d - (p_ + q_), p_, xy, m_)) {
+                                 pg_d2 e1 = {NIw, NIw}, e2 = {NIw, NIw}; double m1 = NIw, m2 = NIw;
+                                 far_wait3(xy, m_, e1, m1, e2, m2);
+                             }
+                             xs = xy.x; ys = xy.y; ms = m_;
+                         },
+                         [&](int k, int &p_, double &lw) { int dist; edge_at<true>(gl_, k, r, dist, lw); p_ = r - dist; },
+                         [&](int k, int &q_, double &rw) { int dist; edge_at<false>(gr_, k, j, dist, rw); q_ = j - dist; },
+                         bx, by, bm, px, py, pm);
             }
             {
                 double *o = (double *)((char *)&PM.sc[0][0][0] + wsb + (r & (PWPOS - 1)) * 24);
@@ -1498,6 +1587,13 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
         }
         asm volatile("s_waitcnt vmcnt(30)" ::: "memory");  // the stores of five steps ago have retired (older cells of the run are read from L2)
         flag_store(&PM.progress[wave], d);
+#ifdef PG_PIPE_STATS
+        {
+            const long long st_t5 = __builtin_readcyclecounter();
+            st_cls_t[4] += st_t5 - st_step0; ++st_cls_n[4];
+            st_w[0] += st_t1 - st_step0; st_w[1] += st_t2 - st_t1; st_w[2] += st_t3 - st_t2; st_w[3] += st_t5 - st_t3;
+        }
+#endif
         ++d;
         dA = nxt;
         if ((nxt.s4 & 15) != 4 || d >= sleep) break;
@@ -1920,11 +2016,13 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
 #ifdef PG_PIPE_STATS
                 for (int k = 0; k < 5; ++k) { C_.st_cls_t[k] = st_cls_t[k]; C_.st_cls_n[k] = st_cls_n[k]; }
                 for (int k = 0; k < 10; ++k) { C_.st_poll_t[k] = st_poll_t[k]; C_.st_poll_n[k] = st_poll_n[k]; }
+                for (int k = 0; k < 4; ++k) C_.st_w[k] = st_w[k];
 #endif
                 if ((dA.s4 & 15) == 4) wide_run(C_); else hot_run(C_);
 #ifdef PG_PIPE_STATS
                 for (int k = 0; k < 5; ++k) { st_cls_t[k] = C_.st_cls_t[k]; st_cls_n[k] = C_.st_cls_n[k]; }
                 for (int k = 0; k < 10; ++k) { st_poll_t[k] = C_.st_poll_t[k]; st_poll_n[k] = C_.st_poll_n[k]; }
+                for (int k = 0; k < 4; ++k) st_w[k] = C_.st_w[k];
 #endif
                 d = __builtin_amdgcn_readfirstlane(C_.d); row = C_.row;
                 r1x = C_.px; r1y = C_.py; r1m = C_.pm; r2x = C_.cx; r2y = C_.cy; r2m = C_.cm;

@@ -10,14 +10,16 @@ REACH, WIDTH, WINDOW, RING, WAKE = 15, 241, 352, 15, 6      # dp_device.h: PG_PI
 
 
 def site_features(g, n):
-    span = np.zeros(n, np.int64); simple = np.zeros(n, bool); nopred = np.zeros(n, bool)
+    span = np.zeros(n, np.int64); simple = np.zeros(n, bool); nopred = np.zeros(n, bool); easy = np.zeros(n, bool)
     for s in range(n):
         a, b = g.bwd_off[s], g.bwd_off[s + 1]
         if b > a:
             span[s] = s - g.bwd_src[a:b].min()
         nopred[s] = b == a
         simple[s] = s > 0 and b - a == 1 and g.bwd_src[a] == s - 1 and g.bwd_logw[a] == 0.0
-    return span, simple, nopred
+        # what the compute waves evaluate themselves: one edge from the previous site, alone or beside ONE other edge
+        easy[s] = s > 0 and b - a in (1, 2) and int((g.bwd_src[a:b] == s - 1).sum()) == 1
+    return span, simple, nopred, easy
 
 
 def brute_plan(left, right, band):
@@ -26,8 +28,8 @@ def brute_plan(left, right, band):
     if band is not None:
         lo = np.maximum(band.upper[:Lx].astype(np.int64), 0); hi = np.minimum(band.lower[:Lx].astype(np.int64), Ly - 1)
     nd = Lx + Ly - 1
-    sl, simL, npL = site_features(left, Lx)
-    sr, simR, npR = site_features(right, Ly)
+    sl, simL, npL, easyL = site_features(left, Lx)
+    sr, simR, npR, easyR = site_features(right, Ly)
     distL = [[s - p for p in left.bwd_src[left.bwd_off[s]:left.bwd_off[s + 1]]] or [1] for s in range(Lx)]
     distR = [[s - p for p in right.bwd_src[right.bwd_off[s]:right.bwd_off[s + 1]]] or [1] for s in range(Ly)]
     cls = np.zeros(nd, np.uint8)
@@ -52,7 +54,9 @@ def brute_plan(left, right, band):
         elif (imin < REACH or d - imax < REACH) and (any(not simL[i] for i in rows) or any(not simR[j] for j in cols)):
             c = 2
         elif any(not simL[i] for i in rows) or any(not simR[j] for j in cols):
-            c = 1
+            # class 1 (the compute waves' own) only if every multi-edge site on the diagonal is an easy one; the plan is
+            # that of a job whose model table fits LDS
+            c = 1 if all(easyL[i] for i in rows) and all(easyR[j] for j in cols) else 2
         else:
             c = 0
         cls[d] = c
