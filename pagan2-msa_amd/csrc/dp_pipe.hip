@@ -1135,10 +1135,15 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
     const unsigned a_fup = (unsigned)(unsigned long long)(lds_char *)&PM.progress[up], a_fme = (unsigned)(unsigned long long)(lds_char *)&PM.progress[wave];
     const unsigned ni_hi = 0xfff00000u;
     const unsigned a_null = (unsigned)(unsigned long long)(lds_char *)&PM.null_cell[0];
+    const unsigned a_asd = (unsigned)(unsigned long long)(lds_char *)&PM.assist_done[0];
+    const unsigned a_stx = (unsigned)(unsigned long long)(lds_char *)&PM.sx[0][tid], a_spx = (unsigned)(unsigned long long)(lds_char *)&PM.spx[0][tid];
+    static_assert(offsetof(PipeSmem, sy) - offsetof(PipeSmem, sx) == 6144 && offsetof(PipeSmem, sM) - offsetof(PipeSmem, sx) == 12288 &&
+                  offsetof(PipeSmem, spy) - offsetof(PipeSmem, spx) == 3072 && offsetof(PipeSmem, spm) - offsetof(PipeSmem, spx) == 6144 &&
+                  PST == 3 && PNT == 256, "the class 2 merge of dp_pipe_hot.inc addresses the staging arrays by these strides");
     for (;;) {
 #ifndef PG_NO_HOT_ASM
-        if ((cur.s4 & 15) <= 1) {
-            // ---- consecutive class 0 / class 1 diagonals: hand-scheduled loop (tools/gen_hot_asm.py has the register plan;
+        if ((cur.s4 & 15) <= 2) {
+            // ---- consecutive class 0 / 1 / 2 diagonals: hand-scheduled loop (tools/gen_hot_asm.py has the register plan;
             // the C++ step below states the same arithmetic) ----
             // It runs until a diagonal needs anything else -- another class, the end of the wave's
             // interval, a flag that has to be polled -- and leaves that diagonal untouched: d, the ring row, the lane's row
@@ -1157,6 +1162,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                 : [ge] "v"(ge), [go] "v"(go), [ng] "v"(ng), [tng2] "v"(tng2), [tng1] "v"(tng1), [ni] "v"(NI), [nihi] "v"(ni_hi),
                   [tid24] "v"(a_tid24), [bpos24] "v"(a_bpos24), [fup] "v"(a_fup), [fme] "v"(a_fme),
                   [c18] "v"(1u << 18), [nulla] "v"(a_null), [tid] "v"(tid), [ringb] "s"(lds_ring),
+                  [asd] "s"(a_asd), [stx] "v"(a_stx), [spxa] "v"(a_spx),
                   [sleep] "s"(sleep), [okuntil] "s"(ok_until), [pdn] "s"(p_dn), [S] "s"(S),
                   [bR] "s"(a_recR), [bL] "s"(a_recL), [bT] "s"(a_table),
                   [sclo] "s"(sc_lo), [schi] "s"(sc_hi), [bplo] "s"(bp_lo), [bphi] "s"(bp_hi)

@@ -209,6 +209,74 @@ def class1(E, k):
     a(".Lpg_c1done%s:" % sfx)
 
 
+def class2(E, k):
+    """The merge of a class 2 step: what the diagonal's assist wave staged -- for every multi-edge cell, the best X / Y
+    candidate over the edges that do not come from the previous site and the best M over all edge pairs (dp_pipe.hip,
+    pipe_assist) -- into the base step's candidates.  X / Y by value, a tie by list position (PS_FIRST: the staged winner
+    precedes the previous-site edge; PS_ONLY: there is no previous-site edge); M as staged."""
+    a = E.a
+    sfx = "%d_%%=" % k
+    ex, ey, em = T[0], T[1], T[2]
+    a("; ---- class 2: merge what the assist wave of this diagonal staged ----")
+    a("s_mul_hi_u32 s68, %[d], 0xaaaaaaab")
+    a("s_lshr_b32 s68, s68, 1")
+    a("s_mul_i32 s68, s68, 3")
+    a("s_sub_i32 s72, %[d], s68")                              # staging slot (and assist wave): d % 3
+    a("s_lshl_b32 s68, s72, 2")
+    a("s_add_u32 s68, s68, %[asd]")
+    a("v_mov_b32_e32 v217, s68")                               # address of the assist wave's progress flag
+    a("s_lshl_b32 s69, s72, 11")
+    a("v_add_u32_e32 v218, s69, %[stx]")                       # sx[slot][lane]; sy, sM follow at 6144-byte strides
+    a("s_lshl_b32 s69, s72, 10")
+    a("v_add_u32_e32 v219, s69, %[spxa]")                      # spx[slot][lane]; spy, spm at 3072-byte strides
+    a("s_mov_b32 s72, 64")
+    a(".Lpg_c2read%s:" % sfx)
+    a("ds_read_b32 v223, v217")                                # flag first: LDS executes in order
+    a("ds_read_b64 %s, v218" % pr(ex))
+    a("ds_read_b64 %s, v218 offset:6144" % pr(ey))
+    a("ds_read_b64 %s, v218 offset:12288" % pr(em))
+    a("ds_read_b32 v220, v219")
+    a("ds_read_b32 v221, v219 offset:3072")
+    a("ds_read_b32 v222, v219 offset:6144")
+    a("s_waitcnt lgkmcnt(0)")                                   # (and the two site records)
+    a("v_readfirstlane_b32 s68, v223")
+    a("s_cmp_lt_i32 s68, %[d]")
+    a("s_cbranch_scc0 .Lpg_c2ok%s" % sfx)
+    a("s_sleep 1")                                              # the assist wave is, as a rule, nearly there
+    a("s_sub_i32 s72, s72, 1")
+    a("s_cmp_lg_u32 s72, 0")
+    a("s_cbranch_scc1 .Lpg_c2read%s" % sfx)
+    a("s_branch .Lpg_exit%s" % sfx)                             # nothing of this step is committed: the caller's poll takes over
+    a(".Lpg_c2ok%s:" % sfx)
+    a("v_and_b32_e32 v217, 0x10000, v%d" % RL)
+    a("v_and_b32_e32 v218, 0x10000, v%d" % CR)
+    a("v_cmp_eq_u32_e64 s[74:75], 0, v217")                     # msL: the left site is a multi-edge one
+    a("v_cmp_eq_u32_e64 s[76:77], 0, v218")                     # msR
+    for (sv, val, bst, pw, ms, first_shift, slot_shift, keep) in ((220, ex, BX, PXW, "s[74:75]", 18, 4, 0x3ffff), (221, ey, BY, PYW, "s[76:77]", 4, 18, 0x01fc000f)):
+        a("v_cmp_gt_f64_e64 s[84:85], %s, %s" % (pr(val), pr(bst)))
+        a("v_cmp_eq_f64_e64 s[86:87], %s, %s" % (pr(val), pr(bst)))
+        a("v_and_b32_e32 v217, 0x40000000, v%d" % sv)
+        a("v_cmp_gt_i32_e64 s[78:79], 0, v%d" % sv)             # PS_ONLY (bit 31)
+        a("v_cmp_ne_u32_e64 s[80:81], 0, v217")                 # PS_FIRST
+        a("v_bfe_u32 v218, v%d, %d, 7" % (sv, first_shift))     # the previous-site edge's list slot
+        a("s_and_b64 s[86:87], s[86:87], s[80:81]")
+        a("s_or_b64 s[84:85], s[84:85], s[86:87]")
+        a("v_lshlrev_b32_e32 v218, %d, v218" % slot_shift)
+        a("s_or_b64 s[84:85], s[84:85], s[78:79]")
+        a("s_and_b64 s[84:85], s[84:85], %s" % ms)              # take the staged candidate
+        a("v_cndmask_b32_e64 v218, 0, v218, %s" % ms)
+        a("v_and_b32_e32 v217, 0x%x, v%d" % (keep, sv))
+        a("v_or_b32_e32 v%d, v%d, v218" % (pw, pw))
+        a("v_cndmask_b32_e64 v%d, v%d, v%d, s[84:85]" % (bst, bst, val))
+        a("v_cndmask_b32_e64 v%d, v%d, v%d, s[84:85]" % (bst + 1, bst + 1, val + 1))
+        a("v_cndmask_b32_e64 v%d, v%d, v217, s[84:85]" % (pw, pw))
+    a("s_or_b64 s[84:85], s[74:75], s[76:77]")
+    a("s_nop 0")
+    a("v_cndmask_b32_e64 v%d, v%d, v%d, s[84:85]" % (BM, BM, em))
+    a("v_cndmask_b32_e64 v%d, v%d, v%d, s[84:85]" % (BM + 1, BM + 1, em + 1))
+    a("v_cndmask_b32_e64 v%d, v%d, v222, s[84:85]" % (PMW, PMW))
+
+
 def step(E, k):
     """One diagonal.  k = 0 / 1: which half of the unrolled pair (selects descriptor and Q roles)."""
     a = E.a
@@ -267,8 +335,8 @@ def step(E, k):
     # the LDS batch and the descriptor of this diagonal (requested a step ago) are here
     a("s_waitcnt lgkmcnt(0)")
     a("s_and_b32 s73, s%d, 15" % s4)
-    a("s_cmp_gt_u32 s73, 1")
-    a("s_cbranch_scc1 .Lpg_exit%s" % sfx)                      # not class 0 / 1
+    a("s_cmp_gt_u32 s73, 2")
+    a("s_cbranch_scc1 .Lpg_exit%s" % sfx)                      # not class 0 .. 2
     if EXP == "b":
         a("s_mov_b32 s73, 0")
     a("s_cmp_ge_i32 %[d], %[sleep]")
@@ -281,9 +349,12 @@ def step(E, k):
     a("s_max_i32 %[pup], %[pup], s68")
     a("s_sub_i32 s69, %[d], 1")
     a("s_cmp_lt_i32 %[pup], s69")
-    a("s_cbranch_scc0 .Lpg_upok%s" % sfx)
+    a("s_cbranch_scc1 .Lpg_upwait%s" % sfx)
+    a(".Lpg_upok%s:" % sfx)
+    E.cur = E.ool
     # the upstream wave has not completed d-1 yet: it is, as a rule, a fraction of a step away.  Look again a few times
     # (flag first, then lane 0's operand: LDS executes in order) before handing the wait to the caller's poll.
+    a(".Lpg_upwait%s:" % sfx)
     a("s_mov_b32 s72, 48")
     a(".Lpg_upretry%s:" % sfx)
     a("s_sleep 1")
@@ -299,7 +370,7 @@ def step(E, k):
     a("s_cmp_lg_u32 s72, 0")
     a("s_cbranch_scc1 .Lpg_upretry%s" % sfx)
     a("s_branch .Lpg_exit%s" % sfx)
-    a(".Lpg_upok%s:" % sfx)
+    E.cur = E.L
     # row hand-over
     a("v_cmp_gt_i32_e32 vcc, s%d, %%[row]" % lo)
     a("v_add_u32_e32 v222, 0x100, %[row]")
@@ -348,7 +419,13 @@ def step(E, k):
     a(".Lpg_commit%s:" % sfx)
     E.cur = E.ool
     a(".Lpg_c1%s:" % sfx)
+    a("s_cmp_eq_u32 s73, 2")
+    a("s_cbranch_scc1 .Lpg_c2%s" % sfx)
     class1(E, k)
+    a("s_load_dwordx8 s[%d:%d], s[70:71], 0x20" % (nxt, nxt + 7))
+    a("s_branch .Lpg_commit%s" % sfx)
+    a(".Lpg_c2%s:" % sfx)
+    class2(E, k)
     a("s_load_dwordx8 s[%d:%d], s[70:71], 0x20" % (nxt, nxt + 7))
     a("s_branch .Lpg_commit%s" % sfx)
     E.cur = E.L
