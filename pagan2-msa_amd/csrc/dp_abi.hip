@@ -67,6 +67,7 @@ struct HostJob {
     std::vector<uint8_t> cls;    // per diagonal: how dp_pipe.hip computes it (empty: not a pipe job)
     std::vector<int> sched;      // dp_pipe.hip: awake intervals of the four compute waves (dp_device.h)
     std::vector<int> lead_req;   // dp_pipe.hip: per diagonal, what the downstream wave must have completed first
+    std::vector<uint8_t> ring2;  // dp_pipe.hip: class 2 diagonals whose operands all lie in the ring
     std::vector<int> tiles;      // dp_tiles.hip (jobs that are not ring_ok): tile row, tile column of every tile that may hold a cell
     int n_bound = 0;             // traceback boundaries (dp_device.h)
     std::vector<int> tb;         // [n_bound + 2] table offsets
@@ -134,7 +135,8 @@ struct SiteFeat {
 // covers sites with one edge from the previous site and at most one more ("easy", SiteFeat::not_easy); a diagonal that
 // holds any other multi-edge site is class 2 (the assist waves stage its candidates, ring-resident operands included).
 void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, const RowBand &rb,
-                        const DiagIndex &dx, bool inwave, std::vector<uint8_t> *out, std::vector<int> *lead_req) {
+                        const DiagIndex &dx, bool inwave, std::vector<uint8_t> *out, std::vector<int> *lead_req,
+                        std::vector<uint8_t> *ring2 = nullptr) {
     const int nd = Lx + Ly - 1;
     SiteFeat fl, fr;
     fl.build(L, Lx); fr.build(R, Ly);
@@ -159,6 +161,7 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
         mark(i1 + j, i2 + j);
     }
     out->assign(nd, 0);
+    if (ring2) ring2->assign(nd, 0);
     int run = 0, last_wide = -1000;
     for (int d = 0; d < nd; ++d) {
         run += far[d];
@@ -173,6 +176,9 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
         else if (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)
             c = (inwave && (fl.not_easy[hi + 1] - fl.not_easy[lo] > 0 || fr.not_easy[d - lo + 1] - fr.not_easy[d - hi] > 0)) ? 2 : 1;
         else c = 0;
+        // a class 2 diagonal whose operands all lie in the ring (it is class 2 for the shape of a site only): the assist waves
+        // take their ring-only code for it
+        if (ring2) (*ring2)[d] = c == 2 && run == 0 && !(lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH);
         (*out)[d] = c;
     }
     // How far back in the LDS ring the cells of a diagonal read: 2 for simple cells, span(i) + span(j) for a
@@ -427,7 +433,7 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
                       edges_fit_ring(jb.right, hj->Ly, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES);
         if (hj->ring_ok) {
             classify_diagonals(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, jb.model->n_states * jb.model->n_states <= 256,
-                               &hj->cls, &hj->lead_req);
+                               &hj->cls, &hj->lead_req, &hj->ring2);
             schedule_waves(hj->dx, hj->cls, &hj->sched);
         }
     } else {
@@ -946,7 +952,8 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
                 packed[8 * t + 2] = (int)(boff & 0xffffffffLL); packed[8 * t + 3] = (int)(boff >> 32);
                 // (a wide diagonal reuses the ring's memory: nothing older than it is resident afterwards)
                 mask = (t >= 1 && hj.cls[t - 1] <= 3) ? (((mask << 1) | 2u) & (((1u << PG_PIPE_REACH) - 1u) & ~1u)) : 0u;
-                const unsigned pair = t + 1 < hj.cls.size() && hj.cls[t + 1] <= 2 ? 1u : 0u;   // the next step is hot too
+                // bit 4: large tables -- the next step is hot too; small tables -- a class 2 diagonal with every operand in the ring
+                const unsigned pair = big_table ? (t + 1 < hj.cls.size() && hj.cls[t + 1] <= 2 ? 1u : 0u) : (hj.ring2[t] ? 1u : 0u);
                 packed[8 * t + 4] = (int)(hj.cls[t] | (pair << 4) | (mask << 5) | ((unsigned)hop[t] << 20));
                 packed[8 * t + 5] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[8 * t + 6] = (int)(hj.dx.doff[t] >> 32);
                 packed[8 * t + 7] = hj.lead_req[t];

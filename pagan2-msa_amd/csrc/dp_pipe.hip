@@ -923,8 +923,11 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
             const int d = scan_d;
             const pg_i8 cur = psc[d];
             scan_d += PNA * (int)((unsigned)cur.s4 >> 20);          // the host's hop count: straight to this wave's next diagonal with work
-            const int cls = cur.s4 & 15;
-            if (!(cls == 2 || (!TAB_LDS && cls <= 1))) continue;   // small tables: class 1 is the compute waves' own (hot_run)
+            const int cls0 = cur.s4 & 15;
+            if (!(cls0 == 2 || (!TAB_LDS && cls0 <= 1))) continue;  // small tables: class 1 is the compute waves' own (hot_run)
+            // small tables: bit 4 marks a class 2 diagonal whose operands all lie in the ring (class 2 for the shape of a site):
+            // the ring-only code paths, as for class 1
+            const int cls = (TAB_LDS && cls0 == 2 && (cur.s4 & 16)) ? 1 : cls0;
             const int lo = cur.x, hi = cur.y;
             if (rows_ld <= hi) rows_ld = POLL(&PM.loaded[0], hi + 1, 1);
             if (cols_ld <= d - lo) cols_ld = POLL(&PM.loaded[1], d - lo + 1, 2);
