@@ -1459,9 +1459,8 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             rr[q] = r; kind[q] = 0;
             l2q[q] = r2q[q] = lSq[q] = rSq[q] = false;
             kLq[q] = kRq[q] = 0;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) { o_xy[q][t].x = NIw; o_xy[q][t].y = NIw; o_m[q][t] = NIw; }
             gl[q] = pg_i4{0, 0, 0, 0}; gr[q] = pg_i4{0, 0, 0, 0};
+            if (!__any(r <= hi)) continue;                      // none of the wave's lanes has a (second) row on this diagonal
             if (r <= hi) {
                 gl[q] = PM.recL[r & (PRW - 1)]; gr[q] = PM.recR[j & (PRW - 1)];
                 const int nl = (gl[q].x >> PR_NE_SHIFT) & 127, nr = (gr[q].x >> PR_NE_SHIFT) & 127;
@@ -1493,7 +1492,7 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             auto fetch = [&](bool need, int age, int p_, pg_d2 &xy, double &m) {
                 if (!__any(need)) return;
                 if (!__any(need && age > amax)) rd(need, age, p_, xy, m);
-                else if (need) asked |= wcell(true, age, p_, xy, m);
+                else asked |= wcell(need, age, p_, xy, m);          // (-inf for the lanes without it)
             };
             fetch(b1, 1, r - 1, o_xy[q][0], o_m[q][0]);
             fetch(b1, 1, r, o_xy[q][1], o_m[q][1]);
