@@ -815,6 +815,10 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
     int q_oa0 = 0, q_oa1 = 0, q_ob0 = 0, q_ob1 = 0, q_adjs = -1;
     unsigned q_e0 = 0, q_e1 = 0;                                   // ADJ flag / slot bits of the two edges in an M back-pointer
     double q_w0 = 0, q_w1 = 0;
+    // class 2 batches of the usual shape: the operand cells that left the ring, fetched from L2 while the batch is prepared
+    // (off the chain "compute waves completed d-2 -> d is staged": what remains there is the same as for class 1)
+    double q_fx[4] = {0, 0, 0, 0}, q_fy[4] = {0, 0, 0, 0}, q_fm[4] = {0, 0, 0, 0};
+    bool q_far[4] = {false, false, false, false};
     int scan_d = a;                                                // next diagonal whose descriptor has not been looked at
 
     // classification of one multi-edge cell: 1 one multi-edge site with <= 2 edges, 2 ... with 3, 3 two multi-edge sites
@@ -947,30 +951,77 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
             if (!q_big) {
                 bool on;
                 fetch_batch(d, d % PST, q_n, on, q_row, q_j, q_kind, q_rL, q_cR, q_tM, q_tX);
-                q_fast = cls == 1 && q_n > 0 && __builtin_amdgcn_ballot_w64(on && q_kind != 1) == 0;
-                if (q_fast && on) {
-                    // assist1_cell<false, false>'s operand selection, done ahead of time
-                    q_left = !(q_rL.x & PR_SIMPLE);
-                    const pg_i4 m = q_left ? q_rL : q_cR;
-                    const bool has1 = ((m.x >> PR_NE_SHIFT) & 127) > 1;
-                    const int d0 = m.y & 0xffff, d1 = (int)((unsigned)m.y >> 16);
-                    q_w0 = (double)__int_as_float(m.z); q_w1 = (double)__int_as_float(m.w);
-                    const int slot = d % PRK;
-                    auto cell_off = [&](int age, int p, bool present) {
-                        int s_ = slot - age;
-                        s_ += s_ < 0 ? PRK : 0;
-                        const double *c = present ? &PM.sc[s_][p & (PNT - 1)][0] : &PM.null_cell[0];
-                        return (int)((const char *)c - (const char *)&PM);
-                    };
-                    q_oa0 = cell_off(d0, q_left ? q_row - d0 : q_row, d0 != 1);
-                    q_oa1 = cell_off(d1, q_left ? q_row - d1 : q_row, has1 && d1 != 1);
-                    q_ob0 = cell_off(d0 + 1, q_left ? q_row - d0 : q_row - 1, true);
-                    q_ob1 = cell_off(d1 + 1, q_left ? q_row - d1 : q_row - 1, has1);
-                    const unsigned adj = q_left ? PG_BP_ADJL : PG_BP_ADJR, other = q_left ? PG_BP_ADJR : PG_BP_ADJL;
-                    const unsigned kk = q_left ? (1u << 4) : (1u << 18);
-                    q_e0 = (d0 == 1 ? adj : 0u) | other;
-                    q_e1 = (d1 == 1 ? adj : 0u) | kk | other;
-                    q_adjs = d0 == 1 ? 0 : ((has1 && d1 == 1) ? 1 : -1);
+                q_fast = (cls == 1 || (TAB_LDS && cls == 2)) && q_n > 0 && __builtin_amdgcn_ballot_w64(on && q_kind != 1) == 0;
+                if (q_fast) {
+                    bool ok = true, any_far = false;
+                    int f_age[4] = {0, 0, 0, 0}, f_p[4] = {0, 0, 0, 0};
+                    q_far[0] = q_far[1] = q_far[2] = q_far[3] = false;
+                    if (on) {
+                        // assist1_cell<., false>'s operand selection, done ahead of time
+                        q_left = !(q_rL.x & PR_SIMPLE);
+                        const pg_i4 m = q_left ? q_rL : q_cR;
+                        const int site = q_left ? q_row : q_j;
+                        const bool has1 = ((m.x >> PR_NE_SHIFT) & 127) > 1;
+                        const int d0 = m.y & 0xffff, d1 = (int)((unsigned)m.y >> 16);
+                        q_w0 = (double)__int_as_float(m.z); q_w1 = (double)__int_as_float(m.w);
+                        const int slot = d % PRK;
+                        // an operand `age` diagonals back in ring column p: its ring offset, the all -inf cell if it is absent, or
+                        // -- class 2, not in the ring -- a request for L2 (k = which of the four)
+                        auto cell_off = [&](int k, int age, int p, bool present) {
+                            const bool resident = cls == 1 || (age < PAGE && ((q_mask >> age) & 1u));
+                            if (present && !resident) {
+                                q_far[k] = true; any_far = true; f_age[k] = age; f_p[k] = p;
+                                if (age < PAGE) ok = false;        // a recent diagonal that is not in the ring (after a wide run): not landed yet
+                            }
+                            int s_ = slot - age;
+                            s_ += s_ < 0 ? PRK : 0;
+                            const double *c = (present && resident) ? &PM.sc[s_ < 0 ? 0 : s_][p & (PNT - 1)][0] : &PM.null_cell[0];
+                            return (int)((const char *)c - (const char *)&PM);
+                        };
+                        q_oa0 = cell_off(0, d0, q_left ? q_row - d0 : q_row, d0 != 1);
+                        q_oa1 = cell_off(1, d1, q_left ? q_row - d1 : q_row, has1 && d1 != 1);
+                        q_ob0 = cell_off(2, d0 + 1, q_left ? q_row - d0 : q_row - 1, true);
+                        q_ob1 = cell_off(3, d1 + 1, q_left ? q_row - d1 : q_row - 1, has1);
+                        // an edge that starts at site 0 opens a gap for free (BA.h:490-513): left to the general code
+                        if (cls == 2 && ((d0 != 1 && site == d0) || (has1 && d1 != 1 && site == d1))) ok = false;
+                        const unsigned adj = q_left ? PG_BP_ADJL : PG_BP_ADJR, other = q_left ? PG_BP_ADJR : PG_BP_ADJL;
+                        const unsigned kk = q_left ? (1u << 4) : (1u << 18);
+                        q_e0 = (d0 == 1 ? adj : 0u) | other;
+                        q_e1 = (d1 == 1 ? adj : 0u) | kk | other;
+                        q_adjs = d0 == 1 ? 0 : ((has1 && d1 == 1) ? 1 : -1);
+                    }
+                    if (__builtin_amdgcn_ballot_w64(on && !ok) != 0) q_fast = false;
+                    else if (__builtin_amdgcn_ballot_w64(on && any_far) != 0) {
+                        // the cells that left the ring (>= PAGE diagonals back: landed, every wave keeps all but its last eight
+                        // steps' stores retired), requested together and waited for here: this wave has nothing else in flight
+                        if (diags_ld < d) diags_ld = POLL(&PM.loaded[2], d, 5);
+                        // (this may run any number of diagonals ahead of the compute waves: a cell PAGE or more diagonals back
+                        // has landed once every wave has completed d - PAGE + PLAND)
+                        if (pw0 < d - PAGE + PLAND) pw0 = POLL(&PM.progress[0], d - PAGE + PLAND, 9);
+                        if (pw1 < d - PAGE + PLAND) pw1 = POLL(&PM.progress[1], d - PAGE + PLAND, 9);
+                        if (pw2 < d - PAGE + PLAND) pw2 = POLL(&PM.progress[2], d - PAGE + PLAND, 9);
+                        if (pw3 < d - PAGE + PLAND) pw3 = POLL(&PM.progress[3], d - PAGE + PLAND, 9);
+                        pg_d2 fxy[4];
+                        double fm_[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            fxy[k].x = NI_; fxy[k].y = NI_; fm_[k] = NI_;
+                            if (q_far[k]) {
+                                const int dd = d - f_age[k];
+                                pg_i4 ds;
+                                if (f_age[k] <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
+                                else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
+                                if (f_p[k] >= ds.x && f_p[k] <= ds.y) {
+                                    const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (f_p[k] - ds.x);
+                                    far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc_out + boff), fxy[k], fm_[k]);
+                                }
+                            }
+                        }
+                        far_wait3(fxy[0], fm_[0], fxy[1], fm_[1], fxy[2], fm_[2]);
+                        { pg_d2 dq = {NI_, NI_}; double dm = NI_; far_wait3(fxy[3], fm_[3], dq, dm, dq, dm); }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { q_fx[k] = fxy[k].x; q_fy[k] = fxy[k].y; q_fm[k] = fm_[k]; }
+                    }
                 }
             }
             return;
@@ -1002,8 +1053,14 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
                 const char *base = (const char *)&PM;
                 const double *a0 = (const double *)(base + q_oa0), *a1 = (const double *)(base + q_oa1);
                 const double *b0 = (const double *)(base + q_ob0), *b1 = (const double *)(base + q_ob1);
-                const double a0x = a0[PG_X], a0y = a0[PG_Y], a0m = a0[PG_M], a1x = a1[PG_X], a1y = a1[PG_Y], a1m = a1[PG_M];
-                const double b0x = b0[PG_X], b0y = b0[PG_Y], b0m = b0[PG_M], b1x = b1[PG_X], b1y = b1[PG_Y], b1m = b1[PG_M];
+                double a0x = a0[PG_X], a0y = a0[PG_Y], a0m = a0[PG_M], a1x = a1[PG_X], a1y = a1[PG_Y], a1m = a1[PG_M];
+                double b0x = b0[PG_X], b0y = b0[PG_Y], b0m = b0[PG_M], b1x = b1[PG_X], b1y = b1[PG_Y], b1m = b1[PG_M];
+                if (q_cls == 2) {                                  // what came from L2 when the batch was prepared
+                    a0x = q_far[0] ? q_fx[0] : a0x; a0y = q_far[0] ? q_fy[0] : a0y; a0m = q_far[0] ? q_fm[0] : a0m;
+                    a1x = q_far[1] ? q_fx[1] : a1x; a1y = q_far[1] ? q_fy[1] : a1y; a1m = q_far[1] ? q_fm[1] : a1m;
+                    b0x = q_far[2] ? q_fx[2] : b0x; b0y = q_far[2] ? q_fy[2] : b0y; b0m = q_far[2] ? q_fm[2] : b0m;
+                    b1x = q_far[3] ? q_fx[3] : b1x; b1y = q_far[3] ? q_fy[3] : b1y; b1m = q_far[3] ? q_fm[3] : b1m;
+                }
                 const unsigned kk = q_left ? (1u << 4) : (1u << 18);
                 const unsigned self = q_left ? PG_X : PG_Y, cross = q_left ? PG_Y : PG_X;
                 double eg = NI_, em = NI_;
@@ -1135,6 +1192,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
     const unsigned a_tid24 = lds_ring + (unsigned)tid24, a_bpos24 = lds_ring + (unsigned)bpos24;
     const unsigned a_recR = (unsigned)(unsigned long long)(lds_char *)&PM.recR[0], a_recL = (unsigned)(unsigned long long)(lds_char *)&PM.recL[0];
     const unsigned a_table = (unsigned)(unsigned long long)(lds_char *)&PM.table[0];
+    const unsigned a_fdn = (unsigned)(unsigned long long)(lds_char *)&PM.progress[dn];
     const unsigned a_fup = (unsigned)(unsigned long long)(lds_char *)&PM.progress[up], a_fme = (unsigned)(unsigned long long)(lds_char *)&PM.progress[wave];
     const unsigned ni_hi = 0xfff00000u;
     const unsigned a_null = (unsigned)(unsigned long long)(lds_char *)&PM.null_cell[0];
@@ -1145,7 +1203,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                   PST == 3 && PNT == 256, "the class 2 merge of dp_pipe_hot.inc addresses the staging arrays by these strides");
     for (;;) {
 #ifndef PG_NO_HOT_ASM
-        if ((cur.s4 & 15) <= 2) {
+        {
             // ---- consecutive class 0 / 1 / 2 diagonals: hand-scheduled loop (tools/gen_hot_asm.py has the register plan;
             // the C++ step below states the same arithmetic) ----
             // It runs until a diagonal needs anything else -- another class, the end of the wave's
@@ -1161,12 +1219,12 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
 #include "dp_pipe_hot.inc"
                 : [row] "+v"(row), [colx] "+v"(colx), [rowx] "+v"(rowx), [sm] "+v"(smv),
                   [p0] "+v"(PX), [p1] "+v"(PY), [p2] "+v"(PMm), [c0] "+v"(CX), [c1] "+v"(CY), [c2] "+v"(CM),
-                  [d] "+s"(d), [sb] "+s"(sb), [pup] "+s"(p_up), [dptr] "+s"(dptr)
+                  [d] "+s"(d), [sb] "+s"(sb), [pup] "+s"(p_up), [pdn] "+s"(p_dn), [dptr] "+s"(dptr)
                 : [ge] "v"(ge), [go] "v"(go), [ng] "v"(ng), [tng2] "v"(tng2), [tng1] "v"(tng1), [ni] "v"(NI), [nihi] "v"(ni_hi),
                   [tid24] "v"(a_tid24), [bpos24] "v"(a_bpos24), [fup] "v"(a_fup), [fme] "v"(a_fme),
                   [c18] "v"(1u << 18), [nulla] "v"(a_null), [tid] "v"(tid), [ringb] "s"(lds_ring),
                   [asd] "s"(a_asd), [stx] "v"(a_stx), [spxa] "v"(a_spx),
-                  [sleep] "s"(sleep), [okuntil] "s"(ok_until), [pdn] "s"(p_dn), [S] "s"(S),
+                  [sleep] "s"(sleep), [okuntil] "s"(ok_until), [S] "s"(S), [fdn] "v"(a_fdn),
                   [bR] "s"(a_recR), [bL] "s"(a_recL), [bT] "s"(a_table),
                   [sclo] "s"(sc_lo), [schi] "s"(sc_hi), [bplo] "s"(bp_lo), [bphi] "s"(bp_hi)
                 : "memory", "vcc", "scc",
@@ -1183,16 +1241,42 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                   "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
                   "s68", "s69", "s70", "s71", "s72", "s73");
             d = __builtin_amdgcn_readfirstlane(d);
-            if (d != d_in) {
-                // the operand pipeline of diagonal d from the LDS windows, the descriptor from memory
-                cur = psc[d];
-                hstg = d % PST;
-                rLc = PM.recL[row & (PRW - 1)];
-                cR0 = PM.recR[(d - row) & (PRW - 1)];
-                cR1 = PM.recR[(d + 1 - row) & (PRW - 1)];
-                sm = PM.table[((rLc.x & 0xffff) + __umul24(cR0.x & 0xffff, S)) & 255];
-                if ((cur.s4 & 15) > 2 || d >= sleep) { dA = cur; break; }
+            (void)d_in;
+            // the operand pipeline of diagonal d from the LDS windows, the descriptor from memory
+            cur = psc[d];
+            hstg = d % PST;
+            rLc = PM.recL[row & (PRW - 1)];
+            cR0 = PM.recR[(d - row) & (PRW - 1)];
+            cR1 = PM.recR[(d + 1 - row) & (PRW - 1)];
+            sm = PM.table[((rLc.x & 0xffff) + __umul24(cR0.x & 0xffff, S)) & 255];
+            if ((cur.s4 & 15) > 2 || d >= sleep) { dA = cur; break; }
+            // The loop stopped at a diagonal it could run but for a flag: wait here (polls that sleep, spin limits that
+            // end in an error status) for everything diagonal d needs, then go back into it -- the arithmetic below is the
+            // loop's C++ rendering, compiled in with -DPG_NO_HOT_ASM only.
+            {
+                const int lo = cur.x, hi = cur.y;
+                if (d > ok_until) {
+                    int need = hi + 3 < Lx - 1 ? hi + 3 : Lx - 1;
+                    if (rows_ld <= need) rows_ld = POLLX(&PM.loaded[0], need + 1, 1);
+                    int margin = rows_ld >= Lx ? nd : rows_ld - 1 - need;
+                    need = d + 2 - lo < Ly - 1 ? d + 2 - lo : Ly - 1;
+                    if (cols_ld <= need) cols_ld = POLLX(&PM.loaded[1], need + 1, 2);
+                    const int mc = cols_ld >= Ly ? nd : cols_ld - 1 - need;
+                    margin = mc < margin ? mc : margin;
+                    ok_until = d + margin;
+                }
+                if (cur.s7 > p_dn) p_dn = POLLX(&PM.progress[dn], cur.s7, 3);
+                if (d - 1 > p_up && __any(row <= hi + 1)) p_up = POLLX(&PM.progress[up], d - 1, 4);
+                if ((cur.s4 & 15) == 2) {
+                    if (hstg == 0) { if (as0 < d) as0 = POLLX(&PM.assist_done[0], d, 8); }
+                    else if (hstg == 1) { if (as1 < d) as1 = POLLX(&PM.assist_done[1], d, 8); }
+                    else { if (as2 < d) as2 = POLLX(&PM.assist_done[2], d, 8); }
+                }
+                // after an abort (a wait somewhere ran into its spin limit) every wait passes: the wave runs to the end of its
+                // interval on whatever it reads and reports the status when it leaves the kernel
+                if (flag_load(&PM.abort_flag) != 0) { p_up = 0x7ffffff0; p_dn = 0x7ffffff0; }
             }
+            continue;
         }
 #endif
         const int lo = cur.x, hi = cur.y, cls = cur.s4 & 15;

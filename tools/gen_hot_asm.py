@@ -339,12 +339,34 @@ def step(E, k):
     a("s_cbranch_scc1 .Lpg_exit%s" % sfx)                      # not class 0 .. 2
     if EXP == "b":
         a("s_mov_b32 s73, 0")
+    if EXP == "d":
+        a("s_cmp_eq_u32 s73, 2")
+        a("s_cselect_b32 s73, 0, s73")
     a("s_cmp_ge_i32 %[d], %[sleep]")
     a("s_cbranch_scc1 .Lpg_exit%s" % sfx)
     a("s_cmp_gt_i32 %[d], %[okuntil]")
     a("s_cbranch_scc1 .Lpg_exit%s" % sfx)                      # the loader's flags have to be looked at
     a("s_cmp_gt_i32 s%d, %%[pdn]" % s7)
-    a("s_cbranch_scc1 .Lpg_exit%s" % sfx)                      # the downstream wave's flag has to be looked at
+    a("s_cbranch_scc1 .Lpg_dnwait%s" % sfx)                    # the downstream wave's flag has to be looked at
+    a(".Lpg_dnok%s:" % sfx)
+    E.cur = E.ool
+    # ring row reuse: the downstream wave must have completed the last diagonal that reads the row this step overwrites.
+    # Where long edges are about it may lag two diagonals at most: look at its flag here, a few times, before giving up
+    a(".Lpg_dnwait%s:" % sfx)
+    a("s_mov_b32 s72, 48")
+    a(".Lpg_dnretry%s:" % sfx)
+    a("ds_read_b32 v222, %[fdn]")
+    a("s_waitcnt lgkmcnt(0)")
+    a("v_readfirstlane_b32 s68, v222")
+    a("s_max_i32 %[pdn], %[pdn], s68")
+    a("s_cmp_gt_i32 s%d, %%[pdn]" % s7)
+    a("s_cbranch_scc0 .Lpg_dnok%s" % sfx)
+    a("s_sleep 1")
+    a("s_sub_i32 s72, s72, 1")
+    a("s_cmp_lg_u32 s72, 0")
+    a("s_cbranch_scc1 .Lpg_dnretry%s" % sfx)
+    a("s_branch .Lpg_exit%s" % sfx)
+    E.cur = E.L
     a("v_readfirstlane_b32 s68, v223")
     a("s_max_i32 %[pup], %[pup], s68")
     a("s_sub_i32 s69, %[d], 1")
