@@ -1228,6 +1228,8 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                   [bR] "s"(a_recR), [bL] "s"(a_recL), [bT] "s"(a_table),
                   [sclo] "s"(sc_lo), [schi] "s"(sc_hi), [bplo] "s"(bp_lo), [bphi] "s"(bp_hi)
                 : "memory", "vcc", "scc",
+                  "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153",
+                  "v154", "v155", "v156", "v157",
                   "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173",
                   "v174", "v175", "v176", "v177", "v178", "v179",
                   "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250",

@@ -30,6 +30,9 @@ BX, BY, BM = 208, 210, 212
 PXW, PYW, PMW = 214, 215, 216
 U = (192, 194, 196)                      # operand cell: x, y, m
 V = (200, 202, 204)
+W1 = (140, 142, 144)                     # more operand cells of a class 1 step
+W2 = (146, 148, 150)
+W3 = (152, 154, 156)
 RL, CR = 236, 240                        # site records: x, y, z, w (64-bit aligned tuples)
 KL, KR = 244, 245
 LWA, LWS, RWA, RWS = 246, 248, 250, 252
@@ -142,24 +145,49 @@ def class1(E, k):
     # list slots of the previous-site edges in the back-pointers: v221 = lbA (slot << 4), v222 = rbA (slot << 18)
     a("v_cndmask_b32_e64 v221, 0, 16, s[78:79]")
     a("v_cndmask_b32_e64 v222, 0, %[c18], s[80:81]")
-    a("v_or_b32_e32 v%d, v%d, v221" % (PXW, PXW))
-    a("v_or_b32_e32 v%d, v%d, v222" % (PYW, PYW))
-    # the pair of the two previous-site edges, with their weights (the base step's bm left them out)
     c1, c2, c3, m23 = T[0], T[1], T[2], T[3]
-    E.pair_cands(C, LWA, RWA, c1, c2, c3)
-    E.fmax3(BM, PMW, c1, c2, c3, 14, 12, 13, m23)
-    a("v_or3_b32 v%d, v%d, v221, v222" % (PMW, PMW))
-    # ---- the right site's other edge: Y from (row, j-kR), the pair (previous-site left edge, it) from (row-1, j-kR) ----
+    # ---- every operand cell of the blocks below requested in ONE batch (each block only if a lane of the wave needs it):
+    #   right site's other edge: (row, j-kR) -> U, (row-1, j-kR) -> V; left site's: (row-kL, j) -> W1, (row-kL, j-1) -> W2;
+    #   both: (row-kL, j-kR) -> W3.  The weighted pair of the two previous-site edges runs while they are in flight.
     a("s_cmp_eq_u64 s[76:77], 0")
-    a("s_cbranch_scc1 .Lpg_noR%s" % sfx)
+    a("s_cbranch_scc1 .Lpg_rdL%s" % sfx)
     a("v_mul_u32_u24_e32 v217, 0x1800, v%d" % KR)
     E.ring_addr(218, 217, "%[tid24]", "s[76:77]")
     a("v_add_u32_e32 v217, 0x1800, v217")
     E.ring_addr(219, 217, "%[bpos24]", "s[76:77]")
     E.read_cell(U, 218)
     E.read_cell(V, 219)
+    a(".Lpg_rdL%s:" % sfx)
+    a("s_cmp_eq_u64 s[74:75], 0")
+    a("s_cbranch_scc1 .Lpg_rdX%s" % sfx)
+    a("v_sub_u32_e32 v%d, %%[tid], v%d" % (POSL, KL))
+    a("v_and_b32_e32 v%d, 0xff, v%d" % (POSL, POSL))
+    a("v_mad_u32_u24 v%d, v%d, 24, %%[ringb]" % (POSL, POSL))
+    a("v_mul_u32_u24_e32 v217, 0x1800, v%d" % KL)
+    E.ring_addr(218, 217, "v%d" % POSL, "s[74:75]")
+    a("v_add_u32_e32 v219, 0x1800, v217")
+    E.ring_addr(220, 219, "v%d" % POSL, "s[74:75]")
+    E.read_cell(W1, 218)
+    E.read_cell(W2, 220)
+    a("s_cmp_eq_u64 s[82:83], 0")
+    a("s_cbranch_scc1 .Lpg_rdX%s" % sfx)
+    a("v_add_u32_e32 v217, v%d, v%d" % (KL, KR))
+    a("v_mul_u32_u24_e32 v217, 0x1800, v217")
+    E.ring_addr(220, 217, "v%d" % POSL, "s[82:83]")
+    E.read_cell(W3, 220)
+    a(".Lpg_rdX%s:" % sfx)
+    a("v_or_b32_e32 v%d, v%d, v221" % (PXW, PXW))
+    a("v_or_b32_e32 v%d, v%d, v222" % (PYW, PYW))
+    # the pair of the two previous-site edges, with their weights (the base step's bm left them out)
+    E.pair_cands(C, LWA, RWA, c1, c2, c3)
+    E.fmax3(BM, PMW, c1, c2, c3, 14, 12, 13, m23)
+    a("v_or3_b32 v%d, v%d, v221, v222" % (PMW, PMW))
     a("v_cndmask_b32_e64 v220, %[c18], 0, s[80:81]")           # rbS
+    a("v_cndmask_b32_e64 v218, 16, 0, s[78:79]")                # lbS
     a("s_waitcnt lgkmcnt(0)")
+    # ---- the right site's other edge: Y from (row, j-kR), the pair (previous-site left edge, it) from (row-1, j-kR) ----
+    a("s_cmp_eq_u64 s[76:77], 0")
+    a("s_cbranch_scc1 .Lpg_noR%s" % sfx)
     E.gap_cands(U, 1, 0, c1, c2, c3)
     E.fmax3(T[4], 217, c1, c2, c3, 1, 0, 2, m23)
     a("v_or_b32_e32 v217, v217, v220")
@@ -172,34 +200,17 @@ def class1(E, k):
     # ---- the left site's other edge: X from (row-kL, j), the pair (it, previous-site right edge) from (row-kL, j-1) ----
     a("s_cmp_eq_u64 s[74:75], 0")
     a("s_cbranch_scc1 .Lpg_noL%s" % sfx)
-    a("v_sub_u32_e32 v%d, %%[tid], v%d" % (POSL, KL))
-    a("v_and_b32_e32 v%d, 0xff, v%d" % (POSL, POSL))
-    a("v_mad_u32_u24 v%d, v%d, 24, %%[ringb]" % (POSL, POSL))
-    a("v_mul_u32_u24_e32 v217, 0x1800, v%d" % KL)
-    E.ring_addr(218, 217, "v%d" % POSL, "s[74:75]")
-    a("v_add_u32_e32 v219, 0x1800, v217")
-    E.ring_addr(220, 219, "v%d" % POSL, "s[74:75]")
-    E.read_cell(U, 218)
-    E.read_cell(V, 220)
-    a("v_cndmask_b32_e64 v218, 16, 0, s[78:79]")                # lbS
-    a("s_waitcnt lgkmcnt(0)")
-    E.gap_cands(U, 0, 1, c1, c2, c3)
+    E.gap_cands(W1, 0, 1, c1, c2, c3)
     E.fmax3(T[4], 219, c1, c2, c3, 0, 1, 2, m23)
     a("v_or_b32_e32 v219, v219, v218")
     E.take_better(BX, PXW, T[4], 219, "s[78:79]")
-    E.pair_cands(V, LWS, RWA, c1, c2, c3)
+    E.pair_cands(W2, LWS, RWA, c1, c2, c3)
     E.fmax3(T[5], 219, c1, c2, c3, 10, 8, 9, m23)               # m2 (T5), p2 (v219)
     a("v_or3_b32 v219, v219, v218, v222")
     # both sites have another edge: the pair of the two, from (row-kL, j-kR)
     a("s_cmp_eq_u64 s[82:83], 0")
     a("s_cbranch_scc1 .Lpg_noLR%s" % sfx)
-    a("v_add_u32_e32 v217, v%d, v%d" % (KL, KR))
-    a("v_mul_u32_u24_e32 v217, 0x1800, v217")
-    E.ring_addr(220, 217, "v%d" % POSL, "s[82:83]")
-    E.read_cell(U, 220)
-    a("v_cndmask_b32_e64 v220, %[c18], 0, s[80:81]")           # rbS
-    a("s_waitcnt lgkmcnt(0)")
-    E.pair_cands(U, LWS, RWS, c1, c2, c3)
+    E.pair_cands(W3, LWS, RWS, c1, c2, c3)
     E.fmax3(T[4], 217, c1, c2, c3, 2, 0, 1, m23)
     a("v_or3_b32 v217, v217, v218, v220")
     E.take_better(T[5], 219, T[4], 217, "s[80:81]")
@@ -342,6 +353,8 @@ def step(E, k):
     if EXP == "d":
         a("s_cmp_eq_u32 s73, 2")
         a("s_cselect_b32 s73, 0, s73")
+    if EXP == "e":
+        a("s_mov_b32 s73, 0")
     a("s_cmp_ge_i32 %[d], %[sleep]")
     a("s_cbranch_scc1 .Lpg_exit%s" % sfx)
     a("s_cmp_gt_i32 %[d], %[okuntil]")
