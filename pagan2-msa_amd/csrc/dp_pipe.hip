@@ -65,7 +65,10 @@ static_assert(PNA == 3 && PST == 3 && PAGE >= PLAND + 4, "assist wave a stages t
 #define PS_ONLY 0x80000000u      // the site has no edge from the previous site: the staged value IS the state's value
 #define PS_FIRST 0x40000000u     // the staged winner precedes the previous-site edge in the list: it wins a tie
 #define PS_BP 0x3fffffffu
-#define PSPIN_LIMIT (1 << 25)     // ~10 s of polling: far beyond any legitimate wait (a wave sleeping through a long gap)
+#ifndef PG_SPIN_LIMIT_LOG2
+#define PG_SPIN_LIMIT_LOG2 25
+#endif
+#define PSPIN_LIMIT (1 << PG_SPIN_LIMIT_LOG2)     // seconds of polling: far beyond any legitimate wait (a wave sleeping through a long gap)
 
 // site record, word x
 #define PR_SIMPLE 0x10000        // one bwd edge, from the previous site, log-weight 0
@@ -94,6 +97,7 @@ struct PipeSmem {
     int as_list[PNA][64];        // rows of the multi-edge cells of the diagonal an assist wave is working on, compacted
 };
 
+static_assert(sizeof(PipeSmem) <= 160 * 1024, "PipeSmem has to fit the 160 KB of LDS of a gfx950 compute unit");
 unsigned pg_pipe_lds_bytes() { return (unsigned)sizeof(PipeSmem); }
 unsigned pg_pipe_block() { return PBLOCK; }
 
@@ -924,6 +928,7 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
     auto prepare = [&]() {
         q_d = -1;
         while (scan_d < nd) {
+            if (flag_load(&PM.abort_flag) != 0) return;
             const int d = scan_d;
             const pg_i8 cur = psc[d];
             scan_d += PNA * (int)((unsigned)cur.s4 >> 20);          // the host's hop count: straight to this wave's next diagonal with work
@@ -1038,6 +1043,7 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
     prepare();
     while (q_d >= 0) {
         const int d = q_d;
+        if (flag_load(&PM.abort_flag) != 0) break;
         ASTAMP(0);
         // every compute wave has completed d-2 (or sleeps through it); a poll that ran into an abort returns "done" and
         // the wave runs to the end of its list on whatever is in the ring (reads stay inside the arena)
@@ -1274,9 +1280,8 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                     else if (hstg == 1) { if (as1 < d) as1 = POLLX(&PM.assist_done[1], d, 8); }
                     else { if (as2 < d) as2 = POLLX(&PM.assist_done[2], d, 8); }
                 }
-                // after an abort (a wait somewhere ran into its spin limit) every wait passes: the wave runs to the end of its
-                // interval on whatever it reads and reports the status when it leaves the kernel
-                if (flag_load(&PM.abort_flag) != 0) { p_up = 0x7ffffff0; p_dn = 0x7ffffff0; }
+                // after an abort (a wait somewhere ran into its spin limit) the wave leaves: the kernel's loop sees the flag
+                if (flag_load(&PM.abort_flag) != 0) { dA = cur; break; }
             }
             continue;
         }
@@ -1690,7 +1695,7 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
 #endif
         ++d;
         dA = nxt;
-        if ((nxt.s4 & 15) != 4 || d >= sleep) break;
+        if ((nxt.s4 & 15) != 4 || d >= sleep || flag_load(&PM.abort_flag) != 0) break;
         cur = nxt;
     }
     // back to step(): this lane's row for the narrow diagonals, nothing in registers or prefetched; the ring's
@@ -1776,7 +1781,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         flag_store(&PM.arrived[wave], wake - 1);
         flag_store(&PM.progress[wave], wake - 1);
-        if (wake >= nd) break;
+        if (wake >= nd || flag_load(&PM.abort_flag) != 0) break;
 
         cdesc8_p pp = psc + wake;                                  // descriptor last requested
         pg_i8 dA = *pp, dB = dA;                                   // descriptors of this step / the next one (roles alternate)
@@ -2091,6 +2096,9 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
 
         int d = wake;
         while (d < sleep) {
+            // a wait somewhere ran into its spin limit: every wave leaves as fast as it can (what it would compute from here on is
+            // built on operands nobody waited for); the status is reported below
+            if (flag_load(&PM.abort_flag) != 0) { d = nd; break; }
 #ifdef PG_PIPE_STATS
             st_on = (dA.s4 & 15) == PG_STAT_CLASS && __any(row <= dA.y && row >= dA.x);
             st_t = __builtin_readcyclecounter();
