@@ -250,15 +250,63 @@ __device__ __forceinline__ void edge_at(const pg_i4 &rec, int k, int site, int &
     }
 }
 
-// A cell's 24 bytes requested from L2 without waiting; far_wait3 is the wait (and the point after which
-// the compiler may use the registers).
+// Cells from L2, several at once: every load AND the wait sit in ONE asm statement.  (Requesting in one statement and
+// waiting in a later one leaves registers with a load in flight visible to the compiler, which may copy or spill them
+// at a join or under pressure -- the copy reads the old content, and the load lands in a register that holds something
+// else by then.  It showed as a memory fault that came and went with unrelated code.)  A lane that does not want one
+// of the cells passes need = false: it loads the arena's first cell, which is always readable, and keeps what it had.
 typedef double pg_d2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void far_cell_issue(PG_GLOBAL const double *p, pg_d2 &xy, double &m) {
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %2, off offset:16 sc1"
-                 : "=&v"(xy), "=&v"(m) : "v"(p) : "memory");
+struct FarAsk { bool need; long long boff; };                     // byte offset of the cell in the job's score array
+// (one cell: its loads under the lanes that want it; the other lanes keep what the registers hold)
+#define PG_FAR_LD(xy, m_, a, mk) "s_and_b64 exec, %[sv], %[" #mk "]\n\tglobal_load_dwordx4 %[" #xy "], %[" #a "], off sc1\n\t" \
+                                 "global_load_dwordx2 %[" #m_ "], %[" #a "], off offset:16 sc1\n\t"
+__device__ __forceinline__ void far_fetch4(gdouble_w sc, const FarAsk &a0, const FarAsk &a1, const FarAsk &a2, const FarAsk &a3,
+                                           pg_d2 &xy0, double &m0, pg_d2 &xy1, double &m1, pg_d2 &xy2, double &m2, pg_d2 &xy3, double &m3) {
+    const unsigned long long k0 = __builtin_amdgcn_ballot_w64(a0.need), k1 = __builtin_amdgcn_ballot_w64(a1.need);
+    const unsigned long long k2 = __builtin_amdgcn_ballot_w64(a2.need), k3 = __builtin_amdgcn_ballot_w64(a3.need);
+    if ((k0 | k1 | k2 | k3) == 0) return;
+    PG_GLOBAL const char *b = (PG_GLOBAL const char *)sc;
+    PG_GLOBAL const char *p0 = b + a0.boff, *p1 = b + a1.boff, *p2 = b + a2.boff, *p3 = b + a3.boff;
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 PG_FAR_LD(x0, u0, p0, k0) PG_FAR_LD(x1, u1, p1, k1) PG_FAR_LD(x2, u2, p2, k2) PG_FAR_LD(x3, u3, p3, k3)
+                 "s_mov_b64 exec, %[sv]\n\ts_waitcnt vmcnt(0)"
+                 : [x0] "+v"(xy0), [u0] "+v"(m0), [x1] "+v"(xy1), [u1] "+v"(m1), [x2] "+v"(xy2), [u2] "+v"(m2), [x3] "+v"(xy3), [u3] "+v"(m3),
+                   [sv] "=&s"(sv)
+                 : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [k0] "s"(k0), [k1] "s"(k1), [k2] "s"(k2), [k3] "s"(k3)
+                 : "memory");
 }
-__device__ __forceinline__ void far_wait3(pg_d2 &a, double &am, pg_d2 &b, double &bm, pg_d2 &c, double &cm) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(am), "+v"(b), "+v"(bm), "+v"(c), "+v"(cm) : : "memory");
+__device__ __forceinline__ void far_fetch8(gdouble_w sc, const FarAsk (&a)[8], pg_d2 (&xy)[8], double (&m)[8]) {
+    const unsigned long long k0 = __builtin_amdgcn_ballot_w64(a[0].need), k1 = __builtin_amdgcn_ballot_w64(a[1].need);
+    const unsigned long long k2 = __builtin_amdgcn_ballot_w64(a[2].need), k3 = __builtin_amdgcn_ballot_w64(a[3].need);
+    const unsigned long long k4 = __builtin_amdgcn_ballot_w64(a[4].need), k5 = __builtin_amdgcn_ballot_w64(a[5].need);
+    const unsigned long long k6 = __builtin_amdgcn_ballot_w64(a[6].need), k7 = __builtin_amdgcn_ballot_w64(a[7].need);
+    if ((k0 | k1 | k2 | k3 | k4 | k5 | k6 | k7) == 0) return;
+    PG_GLOBAL const char *b = (PG_GLOBAL const char *)sc;
+    PG_GLOBAL const char *p0 = b + a[0].boff, *p1 = b + a[1].boff, *p2 = b + a[2].boff, *p3 = b + a[3].boff;
+    PG_GLOBAL const char *p4 = b + a[4].boff, *p5 = b + a[5].boff, *p6 = b + a[6].boff, *p7 = b + a[7].boff;
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 PG_FAR_LD(x0, u0, p0, k0) PG_FAR_LD(x1, u1, p1, k1) PG_FAR_LD(x2, u2, p2, k2) PG_FAR_LD(x3, u3, p3, k3)
+                 PG_FAR_LD(x4, u4, p4, k4) PG_FAR_LD(x5, u5, p5, k5) PG_FAR_LD(x6, u6, p6, k6) PG_FAR_LD(x7, u7, p7, k7)
+                 "s_mov_b64 exec, %[sv]\n\ts_waitcnt vmcnt(0)"
+                 : [x0] "+v"(xy[0]), [u0] "+v"(m[0]), [x1] "+v"(xy[1]), [u1] "+v"(m[1]), [x2] "+v"(xy[2]), [u2] "+v"(m[2]),
+                   [x3] "+v"(xy[3]), [u3] "+v"(m[3]), [x4] "+v"(xy[4]), [u4] "+v"(m[4]), [x5] "+v"(xy[5]), [u5] "+v"(m[5]),
+                   [x6] "+v"(xy[6]), [u6] "+v"(m[6]), [x7] "+v"(xy[7]), [u7] "+v"(m[7]), [sv] "=&s"(sv)
+                 : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [p4] "v"(p4), [p5] "v"(p5), [p6] "v"(p6), [p7] "v"(p7),
+                   [k0] "s"(k0), [k1] "s"(k1), [k2] "s"(k2), [k3] "s"(k3), [k4] "s"(k4), [k5] "s"(k5), [k6] "s"(k6), [k7] "s"(k7)
+                 : "memory");
+}
+// the L2 address of cell (p, d - age), or "not wanted" when it lies outside the band (the caller keeps -inf)
+__device__ __forceinline__ FarAsk far_ask(cdesc8_p psc, int d, int age, int p) {
+    const int dd = d - age;
+    pg_i4 ds;
+    if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
+    else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
+    FarAsk f;
+    f.need = p >= ds.x && p <= ds.y;
+    f.boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p - ds.x);
+    return f;
 }
 
 // Up to three earlier cells at once (the X, Y and M operands of one (left edge, right edge) item), each `age`
@@ -273,8 +321,9 @@ __device__ __forceinline__ void old_cells3(gdouble_w sc, cdesc8_p psc, int d, in
     const double NI = neg_inf();
     pg_d2 xy0 = {NI, NI}, xy1 = {NI, NI}, xy2 = {NI, NI};
     double m0 = NI, m1 = NI, m2 = NI;
-    auto fetch = [&](const CellAsk &a, pg_d2 &xy, double &m) {
-        if (!a.need) return;
+    auto fetch = [&](const CellAsk &a, pg_d2 &xy, double &m) -> FarAsk {
+        FarAsk f = {false, 0};
+        if (!a.need) return f;
         if (!FAR || (a.age < PAGE && ((resmask >> a.age) & 1u))) {
             int s = slot - a.age;
             s += s < 0 ? PRK : 0;
@@ -282,18 +331,17 @@ __device__ __forceinline__ void old_cells3(gdouble_w sc, cdesc8_p psc, int d, in
             xy.y = PM.sc[s][a.p & (PNT - 1)][PG_Y];
             m = PM.sc[s][a.p & (PNT - 1)][PG_M];
         } else {
-            const int dd = d - a.age;
-            pg_i4 ds;
-            if (a.age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
-            else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
-            if (a.p >= ds.x && a.p <= ds.y) {
-                const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (a.p - ds.x);
-                far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc + boff), xy, m);
-            }
+            f = far_ask(psc, d, a.age, a.p);
         }
+        return f;
     };
-    fetch(a0, xy0, m0); fetch(a1, xy1, m1); fetch(a2, xy2, m2);
-    if (FAR) far_wait3(xy0, m0, xy1, m1, xy2, m2);
+    const FarAsk f0 = fetch(a0, xy0, m0), f1 = fetch(a1, xy1, m1), f2 = fetch(a2, xy2, m2);
+    if (FAR) {
+        const FarAsk none = {false, 0};
+        pg_d2 dq = {NI, NI};
+        double dm = NI;
+        far_fetch4(sc, f0, f1, f2, none, xy0, m0, xy1, m1, xy2, m2, dq, dm);
+    }
     v[0][0] = xy0.x; v[0][1] = xy0.y; v[0][2] = m0;
     v[1][0] = xy1.x; v[1][1] = xy1.y; v[1][2] = m1;
     v[2][0] = xy2.x; v[2][1] = xy2.y; v[2][2] = m2;
@@ -407,22 +455,17 @@ __device__ __forceinline__ void multi2_cell(gdouble_w sc, cdesc8_p psc, int d, u
         // some cells have left the ring: those are requested from L2 together and waited for once
         pg_d2 q[8];
         double qm[8];
+        FarAsk fa[8];
         auto cell = [&](int k, int age, int p, bool present) {
             q[k].x = NI; q[k].y = NI; qm[k] = NI;
+            fa[k].need = false; fa[k].boff = 0;
             if (!present) return;
             if (age < PAGE && ((resmask >> age) & 1u)) {
                 int s = slot - age;
                 s += s < 0 ? PRK : 0;
                 q[k].x = PM.sc[s][p & (PNT - 1)][PG_X]; q[k].y = PM.sc[s][p & (PNT - 1)][PG_Y]; qm[k] = PM.sc[s][p & (PNT - 1)][PG_M];
             } else {
-                const int dd = d - age;
-                pg_i4 ds;
-                if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
-                else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
-                if (p >= ds.x && p <= ds.y) {
-                    const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p - ds.x);
-                    far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc + boff), q[k], qm[k]);
-                }
+                fa[k] = far_ask(psc, d, age, p);
             }
         };
         cell(0, dL0, row - dL0, true);
@@ -433,9 +476,7 @@ __device__ __forceinline__ void multi2_cell(gdouble_w sc, cdesc8_p psc, int d, u
         cell(5, dL0 + dR1, row - dL0, r1);
         cell(6, dL1 + dR0, row - dL1, l1);
         cell(7, dL1 + dR1, row - dL1, l1 && r1);
-        far_wait3(q[0], qm[0], q[1], qm[1], q[2], qm[2]);
-        far_wait3(q[3], qm[3], q[4], qm[4], q[5], qm[5]);
-        { pg_d2 dq = {NI, NI}; double dm = NI; far_wait3(q[6], qm[6], q[7], qm[7], dq, dm); }
+        far_fetch8(sc, fa, q, qm);
         xa_x = q[0].x; xa_y = q[0].y; xa_m = qm[0];  xb_x = q[1].x; xb_y = q[1].y; xb_m = qm[1];
         ya_x = q[2].x; ya_y = q[2].y; ya_m = qm[2];  yb_x = q[3].x; yb_y = q[3].y; yb_m = qm[3];
         m00x = q[4].x; m00y = q[4].y; m00m = qm[4];  m01x = q[5].x; m01y = q[5].y; m01m = qm[5];
@@ -593,22 +634,17 @@ __device__ __forceinline__ void assist2_cell(gdouble_w sc, cdesc8_p psc, int d, 
     } else {
         pg_d2 q[8];
         double qm[8];
+        FarAsk fa[8];
         auto cell = [&](int k, int age, int p, bool present) {
             q[k].x = NI; q[k].y = NI; qm[k] = NI;
+            fa[k].need = false; fa[k].boff = 0;
             if (!present) return;
             if (age < PAGE && ((resmask >> age) & 1u)) {
                 int s_ = slot - age;
                 s_ += s_ < 0 ? PRK : 0;
                 q[k].x = PM.sc[s_][p & (PNT - 1)][PG_X]; q[k].y = PM.sc[s_][p & (PNT - 1)][PG_Y]; qm[k] = PM.sc[s_][p & (PNT - 1)][PG_M];
             } else {
-                const int dd = d - age;
-                pg_i4 ds;
-                if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
-                else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
-                if (p >= ds.x && p <= ds.y) {
-                    const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p - ds.x);
-                    far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc + boff), q[k], qm[k]);
-                }
+                fa[k] = far_ask(psc, d, age, p);
             }
         };
         cell(0, dL0, row - dL0, xa_on);
@@ -619,9 +655,7 @@ __device__ __forceinline__ void assist2_cell(gdouble_w sc, cdesc8_p psc, int d, 
         cell(5, dL0 + dR1, row - dL0, r1);
         cell(6, dL1 + dR0, row - dL1, l1);
         cell(7, dL1 + dR1, row - dL1, l1 && r1);
-        far_wait3(q[0], qm[0], q[1], qm[1], q[2], qm[2]);
-        far_wait3(q[3], qm[3], q[4], qm[4], q[5], qm[5]);
-        { pg_d2 dq = {NI, NI}; double dm = NI; far_wait3(q[6], qm[6], q[7], qm[7], dq, dm); }
+        far_fetch8(sc, fa, q, qm);
         xa_x = q[0].x; xa_y = q[0].y; xa_m = qm[0];  xb_x = q[1].x; xb_y = q[1].y; xb_m = qm[1];
         ya_x = q[2].x; ya_y = q[2].y; ya_m = qm[2];  yb_x = q[3].x; yb_y = q[3].y; yb_m = qm[3];
         m00x = q[4].x; m00y = q[4].y; m00m = qm[4];  m01x = q[5].x; m01y = q[5].y; m01m = qm[5];
@@ -709,24 +743,21 @@ __device__ __forceinline__ void assist1_cell(gdouble_w sc, cdesc8_p psc, int d, 
         cell(d1 + 1, mb1, has1, b1x, b1y, b1m);
         if (THREE) { cell(d2, ga2, g2, a2x, a2y, a2m); cell(d2 + 1, mb2, has2, b2x, b2y, b2m); }
     } else {
-        pg_d2 q[6];
-        double qm[6];
+        pg_d2 q[8];
+        double qm[8];
+        FarAsk fa[8];
+        q[6].x = NI; q[6].y = NI; qm[6] = NI; q[7] = q[6]; qm[7] = NI;
+        fa[6].need = false; fa[6].boff = 0; fa[7] = fa[6];
         auto cell = [&](int k, int age, int p, bool present) {
             q[k].x = NI; q[k].y = NI; qm[k] = NI;
+            fa[k].need = false; fa[k].boff = 0;
             if (!present) return;
             if (age < PAGE && ((resmask >> age) & 1u)) {
                 int s_ = slot - age;
                 s_ += s_ < 0 ? PRK : 0;
                 q[k].x = PM.sc[s_][p & (PNT - 1)][PG_X]; q[k].y = PM.sc[s_][p & (PNT - 1)][PG_Y]; qm[k] = PM.sc[s_][p & (PNT - 1)][PG_M];
             } else {
-                const int dd = d - age;
-                pg_i4 ds;
-                if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
-                else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
-                if (p >= ds.x && p <= ds.y) {
-                    const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p - ds.x);
-                    far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc + boff), q[k], qm[k]);
-                }
+                fa[k] = far_ask(psc, d, age, p);
             }
         };
         cell(0, d0, ga0, g0);
@@ -735,8 +766,7 @@ __device__ __forceinline__ void assist1_cell(gdouble_w sc, cdesc8_p psc, int d, 
         cell(3, d1 + 1, mb1, has1);
         cell(4, d2, ga2, g2);
         cell(5, d2 + 1, mb2, has2);
-        far_wait3(q[0], qm[0], q[1], qm[1], q[2], qm[2]);
-        far_wait3(q[3], qm[3], q[4], qm[4], q[5], qm[5]);
+        far_fetch8(sc, fa, q, qm);
         a0x = q[0].x; a0y = q[0].y; a0m = qm[0];  a1x = q[1].x; a1y = q[1].y; a1m = qm[1];
         b0x = q[2].x; b0y = q[2].y; b0m = qm[2];  b1x = q[3].x; b1y = q[3].y; b1m = qm[3];
         a2x = q[4].x; a2y = q[4].y; a2m = qm[4];  b2x = q[5].x; b2y = q[5].y; b2m = qm[5];
@@ -1008,22 +1038,14 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
                         if (pw3 < d - PAGE + PLAND) pw3 = POLL(&PM.progress[3], d - PAGE + PLAND, 9);
                         pg_d2 fxy[4];
                         double fm_[4];
+                        FarAsk fa[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             fxy[k].x = NI_; fxy[k].y = NI_; fm_[k] = NI_;
-                            if (q_far[k]) {
-                                const int dd = d - f_age[k];
-                                pg_i4 ds;
-                                if (f_age[k] <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
-                                else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
-                                if (f_p[k] >= ds.x && f_p[k] <= ds.y) {
-                                    const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (f_p[k] - ds.x);
-                                    far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc_out + boff), fxy[k], fm_[k]);
-                                }
-                            }
+                            fa[k].need = false; fa[k].boff = 0;
+                            if (q_far[k]) fa[k] = far_ask(psc, d, f_age[k], f_p[k]);
                         }
-                        far_wait3(fxy[0], fm_[0], fxy[1], fm_[1], fxy[2], fm_[2]);
-                        { pg_d2 dq = {NI_, NI_}; double dm = NI_; far_wait3(fxy[3], fm_[3], dq, dm, dq, dm); }
+                        far_fetch4(sc_out, fa[0], fa[1], fa[2], fa[3], fxy[0], fm_[0], fxy[1], fm_[1], fxy[2], fm_[2], fxy[3], fm_[3]);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) { q_fx[k] = fxy[k].x; q_fy[k] = fxy[k].y; q_fm[k] = fm_[k]; }
                     }
@@ -1511,28 +1533,20 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
         const int wsb = (d % PWK) * PWROW_BYTES;
         const long long soff = ((long long)cur.w << 32) | (unsigned)cur.z;
         PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff, *brow = (PG_GLOBAL char *)bp_out + (soff >> 1);
-        // one operand cell (p, d - age): requested from L2 (returns true: the caller waits) or read from the wide ring;
-        // -inf outside the band
-        auto wcell = [&](bool need, int age, int p_, pg_d2 &xy, double &m) -> bool {
+        // one operand cell (p, d - age): read from the wide ring, or -- not there -- what to ask L2 for (the caller fetches
+        // all of a step's requests in one statement); -inf outside the band
+        auto wcell = [&](bool need, int age, int p_, pg_d2 &xy, double &m) -> FarAsk {
+            FarAsk f = {false, 0};
             xy.x = NIw; xy.y = NIw; m = NIw;
-            if (!need) return false;
+            if (!need) return f;
             if (age <= amax) {
                 int rb = wsb - age * PWROW_BYTES;
                 rb += rb < 0 ? PWK * PWROW_BYTES : 0;
                 const double *c = (const double *)((const char *)&PM.sc[0][0][0] + rb + (p_ & (PWPOS - 1)) * 24);
                 xy.x = c[PG_X]; xy.y = c[PG_Y]; m = c[PG_M];
-                return false;
+                return f;
             }
-            const int dd = d - age;
-            pg_i4 ds;
-            if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
-            else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
-            if (p_ >= ds.x && p_ <= ds.y) {
-                const long long boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p_ - ds.x);
-                far_cell_issue((gdouble_w)((PG_GLOBAL char *)sc_out + boff), xy, m);
-                return true;
-            }
-            return false;
+            return far_ask(psc, d, age, p_);
         };
         // Both rows of the lane in phases, so that a step pays at most ONE L2 round trip for its batched cells: request /
         // read every operand, wait once (only if some lane asked L2: a wait also covers the wave's stores in flight),
@@ -1543,7 +1557,7 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
         double o_m[2][8];
         bool l2q[2], r2q[2], lSq[2], rSq[2];
         int kLq[2], kRq[2];
-        bool asked = false;
+        FarAsk o_f[2][8];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int r = lo + ((tid - lo) & (PNT - 1)) + PNT * q, j = d - r;
@@ -1551,6 +1565,8 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             l2q[q] = r2q[q] = lSq[q] = rSq[q] = false;
             kLq[q] = kRq[q] = 0;
             gl[q] = pg_i4{0, 0, 0, 0}; gr[q] = pg_i4{0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { o_f[q][t].need = false; o_f[q][t].boff = 0; }
             if (!__any(r <= hi)) continue;                      // none of the wave's lanes has a (second) row on this diagonal
             if (r <= hi) {
                 gl[q] = PM.recL[r & (PRW - 1)]; gr[q] = PM.recR[j & (PRW - 1)];
@@ -1580,32 +1596,26 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             };
             // one operand of the wave's batched cells: nothing if no lane has it, a plain LDS read while every lane's lies in
             // the wide ring, the L2-or-ring path otherwise
-            auto fetch = [&](bool need, int age, int p_, pg_d2 &xy, double &m) {
-                if (!__any(need)) return;
-                if (!__any(need && age > amax)) rd(need, age, p_, xy, m);
-                else asked |= wcell(need, age, p_, xy, m);          // (-inf for the lanes without it)
+            auto fetch = [&](int t, bool need, int age, int p_) {
+                if (!__any(need)) { o_xy[q][t].x = NIw; o_xy[q][t].y = NIw; o_m[q][t] = NIw; return; }
+                if (!__any(need && age > amax)) rd(need, age, p_, o_xy[q][t], o_m[q][t]);
+                else o_f[q][t] = wcell(need, age, p_, o_xy[q][t], o_m[q][t]);          // (-inf for the lanes without it)
             };
-            fetch(b1, 1, r - 1, o_xy[q][0], o_m[q][0]);
-            fetch(b1, 1, r, o_xy[q][1], o_m[q][1]);
-            fetch(b1, 2, r - 1, o_xy[q][2], o_m[q][2]);
-            fetch(b1 && l2, kL, r - kL, o_xy[q][3], o_m[q][3]);
-            fetch(b1 && l2, kL + 1, r - kL, o_xy[q][4], o_m[q][4]);
-            fetch(b1 && r2, kR, r, o_xy[q][5], o_m[q][5]);
-            fetch(b1 && r2, kR + 1, r - 1, o_xy[q][6], o_m[q][6]);
-            fetch(b1 && l2 && r2, kL + kR, r - kL, o_xy[q][7], o_m[q][7]);
+            fetch(0, b1, 1, r - 1);
+            fetch(1, b1, 1, r);
+            fetch(2, b1, 2, r - 1);
+            fetch(3, b1 && l2, kL, r - kL);
+            fetch(4, b1 && l2, kL + 1, r - kL);
+            fetch(5, b1 && r2, kR, r);
+            fetch(6, b1 && r2, kR + 1, r - 1);
+            fetch(7, b1 && l2 && r2, kL + kR, r - kL);
         }
 #ifdef PG_PIPE_STATS
         const long long st_t2 = __builtin_readcyclecounter();
 #endif
-        if (__any(asked)) {
-            // one wait; the empty statements keep every possibly-requested register below it
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                far_wait3(o_xy[q][0], o_m[q][0], o_xy[q][1], o_m[q][1], o_xy[q][2], o_m[q][2]);
-                far_wait3(o_xy[q][3], o_m[q][3], o_xy[q][4], o_m[q][4], o_xy[q][5], o_m[q][5]);
-                { pg_d2 dq = {NIw, NIw}; double dm = NIw; far_wait3(o_xy[q][6], o_m[q][6], o_xy[q][7], o_m[q][7], dq, dm); }
-            }
-        }
+        // what the wave asked L2 for, both rows: one statement per row, requests and wait (it does nothing if no lane asked)
+        far_fetch8(sc_out, o_f[0], o_xy[0], o_m[0]);
+        far_fetch8(sc_out, o_f[1], o_xy[1], o_m[1]);
 #ifdef PG_PIPE_STATS
         const long long st_t3 = __builtin_readcyclecounter();
 #endif
@@ -1660,9 +1670,11 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
                 cell_any(J, r, j, r > 0 ? nl : 0, j > 0 ? nr : 0, smv, no_terminal_edges, reduced_terminal,
                          [&](int p_, int q_, double &xs, double &ys, double &ms) {
                              pg_d2 xy; double m_;
-                             if (wcell(p_ >= 0 && q_ >= 0, d - (p_ + q_), p_, xy, m_)) {
-                                 pg_d2 e1 = {NIw, NIw}, e2 = {NIw, NIw}; double m1 = NIw, m2 = NIw;
-                                 far_wait3(xy, m_, e1, m1, e2, m2);
+                             const FarAsk f = wcell(p_ >= 0 && q_ >= 0, d - (p_ + q_), p_, xy, m_);
+                             {
+                                 const FarAsk none = {false, 0};
+                                 pg_d2 e1 = {NIw, NIw}, e2 = {NIw, NIw}, e3 = {NIw, NIw}; double m1 = NIw, m2 = NIw, m3 = NIw;
+                                 far_fetch4(sc_out, f, none, none, none, xy, m_, e1, m1, e2, m2, e3, m3);
                              }
                              xs = xy.x; ys = xy.y; ms = m_;
                          },
@@ -2016,14 +2028,13 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
                         const bool inA = pa >= p1.x && pa <= p1.y, inB = r <= p1.y, inC = pa >= p2.x && pa <= p2.y;
                         const int ca_ = pa < p1.x ? p1.x : (pa > p1.y ? p1.y : pa), cb_ = r > p1.y ? p1.y : r;
                         const int cc_ = pa < p2.x ? p2.x : (pa > p2.y ? p2.y : pa);
-                        pg_d2 axy, bxy, cxy;
-                        double am, bmm, cm;
-                        far_cell_issue((gdouble_w)(s1 + 24u * (unsigned)(ca_ - p1.x)), axy, am);
-                        far_cell_issue((gdouble_w)(s1 + 24u * (unsigned)(cb_ - p1.x)), bxy, bmm);
-                        far_cell_issue((gdouble_w)(s2 + 24u * (unsigned)(cc_ - p2.x)), cxy, cm);
+                        pg_d2 axy = {NI, NI}, bxy = {NI, NI}, cxy = {NI, NI}, dxy = {NI, NI};
+                        double am = NI, bmm = NI, cm = NI, dmm = NI;
+                        const FarAsk fa_ = {true, off1 + 24ll * (ca_ - p1.x)}, fb_ = {true, off1 + 24ll * (cb_ - p1.x)};
+                        const FarAsk fc_ = {true, off2 + 24ll * (cc_ - p2.x)}, fn_ = {false, 0};
                         const int ti = (gl.x & 0xffff) + (gr.x & 0xffff) * S;
                         const float sm = TAB_LDS ? PM.table[ti & 255] : 0.0f;
-                        far_wait3(axy, am, bxy, bmm, cxy, cm);
+                        far_fetch4(sc_out, fa_, fb_, fc_, fn_, axy, am, bxy, bmm, cxy, cm, dxy, dmm);
                         const float smv = TAB_LDS ? sm : far_f32(table + ti);
                         const double tM = tng2 + (double)smv, tX = tng1 + (double)smv;
                         const double ax = inA ? axy.x : NI, ay = inA ? axy.y : NI, amv = inA ? am : NI;
