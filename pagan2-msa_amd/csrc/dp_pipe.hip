@@ -177,15 +177,31 @@ __device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_
     int *es = LEFT ? PM.esL : PM.esR;
     float *ew = LEFT ? PM.ewL : PM.ewR;
     const int r = first + lane;
+    // two round trips for the usual chunk: offsets and states, then the sites' first two edges together with the chunk's
+    // edge list for the LDS window; a third (and on) only where a site has more than two edges
+    int b = 0, en = 0, w = 0;
+    if (r < n) { b = off[r]; en = off[r + 1]; w = st[r] & 0xffff; }
+    const int ne = en - b;
+    const int rend = first + 64 < n ? first + 64 : n;
+    const int e0 = __builtin_amdgcn_readfirstlane(b), e1 = __builtin_amdgcn_readlane(en, rend - 1 - first);
+    int d0 = 0, d1 = 0;
+    float w0 = 0.0f, w1 = 0.0f;
+    if (ne >= 1) { d0 = r - src[b]; w0 = lw[b]; }
+    if (ne >= 2) { d1 = r - src[b + 1]; w1 = lw[b + 1]; }
+    for (int e = e0 + lane; e < e1; e += 128) {
+        const bool two = e + 64 < e1;
+        const int s0 = src[e];
+        const float x0 = lw[e];
+        int s1 = 0;
+        float x1 = 0.0f;
+        if (two) { s1 = src[e + 64]; x1 = lw[e + 64]; }
+        es[e & (PEC - 1)] = s0; ew[e & (PEC - 1)] = x0;
+        if (two) { es[(e + 64) & (PEC - 1)] = s1; ew[(e + 64) & (PEC - 1)] = x1; }
+    }
     if (r < n) {
-        const int b = off[r], en = off[r + 1], ne = en - b;
-        int w = st[r] & 0xffff;
-        int d0 = 0, d1 = 0, span = 0;
-        float w0 = 0.0f, w1 = 0.0f;
-        if (ne >= 1) { d0 = r - src[b]; w0 = lw[b]; }
-        if (ne >= 2) { d1 = r - src[b + 1]; w1 = lw[b + 1]; }
+        int span = d0 > d1 ? d0 : d1;
+        for (int e = b + 2; e < en && e < b + 16; ++e) { const int sp = r - src[e]; span = sp > span ? sp : span; }
         if (r > 0 && ne == 1 && d0 == 1 && w0 == 0.0f) w |= PR_SIMPLE;
-        for (int e = b; e < en && e < b + 16; ++e) { const int sp = r - src[e]; span = sp > span ? sp : span; }
         if (ne > 16 || span > 255) span = 255;
         w |= (ne < 127 ? ne : 127) << PR_NE_SHIFT;
         w |= span << PR_SPAN_SHIFT;
@@ -195,11 +211,13 @@ __device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_
         rec[r & (PRW - 1)] = v;
         eb[r & (PRW - 1)] = b;
     }
-    const int rend = first + 64 < n ? first + 64 : n;
-    const int e0 = off[first], e1 = off[rend];
-    for (int e = e0 + lane; e < e1; e += 64) { es[e & (PEC - 1)] = src[e]; ew[e & (PEC - 1)] = lw[e]; }
 }
 
+// The site-record windows are filled as far ahead as they allow -- a record may replace the one PRW sites before it once
+// the slowest wave's diagonal has left that site behind (a band's first row and first column never fall) -- and at least as
+// far as the diagonal PLOOK ahead needs; the descriptor window follows PLOOK diagonals ahead.  One chunk of rows and one of
+// columns per round, each published as it lands.
+#define PREC_BACK 72              // 64 (a chunk) + 8: the records up to 8 sites before the slowest diagonal's first stay
 __device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lane) {
     int rows = 0, cols = 0, diags = 0;
     for (;;) {
@@ -209,31 +227,41 @@ __device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lan
         const int dcur = pmin + 1;                                 // the slowest wave may be computing this one
         if (dcur >= J.nd) return;
         const int da = dcur + PLOOK < J.nd - 1 ? dcur + PLOOK : J.nd - 1;
-        const pg_i8 ds = psc[da];
+        const pg_i8 ds = psc[da], dc = psc[dcur];
         int want_rows = ds.y + 5, want_cols = da - ds.x + 4;       // rows <= hi+4, columns <= jmax+3 of diagonal da
+        if (dc.y >= dc.x) {
+            const int far_rows = dc.x + PRW - PREC_BACK, far_cols = dcur - dc.y + PRW - PREC_BACK;
+            want_rows = want_rows > far_rows ? want_rows : far_rows;
+            want_cols = want_cols > far_cols ? want_cols : far_cols;
+        }
         want_rows = want_rows < J.Lx ? want_rows : J.Lx;
         want_cols = want_cols < J.Ly ? want_cols : J.Ly;
         bool any = false;
         // descriptors of the diagonals up to da: what a far read needs to find an old cell
         // (entries older than dcur - PDR + PLOOK are overwritten; readers look back PDR_REACH at most)
-        while (diags <= da) {
-            const int t = diags + lane;
-            if (t <= da) {
-                const pg_i4 v = *((PG_GLOBAL const pg_i4 *)psc + 2 * t);
-                PM.dring[t & (PDR - 1)] = v;
+        if (diags <= da) {
+            while (diags <= da) {
+                const int t = diags + lane;
+                if (t <= da) {
+                    const pg_i4 v = *((PG_GLOBAL const pg_i4 *)psc + 2 * t);
+                    PM.dring[t & (PDR - 1)] = v;
+                }
+                diags = diags + 64 < da + 1 ? diags + 64 : da + 1;
             }
-            diags = diags + 64 < da + 1 ? diags + 64 : da + 1;
+            flag_store(&PM.loaded[2], diags);
             any = true;
         }
-        while (rows < want_rows) { load_rec_chunk<true>(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL); rows += 64; any = true; }
-        while (cols < want_cols) { load_rec_chunk<false>(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR); cols += 64; any = true; }
-        if (any) {
+        if (rows < want_rows) {
+            load_rec_chunk<true>(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL);
+            rows += 64; any = true;
             flag_store(&PM.loaded[0], rows);
-            flag_store(&PM.loaded[1], cols);
-            flag_store(&PM.loaded[2], diags);
-        } else {
-            __builtin_amdgcn_s_sleep(8);
         }
+        if (cols < want_cols) {
+            load_rec_chunk<false>(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR);
+            cols += 64; any = true;
+            flag_store(&PM.loaded[1], cols);
+        }
+        if (!any) __builtin_amdgcn_s_sleep(8);
     }
 }
 
