@@ -21,6 +21,7 @@
 #include <new>
 #include <type_traits>
 #include <vector>
+#include <unordered_map>
 
 #include "../../include/pagan_dp.h"
 #include "dp_device.h"
@@ -30,6 +31,7 @@ template <int BLOCK> __global__ void pg_fill_wavefront(const PgDevJob *jobs, con
 template <bool TAB_LDS> __global__ void pg_fill_ring(const PgDevJob *jobs, const int *which, unsigned flags);
 template <bool TAB_LDS> __global__ void pg_fill_pipe(const PgDevJob *jobs, const int *which, unsigned flags);
 __global__ void pg_fill_tiles(const PgDevJob *jobs, const int *tiles, unsigned flags);
+__global__ void pg_fill_tiles_flow(const PgDevJob *jobs, const int *tiles, int n_tiles, int n_diag, int *flow, unsigned flags);
 __global__ void pg_end_corner(const PgDevJob *jobs);
 __global__ void pg_trace_spec(const PgDevJob *jobs);
 __global__ void pg_trace_compose(const PgDevJob *jobs);
@@ -360,8 +362,12 @@ struct pagan_batch {
     PgDevJob *d_jobs = nullptr;
     int *d_which = nullptr;      // [n]: ring-kernel jobs first, then the ones of the HBM wavefront kernel
     int n_ring = 0, n_wide = 0;
-    int *d_tiles = nullptr;      // dp_tiles.hip: {job, tile row, tile column, 0} of all tiled jobs, ordered by row + column
-    std::vector<int> tile_off;   // first tile of launch t (tile_off.back() = total)
+    int *d_tiles = nullptr;      // dp_tiles.hip: {job, tile row, tile column, position of the tile above} of all tiled jobs, ordered by
+                                 // row + column; then the positions of the tiles to the left; then tile_off (pg_fill_tiles_flow)
+    int *d_flow = nullptr;       // pg_fill_tiles_flow's queue head, finished tiles per diagonal, done flags (zeroed per launch)
+    size_t flow_ints = 0;
+    bool tiles_flow = true;      // one persistent launch (default) or one launch per tile anti-diagonal (PAGAN_DP_TILES=launches)
+    std::vector<int> tile_off;   // first tile of tile anti-diagonal t (tile_off.back() = total)
     hipStream_t stream2 = nullptr;   // the tile launches, when the batch also has jobs of the other kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_ring_small = 0;        // ring jobs whose model table fits the LDS cache (listed first)
@@ -538,9 +544,15 @@ int launch_fill(pagan_batch *b) {
     if (b->tile_off.size() > 1) {
         static std::atomic<bool> tiles_set_dev[64];
         std::atomic<bool> &tiles_set = tiles_set_dev[b->device & 63];
+        static std::atomic<int> n_cu_dev[64];
         if (!tiles_set.load()) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_tiles),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_tiles_lds_bytes()));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_tiles_flow),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_tiles_lds_bytes()));
+            int n_cu = 0;
+            HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, b->device));
+            n_cu_dev[b->device & 63].store(n_cu > 0 ? n_cu : 256);
             tiles_set.store(true);
         }
         // one launch per tile anti-diagonal, all tiled jobs of the batch together; beside the other kernels
@@ -550,11 +562,19 @@ int launch_fill(pagan_batch *b) {
             HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
             st = b->stream2;
         }
-        for (size_t t = 0; t + 1 < b->tile_off.size(); ++t) {
-            const int cnt = b->tile_off[t + 1] - b->tile_off[t];
-            if (cnt > 0)
-                hipLaunchKernelGGL(pg_fill_tiles, dim3(cnt), dim3(64), pg_tiles_lds_bytes(), st, b->d_jobs,
-                                   b->d_tiles + 4 * (size_t)b->tile_off[t], b->flags);
+        if (b->tiles_flow) {
+            // one persistent wave per compute unit (a tile fills the LDS) drains the batch's tiles in dependency order
+            const int n_tiles = b->tile_off.back(), n_diag = (int)b->tile_off.size() - 1;
+            HIP_TRY(hipMemsetAsync(b->d_flow, 0, sizeof(int) * b->flow_ints, st));
+            hipLaunchKernelGGL(pg_fill_tiles_flow, dim3(std::min(n_tiles, n_cu_dev[b->device & 63].load())), dim3(64), pg_tiles_lds_bytes(),
+                               st, b->d_jobs, b->d_tiles, n_tiles, n_diag, b->d_flow, b->flags);
+        } else {
+            for (size_t t = 0; t + 1 < b->tile_off.size(); ++t) {
+                const int cnt = b->tile_off[t + 1] - b->tile_off[t];
+                if (cnt > 0)
+                    hipLaunchKernelGGL(pg_fill_tiles, dim3(cnt), dim3(64), pg_tiles_lds_bytes(), st, b->d_jobs,
+                                       b->d_tiles + 4 * (size_t)b->tile_off[t], b->flags);
+            }
         }
     }
     if (b->n_ring > 0) {
@@ -866,15 +886,32 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             for (size_t q = 0; q < tl.size(); q += 2) ++b->tile_off[tl[q] + tl[q + 1] + 1];
         }
         for (int t = 0; t < T; ++t) b->tile_off[t + 1] += b->tile_off[t];
-        tile_list.assign(4 * (size_t)b->tile_off[T] + 4, 0);
+        const size_t N = (size_t)b->tile_off[T];
+        tile_list.assign(4 * N + 4 + N + (size_t)T + 1, 0);
         std::vector<int> cur(b->tile_off.begin(), b->tile_off.end() - 1);
+        std::unordered_map<uint64_t, int> where;               // (job, tile row, tile column) -> position in the list
+        where.reserve(2 * N);
+        auto key = [](int k, int a, int bb) { return ((uint64_t)(uint32_t)k << 40) | ((uint64_t)(uint32_t)a << 20) | (uint64_t)(uint32_t)bb; };
         for (int k : which_tiled) {
             const std::vector<int> &tl = b->jobs[k].tiles;
             for (size_t q = 0; q < tl.size(); q += 2) {
-                const size_t at = 4 * (size_t)cur[tl[q] + tl[q + 1]]++;
+                const int pos = cur[tl[q] + tl[q + 1]]++;
+                const size_t at = 4 * (size_t)pos;
                 tile_list[at] = k; tile_list[at + 1] = tl[q]; tile_list[at + 2] = tl[q + 1];
+                where[key(k, tl[q], tl[q + 1])] = pos;
             }
         }
+        // pg_fill_tiles_flow: the tiles above and to the left (list positions, -1: not in the band), the diagonals' offsets
+        for (size_t pos = 0; pos < N; ++pos) {
+            const int k = tile_list[4 * pos], a = tile_list[4 * pos + 1], bb = tile_list[4 * pos + 2];
+            auto up = a > 0 ? where.find(key(k, a - 1, bb)) : where.end();
+            auto lf = bb > 0 ? where.find(key(k, a, bb - 1)) : where.end();
+            tile_list[4 * pos + 3] = up == where.end() ? -1 : up->second;
+            tile_list[4 * N + 4 + pos] = lf == where.end() ? -1 : lf->second;
+        }
+        for (int t = 0; t <= T; ++t) tile_list[4 * N + 4 + N + (size_t)t] = b->tile_off[t];
+        b->flow_ints = 1 + (size_t)T + N;
+        if (const char *f = std::getenv("PAGAN_DP_TILES")) b->tiles_flow = std::strcmp(f, "launches") != 0;   // A/B switch
     }
     b->n_ring_small = (int)which_ring.size();
     which_ring.insert(which_ring.end(), which_ring_big.begin(), which_ring_big.end());
@@ -889,6 +926,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     PgDevJob *jobs_off = sizer.take<PgDevJob>(n);
     int *which_off = sizer.take<int>(n);
     int *tiles_off = sizer.take<int>(tile_list.size());
+    int *flow_off = sizer.take<int>(b->flow_ints);
     for (int k = 0; k < n; ++k) carve_job(sizer, jobs[k], b->jobs[k], &b->dj[k]);
     const size_t in_bytes = sizer.cur;
     b->out_begin = in_bytes;
@@ -985,6 +1023,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     b->d_which = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(which_off));
     if (!tile_list.empty()) std::memcpy(stage.data() + reinterpret_cast<size_t>(tiles_off), tile_list.data(), sizeof(int) * tile_list.size());
     b->d_tiles = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(tiles_off));
+    b->d_flow = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(flow_off));
     HIP_TRY(hipStreamCreate(&b->stream));
     for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
     if (!which_tiled.empty() && b->n_ring + b->n_wide > 0) {

@@ -84,12 +84,10 @@ extern __shared__ __attribute__((aligned(16))) char pg_tiles_lds[];
 #define TM (*reinterpret_cast<TileSmem *>(pg_tiles_lds))
 #define TAT(p, q) (((q) - j0 + TH) * TP + ((p) - i0 + TH))
 
-// tiles[blockIdx.x] = {job, tile row a, tile column b, -}
-__global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__ jobs, const int *__restrict__ tiles,
-                                                    unsigned flags) {
+// One tile {job, tile row a, tile column b, -} by one wave.
+__device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, const pg_i4 T, unsigned flags) {
     const bool no_terminal_edges = flags & 1u;
     const bool reduced_terminal = !(flags & 2u);
-    const pg_i4 T = ((cdesc_p)tiles)[blockIdx.x];
     const View J = load_view(jobs + T.x);
     const int i0 = T.y * TS, j0 = T.z * TS;
     const int r = (int)threadIdx.x;
@@ -553,3 +551,56 @@ __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__
     }
 #endif
 }
+
+// tiles[blockIdx.x] = {job, tile row a, tile column b, -}: one launch per tile anti-diagonal (PAGAN_DP_TILES=launches)
+__global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__ jobs, const int *__restrict__ tiles,
+                                                    unsigned flags) {
+    tile_body(jobs, ((cdesc_p)tiles)[blockIdx.x], flags);
+}
+
+// ---- dataflow schedule: ONE launch for all tile anti-diagonals of the batch ----
+// A launch per anti-diagonal leaves compute units idle whenever a diagonal's tile count is not a multiple of their number
+// (one tile per CU: the tile fills LDS) and at every diagonal's tail: the root of a 512-leaf tree ran at 42 % of the
+// tile time x tiles / CUs bound.  Here one persistent wave per CU takes tiles from a queue in anti-diagonal order
+// (`flow[0]`); tile (a,b) of diagonal t starts once
+//   - every tile of the diagonals <= t-2 is done (`fin[t']` counts finished tiles; a wave keeps a watermark), which covers
+//     (a-1,b-1) and every tile a far bwd edge may read, and
+//   - its neighbours (a-1,b) and (a,b-1) of diagonal t-1 are done (`done[]`, list positions from the host; -1: not in
+//     the band).
+// A wave only ever waits for tiles that were handed out before its own -- to waves that are running -- so the queue drains.
+// Visibility across the XCDs' L2s: the finishing wave's stores are released at agent scope before its flags are set, the
+// starting wave acquires at agent scope after it has seen them (the compiler's gfx950 memory model: write-back of the
+// L2 / invalidate); the flags themselves are agent-scope atomics.
+// tiles: 4 * (n_tiles + 1) ints of {job, a, b, list position of (a-1,b) or -1}, then n_tiles list positions of (a,b-1) or
+// -1, then n_diag + 1 first-tile offsets per diagonal.  flow (zeroed by the host before every launch): [0] next tile,
+// [1 .. n_diag] finished tiles per diagonal, then n_tiles done flags.
+__global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restrict__ jobs, const int *__restrict__ tiles,
+                                                         int n_tiles, int n_diag, int *__restrict__ flow, unsigned flags) {
+    const int *left = tiles + 4 * ((size_t)n_tiles + 1);
+    const int *first = left + n_tiles;
+    int *fin = flow + 1, *done = flow + 1 + n_diag;
+    int water = 0;                                             // every diagonal < water is complete
+    auto wait_ge = [&](int *p, int need) {
+        while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(32);
+    };
+    for (;;) {
+        int idx = 0;
+        if (threadIdx.x == 0) idx = __hip_atomic_fetch_add(&flow[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx >= n_tiles) break;
+        const pg_i4 T = ((cdesc_p)tiles)[idx];
+        const int t = T.y + T.z;
+        for (; water <= t - 2; ++water) wait_ge(&fin[water], first[water + 1] - first[water]);
+        if (T.w >= 0) wait_ge(&done[T.w], 1);
+        const int lf = left[idx];
+        if (lf >= 0) wait_ge(&done[lf], 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        tile_body(jobs, T, flags);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // (waits for the wave's stores, writes the L2 back)
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&done[idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&fin[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
