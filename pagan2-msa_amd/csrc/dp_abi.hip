@@ -31,7 +31,7 @@ template <int BLOCK> __global__ void pg_fill_wavefront(const PgDevJob *jobs, con
 template <bool TAB_LDS> __global__ void pg_fill_ring(const PgDevJob *jobs, const int *which, unsigned flags);
 template <bool TAB_LDS> __global__ void pg_fill_pipe(const PgDevJob *jobs, const int *which, unsigned flags);
 __global__ void pg_fill_tiles(const PgDevJob *jobs, const int *tiles, unsigned flags);
-__global__ void pg_fill_tiles_flow(const PgDevJob *jobs, const int *tiles, int n_tiles, int n_diag, int *flow, unsigned flags);
+__global__ void pg_fill_tiles_flow(const PgDevJob *jobs, const int *tiles, int n_tiles, int n_diag, int *flow, unsigned flags, int use_water);
 __global__ void pg_end_corner(const PgDevJob *jobs);
 __global__ void pg_trace_spec(const PgDevJob *jobs);
 __global__ void pg_trace_compose(const PgDevJob *jobs);
@@ -366,6 +366,7 @@ struct pagan_batch {
                                  // row + column; then the positions of the tiles to the left; then tile_off (pg_fill_tiles_flow)
     int *d_flow = nullptr;       // pg_fill_tiles_flow's queue head, finished tiles per diagonal, done flags (zeroed per launch)
     size_t flow_ints = 0;
+    bool tiles_water = false;    // some job's tiles are no staircase: a tile also waits for all diagonals <= its own - 2
     bool tiles_flow = true;      // one persistent launch (default) or one launch per tile anti-diagonal (PAGAN_DP_TILES=launches)
     std::vector<int> tile_off;   // first tile of tile anti-diagonal t (tile_off.back() = total)
     hipStream_t stream2 = nullptr;   // the tile launches, when the batch also has jobs of the other kernels
@@ -567,7 +568,7 @@ int launch_fill(pagan_batch *b) {
             const int n_tiles = b->tile_off.back(), n_diag = (int)b->tile_off.size() - 1;
             HIP_TRY(hipMemsetAsync(b->d_flow, 0, sizeof(int) * b->flow_ints, st));
             hipLaunchKernelGGL(pg_fill_tiles_flow, dim3(std::min(n_tiles, n_cu_dev[b->device & 63].load())), dim3(64), pg_tiles_lds_bytes(),
-                               st, b->d_jobs, b->d_tiles, n_tiles, n_diag, b->d_flow, b->flags);
+                               st, b->d_jobs, b->d_tiles, n_tiles, n_diag, b->d_flow, b->flags, b->tiles_water ? 1 : 0);
         } else {
             for (size_t t = 0; t + 1 < b->tile_off.size(); ++t) {
                 const int cnt = b->tile_off[t + 1] - b->tile_off[t];
@@ -887,7 +888,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         }
         for (int t = 0; t < T; ++t) b->tile_off[t + 1] += b->tile_off[t];
         const size_t N = (size_t)b->tile_off[T];
-        tile_list.assign(4 * N + 4 + N + (size_t)T + 1, 0);
+        tile_list.assign(4 * N + 4 + 2 * N + (size_t)T + 1, 0);
         std::vector<int> cur(b->tile_off.begin(), b->tile_off.end() - 1);
         std::unordered_map<uint64_t, int> where;               // (job, tile row, tile column) -> position in the list
         where.reserve(2 * N);
@@ -906,10 +907,37 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             const int k = tile_list[4 * pos], a = tile_list[4 * pos + 1], bb = tile_list[4 * pos + 2];
             auto up = a > 0 ? where.find(key(k, a - 1, bb)) : where.end();
             auto lf = bb > 0 ? where.find(key(k, a, bb - 1)) : where.end();
+            auto dg = a > 0 && bb > 0 ? where.find(key(k, a - 1, bb - 1)) : where.end();
             tile_list[4 * pos + 3] = up == where.end() ? -1 : up->second;
             tile_list[4 * N + 4 + pos] = lf == where.end() ? -1 : lf->second;
+            tile_list[4 * N + 4 + N + pos] = dg == where.end() ? -1 : dg->second;
         }
-        for (int t = 0; t <= T; ++t) tile_list[4 * N + 4 + N + (size_t)t] = b->tile_off[t];
+        for (int t = 0; t <= T; ++t) tile_list[4 * N + 4 + 2 * N + (size_t)t] = b->tile_off[t];
+        // The neighbour flags alone order a tile behind everything it can read only if the job's tiles form a staircase
+        // (dp_tiles.hip): every tile row a contiguous run of columns, first and last column never falling from one row to
+        // the next, no empty row between two rows, consecutive rows touching.
+        for (int k : which_tiled) {
+            const std::vector<int> &tl = b->jobs[k].tiles;
+            std::vector<std::pair<int, int>> span;             // per tile row: first, last column
+            std::vector<int> count;
+            for (size_t q = 0; q < tl.size(); q += 2) {
+                const int a = tl[q], bb = tl[q + 1];
+                if ((int)span.size() <= a) { span.resize(a + 1, {1 << 30, -1}); count.resize(a + 1, 0); }
+                span[a].first = std::min(span[a].first, bb); span[a].second = std::max(span[a].second, bb);
+                ++count[a];
+            }
+            bool stair = true;
+            int prev = -1;
+            for (int a = 0; a < (int)span.size() && stair; ++a) {
+                if (count[a] == 0) { if (prev >= 0) stair = false; continue; }     // (rows before the first tile row are fine)
+                if (count[a] != span[a].second - span[a].first + 1) stair = false;
+                if (prev >= 0 && (prev != a - 1 || span[a].first < span[prev].first || span[a].second < span[prev].second ||
+                                  span[a].first > span[prev].second + 1)) stair = false;
+                prev = a;
+            }
+            if (!stair) b->tiles_water = true;
+        }
+        if (const char *f = std::getenv("PAGAN_DP_TILES")) if (std::strcmp(f, "watermark") == 0) b->tiles_water = true;
         b->flow_ints = 1 + (size_t)T + N;
         if (const char *f = std::getenv("PAGAN_DP_TILES")) b->tiles_flow = std::strcmp(f, "launches") != 0;   // A/B switch
     }

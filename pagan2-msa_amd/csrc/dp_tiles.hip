@@ -562,22 +562,25 @@ __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__
 // A launch per anti-diagonal leaves compute units idle whenever a diagonal's tile count is not a multiple of their number
 // (one tile per CU: the tile fills LDS) and at every diagonal's tail: the root of a 512-leaf tree ran at 42 % of the
 // tile time x tiles / CUs bound.  Here one persistent wave per CU takes tiles from a queue in anti-diagonal order
-// (`flow[0]`); tile (a,b) of diagonal t starts once
-//   - every tile of the diagonals <= t-2 is done (`fin[t']` counts finished tiles; a wave keeps a watermark), which covers
-//     (a-1,b-1) and every tile a far bwd edge may read, and
-//   - its neighbours (a-1,b) and (a,b-1) of diagonal t-1 are done (`done[]`, list positions from the host; -1: not in
-//     the band).
+// (`flow[0]`); tile (a,b) of diagonal t starts once its neighbours (a-1,b), (a,b-1) and (a-1,b-1) are done (`done[]`, list
+// positions from the host; -1: not in the band).  Where the tiles of every job form a staircase -- each tile row a
+// contiguous run of columns, first and last column never falling, consecutive rows touching (the host checks; any band
+// the anchors make does) -- that is enough: by induction every tile (a',b') <= (a,b) is done then, i.e. every tile a bwd
+// edge of this tile's cells can reach.  Otherwise (`use_water`) a tile also waits until every tile of the diagonals <= t-2
+// is done (`fin[t']` counts finished tiles; a wave keeps a watermark): 45 % of a wave's time on the root of a 512-leaf tree.
 // A wave only ever waits for tiles that were handed out before its own -- to waves that are running -- so the queue drains.
 // Visibility across the XCDs' L2s: the finishing wave's stores are released at agent scope before its flags are set, the
 // starting wave acquires at agent scope after it has seen them (the compiler's gfx950 memory model: write-back of the
 // L2 / invalidate); the flags themselves are agent-scope atomics.
 // tiles: 4 * (n_tiles + 1) ints of {job, a, b, list position of (a-1,b) or -1}, then n_tiles list positions of (a,b-1) or
-// -1, then n_diag + 1 first-tile offsets per diagonal.  flow (zeroed by the host before every launch): [0] next tile,
+// -1, the same for (a-1,b-1), then n_diag + 1 first-tile offsets per diagonal.  flow (zeroed by the host before every launch): [0] next tile,
 // [1 .. n_diag] finished tiles per diagonal, then n_tiles done flags.
 __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restrict__ jobs, const int *__restrict__ tiles,
-                                                         int n_tiles, int n_diag, int *__restrict__ flow, unsigned flags) {
+                                                         int n_tiles, int n_diag, int *__restrict__ flow, unsigned flags,
+                                                         int use_water) {
     const int *left = tiles + 4 * ((size_t)n_tiles + 1);
-    const int *first = left + n_tiles;
+    const int *diag = left + n_tiles;
+    const int *first = diag + n_tiles;
     int *fin = flow + 1, *done = flow + 1 + n_diag;
     int water = 0;                                             // every diagonal < water is complete
     auto wait_ge = [&](int *p, int need) {
@@ -590,13 +593,35 @@ __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restr
         if (idx >= n_tiles) break;
         const pg_i4 T = ((cdesc_p)tiles)[idx];
         const int t = T.y + T.z;
-        for (; water <= t - 2; ++water) wait_ge(&fin[water], first[water + 1] - first[water]);
+#ifdef PG_TILE_STATS
+        const unsigned long long fs0 = __builtin_amdgcn_s_memtime();
+#endif
+        if (use_water) for (; water <= t - 2; ++water) wait_ge(&fin[water], first[water + 1] - first[water]);
+#ifdef PG_TILE_STATS
+        const unsigned long long fs1 = __builtin_amdgcn_s_memtime();
+#endif
         if (T.w >= 0) wait_ge(&done[T.w], 1);
         const int lf = left[idx];
         if (lf >= 0) wait_ge(&done[lf], 1);
+        const int dg = diag[idx];
+        if (dg >= 0) wait_ge(&done[dg], 1);
+#ifdef PG_TILE_STATS
+        const unsigned long long fs2 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         tile_body(jobs, T, flags);
+#ifdef PG_TILE_STATS
+        const unsigned long long fs3 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // (waits for the wave's stores, writes the L2 back)
+#ifdef PG_TILE_STATS
+        if (threadIdx.x == 0) {      // [9] waiting for whole diagonals, [10] for the neighbours, [11] acquire + tile, [12] release
+            const View Jv = load_view(jobs + T.x);
+            unsigned long long *out = (unsigned long long *)(jobs[T.x].trace + ((3 * (Jv.Lx + Jv.Ly) - 64) & ~1));
+            atomicAdd(out + 9, fs1 - fs0); atomicAdd(out + 10, fs2 - fs1); atomicAdd(out + 11, fs3 - fs2);
+            atomicAdd(out + 12, __builtin_amdgcn_s_memtime() - fs3);
+        }
+#endif
         if (threadIdx.x == 0) {
             __hip_atomic_store(&done[idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(&fin[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

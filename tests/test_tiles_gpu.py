@@ -139,3 +139,37 @@ def test_band_with_boxes_on_the_matrix_edges(pg, oracle):
     assert len(tiles) > 30
     model = synth.random_model(15, 11)
     same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band))
+
+
+@pytest.mark.parametrize("schedule", ["flow", "watermark", "launches"])
+def test_tile_schedules_agree(pg, oracle, monkeypatch, schedule):
+    """The dataflow launch (neighbour flags only / plus the diagonal watermark) and the launch per tile anti-diagonal
+    compute the same alignment -- on a matrix deep enough that many tiles are in flight at once, with bwd edges that reach
+    several tiles back (operands another wave wrote during the same launch)."""
+    if schedule != "flow":
+        monkeypatch.setenv("PAGAN_DP_TILES", schedule)
+    left = synth.random_graph(1500, 15, 91, p_extra=0.08, max_deg=4, max_span=300, p_dead=0.01)
+    right = synth.random_graph(1400, 15, 92, p_extra=0.08, max_deg=4, max_span=300, p_dead=0.01)
+    model = synth.random_model(15, 13)
+    band = wide_band(left.n_sites - 1, right.n_sites - 1, 700, 5)
+    jobs = [(left, right, model, None), (left, right, model, band), (right, left, model, None)]
+    got = pg.align_batch(jobs)
+    for k, (l, r, m, bd) in enumerate(jobs):
+        same(got[k], oracle.dp_align(l, r, m, bd), "%s job %d" % (schedule, k))
+
+
+def test_band_whose_tiles_are_no_staircase(pg, oracle):
+    """Rows whose column ranges do not touch (the band is monotone, so it is accepted; cells behind the jump are reachable
+    through skip edges only): the tile rows do not touch either, the neighbour flags do not order a tile behind everything
+    it may read, and the host falls back to the diagonal watermark."""
+    left = synth.random_graph(700, 15, 95, p_extra=0.15, max_deg=4, max_span=400)
+    right = synth.random_graph(900, 15, 96, p_extra=0.15, max_deg=4, max_span=400)
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    upper = np.zeros(Lx, np.int64); lower = np.zeros(Lx, np.int64)
+    upper[:350] = 0; lower[:350] = 330
+    upper[350:] = 520; lower[350:] = Ly - 1                                # a jump of three tile columns between two rows
+    band = abi.Band(upper, lower)
+    side, tiles = pg.debug_tiles(left, right, band)
+    assert len(tiles) > 30
+    model = synth.random_model(15, 17)
+    same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band))
