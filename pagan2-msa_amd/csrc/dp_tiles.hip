@@ -85,7 +85,21 @@ extern __shared__ __attribute__((aligned(16))) char pg_tiles_lds[];
 #define TAT(p, q) (((q) - j0 + TH) * TP + ((p) - i0 + TH))
 
 // One tile {job, tile row a, tile column b, -} by one wave.
-__device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, const pg_i4 T, unsigned flags) {
+// LAG (pg_fill_tiles_flow on staircase tile sets): the tile starts while the tiles above (`up`) and to the left (`lf`) are
+// still running, TLAG steps behind them.  Lane 0's cell of step s reads row i0-1 at column j0+s, which the tile above
+// completes at its step s+63, and lane r's first cell (step r, column j0) reads row i0+r at column j0-1, which the tile to
+// the left completes at its step r+63: so the steps [16k, 16k+16) need both neighbours' steps <= 16k+78 published, and from
+// step 64 on the tile reads nothing a neighbour has not finished.  The halo is therefore loaded in blocks of TBLK steps'
+// worth -- the next TBLK columns of the rows above, the next TBLK rows of the columns to the left -- each after a wait
+// for the neighbours' progress (`prog[]`, published with an agent-scope release every TBLK steps), with L2-coherent loads
+// (sc1: the cells may have been written by a wave of another XCD a moment ago).  A bwd edge that reaches before the halo
+// reads cells (p,q) <= (i,j) of tiles above / to the left, complete at their step <= s+63 as well, or of tiles further
+// back, which were TLAG steps ahead of those.
+#define TBLK 16                    // (TH + TBLK) * TH + TBLK * TH <= 5 * 64: halo_block's five cells per lane
+#define TDONE (1 << 20)
+template <bool LAG>
+__device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, const pg_i4 T, unsigned flags, int *prog = nullptr,
+                                          int self = -1, int up = -1, int lf = -1) {
     const bool no_terminal_edges = flags & 1u;
     const bool reduced_terminal = !(flags & 2u);
     const View J = load_view(jobs + T.x);
@@ -171,10 +185,12 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
     double hm[THC];
 #pragma unroll
     for (int u = 0; u < THC; ++u) {
-        hv[u] = hv[u] && hp[u] >= hd[u].x && hp[u] <= hd[u].y;
+        hv[u] = !LAG && hv[u] && hp[u] >= hd[u].x && hp[u] <= hd[u].y;
         const long long ix = hv[u] ? (((long long)hd[u].w << 32) | (unsigned)hd[u].z) + (hp[u] - hd[u].x) : 0;
-        hxy[u] = *(PG_GLOBAL const d2 *)(J.sc + 3 * ix);
-        hm[u] = J.sc[3 * ix + 2];
+        if (!LAG) {
+            hxy[u] = *(PG_GLOBAL const d2 *)(J.sc + 3 * ix);
+            hm[u] = J.sc[3 * ix + 2];
+        } else { hxy[u].x = NI; hxy[u].y = NI; hm[u] = NI; }
     }
     int gp[THC], gat[THC];
     bool gv[THC];
@@ -215,10 +231,12 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
     // round 3: the remaining halo cells (and, for a table too large for LDS, the tile's model scores)
 #pragma unroll
     for (int u = 0; u < THC; ++u) {
-        gv[u] = gv[u] && gp[u] >= gd[u].x && gp[u] <= gd[u].y;
+        gv[u] = !LAG && gv[u] && gp[u] >= gd[u].x && gp[u] <= gd[u].y;
         const long long ix = gv[u] ? (((long long)gd[u].w << 32) | (unsigned)gd[u].z) + (gp[u] - gd[u].x) : 0;
-        hxy[u] = *(PG_GLOBAL const d2 *)(J.sc + 3 * ix);
-        hm[u] = J.sc[3 * ix + 2];
+        if (!LAG) {
+            hxy[u] = *(PG_GLOBAL const d2 *)(J.sc + 3 * ix);
+            hm[u] = J.sc[3 * ix + 2];
+        } else { hxy[u].x = NI; hxy[u].y = NI; hm[u] = NI; }
     }
     // the model's scores for the tile's 64 x 64 state pairs (VA:1363): from the table's LDS copy, or -- a
     // protein table is 211 x 211 floats -- from HBM/L2, sixteen loads in flight per lane
@@ -261,11 +279,66 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
 #ifdef PG_TILE_STATS
     const unsigned long long st_loop = __builtin_amdgcn_s_memtime();
 #endif
+    // LAG: the halo cells of one block of steps (k = s / TBLK, s < TS): columns j0 + TBLK k ... of the TH rows above (the
+    // first block also takes the corner), rows i0 + TBLK k ... of the TH columns to the left
+    auto halo_block = [&](int k) {
+        const int c0 = k == 0 ? -TH : TBLK * k, ncol = k == 0 ? TH + TBLK : TBLK;
+        const int ntop = ncol * TH, nall = ntop + TBLK * TH;
+        // at most five cells per lane ((TH + TBLK) * TH + TBLK * TH = 320): requested together, one wait
+        bool hv_[5];
+        int hat_[5];
+        PG_GLOBAL const double *hp_[5];
+        d2 hxy_[5];
+        double hm_[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int e = r + 64 * u;
+            int p, q;
+            if (e < ntop) { p = i0 - TH + e / ncol; q = j0 + c0 + e % ncol; }
+            else { const int e2 = e - ntop; q = j0 - TH + e2 / TBLK; p = i0 + TBLK * k + e2 % TBLK; }
+            hv_[u] = e < nall && p >= 0 && q >= 0 && p < J.Lx && q < J.Ly;
+            const pg_i4 F = TM.dsc[hv_[u] ? p + q - (dbase - TDB) : TDB];
+            hv_[u] = hv_[u] && p >= F.x && p <= F.y;
+            const long long ix = hv_[u] ? (((long long)F.w << 32) | (unsigned)F.z) + (p - F.x) : 0;
+            hp_[u] = J.sc + 3 * ix;
+            hat_[u] = hv_[u] ? TAT(p, q) : TNULL;
+            hxy_[u].x = NI; hxy_[u].y = NI; hm_[u] = NI;
+        }
+        const unsigned long long k0 = __builtin_amdgcn_ballot_w64(hv_[0]), k1 = __builtin_amdgcn_ballot_w64(hv_[1]);
+        const unsigned long long k2 = __builtin_amdgcn_ballot_w64(hv_[2]), k3 = __builtin_amdgcn_ballot_w64(hv_[3]);
+        const unsigned long long k4 = __builtin_amdgcn_ballot_w64(hv_[4]);
+        if ((k0 | k1 | k2 | k3 | k4) == 0) return;
+        unsigned long long sv;
+#define PG_HALO_LD(n) "s_and_b64 exec, %[sv], %[k" #n "]\n\tglobal_load_dwordx4 %[x" #n "], %[p" #n "], off sc1\n\tglobal_load_dwordx2 %[u" #n "], %[p" #n "], off offset:16 sc1\n\t"
+        asm volatile("s_mov_b64 %[sv], exec\n\t" PG_HALO_LD(0) PG_HALO_LD(1) PG_HALO_LD(2) PG_HALO_LD(3) PG_HALO_LD(4)
+                     "s_mov_b64 exec, %[sv]\n\ts_waitcnt vmcnt(0)"
+                     : [x0] "+v"(hxy_[0]), [u0] "+v"(hm_[0]), [x1] "+v"(hxy_[1]), [u1] "+v"(hm_[1]), [x2] "+v"(hxy_[2]), [u2] "+v"(hm_[2]),
+                       [x3] "+v"(hxy_[3]), [u3] "+v"(hm_[3]), [x4] "+v"(hxy_[4]), [u4] "+v"(hm_[4]), [sv] "=&s"(sv)
+                     : [p0] "v"(hp_[0]), [p1] "v"(hp_[1]), [p2] "v"(hp_[2]), [p3] "v"(hp_[3]), [p4] "v"(hp_[4]),
+                       [k0] "s"(k0), [k1] "s"(k1), [k2] "s"(k2), [k3] "s"(k3), [k4] "s"(k4)
+                     : "memory");
+#undef PG_HALO_LD
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+            if (hv_[u]) { TM.sc[hat_[u]][0] = hxy_[u].x; TM.sc[hat_[u]][1] = hxy_[u].y; TM.sc[hat_[u]][2] = hm_[u]; }
+    };
+    auto wait_prog = [&](int which, int need) {
+        if (which < 0) return;
+        while (__hip_atomic_load(&prog[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+    };
     for (int s = 0; s <= s_last; ++s) {
 #ifdef PG_TILE_STATS
         const unsigned long long st_a = __builtin_amdgcn_s_memtime();
         int st_kind = -1;
 #endif
+        if (LAG && s < TS && (s & (TBLK - 1)) == 0) {
+            const int need = s + TBLK - 1 + TS;                   // the neighbours' steps <= s + TBLK - 1 + 63 are published
+            wait_prog(up, need < 2 * TS - 1 ? need : TDONE);
+            wait_prog(lf, need < 2 * TS - 1 ? need : TDONE);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            halo_block(s / TBLK);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         const pg_i4 Dn = TM.dsc[TDB + s + 1];
         const int jj = s - r;
         pg_i4 cn = pg_i4{0, 0, 0, 0}, cen = pg_i4{0, 0, 0, 0};
@@ -533,6 +606,11 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
         }
         D = Dn; c = cn; ce = cen;
         asm volatile("" ::: "memory");
+        // (the first progress anybody waits for is TS + TBLK - 1)
+        if (LAG && (s & (TBLK - 1)) == TBLK - 1 && s >= TS && s < s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (waits for the wave's stores, writes the L2 back)
+            if (r == 0) __hip_atomic_store(&prog[self], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #ifdef PG_TILE_STATS
         if (st_kind >= 0) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -555,7 +633,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
 // tiles[blockIdx.x] = {job, tile row a, tile column b, -}: one launch per tile anti-diagonal (PAGAN_DP_TILES=launches)
 __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__ jobs, const int *__restrict__ tiles,
                                                     unsigned flags) {
-    tile_body(jobs, ((cdesc_p)tiles)[blockIdx.x], flags);
+    tile_body<false>(jobs, ((cdesc_p)tiles)[blockIdx.x], flags);
 }
 
 // ---- dataflow schedule: ONE launch for all tile anti-diagonals of the batch ----
@@ -597,19 +675,20 @@ __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restr
         const unsigned long long fs0 = __builtin_amdgcn_s_memtime();
 #endif
         if (use_water) for (; water <= t - 2; ++water) wait_ge(&fin[water], first[water + 1] - first[water]);
+        const int lf = left[idx], dg = diag[idx];
 #ifdef PG_TILE_STATS
         const unsigned long long fs1 = __builtin_amdgcn_s_memtime();
 #endif
-        if (T.w >= 0) wait_ge(&done[T.w], 1);
-        const int lf = left[idx];
-        if (lf >= 0) wait_ge(&done[lf], 1);
-        const int dg = diag[idx];
-        if (dg >= 0) wait_ge(&done[dg], 1);
+        if (use_water) {
+            if (T.w >= 0) wait_ge(&done[T.w], TDONE);
+            if (lf >= 0) wait_ge(&done[lf], TDONE);
+        } else if (T.w < 0 && lf < 0 && dg >= 0) wait_ge(&done[dg], TDONE);    // (the band enters through the corner)
 #ifdef PG_TILE_STATS
         const unsigned long long fs2 = __builtin_amdgcn_s_memtime();
 #endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        tile_body(jobs, T, flags);
+        if (use_water) tile_body<false>(jobs, T, flags);
+        else tile_body<true>(jobs, T, flags, done, idx, T.w, lf);
 #ifdef PG_TILE_STATS
         const unsigned long long fs3 = __builtin_amdgcn_s_memtime();
 #endif
@@ -623,7 +702,7 @@ __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restr
         }
 #endif
         if (threadIdx.x == 0) {
-            __hip_atomic_store(&done[idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&done[idx], TDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(&fin[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
