@@ -337,10 +337,13 @@ def bench_work_queue(args, rank, local_rank, world):
 
 def fill_kernel(anchors):
     """Name of the kernel the timed fill launches: the banded workloads run the register-wavefront kernel
-    (or the older LDS ring kernel behind PAGAN_DP_FILL=ring), full matrices the tiled kernel (one launch per
-    tile anti-diagonal; or the one-workgroup HBM wavefront behind PAGAN_DP_WIDE=wavefront)."""
+    (or the older LDS ring kernel behind PAGAN_DP_FILL=ring), full matrices the tiled kernel (one persistent launch
+    per batch, tiles in dataflow order; one launch per tile anti-diagonal behind PAGAN_DP_TILES=launches; or the
+    one-workgroup HBM wavefront behind PAGAN_DP_WIDE=wavefront)."""
     if not anchors:
-        return "pg_fill_wavefront" if os.environ.get("PAGAN_DP_WIDE") == "wavefront" else "pg_fill_tiles"
+        if os.environ.get("PAGAN_DP_WIDE") == "wavefront":
+            return "pg_fill_wavefront"
+        return "pg_fill_tiles" if os.environ.get("PAGAN_DP_TILES") == "launches" else "pg_fill_tiles_flow"
     return "pg_fill_ring" if os.environ.get("PAGAN_DP_FILL") == "ring" else "pg_fill_pipe"
 
 

@@ -938,7 +938,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             if (!stair) b->tiles_water = true;
         }
         if (const char *f = std::getenv("PAGAN_DP_TILES")) if (std::strcmp(f, "watermark") == 0) b->tiles_water = true;
-        b->flow_ints = 1 + (size_t)T + N;
+        b->flow_ints = 1 + (size_t)T + N + 1;                  // queue head, finished tiles per diagonal, progress per tile, give-up flag
         if (const char *f = std::getenv("PAGAN_DP_TILES")) b->tiles_flow = std::strcmp(f, "launches") != 0;   // A/B switch
     }
     b->n_ring_small = (int)which_ring.size();

@@ -84,6 +84,27 @@ extern __shared__ __attribute__((aligned(16))) char pg_tiles_lds[];
 #define TM (*reinterpret_cast<TileSmem *>(pg_tiles_lds))
 #define TAT(p, q) (((q) - j0 + TH) * TP + ((p) - i0 + TH))
 
+// A wait of the dataflow schedule: every wait is for a tile that was handed out earlier to a running wave, so it ends; the
+// limit (seconds of polling) only turns a logic error into an error status of the tile's job (pg_end_corner reports it)
+// instead of a hung GPU.  After one wave gave up every wait passes and the waves stop taking tiles.
+#ifndef PG_FLOW_SPIN_LOG2
+#define PG_FLOW_SPIN_LOG2 24
+#endif
+__device__ __forceinline__ void flow_wait(int *p, int need, int *giveup, int *status) {
+    int spins = 0;
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(16);
+        if ((++spins & 63) == 0) {
+            if (__hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+            if (spins >= (1 << PG_FLOW_SPIN_LOG2)) {
+                __hip_atomic_store(giveup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (threadIdx.x == 0) *status = 0x7e;            // "a tile's wait for its neighbours never ended"
+                return;
+            }
+        }
+    }
+}
+
 // One tile {job, tile row a, tile column b, -} by one wave.
 // LAG (pg_fill_tiles_flow on staircase tile sets): the tile starts while the tiles above (`up`) and to the left (`lf`) are
 // still running, TLAG steps behind them.  Lane 0's cell of step s reads row i0-1 at column j0+s, which the tile above
@@ -99,7 +120,7 @@ extern __shared__ __attribute__((aligned(16))) char pg_tiles_lds[];
 #define TDONE (1 << 20)
 template <bool LAG>
 __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, const pg_i4 T, unsigned flags, int *prog = nullptr,
-                                          int self = -1, int up = -1, int lf = -1) {
+                                          int self = -1, int up = -1, int lf = -1, int *giveup = nullptr) {
     const bool no_terminal_edges = flags & 1u;
     const bool reduced_terminal = !(flags & 2u);
     const View J = load_view(jobs + T.x);
@@ -324,7 +345,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
     };
     auto wait_prog = [&](int which, int need) {
         if (which < 0) return;
-        while (__hip_atomic_load(&prog[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+        flow_wait(&prog[which], need, giveup, jobs[T.x].fill_status);
     };
     for (int s = 0; s <= s_last; ++s) {
 #ifdef PG_TILE_STATS
@@ -661,9 +682,7 @@ __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restr
     const int *first = diag + n_tiles;
     int *fin = flow + 1, *done = flow + 1 + n_diag;
     int water = 0;                                             // every diagonal < water is complete
-    auto wait_ge = [&](int *p, int need) {
-        while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(32);
-    };
+    int *giveup = done + n_tiles;                              // set by a wave whose wait ran into its limit: everybody leaves
     for (;;) {
         int idx = 0;
         if (threadIdx.x == 0) idx = __hip_atomic_fetch_add(&flow[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -671,6 +690,8 @@ __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restr
         if (idx >= n_tiles) break;
         const pg_i4 T = ((cdesc_p)tiles)[idx];
         const int t = T.y + T.z;
+        auto wait_ge = [&](int *p, int need) { flow_wait(p, need, giveup, jobs[T.x].fill_status); };
+        if (__hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
 #ifdef PG_TILE_STATS
         const unsigned long long fs0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -688,7 +709,7 @@ __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restr
 #endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (use_water) tile_body<false>(jobs, T, flags);
-        else tile_body<true>(jobs, T, flags, done, idx, T.w, lf);
+        else tile_body<true>(jobs, T, flags, done, idx, T.w, lf, giveup);
 #ifdef PG_TILE_STATS
         const unsigned long long fs3 = __builtin_amdgcn_s_memtime();
 #endif
