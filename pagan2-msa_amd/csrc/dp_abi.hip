@@ -366,6 +366,7 @@ struct pagan_batch {
                                  // row + column; then the positions of the tiles to the left; then tile_off (pg_fill_tiles_flow)
     int *d_flow = nullptr;       // pg_fill_tiles_flow's queue head, finished tiles per diagonal, done flags (zeroed per launch)
     size_t flow_ints = 0;
+    bool tiles_nolag = false;    // PAGAN_DP_TILES=nolag: tiles wait for their neighbours to finish (A/B switch)
     bool tiles_water = false;    // some job's tiles are no staircase: a tile also waits for all diagonals <= its own - 2
     bool tiles_flow = true;      // one persistent launch (default) or one launch per tile anti-diagonal (PAGAN_DP_TILES=launches)
     std::vector<int> tile_off;   // first tile of tile anti-diagonal t (tile_off.back() = total)
@@ -566,9 +567,18 @@ int launch_fill(pagan_batch *b) {
         if (b->tiles_flow) {
             // one persistent wave per compute unit (a tile fills the LDS) drains the batch's tiles in dependency order
             const int n_tiles = b->tile_off.back(), n_diag = (int)b->tile_off.size() - 1;
+            // (last argument) tiles run 80 steps behind their neighbours unless the batch has so many tiles per anti-diagonal
+            // that the compute units are the bound either way (measured on cfg5: 575 per diagonal 65 -> 56 ms without the lag,
+            // 320 per diagonal 46 -> 48 ms: the switch sits at 1.75 x the number of compute units)
+            // no more waves than can have a tile to work on: the tiles of two anti-diagonals (a tile runs 80 steps behind
+            // its neighbours) -- a persistent wave holds its compute unit's LDS, which the batch's banded jobs need too
+            int widest = 1;
+            for (int t = 0; t < n_diag; ++t) widest = std::max(widest, b->tile_off[t + 1] - b->tile_off[t]);
+            const int waves = std::min({n_tiles, n_cu_dev[b->device & 63].load(), 2 * widest + 8});
             HIP_TRY(hipMemsetAsync(b->d_flow, 0, sizeof(int) * b->flow_ints, st));
-            hipLaunchKernelGGL(pg_fill_tiles_flow, dim3(std::min(n_tiles, n_cu_dev[b->device & 63].load())), dim3(64), pg_tiles_lds_bytes(),
-                               st, b->d_jobs, b->d_tiles, n_tiles, n_diag, b->d_flow, b->flags, b->tiles_water ? 1 : 0);
+            hipLaunchKernelGGL(pg_fill_tiles_flow, dim3(waves), dim3(64), pg_tiles_lds_bytes(),
+                               st, b->d_jobs, b->d_tiles, n_tiles, n_diag, b->d_flow, b->flags,
+                               b->tiles_water ? 1 : (4ll * n_tiles >= 7ll * n_cu_dev[b->device & 63].load() * n_diag || b->tiles_nolag ? 2 : 0));
         } else {
             for (size_t t = 0; t + 1 < b->tile_off.size(); ++t) {
                 const int cnt = b->tile_off[t + 1] - b->tile_off[t];
@@ -938,6 +948,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             if (!stair) b->tiles_water = true;
         }
         if (const char *f = std::getenv("PAGAN_DP_TILES")) if (std::strcmp(f, "watermark") == 0) b->tiles_water = true;
+        if (const char *f = std::getenv("PAGAN_DP_TILES")) if (std::strcmp(f, "nolag") == 0) b->tiles_nolag = true;
         b->flow_ints = 1 + (size_t)T + N + 1;                  // queue head, finished tiles per diagonal, progress per tile, give-up flag
         if (const char *f = std::getenv("PAGAN_DP_TILES")) b->tiles_flow = std::strcmp(f, "launches") != 0;   // A/B switch
     }

@@ -665,8 +665,11 @@ __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__
 // positions from the host; -1: not in the band).  Where the tiles of every job form a staircase -- each tile row a
 // contiguous run of columns, first and last column never falling, consecutive rows touching (the host checks; any band
 // the anchors make does) -- that is enough: by induction every tile (a',b') <= (a,b) is done then, i.e. every tile a bwd
-// edge of this tile's cells can reach.  Otherwise (`use_water`) a tile also waits until every tile of the diagonals <= t-2
-// is done (`fin[t']` counts finished tiles; a wave keeps a watermark): 45 % of a wave's time on the root of a 512-leaf tree.
+// edge of this tile's cells can reach.  Otherwise (`use_water` 1) a tile also waits until every tile of the diagonals <= t-2
+// is done (`fin[t']` counts finished tiles; a wave keeps a watermark).  `use_water` 0: staircase jobs, tiles start 80 steps
+// behind their neighbours (tile_body<true>); 2: staircase jobs, a tile waits for its neighbours to finish -- the host picks
+// it when the batch has more tiles per anti-diagonal than the chip has compute units (the lag buys nothing then and its
+// progress flags and block-wise halo cost 15 %).
 // A wave only ever waits for tiles that were handed out before its own -- to waves that are running -- so the queue drains.
 // Visibility across the XCDs' L2s: the finishing wave's stores are released at agent scope before its flags are set, the
 // starting wave acquires at agent scope after it has seen them (the compiler's gfx950 memory model: write-back of the
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restr
 #ifdef PG_TILE_STATS
         const unsigned long long fs0 = __builtin_amdgcn_s_memtime();
 #endif
-        if (use_water) for (; water <= t - 2; ++water) wait_ge(&fin[water], first[water + 1] - first[water]);
+        if (use_water == 1) for (; water <= t - 2; ++water) wait_ge(&fin[water], first[water + 1] - first[water]);
         const int lf = left[idx], dg = diag[idx];
 #ifdef PG_TILE_STATS
         const unsigned long long fs1 = __builtin_amdgcn_s_memtime();
@@ -703,6 +706,7 @@ __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restr
         if (use_water) {
             if (T.w >= 0) wait_ge(&done[T.w], TDONE);
             if (lf >= 0) wait_ge(&done[lf], TDONE);
+            if (use_water == 2 && dg >= 0) wait_ge(&done[dg], TDONE);
         } else if (T.w < 0 && lf < 0 && dg >= 0) wait_ge(&done[dg], TDONE);    // (the band enters through the corner)
 #ifdef PG_TILE_STATS
         const unsigned long long fs2 = __builtin_amdgcn_s_memtime();

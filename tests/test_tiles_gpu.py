@@ -141,7 +141,7 @@ def test_band_with_boxes_on_the_matrix_edges(pg, oracle):
     same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band))
 
 
-@pytest.mark.parametrize("schedule", ["flow", "watermark", "launches"])
+@pytest.mark.parametrize("schedule", ["flow", "nolag", "watermark", "launches"])
 def test_tile_schedules_agree(pg, oracle, monkeypatch, schedule):
     """The dataflow launch (neighbour flags only / plus the diagonal watermark) and the launch per tile anti-diagonal
     compute the same alignment -- on a matrix deep enough that many tiles are in flight at once, with bwd edges that reach
