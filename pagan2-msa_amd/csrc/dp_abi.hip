@@ -543,10 +543,11 @@ template <class T> void put(Stage &stage, const void *devptr_as_off, const T *sr
 }
 
 int launch_fill(pagan_batch *b) {
+    hipStream_t tile_stream = nullptr;
+    static std::atomic<int> n_cu_dev[64];
     if (b->tile_off.size() > 1) {
         static std::atomic<bool> tiles_set_dev[64];
         std::atomic<bool> &tiles_set = tiles_set_dev[b->device & 63];
-        static std::atomic<int> n_cu_dev[64];
         if (!tiles_set.load()) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_tiles),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_tiles_lds_bytes()));
@@ -564,29 +565,7 @@ int launch_fill(pagan_batch *b) {
             HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
             st = b->stream2;
         }
-        if (b->tiles_flow) {
-            // one persistent wave per compute unit (a tile fills the LDS) drains the batch's tiles in dependency order
-            const int n_tiles = b->tile_off.back(), n_diag = (int)b->tile_off.size() - 1;
-            // (last argument) tiles run 80 steps behind their neighbours unless the batch has so many tiles per anti-diagonal
-            // that the compute units are the bound either way (measured on cfg5: 575 per diagonal 65 -> 56 ms without the lag,
-            // 320 per diagonal 46 -> 48 ms: the switch sits at 1.75 x the number of compute units)
-            // no more waves than can have a tile to work on: the tiles of two anti-diagonals (a tile runs 80 steps behind
-            // its neighbours) -- a persistent wave holds its compute unit's LDS, which the batch's banded jobs need too
-            int widest = 1;
-            for (int t = 0; t < n_diag; ++t) widest = std::max(widest, b->tile_off[t + 1] - b->tile_off[t]);
-            const int waves = std::min({n_tiles, n_cu_dev[b->device & 63].load(), 2 * widest + 8});
-            HIP_TRY(hipMemsetAsync(b->d_flow, 0, sizeof(int) * b->flow_ints, st));
-            hipLaunchKernelGGL(pg_fill_tiles_flow, dim3(waves), dim3(64), pg_tiles_lds_bytes(),
-                               st, b->d_jobs, b->d_tiles, n_tiles, n_diag, b->d_flow, b->flags,
-                               b->tiles_water ? 1 : (4ll * n_tiles >= 7ll * n_cu_dev[b->device & 63].load() * n_diag || b->tiles_nolag ? 2 : 0));
-        } else {
-            for (size_t t = 0; t + 1 < b->tile_off.size(); ++t) {
-                const int cnt = b->tile_off[t + 1] - b->tile_off[t];
-                if (cnt > 0)
-                    hipLaunchKernelGGL(pg_fill_tiles, dim3(cnt), dim3(64), pg_tiles_lds_bytes(), st, b->d_jobs,
-                                       b->d_tiles + 4 * (size_t)b->tile_off[t], b->flags);
-            }
-        }
+        tile_stream = st;
     }
     if (b->n_ring > 0) {
         // > 64 KB of dynamic LDS has to be opted into once per device (a process may drive several)
@@ -628,6 +607,33 @@ int launch_fill(pagan_batch *b) {
         case 64: hipLaunchKernelGGL(pg_fill_wavefront<64>, grid, dim3(64), 0, b->stream, b->d_jobs, which, b->flags); break;
         case 256: hipLaunchKernelGGL(pg_fill_wavefront<256>, grid, dim3(256), 0, b->stream, b->d_jobs, which, b->flags); break;
         default: hipLaunchKernelGGL(pg_fill_wavefront<1024>, grid, dim3(1024), 0, b->stream, b->d_jobs, which, b->flags); break;
+        }
+    }
+    if (b->tile_off.size() > 1) {
+        // after the banded kernels: their workgroups get compute units first; the persistent waves below hold theirs
+        hipStream_t st = tile_stream;
+        if (b->tiles_flow) {
+            // one persistent wave per compute unit (a tile fills the LDS) drains the batch's tiles in dependency order
+            const int n_tiles = b->tile_off.back(), n_diag = (int)b->tile_off.size() - 1;
+            // (last argument) tiles run 80 steps behind their neighbours unless the batch has so many tiles per anti-diagonal
+            // that the compute units are the bound either way (measured on cfg5: 575 per diagonal 65 -> 56 ms without the lag,
+            // 320 per diagonal 46 -> 48 ms: the switch sits at 1.75 x the number of compute units)
+            // no more waves than can have a tile to work on: the tiles of two anti-diagonals (a tile runs 80 steps behind
+            // its neighbours) -- a persistent wave holds its compute unit's LDS, which the batch's banded jobs need too
+            int widest = 1;
+            for (int t = 0; t < n_diag; ++t) widest = std::max(widest, b->tile_off[t + 1] - b->tile_off[t]);
+            const int waves = std::min({n_tiles, n_cu_dev[b->device & 63].load(), 2 * widest + 8});
+            HIP_TRY(hipMemsetAsync(b->d_flow, 0, sizeof(int) * b->flow_ints, st));
+            hipLaunchKernelGGL(pg_fill_tiles_flow, dim3(waves), dim3(64), pg_tiles_lds_bytes(),
+                               st, b->d_jobs, b->d_tiles, n_tiles, n_diag, b->d_flow, b->flags,
+                               b->tiles_water ? 1 : (4ll * n_tiles >= 7ll * n_cu_dev[b->device & 63].load() * n_diag || b->tiles_nolag ? 2 : 0));
+        } else {
+            for (size_t t = 0; t + 1 < b->tile_off.size(); ++t) {
+                const int cnt = b->tile_off[t + 1] - b->tile_off[t];
+                if (cnt > 0)
+                    hipLaunchKernelGGL(pg_fill_tiles, dim3(cnt), dim3(64), pg_tiles_lds_bytes(), st, b->d_jobs,
+                                       b->d_tiles + 4 * (size_t)b->tile_off[t], b->flags);
+            }
         }
     }
     if (b->tile_off.size() > 1 && b->stream2) {

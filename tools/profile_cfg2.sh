@@ -1,3 +1,4 @@
+# rocprofv3 kernel statistics of the cfg2 pass (16 x 2 kb, full matrices, tiled kernel): gpurun_out/prof_r02_cfg2/bench_cfg2_tiles_kernel_stats.csv
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
