@@ -351,7 +351,65 @@ ArenaPool arena_pool;
 
 } // namespace
 
+// ---- dead sites ----------------------------------------------------------------------------------------------------
+// A site without bwd edges (other than the start site) -- or with bwd edges from such sites only -- has no live
+// predecessor: every cell of its row / column is -inf in all three states, nothing can leave it, and no path visits it (the path SKIPS it: insert_preexisting_gap,
+// viterbi_alignment.h:146-193, restated in replay()).  High in a deep tree such sites are many (root of 512 x 10 kb: 44 %
+// of each sequence), so the alignment is run on the COMPACTED graphs -- dead sites removed, the edges that start at one
+// dropped (their candidates are -inf), the band re-indexed -- and the device's path is mapped back to the caller's site
+// numbers and edge-list positions before replay() turns it into columns and used edges.  Scores, path and used edges are
+// the ones of the full matrices; `cells` stays the caller's count.  PAGAN_DP_COMPACT=0 switches it off.
+struct CompactSide {
+    std::vector<int> keep;       // compacted site -> caller's site
+    std::vector<int> state, off, src, eid, slot;   // compacted graph arrays; slot: position of the edge in the caller's list of its site
+    std::vector<float> w;
+    pagan_graph g;
+    int dead = 0;
+    void build(const pagan_graph *o) {
+        const int n = o->n_sites;
+        std::vector<int> newidx(n, -1);
+        keep.clear();
+        for (int s_ = 0; s_ < n; ++s_) {
+            // dead: no bwd edge, or (bwd edges point to earlier sites, so one ascending pass sees the whole cascade) none
+            // from a site that is alive
+            bool is_dead = s_ != 0 && s_ != n - 1;
+            for (int e = o->bwd_off[s_]; is_dead && e < o->bwd_off[s_ + 1]; ++e) {
+                const int from = o->bwd_src[e];
+                if (from >= s_ || (from >= 0 && newidx[from] >= 0)) is_dead = false;      // (an edge that is not backward: keep the site)
+            }
+            if (is_dead) { ++dead; continue; }
+            newidx[s_] = (int)keep.size();
+            keep.push_back(s_);
+        }
+        const int m = (int)keep.size();
+        state.resize(m); off.assign(m + 1, 0);
+        src.clear(); eid.clear(); slot.clear(); w.clear();
+        for (int t = 0; t < m; ++t) {
+            const int s_ = keep[t];
+            state[t] = o->state[s_];
+            off[t] = (int)src.size();
+            for (int e = o->bwd_off[s_]; e < o->bwd_off[s_ + 1]; ++e) {
+                const int from = o->bwd_src[e];
+                if (from < 0 || from >= n || newidx[from] < 0) continue;      // (a bad index is check_graph's to report)
+                src.push_back(newidx[from]); w.push_back(o->bwd_logw[e]); eid.push_back(o->bwd_eid[e]); slot.push_back(e - o->bwd_off[s_]);
+            }
+        }
+        off[m] = (int)src.size();
+        g.n_sites = m; g.n_edges = o->n_edges; g.state = state.data(); g.bwd_off = off.data();
+        g.bwd_src = src.data(); g.bwd_logw = w.data(); g.bwd_eid = eid.data();
+    }
+};
+struct CompactJob {
+    bool on = false;
+    const pagan_graph *L0 = nullptr, *R0 = nullptr;   // the caller's graphs
+    int64_t cells0 = 0;                               // the caller's in-band cells
+    CompactSide l, r;
+    std::vector<int> up, lo;
+    pagan_band band;
+};
+
 struct pagan_batch {
+    std::vector<CompactJob> compact;
     int n = 0;
     int device = 0;
     uint32_t flags = 0;
@@ -872,17 +930,66 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     const bool verbose = std::getenv("PAGAN_DP_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tc0 = now();
+    // dead sites out (see CompactJob): the rest of this function works on the effective jobs
+    std::vector<pagan_job> eff(jobs, jobs + n);
+    b->compact.resize(n);
+    {
+        const char *ce = std::getenv("PAGAN_DP_COMPACT");
+        const bool allow = !(ce && std::strcmp(ce, "0") == 0);
+        parallel_jobs(n, [&](int k) {
+            const pagan_job &jb = jobs[k];
+            CompactJob &cj = b->compact[k];
+            if (!allow || !jb.left || !jb.right || !jb.model) return;
+            if (check_graph(jb.left) != PAGAN_OK || check_graph(jb.right) != PAGAN_OK) return;     // validate_job reports it
+            const int nl = jb.left->n_sites, nr = jb.right->n_sites;
+            int dl = 0, dr = 0;
+            for (int s_ = 1; s_ + 1 < nl; ++s_) dl += jb.left->bwd_off[s_ + 1] == jb.left->bwd_off[s_];
+            for (int s_ = 1; s_ + 1 < nr; ++s_) dr += jb.right->bwd_off[s_ + 1] == jb.right->bwd_off[s_];
+            if (20 * (dl + dr) < nl + nr) return;                      // under 5 %: not worth the copies
+            // (what validate_job would refuse on the caller's graphs must not slip through on the smaller ones)
+            for (int s_ = 1; s_ + 1 < nl; ++s_) if (jb.left->state[s_] < 0 || jb.left->state[s_] >= jb.model->n_states) return;
+            for (int s_ = 1; s_ + 1 < nr; ++s_) if (jb.right->state[s_] < 0 || jb.right->state[s_] >= jb.model->n_states) return;
+            RowBand rb0;
+            if (rb0.build(nl - 1, nr - 1, jb.band) != PAGAN_OK) return;
+            cj.cells0 = rb0.cells();
+            cj.L0 = jb.left; cj.R0 = jb.right;
+            cj.l.build(jb.left); cj.r.build(jb.right);
+            eff[k].left = &cj.l.g; eff[k].right = &cj.r.g;
+            if (jb.band) {
+                // columns: the right graph's sites below its end site; kept columns before column c: before[c]
+                std::vector<int> before(nr, 0);
+                {
+                    size_t q = 0;
+                    for (int c = 0; c < nr; ++c) {
+                        before[c] = (int)q;
+                        if (q < cj.r.keep.size() && cj.r.keep[q] == c) ++q;
+                    }
+                }
+                const int rows = (int)cj.l.keep.size() - 1;                 // kept sites below the left end site
+                cj.up.resize(rows); cj.lo.resize(rows);
+                for (int t = 0; t < rows; ++t) {
+                    const int i = cj.l.keep[t];
+                    const int a = rb0.lo[i], z = rb0.hi[i];               // clamped to the matrix by RowBand
+                    cj.up[t] = before[a];                                   // first kept column >= a
+                    cj.lo[t] = (z + 1 < nr ? before[z + 1] : before[nr - 1] + 1) - 1;      // last kept column <= z
+                }
+                cj.band.n = rows; cj.band.upper = cj.up.data(); cj.band.lower = cj.lo.data();
+                eff[k].band = &cj.band;
+            }
+            cj.on = true;
+        });
+    }
     parallel_jobs(n, [&](int k) {
         RowBand rb;
-        job_rc[k] = validate_job(jobs[k], &b->jobs[k], &rb, b->use_pipe);
+        job_rc[k] = validate_job(eff[k], &b->jobs[k], &rb, b->use_pipe);
     });
     for (int k = 0; k < n; ++k) {
         const int rc = job_rc[k];
         if (rc != PAGAN_OK) return rc;
-        b->cells += b->jobs[k].dx.cells;
+        b->cells += b->compact[k].on ? b->compact[k].cells0 : b->jobs[k].dx.cells;       // the caller's cells
         if (b->jobs[k].n_bound > b->max_bound) b->max_bound = b->jobs[k].n_bound;
         if (b->jobs[k].ring_ok && !force_v1) {
-            (jobs[k].model->n_states <= 16 ? which_ring : which_ring_big).push_back(k);
+            (eff[k].model->n_states <= 16 ? which_ring : which_ring_big).push_back(k);
             continue;
         }
         if (use_tiles && !b->jobs[k].ring_ok && !b->jobs[k].tiles.empty()) { which_tiled.push_back(k); continue; }
@@ -972,7 +1079,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     int *which_off = sizer.take<int>(n);
     int *tiles_off = sizer.take<int>(tile_list.size());
     int *flow_off = sizer.take<int>(b->flow_ints);
-    for (int k = 0; k < n; ++k) carve_job(sizer, jobs[k], b->jobs[k], &b->dj[k]);
+    for (int k = 0; k < n; ++k) carve_job(sizer, eff[k], b->jobs[k], &b->dj[k]);
     const size_t in_bytes = sizer.cur;
     b->out_begin = in_bytes;
     for (int k = 0; k < n; ++k) carve_outputs(sizer, b->jobs[k], &b->dj[k]);
@@ -994,7 +1101,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     Stage stage(in_bytes);
     if (!stage.data()) return PAGAN_E_NOMEM;
     parallel_jobs(n, [&](int k) {
-        const pagan_job &jb = jobs[k];
+        const pagan_job &jb = eff[k];
         const HostJob &hj = b->jobs[k];
         const PgDevJob &d = b->dj[k];
         const pagan_graph *L = jb.left, *R = jb.right;
@@ -1147,6 +1254,43 @@ int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
     }
     std::vector<int> rcs(b->n, PAGAN_OK);
     parallel_jobs(b->n, [&](int k) {
+        const CompactJob &cj = b->compact[k];
+        if (cj.on && (got[k].endcell[0] == 0 || got[k].endcell[0] == 1)) {
+            // the device's path in the caller's site numbers and edge-list positions, then the usual replay on the caller's graphs
+            Fetched &f = got[k];
+            const CompactSide &cl = cj.l, &cr = cj.r;
+            const int ml = (int)cl.keep.size(), mr = (int)cr.keep.size();
+            bool ok = true;
+            auto site = [&](const CompactSide &c, int m_, int t) { if (t < 0 || t >= m_) { ok = false; return 0; } return c.keep[t]; };
+            auto slot_of = [&](const CompactSide &c, int m_, int t, int k_) {
+                if (t < 0 || t >= m_ || k_ < 0 || k_ >= c.off[t + 1] - c.off[t]) { ok = false; return 0; }
+                return c.slot[c.off[t] + k_];
+            };
+            if (f.endcell[4] >= 0) f.endcell[4] = slot_of(cl, ml, ml - 1, f.endcell[4]);
+            if (f.endcell[5] >= 0) f.endcell[5] = slot_of(cr, mr, mr - 1, f.endcell[5]);
+            if (f.endcell[0] == 0) {
+                f.endcell[2] = site(cl, ml, f.endcell[2]); f.endcell[3] = site(cr, mr, f.endcell[3]);
+                const int nt = f.endcell[6];
+                for (int t = 0; t < nt && ok; ++t) {
+                    const int ci = f.trace[3 * t], cjx = f.trace[3 * t + 1];
+                    const unsigned w_ = (unsigned)f.trace[3 * t + 2];
+                    const int vit = (int)(w_ & 3u);
+                    int k1 = (int)((w_ >> 4) & 16383u), k2 = (int)(w_ >> 18);
+                    if (vit != PAGAN_Y_MAT) k1 = slot_of(cl, ml, ci, k1);
+                    if (vit != PAGAN_X_MAT) k2 = slot_of(cr, mr, cjx, k2);
+                    f.trace[3 * t] = site(cl, ml, ci); f.trace[3 * t + 1] = site(cr, mr, cjx);
+                    f.trace[3 * t + 2] = (int)((w_ & 15u) | ((unsigned)k1 << 4) | ((unsigned)k2 << 18));
+                }
+            }
+            if (!ok) { rcs[k] = PAGAN_E_INTERNAL; return; }
+            HostJob orig;
+            orig.L = cj.L0; orig.R = cj.R0; orig.Lx = cj.L0->n_sites - 1; orig.Ly = cj.R0->n_sites - 1;
+            orig.dx.cells = cj.cells0;
+            rcs[k] = replay(orig, f.endcell, f.endscore, f.trace.data(), &out[k]);
+            out[k].fill_ms = ms[0];
+            out[k].trace_ms = ms[1];
+            return;
+        }
         rcs[k] = replay(b->jobs[k], got[k].endcell, got[k].endscore, got[k].trace.data(), &out[k]);
         out[k].fill_ms = ms[0];
         out[k].trace_ms = ms[1];

@@ -173,3 +173,27 @@ def test_band_whose_tiles_are_no_staircase(pg, oracle):
     assert len(tiles) > 30
     model = synth.random_model(15, 17)
     same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band))
+
+
+@pytest.mark.parametrize("compact", ["on", "off"])
+@pytest.mark.parametrize("p_dead", [0.06, 0.3, 0.6])
+def test_many_dead_sites(pg, oracle, monkeypatch, compact, p_dead):
+    """Sites without bwd edges make whole rows / columns -inf; from 5 % on the library aligns the compacted graphs and maps
+    the path back (dp_abi.hip: CompactJob).  Full matrix, wide band and a narrow band (the banded kernel), edges that start
+    at dead sites included; with PAGAN_DP_COMPACT=0 the same inputs go through uncompacted."""
+    if compact == "off":
+        monkeypatch.setenv("PAGAN_DP_COMPACT", "0")
+    left = synth.random_graph(900, 15, 501, p_extra=0.15, max_deg=4, max_span=40, p_dead=p_dead)
+    right = synth.random_graph(840, 15, 502, p_extra=0.15, max_deg=4, max_span=40, p_dead=p_dead)
+    model = synth.random_model(15, 21)
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    centre = np.arange(Lx) * (Ly - 1) // (Lx - 1)
+    narrow_u = np.maximum.accumulate(np.maximum(centre - 60, 0)); narrow_l = np.maximum.accumulate(np.minimum(centre + 60, Ly - 1))
+    narrow_u[0] = 0; narrow_l[-1] = Ly - 1
+    jobs = [(left, right, model, None), (left, right, model, wide_band(Lx, Ly, 400, 3)),
+            (left, right, model, abi.Band(narrow_u, narrow_l)), (right, left, model, None)]
+    got = pg.align_batch(jobs)
+    for k, (l, r, m, bd) in enumerate(jobs):
+        want = oracle.dp_align(l, r, m, bd)
+        same(got[k], want, "p_dead %.2f compact %s job %d" % (p_dead, compact, k))
+        assert got[k].cells == want.cells
