@@ -372,7 +372,9 @@ struct CompactSide {
         for (int s_ = 0; s_ < n; ++s_) {
             // dead: no bwd edge, or (bwd edges point to earlier sites, so one ascending pass sees the whole cascade) none
             // from a site that is alive
-            bool is_dead = s_ != 0 && s_ != n - 1;
+            // (the last site before the end site stays whatever it is: the terminal-gap rules, VA:875-879 and its X twin,
+            // name the LAST row / column of the matrix, and that must be the same site in both numberings)
+            bool is_dead = s_ != 0 && s_ < n - 2;
             for (int e = o->bwd_off[s_]; is_dead && e < o->bwd_off[s_ + 1]; ++e) {
                 const int from = o->bwd_src[e];
                 if (from >= s_ || (from >= 0 && newidx[from] >= 0)) is_dead = false;      // (an edge that is not backward: keep the site)
@@ -943,8 +945,8 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             if (check_graph(jb.left) != PAGAN_OK || check_graph(jb.right) != PAGAN_OK) return;     // validate_job reports it
             const int nl = jb.left->n_sites, nr = jb.right->n_sites;
             int dl = 0, dr = 0;
-            for (int s_ = 1; s_ + 1 < nl; ++s_) dl += jb.left->bwd_off[s_ + 1] == jb.left->bwd_off[s_];
-            for (int s_ = 1; s_ + 1 < nr; ++s_) dr += jb.right->bwd_off[s_ + 1] == jb.right->bwd_off[s_];
+            for (int s_ = 1; s_ + 2 < nl; ++s_) dl += jb.left->bwd_off[s_ + 1] == jb.left->bwd_off[s_];
+            for (int s_ = 1; s_ + 2 < nr; ++s_) dr += jb.right->bwd_off[s_ + 1] == jb.right->bwd_off[s_];
             if (20 * (dl + dr) < nl + nr) return;                      // under 5 %: not worth the copies
             // (what validate_job would refuse on the caller's graphs must not slip through on the smaller ones)
             for (int s_ = 1; s_ + 1 < nl; ++s_) if (jb.left->state[s_] < 0 || jb.left->state[s_] >= jb.model->n_states) return;

@@ -197,3 +197,30 @@ def test_many_dead_sites(pg, oracle, monkeypatch, compact, p_dead):
         want = oracle.dp_align(l, r, m, bd)
         same(got[k], want, "p_dead %.2f compact %s job %d" % (p_dead, compact, k))
         assert got[k].cells == want.cells
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dead_sites_at_the_matrix_edges(pg, oracle, seed):
+    """The terminal-gap rules name the first and the last row / column: with the last real site of a sequence dead (and
+    the first ones), the compacted matrices must still apply them to the same sites."""
+    rng = np.random.default_rng(900 + seed)
+    left = synth.random_graph(500, 15, 600 + seed, p_extra=0.15, max_deg=4, max_span=40, p_dead=0.3)
+    right = synth.random_graph(460, 15, 700 + seed, p_extra=0.15, max_deg=4, max_span=40, p_dead=0.3)
+
+    def kill(g, sites):
+        """the given sites lose their bwd edges"""
+        off = g.bwd_off.astype(np.int64)
+        keep = np.ones(int(off[-1]), bool)
+        for s in sites:
+            keep[off[s]:off[s + 1]] = False
+        cnt = np.diff(off)
+        cnt[list(sites)] = 0
+        new_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+        return abi.Graph(g.state, new_off, g.bwd_src[keep], g.bwd_logw[keep], g.bwd_eid[keep], n_edges=g.n_edges)
+
+    n_l, n_r = left.n_sites, right.n_sites
+    left2 = kill(left, [n_l - 2] + ([1, 2] if seed % 2 else []))
+    right2 = kill(right, [n_r - 2] if seed % 3 else [1])
+    model = synth.random_model(15, 31 + seed)
+    for flags in (0, abi.OPT_NO_TERMINAL_EDGES, abi.OPT_NO_REDUCED_TERMINAL_PEN):
+        same(pg.align(left2, right2, model, flags=flags), oracle.dp_align(left2, right2, model, flags=flags), "seed %d flags %d" % (seed, flags))
