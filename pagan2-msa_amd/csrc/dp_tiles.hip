@@ -668,15 +668,16 @@ __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__
 // edge of this tile's cells can reach.  Otherwise (`use_water` 1) a tile also waits until every tile of the diagonals <= t-2
 // is done (`fin[t']` counts finished tiles; a wave keeps a watermark).  `use_water` 0: staircase jobs, tiles start 80 steps
 // behind their neighbours (tile_body<true>); 2: staircase jobs, a tile waits for its neighbours to finish -- the host picks
-// it when the batch has more tiles per anti-diagonal than the chip has compute units (the lag buys nothing then and its
-// progress flags and block-wise halo cost 15 %).
+// it when the batch has more than 1.75 x as many tiles per anti-diagonal as the chip has compute units (the lag buys
+// nothing then and its progress flags and block-wise halo cost 15 %).
 // A wave only ever waits for tiles that were handed out before its own -- to waves that are running -- so the queue drains.
 // Visibility across the XCDs' L2s: the finishing wave's stores are released at agent scope before its flags are set, the
 // starting wave acquires at agent scope after it has seen them (the compiler's gfx950 memory model: write-back of the
 // L2 / invalidate); the flags themselves are agent-scope atomics.
 // tiles: 4 * (n_tiles + 1) ints of {job, a, b, list position of (a-1,b) or -1}, then n_tiles list positions of (a,b-1) or
-// -1, the same for (a-1,b-1), then n_diag + 1 first-tile offsets per diagonal.  flow (zeroed by the host before every launch): [0] next tile,
-// [1 .. n_diag] finished tiles per diagonal, then n_tiles done flags.
+// -1, the same for (a-1,b-1), then n_diag + 1 first-tile offsets per diagonal.  flow (zeroed by the host before every
+// launch): [0] next tile, [1 .. n_diag] finished tiles per diagonal, then n_tiles progress words (steps published; TDONE:
+// finished), then the give-up flag (flow_wait).
 __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restrict__ jobs, const int *__restrict__ tiles,
                                                          int n_tiles, int n_diag, int *__restrict__ flow, unsigned flags,
                                                          int use_water) {
