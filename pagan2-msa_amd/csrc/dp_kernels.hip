@@ -464,12 +464,23 @@ struct TNode { int i, j, vit; };
 __device__ __forceinline__ bool trace_done(const TNode &n) { return n.i < 1 && n.j < 1; }
 
 // One chase step: emit (i, j, w) for the cell `n` names and move to its predecessor.
-__device__ __forceinline__ bool trace_step(const View &J, TNode &n, int &w) {
+// A chase is a chain of dependent loads (descriptor of the diagonal -> back-pointer -> edge list); the descriptors of the two
+// diagonals a step usually moves to (dd-1: a gap move, dd-2: a match, both through an edge from the previous site) are
+// requested together with the back-pointer and kept in `C`, so that a step costs one round trip instead of two.
+struct TCache { int d0 = -1000; pg_i4 a, b, c; };     // descriptors {imin, imax, doff low, doff high} of d0, d0-1, d0-2
+__device__ __forceinline__ bool trace_step(const View &J, TNode &n, int &w, TCache &C) {
     if (n.vit < 0 || n.vit > 2 || n.i < 0 || n.j < 0 || n.i >= J.Lx || n.j >= J.Ly) return false;
     const int dd = n.i + n.j;
-    const int mn = J.imin[dd], mx = J.imax[dd];
+    PG_GLOBAL const pg_i4 *gd = (PG_GLOBAL const pg_i4 *)(unsigned long long)J.dsc;
+    const int back = C.d0 - dd;
+    pg_i4 D;
+    if (back == 0) { D = C.a; }
+    else if (back == 1) { D = C.b; C.a = C.b; C.b = C.c; C.c = gd[dd >= 2 ? dd - 2 : 0]; C.d0 = dd; }
+    else if (back == 2) { D = C.c; C.a = C.c; C.b = gd[dd >= 1 ? dd - 1 : 0]; C.c = gd[dd >= 2 ? dd - 2 : 0]; C.d0 = dd; }
+    else { D = gd[dd]; C.a = D; C.b = gd[dd >= 1 ? dd - 1 : 0]; C.c = gd[dd >= 2 ? dd - 2 : 0]; C.d0 = dd; }
+    const int mn = D.x, mx = D.y;
     if (n.i < mn || n.i > mx) return false;
-    const long long ix = J.doff[dd] + (n.i - mn);
+    const long long ix = (((long long)D.w << 32) | (unsigned)D.z) + (n.i - mn);
     const unsigned b = J.bp[3 * ix + n.vit];
     w = (int)((unsigned)n.vit | (b & ~3u));
     const unsigned from = b & 3u;
@@ -568,11 +579,12 @@ __global__ __launch_bounds__(128) void pg_trace_spec(const PgDevJob *__restrict_
         n.vit = e % 3;
         int steps = 0, kind = EXIT_DONE, w;
         bool ok = true;
+        TCache tc;
         for (;;) {
             if (trace_done(n)) { kind = EXIT_DONE; break; }
             const int dd = n.i + n.j;
             if (steps > 0 && k > 1 && dd <= low) { kind = dd >= low - 1 ? EXIT_ENTRY : EXIT_MISS; break; }
-            if (steps > 4 * PG_SEG || !trace_step(J, n, w)) { ok = false; break; }
+            if (steps > 4 * PG_SEG || !trace_step(J, n, w, tc)) { ok = false; break; }
             ++steps;
         }
         // where the chase arrived, and -- when that is a cell of the next lower boundary -- its entry there,
@@ -600,6 +612,7 @@ __global__ void pg_trace_compose(const PgDevJob *__restrict__ jobs) {
     int off = 0, nseg = 0, status = 0;
     gint_w tr = J.trace;
     long long cur = -1;                 // table entry of node n, when the previous hop delivered it
+    TCache tc;
     while (!trace_done(n)) {
         if (off >= cap) { status = 2; break; }
         if (cur < 0) {
@@ -626,7 +639,7 @@ __global__ void pg_trace_compose(const PgDevJob *__restrict__ jobs) {
             // jumped over a pair): chase serially until one is reached
             int w;
             const int ci = n.i, cj = n.j;
-            if (!trace_step(J, n, w)) { status = 2; break; }
+            if (!trace_step(J, n, w, tc)) { status = 2; break; }
             tr[3 * off] = ci; tr[3 * off + 1] = cj; tr[3 * off + 2] = w;
             ++off;
         }
@@ -644,10 +657,11 @@ __global__ __launch_bounds__(64) void pg_trace_emit(const PgDevJob *__restrict__
     TNode n; n.i = sg[0]; n.j = sg[1]; n.vit = sg[2];
     const int steps = sg[3];
     gint_w tr = J.trace + 3 * (long long)sg[4];
+    TCache tc;
     for (int t = 0; t < steps; ++t) {
         int w;
         const int ci = n.i, cj = n.j;
-        if (!trace_step(J, n, w)) { J.endcell[0] = 2; return; }     // cannot happen: pg_trace_spec walked the same cells
+        if (!trace_step(J, n, w, tc)) { J.endcell[0] = 2; return; }     // cannot happen: pg_trace_spec walked the same cells
         tr[3 * t] = ci; tr[3 * t + 1] = cj; tr[3 * t + 2] = w;
     }
 }
