@@ -220,7 +220,8 @@ def bench_one_gpu(args, device):
                                  "frac_of_floor": STEP_FLOOR_US / us_per_step,
                                  "note": "steps = anti-diagonals on the critical path (longest alignment of every level); "
                                          "floor from tools/ubench/issue_rate.hip"}},
-        "kernels_ms": {"fill": fill_step_ms, "end_and_trace": float(trace_ms.mean(axis=0).sum())},
+        "kernels_ms": {"fill": fill_step_ms, "end_and_trace": float(trace_ms.mean(axis=0).sum()),
+                       "end_and_trace_by_level": [float(x) for x in trace_ms.mean(axis=0)]},
         "e2e_wall_s": e2e_wall,
         "e2e_wall_first_in_process_s": e2e_wall_cold,
         "e2e_cells_per_s": cells / e2e_wall,

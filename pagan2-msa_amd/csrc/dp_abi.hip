@@ -471,20 +471,26 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
         const int nd = hj->Lx + hj->Ly - 1;
         hj->n_bound = (nd - 1) / PG_SEG;
         hj->tb.assign(hj->n_bound + 2, 0);
-        int run = 0;
+        int run = 0, widest = 0;
         for (int k = 1; k <= hj->n_bound; ++k) {
             hj->tb[k] = run;
             const int D = k * PG_SEG;
             const int wa = hj->dx.imax[D] - hj->dx.imin[D] + 1, wb = hj->dx.imax[D - 1] - hj->dx.imin[D - 1] + 1;
-            run += 3 * ((wa > 0 ? wa : 0) + (wb > 0 ? wb : 0));
+            const int e = 3 * ((wa > 0 ? wa : 0) + (wb > 0 ? wb : 0));
+            run += e;
+            widest = std::max(widest, e);
         }
         hj->tb[hj->n_bound + 1] = run;
         // The segmented traceback chases from EVERY cell of every boundary: worth it for a narrow
         // band over a long path (2 x 100 kb: 2.6e5 chases of 128 cells against one chase of 2e5),
         // wasteful for a short path through a full matrix (thousands of cells per boundary).  Fall
         // back to the single serial chase (pg_trace_compose with no boundaries) in that case.
+        // Measured: a chase of PG_SEG cells takes ~PG_SEG us (a chain of dependent L2 / HBM reads) and a boundary's entries are
+        // dealt over the 128 threads of one workgroup; the serial chase costs 0.3 - 1.4 us per cell of the path.  So: short
+        // paths serially; paths under 20,000 cells segmented only through a narrow band (512 leaves of 10 kb: 13.7 -> 4.7 ms;
+        // 16 x 2 kb full matrices stay serial: 2 ms against 12); anything whose speculative work dwarfs the path serially.
         const long long speculative = (long long)run / 3 * PG_SEG, serial = (long long)hj->Lx + hj->Ly;
-        if (serial < 20000 || speculative > 2000 * serial) {
+        if (serial < 2000 || (serial < 20000 && widest > 3000) || speculative > 2000 * serial) {
             hj->n_bound = 0;
             hj->tb.assign(2, 0);
         }
