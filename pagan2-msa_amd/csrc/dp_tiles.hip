@@ -354,11 +354,23 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
 #endif
         if (LAG && s < TS && (s & (TBLK - 1)) == 0) {
             const int need = s + TBLK - 1 + TS;                   // the neighbours' steps <= s + TBLK - 1 + 63 are published
+#ifdef PG_TILE_STATS
+            const unsigned long long lw0 = __builtin_amdgcn_s_memtime();
+#endif
             wait_prog(up, need < 2 * TS - 1 ? need : TDONE);
             wait_prog(lf, need < 2 * TS - 1 ? need : TDONE);
+#ifdef PG_TILE_STATS
+            const unsigned long long lw1 = __builtin_amdgcn_s_memtime();
+#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             halo_block(s / TBLK);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef PG_TILE_STATS
+            if (r == 0) {      // [13] waiting for the neighbours' progress, [14] acquire + halo block
+                unsigned long long *out = (unsigned long long *)(jobs[T.x].trace + ((3 * (J.Lx + J.Ly) - 64) & ~1));
+                atomicAdd(out + 13, lw1 - lw0); atomicAdd(out + 14, __builtin_amdgcn_s_memtime() - lw1);
+            }
+#endif
         }
         const pg_i4 Dn = TM.dsc[TDB + s + 1];
         const int jj = s - r;
