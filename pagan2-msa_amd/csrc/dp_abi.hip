@@ -692,7 +692,8 @@ int launch_fill(pagan_batch *b) {
             HIP_TRY(hipMemsetAsync(b->d_flow, 0, sizeof(int) * b->flow_ints, st));
             hipLaunchKernelGGL(pg_fill_tiles_flow, dim3(waves), dim3(64), pg_tiles_lds_bytes(),
                                st, b->d_jobs, b->d_tiles, n_tiles, n_diag, b->d_flow, b->flags,
-                               b->tiles_water ? 1 : (4ll * n_tiles >= 7ll * n_cu_dev[b->device & 63].load() * n_diag || b->tiles_nolag ? 2 : 0));
+                               b->tiles_water ? 1 : (4ll * n_tiles >= 7ll * n_cu_dev[b->device & 63].load() * n_diag || b->tiles_nolag ? 2 :
+                                                      (2ll * n_tiles < (long long)n_cu_dev[b->device & 63].load() * n_diag ? 3 : 0)));
         } else {
             for (size_t t = 0; t + 1 < b->tile_off.size(); ++t) {
                 const int cnt = b->tile_off[t + 1] - b->tile_off[t];

@@ -118,7 +118,7 @@ __device__ __forceinline__ void flow_wait(int *p, int need, int *giveup, int *st
 // back, which were TLAG steps ahead of those.
 #define TBLK 16                    // (TH + TBLK) * TH + TBLK * TH <= 5 * 64: halo_block's five cells per lane
 #define TDONE (1 << 20)
-template <bool LAG>
+template <bool LAG, int TB = TBLK>
 __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, const pg_i4 T, unsigned flags, int *prog = nullptr,
                                           int self = -1, int up = -1, int lf = -1, int *giveup = nullptr) {
     const bool no_terminal_edges = flags & 1u;
@@ -300,12 +300,12 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
 #ifdef PG_TILE_STATS
     const unsigned long long st_loop = __builtin_amdgcn_s_memtime();
 #endif
-    // LAG: the halo cells of one block of steps (k = s / TBLK, s < TS): columns j0 + TBLK k ... of the TH rows above (the
-    // first block also takes the corner), rows i0 + TBLK k ... of the TH columns to the left
+    // LAG: the halo cells of one block of steps (k = s / TB, s < TS): columns j0 + TB k ... of the TH rows above (the
+    // first block also takes the corner), rows i0 + TB k ... of the TH columns to the left
     auto halo_block = [&](int k) {
-        const int c0 = k == 0 ? -TH : TBLK * k, ncol = k == 0 ? TH + TBLK : TBLK;
-        const int ntop = ncol * TH, nall = ntop + TBLK * TH;
-        // at most five cells per lane ((TH + TBLK) * TH + TBLK * TH = 320): requested together, one wait
+        const int c0 = k == 0 ? -TH : TB * k, ncol = k == 0 ? TH + TB : TB;
+        const int ntop = ncol * TH, nall = ntop + TB * TH;
+        // at most five cells per lane ((TH + TB) * TH + TB * TH = 320): requested together, one wait
         bool hv_[5];
         int hat_[5];
         PG_GLOBAL const double *hp_[5];
@@ -316,7 +316,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
             const int e = r + 64 * u;
             int p, q;
             if (e < ntop) { p = i0 - TH + e / ncol; q = j0 + c0 + e % ncol; }
-            else { const int e2 = e - ntop; q = j0 - TH + e2 / TBLK; p = i0 + TBLK * k + e2 % TBLK; }
+            else { const int e2 = e - ntop; q = j0 - TH + e2 / TB; p = i0 + TB * k + e2 % TB; }
             hv_[u] = e < nall && p >= 0 && q >= 0 && p < J.Lx && q < J.Ly;
             const pg_i4 F = TM.dsc[hv_[u] ? p + q - (dbase - TDB) : TDB];
             hv_[u] = hv_[u] && p >= F.x && p <= F.y;
@@ -352,8 +352,8 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
         const unsigned long long st_a = __builtin_amdgcn_s_memtime();
         int st_kind = -1;
 #endif
-        if (LAG && s < TS && (s & (TBLK - 1)) == 0) {
-            const int need = s + TBLK - 1 + TS;                   // the neighbours' steps <= s + TBLK - 1 + 63 are published
+        if (LAG && s < TS && (s & (TB - 1)) == 0) {
+            const int need = s + TB - 1 + TS;                   // the neighbours' steps <= s + TB - 1 + 63 are published
 #ifdef PG_TILE_STATS
             const unsigned long long lw0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -363,7 +363,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
             const unsigned long long lw1 = __builtin_amdgcn_s_memtime();
 #endif
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            halo_block(s / TBLK);
+            halo_block(s / TB);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef PG_TILE_STATS
             if (r == 0) {      // [13] waiting for the neighbours' progress, [14] acquire + halo block
@@ -639,8 +639,8 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
         }
         D = Dn; c = cn; ce = cen;
         asm volatile("" ::: "memory");
-        // (the first progress anybody waits for is TS + TBLK - 1)
-        if (LAG && (s & (TBLK - 1)) == TBLK - 1 && s >= TS && s < s_last) {
+        // (the first progress anybody waits for is TS + TB - 1)
+        if (LAG && (s & (TB - 1)) == TB - 1 && s >= TS && s < s_last) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (waits for the wave's stores, writes the L2 back)
             if (r == 0) __hip_atomic_store(&prog[self], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -716,7 +716,8 @@ __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restr
 #ifdef PG_TILE_STATS
         const unsigned long long fs1 = __builtin_amdgcn_s_memtime();
 #endif
-        if (use_water) {
+        const bool lag = use_water == 0 || use_water == 3;
+        if (!lag) {
             if (T.w >= 0) wait_ge(&done[T.w], TDONE);
             if (lf >= 0) wait_ge(&done[lf], TDONE);
             if (use_water == 2 && dg >= 0) wait_ge(&done[dg], TDONE);
@@ -725,7 +726,8 @@ __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restr
         const unsigned long long fs2 = __builtin_amdgcn_s_memtime();
 #endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (use_water) tile_body<false>(jobs, T, flags);
+        if (!lag) tile_body<false>(jobs, T, flags);
+        else if (use_water == 3) tile_body<true, 8>(jobs, T, flags, done, idx, T.w, lf, giveup);
         else tile_body<true>(jobs, T, flags, done, idx, T.w, lf, giveup);
 #ifdef PG_TILE_STATS
         const unsigned long long fs3 = __builtin_amdgcn_s_memtime();
