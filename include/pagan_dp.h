@@ -187,6 +187,15 @@ int  pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, cons
  * min(count, cap)), 0 when the job cannot be tiled (a tile's sites have too many bwd edges), < 0 on error */
 int  pagan_dp_debug_tiles(const pagan_graph *left, const pagan_graph *right, const pagan_band *band,
                           int32_t *tiles /* [2 * cap] */, int32_t cap, int32_t *tile_side);
+/* diagnostic, host only: what the library does about sites without a live predecessor (from 5 % of a job's sites
+ * on it aligns the compacted graphs and maps the path back; PAGAN_DP_COMPACT=0 switches that off).  keep_*[t] = the
+ * caller's site of compacted site t ([n_sites] at most); slot_*[e] = for the compacted graph's bwd edges in order, the
+ * position of the edge in the caller's list of its site ([bwd_off[n_sites]] at most); upper / lower = the band over the
+ * compacted matrices ([n_sites of left] at most, NULL: not wanted); n_out[4] = kept left sites, kept right sites, kept
+ * left edges, kept right edges.  Any output pointer may be NULL. */
+int  pagan_dp_debug_compact(const pagan_graph *left, const pagan_graph *right, const pagan_band *band, int32_t *keep_left,
+                            int32_t *keep_right, int32_t *slot_left, int32_t *slot_right, int32_t *upper, int32_t *lower,
+                            int32_t *n_out);
 /* diagnostic: job k's scores, [cells][3] doubles (X, Y, M), diagonal-major                */
 int  pagan_batch_debug_scores(pagan_batch *b, int32_t k, double *dst, int64_t count);
 /* diagnostic: overwrite all device outputs with 0xFF (NaN scores) before a run           */

@@ -172,6 +172,24 @@ def debug_tiles(left, right, band=None):
     return side.value, [tuple(int(v) for v in out[2 * k: 2 * k + 2]) for k in range(min(n, cap))]
 
 
+def debug_compact(left, right, band=None):
+    """Diagnostic (host only): the compacted numbering the library aligns graphs with many dead sites in:
+    dict with keep_left / keep_right (compacted site -> caller's site), slot_left / slot_right (per kept bwd edge: its position
+    in the caller's list of its site), upper / lower (the band over the compacted matrices)."""
+    import numpy as np
+    L = lib()
+    p32 = C.POINTER(C.c_int32)
+    kl = np.zeros(left.n_sites, np.int32); kr = np.zeros(right.n_sites, np.int32)
+    sl = np.zeros(max(int(left.bwd_off[-1]), 1), np.int32); sr = np.zeros(max(int(right.bwd_off[-1]), 1), np.int32)
+    up = np.zeros(left.n_sites, np.int32); lo = np.zeros(left.n_sites, np.int32)
+    n = np.zeros(4, np.int32)
+    _check(L.pagan_dp_debug_compact(C.byref(left.c), C.byref(right.c), C.byref(band.c) if band is not None else None,
+                                    kl.ctypes.data_as(p32), kr.ctypes.data_as(p32), sl.ctypes.data_as(p32), sr.ctypes.data_as(p32),
+                                    up.ctypes.data_as(p32), lo.ctypes.data_as(p32), n.ctypes.data_as(p32)), "pagan_dp_debug_compact")
+    return {"keep_left": kl[:n[0]].copy(), "keep_right": kr[:n[1]].copy(), "slot_left": sl[:n[2]].copy(), "slot_right": sr[:n[3]].copy(),
+            "upper": up[:n[0] - 1].copy(), "lower": lo[:n[0] - 1].copy()}
+
+
 def debug_plan(left, right, band=None, with_lead=False):
     """Diagnostic (host only): (classes[Lx+Ly-1] uint8, [awake intervals of wave 0..3]) the banded fill kernel
     would be given for this job; with_lead adds the per-diagonal downstream-progress requirement."""

@@ -410,6 +410,28 @@ struct CompactJob {
     pagan_band band;
 };
 
+// The caller's band over the compacted matrices: row t is the caller's row l.keep[t]; its interval keeps the first / last
+// kept column inside the caller's interval (empty where none is).  rb0: the caller's band, clamped (RowBand).
+void compact_band(const RowBand &rb0, const CompactSide &l, const CompactSide &r, int nr, std::vector<int> *up, std::vector<int> *lo) {
+    // columns: the right graph's sites below its end site; kept columns before column c: before[c]
+    std::vector<int> before(nr, 0);
+    {
+        size_t q = 0;
+        for (int c = 0; c < nr; ++c) {
+            before[c] = (int)q;
+            if (q < r.keep.size() && r.keep[q] == c) ++q;
+        }
+    }
+    const int rows = (int)l.keep.size() - 1;                    // kept sites below the left end site
+    up->resize(rows); lo->resize(rows);
+    for (int t = 0; t < rows; ++t) {
+        const int i = l.keep[t];
+        const int a = rb0.lo[i], z = rb0.hi[i];                  // clamped to the matrix by RowBand
+        (*up)[t] = before[a];                                     // first kept column >= a
+        (*lo)[t] = (z + 1 < nr ? before[z + 1] : before[nr - 1] + 1) - 1;      // last kept column <= z
+    }
+}
+
 struct pagan_batch {
     std::vector<CompactJob> compact;
     int n = 0;
@@ -893,6 +915,32 @@ int pagan_dp_debug_tiles(const pagan_graph *left, const pagan_graph *right, cons
     return n;
 }
 
+int pagan_dp_debug_compact(const pagan_graph *left, const pagan_graph *right, const pagan_band *band, int32_t *keep_left,
+                           int32_t *keep_right, int32_t *slot_left, int32_t *slot_right, int32_t *upper, int32_t *lower,
+                           int32_t *n_out /* [4]: kept left sites, kept right sites, kept left edges, kept right edges */) {
+    if (!left || !right || !n_out) return PAGAN_E_ARG;
+    int rc;
+    if ((rc = check_graph(left)) != PAGAN_OK) return rc;
+    if ((rc = check_graph(right)) != PAGAN_OK) return rc;
+    CompactSide l, r;
+    l.build(left); r.build(right);
+    n_out[0] = (int32_t)l.keep.size(); n_out[1] = (int32_t)r.keep.size();
+    n_out[2] = (int32_t)l.slot.size(); n_out[3] = (int32_t)r.slot.size();
+    if (keep_left) std::copy(l.keep.begin(), l.keep.end(), keep_left);
+    if (keep_right) std::copy(r.keep.begin(), r.keep.end(), keep_right);
+    if (slot_left) std::copy(l.slot.begin(), l.slot.end(), slot_left);
+    if (slot_right) std::copy(r.slot.begin(), r.slot.end(), slot_right);
+    if (upper && lower) {
+        RowBand rb0;
+        if ((rc = rb0.build(left->n_sites - 1, right->n_sites - 1, band)) != PAGAN_OK) return rc;
+        std::vector<int> up, lo;
+        compact_band(rb0, l, r, right->n_sites, &up, &lo);
+        std::copy(up.begin(), up.end(), upper);
+        std::copy(lo.begin(), lo.end(), lower);
+    }
+    return PAGAN_OK;
+}
+
 int64_t pagan_dp_count_cells(int32_t left_sites, int32_t right_sites, const pagan_band *band) {
     if (left_sites < 2 || right_sites < 2) return PAGAN_E_ARG;
     RowBand rb;
@@ -965,23 +1013,8 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             cj.l.build(jb.left); cj.r.build(jb.right);
             eff[k].left = &cj.l.g; eff[k].right = &cj.r.g;
             if (jb.band) {
-                // columns: the right graph's sites below its end site; kept columns before column c: before[c]
-                std::vector<int> before(nr, 0);
-                {
-                    size_t q = 0;
-                    for (int c = 0; c < nr; ++c) {
-                        before[c] = (int)q;
-                        if (q < cj.r.keep.size() && cj.r.keep[q] == c) ++q;
-                    }
-                }
-                const int rows = (int)cj.l.keep.size() - 1;                 // kept sites below the left end site
-                cj.up.resize(rows); cj.lo.resize(rows);
-                for (int t = 0; t < rows; ++t) {
-                    const int i = cj.l.keep[t];
-                    const int a = rb0.lo[i], z = rb0.hi[i];               // clamped to the matrix by RowBand
-                    cj.up[t] = before[a];                                   // first kept column >= a
-                    cj.lo[t] = (z + 1 < nr ? before[z + 1] : before[nr - 1] + 1) - 1;      // last kept column <= z
-                }
+                compact_band(rb0, cj.l, cj.r, nr, &cj.up, &cj.lo);
+                const int rows = (int)cj.up.size();
                 cj.band.n = rows; cj.band.upper = cj.up.data(); cj.band.lower = cj.lo.data();
                 eff[k].band = &cj.band;
             }
