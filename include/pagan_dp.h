@@ -187,6 +187,10 @@ int  pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, cons
  * min(count, cap)), 0 when the job cannot be tiled (a tile's sites have too many bwd edges), < 0 on error */
 int  pagan_dp_debug_tiles(const pagan_graph *left, const pagan_graph *right, const pagan_band *band,
                           int32_t *tiles /* [2 * cap] */, int32_t cap, int32_t *tile_side);
+/* diagnostic, host only: 1 if the n tiles (tile row, tile column pairs) form a staircase -- every tile row a contiguous
+ * run of columns, first and last column never falling, no empty row between two rows, consecutive rows touching -- which
+ * is when the tiled kernel's dataflow launch orders a tile behind its three neighbours only; 0 otherwise; < 0 on error */
+int  pagan_dp_debug_tiles_staircase(const int32_t *tiles, int32_t n);
 /* diagnostic, host only: what the library does about sites without a live predecessor (from 5 % of a job's sites
  * on it aligns the compacted graphs and maps the path back; PAGAN_DP_COMPACT=0 switches that off).  keep_*[t] = the
  * caller's site of compacted site t ([n_sites] at most); slot_*[e] = for the compacted graph's bwd edges in order, the

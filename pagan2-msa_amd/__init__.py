@@ -172,6 +172,15 @@ def debug_tiles(left, right, band=None):
     return side.value, [tuple(int(v) for v in out[2 * k: 2 * k + 2]) for k in range(min(n, cap))]
 
 
+def debug_tiles_staircase(tiles):
+    """Diagnostic (host only): whether a list of (tile row, tile column) pairs is a staircase (include/pagan_dp.h)."""
+    import numpy as np
+    a = np.ascontiguousarray(np.array(tiles, np.int32).reshape(-1, 2))
+    rc = lib().pagan_dp_debug_tiles_staircase(a.ctypes.data_as(C.POINTER(C.c_int32)), len(a))
+    _check(min(rc, 0), "pagan_dp_debug_tiles_staircase")
+    return bool(rc)
+
+
 def debug_compact(left, right, band=None):
     """Diagnostic (host only): the compacted numbering the library aligns graphs with many dead sites in:
     dict with keep_left / keep_right (compacted site -> caller's site), slot_left / slot_right (per kept bwd edge: its position

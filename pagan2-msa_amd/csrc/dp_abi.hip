@@ -272,6 +272,29 @@ void list_tiles(int Lx, const RowBand &rb, std::vector<int> *out) {
 }
 
 // dp_tiles.hip stages the bwd edges of a tile's 64 rows and 64 columns in LDS windows of PG_TILE_EDGES entries
+// A job's tiles (tile row, tile column pairs) form a staircase: every tile row a contiguous run of columns, first and last
+// column never falling from one row to the next, no empty row between two rows, consecutive rows touching.  Then waiting
+// for a tile's three neighbours orders it behind every tile (a',b') <= (a,b) (dp_tiles.hip, pg_fill_tiles_flow).
+bool tiles_staircase(const std::vector<int> &tl) {
+    std::vector<std::pair<int, int>> span;             // per tile row: first, last column
+    std::vector<int> count;
+    for (size_t q = 0; q < tl.size(); q += 2) {
+        const int a = tl[q], bb = tl[q + 1];
+        if ((int)span.size() <= a) { span.resize(a + 1, {1 << 30, -1}); count.resize(a + 1, 0); }
+        span[a].first = std::min(span[a].first, bb); span[a].second = std::max(span[a].second, bb);
+        ++count[a];
+    }
+    int prev = -1;
+    for (int a = 0; a < (int)span.size(); ++a) {
+        if (count[a] == 0) { if (prev >= 0) return false; continue; }     // (rows before the first tile row are fine)
+        if (count[a] != span[a].second - span[a].first + 1) return false;
+        if (prev >= 0 && (prev != a - 1 || span[a].first < span[prev].first || span[a].second < span[prev].second ||
+                          span[a].first > span[prev].second + 1)) return false;
+        prev = a;
+    }
+    return true;
+}
+
 bool edges_fit_tiles(const pagan_graph *g, int n) {
     for (int a = 0; a < n; a += PG_TILE)
         if (g->bwd_off[std::min(n, a + PG_TILE)] - g->bwd_off[a] > PG_TILE_EDGES) return false;
@@ -915,6 +938,11 @@ int pagan_dp_debug_tiles(const pagan_graph *left, const pagan_graph *right, cons
     return n;
 }
 
+int pagan_dp_debug_tiles_staircase(const int32_t *tiles, int32_t n) {
+    if (!tiles || n < 0) return PAGAN_E_ARG;
+    return tiles_staircase(std::vector<int>(tiles, tiles + 2 * (size_t)n)) ? 1 : 0;
+}
+
 int pagan_dp_debug_compact(const pagan_graph *left, const pagan_graph *right, const pagan_band *band, int32_t *keep_left,
                            int32_t *keep_right, int32_t *slot_left, int32_t *slot_right, int32_t *upper, int32_t *lower,
                            int32_t *n_out /* [4]: kept left sites, kept right sites, kept left edges, kept right edges */) {
@@ -1082,24 +1110,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         // (dp_tiles.hip): every tile row a contiguous run of columns, first and last column never falling from one row to
         // the next, no empty row between two rows, consecutive rows touching.
         for (int k : which_tiled) {
-            const std::vector<int> &tl = b->jobs[k].tiles;
-            std::vector<std::pair<int, int>> span;             // per tile row: first, last column
-            std::vector<int> count;
-            for (size_t q = 0; q < tl.size(); q += 2) {
-                const int a = tl[q], bb = tl[q + 1];
-                if ((int)span.size() <= a) { span.resize(a + 1, {1 << 30, -1}); count.resize(a + 1, 0); }
-                span[a].first = std::min(span[a].first, bb); span[a].second = std::max(span[a].second, bb);
-                ++count[a];
-            }
-            bool stair = true;
-            int prev = -1;
-            for (int a = 0; a < (int)span.size() && stair; ++a) {
-                if (count[a] == 0) { if (prev >= 0) stair = false; continue; }     // (rows before the first tile row are fine)
-                if (count[a] != span[a].second - span[a].first + 1) stair = false;
-                if (prev >= 0 && (prev != a - 1 || span[a].first < span[prev].first || span[a].second < span[prev].second ||
-                                  span[a].first > span[prev].second + 1)) stair = false;
-                prev = a;
-            }
+            const bool stair = tiles_staircase(b->jobs[k].tiles);
             if (!stair) b->tiles_water = true;
         }
         if (const char *f = std::getenv("PAGAN_DP_TILES")) if (std::strcmp(f, "watermark") == 0) b->tiles_water = true;

@@ -77,3 +77,40 @@ def test_cascade_and_edges_from_dead_sites():
     got = pg.debug_compact(g, g)
     assert got["keep_left"].tolist() == [0, 1, 2, 5, 6, 7, 8]
     assert got["slot_left"].tolist() == [0, 0, 1, 0, 0, 0]
+
+
+def test_staircase_predicate():
+    """When the tiled kernel's dataflow launch may order a tile behind its three neighbours only (dp_abi.hip: tiles_staircase)."""
+    full = [(a, b) for a in range(5) for b in range(6)]
+    assert pg.debug_tiles_staircase(full)
+    band = [(a, b) for a in range(8) for b in range(max(0, a - 1), min(8, a + 3))]
+    assert pg.debug_tiles_staircase(band)
+    assert pg.debug_tiles_staircase([(3, 4)])                                   # one tile; rows before the first one do not count
+    assert not pg.debug_tiles_staircase([(0, 0), (0, 1), (0, 3)])               # a hole in a row
+    assert not pg.debug_tiles_staircase([(0, 0), (0, 1), (2, 1), (2, 2)])       # an empty row between two rows
+    assert not pg.debug_tiles_staircase([(0, 0), (0, 1), (1, 3), (1, 4)])       # rows that do not touch
+    assert pg.debug_tiles_staircase([(0, 0), (0, 1), (1, 2), (1, 3)])           # touching through the corner
+    assert not pg.debug_tiles_staircase([(0, 2), (0, 3), (1, 1), (1, 2), (1, 3)])   # first column falls
+    assert not pg.debug_tiles_staircase([(0, 0), (0, 1), (0, 2), (1, 0), (1, 1)])   # last column falls
+
+
+def test_real_bands_are_staircases():
+    left = synth.random_graph(700, 15, 5, p_extra=0.1, max_deg=3, max_span=20)
+    right = synth.random_graph(900, 15, 6, p_extra=0.1, max_deg=3, max_span=20)
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    centre = np.arange(Lx) * (Ly - 1) // (Lx - 1)
+    upper = np.maximum.accumulate(np.maximum(centre - 300, 0)); lower = np.maximum.accumulate(np.minimum(centre + 300, Ly - 1))
+    upper[0] = 0; lower[-1] = Ly - 1
+    side, tiles = pg.debug_tiles(left, right, abi.Band(upper, lower))
+    assert len(tiles) > 20 and pg.debug_tiles_staircase(tiles)
+    side, tiles = pg.debug_tiles(left, right)
+    assert pg.debug_tiles_staircase(tiles)
+    # a jump of three tile columns between two rows: inside a tile row the tile list bridges it (a tile row is listed from
+    # its first row's first column to its last row's last column), on a tile-row boundary it does not -- the band of
+    # tests/test_tiles_gpu.py::test_band_whose_tiles_are_no_staircase
+    for jump_row, stair in ((350, True), (320, False)):
+        upper = np.zeros(Lx, np.int64); lower = np.zeros(Lx, np.int64)
+        upper[:jump_row] = 0; lower[:jump_row] = 330
+        upper[jump_row:] = 520; lower[jump_row:] = Ly - 1
+        side, tiles = pg.debug_tiles(left, right, abi.Band(upper, lower))
+        assert len(tiles) > 20 and pg.debug_tiles_staircase(tiles) == stair, jump_row

@@ -166,8 +166,9 @@ def test_band_whose_tiles_are_no_staircase(pg, oracle):
     right = synth.random_graph(900, 15, 96, p_extra=0.15, max_deg=4, max_span=400)
     Lx, Ly = left.n_sites - 1, right.n_sites - 1
     upper = np.zeros(Lx, np.int64); lower = np.zeros(Lx, np.int64)
-    upper[:350] = 0; lower[:350] = 330
-    upper[350:] = 520; lower[350:] = Ly - 1                                # a jump of three tile columns between two rows
+    upper[:320] = 0; lower[:320] = 330
+    upper[320:] = 520; lower[320:] = Ly - 1                                # a jump of three tile columns, on a tile-row boundary
+    assert not pg.debug_tiles_staircase(pg.debug_tiles(left, right, abi.Band(upper, lower))[1])
     band = abi.Band(upper, lower)
     side, tiles = pg.debug_tiles(left, right, band)
     assert len(tiles) > 30
