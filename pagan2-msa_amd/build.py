@@ -31,8 +31,12 @@ def sources():
 
 def inputs():
     inc = os.path.join(HERE, "..", "include")
-    return (sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) +
-            sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")))
+    # every text file of csrc/ takes part (headers, the generated dp_pipe_hot.inc that dp_pipe.hip includes, sources
+    # not in SOURCES yet): a file the compiler may read must never change without the digest changing
+    listed = set(sources())
+    extra = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                   if f.endswith((".h", ".inc", ".hip", ".cpp", ".hpp")) and os.path.join(CSRC, f) not in listed)
+    return sources() + extra + sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
 
 
 def digest():

@@ -41,3 +41,21 @@ def test_in_tree_library_matches_the_sources():
     lib = C.CDLL(mod.LIB)
     missing = [s for s in sorted(declared_symbols()) if not hasattr(lib, s)]
     assert not missing, missing
+
+
+def test_generated_hot_loop_takes_part_in_the_digest(tmp_path, monkeypatch):
+    """dp_pipe.hip includes dp_pipe_hot.inc: regenerating it must make the shipped library stale (round-2 advisor finding)."""
+    mod = _build_module()
+    names = [os.path.basename(p) for p in mod.inputs()]
+    assert "dp_pipe_hot.inc" in names and "dp_pipe.hip" in names and "pagan_dp.h" in names
+    assert len(names) == len(set(names))
+    # the same check on a copy of csrc/ with one byte of the .inc changed
+    import shutil
+    csrc = tmp_path / "csrc"
+    shutil.copytree(mod.CSRC, csrc)
+    before = mod.digest()
+    monkeypatch.setattr(mod, "CSRC", str(csrc))
+    assert mod.digest() == before
+    with open(csrc / "dp_pipe_hot.inc", "a") as f:
+        f.write("\n")
+    assert mod.digest() != before
