@@ -202,6 +202,8 @@ int  pagan_dp_debug_compact(const pagan_graph *left, const pagan_graph *right, c
                             int32_t *n_out);
 /* diagnostic: job k's scores, [cells][3] doubles (X, Y, M), diagonal-major                */
 int  pagan_batch_debug_scores(pagan_batch *b, int32_t k, double *dst, int64_t count);
+/* diagnostic: job k's back-pointers, [cells][3] packed words (X, Y, M), diagonal-major   */
+int  pagan_batch_debug_backptrs(pagan_batch *b, int32_t k, uint32_t *dst, int64_t count);
 /* diagnostic: overwrite all device outputs with 0xFF (NaN scores) before a run           */
 int  pagan_batch_debug_poison(pagan_batch *b);
 

@@ -271,6 +271,14 @@ class Batch:
                "pagan_batch_debug_scores")
         return out
 
+    def debug_backptrs(self, k):
+        """Diagnostic: job k's device back-pointer array as [cells, 3] uint32 (X, Y, M), diagonal-major."""
+        import numpy as np
+        out = np.empty((self.cells_of(k), 3), np.uint32)
+        _check(self._L.pagan_batch_debug_backptrs(self._h, k, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size),
+               "pagan_batch_debug_backptrs")
+        return out
+
     def cells_of(self, k):
         left, right, _, band = self.jobs[k]
         return self._L.pagan_dp_count_cells(left.n_sites, right.n_sites, C.byref(band.c) if band is not None else None)

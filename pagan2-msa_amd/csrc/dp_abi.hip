@@ -33,6 +33,7 @@ template <bool TAB_LDS> __global__ void pg_fill_pipe(const PgDevJob *jobs, const
 __global__ void pg_fill_tiles(const PgDevJob *jobs, const int *tiles, unsigned flags);
 __global__ void pg_fill_tiles_flow(const PgDevJob *jobs, const int *tiles, int n_tiles, int n_diag, int *flow, unsigned flags, int use_water);
 __global__ void pg_end_corner(const PgDevJob *jobs);
+__global__ void pg_backptr(const PgDevJob *jobs, const int *which, unsigned flags);
 __global__ void pg_trace_spec(const PgDevJob *jobs);
 __global__ void pg_trace_compose(const PgDevJob *jobs);
 __global__ void pg_trace_emit(const PgDevJob *jobs);
@@ -479,6 +480,8 @@ struct pagan_batch {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_ring_small = 0;        // ring jobs whose model table fits the LDS cache (listed first)
     bool use_pipe = true;        // LDS-staged jobs run pg_fill_pipe (default) or the older pg_fill_ring
+    int bp_pass = 1;             // pg_fill_pipe's jobs: 1 back-pointers by pg_backptr after the fill (its hot loop stores scores only),
+                                 // 2 (PAGAN_DP_BP=verify, diagnostic builds that still write them in the fill) pg_backptr compares
     int max_bound = 0;           // largest traceback boundary count of any job
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -702,6 +705,12 @@ int launch_fill(pagan_batch *b) {
             if (n_big > 0)
                 hipLaunchKernelGGL(pg_fill_pipe<false>, dim3(n_big), dim3(pg_pipe_block()), pg_pipe_lds_bytes(), b->stream,
                                    b->d_jobs, b->d_which + n_small, b->flags);
+            if (b->bp_pass) {
+                int max_nd = 1;
+                for (const PgDevJob &d : b->dj) max_nd = std::max(max_nd, d.nd);
+                hipLaunchKernelGGL(pg_backptr, dim3((max_nd + PG_BP_DIAGS - 1) / PG_BP_DIAGS, b->n_ring), dim3(256), 0, b->stream,
+                                   b->d_jobs, b->d_which, (b->flags & 0xffu) | (b->bp_pass == 2 ? 0x100u : 0u));
+            }
         } else {
             if (n_small > 0)
                 hipLaunchKernelGGL(pg_fill_ring<true>, dim3(n_small), dim3(576), pg_ring_lds_bytes(), b->stream,
@@ -1006,6 +1015,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     const bool force_v1 = std::getenv("PAGAN_DP_FORCE_GLOBAL_WAVEFRONT") != nullptr;   // A/B switch for profiling
     // A/B switch: PAGAN_DP_FILL=ring runs the barrier-per-diagonal LDS kernel instead of the register wavefront
     if (const char *f = std::getenv("PAGAN_DP_FILL")) b->use_pipe = std::strcmp(f, "ring") != 0;
+    if (const char *f = std::getenv("PAGAN_DP_BP")) b->bp_pass = std::strcmp(f, "verify") == 0 ? 2 : (std::strcmp(f, "fill") == 0 ? 0 : 1);
     if (const char *f = std::getenv("PAGAN_DP_DEBUG_FLAGS")) b->flags |= (uint32_t)std::strtoul(f, nullptr, 0) & 0xff00u;
     // A/B switch: PAGAN_DP_WIDE=wavefront sends the wide jobs to the one-workgroup HBM wavefront instead of the tiles
     const char *wide_env = std::getenv("PAGAN_DP_WIDE");
@@ -1368,6 +1378,14 @@ int pagan_batch_debug_scores(pagan_batch *b, int32_t k, double *dst, int64_t cou
     if (!b || k < 0 || k >= b->n || !dst || count > 3 * b->jobs[k].dx.cells) return PAGAN_E_ARG;
     HIP_TRY(hipStreamSynchronize(b->stream));
     HIP_TRY(hipMemcpy(dst, b->dj[k].sc, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+    return PAGAN_OK;
+}
+
+// Diagnostic: job k's back-pointer array, [cells][3] packed words (dp_device.h) in diagonal-major order.
+int pagan_batch_debug_backptrs(pagan_batch *b, int32_t k, uint32_t *dst, int64_t count) {
+    if (!b || k < 0 || k >= b->n || !dst || count > 3 * b->jobs[k].dx.cells) return PAGAN_E_ARG;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(dst, b->dj[k].bp, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost));
     return PAGAN_OK;
 }
 

@@ -53,6 +53,72 @@ template __global__ void pg_fill_wavefront<256>(const PgDevJob *, const int *, u
 template __global__ void pg_fill_wavefront<1024>(const PgDevJob *, const int *, unsigned);
 
 // ---------------------------------------------------------------------------------------------
+// Back-pointer pass.  A back-pointer is a function of scores that are final once the fill has passed the cell:
+// the first candidate, in the reference's order, that equals the state's maximum (first_is_bigger is strict,
+// basic_alignment.h:449-462; candidates VA:1328-1349, 1396-1433, 2029-2219).  Nothing on the fill's dependency
+// chain needs it, so the banded fill's hand-scheduled loop (dp_pipe.hip) computes and stores scores only and this
+// kernel -- one thread per cell, every cell independent -- re-evaluates each cell's candidates from the stored
+// scores of its predecessors, with the same expressions on the same doubles, and writes the 12 bytes.  HBM-bound:
+// 24 B read (neighbours come out of L2) + 12 B written per cell.
+// grid (ceil(max nd / PG_BP_DIAGS), n_jobs), block 256: wave w of block b takes the diagonals
+// b * PG_BP_DIAGS + w, + 4, ...; its lanes the diagonal's cells.
+// flags bit 8 (diagnostic): nothing is written; the recomputed scores AND back-pointers are compared with what the
+// fill kernel stored, a difference sets fill_status to 0x7d (tests run this over whole matrices filled by the
+// kernels that still write their own back-pointers).
+__global__ __launch_bounds__(256) void pg_backptr(const PgDevJob *__restrict__ jobs, const int *__restrict__ which,
+                                                  unsigned flags) {
+    const PgDevJob *__restrict__ job = jobs + which[blockIdx.y];
+    const int first = blockIdx.x * PG_BP_DIAGS;
+    if (first >= job->nd) return;
+    const View J = load_view(job);
+    const bool no_terminal_edges = flags & 1u;
+    const bool reduced_terminal = !(flags & 2u);
+    const bool verify = flags & 0x100u;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int end = first + PG_BP_DIAGS < J.nd ? first + PG_BP_DIAGS : J.nd;
+    for (int d = first + wave; d < end; d += 4) {
+        const pg_i4 cur = J.dsc[d];
+        const int lo = cur.x, hi = cur.y;
+        if (hi < lo) continue;
+        const long long base = ((long long)cur.w << 32) | (unsigned)cur.z;
+        Diag d1 = {0, -1, 0}, d2 = {0, -1, 0};
+        if (d > 0) { const pg_i4 p = J.dsc[d - 1]; d1 = {p.x, p.y, ((long long)p.w << 32) | (unsigned)p.z}; }
+        if (d > 1) { const pg_i4 p = J.dsc[d - 2]; d2 = {p.x, p.y, ((long long)p.w << 32) | (unsigned)p.z}; }
+        for (int i = lo + lane; i <= hi; i += 64) {
+            const int j = d - i;
+            const long long at = base + (i - lo);
+            int l0 = 0, l1 = 0, r0 = 0, r1 = 0;
+            if (i > 0) { l0 = J.offL[i]; l1 = J.offL[i + 1]; }
+            if (j > 0) { r0 = J.offR[j]; r1 = J.offR[j + 1]; }
+            float sm = 0.0f;
+            if (i > 0 && j > 0 && l1 > l0 && r1 > r0) sm = J.table[J.stL[i] + J.stR[j] * J.S];       // VA:1363
+            double bx, by, bm;
+            unsigned px, py, pm;
+            cell_any(J, i, j, l1 - l0, r1 - r0, sm, no_terminal_edges, reduced_terminal,
+                     [&](int p, int q, double &xs, double &ys, double &ms) {
+                         const long long ix = hbm_index(J, d, d1, d2, p, q);
+                         xs = ys = ms = neg_inf();
+                         if (ix >= 0) { xs = J.sc[3 * ix + PG_X]; ys = J.sc[3 * ix + PG_Y]; ms = J.sc[3 * ix + PG_M]; }
+                     },
+                     [&](int k, int &p, double &lw) { p = J.srcL[l0 + k]; lw = (double)J.lwL[l0 + k]; },
+                     [&](int k, int &q, double &rw) { q = J.srcR[r0 + k]; rw = (double)J.lwR[r0 + k]; },
+                     bx, by, bm, px, py, pm);
+            if (verify) {
+                const bool same = __double_as_longlong(bx) == __double_as_longlong(J.sc[3 * at + PG_X]) &&
+                                  __double_as_longlong(by) == __double_as_longlong(J.sc[3 * at + PG_Y]) &&
+                                  __double_as_longlong(bm) == __double_as_longlong(J.sc[3 * at + PG_M]) &&
+                                  px == J.bp[3 * at + PG_X] && py == J.bp[3 * at + PG_Y] && pm == J.bp[3 * at + PG_M];
+                if (!same) *(PG_GLOBAL int *)job->fill_status = 0x7d;
+            } else {
+                typedef unsigned u3 __attribute__((ext_vector_type(3)));
+                u3 b; b.x = px; b.y = py; b.z = pm;
+                *(PG_GLOBAL u3 *)(J.bp + 3 * at) = b;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Banded wavefront with the active band staged in LDS ("ring" kernel).
 //
 // One workgroup per alignment: 2 NW compute waves + one loader wave, one s_barrier per

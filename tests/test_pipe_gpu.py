@@ -88,3 +88,46 @@ def test_negative_zero_parameter_keeps_the_comparing_kernel(pg, oracle):
     cls, _ = pg.debug_plan(left, right, band)        # the planner itself does not look at the model
     assert cls.size == left.n_sites + right.n_sites - 3
     same(pg.align(left, right, m2, band), oracle.dp_align(left, right, m2, band))
+
+
+def poisoned_run(pg, job, flags=0):
+    b = pg.Batch([job], flags=flags)
+    pg.lib().pagan_batch_debug_poison(b._h)
+    b.run(); b.sync()
+    return b
+
+
+@pytest.mark.parametrize("seed,kw", [(0, {}), (1, {}), (2, dict(max_span=8)), (12, dict(n=500, max_span=6, box=False, p_dead=0.2)),
+                                      (13, dict(n=500, max_span=30, box=False, p_dead=0.4))])
+def test_backpointer_pass_writes_what_the_comparing_kernels_write(pg, monkeypatch, seed, kw):
+    """pg_backptr re-derives every cell's back-pointers from the stored scores (the banded fill's hot loop stores scores
+    only).  Reference for the words: the older ring kernel, which evaluates every candidate with compare-and-replace
+    in the reference's order and writes its own back-pointers; every word of every cell must agree -- classes 0-5, dead
+    sites, far edges."""
+    job = banded_job(seed, **kw)
+    monkeypatch.setenv("PAGAN_DP_COMPACT", "0")      # the device arrays are read back as the caller's matrices
+    words = {}
+    for mode, kernel in (("fill", "ring"), ("pass", "pipe")):
+        monkeypatch.setenv("PAGAN_DP_FILL", kernel)
+        monkeypatch.setenv("PAGAN_DP_BP", mode)
+        b = poisoned_run(pg, job)
+        words[mode] = (b.debug_backptrs(0), b.debug_scores(0))
+        b.close()
+    assert np.array_equal(words["fill"][1].view(np.int64), words["pass"][1].view(np.int64)), "scores differ"
+    bad = np.argwhere(words["fill"][0] != words["pass"][0])
+    assert bad.size == 0, "first differing back-pointers (cell, state): %s" % bad[:5].tolist()
+
+
+@pytest.mark.parametrize("flags", [0, abi.OPT_NO_TERMINAL_EDGES, abi.OPT_NO_REDUCED_TERMINAL_PEN])
+def test_backpointer_pass_under_the_option_bits(pg, oracle, monkeypatch, flags):
+    job = banded_job(7, n=400, box=False)
+    words = {}
+    for mode, kernel in (("fill", "ring"), ("pass", "pipe")):
+        monkeypatch.setenv("PAGAN_DP_FILL", kernel)
+        monkeypatch.setenv("PAGAN_DP_BP", mode)
+        b = poisoned_run(pg, job, flags)
+        words[mode] = b.debug_backptrs(0)
+        if mode == "pass":
+            same(b.fetch()[0], oracle.dp_align(*job, flags=flags))
+        b.close()
+    assert np.array_equal(words["fill"], words["pass"])
