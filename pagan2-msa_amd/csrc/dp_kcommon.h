@@ -93,10 +93,11 @@ __device__ __forceinline__ long long hbm_index(const View &J, int d, const Diag 
 //   edge_r(k, q, rw)          the same for right site j
 // nl / nr = number of bwd edges of the two sites, sm = the model's log score of the two states
 // (used only when i > 0 && j > 0 and both sites have edges).
+// (cell_any_t: the match terms tM = D(2*ng) + D(sm), tX = D(0+ng) + D(sm) come ready -- dp_pipe.hip keeps them in LDS)
 template <class Fetch, class EdgeL, class EdgeR>
-__device__ __forceinline__ void cell_any(const View &J, int i, int j, int nl, int nr, float sm, bool no_terminal_edges,
-                                         bool reduced_terminal, Fetch fetch, EdgeL edge_l, EdgeR edge_r, double &bx,
-                                         double &by, double &bm, unsigned &px, unsigned &py, unsigned &pm) {
+__device__ __forceinline__ void cell_any_t(const View &J, int i, int j, int nl, int nr, double tM, double tX, bool no_terminal_edges,
+                                           bool reduced_terminal, Fetch fetch, EdgeL edge_l, EdgeR edge_r, double &bx,
+                                           double &by, double &bm, unsigned &px, unsigned &py, unsigned &pm) {
     const double NI = neg_inf();
     bx = NI; by = NI; bm = NI;
     px = PG_BP_NONE; py = PG_BP_NONE; pm = PG_BP_NONE;
@@ -143,8 +144,6 @@ __device__ __forceinline__ void cell_any(const View &J, int i, int j, int nl, in
     }
     // ---- M: both sites consumed (VA:956-963, 1353-1436) ----
     if (i > 0 && j > 0 && nl > 0 && nr > 0) {
-        const double tM = (double)(2 * J.ng) + (double)sm;                      // VA:1364
-        const double tX = (double)(0.0f + J.ng) + (double)sm;                   // VA:1366-1367
         for (int k1 = 0; k1 < nl; ++k1) {
             int p; double lw;
             edge_l(k1, p, lw);
@@ -162,6 +161,15 @@ __device__ __forceinline__ void cell_any(const View &J, int i, int j, int nl, in
             }
         }
     }
+}
+
+template <class Fetch, class EdgeL, class EdgeR>
+__device__ __forceinline__ void cell_any(const View &J, int i, int j, int nl, int nr, float sm, bool no_terminal_edges,
+                                         bool reduced_terminal, Fetch fetch, EdgeL edge_l, EdgeR edge_r, double &bx,
+                                         double &by, double &bm, unsigned &px, unsigned &py, unsigned &pm) {
+    const double tM = (double)(2 * J.ng) + (double)sm;                          // VA:1364
+    const double tX = (double)(0.0f + J.ng) + (double)sm;                       // VA:1366-1367
+    cell_any_t(J, i, j, nl, nr, tM, tX, no_terminal_edges, reduced_terminal, fetch, edge_l, edge_r, bx, by, bm, px, py, pm);
 }
 
 // The same with every operand in HBM/L2 (graph arrays, model table, scores), written at `at`.

@@ -82,7 +82,10 @@ struct PipeSmem {
     int ebL[PRW], ebR[PRW];      // first bwd edge of the site (edge numbering of the graph)
     int esL[PEC], esR[PEC];
     float ewL[PEC], ewR[PEC];
-    float table[256];
+    // small model tables (S*S <= 256, TAB_LDS): the match terms of every state pair, ready to add --
+    // tab2[a + b*S] = { D(2*ng) + D(s(a,b)), D(0+ng) + D(s(a,b)) } (VA:1363-1367), computed once per workgroup with the expressions every
+    // other path uses; large tables: the model scores the assist waves gather per staging slot
+    union { double tab2[256][2]; float ssm[PST][PNT]; };
     double null_cell[4];         // -inf, -inf, -inf: what a missing second edge reads
     int progress[PNW];           // last diagonal each compute wave completed (or sleeps through)
     int arrived[PNW];            // last rendezvous diagonal each compute wave drained for
@@ -92,7 +95,6 @@ struct PipeSmem {
     // best candidate of X / Y over the bwd edges that do NOT come from the previous site, M over all edge pairs
     double sx[PST][PNT], sy[PST][PNT], sM[PST][PNT];
     unsigned spx[PST][PNT], spy[PST][PNT], spm[PST][PNT];
-    float ssm[PST][PNT];         // the model's score of the cell (large tables: gathered from L2 by the assist wave)
     int assist_done[PNA];        // last diagonal each assist wave has staged
     int as_list[PNA][64];        // rows of the multi-edge cells of the diagonal an assist wave is working on, compacted
 };
@@ -943,8 +945,8 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
             row = list[lane]; j = d - row;
             rL = PM.recL[row & (PRW - 1)]; cR = PM.recR[j & (PRW - 1)];
             const int ti = (rL.x & 0xffff) + (cR.x & 0xffff) * S;
-            const float sm = TAB_LDS ? PM.table[ti & 255] : PM.ssm[stg][row & (PNT - 1)];
-            tM = tng2 + (double)sm; tX = tng1 + (double)sm;
+            if (TAB_LDS) { tM = PM.tab2[ti & 255][0]; tX = PM.tab2[ti & 255][1]; }
+            else { const float sm = PM.ssm[stg][row & (PNT - 1)]; tM = tng2 + (double)sm; tX = tng1 + (double)sm; }
             kind = classify(rL, cR);
         }
     };
@@ -1212,6 +1214,13 @@ __device__ __forceinline__ pg_i8 uniform_i8(const pg_i8 &v) {
 #define WCTX_STATS(c)
 #endif
 
+// every VGPR from v136 up and the SGPRs s36..s87 belong to the hand-scheduled loop (tools/gen_hot_asm.py has the plan)
+#define PG_V8(a) "v" #a "0", "v" #a "1", "v" #a "2", "v" #a "3", "v" #a "4", "v" #a "5", "v" #a "6", "v" #a "7", "v" #a "8", "v" #a "9"
+#define PG_S8(a) "s" #a "0", "s" #a "1", "s" #a "2", "s" #a "3", "s" #a "4", "s" #a "5", "s" #a "6", "s" #a "7", "s" #a "8", "s" #a "9"
+#define PG_HOT_CLOBBERS "v136", "v137", "v138", "v139", PG_V8(14), PG_V8(15), PG_V8(16), PG_V8(17), PG_V8(18), PG_V8(19), PG_V8(20), \
+    PG_V8(21), PG_V8(22), PG_V8(23), PG_V8(24), "v250", "v251", "v252", "v253", "v254", "v255", \
+    "s36", "s37", "s38", "s39", PG_S8(4), PG_S8(5), PG_S8(6), PG_S8(7), "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87"
+
 // ---- hot run (model table in LDS): the diagonals from d on while their class is 0, 1 or 2 ----
 // One iteration per diagonal.  Across iterations only the lane's cell of the previous diagonal (P), the shifted
 // cell of the diagonal before (C) and the operand pipeline (row record, two column records, model score) live in
@@ -1232,14 +1241,15 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
     WCTX_STATS(C_);
     double PX = C_.px, PY = C_.py, PMm = C_.pm, CX = C_.cx, CY = C_.cy, CM = C_.cm;
     const pg_i4 ca = C_.ca, cb = C_.cb;
-    const float smf = C_.smf;
     pg_i8 dA = uniform_i8(C_.dA);
     pg_i8 cur = dA;
     int sb = (d % PRK) * PROW_BYTES;                        // ring row of diagonal d, as a byte offset
     int hstg = d % PST;                                     // staging slot (and assist wave) of diagonal d
     pg_i4 rLc = PM.recL[row & (PRW - 1)];                   // (garbage while the row is beyond the staged ones: inactive)
     pg_i4 cR0 = ca, cR1 = cb;                               // records of the columns d - row and d + 1 - row
-    float sm = smf;                                         // model score of (row, d - row)
+    // match terms of (row, d - row): tM = D(2*ng) + D(s), tX = D(0+ng) + D(s), ready in LDS (PM.tab2)
+    int ti0 = ((rLc.x & 0xffff) + __umul24(cR0.x & 0xffff, S)) & 255;
+    double tMc = PM.tab2[ti0][0], tXc = PM.tab2[ti0][1];
     const int tid24 = tid * 24, bpos24 = bslot * 24;
     const int null_off = (int)offsetof(PipeSmem, null_cell);
     // LDS addresses the class 0 loop below works with
@@ -1247,7 +1257,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
     const unsigned lds_ring = (unsigned)(unsigned long long)(lds_char *)&PM.sc[0][0][0];
     const unsigned a_tid24 = lds_ring + (unsigned)tid24, a_bpos24 = lds_ring + (unsigned)bpos24;
     const unsigned a_recR = (unsigned)(unsigned long long)(lds_char *)&PM.recR[0], a_recL = (unsigned)(unsigned long long)(lds_char *)&PM.recL[0];
-    const unsigned a_table = (unsigned)(unsigned long long)(lds_char *)&PM.table[0];
+    const unsigned a_table = (unsigned)(unsigned long long)(lds_char *)&PM.tab2[0][0];
     const unsigned a_fdn = (unsigned)(unsigned long long)(lds_char *)&PM.progress[dn];
     const unsigned a_fup = (unsigned)(unsigned long long)(lds_char *)&PM.progress[up], a_fme = (unsigned)(unsigned long long)(lds_char *)&PM.progress[wave];
     const unsigned ni_hi = 0xfff00000u;
@@ -1266,48 +1276,64 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
             // interval, a flag that has to be polled -- and leaves that diagonal untouched: d, the ring row, the lane's row
             // and cells come back; the operand pipeline is reloaded below.
             unsigned long long dptr = (unsigned long long)(psc + d);
-            int colx = cR1.x, rowx = rLc.x;
-            float smv = sm;
+            int colx = cR1.x & 0xffff, rowx = rLc.x & 0xffff;      // states of column d + 1 - row and of the row
+            double tm_io = tMc, tx_io = tXc;
             const unsigned sc_lo = (unsigned)(unsigned long long)sc_out, sc_hi = (unsigned)((unsigned long long)sc_out >> 32);
-            const unsigned bp_lo = (unsigned)(unsigned long long)bp_out, bp_hi = (unsigned)((unsigned long long)bp_out >> 32);
             const int d_in = d;
+            // the loop stops in front of the first diagonal it may not run without looking at the loader's flags or past the
+            // wave's interval
+            const int stop = __builtin_amdgcn_readfirstlane(sleep < ok_until + 1 ? sleep : ok_until + 1);
+#ifdef PG_PIPE_STATS
+            const long long st_t_in = __builtin_readcyclecounter();
+#endif
+            int k0 = 0, k1 = 0, k2 = 0;        // diagnostic builds (PG_HOT_EXP=k): waits for the upstream wave, looks at its flag, waits for the downstream wave
             asm volatile(
 #include "dp_pipe_hot.inc"
-                : [row] "+v"(row), [colx] "+v"(colx), [rowx] "+v"(rowx), [sm] "+v"(smv),
+                : [row] "+v"(row), [colx] "+v"(colx), [rowx] "+v"(rowx), [tm] "+v"(tm_io), [tx] "+v"(tx_io),
                   [p0] "+v"(PX), [p1] "+v"(PY), [p2] "+v"(PMm), [c0] "+v"(CX), [c1] "+v"(CY), [c2] "+v"(CM),
-                  [d] "+s"(d), [sb] "+s"(sb), [pup] "+s"(p_up), [pdn] "+s"(p_dn), [dptr] "+s"(dptr)
-                : [ge] "v"(ge), [go] "v"(go), [ng] "v"(ng), [tng2] "v"(tng2), [tng1] "v"(tng1), [ni] "v"(NI), [nihi] "v"(ni_hi),
+                  [d] "+s"(d), [sb] "+s"(sb), [pup] "+s"(p_up), [pdn] "+s"(p_dn), [dptr] "+s"(dptr),
+                  [k0] "+s"(k0), [k1] "+s"(k1), [k2] "+s"(k2)
+                : [ge] "v"(ge), [go] "v"(go), [ng] "v"(ng), [nihi] "v"(ni_hi), [pihi] "v"(0x7ff00000u),
                   [tid24] "v"(a_tid24), [bpos24] "v"(a_bpos24), [fup] "v"(a_fup), [fme] "v"(a_fme),
-                  [c18] "v"(1u << 18), [nulla] "v"(a_null), [tid] "v"(tid), [ringb] "s"(lds_ring),
+                  [nulla] "v"(a_null), [tid] "v"(tid), [ringb] "s"(lds_ring),
                   [asd] "s"(a_asd), [stx] "v"(a_stx), [spxa] "v"(a_spx),
-                  [sleep] "s"(sleep), [okuntil] "s"(ok_until), [S] "s"(S), [fdn] "v"(a_fdn),
+                  [stop] "s"(stop), [S] "s"(S), [fdn] "v"(a_fdn),
                   [bR] "s"(a_recR), [bL] "s"(a_recL), [bT] "s"(a_table),
-                  [sclo] "s"(sc_lo), [schi] "s"(sc_hi), [bplo] "s"(bp_lo), [bphi] "s"(bp_hi)
+                  [sclo] "s"(sc_lo), [schi] "s"(sc_hi)
                 : "memory", "vcc", "scc",
-                  "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153",
-                  "v154", "v155", "v156", "v157",
-                  "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173",
-                  "v174", "v175", "v176", "v177", "v178", "v179",
-                  "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250",
-                  "v251", "v252", "v253", "v254", "v255",
-                  "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
-                  "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193",
-                  "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207",
-                  "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221",
-                  "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235",
-                  "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
-                  "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
-                  "s68", "s69", "s70", "s71", "s72", "s73");
+                  PG_HOT_CLOBBERS);
             d = __builtin_amdgcn_readfirstlane(d);
             (void)d_in;
+#ifdef PG_PIPE_STATS
+            {   // one record per run of the loop (first diagonal, diagonal it stopped in front of, clock at entry and exit / 16,
+                // waits for the upstream wave | 48-look exits << 16): upper half of the job's trace buffer, per wave
+                const long long st_t_out = __builtin_readcyclecounter();
+                const int n3 = 3 * (Lx + Ly), r0 = (n3 / 4 * 3 + 15) & ~15, cap = (n3 - 1200 - r0 - 16) / 16;
+                if (cap > 0 && n3 >= 4096 && (tid & 63) == 0) {
+                    PG_GLOBAL int *tb = (PG_GLOBAL int *)C_.job->trace;
+                    const int slot = atomicAdd((int *)(tb + r0 + wave), 1);
+                    if (slot < cap) {
+                        PG_GLOBAL int *o = tb + r0 + 16 + 4 * (slot * 4 + wave);
+                        o[0] = d_in; o[1] = __builtin_amdgcn_readfirstlane(d) | ((k0 >> 16) ? 0x40000000 : 0); o[2] = (int)(st_t_in >> 4); o[3] = (int)(st_t_out >> 4);
+                    }
+                }
+            }
+            st_poll_n[9] += k0 & 0xffff; st_poll_n[6] += k1; st_poll_t[9] += (long long)(k2 & 0xffff) << 8; st_poll_n[5] += k0 >> 16; st_poll_t[5] += (long long)(k2 >> 16) << 8; st_poll_n[0] += 1; st_poll_t[0] += (long long)(d - d_in) << 8;
+#else
+            (void)k0; (void)k1; (void)k2;
+#endif
             // the operand pipeline of diagonal d from the LDS windows, the descriptor from memory
             cur = psc[d];
             hstg = d % PST;
             rLc = PM.recL[row & (PRW - 1)];
             cR0 = PM.recR[(d - row) & (PRW - 1)];
             cR1 = PM.recR[(d + 1 - row) & (PRW - 1)];
-            sm = PM.table[((rLc.x & 0xffff) + __umul24(cR0.x & 0xffff, S)) & 255];
+            ti0 = ((rLc.x & 0xffff) + __umul24(cR0.x & 0xffff, S)) & 255;
+            tMc = PM.tab2[ti0][0]; tXc = PM.tab2[ti0][1];
             if ((cur.s4 & 15) > 2 || d >= sleep) { dA = cur; break; }
+#ifdef PG_PIPE_STATS
+            st_poll_n[7] += (__any(row <= cur.y + 1) ? 0 : 1);
+#endif
             // The loop stopped at a diagonal it could run but for a flag: wait here (polls that sleep, spin limits that
             // end in an error status) for everything diagonal d needs, then go back into it -- the arithmetic below is the
             // loop's C++ rendering, compiled in with -DPG_NO_HOT_ASM only.
@@ -1372,7 +1398,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
         // ---- row hand-over: a lane whose row left the band takes the next one of its residue (far below the band) ----
         row += row < lo ? PNT : 0;
         const bool active = row <= hi;
-        const double tM = tng2 + (double)sm, tX = tng1 + (double)sm;
+        const double tM = tMc, tX = tXc;
         double bx, by, bm;
         unsigned px, py, pm;
         // candidates that do not need the shift first: the LDS read above is in flight
@@ -1488,7 +1514,8 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
 #endif
         // ---- operand pipeline for the next steps: one LDS wait per step, at its top ----
         const pg_i4 cR2 = PM.recR[(d + 2 - row) & (PRW - 1)];
-        const float sm1 = PM.table[((rLc.x & 0xffff) + __umul24(cR1.x & 0xffff, S)) & 255];
+        const int ti1 = ((rLc.x & 0xffff) + __umul24(cR1.x & 0xffff, S)) & 255;
+        const double tM1 = PM.tab2[ti1][0], tX1 = PM.tab2[ti1][1];
         const pg_i4 rLn = PM.recL[row & (PRW - 1)];
         PX = bx; PY = by; PMm = bm;
         CX = AX; CY = AY; CM = AM;
@@ -1501,13 +1528,13 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
         ++d;
         sb = sb + PROW_BYTES == PRING_BYTES ? 0 : sb + PROW_BYTES;
         hstg = hstg + 1 == PST ? 0 : hstg + 1;
-        cR0 = cR1; cR1 = cR2; sm = sm1; rLc = rLn;
+        cR0 = cR1; cR1 = cR2; tMc = tM1; tXc = tX1; rLc = rLn;
         if ((nxt.s4 & 15) > 2 || d >= sleep) { dA = nxt; break; }        // the next diagonal is not class 0..2, or the wave's interval ends
         cur = nxt;
     }
     // hand the state back to step(): the column records and model score of diagonal d (the row records are reloaded there,
     // nothing of lane 0's operand is prefetched)
-    C_.ca = cR0; C_.cb = cR1; C_.smf = sm;
+    C_.ca = cR0; C_.cb = cR1;
     C_.px = PX; C_.py = PY; C_.pm = PMm; C_.cx = CX; C_.cy = CY; C_.cm = CM;
     C_.dA = dA;
     WCTX_OUT(C_);
@@ -1655,8 +1682,8 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
             if (kind[q] == 1) {
                 const bool l2 = l2q[q], r2 = r2q[q], lS = lSq[q], rS = rSq[q];
-                const float smv = PM.table[((gl[q].x & 0xffff) + __umul24(gr[q].x & 0xffff, S)) & 255];
-                const double tM = tng2 + (double)smv, tX = tng1 + (double)smv;
+                const int ti_ = ((gl[q].x & 0xffff) + __umul24(gr[q].x & 0xffff, S)) & 255;
+                const double tM = PM.tab2[ti_][0], tX = PM.tab2[ti_][1];
                 const double lw0 = (double)__int_as_float(gl[q].z), lw1 = (double)__int_as_float(gl[q].w);
                 const double rw0 = (double)__int_as_float(gr[q].z), rw1 = (double)__int_as_float(gr[q].w);
                 const double lwA = lS ? lw1 : lw0, lwS = lS ? lw0 : lw1, rwA = rS ? rw1 : rw0, rwS = rS ? rw0 : rw1;
@@ -1692,10 +1719,13 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             } else if (kind[q] == 2) {
                 // first/last rows and columns, sites without edges, more than two edges, ...: the general rules
                 const int nl = (gl[q].x >> PR_NE_SHIFT) & 127, nr = (gr[q].x >> PR_NE_SHIFT) & 127;
-                float smv = 0.0f;
-                if (r > 0 && j > 0 && nl > 0 && nr > 0) smv = PM.table[((gl[q].x & 0xffff) + __umul24(gr[q].x & 0xffff, S)) & 255];
+                double tM_ = 0, tX_ = 0;
+                if (r > 0 && j > 0 && nl > 0 && nr > 0) {
+                    const int ti_ = ((gl[q].x & 0xffff) + __umul24(gr[q].x & 0xffff, S)) & 255;
+                    tM_ = PM.tab2[ti_][0]; tX_ = PM.tab2[ti_][1];
+                }
                 const pg_i4 gl_ = gl[q], gr_ = gr[q];
-                cell_any(J, r, j, r > 0 ? nl : 0, j > 0 ? nr : 0, smv, no_terminal_edges, reduced_terminal,
+                cell_any_t(J, r, j, r > 0 ? nl : 0, j > 0 ? nr : 0, tM_, tX_, no_terminal_edges, reduced_terminal,
                          [&](int p_, int q_, double &xs, double &ys, double &ms) {
                              pg_d2 xy; double m_;
                              const FarAsk f = wcell(p_ >= 0 && q_ >= 0, d - (p_ + q_), p_, xy, m_);
@@ -1765,7 +1795,11 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int S = job->S;
-    if (TAB_LDS) for (int k = tid; k < S * S; k += PBLOCK) PM.table[k] = job->table[k];
+    if (TAB_LDS) {
+        const float f_ng0 = job->ng;
+        const double t2 = (double)(2 * f_ng0), t1 = (double)(0.0f + f_ng0);       // VA:1364-1367: float operations, promoted
+        for (int k = tid; k < S * S; k += PBLOCK) { const float t = job->table[k]; PM.tab2[k][0] = t2 + (double)t; PM.tab2[k][1] = t1 + (double)t; }
+    }
     for (int k = tid; k < PRK * PNT * 3; k += PBLOCK) (&PM.sc[0][0][0])[k] = neg_inf();
     if (tid < 4) PM.null_cell[tid] = neg_inf();
     if (tid < PNW) { PM.progress[tid] = -1; PM.arrived[tid] = -1; }
@@ -1773,6 +1807,15 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
     if (tid < PNA) PM.assist_done[tid] = -1;
     __syncthreads();
 
+#ifdef PG_PIPE_STATS
+    if (tid < 4 && 3 * (job->Lx + job->Ly) >= 4096)           // slot counters of the per-run records (hot_run)
+        ((PG_GLOBAL int *)job->trace)[((3 * (job->Lx + job->Ly) / 4 * 3 + 15) & ~15) + tid] = 0;
+    if (lane == 0 && 3 * (job->Lx + job->Ly) >= 4096) {       // which SIMD / CU every wave of the workgroup landed on
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        ((PG_GLOBAL int *)job->trace)[3 * (job->Lx + job->Ly) - 1100 + (tid >> 6)] = (int)hwid;
+    }
+#endif
     if (tid >= PNT + 64 * PNA) {
         const View J = load_view(job);
         pipe_loader(J, psc, lane);
@@ -1856,8 +1899,8 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
             else n_items = (nL > 0 ? nL : 1) * (nR > 0 ? nR : 1);
             if (nL > 0 && nR > 0) {
                 const int ti = (wi & 0xffff) + (wj & 0xffff) * S;
-                const float sm = TAB_LDS ? PM.table[ti] : far_f32(table + ti);
-                tM = tng2 + (double)sm; tX = tng1 + (double)sm;
+                if (TAB_LDS) { tM = PM.tab2[ti][0]; tX = PM.tab2[ti][1]; }
+                else { const float sm = far_f32(table + ti); tM = tng2 + (double)sm; tX = tng1 + (double)sm; }
             }
             const double extX = (double)(((j == 0 || j == Ly - 1) && !no_terminal_edges) ? f_gE : f_ge);
             const double extY = (double)(((r == 0 || r == Lx - 1) && !no_terminal_edges) ? f_gE : f_ge);
@@ -2061,10 +2104,10 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
                         const FarAsk fa_ = {true, off1 + 24ll * (ca_ - p1.x)}, fb_ = {true, off1 + 24ll * (cb_ - p1.x)};
                         const FarAsk fc_ = {true, off2 + 24ll * (cc_ - p2.x)}, fn_ = {false, 0};
                         const int ti = (gl.x & 0xffff) + (gr.x & 0xffff) * S;
-                        const float sm = TAB_LDS ? PM.table[ti & 255] : 0.0f;
+                        double tM = 0, tX = 0;
+                        if (TAB_LDS) { tM = PM.tab2[ti & 255][0]; tX = PM.tab2[ti & 255][1]; }
                         far_fetch4(sc_out, fa_, fb_, fc_, fn_, axy, am, bxy, bmm, cxy, cm, dxy, dmm);
-                        const float smv = TAB_LDS ? sm : far_f32(table + ti);
-                        const double tM = tng2 + (double)smv, tX = tng1 + (double)smv;
+                        if (!TAB_LDS) { const float smv = far_f32(table + ti); tM = tng2 + (double)smv; tX = tng1 + (double)smv; }
                         const double ax = inA ? axy.x : NI, ay = inA ? axy.y : NI, amv = inA ? am : NI;
                         const double bxv = inB ? bxy.x : NI, byv = inB ? bxy.y : NI, bmv = inB ? bmm : NI;
                         const double cxv = inC ? cxy.x : NI, cyv = inC ? cxy.y : NI, cmv = inC ? cm : NI;
@@ -2077,9 +2120,11 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
                         if ((unsigned)(nl - 1) < 2u && (unsigned)(nr - 1) < 2u && r >= 2 && r <= Lx - 2 && jj >= 2 && jj <= Ly - 2) {
                             // interior cell, at most two bwd edges per site: its eight operands in one round trip
                             const int ti = (gl.x & 0xffff) + (gr.x & 0xffff) * S;
-                            const float smv = TAB_LDS ? PM.table[ti & 255] : far_f32(table + ti);
+                            double tM, tX;
+                            if (TAB_LDS) { tM = PM.tab2[ti & 255][0]; tX = PM.tab2[ti & 255][1]; }
+                            else { const float smv = far_f32(table + ti); tM = tng2 + (double)smv; tX = tng1 + (double)smv; }
                             multi2_cell<true>(sc_out, psc, d, resmask, slot, gl, gr, r, jj, reduced_terminal, go, ge, ng,
-                                              tng2 + (double)smv, tng1 + (double)smv, wx, wy, wm, qx, qy, qm);
+                                              tM, tX, wx, wy, wm, qx, qy, qm);
                         } else {
                             gen_cell(d, slot, resmask, r, jj, wx, wy, wm, qx, qy, qm);
                         }
@@ -2115,7 +2160,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
             // ahead (column d+2-row) replaces this step's, the model score one step ahead (a lane's row
             // record is in its registers at least three steps before the row enters the band).
             cra = PM.recR[(d + 2 - row) & (PRW - 1)];
-            if (TAB_LDS) smf = PM.table[((rL.x & 0xffff) + (crb.x & 0xffff) * S) & 255];
+            // (small tables: classes 0..2 run in hot_run, which takes the match terms from PM.tab2 itself)
             // lane 0's operand of the next step, if the upstream wave has already produced it: into the set
             // that was C here and is A there
             nb_valid = p_up >= d;

@@ -47,8 +47,8 @@ if os.environ.get("PG_STAMPS"):
         print("wave %d wide steps, Mcycles: drain before %.0f, rendezvous %.0f, cells %.0f, drain after %.0f" % ((w,) + tuple(t / 1e6)))
 if os.environ.get("PG_STAMPS"):
     b4 = raw[n_int - 800:]
-    kinds = {1: "loader rows", 2: "loader cols", 3: "downstream (ring row reuse)", 4: "upstream (row above)", 5: "descriptor window",
-             6: "far: all waves 8 steps behind", 7: "rendezvous", 8: "assist wave (staged multi-edge candidates)"}
+    kinds = {0: "asm loop entries / diagonals run in it (M)", 1: "loader rows", 2: "loader cols", 3: "downstream (ring row reuse)", 4: "upstream (row above)", 5: "descriptor window / asm: exits after 48 looks at the upstream flag (count), ... downstream (M)",
+             6: "far: all waves 8 steps behind / asm: looks at the upstream flag (count)", 7: "rendezvous / asm: exits with no row near the band (count)", 8: "assist wave (staged multi-edge candidates)", 9: "asm: upstream waits (count) / downstream waits (M = count / 1e6)"}
     for w in range(4):
         n = b4[20 * w: 20 * w + 10].astype(np.int64); t = b4[20 * w + 10: 20 * w + 20].astype(np.int64) * 256
         print("wave %d waits (count, Mcycles): " % w + "; ".join("%s %d %.0fM" % (kinds[k], n[k], t[k] / 1e6) for k in sorted(kinds)))
@@ -59,6 +59,17 @@ if os.environ.get("PG_STAMPS"):
         t = b5[8 * a_ + 1: 8 * a_ + 5].astype(np.int64) * 256
         print("assist %d: %d diagonals; cycles/diagonal: prepare %.0f, wait for compute waves %.0f, compute %.0f, publish %.0f" %
               ((a_, n) + tuple(t / n)))
+if os.environ.get("PG_STAMPS"):
+    b6 = raw[n_int - 1100: n_int - 1092].astype(np.int64)
+    print("waves 0-3 compute, 4-6 assist, 7 loader: (wave slot, SIMD, CU) =", [(int(x & 15), int((x >> 4) & 3), int((x >> 8) & 15)) for x in b6])
+if os.environ.get("PG_STAMPS") and os.environ.get("PG_RUNS_OUT"):
+    r0 = (n_int // 4 * 3 + 15) & ~15
+    cap = (n_int - 1200 - r0 - 16) // 16
+    cnt = raw[r0: r0 + 4].copy()
+    recs = raw[r0 + 16: r0 + 16 + 16 * cap].reshape(cap, 4, 4)
+    cls_, _w = pg.debug_plan(l, r, b)
+    np.savez_compressed(os.environ["PG_RUNS_OUT"], cnt=cnt, recs=recs[: int(min(cap, cnt.max()))], cls=cls_)
+    print("runs of the asm loop per wave:", cnt.tolist(), "capacity", cap)
 if os.environ.get("PG_CHECK"):
     import oracle
     bad = 0

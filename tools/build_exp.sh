@@ -1,0 +1,15 @@
+#!/bin/bash
+# Timing experiments on the hand-scheduled loop: builds pagan2-msa_amd/libpagan_dp_exp_<x>.so for every PG_HOT_EXP
+# variant named on the command line (tools/gen_hot_asm.py: the variants drop parts of the step -- WRONG RESULTS, same
+# schedule), then regenerates the product's loop.  Use with PAGAN_DP_LIB=... tests/diagnostics/probe_pair.py.
+set -e
+cd "$(dirname "$0")/.."
+for x in "$@"; do
+    PG_HOT_EXP=$x python tools/gen_hot_asm.py
+    python - "$x" <<'PY'
+import importlib.util, sys
+spec = importlib.util.spec_from_file_location("_b", "pagan2-msa_amd/build.py"); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+print(m.build(force=True, out=m.HERE + "/libpagan_dp_exp_%s.so" % sys.argv[1]))
+PY
+done
+python tools/gen_hot_asm.py

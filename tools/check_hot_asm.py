@@ -103,6 +103,13 @@ def main():
     a = hip.index('#include "dp_pipe_hot.inc"')
     b = hip.index(");", a)
     clob = set(re.findall(r'"([vs]\d+|vcc|scc)"', hip[a:b]))
+    if "PG_HOT_CLOBBERS" in hip[a:b]:
+        # the macro in front of hot_run: every VGPR from v136 up, the SGPRs s36 .. s87 (its expansion is checked here too)
+        m = re.search(r"#define PG_HOT_CLOBBERS(.*?)\n\n", hip, re.S)
+        text = m.group(1)
+        for pre, lo in re.findall(r"PG_([VS])8\((\d+)\)", text):
+            clob |= {"%s%d%d" % (pre.lower(), int(lo), k) for k in range(10)}
+        clob |= set(re.findall(r'"([vs]\d+)"', text))
     missing = sorted(x for x in named if x not in clob and x != "vcc")
     if missing:
         print("registers named by the loop but not clobbered:", " ".join(missing))
