@@ -61,6 +61,7 @@
 #define PBLOCK (PNT + 64 * PNA + 64)     // compute waves, assist waves, loader wave
 static_assert(PNTW == PNT - PAGE && PRK >= PAGE && PG_PIPE_WINDOW + 160 <= PRW, "kernel geometry out of step with dp_device.h");
 static_assert(PNA == 3 && PST == 3 && PAGE >= PLAND + 4, "assist wave a stages the diagonals d % 3 == a into slot a, at most two diagonals ahead; far cells have landed");
+#define PFAR_POOL ((PNT * 4) / 24)  // cells of 24 bytes in one staging slot of spm
 // staged back-pointer words: the regular bits of a back-pointer plus what the compute wave needs to merge
 #define PS_ONLY 0x80000000u      // the site has no edge from the previous site: the staged value IS the state's value
 #define PS_FIRST 0x40000000u     // the staged winner precedes the previous-site edge in the list: it wins a tie
@@ -883,8 +884,31 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
     // (off the chain "compute waves completed d-2 -> d is staged": what remains there is the same as for class 1)
     double q_fx[4] = {0, 0, 0, 0}, q_fy[4] = {0, 0, 0, 0}, q_fm[4] = {0, 0, 0, 0};
     bool q_far[4] = {false, false, false, false};
+    // Small tables (scores-only hot loop): batches whose cells have at most three edges on one side opposite a simple site, or at
+    // most two on either side (kinds 1..3: all but a few) are decoded down to EIGHT operand slots per cell -- 0,1 the left
+    // site's edges that do not start at the previous site (X from (row-dL, j)), 2,3 the right site's (Y from (row, j-dR)),
+    // 4..7 the (left edge, right edge) pairs (M from (row-dL, j-dR)) with their two weights -- each an LDS offset into the
+    // ring (the all -inf cell if absent) or, for a cell that left the ring, its scores fetched from L2 HERE, off the chain
+    // "compute waves completed d-2 -> d is staged".  Only VALUES are staged (the back-pointers come from pg_backptr), so
+    // the order of the candidates does not matter: a state's value is the maximum over its edges of
+    // max(own + ge, max(other, M + ng) + go), M's over its pairs of (max(M + tM, max(X, Y) + tX) + lw) + rw (the folding
+    // tools/gen_hot_asm.py explains).
+    // The fetched cells go into a pool of PFAR_POOL cells per assist wave (the memory of spm[a][.]: nobody reads staged M
+    // back-pointers of a small-table job) and the slot's offset points there: the chain reads eight cells, wherever they are.
+    bool q_val = false, v_msL = false, v_msR = false, v_onlyL = false, v_onlyR = false;
+    bool q_three = false, q_gap2 = false, q_pair34 = false;       // wave-uniform: some cell of the batch has a third edge / a second gap operand / more than two pairs
+    int v_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double v_lw[4] = {0, 0, 0, 0}, v_rw[4] = {0, 0, 0, 0};
     int scan_d = a;                                                // next diagonal whose descriptor has not been looked at
 
+#ifdef PG_PIPE_STATS
+    long long as_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // cycles: prepare (rest), waiting for the compute waves, compute, publish; inside prepare: scan, batch, decode, far
+    int as_n = 0;
+#define ASTAMP(k) do { const long long t_ = __builtin_readcyclecounter(); as_t[k] += t_ - as_t0; as_t0 = t_; } while (0)
+    long long as_t0 = __builtin_readcyclecounter();
+#else
+#define ASTAMP(k)
+#endif
     // classification of one multi-edge cell: 1 one multi-edge site with <= 2 edges, 2 ... with 3, 3 two multi-edge sites
     // with <= 2 edges each, 4 anything else
     auto classify = [&](const pg_i4 &rL, const pg_i4 &cR) {
@@ -914,7 +938,8 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
                     else assist1_cell<false, false>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, eg, em, pg, pm, left);
                 }
                 if (left) { PM.sx[stg][at] = eg; PM.spx[stg][at] = pg; } else { PM.sy[stg][at] = eg; PM.spy[stg][at] = pg; }
-                PM.sM[stg][at] = em; PM.spm[stg][at] = pm;
+                PM.sM[stg][at] = em;
+                if (!TAB_LDS) PM.spm[stg][at] = pm;                // (small tables: spm's memory is the far-cell pool)
             }
         } else if (on) {
             double ex, ey, em;
@@ -934,7 +959,8 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
                 else assist2_cell<false>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, ex, ey, em, px, py, pm);
             }
             PM.sx[stg][at] = ex; PM.sy[stg][at] = ey; PM.sM[stg][at] = em;
-            PM.spx[stg][at] = px; PM.spy[stg][at] = py; PM.spm[stg][at] = pm;
+            PM.spx[stg][at] = px; PM.spy[stg][at] = py;
+            if (!TAB_LDS) PM.spm[stg][at] = pm;
         }
     };
     // one batch from the compacted list into registers
@@ -985,13 +1011,15 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
         return flush ? total : n_ns;
     };
     // looks for the next diagonal of this wave with work and prepares it
+    pg_i8 q_next = psc[a < nd ? a : 0];                            // descriptor of scan_d, requested a pass ahead (a scalar load that misses costs ~2k cycles)
     auto prepare = [&]() {
         q_d = -1;
         while (scan_d < nd) {
             if (flag_load(&PM.abort_flag) != 0) return;
             const int d = scan_d;
-            const pg_i8 cur = psc[d];
+            const pg_i8 cur = q_next;
             scan_d += PNA * (int)((unsigned)cur.s4 >> 20);          // the host's hop count: straight to this wave's next diagonal with work
+            q_next = psc[scan_d < nd ? scan_d : nd];                // (the array carries one entry of padding)
             const int cls0 = cur.s4 & 15;
             if (!(cls0 == 2 || (!TAB_LDS && cls0 <= 1))) continue;  // small tables: class 1 is the compute waves' own (hot_run)
             // small tables: bit 4 marks a class 2 diagonal whose operands all lie in the ring (class 2 for the shape of a site):
@@ -1009,14 +1037,131 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
                 if (pw2 < d - PST) pw2 = POLL(&PM.progress[2], d - PST, 9);
                 if (pw3 < d - PST) pw3 = POLL(&PM.progress[3], d - PST, 9);
             }
+            ASTAMP(0);
             const int n = scan(d, cls, lo, hi, q_mask, false);
+            ASTAMP(4);
             q_big = n > 64;
             q_n = q_big ? 0 : n;
             q_fast = false;
+            q_val = false;
             if (!q_big) {
                 bool on;
                 fetch_batch(d, d % PST, q_n, on, q_row, q_j, q_kind, q_rL, q_cR, q_tM, q_tX);
-                q_fast = (cls == 1 || (TAB_LDS && cls == 2)) && q_n > 0 && __builtin_amdgcn_ballot_w64(on && q_kind != 1) == 0;
+                ASTAMP(5);
+                if (TAB_LDS && q_n > 0 && __builtin_amdgcn_ballot_w64(on && (q_kind < 1 || q_kind > 3)) == 0) {
+                    bool ok = true, any_far = false;
+                    int f_age[8], f_p[8];
+                    bool v_far[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { f_age[k] = 0; f_p[k] = 0; v_far[k] = false; v_off[k] = (int)offsetof(PipeSmem, null_cell); }
+                    {
+                        // straight-line, for every lane (the ones without a cell decode zeros and keep the all -inf cell);
+                        // third edges, second gap operands and the third / fourth pair only when some cell has them
+                        const int nL = on ? (q_rL.x >> PR_NE_SHIFT) & 127 : 1, nR = on ? (q_cR.x >> PR_NE_SHIFT) & 127 : 1;
+                        int dL[3] = {1, 1, 1}, dR[3] = {1, 1, 1};
+                        double lwv[3] = {0, 0, 0}, rwv[3] = {0, 0, 0};
+                        edge_at<true>(q_rL, 0, q_row, dL[0], lwv[0]); edge_at<true>(q_rL, 1, q_row, dL[1], lwv[1]);
+                        edge_at<false>(q_cR, 0, q_j, dR[0], rwv[0]); edge_at<false>(q_cR, 1, q_j, dR[1], rwv[1]);
+                        if (!on || nL < 1) dL[0] = 1;
+                        if (!on || nL < 2) dL[1] = 1;
+                        if (!on || nR < 1) dR[0] = 1;
+                        if (!on || nR < 2) dR[1] = 1;
+                        q_three = __builtin_amdgcn_ballot_w64(on && (nL > 2 || nR > 2)) != 0;
+                        if (q_three) {
+                            if (on && nL > 2) edge_at<true>(q_rL, 2, q_row, dL[2], lwv[2]);
+                            if (on && nR > 2) edge_at<false>(q_cR, 2, q_j, dR[2], rwv[2]);
+                        }
+                        v_msL = !(q_rL.x & PR_SIMPLE); v_msR = !(q_cR.x & PR_SIMPLE);
+                        const int slot = d % PRK;
+                        const int null_off = (int)offsetof(PipeSmem, null_cell), ring_off = (int)offsetof(PipeSmem, sc);
+                        // one operand: in the ring (class 1: all of them), or -- class 2 -- asked of L2 below
+                        auto put = [&](int k, bool present, int age, int p_) {
+                            const bool resident = cls == 1 || (age < PAGE && ((q_mask >> (age & 31)) & 1u));
+                            int s_ = slot - age;
+                            s_ += s_ < 0 ? PRK : 0;
+                            const int off = ring_off + (s_ * PNT + (p_ & (PNT - 1))) * 24;
+                            v_off[k] = (present && resident) ? off : null_off;
+                            const bool far = present && !resident;
+                            ok = ok && !(far && age < PAGE);       // a recent diagonal that is not in the ring (after a wide run): not landed yet
+                            v_far[k] = far; any_far = any_far || far; f_age[k] = age; f_p[k] = p_;
+                        };
+                        // gap operands: the (at most two) edges of a side that do not start at the previous site
+                        const bool naL0 = dL[0] != 1, naL1 = dL[1] != 1, naL2 = dL[2] != 1;
+                        const bool naR0 = dR[0] != 1, naR1 = dR[1] != 1, naR2 = dR[2] != 1;
+                        const int cL = (int)naL0 + (int)naL1 + (int)naL2, cR_ = (int)naR0 + (int)naR1 + (int)naR2;
+                        if (on && (cL > 2 || cR_ > 2 || nL * nR > 4 || nL < 1 || nR < 1)) ok = false;
+                        const int gL0 = naL0 ? dL[0] : (naL1 ? dL[1] : dL[2]), gL1 = (naL0 && naL1) ? dL[1] : dL[2];
+                        const int gR0 = naR0 ? dR[0] : (naR1 ? dR[1] : dR[2]), gR1 = (naR0 && naR1) ? dR[1] : dR[2];
+                        put(0, on && cL >= 1, gL0, q_row - gL0);
+                        put(2, on && cR_ >= 1, gR0, q_row);
+                        q_gap2 = __builtin_amdgcn_ballot_w64(on && (cL >= 2 || cR_ >= 2)) != 0;
+                        if (q_gap2) {
+                            put(1, on && cL >= 2, gL1, q_row - gL1);
+                            put(3, on && cR_ >= 2, gR1, q_row);
+                        }
+                        v_onlyL = cL == nL; v_onlyR = cR_ == nR;  // no edge from the previous site: the staged value IS the state's
+                        // pairs, row-major (at most four): t -> (k1, k2)
+                        q_pair34 = __builtin_amdgcn_ballot_w64(on && nL * nR > 2) != 0;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            if (t >= 2 && !q_pair34) break;
+                            const int k1 = nR == 1 ? t : (nR == 2 ? t >> 1 : (t >= 3 ? 1 : 0)), k2 = t - k1 * nR;
+                            const bool present = on && t < nL * nR && k1 < 3;
+                            const int a1 = k1 == 0 ? dL[0] : (k1 == 1 ? dL[1] : dL[2]), a2 = k2 == 0 ? dR[0] : (k2 == 1 ? dR[1] : dR[2]);
+                            v_lw[t] = k1 == 0 ? lwv[0] : (k1 == 1 ? lwv[1] : lwv[2]);
+                            v_rw[t] = k2 == 0 ? rwv[0] : (k2 == 1 ? rwv[1] : rwv[2]);
+                            put(4 + t, present, a1 + a2, q_row - a1);
+                        }
+                        // an edge that starts at site 0 opens a gap for free (BA.h:490-513): left to the general code
+                        if (on && ((naL0 && q_row == dL[0]) || (naL1 && q_row == dL[1]) || (naL2 && q_row == dL[2]) ||
+                                   (naR0 && q_j == dR[0]) || (naR1 && q_j == dR[1]) || (naR2 && q_j == dR[2]))) ok = false;
+                    }
+                    ASTAMP(6);
+                    if (__builtin_amdgcn_ballot_w64(on && !ok) == 0) {
+                        q_val = true;
+                        if (__builtin_amdgcn_ballot_w64(on && any_far) != 0) {
+                            // cells that left the ring (>= PAGE diagonals back) have landed once every wave has completed d - PAGE + PLAND
+                            if (diags_ld < d) diags_ld = POLL(&PM.loaded[2], d, 5);
+                            if (pw0 < d - PAGE + PLAND) pw0 = POLL(&PM.progress[0], d - PAGE + PLAND, 9);
+                            if (pw1 < d - PAGE + PLAND) pw1 = POLL(&PM.progress[1], d - PAGE + PLAND, 9);
+                            if (pw2 < d - PAGE + PLAND) pw2 = POLL(&PM.progress[2], d - PAGE + PLAND, 9);
+                            if (pw3 < d - PAGE + PLAND) pw3 = POLL(&PM.progress[3], d - PAGE + PLAND, 9);
+                            ASTAMP(8);
+                            FarAsk fa[8];
+                            pg_d2 fxy[8];
+                            double fm_[8];
+                            int n_pool = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                fa[k].need = false; fa[k].boff = 0; fxy[k].x = NI_; fxy[k].y = NI_; fm_[k] = NI_;
+                                if (on && v_far[k]) fa[k] = far_ask(psc, d, f_age[k], f_p[k]);   // (need = false outside the band: the slot keeps -inf)
+                                // its place in the pool
+                                const unsigned long long mk = __builtin_amdgcn_ballot_w64(fa[k].need);
+                                if (fa[k].need) {
+                                    const int at_ = n_pool + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                                    v_off[k] = (int)((const char *)&PM.spm[a][0] - (const char *)&PM) + 24 * at_;
+                                }
+                                n_pool += __builtin_popcountll(mk);
+                            }
+                            ASTAMP(9);
+                            if (n_pool > PFAR_POOL) { q_val = false; }       // (more far cells than the pool holds: the general code)
+                            else {
+                                far_fetch8(sc_out, fa, fxy, fm_);
+                                ASTAMP(10);
+#pragma unroll
+                                for (int k = 0; k < 8; ++k)
+                                    if (fa[k].need) {
+                                        double *c = (double *)((char *)&PM + v_off[k]);
+                                        c[PG_X] = fxy[k].x; c[PG_Y] = fxy[k].y; c[PG_M] = fm_[k];
+                                    }
+                            }
+                            ASTAMP(7);
+                        }
+                        if (q_val) return;
+                    }
+                }
+                // (small tables: the eight-slot decoding above replaces this one; what it declined goes to the general code)
+                q_fast = !TAB_LDS && cls == 1 && q_n > 0 && __builtin_amdgcn_ballot_w64(on && q_kind != 1) == 0;
                 if (q_fast) {
                     bool ok = true, any_far = false;
                     int f_age[4] = {0, 0, 0, 0}, f_p[4] = {0, 0, 0, 0};
@@ -1084,14 +1229,6 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
             return;
         }
     };
-#ifdef PG_PIPE_STATS
-    long long as_t[4] = {0, 0, 0, 0};      // cycles: prepare, waiting for the compute waves, compute, publish
-    int as_n = 0;
-#define ASTAMP(k) do { const long long t_ = __builtin_readcyclecounter(); as_t[k] += t_ - as_t0; as_t0 = t_; } while (0)
-    long long as_t0 = __builtin_readcyclecounter();
-#else
-#define ASTAMP(k)
-#endif
     prepare();
     while (q_d >= 0) {
         const int d = q_d;
@@ -1106,6 +1243,33 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
         if (q_cls == 2 && diags_ld < d) diags_ld = POLL(&PM.loaded[2], d, 5);
         ASTAMP(1);
         if (q_big) scan(d, q_cls, q_lo, q_hi, q_mask, true);
+        else if (q_val) {
+            if (lane < q_n) {
+                const char *base = (const char *)&PM;
+                double cx[8], cy[8], cm[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    cx[k] = NI_; cy[k] = NI_; cm[k] = NI_;
+                    if (((k == 1 || k == 3) && !q_gap2) || (k >= 6 && !q_pair34)) continue;      // (wave-uniform: no cell of the batch has it)
+                    const double *c = (const double *)(base + v_off[k]);
+                    cx[k] = c[PG_X]; cy[k] = c[PG_Y]; cm[k] = c[PG_M];
+                }
+                auto gapv = [&](double own, double other, double m_) { return __builtin_fmax(own + ge, __builtin_fmax(other, m_ + ng) + go); };
+                double ex = gapv(cx[0], cy[0], cm[0]), ey = gapv(cy[2], cx[2], cm[2]);
+                if (q_gap2) { ex = __builtin_fmax(ex, gapv(cx[1], cy[1], cm[1])); ey = __builtin_fmax(ey, gapv(cy[3], cx[3], cm[3])); }
+                double em = NI_;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t >= 2 && !q_pair34) break;
+                    const double v = (__builtin_fmax(cm[4 + t] + q_tM, __builtin_fmax(cx[4 + t], cy[4 + t]) + q_tX) + v_lw[t]) + v_rw[t];
+                    em = __builtin_fmax(em, v);
+                }
+                const int stg = a, at = q_row & (PNT - 1);          // d % PST == d % PNA == a
+                if (v_msL) { PM.sx[stg][at] = ex; PM.spx[stg][at] = v_onlyL ? PS_ONLY : 0u; }
+                if (v_msR) { PM.sy[stg][at] = ey; PM.spy[stg][at] = v_onlyR ? PS_ONLY : 0u; }
+                PM.sM[stg][at] = em;
+            }
+        }
         else if (q_fast) {
             if (lane < q_n) {
                 const char *base = (const char *)&PM;
@@ -1147,9 +1311,9 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
     }
 #ifdef PG_PIPE_STATS
     if (lane == 0 && 3 * (job->Lx + job->Ly) >= 4096) {
-        PG_GLOBAL int *o = (PG_GLOBAL int *)job->trace + 3 * (job->Lx + job->Ly) - 1000 + 8 * a;
+        PG_GLOBAL int *o = (PG_GLOBAL int *)job->trace + 3 * (job->Lx + job->Ly) - 1000 + 16 * a;
         o[0] = as_n;
-        for (int k = 0; k < 4; ++k) o[1 + k] = (int)(as_t[k] >> 8);
+        for (int k = 0; k < 12; ++k) o[1 + k] = (int)(as_t[k] >> 8);
     }
 #endif
 }
@@ -1474,7 +1638,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
             else if (hstg == 1) { if (as1 < d) as1 = POLLX(&PM.assist_done[1], d, 8); }
             else { if (as2 < d) as2 = POLLX(&PM.assist_done[2], d, 8); }
             const double ex = PM.sx[hstg][tid], ey = PM.sy[hstg][tid], em = PM.sM[hstg][tid];
-            const unsigned sfx = PM.spx[hstg][tid], sfy = PM.spy[hstg][tid], sfm = PM.spm[hstg][tid];
+            const unsigned sfx = PM.spx[hstg][tid], sfy = PM.spy[hstg][tid], sfm = PG_BP_NONE;      // (no staged M back-pointer: pg_backptr derives them all)
             const bool msL = !(rLc.x & PR_SIMPLE), msR = !(cR0.x & PR_SIMPLE);
             const bool tkx = msL && ((sfx & PS_ONLY) || ex > bx || (ex == bx && (sfx & PS_FIRST)));
             const bool tky = msR && ((sfy & PS_ONLY) || ey > by || (ey == by && (sfy & PS_FIRST)));
