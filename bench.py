@@ -39,12 +39,19 @@ WORKLOADS = {
     "cfg3_64x500aa_protein_full": (3, 64, 500, 0.05, 0.04, 0.004, 4.0, 0, "ARNDCQEGHILKMFPSTWYV"),
     "cfg5_512x10kb_dna_anchored": (5, 512, 10000, 0.02, 0.016, 0.0016, 4.0, 1, "ACGT"),
     "smoke_8x3kb_dna_anchored": (0, 8, 3000, 0.01, 0.008, 0.0008, 4.0, 1, "ACGT"),
+    # forward/backward (--full-probability) over the 15 node pairs of cfg2's tree
+    "fb_cfg2_16x2kb_dna_full": (2, 16, 2000, 0.05, 0.04, 0.004, 4.0, 0, "ACGT"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_CELL = 36            # 3 states x (f64 score + u32 back-pointer), SURVEY.md s.8(d)
-STEP_FLOOR_US = 0.25           # a lone wave's ~100 straight-line instructions per diagonal x 5.5 cycles at 2.4 GHz
-                               # (tools/ubench/issue_rate.hip)
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_fill.json")
+# Latency floors of one anti-diagonal step of the banded kernel.  The recurrence's true chain per diagonal
+# is two dependent fp64 operations (add -> max): ~2 x 8.4 cycles.  THIS FORMULATION's floor is what its class 0 step costs
+# a wave that waits for nobody: 83 instructions of which 9 are LDS operations (tools/ubench/lds_rate.hip: 5.2 cycles per
+# VALU / SALU instruction, 6-28 per LDS instruction), measured with every flag check removed: 389 cycles.
+CHAIN_FLOOR_US = 2 * 8.4 / 2400.0
+STEP_FLOOR_US = 389 / 2400.0
+PMC_PROFILE = os.path.join("profiles", "r03_pmc_fill.json")
+KERNELS = ("pg_fill_pipe", "pg_backptr", "pg_fill_tiles_flow", "pg_fill_wavefront")
 
 
 def make_inputs(workload):
@@ -66,8 +73,10 @@ def main():
                     help="N > 1 under torchrun: nccl (= RCCL, the default) or gloo (rehearsal on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: rank r uses device r %% device_count instead of device r (numbers are meaningless)")
-    ap.add_argument("--allow-stale-traffic", action="store_true",
-                    help="report roofline.traffic = null instead of failing when %s does not match this run" % PMC_PROFILE)
+    ap.add_argument("--allow-stale-traffic", action="store_true", help="(accepted for older scripts: this is the default now)")
+    ap.add_argument("--strict-traffic", action="store_true",
+                    help="fail instead of reporting roofline.traffic = null when %s does not describe this run "
+                         "(the profiling scripts use it)" % PMC_PROFILE)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,7 +96,86 @@ def main():
     torch.cuda.set_device(local_rank)
     if args.gpus > 1:
         return bench_work_queue(args, rank, local_rank, world)
+    if (args.workload or "").startswith("fb_"):
+        return bench_forward_backward(args, local_rank)
     return bench_one_gpu(args, local_rank)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def bench_forward_backward(args, device):
+    """Forward + backward sum-product sweeps (pg_fb_forward / pg_fb_backward, log space) over every node pair of the
+    workload's tree: cells/s of the two sweeps, per-kernel HIP-event times, the HBM roofline at 48 B per cell (two matrices
+    of 3 fp64 states, each written once), and the oracle's log-space restatement as the CPU baseline."""
+    import numpy as np
+    import pagan2_msa_amd as pg
+    from pagan2_msa_amd import host
+
+    workload = args.workload
+    cfg, leaves, length, branch, sub, indel, mean_len, anchors, alphabet = WORKLOADS[workload]
+    pg.lib().pagan_dp_select_device(device)
+    names, seqs, newick = make_inputs(workload)
+    msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=device, n_devices=1).align()
+    bf = np.array([sum(sq.count(x) for sq in seqs) for x in alphabet], np.float32)
+    bf /= bf.sum()
+    n_nodes = msa.n_internal
+    jobs = []
+    for k in range(n_nodes):
+        left, right, _model, band = msa.node_job(k)
+        jobs.append((left, right, host.model_prob(1 if len(alphabet) == 4 else 2, msa.node_info(k).dist, base_freq=bf), band))
+
+    def one_pass():
+        fwd = bwd = 0.0
+        cells, totals = 0, []
+        for left, right, mp, band in jobs:
+            fb = pg.FullProbability(left, right, mp, band, device=device)
+            fwd += fb.forward_ms; bwd += fb.backward_ms; cells += fb.cells
+            totals.append((fb.log_fwd, fb.log_bwd))
+            fb.close()
+        return fwd, bwd, cells, totals
+
+    for _ in range(args.warmup):
+        one_pass()
+    t0 = time.perf_counter()
+    acc = [one_pass() for _ in range(args.steps)]
+    elapsed = time.perf_counter() - t0
+    fwd_ms = float(np.mean([a[0] for a in acc])); bwd_ms = float(np.mean([a[1] for a in acc]))
+    cells, totals = acc[-1][2], acc[-1][3]
+    dev_s = (fwd_ms + bwd_ms) * 1e-3
+    ok = all(abs(f - b) <= 1e-7 * max(1.0, abs(f)) for f, b in totals)       # the reference's own check (VA:351-355): forward total = backward total
+    out = {
+        "metric": "DP cells/sec of the forward + backward sweeps (--full-probability), %s node pairs" % workload,
+        "value": cells / dev_s, "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dev_s, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": workload, "leaves": leaves, "length": length, "node_pairs": n_nodes, "cells_per_step": int(cells),
+                   "note": "value counts device time of the two kernels; wall per pass incl. allocation and upload: %.1f ms" % (1e3 * elapsed / args.steps)},
+        "roofline": {"bound": "hbm", "achieved": 48 * cells / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": 48 * cells / dev_s / 1e9 / HBM_PEAK_GBS, "kernel": "pg_fb_forward + pg_fb_backward",
+                     "algorithmic_bytes_per_cell": 48, "traffic": None,
+                     "kernels": [{"kernel": "pg_fb_forward", "ms_per_step": fwd_ms, "achieved": 24 * cells / (fwd_ms * 1e-3) / 1e9},
+                                 {"kernel": "pg_fb_backward", "ms_per_step": bwd_ms, "achieved": 24 * cells / (bwd_ms * 1e-3) / 1e9}]},
+        "parity_self_check": bool(ok),
+    }
+    if not args.no_cpu_baseline:
+        import oracle
+        oracle.build()
+        t0 = time.perf_counter()
+        c_cells, used, agree = 0, 0, True
+        for (left, right, mp, band), (lf, lb) in zip(jobs, totals):
+            if time.perf_counter() - t0 > args.cpu_seconds:
+                break
+            olf, olb, _p, _f = oracle.fb(left, right, mp, band=band, matrices=False)
+            agree = agree and abs(olf - lf) <= 1e-9 * abs(olf) and abs(olb - lb) <= 1e-9 * abs(olb)
+            c_cells += (left.n_sites - 1) * (right.n_sites - 1) if band is None else 0
+            used += 1
+        secs = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": c_cells / secs if secs > 0 else 0.0, "unit": "cells/s", "cores": 1, "kind": "port",
+                               "sample": "%d of %d node pairs, log-space restatement of the reference's forward + backward, %.1f s, single thread"
+                                         % (used, n_nodes, secs), "matches_gpu": bool(agree)}
+        ok = ok and agree
+    print(json.dumps(out))
+    if not ok:
+        raise SystemExit("bench.py: forward/backward self-check FAILED")
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -153,13 +241,15 @@ def bench_one_gpu(args, device):
     torch.cuda.synchronize()
     fill_ms = np.zeros((args.steps, len(batches)))
     trace_ms = np.zeros((args.steps, len(batches)))
-    ms = (C.c_double * 2)()
+    kern_ms = np.zeros((args.steps, len(batches), 4))          # per kernel: KERNELS
+    ms = (C.c_double * 6)()
     t0 = time.perf_counter()
     for s in range(args.steps):
         for b, hb in enumerate(batches):
             run(hb)
-            L.pagan_batch_last_ms(hb, ms)        # HIP events on the library's own stream bracket each kernel
-            fill_ms[s, b], trace_ms[s, b] = ms[0], ms[1]
+            L.pagan_batch_last_ms_detail(hb, ms)  # HIP events on the library's own streams bracket each kernel
+            fill_ms[s, b], trace_ms[s, b] = ms[5], ms[4]
+            kern_ms[s, b] = [max(ms[k], 0.0) for k in range(4)]
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
@@ -185,9 +275,34 @@ def bench_one_gpu(args, device):
 
     fill_launch_ms = fill_ms.mean(axis=0)                      # per level launch
     fill_step_ms = float(fill_launch_ms.sum())
-    achieved = BYTES_PER_CELL * cells / (fill_step_ms * 1e-3) / 1e9
     crit_steps = int(sum(steps_level))
     us_per_step = 1e3 * fill_step_ms / crit_steps
+    # per kernel: its cells (the planner's routing of every node, host only), its launches, its time.  The dominant kernel's
+    # figures are the roofline object's top-level fields; every kernel of the workload is listed under roofline.kernels.
+    routed = {}
+    for k in range(n_nodes):
+        left, right, model, band = msa.node_job(k)
+        route = pg.debug_route(left, right, model, band)[0].split(" ")[0]
+        routed[route] = routed.get(route, 0) + int(infos[k].cells)
+    kmean = kern_ms.mean(axis=0)                               # [level, kernel]
+    per_kernel = []
+    for q, name in enumerate(KERNELS):
+        t_ms = float(kmean[:, q].sum())
+        launches = int((kmean[:, q] > 0).sum())
+        if launches == 0:
+            continue
+        kcells = cells if name == "pg_backptr" else routed.get(name, 0)
+        if name == "pg_backptr":
+            kcells = routed.get("pg_fill_pipe", 0)
+            kbytes = 36                                        # 24 B of scores read (neighbours out of L2) + 12 B written per cell
+        else:
+            kbytes = 24 if name == "pg_fill_pipe" else BYTES_PER_CELL     # the banded fill stores scores only since round 3
+        ach = kbytes * kcells / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+        per_kernel.append({"kernel": name, "ms_per_step": t_ms, "launches_per_step": launches, "avg_launch_ms": t_ms / launches,
+                           "cells": int(kcells), "algorithmic_bytes_per_cell": kbytes, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                           "launch_ms_by_level": [float(x) for x in kmean[:, q]]})
+    dom = max(per_kernel, key=lambda e: e["ms_per_step"])
+    achieved = dom["achieved"]
     out = {
         "metric": ("DP cells/sec, 32x100 kb DNA progressive align (hot path in dependency order: fill + traceback per tree level)"
                    if workload.startswith("cfg4") else
@@ -211,15 +326,21 @@ def bench_one_gpu(args, device):
         "value_resident_batch": side_by_side,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "kernel": fill_kernel(anchors), "launches_per_step": len(batches),
-                     "avg_launch_ms": float(fill_launch_ms.mean()), "launch_ms_by_level": [float(x) for x in fill_launch_ms],
+                     "kernel": dom["kernel"], "launches_per_step": dom["launches_per_step"],
+                     "avg_launch_ms": dom["avg_launch_ms"], "launch_ms_by_level": dom["launch_ms_by_level"],
+                     "fill_ms_by_level": [float(x) for x in fill_launch_ms],
                      "cells_by_level": cells_level,
-                     "algorithmic_bytes_per_cell": BYTES_PER_CELL,
-                     "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells / len(batches),
-                     "latency": {"steps": crit_steps, "us_per_step": us_per_step, "floor_us_per_step": STEP_FLOOR_US,
-                                 "frac_of_floor": STEP_FLOOR_US / us_per_step,
-                                 "note": "steps = anti-diagonals on the critical path (longest alignment of every level); "
-                                         "floor from tools/ubench/issue_rate.hip"}},
+                     "algorithmic_bytes_per_cell": dom["algorithmic_bytes_per_cell"],
+                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_cell"] * dom["cells"] / dom["launches_per_step"],
+                     "algorithmic_bytes_per_cell_whole_fill": BYTES_PER_CELL,
+                     "kernels": per_kernel,
+                     "latency": {"steps": crit_steps, "us_per_step": us_per_step,
+                                 "chain_floor_us_per_step": CHAIN_FLOOR_US, "formulation_floor_us_per_step": STEP_FLOOR_US,
+                                 "floor_us_per_step": STEP_FLOOR_US, "frac_of_floor": STEP_FLOOR_US / us_per_step,
+                                 "note": "steps = anti-diagonals on the critical path (longest alignment of every level; banded "
+                                         "workloads).  chain floor: the recurrence's two dependent fp64 operations per diagonal; "
+                                         "formulation floor: this kernel's class 0 step with no wave waiting for another "
+                                         "(83 instructions, 9 of them LDS operations; tools/ubench/lds_rate.hip)"}},
         "kernels_ms": {"fill": fill_step_ms, "end_and_trace": float(trace_ms.mean(axis=0).sum()),
                        "end_and_trace_by_level": [float(x) for x in trace_ms.mean(axis=0)]},
         "e2e_wall_s": e2e_wall,
@@ -228,7 +349,7 @@ def bench_one_gpu(args, device):
         "e2e_breakdown_s": tm,
         "parity_self_check": bool(ok),
     }
-    out["roofline"].update(pmc_traffic(workload, cells, fill_kernel(anchors), len(batches), args.allow_stale_traffic))
+    out["roofline"].update(pmc_traffic(workload, cells, dom["kernel"], dom["launches_per_step"], args.strict_traffic))
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(msa, n_nodes, args.cpu_seconds)
         ok = ok and out["cpu_baseline"]["matches_gpu"]
@@ -325,6 +446,10 @@ def bench_work_queue(args, rank, local_rank, world):
             "speedup_vs_one_gpu": solo_s / (elapsed_max / args.steps),
             "e2e_breakdown_s_rank0": msa.timing(),
             "parity_self_check": bool(same),
+            "note": "BASELINE.json's headline (cfg4, 32 x 100 kb) does not shard: its levels hold 16/8/4/2/1 banded alignments, one "
+                    "workgroup each, which one MI355X already runs side by side, and a level lasts as long as its slowest "
+                    "alignment -- expect a flat DP time at 2/4/8 GPUs (only host work shards).  cfg5 (512 x 10 kb, 256 ready "
+                    "nodes at the first level, tiled wide-band alignments above) is the workload whose units fill more than one GPU.",
             "roofline": None, "cpu_baseline": None,
         }
         print(json.dumps(out))
@@ -348,11 +473,11 @@ def fill_kernel(anchors):
     return "pg_fill_ring" if os.environ.get("PAGAN_DP_FILL") == "ring" else "pg_fill_pipe"
 
 
-def pmc_traffic(workload, cells, kernel, launches, allow_stale):
-    """HBM bytes per launch of the fill kernel from the committed rocprofv3 --pmc passes of this same command
+def pmc_traffic(workload, cells, kernel, launches, strict):
+    """HBM bytes per launch of the dominant fill kernel from the committed rocprofv3 --pmc passes of this same command
     (WRITE_SIZE and FETCH_SIZE need separate profiler passes, they cannot be read from inside the bench).  The
-    profile names its workload, kernel and cells; a mismatch means it was taken on something else and is an error
-    (--allow-stale-traffic turns that into traffic = null)."""
+    profile names its workload, kernel and cells; a mismatch means it was taken on something else: traffic = null and
+    a warning (--strict-traffic: an error -- the profiling scripts use it)."""
     path = os.path.join(ROOT, PMC_PROFILE)
     try:
         prof = json.load(open(path))
@@ -367,10 +492,10 @@ def pmc_traffic(workload, cells, kernel, launches, allow_stale):
         prof, why = None, "cannot read it: %s" % e
     if why is None:
         return {"traffic": prof["hbm_bytes_per_step"] / launches, "traffic_source": PMC_PROFILE,
-                "traffic_over_algorithmic": prof["hbm_bytes_per_step"] / (BYTES_PER_CELL * cells)}
-    if workload.startswith("cfg4") and not allow_stale:
-        raise SystemExit("bench.py: %s does not describe this run (%s); re-collect it (DESIGN.md s.4) or pass "
-                         "--allow-stale-traffic" % (PMC_PROFILE, why))
+                "traffic_over_algorithmic": prof["hbm_bytes_per_step"] / (prof.get("algorithmic_bytes_per_cell", BYTES_PER_CELL) * cells)}
+    if strict:
+        raise SystemExit("bench.py: %s does not describe this run (%s); re-collect it (DESIGN.md s.4)" % (PMC_PROFILE, why))
+    print("bench.py: roofline.traffic = null: %s does not describe this run (%s)" % (PMC_PROFILE, why), file=sys.stderr)
     return {"traffic": None, "traffic_source": "%s not applicable: %s" % (PMC_PROFILE, why)}
 
 
@@ -391,9 +516,30 @@ def cpu_baseline(msa, n_nodes, budget_s):
         cells += r.cells
         used += 1
         agree = agree and r.same_alignment(msa.node_result(k))
-    return {"value": cells / secs if secs > 0 else 0.0, "unit": "cells/s", "cores": 1, "kind": "port",
-            "sample": "%d of %d node alignments of the same workload, %d cells, %.1f s, single thread" %
-                      (used, n_nodes, cells, secs), "matches_gpu": bool(agree)}
+    out = {"value": cells / secs if secs > 0 else 0.0, "unit": "cells/s", "cores": 1, "kind": "port",
+           "sample": "%d of %d node alignments of the same workload, %d cells, %.1f s, single thread" %
+                     (used, n_nodes, cells, secs), "matches_gpu": bool(agree)}
+    # the same restatement over every core of the host: node alignments of one level are independent,
+    # one thread each (ctypes releases the GIL); bounded to about a third of the single-thread budget
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        n_thr = os.cpu_count() or 1
+        jobs, est = [], 0.0
+        for k in order:
+            c = int(msa.node_info(k).cells)
+            if est >= budget_s * n_thr / 3.0 and jobs:
+                break
+            jobs.append(k); est += c / max(out["value"], 1.0)
+        inputs = [msa.node_job(k) for k in jobs]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(n_thr) as ex:
+            rs = list(ex.map(lambda j: oracle.dp_align(*j).cells, inputs))
+        dt = time.perf_counter() - t0
+        out["all_cores"] = {"value": sum(rs) / dt, "unit": "cells/s", "cores": n_thr,
+                            "sample": "%d node alignments, one thread each over %d threads, %d cells, %.1f s" % (len(jobs), n_thr, sum(rs), dt)}
+    except Exception as e:          # the single-thread figure stands on its own
+        out["all_cores"] = {"value": None, "error": str(e)}
+    return out
 
 
 if __name__ == "__main__":

@@ -171,6 +171,10 @@ int  pagan_batch_sync(pagan_batch *b);
 int  pagan_batch_fetch(pagan_batch *b, pagan_result *out /* [n] */);
 /* device milliseconds of the last run: [0]=fill kernel, [1]=end corner+traceback  */
 int  pagan_batch_last_ms(pagan_batch *b, double ms[2]);
+/* the same per kernel: ms[0] banded fill (pg_fill_pipe), ms[1] pg_backptr, ms[2] tiled fill (pg_fill_tiles_flow; it runs
+ * beside the banded kernels of a mixed batch), ms[3] HBM wavefront fill, ms[4] end corner + traceback, ms[5] the whole
+ * fill; -1 where the batch launched no such kernel */
+int  pagan_batch_last_ms_detail(pagan_batch *b, double ms[6]);
 int64_t pagan_batch_cells(const pagan_batch *b);
 void pagan_batch_destroy(pagan_batch *b);
 /* diagnostic builds only: raw bytes of job k's device trace buffer                    */
@@ -200,6 +204,11 @@ int  pagan_dp_debug_tiles_staircase(const int32_t *tiles, int32_t n);
 int  pagan_dp_debug_compact(const pagan_graph *left, const pagan_graph *right, const pagan_band *band, int32_t *keep_left,
                             int32_t *keep_right, int32_t *slot_left, int32_t *slot_right, int32_t *upper, int32_t *lower,
                             int32_t *n_out);
+/* diagnostic (host only): the fill kernel pagan_batch_create would give this job -- 0 pg_fill_pipe (model table in LDS),
+ * 1 pg_fill_pipe (large table), 2 pg_fill_tiles_flow, 3 pg_fill_wavefront; n_out[0] = 1 when its dead sites are taken
+ * out first, n_out[1] = cells of its widest anti-diagonal (n_out may be NULL); negative: the job's validation error  */
+int  pagan_dp_debug_route(const pagan_graph *left, const pagan_graph *right, const pagan_model *model, const pagan_band *band,
+                          int32_t *n_out);
 /* diagnostic: job k's scores, [cells][3] doubles (X, Y, M), diagonal-major                */
 int  pagan_batch_debug_scores(pagan_batch *b, int32_t k, double *dst, int64_t count);
 /* diagnostic: job k's back-pointers, [cells][3] packed words (X, Y, M), diagonal-major   */
@@ -234,6 +243,8 @@ int  pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan
 /* log of max_end.fwd_score ("full probability", VA:1562-1563) and of match[0][0].bwd_score (VA:345-349);
  * the reference checks their ratio (VA:351-355).                                                          */
 int  pagan_fb_totals(const pagan_fb *fb, double *log_fwd, double *log_bwd, int64_t *cells);
+/* device time of the two sweeps of pagan_fb_run, milliseconds: ms[0] pg_fb_forward, ms[1] pg_fb_backward */
+int  pagan_fb_kernel_ms(const pagan_fb *fb, double ms[2]);
 /* which: 0 log forward, 1 log backward, 2 posterior (compute_posterior_score, VA:1029-1034);
  * dst [Lx][Ly][3] row-major, states X, Y, M; outside the tunnel -inf / 0.                                  */
 int  pagan_fb_dump(pagan_fb *fb, int32_t which, double *dst);

@@ -109,6 +109,9 @@ class FullProbability:
         a, b, c = C.c_double(), C.c_double(), C.c_int64()
         _check(self._L.pagan_fb_totals(self._h, C.byref(a), C.byref(b), C.byref(c)), "pagan_fb_totals")
         self.log_fwd, self.log_bwd, self.cells = a.value, b.value, c.value
+        kms = (C.c_double * 2)()
+        _check(self._L.pagan_fb_kernel_ms(self._h, kms), "pagan_fb_kernel_ms")
+        self.forward_ms, self.backward_ms = kms[0], kms[1]
         self.shape = (left.n_sites - 1, right.n_sites - 1, 3)
 
     def _dump(self, which):
@@ -197,6 +200,20 @@ def debug_compact(left, right, band=None):
                                     up.ctypes.data_as(p32), lo.ctypes.data_as(p32), n.ctypes.data_as(p32)), "pagan_dp_debug_compact")
     return {"keep_left": kl[:n[0]].copy(), "keep_right": kr[:n[1]].copy(), "slot_left": sl[:n[2]].copy(), "slot_right": sr[:n[3]].copy(),
             "upper": up[:n[0] - 1].copy(), "lower": lo[:n[0] - 1].copy()}
+
+
+ROUTES = ("pg_fill_pipe", "pg_fill_pipe (large table)", "pg_fill_tiles_flow", "pg_fill_wavefront")
+
+
+def debug_route(left, right, model, band=None):
+    """Diagnostic (host only): (fill kernel pagan_batch_create would give this job, dead sites taken out first?, cells of
+    the widest anti-diagonal)."""
+    import numpy as np
+    n = np.zeros(2, np.int32)
+    rc = lib().pagan_dp_debug_route(C.byref(left.c), C.byref(right.c), C.byref(model.c), C.byref(band.c) if band is not None else None,
+                                    n.ctypes.data_as(C.POINTER(C.c_int32)))
+    _check(min(rc, 0), "pagan_dp_debug_route")
+    return ROUTES[rc], bool(n[0]), int(n[1])
 
 
 def debug_plan(left, right, band=None, with_lead=False):

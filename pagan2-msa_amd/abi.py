@@ -187,6 +187,8 @@ def declare(lib):
     lib.pagan_batch_fetch.restype = C.c_int
     lib.pagan_batch_last_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.pagan_batch_last_ms.restype = C.c_int
+    lib.pagan_batch_last_ms_detail.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.pagan_batch_last_ms_detail.restype = C.c_int
     lib.pagan_batch_cells.argtypes = [C.c_void_p]
     lib.pagan_batch_cells.restype = C.c_int64
     lib.pagan_batch_destroy.argtypes = [C.c_void_p]
@@ -201,6 +203,8 @@ def declare(lib):
     lib.pagan_dp_debug_compact.restype = C.c_int
     lib.pagan_dp_debug_tiles_staircase.argtypes = [_i32p, C.c_int32]
     lib.pagan_dp_debug_tiles_staircase.restype = C.c_int
+    lib.pagan_dp_debug_route.argtypes = [gp, gp, C.POINTER(CModel), bp, _i32p]
+    lib.pagan_dp_debug_route.restype = C.c_int
     lib.pagan_batch_debug_scores.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_int64]
     lib.pagan_batch_debug_scores.restype = C.c_int
     lib.pagan_batch_debug_backptrs.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32), C.c_int64]
@@ -216,6 +220,8 @@ def declare(lib):
     lib.pagan_fb_run.restype = C.c_int
     lib.pagan_fb_totals.argtypes = [C.c_void_p, f64p, f64p, C.POINTER(C.c_int64)]
     lib.pagan_fb_totals.restype = C.c_int
+    lib.pagan_fb_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.pagan_fb_kernel_ms.restype = C.c_int
     lib.pagan_fb_dump.argtypes = [C.c_void_p, C.c_int32, f64p]
     lib.pagan_fb_dump.restype = C.c_int
     lib.pagan_fb_posterior_cells.argtypes = [C.c_void_p, C.c_int32, _i32p, f64p]
@@ -232,6 +238,6 @@ def declare(lib):
 EXPORTED = ["pagan_dp_align", "pagan_dp_align_batch", "pagan_result_free", "pagan_dp_predict_bytes",
             "pagan_dp_count_cells", "pagan_dp_device_count", "pagan_dp_select_device", "pagan_batch_create",
             "pagan_batch_run", "pagan_batch_sync", "pagan_batch_fetch", "pagan_batch_last_ms",
-            "pagan_batch_cells", "pagan_batch_destroy", "pagan_batch_debug_trace", "pagan_dp_debug_plan", "pagan_dp_debug_tiles", "pagan_dp_debug_compact", "pagan_dp_debug_tiles_staircase", "pagan_dp_release_cache", "pagan_dp_cached_device_bytes", "pagan_batch_debug_scores", "pagan_batch_debug_backptrs", "pagan_batch_debug_poison",
-            "pagan_fb_run", "pagan_fb_totals", "pagan_fb_dump", "pagan_fb_posterior_cells", "pagan_fb_sample_path",
+            "pagan_batch_cells", "pagan_batch_last_ms_detail", "pagan_batch_destroy", "pagan_batch_debug_trace", "pagan_dp_debug_plan", "pagan_dp_debug_tiles", "pagan_dp_debug_compact", "pagan_dp_debug_tiles_staircase", "pagan_dp_release_cache", "pagan_dp_cached_device_bytes", "pagan_dp_debug_route", "pagan_batch_debug_scores", "pagan_batch_debug_backptrs", "pagan_batch_debug_poison",
+            "pagan_fb_run", "pagan_fb_totals", "pagan_fb_kernel_ms", "pagan_fb_dump", "pagan_fb_posterior_cells", "pagan_fb_sample_path",
             "pagan_fb_destroy", "pagan_dp_version"]

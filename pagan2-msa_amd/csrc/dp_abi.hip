@@ -485,6 +485,10 @@ struct pagan_batch {
     int max_bound = 0;           // largest traceback boundary count of any job
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // per-kernel brackets inside the fill (pagan_batch_last_ms_detail): 0/1 around the banded kernel, 2 behind pg_backptr,
+    // 3/4 around the tiled kernel (on its own stream when the batch also has banded jobs), 5 behind the HBM wavefront
+    hipEvent_t evk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool evk_set[6] = {false, false, false, false, false, false};
     int64_t cells = 0;
     size_t out_begin = 0;        // arena offset where the output arrays start
     bool ran = false;
@@ -698,6 +702,7 @@ int launch_fill(pagan_batch *b) {
         }
         // model tables of <= 16 states (DNA: 15) are cached in LDS; larger ones stay in HBM/L2
         const int n_small = b->n_ring_small, n_big = b->n_ring - b->n_ring_small;
+        HIP_TRY(hipEventRecord(b->evk[0], b->stream)); b->evk_set[0] = true;
         if (b->use_pipe) {
             if (n_small > 0)
                 hipLaunchKernelGGL(pg_fill_pipe<true>, dim3(n_small), dim3(pg_pipe_block()), pg_pipe_lds_bytes(), b->stream,
@@ -705,13 +710,16 @@ int launch_fill(pagan_batch *b) {
             if (n_big > 0)
                 hipLaunchKernelGGL(pg_fill_pipe<false>, dim3(n_big), dim3(pg_pipe_block()), pg_pipe_lds_bytes(), b->stream,
                                    b->d_jobs, b->d_which + n_small, b->flags);
+            HIP_TRY(hipEventRecord(b->evk[1], b->stream)); b->evk_set[1] = true;
             if (b->bp_pass) {
                 int max_nd = 1;
                 for (const PgDevJob &d : b->dj) max_nd = std::max(max_nd, d.nd);
                 hipLaunchKernelGGL(pg_backptr, dim3((max_nd + PG_BP_DIAGS - 1) / PG_BP_DIAGS, b->n_ring), dim3(256), 0, b->stream,
                                    b->d_jobs, b->d_which, (b->flags & 0xffu) | (b->bp_pass == 2 ? 0x100u : 0u));
+                HIP_TRY(hipEventRecord(b->evk[2], b->stream)); b->evk_set[2] = true;
             }
         } else {
+            b->evk_set[1] = false;
             if (n_small > 0)
                 hipLaunchKernelGGL(pg_fill_ring<true>, dim3(n_small), dim3(576), pg_ring_lds_bytes(), b->stream,
                                    b->d_jobs, b->d_which, b->flags);
@@ -728,10 +736,12 @@ int launch_fill(pagan_batch *b) {
         case 256: hipLaunchKernelGGL(pg_fill_wavefront<256>, grid, dim3(256), 0, b->stream, b->d_jobs, which, b->flags); break;
         default: hipLaunchKernelGGL(pg_fill_wavefront<1024>, grid, dim3(1024), 0, b->stream, b->d_jobs, which, b->flags); break;
         }
+        HIP_TRY(hipEventRecord(b->evk[5], b->stream)); b->evk_set[5] = true;
     }
     if (b->tile_off.size() > 1) {
         // after the banded kernels: their workgroups get compute units first; the persistent waves below hold theirs
         hipStream_t st = tile_stream;
+        HIP_TRY(hipEventRecord(b->evk[3], st)); b->evk_set[3] = true;
         if (b->tiles_flow) {
             // one persistent wave per compute unit (a tile fills the LDS) drains the batch's tiles in dependency order
             const int n_tiles = b->tile_off.back(), n_diag = (int)b->tile_off.size() - 1;
@@ -757,6 +767,7 @@ int launch_fill(pagan_batch *b) {
             }
         }
     }
+    if (b->tile_off.size() > 1) { HIP_TRY(hipEventRecord(b->evk[4], tile_stream)); b->evk_set[4] = true; }
     if (b->tile_off.size() > 1 && b->stream2) {
         HIP_TRY(hipEventRecord(b->ev_join, b->stream2));
         HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
@@ -903,6 +914,61 @@ int pagan_dp_select_device(int32_t device) {
     return PAGAN_OK;
 }
 
+// Dead sites out of one job (see CompactJob): fills `cj` and points `eff` at the compacted graphs / band when the job
+// qualifies (5 % dead sites or more, nothing validate_job would refuse).
+static void compact_job(const pagan_job &jb, bool allow, CompactJob *cjp, pagan_job *eff) {
+    CompactJob &cj = *cjp;
+    if (!allow || !jb.left || !jb.right || !jb.model) return;
+    if (check_graph(jb.left) != PAGAN_OK || check_graph(jb.right) != PAGAN_OK) return;     // validate_job reports it
+    const int nl = jb.left->n_sites, nr = jb.right->n_sites;
+    int dl = 0, dr = 0;
+    for (int s_ = 1; s_ + 2 < nl; ++s_) dl += jb.left->bwd_off[s_ + 1] == jb.left->bwd_off[s_];
+    for (int s_ = 1; s_ + 2 < nr; ++s_) dr += jb.right->bwd_off[s_ + 1] == jb.right->bwd_off[s_];
+    if (20 * (dl + dr) < nl + nr) return;                      // under 5 %: not worth the copies
+    // (what validate_job would refuse on the caller's graphs must not slip through on the smaller ones)
+    for (int s_ = 1; s_ + 1 < nl; ++s_) if (jb.left->state[s_] < 0 || jb.left->state[s_] >= jb.model->n_states) return;
+    for (int s_ = 1; s_ + 1 < nr; ++s_) if (jb.right->state[s_] < 0 || jb.right->state[s_] >= jb.model->n_states) return;
+    RowBand rb0;
+    if (rb0.build(nl - 1, nr - 1, jb.band) != PAGAN_OK) return;
+    cj.cells0 = rb0.cells();
+    cj.L0 = jb.left; cj.R0 = jb.right;
+    cj.l.build(jb.left); cj.r.build(jb.right);
+    eff->left = &cj.l.g; eff->right = &cj.r.g;
+    if (jb.band) {
+        compact_band(rb0, cj.l, cj.r, nr, &cj.up, &cj.lo);
+        const int rows = (int)cj.up.size();
+        cj.band.n = rows; cj.band.upper = cj.up.data(); cj.band.lower = cj.lo.data();
+        eff->band = &cj.band;
+    }
+    cj.on = true;
+}
+
+// Host-only: which fill kernel pagan_batch_create would give this job -- 0 pg_fill_pipe (model table in LDS), 1 pg_fill_pipe
+// (large table), 2 pg_fill_tiles_flow, 3 pg_fill_wavefront -- after taking its dead sites out as the batch does; negative: the
+// error validate_job reports.  n_out[0] = 1 when the job is aligned on compacted graphs, n_out[1] = widest diagonal.
+int pagan_dp_debug_route(const pagan_graph *left, const pagan_graph *right, const pagan_model *model, const pagan_band *band,
+                         int32_t *n_out) {
+    pagan_job jb;
+    std::memset(&jb, 0, sizeof(jb));
+    jb.left = left; jb.right = right; jb.model = model; jb.band = band;
+    pagan_job eff = jb;
+    CompactJob cj;
+    const char *ce = std::getenv("PAGAN_DP_COMPACT");
+    compact_job(jb, !(ce && std::strcmp(ce, "0") == 0), &cj, &eff);
+    HostJob hj;
+    RowBand rb;
+    bool use_pipe = true;
+    if (const char *f = std::getenv("PAGAN_DP_FILL")) use_pipe = std::strcmp(f, "ring") != 0;
+    const int rc = validate_job(eff, &hj, &rb, use_pipe);
+    if (rc != PAGAN_OK) return rc;
+    if (n_out) { n_out[0] = cj.on ? 1 : 0; n_out[1] = hj.dx.max_width; }
+    const char *wide_env = std::getenv("PAGAN_DP_WIDE");
+    const bool use_tiles = !std::getenv("PAGAN_DP_FORCE_GLOBAL_WAVEFRONT") && !(wide_env && std::strcmp(wide_env, "wavefront") == 0);
+    if (hj.ring_ok && !std::getenv("PAGAN_DP_FORCE_GLOBAL_WAVEFRONT")) return eff.model->n_states <= 16 ? 0 : 1;
+    if (use_tiles && !hj.tiles.empty()) return 2;
+    return 3;
+}
+
 // Host-only: the per-diagonal classes and the wave schedule pg_fill_pipe would be given for this job
 // (what validate_job computes); lets the planner be tested without a device.
 int pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, const pagan_band *band, uint8_t *cls_out,
@@ -1031,33 +1097,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     {
         const char *ce = std::getenv("PAGAN_DP_COMPACT");
         const bool allow = !(ce && std::strcmp(ce, "0") == 0);
-        parallel_jobs(n, [&](int k) {
-            const pagan_job &jb = jobs[k];
-            CompactJob &cj = b->compact[k];
-            if (!allow || !jb.left || !jb.right || !jb.model) return;
-            if (check_graph(jb.left) != PAGAN_OK || check_graph(jb.right) != PAGAN_OK) return;     // validate_job reports it
-            const int nl = jb.left->n_sites, nr = jb.right->n_sites;
-            int dl = 0, dr = 0;
-            for (int s_ = 1; s_ + 2 < nl; ++s_) dl += jb.left->bwd_off[s_ + 1] == jb.left->bwd_off[s_];
-            for (int s_ = 1; s_ + 2 < nr; ++s_) dr += jb.right->bwd_off[s_ + 1] == jb.right->bwd_off[s_];
-            if (20 * (dl + dr) < nl + nr) return;                      // under 5 %: not worth the copies
-            // (what validate_job would refuse on the caller's graphs must not slip through on the smaller ones)
-            for (int s_ = 1; s_ + 1 < nl; ++s_) if (jb.left->state[s_] < 0 || jb.left->state[s_] >= jb.model->n_states) return;
-            for (int s_ = 1; s_ + 1 < nr; ++s_) if (jb.right->state[s_] < 0 || jb.right->state[s_] >= jb.model->n_states) return;
-            RowBand rb0;
-            if (rb0.build(nl - 1, nr - 1, jb.band) != PAGAN_OK) return;
-            cj.cells0 = rb0.cells();
-            cj.L0 = jb.left; cj.R0 = jb.right;
-            cj.l.build(jb.left); cj.r.build(jb.right);
-            eff[k].left = &cj.l.g; eff[k].right = &cj.r.g;
-            if (jb.band) {
-                compact_band(rb0, cj.l, cj.r, nr, &cj.up, &cj.lo);
-                const int rows = (int)cj.up.size();
-                cj.band.n = rows; cj.band.upper = cj.up.data(); cj.band.lower = cj.lo.data();
-                eff[k].band = &cj.band;
-            }
-            cj.on = true;
-        });
+        parallel_jobs(n, [&](int k) { compact_job(jobs[k], allow, &b->compact[k], &eff[k]); });
     }
     parallel_jobs(n, [&](int k) {
         RowBand rb;
@@ -1241,6 +1281,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     b->d_flow = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(flow_off));
     HIP_TRY(hipStreamCreate(&b->stream));
     for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto &e : b->evk) HIP_TRY(hipEventCreate(&e));
     if (!which_tiled.empty() && b->n_ring + b->n_wide > 0) {
         HIP_TRY(hipStreamCreate(&b->stream2));
         HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -1289,6 +1330,26 @@ int pagan_batch_last_ms(pagan_batch *b, double ms[2]) {
     HIP_TRY(hipEventElapsedTime(&a, b->ev[0], b->ev[1]));
     HIP_TRY(hipEventElapsedTime(&c, b->ev[1], b->ev[2]));
     ms[0] = a; ms[1] = c;
+    return PAGAN_OK;
+}
+
+// ms[0] banded fill kernel (pg_fill_pipe / pg_fill_ring), ms[1] pg_backptr, ms[2] tiled fill, ms[3] HBM wavefront fill (from
+// the end of whatever ran before it on the stream), ms[4] end corner + traceback, ms[5] the whole fill; -1: not launched
+int pagan_batch_last_ms_detail(pagan_batch *b, double ms[6]) {
+    if (!b || !b->ran) return PAGAN_E_ARG;
+    HIP_TRY(hipEventSynchronize(b->ev[2]));
+    auto span = [&](hipEvent_t a, hipEvent_t c, bool ok) -> double {
+        float t = 0;
+        if (!ok || hipEventElapsedTime(&t, a, c) != hipSuccess) return -1.0;
+        return t;
+    };
+    ms[0] = span(b->evk[0], b->evk[1], b->evk_set[0] && b->evk_set[1]);
+    if (ms[0] < 0 && b->evk_set[0]) ms[0] = span(b->evk[0], b->ev[1], true);           // (the ring kernel: no pass behind it)
+    ms[1] = span(b->evk[1], b->evk[2], b->evk_set[1] && b->evk_set[2]);
+    ms[2] = span(b->evk[3], b->evk[4], b->evk_set[3] && b->evk_set[4]);
+    ms[3] = b->evk_set[5] ? span(b->evk_set[2] ? b->evk[2] : (b->evk_set[1] ? b->evk[1] : b->ev[0]), b->evk[5], true) : -1.0;
+    ms[4] = span(b->ev[1], b->ev[2], true);
+    ms[5] = span(b->ev[0], b->ev[1], true);
     return PAGAN_OK;
 }
 
@@ -1402,6 +1463,7 @@ void pagan_batch_destroy(pagan_batch *b) {
     if (b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
     for (auto &e : b->ev) if (e) hipEventDestroy(e);
     if (b->stream2) { hipStreamSynchronize(b->stream2); hipStreamDestroy(b->stream2); }
+    for (auto &e : b->evk) if (e) hipEventDestroy(e);
     if (b->ev_fork) hipEventDestroy(b->ev_fork);
     if (b->ev_join) hipEventDestroy(b->ev_join);
     if (b->arena.dev) arena_pool.give(b->device, b->arena.dev, b->arena.cap);

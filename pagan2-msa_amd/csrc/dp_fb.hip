@@ -213,6 +213,7 @@ struct pagan_fb {
     char *arena = nullptr;
     double *dF = nullptr, *dB = nullptr;
     double totals[2] = {0, 0};
+    float kernel_ms[2] = {0, 0};                        // pg_fb_forward, pg_fb_backward (HIP events)
     std::vector<double> hF;                             // downloaded lazily
     long long at(int i, int j) const {
         if (i < 0 || j < 0 || i >= Lx || j >= Ly) return -1;
@@ -315,12 +316,26 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     fb->dF = J.F; fb->dB = J.B;
     FB_TRY(hipMemcpy(fb->arena, stage.data(), in_bytes, hipMemcpyHostToDevice));
     const int block = fb->dx.max_width >= 192 ? 256 : (fb->dx.max_width >= 96 ? 128 : 64);
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    FB_TRY(hipEventCreate(&e0)); FB_TRY(hipEventCreate(&e1)); FB_TRY(hipEventCreate(&e2));
+    FB_TRY(hipEventRecord(e0, 0));
     hipLaunchKernelGGL(pg_fb_forward, dim3(1), dim3(block), 0, 0, (const PgFbJob *)(b + o_job));
+    FB_TRY(hipEventRecord(e1, 0));
     hipLaunchKernelGGL(pg_fb_backward, dim3(1), dim3(block), 0, 0, (const PgFbJob *)(b + o_job));
+    FB_TRY(hipEventRecord(e2, 0));
     FB_TRY(hipGetLastError());
     FB_TRY(hipDeviceSynchronize());
+    (void)hipEventElapsedTime(&fb->kernel_ms[0], e0, e1);
+    (void)hipEventElapsedTime(&fb->kernel_ms[1], e1, e2);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     FB_TRY(hipMemcpy(fb->totals, b + o_tot, 16, hipMemcpyDeviceToHost));
     *out = guard.release();
+    return PAGAN_OK;
+}
+
+int pagan_fb_kernel_ms(const pagan_fb *fb, double ms[2]) {
+    if (!fb || !ms) return PAGAN_E_ARG;
+    ms[0] = fb->kernel_ms[0]; ms[1] = fb->kernel_ms[1];
     return PAGAN_OK;
 }
 

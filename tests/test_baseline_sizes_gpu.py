@@ -1,0 +1,95 @@
+"""BASELINE.json's configurations at their full sizes: every internal node of the progressive alignment against the
+oracle -- score bits, alignment columns (skip columns included), used child edges -- and, per node, which fill kernel
+the library gave it (host-only planner, the same decision pagan_batch_create takes).
+
+    cfg2  16 x 2 kb DNA, no anchors        15 full matrices        tiles
+    cfg3  64 x 500 aa, WAG, no anchors     63 full matrices        tiles (211-state table)
+    cfg4  32 x 100 kb DNA, prefix anchors  31 banded alignments    register wavefront (2e5-diagonal chains, 16-bit records)
+    cfg5  512 x 10 kb DNA, prefix anchors  511 alignments; checked: the top three levels (root: 1.05e9 cells, compacted,
+          tiles) and a sample of every lower level -- the whole tree is bench.py --workload cfg5's self-check
+
+The workloads are bench.py's (same generator, same seeds)."""
+import numpy as np
+import pytest
+
+import bench
+
+pytestmark = pytest.mark.gpu
+
+
+def walk(pg, workload):
+    from pagan2_msa_amd import host
+    cfg, leaves, length, branch, sub, indel, mean_len, anchors, alphabet = bench.WORKLOADS[workload]
+    names, seqs, newick = bench.make_inputs(workload)
+    msa = host.Msa(names, seqs, newick, use_anchors=anchors).align()
+    rows = msa.alignment()
+    assert all(r.replace("-", "") == s for r, s in zip(rows, seqs)), "the alignment's rows are not the input sequences"
+    return msa
+
+
+def check_nodes(pg, oracle, msa, nodes, expect):
+    """expect(k, info, route, compacted, widest) -> None or a complaint"""
+    for k in nodes:
+        left, right, model, band = msa.node_job(k)
+        want = oracle.dp_align(left, right, model, band)
+        got = msa.node_result(k)
+        assert got.status == want.status, "node %d" % k
+        assert np.float64(got.score).tobytes() == np.float64(want.score).tobytes(), "node %d: score %r != %r" % (k, got.score, want.score)
+        assert got.same_alignment(want), "node %d (level %d): columns or used edges differ" % (k, msa.node_info(k).level)
+        assert got.cells == want.cells
+        route, compacted, widest = pg.debug_route(left, right, model, band)
+        why = expect(k, msa.node_info(k), route, compacted, widest)
+        assert why is None, "node %d: %s (route %s, compacted %s, widest diagonal %d)" % (k, why, route, compacted, widest)
+
+
+def test_cfg2_16x2kb_dna_full_matrices(pg, oracle):
+    msa = walk(pg, "cfg2_16x2kb_dna_full")
+    assert msa.n_internal == 15
+    check_nodes(pg, oracle, msa, range(15), lambda k, info, route, c, w: None if route == "pg_fill_tiles_flow" else "expected the tiled kernel")
+
+
+def test_cfg3_64x500aa_protein_full_matrices(pg, oracle):
+    msa = walk(pg, "cfg3_64x500aa_protein_full")
+    assert msa.n_internal == 63
+    check_nodes(pg, oracle, msa, range(63), lambda k, info, route, c, w: None if route == "pg_fill_tiles_flow" else "expected the tiled kernel")
+
+
+def test_cfg4_32x100kb_dna_anchored(pg, oracle):
+    msa = walk(pg, "cfg4_32x100kb_dna_anchored")
+    assert msa.n_internal == 31
+    seen = set()
+
+    def expect(k, info, route, compacted, widest):
+        left, right, model, band = msa.node_job(k)
+        cls, _ = pg.debug_plan(left, right, band)
+        seen.update(int(c) for c in np.unique(cls))
+        assert cls.size > 190000, "a 2 x 100 kb alignment has about 2e5 anti-diagonals"
+        return None if route == "pg_fill_pipe" else "expected the banded register-wavefront kernel"
+
+    check_nodes(pg, oracle, msa, range(31), expect)
+    assert seen >= {0, 1, 2, 3, 4}, "the tree is meant to reach every class of diagonal: %s" % sorted(seen)
+
+
+def test_cfg5_512x10kb_dna_anchored_top_levels_and_a_sample(pg, oracle):
+    msa = walk(pg, "cfg5_512x10kb_dna_anchored")
+    assert msa.n_internal == 511
+    infos = [msa.node_info(k) for k in range(511)]
+    top = max(i.level for i in infos)
+    rng = np.random.default_rng(5)
+    nodes = [k for k in range(511) if infos[k].level >= top - 2]
+    for lv in range(top - 2):
+        at = [k for k in range(511) if infos[k].level == lv]
+        nodes += [int(k) for k in rng.choice(at, size=min(3, len(at)), replace=False)]
+    routes = {}
+
+    def expect(k, info, route, compacted, widest):
+        routes.setdefault(info.level, set()).add((route, compacted))
+        if info.level == top:
+            if info.cells < 10 ** 9:
+                return "the root is meant to have more than 1e9 cells, has %d" % info.cells
+            if route != "pg_fill_tiles_flow" or not compacted:
+                return "the root is meant to run on the tiled kernel with its dead sites taken out"
+        return None
+
+    check_nodes(pg, oracle, msa, nodes, expect)
+    assert any(r == "pg_fill_pipe" for rs in routes.values() for r, _ in rs), "the lower levels are banded alignments: %s" % routes
