@@ -1368,7 +1368,7 @@ __device__ __forceinline__ pg_i8 uniform_i8(const pg_i8 &v) {
     int rows_ld = __builtin_amdgcn_readfirstlane((c).rows_ld), cols_ld = __builtin_amdgcn_readfirstlane((c).cols_ld), diags_ld = __builtin_amdgcn_readfirstlane((c).diags_ld); \
     int as0 = __builtin_amdgcn_readfirstlane((c).as0), as1 = __builtin_amdgcn_readfirstlane((c).as1), as2 = __builtin_amdgcn_readfirstlane((c).as2); \
     const double NI = neg_inf(); \
-    (void)Lx; (void)Ly; (void)nd; (void)S; (void)up; (void)dn; (void)bslot; (void)as0; (void)as1; (void)as2; (void)diags_ld; (void)ok_until; (void)go; (void)ng; (void)ge; (void)tng2; (void)tng1; (void)NI
+    (void)bp_out; (void)Lx; (void)Ly; (void)nd; (void)S; (void)up; (void)dn; (void)bslot; (void)as0; (void)as1; (void)as2; (void)diags_ld; (void)ok_until; (void)go; (void)ng; (void)ge; (void)tng2; (void)tng1; (void)NI
 #define WCTX_OUT(c) \
     (c).d = d; (c).row = row; (c).p_up = p_up; (c).p_dn = p_dn; (c).ok_until = ok_until; (c).rows_ld = rows_ld; (c).cols_ld = cols_ld; \
     (c).diags_ld = diags_ld; (c).as0 = as0; (c).as1 = as1; (c).as2 = as2
@@ -1751,7 +1751,7 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
         const int amax = d - d0 < PWAGE ? d - d0 : PWAGE;               // ages 1 .. amax are in the wide ring
         const int wsb = (d % PWK) * PWROW_BYTES;
         const long long soff = ((long long)cur.w << 32) | (unsigned)cur.z;
-        PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff, *brow = (PG_GLOBAL char *)bp_out + (soff >> 1);
+        PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff;
         // one operand cell (p, d - age): read from the wide ring, or -- not there -- what to ask L2 for (the caller fetches
         // all of a step's requests in one statement); -inf outside the band
         auto wcell = [&](bool need, int age, int p_, pg_d2 &xy, double &m) -> FarAsk {
@@ -1851,35 +1851,27 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
                 const double lw0 = (double)__int_as_float(gl[q].z), lw1 = (double)__int_as_float(gl[q].w);
                 const double rw0 = (double)__int_as_float(gr[q].z), rw1 = (double)__int_as_float(gr[q].w);
                 const double lwA = lS ? lw1 : lw0, lwS = lS ? lw0 : lw1, rwA = rS ? rw1 : rw0, rwS = rS ? rw0 : rw1;
-                const unsigned lbA = lS ? 1u << 4 : 0u, lbS = lS ? 0u : 1u << 4;
-                const unsigned rbA = rS ? 1u << 18 : 0u, rbS = rS ? 0u : 1u << 18;
                 const pg_d2 a_ = o_xy[q][0], p_ = o_xy[q][1], c_ = o_xy[q][2], lx_ = o_xy[q][3], lm_ = o_xy[q][4], ry_ = o_xy[q][5], rm_ = o_xy[q][6], lr_ = o_xy[q][7];
                 const double am = o_m[q][0], pmm = o_m[q][1], cm = o_m[q][2], lxm = o_m[q][3], lmm = o_m[q][4], rym = o_m[q][5], rmm = o_m[q][6], lrm = o_m[q][7];
-                unsigned f;
-                bx = fmax3_from(a_.x + ge, a_.y + go, (am + ng) + go, PG_X, PG_Y, PG_M, f); px = f | PG_BP_ADJL | lbA;
-                by = fmax3_from(p_.y + ge, p_.x + go, (pmm + ng) + go, PG_Y, PG_X, PG_M, f); py = f | PG_BP_ADJR | rbA;
-                bm = fmax3_from(((cm + tM) + lwA) + rwA, ((c_.x + tX) + lwA) + rwA, ((c_.y + tX) + lwA) + rwA, PG_M, PG_X, PG_Y, f);
-                pm = f | PG_BP_ADJL | PG_BP_ADJR | lbA | rbA;
-                // (absent operands are -inf and cannot win; the blocks are skipped when no lane of the wave has the edge)
+                // scores only (pg_backptr derives the back-pointers): a state's value is the maximum over its edges of
+                // max(own + ge, max(other, M + ng) + go), M's over its pairs of (max(M + tM, max(X, Y) + tX) + lw) + rw -- the
+                // reference's candidates with the maxima regrouped (tools/gen_hot_asm.py); absent operands are -inf
+                auto gapv = [&](double own, double other, double m_) { return __builtin_fmax(own + ge, __builtin_fmax(other, m_ + ng) + go); };
+                auto pairv = [&](const pg_d2 &xy, double m_, double lw, double rw) {
+                    return (__builtin_fmax(m_ + tM, __builtin_fmax(xy.x, xy.y) + tX) + lw) + rw;
+                };
+                bx = gapv(a_.x, a_.y, am);
+                by = gapv(p_.y, p_.x, pmm);
+                bm = pairv(c_, cm, lwA, rwA);
                 if (__any(r2)) {
-                    const double ys = fmax3_from(ry_.y + ge, ry_.x + go, (rym + ng) + go, PG_Y, PG_X, PG_M, f);
-                    take_better(by, py, ys, f | rbS, rS);
-                    const double ms = fmax3_from(((rmm + tM) + lwA) + rwS, ((rm_.x + tX) + lwA) + rwS, ((rm_.y + tX) + lwA) + rwS, PG_M, PG_X, PG_Y, f);
-                    take_better(bm, pm, ms, f | PG_BP_ADJL | lbA | rbS, rS);
+                    by = __builtin_fmax(by, gapv(ry_.y, ry_.x, rym));
+                    bm = __builtin_fmax(bm, pairv(rm_, rmm, lwA, rwS));
                 }
                 if (__any(l2)) {
-                    const double xs = fmax3_from(lx_.x + ge, lx_.y + go, (lxm + ng) + go, PG_X, PG_Y, PG_M, f);
-                    take_better(bx, px, xs, f | lbS, lS);
-                    unsigned f2;
-                    double m2 = fmax3_from(((lmm + tM) + lwS) + rwA, ((lm_.x + tX) + lwS) + rwA, ((lm_.y + tX) + lwS) + rwA, PG_M, PG_X, PG_Y, f2);
-                    unsigned p2 = f2 | PG_BP_ADJR | lbS | rbA;
-                    if (__any(l2 && r2)) {
-                        const double m3 = fmax3_from(((lrm + tM) + lwS) + rwS, ((lr_.x + tX) + lwS) + rwS, ((lr_.y + tX) + lwS) + rwS, PG_M, PG_X, PG_Y, f);
-                        take_better(m2, p2, m3, f | lbS | rbS, rS);
-                    }
-                    take_better(bm, pm, m2, p2, lS);
+                    bx = __builtin_fmax(bx, gapv(lx_.x, lx_.y, lxm));
+                    bm = __builtin_fmax(bm, pairv(lm_, lmm, lwS, rwA));
+                    if (__any(l2 && r2)) bm = __builtin_fmax(bm, pairv(lr_, lrm, lwS, rwS));
                 }
-                px = bx > NIw ? px : PG_BP_NONE; py = by > NIw ? py : PG_BP_NONE; pm = bm > NIw ? pm : PG_BP_NONE;
             } else if (kind[q] == 2) {
                 // first/last rows and columns, sites without edges, more than two edges, ...: the general rules
                 const int nl = (gl[q].x >> PR_NE_SHIFT) & 127, nr = (gr[q].x >> PR_NE_SHIFT) & 127;
@@ -1909,16 +1901,13 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
                 o[PG_X] = bx; o[PG_Y] = by; o[PG_M] = bm;
             }
             if (active) {
-                typedef unsigned u3 __attribute__((ext_vector_type(3)));
-                const unsigned off12 = __umul24((unsigned)(r - lo), 12u);
+                const unsigned off24 = __umul24((unsigned)(r - lo), 24u);
                 pg_d2 xy; xy.x = bx; xy.y = by;
-                *(PG_GLOBAL pg_d2 *)(srow + 2u * off12) = xy;
-                *(PG_GLOBAL double *)(srow + 2u * off12 + 16u) = bm;
-                u3 b3; b3.x = px; b3.y = py; b3.z = pm;
-                *(PG_GLOBAL u3 *)(brow + off12) = b3;
+                *(PG_GLOBAL pg_d2 *)(srow + off24) = xy;
+                *(PG_GLOBAL double *)(srow + off24 + 16u) = bm;
             }
         }
-        asm volatile("s_waitcnt vmcnt(30)" ::: "memory");  // the stores of five steps ago have retired (older cells of the run are read from L2)
+        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");  // the stores of five steps ago have retired (older cells of the run are read from L2)
         flag_store(&PM.progress[wave], d);
 #ifdef PG_PIPE_STATS
         {
