@@ -32,7 +32,7 @@ template <bool TAB_LDS> __global__ void pg_fill_ring(const PgDevJob *jobs, const
 template <bool TAB_LDS> __global__ void pg_fill_pipe(const PgDevJob *jobs, const int *which, unsigned flags);
 __global__ void pg_fill_tiles(const PgDevJob *jobs, const int *tiles, unsigned flags);
 __global__ void pg_fill_tiles_flow(const PgDevJob *jobs, const int *tiles, int n_tiles, int n_diag, int *flow, unsigned flags, int use_water);
-__global__ void pg_end_corner(const PgDevJob *jobs);
+__global__ void pg_end_corner(const PgDevJob *jobs, const int *tiles_gave_up);
 __global__ void pg_backptr(const PgDevJob *jobs, const int *which, unsigned flags);
 __global__ void pg_trace_spec(const PgDevJob *jobs);
 __global__ void pg_trace_compose(const PgDevJob *jobs);
@@ -1305,7 +1305,12 @@ int pagan_batch_run(pagan_batch *b) {
     int rc = launch_fill(b);
     if (rc != PAGAN_OK) return rc;
     HIP_TRY(hipEventRecord(b->ev[1], b->stream));
-    hipLaunchKernelGGL(pg_end_corner, dim3(b->n), dim3(64), 0, b->stream, b->d_jobs);
+    {
+        // (pg_fill_tiles_flow's give-up word sits behind its per-diagonal counters and per-tile flags)
+        const bool flow = b->tile_off.size() > 1 && b->tiles_flow;
+        const int *gave_up = flow ? b->d_flow + 1 + ((int)b->tile_off.size() - 1) + b->tile_off.back() : nullptr;
+        hipLaunchKernelGGL(pg_end_corner, dim3(b->n), dim3(64), 0, b->stream, b->d_jobs, gave_up);
+    }
     if (b->max_bound > 0)
         hipLaunchKernelGGL(pg_trace_spec, dim3(b->max_bound, b->n), dim3(128), 0, b->stream, b->d_jobs);
     hipLaunchKernelGGL(pg_trace_compose, dim3(b->n), dim3(64), 0, b->stream, b->d_jobs);

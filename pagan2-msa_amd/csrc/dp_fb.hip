@@ -316,18 +316,23 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     fb->dF = J.F; fb->dB = J.B;
     FB_TRY(hipMemcpy(fb->arena, stage.data(), in_bytes, hipMemcpyHostToDevice));
     const int block = fb->dx.max_width >= 192 ? 256 : (fb->dx.max_width >= 96 ? 128 : 64);
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    FB_TRY(hipEventCreate(&e0)); FB_TRY(hipEventCreate(&e1)); FB_TRY(hipEventCreate(&e2));
-    FB_TRY(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(pg_fb_forward, dim3(1), dim3(block), 0, 0, (const PgFbJob *)(b + o_job));
-    FB_TRY(hipEventRecord(e1, 0));
-    hipLaunchKernelGGL(pg_fb_backward, dim3(1), dim3(block), 0, 0, (const PgFbJob *)(b + o_job));
-    FB_TRY(hipEventRecord(e2, 0));
+    // the two sweeps are independent of each other: side by side on two streams (a workgroup each)
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    hipStream_t s1 = nullptr, s2 = nullptr;
+    FB_TRY(hipStreamCreate(&s1)); FB_TRY(hipStreamCreate(&s2));
+    FB_TRY(hipEventCreate(&e0)); FB_TRY(hipEventCreate(&e1)); FB_TRY(hipEventCreate(&e2)); FB_TRY(hipEventCreate(&e3));
+    FB_TRY(hipEventRecord(e0, s1));
+    hipLaunchKernelGGL(pg_fb_forward, dim3(1), dim3(block), 0, s1, (const PgFbJob *)(b + o_job));
+    FB_TRY(hipEventRecord(e1, s1));
+    FB_TRY(hipEventRecord(e2, s2));
+    hipLaunchKernelGGL(pg_fb_backward, dim3(1), dim3(block), 0, s2, (const PgFbJob *)(b + o_job));
+    FB_TRY(hipEventRecord(e3, s2));
     FB_TRY(hipGetLastError());
-    FB_TRY(hipDeviceSynchronize());
+    FB_TRY(hipStreamSynchronize(s1)); FB_TRY(hipStreamSynchronize(s2));
     (void)hipEventElapsedTime(&fb->kernel_ms[0], e0, e1);
-    (void)hipEventElapsedTime(&fb->kernel_ms[1], e1, e2);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    (void)hipEventElapsedTime(&fb->kernel_ms[1], e2, e3);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
+    (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2);
     FB_TRY(hipMemcpy(fb->totals, b + o_tot, 16, hipMemcpyDeviceToHost));
     *out = guard.release();
     return PAGAN_OK;

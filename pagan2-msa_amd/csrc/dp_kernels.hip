@@ -578,7 +578,7 @@ enum { EXIT_ENTRY = 0, EXIT_MISS = 1, EXIT_DONE = 2 };
 
 } // namespace
 
-__global__ void pg_end_corner(const PgDevJob *__restrict__ jobs) {
+__global__ void pg_end_corner(const PgDevJob *__restrict__ jobs, const int *__restrict__ tiles_gave_up) {
     if (threadIdx.x != 0) return;
     const View J = load_view(jobs + blockIdx.x);
     const double NI = neg_inf();
@@ -626,6 +626,10 @@ __global__ void pg_end_corner(const PgDevJob *__restrict__ jobs) {
     ec[0] = (best > NI) ? 0 : 1;
     // the fill kernel gave up on a wait (dp_pipe.hip, poll_ge): no result; the status names the wait
     if (jobs[blockIdx.x].fill_status[0] != 0) ec[0] = 0x40000000 | jobs[blockIdx.x].fill_status[0];
+    // the tiled fill (dp_tiles.hip, pg_fill_tiles_flow) abandoned a wait: the waves left the queue and tiles of ANY job of
+    // the batch may be unfilled -- only the job whose tile was waiting carries a status of its own.  No job of the batch
+    // may report what the arena held before.
+    else if (tiles_gave_up && tiles_gave_up[0] != 0) ec[0] = 0x40000000 | 0x7e;
 }
 
 // grid (K_max, n_jobs): block b.x handles boundary k = b.x + 1 of job b.y

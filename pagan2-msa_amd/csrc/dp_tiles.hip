@@ -366,7 +366,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
             halo_block(s / TB);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef PG_TILE_STATS
-            if (r == 0) {      // [13] waiting for the neighbours' progress, [14] acquire + halo block
+            if (r == 0 && 3 * (J.Lx + J.Ly) >= 4096) {      // (long jobs only: the counters borrow the tail of the trace buffer) [13] waiting for the neighbours' progress, [14] acquire + halo block
                 unsigned long long *out = (unsigned long long *)(jobs[T.x].trace + ((3 * (J.Lx + J.Ly) - 64) & ~1));
                 atomicAdd(out + 13, lw1 - lw0); atomicAdd(out + 14, __builtin_amdgcn_s_memtime() - lw1);
             }
@@ -653,7 +653,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
 #endif
     }
 #ifdef PG_TILE_STATS
-    if (r == 0) {
+    if (r == 0 && 3 * (J.Lx + J.Ly) >= 4096) {
         unsigned long long *out = (unsigned long long *)(jobs[T.x].trace + ((3 * (J.Lx + J.Ly) - 64) & ~1));
         atomicAdd(out + 0, 1ull);
         atomicAdd(out + 1, st_loop - st_begin);
@@ -736,9 +736,11 @@ __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restr
 #ifdef PG_TILE_STATS
         if (threadIdx.x == 0) {      // [9] waiting for whole diagonals, [10] for the neighbours, [11] acquire + tile, [12] release
             const View Jv = load_view(jobs + T.x);
+            if (3 * (Jv.Lx + Jv.Ly) >= 4096) {
             unsigned long long *out = (unsigned long long *)(jobs[T.x].trace + ((3 * (Jv.Lx + Jv.Ly) - 64) & ~1));
             atomicAdd(out + 9, fs1 - fs0); atomicAdd(out + 10, fs2 - fs1); atomicAdd(out + 11, fs3 - fs2);
             atomicAdd(out + 12, __builtin_amdgcn_s_memtime() - fs3);
+            }
         }
 #endif
         if (threadIdx.x == 0) {

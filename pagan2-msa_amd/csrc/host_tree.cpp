@@ -115,6 +115,7 @@ struct NodeWork {                // everything one internal node's alignment con
     std::vector<int32_t> upper, lower;
     std::vector<TunnelBlock> blocks;     // empty tunnel blocks, ascending by size (anchor_mode 1; --force-gap takes the last)
     int n_hits = 0, n_forced = 0;
+    int imp_l = 0, imp_r = 0;    // sites of the children of a node whose result was imported (pagan_msa_import_result)
     pagan_graph gl, gr;
     pagan_model pm;
     pagan_band pb;
@@ -750,15 +751,24 @@ int pagan_msa_import_result(pagan_msa *m, const void *buf, int64_t bytes) {
     if (nl) std::memcpy(r.left_used, p, 4 * (size_t)nl);
     p += 4 * (size_t)nl;
     if (nr) std::memcpy(r.right_used, p, 4 * (size_t)nr);
-    w.has_res = true; w.has_job = false; w.device = -1; w.node = id; w.level = m->rounds;
+    // nothing of the payload is kept before all of it has been checked against the child graphs: a column names a child
+    // site (1 .. n_sites - 2) or none (-1), and which of the two it names follows from its path state
     const TreeNode &t = m->tree[m->tree_of_id[id]];
     const SeqGraph &gl = m->graph[m->id_of_tree[t.left]]->g, &gr = m->graph[m->id_of_tree[t.right]]->g;
-    for (int k = 0; k < n_cols; ++k) {
+    bool good = r.status == PAGAN_DP_REACHED || r.status == PAGAN_DP_UNREACHABLE;
+    for (int k = 0; good && k < n_cols; ++k) {
         const pagan_col &c = r.cols[k];
-        if (c.path_state < PAGAN_MATCHED || c.path_state > PAGAN_YSKIPPED || c.left >= gl.n_sites() - 1 || c.right >= gr.n_sites() - 1) return PAGAN_E_ARG;
+        if (c.path_state < PAGAN_MATCHED || c.path_state > PAGAN_YSKIPPED) { good = false; break; }
+        const bool hl = c.path_state == PAGAN_MATCHED || c.path_state == PAGAN_XGAPPED || c.path_state == PAGAN_XSKIPPED;
+        const bool hr = c.path_state == PAGAN_MATCHED || c.path_state == PAGAN_YGAPPED || c.path_state == PAGAN_YSKIPPED;
+        if (hl ? (c.left < 1 || c.left > gl.n_sites() - 2) : c.left != -1) good = false;
+        if (hr ? (c.right < 1 || c.right > gr.n_sites() - 2) : c.right != -1) good = false;
     }
-    for (int k = 0; k < nl; ++k) if (r.left_used[k] < 0 || r.left_used[k] >= gl.n_edges()) return PAGAN_E_ARG;
-    for (int k = 0; k < nr; ++k) if (r.right_used[k] < 0 || r.right_used[k] >= gr.n_edges()) return PAGAN_E_ARG;
+    for (int k = 0; good && k < nl; ++k) if (r.left_used[k] < 0 || r.left_used[k] >= gl.n_edges()) good = false;
+    for (int k = 0; good && k < nr; ++k) if (r.right_used[k] < 0 || r.right_used[k] >= gr.n_edges()) good = false;
+    if (!good) { pagan_result_free(&r); std::memset(&r, 0, sizeof(r)); return PAGAN_E_ARG; }
+    w.has_res = true; w.has_job = false; w.device = -1; w.node = id; w.level = m->rounds;
+    w.imp_l = gl.n_sites(); w.imp_r = gr.n_sites();         // (no job was prepared here: node_info reports the children's sizes from these)
     const double t0 = now_s();
     const int rc = build_parent(m, id);
     m->tm.build_s += now_s() - t0;
@@ -779,7 +789,7 @@ int pagan_msa_node_info(const pagan_msa *m, int32_t k, pagan_node_info *o) {
     o->level = w.level; o->n_hits = w.n_hits; o->n_forced_gaps = w.n_forced;
     o->dist = m->tree[t.left].dist + m->tree[t.right].dist;
     if (w.has_res) {
-        o->left_sites = w.gl.n_sites; o->right_sites = w.gr.n_sites;
+        o->left_sites = w.has_job ? w.gl.n_sites : w.imp_l; o->right_sites = w.has_job ? w.gr.n_sites : w.imp_r;
         o->cells = w.res.cells; o->score = w.res.score; o->status = w.res.status;
     }
     if (m->graph[id]) o->sites = m->graph[id]->g.n_sites();
