@@ -641,7 +641,6 @@ __global__ __launch_bounds__(128) void pg_trace_spec(const PgDevJob *__restrict_
     const int mnA = J.imin[D], wA = max(J.imax[D] - mnA + 1, 0);
     const int mnB = J.imin[D - 1], wB = max(J.imax[D - 1] - mnB + 1, 0);
     const int n_entries = 3 * (wA + wB);
-    const int low = (k - 1) * PG_SEG;                // next lower boundary pair {low, low-1}; k == 1: run to the start
     gint_w tab = J.ttab + 8 * (long long)J.tb[k];
     for (int e = threadIdx.x; e < n_entries; e += blockDim.x) {
         TNode n;
@@ -650,19 +649,28 @@ __global__ __launch_bounds__(128) void pg_trace_spec(const PgDevJob *__restrict_
         int steps = 0, kind = EXIT_DONE, w;
         bool ok = true;
         TCache tc;
+        // the chase aims for the next lower boundary pair {low, low-1} (boundary kb; kb == 0: run to the start).  A long edge
+        // may jump over a pair: the chase then goes on to the pair below (pg_trace_compose would otherwise have to walk
+        // that stretch cell by cell, a chain of dependent reads -- most of its time at the top of a deep tree)
+        int kb = k - 1, low = (k - 1) * PG_SEG;
         for (;;) {
             if (trace_done(n)) { kind = EXIT_DONE; break; }
             const int dd = n.i + n.j;
-            if (steps > 0 && k > 1 && dd <= low) { kind = dd >= low - 1 ? EXIT_ENTRY : EXIT_MISS; break; }
-            if (steps > 4 * PG_SEG || !trace_step(J, n, w, tc)) { ok = false; break; }
+            if (steps > 0 && kb >= 1 && dd <= low) {
+                if (dd >= low - 1) { kind = EXIT_ENTRY; break; }
+                while (kb >= 1 && dd < low - 1) { --kb; low -= PG_SEG; }
+                if (kb >= 1 && dd <= low) { kind = EXIT_ENTRY; break; }           // (dd is low or low - 1 now)
+            }
+            if (steps >= 4 * PG_SEG) { kind = EXIT_MISS; break; }                 // far enough for one entry: pg_trace_compose walks on from here
+            if (!trace_step(J, n, w, tc)) { ok = false; break; }
             ++steps;
         }
-        // where the chase arrived, and -- when that is a cell of the next lower boundary -- its entry there,
+        // where the chase arrived, and -- when that is a cell of a lower boundary -- its entry there,
         // so that pg_trace_compose hops with one dependent read per boundary
         int next = -1;
         if (ok && kind == EXIT_ENTRY && n.vit >= 0 && n.vit <= 2) {
             const int dd = n.i + n.j, mn = J.imin[dd], mx = J.imax[dd];
-            if (n.i >= mn && n.i <= mx) next = J.tb[k - 1] + entry_index(J, k - 1, n);
+            if (n.i >= mn && n.i <= mx) next = J.tb[kb] + entry_index(J, kb, n);
         }
         typedef int i4 __attribute__((ext_vector_type(4)));
         i4 a; a.x = n.i; a.y = n.j; a.z = (n.vit & 3) | (kind << 2); a.w = ok ? steps : -1;

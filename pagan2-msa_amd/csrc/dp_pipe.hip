@@ -904,7 +904,11 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
 #ifdef PG_PIPE_STATS
     long long as_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // cycles: prepare (rest), waiting for the compute waves, compute, publish; inside prepare: scan, batch, decode, far
     int as_n = 0;
-#define ASTAMP(k) do { const long long t_ = __builtin_readcyclecounter(); as_t[k] += t_ - as_t0; as_t0 = t_; } while (0)
+    // (PG_ASSIST_RUNS_ONLY: only diagonals that directly follow this wave's previous one -- the inside of a class 2 run, where the
+    // assist waves are what the compute waves wait for -- are counted; otherwise the idle time between runs dominates the averages)
+    bool as_on = true;
+    int as_prev = -100;
+#define ASTAMP(k) do { const long long t_ = __builtin_readcyclecounter(); if (as_on) as_t[k] += t_ - as_t0; as_t0 = t_; } while (0)
     long long as_t0 = __builtin_readcyclecounter();
 #else
 #define ASTAMP(k)
@@ -1121,7 +1125,9 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
                         q_val = true;
                         if (__builtin_amdgcn_ballot_w64(on && any_far) != 0) {
                             // cells that left the ring (>= PAGE diagonals back) have landed once every wave has completed d - PAGE + PLAND
-                            if (diags_ld < d) diags_ld = POLL(&PM.loaded[2], d, 5);
+                            // (far_ask looks up the descriptors of the diagonals d - age, age >= PAGE, in the loader's window)
+                            if (diags_ld < d - PAGE + 1) diags_ld = POLL(&PM.loaded[2], d - PAGE + 1, 5);
+                            ASTAMP(11);
                             if (pw0 < d - PAGE + PLAND) pw0 = POLL(&PM.progress[0], d - PAGE + PLAND, 9);
                             if (pw1 < d - PAGE + PLAND) pw1 = POLL(&PM.progress[1], d - PAGE + PLAND, 9);
                             if (pw2 < d - PAGE + PLAND) pw2 = POLL(&PM.progress[2], d - PAGE + PLAND, 9);
@@ -1305,9 +1311,15 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
         flag_store(&PM.assist_done[a], d);
         ASTAMP(3);
 #ifdef PG_PIPE_STATS
-        ++as_n;
+        if (as_on) ++as_n;
+        as_prev = d;
 #endif
         prepare();
+#ifdef PG_PIPE_STATS
+#ifdef PG_ASSIST_RUNS_ONLY
+        as_on = q_d == as_prev + PNA;
+#endif
+#endif
     }
 #ifdef PG_PIPE_STATS
     if (lane == 0 && 3 * (job->Lx + job->Ly) >= 4096) {

@@ -58,8 +58,8 @@ if os.environ.get("PG_STAMPS"):
         n = max(int(b5[16 * a_]), 1)
         t = b5[16 * a_ + 1: 16 * a_ + 13].astype(np.int64) * 256 / n
         print("assist %d: %d diagonals; cycles/diagonal: prepare (descriptors, loader) %.0f, wait for compute waves %.0f, compute %.0f, publish %.0f; "
-              "inside prepare: scan %.0f, batch %.0f, decode %.0f, far: pool writes %.0f, polls %.0f, addresses %.0f, L2 loads %.0f" %
-              ((a_, n) + tuple(t[:11])))
+              "inside prepare: scan %.0f, batch %.0f, decode %.0f, far: pool writes %.0f, polls for landed cells %.0f, addresses %.0f, L2 loads %.0f, poll for the descriptor window %.0f" %
+              ((a_, n) + tuple(t[:12])))
 if os.environ.get("PG_STAMPS"):
     b6 = raw[n_int - 1100: n_int - 1092].astype(np.int64)
     print("waves 0-3 compute, 4-6 assist, 7 loader: (wave slot, SIMD, CU) =", [(int(x & 15), int((x >> 4) & 3), int((x >> 8) & 15)) for x in b6])
