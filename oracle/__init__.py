@@ -276,6 +276,26 @@ def eliminate_bad_hits(hits, thr_total=50, thr_partly=400):
     return h[:n].copy()
 
 
+def tunnel_from_hits(hits, g1, g2, width=15):
+    """Find_anchors::define_tunnel alone on a given hit list (positions in the ungapped strings)."""
+    h = np.ascontiguousarray(hits, np.int32).reshape(-1, 4)
+    up = np.zeros(len(g1) + 1, np.int32)
+    lo = np.zeros(len(g1) + 1, np.int32)
+    L = lib()
+    L.oracle_tunnel_from_hits.restype = C.c_int
+    L.oracle_tunnel_from_hits(_ip(h), int(h.shape[0]), g1.encode(), g2.encode(), int(width), _ip(up), _ip(lo))
+    return abi.Band(up, lo)
+
+
+def order_conflicts(hits, len1, len2, trim=5):
+    """Find_anchors::check_hits_order_conflict alone: the surviving hits."""
+    h = np.ascontiguousarray(hits, np.int32).reshape(-1, 4).copy()
+    L = lib()
+    L.oracle_order_conflicts.restype = C.c_int
+    n = L.oracle_order_conflicts(_ip(h), int(h.shape[0]), int(len1), int(len2), int(trim))
+    return h[:n].copy()
+
+
 def tunnel_overlapping(hits, g1, g2, width=15):
     h = np.ascontiguousarray(hits, np.int32).reshape(-1, 4)
     up = np.zeros(len(g1) + 1, np.int32)

@@ -794,6 +794,28 @@ int oracle_define_tunnel(const char *s1, const char *s2, const char *g1, const c
 }
 
 
+// Find_anchors::define_tunnel alone (find_anchors.cpp:320-447) on a given hit list: n x 4 ints (start 1, start 2, length,
+// score), positions in the UNGAPPED strings; upper/lower hold strlen(g1)+1 entries.  (tests/pycheck_tunnel.py reads the
+// same source a second time and is compared with this.)
+int oracle_tunnel_from_hits(const int32_t *hits, int n, const char *g1, const char *g2, int width, int32_t *upper, int32_t *lower) {
+    std::vector<Hit> v;
+    for (int k = 0; k < n; k++) v.push_back({hits[4 * k], hits[4 * k + 1], hits[4 * k + 2], hits[4 * k + 3]});
+    std::vector<int> up, lo;
+    tunnel(v, g1, g2, width, &up, &lo);
+    for (size_t i = 0; i < up.size(); i++) { upper[i] = up[i]; lower[i] = lo[i]; }
+    return (int)up.size();
+}
+
+// Find_anchors::check_hits_order_conflict alone (find_anchors.cpp:225-317) on a given hit list (compacted in place; returns
+// the surviving count)
+int oracle_order_conflicts(int32_t *hits, int n, int len1, int len2, int trim) {
+    std::vector<Hit> v;
+    for (int k = 0; k < n; k++) v.push_back({hits[4 * k], hits[4 * k + 1], hits[4 * k + 2], hits[4 * k + 3]});
+    order_conflicts(len1, len2, trim, &v);
+    for (size_t k = 0; k < v.size(); k++) { hits[4 * k] = v[k].s1; hits[4 * k + 1] = v[k].s2; hits[4 * k + 2] = v[k].len; hits[4 * k + 3] = v[k].score; }
+    return (int)v.size();
+}
+
 // hits: n x 4 ints (start 1, start 2, length, score) in processing order.  Returns the surviving count (compacted in place).
 int oracle_eliminate_bad_hits(int32_t *hits, int n, int thr_total, int thr_partly) {
     std::vector<Hit> v;

@@ -1,11 +1,18 @@
-# rocprofv3 kernel statistics of the cfg2 pass (16 x 2 kb, full matrices, tiled kernel): gpurun_out/prof_r02_cfg2/bench_cfg2_tiles_kernel_stats.csv
+# rocprofv3 passes of the cfg2 bench command (16 x 2 kb, full matrices, tiled kernel): kernel stats + WRITE_SIZE / FETCH_SIZE
+# (separate PMC passes) -> gpurun_out/prof_r03_cfg2/
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r02_cfg2
+O=$R/gpurun_out/prof_r03_cfg2
 mkdir -p $O
 cd $R
-rocprofv3 --kernel-trace --stats -d $O/stats -o s -- python3 bench.py --workload cfg2_16x2kb_dna_full --steps 3 --warmup 1 --no-cpu-baseline --allow-stale-traffic > $O/bench_under_stats.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats -d $O/stats -o s -- python3 bench.py --workload cfg2_16x2kb_dna_full --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_under_stats.json 2> $O/stats.err
 python tools/rocpd_summary.py stats $(find $O/stats -name "*_results.db" | head -1) $O/bench_cfg2_tiles_kernel_stats.csv
-rm -rf $O/stats
-head -8 $O/bench_cfg2_tiles_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/w -o w -- python3 bench.py --workload cfg2_16x2kb_dna_full --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_under_w.json 2> $O/w.err
+python tools/rocpd_summary.py pmc $(find $O/w -name "*_results.db" | head -1) WRITE_SIZE > $O/pmc_write.txt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/f -o f -- python3 bench.py --workload cfg2_16x2kb_dna_full --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_under_f.json 2> $O/f.err
+python tools/rocpd_summary.py pmc $(find $O/f -name "*_results.db" | head -1) FETCH_SIZE > $O/pmc_fetch.txt
+rm -rf $O/stats $O/w $O/f
+head -8 $O/bench_cfg2_tiles_kernel_stats.csv | cut -c1-150
+grep "pg_fill_tiles" $O/pmc_write.txt | cut -c1-300
+grep "pg_fill_tiles" $O/pmc_fetch.txt | cut -c1-300
