@@ -373,6 +373,49 @@ struct ArenaPool {
 };
 ArenaPool arena_pool;
 
+// Streams and events of a batch, reused by the next batch on the same device (at most four idle sets per device).
+struct GpuObjs {
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr}, evk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void destroy() {
+        if (stream) (void)hipStreamDestroy(stream);
+        if (stream2) (void)hipStreamDestroy(stream2);
+        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto &e : evk) if (e) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+    }
+};
+struct GpuObjPool {
+    std::mutex m;
+    std::vector<std::pair<int, GpuObjs>> idle;
+    bool take(int device, GpuObjs *o) {
+        std::lock_guard<std::mutex> g(m);
+        for (size_t k = 0; k < idle.size(); ++k)
+            if (idle[k].first == device) { *o = idle[k].second; idle.erase(idle.begin() + k); return true; }
+        return false;
+    }
+    void give(int device, const GpuObjs &o) {
+        GpuObjs drop;
+        bool dropping = false;
+        {
+            std::lock_guard<std::mutex> g(m);
+            int have = 0;
+            for (auto &e : idle) have += e.first == device;
+            if (have >= 4) { drop = o; dropping = true; }
+            else idle.emplace_back(device, o);
+        }
+        if (dropping) drop.destroy();
+    }
+    void release() {
+        std::vector<std::pair<int, GpuObjs>> all;
+        { std::lock_guard<std::mutex> g(m); all.swap(idle); }
+        for (auto &e : all) { (void)hipSetDevice(e.first); e.second.destroy(); }
+    }
+};
+GpuObjPool gpu_pool;
+
 } // namespace
 
 // ---- dead sites ----------------------------------------------------------------------------------------------------
@@ -476,6 +519,8 @@ struct pagan_batch {
     bool tiles_water = false;    // some job's tiles are no staircase: a tile also waits for all diagonals <= its own - 2
     bool tiles_flow = true;      // one persistent launch (default) or one launch per tile anti-diagonal (PAGAN_DP_TILES=launches)
     std::vector<int> tile_off;   // first tile of tile anti-diagonal t (tile_off.back() = total)
+    hipStream_t pooled_stream2 = nullptr;                       // (owned through the pool whether this batch forks or not)
+    hipEvent_t pooled_fork = nullptr, pooled_join = nullptr;
     hipStream_t stream2 = nullptr;   // the tile launches, when the batch also has jobs of the other kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_ring_small = 0;        // ring jobs whose model table fits the LDS cache (listed first)
@@ -1279,13 +1324,22 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     if (!tile_list.empty()) std::memcpy(stage.data() + reinterpret_cast<size_t>(tiles_off), tile_list.data(), sizeof(int) * tile_list.size());
     b->d_tiles = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(tiles_off));
     b->d_flow = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(flow_off));
-    HIP_TRY(hipStreamCreate(&b->stream));
-    for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
-    for (auto &e : b->evk) HIP_TRY(hipEventCreate(&e));
-    if (!which_tiled.empty() && b->n_ring + b->n_wide > 0) {
-        HIP_TRY(hipStreamCreate(&b->stream2));
-        HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+    {
+        // streams and events come from a per-device pool: a level of a tree walk is followed by the next, and creating and
+        // destroying a dozen of them per batch cost milliseconds of the walk's wall-clock
+        GpuObjs o;
+        if (!gpu_pool.take(b->device, &o)) {
+            HIP_TRY(hipStreamCreate(&o.stream));
+            HIP_TRY(hipStreamCreate(&o.stream2));
+            for (auto &e : o.ev) HIP_TRY(hipEventCreate(&e));
+            for (auto &e : o.evk) HIP_TRY(hipEventCreate(&e));
+            HIP_TRY(hipEventCreateWithFlags(&o.ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&o.ev_join, hipEventDisableTiming));
+        }
+        b->stream = o.stream; b->pooled_stream2 = o.stream2; b->pooled_fork = o.ev_fork; b->pooled_join = o.ev_join;
+        for (int k = 0; k < 3; ++k) b->ev[k] = o.ev[k];
+        for (int k = 0; k < 6; ++k) b->evk[k] = o.evk[k];
+        if (!which_tiled.empty() && b->n_ring + b->n_wide > 0) { b->stream2 = o.stream2; b->ev_fork = o.ev_fork; b->ev_join = o.ev_join; }
     }
     HIP_TRY(hipMemcpyAsync(base, stage.data(), in_bytes, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -1465,12 +1519,15 @@ int pagan_batch_debug_trace(pagan_batch *b, int32_t k, void *dst, int64_t bytes)
 
 void pagan_batch_destroy(pagan_batch *b) {
     if (!b) return;
-    if (b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
-    for (auto &e : b->ev) if (e) hipEventDestroy(e);
-    if (b->stream2) { hipStreamSynchronize(b->stream2); hipStreamDestroy(b->stream2); }
-    for (auto &e : b->evk) if (e) hipEventDestroy(e);
-    if (b->ev_fork) hipEventDestroy(b->ev_fork);
-    if (b->ev_join) hipEventDestroy(b->ev_join);
+    if (b->stream) {
+        (void)hipStreamSynchronize(b->stream);
+        if (b->pooled_stream2) (void)hipStreamSynchronize(b->pooled_stream2);
+        GpuObjs o;
+        o.stream = b->stream; o.stream2 = b->pooled_stream2; o.ev_fork = b->pooled_fork; o.ev_join = b->pooled_join;
+        for (int k = 0; k < 3; ++k) o.ev[k] = b->ev[k];
+        for (int k = 0; k < 6; ++k) o.evk[k] = b->evk[k];
+        gpu_pool.give(b->device, o);
+    }
     if (b->arena.dev) arena_pool.give(b->device, b->arena.dev, b->arena.cap);
     delete b;
 }
@@ -1506,6 +1563,7 @@ int pagan_dp_align(const pagan_graph *left, const pagan_graph *right, const paga
 
 void pagan_dp_release_cache(void) {
     arena_pool.clear(-1);
+    gpu_pool.release();
     std::lock_guard<std::mutex> g(stage_pool.m);
     for (auto &s : stage_pool.idle) std::free(s.first);
     stage_pool.idle.clear();
