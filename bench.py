@@ -293,10 +293,10 @@ def bench_one_gpu(args, device):
             continue
         kcells = cells if name == "pg_backptr" else routed.get(name, 0)
         if name == "pg_backptr":
-            kcells = routed.get("pg_fill_pipe", 0)
+            kcells = routed.get("pg_fill_pipe", 0) + routed.get("pg_fill_tiles_flow", 0)
             kbytes = 36                                        # 24 B of scores read (neighbours out of L2) + 12 B written per cell
         else:
-            kbytes = 24 if name == "pg_fill_pipe" else BYTES_PER_CELL     # the banded fill stores scores only since round 3
+            kbytes = BYTES_PER_CELL if name == "pg_fill_wavefront" else 24    # the banded and the tiled fill store scores only since round 3
         ach = kbytes * kcells / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
         per_kernel.append({"kernel": name, "ms_per_step": t_ms, "launches_per_step": launches, "avg_launch_ms": t_ms / launches,
                            "cells": int(kcells), "algorithmic_bytes_per_cell": kbytes, "achieved": ach, "frac": ach / HBM_PEAK_GBS,

@@ -33,7 +33,7 @@ template <bool TAB_LDS> __global__ void pg_fill_pipe(const PgDevJob *jobs, const
 __global__ void pg_fill_tiles(const PgDevJob *jobs, const int *tiles, unsigned flags);
 __global__ void pg_fill_tiles_flow(const PgDevJob *jobs, const int *tiles, int n_tiles, int n_diag, int *flow, unsigned flags, int use_water);
 __global__ void pg_end_corner(const PgDevJob *jobs, const int *tiles_gave_up);
-__global__ void pg_backptr(const PgDevJob *jobs, const int *which, unsigned flags);
+__global__ void pg_backptr(const PgDevJob *jobs, const int *which, unsigned flags, int diags_per_block);
 __global__ void pg_trace_spec(const PgDevJob *jobs);
 __global__ void pg_trace_compose(const PgDevJob *jobs);
 __global__ void pg_trace_emit(const PgDevJob *jobs);
@@ -376,7 +376,7 @@ ArenaPool arena_pool;
 // Streams and events of a batch, reused by the next batch on the same device (at most four idle sets per device).
 struct GpuObjs {
     hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr}, evk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr}, evk[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void destroy() {
         if (stream) (void)hipStreamDestroy(stream);
@@ -510,7 +510,7 @@ struct pagan_batch {
     Arena arena;
     PgDevJob *d_jobs = nullptr;
     int *d_which = nullptr;      // [n]: ring-kernel jobs first, then the ones of the HBM wavefront kernel
-    int n_ring = 0, n_wide = 0;
+    int n_ring = 0, n_wide = 0, n_tiled = 0;
     int *d_tiles = nullptr;      // dp_tiles.hip: {job, tile row, tile column, position of the tile above} of all tiled jobs, ordered by
                                  // row + column; then the positions of the tiles to the left; then tile_off (pg_fill_tiles_flow)
     int *d_flow = nullptr;       // pg_fill_tiles_flow's queue head, finished tiles per diagonal, done flags (zeroed per launch)
@@ -532,8 +532,8 @@ struct pagan_batch {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     // per-kernel brackets inside the fill (pagan_batch_last_ms_detail): 0/1 around the banded kernel, 2 behind pg_backptr,
     // 3/4 around the tiled kernel (on its own stream when the batch also has banded jobs), 5 behind the HBM wavefront
-    hipEvent_t evk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool evk_set[6] = {false, false, false, false, false, false};
+    hipEvent_t evk[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // (6: behind the tiled jobs' pg_backptr)
+    bool evk_set[7] = {false, false, false, false, false, false, false};
     int64_t cells = 0;
     size_t out_begin = 0;        // arena offset where the output arrays start
     bool ran = false;
@@ -705,6 +705,14 @@ template <class T> void put(Stage &stage, const void *devptr_as_off, const T *sr
     if (count) std::memcpy(stage.data() + reinterpret_cast<size_t>(devptr_as_off), src, sizeof(T) * count);
 }
 
+// diagonals per workgroup of pg_backptr: PG_BP_DIAGS, halved until the grid has a few thousand workgroups (or 4 are left:
+// one per wave)
+static int bp_diags_per_block(int max_nd, int other_dims) {
+    int dpb = PG_BP_DIAGS;
+    while (dpb > 4 && (long long)((max_nd + dpb - 1) / dpb) * other_dims < 4096) dpb /= 2;
+    return dpb;
+}
+
 int launch_fill(pagan_batch *b) {
     hipStream_t tile_stream = nullptr;
     static std::atomic<int> n_cu_dev[64];
@@ -757,10 +765,11 @@ int launch_fill(pagan_batch *b) {
                                    b->d_jobs, b->d_which + n_small, b->flags);
             HIP_TRY(hipEventRecord(b->evk[1], b->stream)); b->evk_set[1] = true;
             if (b->bp_pass) {
-                int max_nd = 1;
-                for (const PgDevJob &d : b->dj) max_nd = std::max(max_nd, d.nd);
-                hipLaunchKernelGGL(pg_backptr, dim3((max_nd + PG_BP_DIAGS - 1) / PG_BP_DIAGS, b->n_ring), dim3(256), 0, b->stream,
-                                   b->d_jobs, b->d_which, (b->flags & 0xffu) | (b->bp_pass == 2 ? 0x100u : 0u));
+                int max_nd = 1, max_w = 1;
+                for (int k = 0; k < b->n; ++k) if (b->jobs[k].ring_ok) { max_nd = std::max(max_nd, b->dj[k].nd); max_w = std::max(max_w, b->jobs[k].dx.max_width); }
+                const int zc = (max_w + PG_BP_CELLS - 1) / PG_BP_CELLS, dpb = bp_diags_per_block(max_nd, b->n_ring * zc);
+                hipLaunchKernelGGL(pg_backptr, dim3((max_nd + dpb - 1) / dpb, b->n_ring, zc), dim3(256), 0, b->stream,
+                                   b->d_jobs, b->d_which, (b->flags & 0xffu) | (b->bp_pass == 2 ? 0x100u : 0u), dpb);
                 HIP_TRY(hipEventRecord(b->evk[2], b->stream)); b->evk_set[2] = true;
             }
         } else {
@@ -812,7 +821,18 @@ int launch_fill(pagan_batch *b) {
             }
         }
     }
-    if (b->tile_off.size() > 1) { HIP_TRY(hipEventRecord(b->evk[4], tile_stream)); b->evk_set[4] = true; }
+    if (b->tile_off.size() > 1) {
+        HIP_TRY(hipEventRecord(b->evk[4], tile_stream)); b->evk_set[4] = true;
+        // the tiled fill stores scores only: its jobs' back-pointers by the pass, behind it on the same stream
+        if (b->n_tiled > 0) {
+            int max_nd = 1, max_w = 1;
+            for (int k = 0; k < b->n; ++k) if (!b->jobs[k].ring_ok && !b->jobs[k].tiles.empty()) { max_nd = std::max(max_nd, b->dj[k].nd); max_w = std::max(max_w, b->jobs[k].dx.max_width); }
+            const int zc = (max_w + PG_BP_CELLS - 1) / PG_BP_CELLS, dpb = bp_diags_per_block(max_nd, b->n_tiled * zc);
+            hipLaunchKernelGGL(pg_backptr, dim3((max_nd + dpb - 1) / dpb, b->n_tiled, zc), dim3(256), 0, tile_stream,
+                               b->d_jobs, b->d_which + b->n_ring + b->n_wide, b->flags & 0xffu, dpb);
+            HIP_TRY(hipEventRecord(b->evk[6], tile_stream)); b->evk_set[6] = true;
+        }
+    }
     if (b->tile_off.size() > 1 && b->stream2) {
         HIP_TRY(hipEventRecord(b->ev_join, b->stream2));
         HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
@@ -1217,7 +1237,9 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     which_ring.insert(which_ring.end(), which_ring_big.begin(), which_ring_big.end());
     b->n_ring = (int)which_ring.size(); b->n_wide = (int)which_wide.size();
     which_ring.insert(which_ring.end(), which_wide.begin(), which_wide.end());
-    which_ring.resize(n, 0);      // tiled jobs are reached through the tile list
+    b->n_tiled = (int)which_tiled.size();
+    which_ring.insert(which_ring.end(), which_tiled.begin(), which_tiled.end());     // (the tiled fill reaches its jobs through the tile list; pg_backptr through this)
+    which_ring.resize(n, 0);
     b->block = max_w <= 64 ? 64 : (max_w <= 512 ? 256 : 1024);
 
     const double tc1 = now();
@@ -1338,7 +1360,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         }
         b->stream = o.stream; b->pooled_stream2 = o.stream2; b->pooled_fork = o.ev_fork; b->pooled_join = o.ev_join;
         for (int k = 0; k < 3; ++k) b->ev[k] = o.ev[k];
-        for (int k = 0; k < 6; ++k) b->evk[k] = o.evk[k];
+        for (int k = 0; k < 7; ++k) b->evk[k] = o.evk[k];
         if (!which_tiled.empty() && b->n_ring + b->n_wide > 0) { b->stream2 = o.stream2; b->ev_fork = o.ev_fork; b->ev_join = o.ev_join; }
     }
     HIP_TRY(hipMemcpyAsync(base, stage.data(), in_bytes, hipMemcpyHostToDevice, b->stream));
@@ -1405,6 +1427,10 @@ int pagan_batch_last_ms_detail(pagan_batch *b, double ms[6]) {
     ms[0] = span(b->evk[0], b->evk[1], b->evk_set[0] && b->evk_set[1]);
     if (ms[0] < 0 && b->evk_set[0]) ms[0] = span(b->evk[0], b->ev[1], true);           // (the ring kernel: no pass behind it)
     ms[1] = span(b->evk[1], b->evk[2], b->evk_set[1] && b->evk_set[2]);
+    {   // (+ the pass over the tiled jobs, which runs behind the tiled fill on its stream)
+        const double t2 = span(b->evk[4], b->evk[6], b->evk_set[4] && b->evk_set[6]);
+        if (t2 >= 0) ms[1] = (ms[1] < 0 ? 0.0 : ms[1]) + t2;
+    }
     ms[2] = span(b->evk[3], b->evk[4], b->evk_set[3] && b->evk_set[4]);
     ms[3] = b->evk_set[5] ? span(b->evk_set[2] ? b->evk[2] : (b->evk_set[1] ? b->evk[1] : b->ev[0]), b->evk[5], true) : -1.0;
     ms[4] = span(b->ev[1], b->ev[2], true);
@@ -1525,7 +1551,7 @@ void pagan_batch_destroy(pagan_batch *b) {
         GpuObjs o;
         o.stream = b->stream; o.stream2 = b->pooled_stream2; o.ev_fork = b->pooled_fork; o.ev_join = b->pooled_join;
         for (int k = 0; k < 3; ++k) o.ev[k] = b->ev[k];
-        for (int k = 0; k < 6; ++k) o.evk[k] = b->evk[k];
+        for (int k = 0; k < 7; ++k) o.evk[k] = b->evk[k];
         gpu_pool.give(b->device, o);
     }
     if (b->arena.dev) arena_pool.give(b->device, b->arena.dev, b->arena.cap);

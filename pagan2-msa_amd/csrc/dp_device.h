@@ -35,6 +35,7 @@
 #define PG_MAX_SLOT 16383
 #define PG_SEG 128           // diagonals per traceback segment
 #define PG_BP_DIAGS 64        // diagonals per workgroup of the back-pointer pass (pg_backptr)
+#define PG_BP_CELLS 1024      // ... and cells of each of them (grid.z covers the rest of a wide diagonal)
 
 // Geometry of the banded fill kernel (dp_pipe.hip) that the host-side planner (dp_abi.hip:
 // classify_diagonals, schedule_waves) has to agree with.

@@ -60,22 +60,23 @@ template __global__ void pg_fill_wavefront<1024>(const PgDevJob *, const int *, 
 // kernel -- one thread per cell, every cell independent -- re-evaluates each cell's candidates from the stored
 // scores of its predecessors, with the same expressions on the same doubles, and writes the 12 bytes.  HBM-bound:
 // 24 B read (neighbours come out of L2) + 12 B written per cell.
-// grid (ceil(max nd / PG_BP_DIAGS), n_jobs), block 256: wave w of block b takes the diagonals
-// b * PG_BP_DIAGS + w, + 4, ...; its lanes the diagonal's cells.
+// grid (ceil(max nd / diags_per_block), n_jobs, ceil(widest diagonal / PG_BP_CELLS)), block 256: wave w of block b takes the
+// diagonals b.x * diags_per_block + w, + 4, ... (diags_per_block: PG_BP_DIAGS, fewer for small batches so that the grid fills the chip); its lanes the cells b.z * PG_BP_CELLS .. of each (a full matrix has diagonals of
+// thousands of cells: one wave per diagonal left most of the chip idle).
 // flags bit 8 (diagnostic): nothing is written; the recomputed scores AND back-pointers are compared with what the
 // fill kernel stored, a difference sets fill_status to 0x7d (tests run this over whole matrices filled by the
 // kernels that still write their own back-pointers).
 __global__ __launch_bounds__(256) void pg_backptr(const PgDevJob *__restrict__ jobs, const int *__restrict__ which,
-                                                  unsigned flags) {
+                                                  unsigned flags, int diags_per_block) {
     const PgDevJob *__restrict__ job = jobs + which[blockIdx.y];
-    const int first = blockIdx.x * PG_BP_DIAGS;
+    const int first = blockIdx.x * diags_per_block;
     if (first >= job->nd) return;
     const View J = load_view(job);
     const bool no_terminal_edges = flags & 1u;
     const bool reduced_terminal = !(flags & 2u);
     const bool verify = flags & 0x100u;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int end = first + PG_BP_DIAGS < J.nd ? first + PG_BP_DIAGS : J.nd;
+    const int end = first + diags_per_block < J.nd ? first + diags_per_block : J.nd;
     for (int d = first + wave; d < end; d += 4) {
         const pg_i4 cur = J.dsc[d];
         const int lo = cur.x, hi = cur.y;
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256) void pg_backptr(const PgDevJob *__restrict__ j
         Diag d1 = {0, -1, 0}, d2 = {0, -1, 0};
         if (d > 0) { const pg_i4 p = J.dsc[d - 1]; d1 = {p.x, p.y, ((long long)p.w << 32) | (unsigned)p.z}; }
         if (d > 1) { const pg_i4 p = J.dsc[d - 2]; d2 = {p.x, p.y, ((long long)p.w << 32) | (unsigned)p.z}; }
-        for (int i = lo + lane; i <= hi; i += 64) {
+        const int c0 = lo + (int)blockIdx.z * PG_BP_CELLS, c1 = c0 + PG_BP_CELLS - 1 < hi ? c0 + PG_BP_CELLS - 1 : hi;
+        for (int i = c0 + lane; i <= c1; i += 64) {
             const int j = d - i;
             const long long at = base + (i - lo);
             int l0 = 0, l1 = 0, r0 = 0, r1 = 0;
@@ -652,12 +654,16 @@ __global__ __launch_bounds__(128) void pg_trace_spec(const PgDevJob *__restrict_
         // the chase aims for the next lower boundary pair {low, low-1} (boundary kb; kb == 0: run to the start).  A long edge
         // may jump over a pair: the chase then goes on to the pair below (pg_trace_compose would otherwise have to walk
         // that stretch cell by cell, a chain of dependent reads -- most of its time at the top of a deep tree)
+        // (only where a boundary is narrow -- a banded alignment: there the serial walk is what costs; on the thousands of
+        // cells of a full matrix's boundary the longer chases of the entries that are NOT on the path cost more)
+        const bool follow = n_entries <= 3 * 512;
         int kb = k - 1, low = (k - 1) * PG_SEG;
         for (;;) {
             if (trace_done(n)) { kind = EXIT_DONE; break; }
             const int dd = n.i + n.j;
             if (steps > 0 && kb >= 1 && dd <= low) {
                 if (dd >= low - 1) { kind = EXIT_ENTRY; break; }
+                if (!follow) { kind = EXIT_MISS; break; }
                 while (kb >= 1 && dd < low - 1) { --kb; low -= PG_SEG; }
                 if (kb >= 1 && dd <= low) { kind = EXIT_ENTRY; break; }           // (dd is low or low - 1 now)
             }

@@ -74,7 +74,10 @@ struct SiteRec { pg_i4 r, e; };
 // basic_alignment.h:449-462); the value is the maximum either way (v_max_f64: one instruction where a
 // compare-and-select of a double costs two more).  v_max_f64 may flip the sign of a zero, so the host keeps jobs
 // with a negative zero among their parameters off this kernel (dp_abi.hip: has_negative_zero).
-#define PG_TAKE(best, bp, c, code) do { const double c__ = (c); bp = c__ > best ? (code) : bp; best = __builtin_fmax(best, c__); } while (0)
+// Round 3: SCORES ONLY.  A back-pointer is a function of scores that are final once the fill has passed the cell, and
+// pg_backptr (dp_kernels.hip) re-derives all of them after the fill; here a candidate only raises its state's value, so the
+// winner's code (and the compare + select that tracked it) is gone from every path of the tile step.
+#define PG_TAKE(best, bp, c, code) do { best = __builtin_fmax(best, (c)); } while (0)
 
 } // namespace
 
@@ -634,7 +637,14 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
             if (active) {
                 const int at = TAT(i, j);
                 TM.sc[at][0] = bx; TM.sc[at][1] = by; TM.sc[at][2] = bm;
-                store_cell(J.sc, J.bp, off + (i - mn), bx, by, bm, px, py, pm);
+                {   // 24 B of scores (the 12 B of back-pointers are pg_backptr's)
+                    typedef double d2 __attribute__((ext_vector_type(2)));
+                    gdouble_w o_ = J.sc + 3 * (off + (i - mn));
+                    d2 xy; xy.x = bx; xy.y = by;
+                    *(PG_GLOBAL d2 *)o_ = xy;
+                    o_[2] = bm;
+                }
+                (void)px; (void)py; (void)pm;
             }
         }
         D = Dn; c = cn; ce = cen;
