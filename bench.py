@@ -123,15 +123,21 @@ def bench_forward_backward(args, device):
         left, right, _model, band = msa.node_job(k)
         jobs.append((left, right, host.model_prob(1 if len(alphabet) == 4 else 2, msa.node_info(k).dist, base_freq=bf), band))
 
+    def one_pair(job):
+        left, right, mp, band = job
+        fb = pg.FullProbability(left, right, mp, band, device=device)
+        out = (fb.forward_ms, fb.backward_ms, fb.cells, (fb.log_fwd, fb.log_bwd))
+        fb.close()
+        return out
+
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(min(len(jobs), 16))      # the node pairs are independent: their sweeps (a workgroup each) run side by side
+
     def one_pass():
-        fwd = bwd = 0.0
-        cells, totals = 0, []
-        for left, right, mp, band in jobs:
-            fb = pg.FullProbability(left, right, mp, band, device=device)
-            fwd += fb.forward_ms; bwd += fb.backward_ms; cells += fb.cells
-            totals.append((fb.log_fwd, fb.log_bwd))
-            fb.close()
-        return fwd, bwd, cells, totals
+        t0 = time.perf_counter()
+        rs = list(pool.map(one_pair, jobs))
+        wall = time.perf_counter() - t0
+        return sum(r[0] for r in rs), sum(r[1] for r in rs), sum(r[2] for r in rs), [r[3] for r in rs], wall
 
     for _ in range(args.warmup):
         one_pass()
@@ -140,7 +146,7 @@ def bench_forward_backward(args, device):
     elapsed = time.perf_counter() - t0
     fwd_ms = float(np.mean([a[0] for a in acc])); bwd_ms = float(np.mean([a[1] for a in acc]))
     cells, totals = acc[-1][2], acc[-1][3]
-    dev_s = max(fwd_ms, bwd_ms) * 1e-3        # the two sweeps of a pair run side by side (two streams)
+    dev_s = float(np.mean([a[4] for a in acc]))       # wall-clock of a pass: every pair's two sweeps side by side (one workgroup each), uploads included
     ok = all(abs(f - b) <= 1e-7 * max(1.0, abs(f)) for f, b in totals)       # the reference's own check (VA:351-355): forward total = backward total
     out = {
         "metric": "DP cells/sec of the forward + backward sweeps (--full-probability), %s node pairs" % workload,
@@ -148,7 +154,7 @@ def bench_forward_backward(args, device):
         "ms_per_step": 1e3 * dev_s, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": workload, "leaves": leaves, "length": length, "node_pairs": n_nodes, "cells_per_step": int(cells),
-                   "note": "value counts the device time of a pair's two sweeps, which run side by side; wall per pass incl. allocation and upload: %.1f ms" % (1e3 * elapsed / args.steps)},
+                   "note": "value = cells / wall-clock of a pass with all node pairs in flight at once (2 workgroups per pair); the per-kernel ms are sums of the kernels' own durations; wall per pass incl. allocation and upload: %.1f ms" % (1e3 * elapsed / args.steps)},
         "roofline": {"bound": "hbm", "achieved": 48 * cells / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": 48 * cells / dev_s / 1e9 / HBM_PEAK_GBS, "kernel": "pg_fb_forward + pg_fb_backward",
                      "algorithmic_bytes_per_cell": 48, "traffic": None,

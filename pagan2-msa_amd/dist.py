@@ -9,12 +9,17 @@ holds the whole (small) tree state and the queue is replayed in rounds:
     ready = msa.ready()                      the same list on every rank
     mine  = the units the work-queue rule (pagan_assign_units, largest first) gives this rank
     msa.align_nodes(mine)                    model, anchors, DP on this rank's GPU, parent graphs
-    all_gather(exported results of `mine`)   the one exchange: path columns + used child edges of the
-                                             nodes a rank aligned, ~1 byte per alignment column
-    msa.import_result(...) for the others'   builds those parents locally
+    post(exported results of `mine`)         into the job's key-value store (the rendezvous store torch.distributed
+                                             was initialised with): path columns + used child edges of the nodes a
+                                             rank aligned, ~1 byte per alignment column
+    fetch + msa.import_result(...)           the other ranks' nodes of the round, as they appear; builds those
+                                             parents locally
 
-The DP itself has no collective; what travels is the finished path of each node, because the next
-round's inputs (the parents' graphs) are built from it on every rank.
+NO collective on the data path (north_star: "an embarrassingly-parallel work queue (no RCCL collectives)"): a finished
+path is posted under its node's key and read by whoever needs it -- a mailbox, point to point through the store, and a
+rank waits only for the nodes it has not aligned itself.  (Round 2 exchanged the same bytes with two all-gathers per
+round; that is kept behind exchange="collective" for comparison.)  The ranks still meet in torch.distributed for what the
+bench contract asks: the barrier around the timed region and the maximum of the elapsed time.
 """
 import numpy as np
 import torch
@@ -82,12 +87,33 @@ def all_gather_bytes(chunks, device="cpu"):
     return out
 
 
-def align_sharded(msa, assign, device="cpu", on_round=None):
+_walks = [0]
+_posted = {}                      # walk -> keys this rank posted (deleted two walks later: by then every rank has read them --
+                                  # a rank starts walk k only after it has received every other rank's nodes of walk k-1, which
+                                  # those ranks posted after finishing walk k-2)
+
+
+def _store():
+    from torch.distributed import distributed_c10d as c10d
+    return c10d._get_default_store()
+
+
+def align_sharded(msa, assign, device="cpu", on_round=None, exchange="store"):
     """The whole progressive alignment of `msa` (a host.Msa, created identically on every rank) with the
     ready nodes of each round dealt over the ranks.  `assign(costs, n_workers)` is the work-queue rule
     (host.assign_units).  Returns per-round records [(n_ready, n_mine, bytes exchanged)]."""
     w, r = world(), rank()
     rounds = []
+    walk = _walks[0]              # (every rank calls this the same number of times: the keys of one walk never meet another's)
+    _walks[0] += 1
+    store = _store() if (w > 1 and exchange == "store") else None
+    if store is not None:
+        for key in _posted.pop(walk - 2, []):
+            try:
+                store.delete_key(key)
+            except Exception:          # (a store without delete: the keys just stay)
+                pass
+        _posted[walk] = []
     while msa.remaining > 0:
         ready = msa.ready()
         if not ready:
@@ -99,7 +125,17 @@ def align_sharded(msa, assign, device="cpu", on_round=None):
             msa.align_nodes(mine)
         chunks = [msa.export_result(n) for n in mine]
         moved = 0
-        if w > 1:
+        if store is not None:
+            for n, c in zip(mine, chunks):
+                store.set("pagan/%d/%d" % (walk, n), c.tobytes())
+                _posted[walk].append("pagan/%d/%d" % (walk, n))
+            for n, o in zip(ready, owner):
+                if int(o) == r:
+                    continue
+                buf = np.frombuffer(store.get("pagan/%d/%d" % (walk, n)), np.uint8)        # (blocks until the owner has posted it)
+                msa.import_result(buf)
+                moved += int(buf.shape[0])
+        elif w > 1:
             for src, theirs in enumerate(all_gather_bytes(chunks, device=device)):
                 if src == r:
                     continue
