@@ -443,7 +443,8 @@ def bench_work_queue(args, rank, local_rank, world):
                        "anchors": "prefix, offset 15" if anchors else "none", "node_alignments": n_nodes,
                        "cells_per_step": int(cells),
                        "parallelism": ("in-process work queue over %d devices" % args.gpus) if in_process else
-                                      ("one rank per GPU, ready nodes dealt per round, paths all-gathered (%s); "
+                                      ("one rank per GPU, ready nodes dealt per round, finished paths posted to / read from the job's "
+                                       "key-value store (no collective on the data path; process group: %s); "
                                        "rank 0 aligned %d of %d nodes%s" % ("RCCL" if args.dist_backend == "nccl" else "gloo", mine, n_nodes,
                                                                             "; REHEARSAL: ranks share a device" if args.share_device else "")),
                        "step": "one whole progressive alignment: model + anchors + DP + parent graphs, host work included"},
