@@ -44,7 +44,7 @@ __global__ void pg_trace_emit(const PgDevJob *jobs);
 #define PG_RING_EDGE_CAP 2048
 unsigned pg_ring_lds_bytes();
 // limits of the register-wavefront kernel: PG_PIPE_* in dp_device.h, shared with dp_pipe.hip
-unsigned pg_pipe_lds_bytes();
+unsigned pg_pipe_lds_bytes();        // (static LDS: reported, not passed at launch)
 unsigned pg_pipe_block();
 unsigned pg_tiles_lds_bytes();
 
@@ -747,10 +747,6 @@ int launch_fill(pagan_batch *b) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_ring_lds_bytes()));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_ring<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_ring_lds_bytes()));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_pipe<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_pipe_lds_bytes()));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_fill_pipe<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_pipe_lds_bytes()));
             lds_set.store(true);
         }
         // model tables of <= 16 states (DNA: 15) are cached in LDS; larger ones stay in HBM/L2
@@ -758,10 +754,10 @@ int launch_fill(pagan_batch *b) {
         HIP_TRY(hipEventRecord(b->evk[0], b->stream)); b->evk_set[0] = true;
         if (b->use_pipe) {
             if (n_small > 0)
-                hipLaunchKernelGGL(pg_fill_pipe<true>, dim3(n_small), dim3(pg_pipe_block()), pg_pipe_lds_bytes(), b->stream,
+                hipLaunchKernelGGL(pg_fill_pipe<true>, dim3(n_small), dim3(pg_pipe_block()), 0 /* its LDS is static */, b->stream,
                                    b->d_jobs, b->d_which, b->flags);
             if (n_big > 0)
-                hipLaunchKernelGGL(pg_fill_pipe<false>, dim3(n_big), dim3(pg_pipe_block()), pg_pipe_lds_bytes(), b->stream,
+                hipLaunchKernelGGL(pg_fill_pipe<false>, dim3(n_big), dim3(pg_pipe_block()), 0, b->stream,
                                    b->d_jobs, b->d_which + n_small, b->flags);
             HIP_TRY(hipEventRecord(b->evk[1], b->stream)); b->evk_set[1] = true;
             if (b->bp_pass) {

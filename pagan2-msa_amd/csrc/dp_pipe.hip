@@ -104,8 +104,11 @@ static_assert(sizeof(PipeSmem) <= 160 * 1024, "PipeSmem has to fit the 160 KB of
 unsigned pg_pipe_lds_bytes() { return (unsigned)sizeof(PipeSmem); }
 unsigned pg_pipe_block() { return PBLOCK; }
 
-extern __shared__ __attribute__((aligned(16))) char pg_pipe_lds[];
-#define PM (*reinterpret_cast<PipeSmem *>(pg_pipe_lds))
+// A STATIC allocation (gfx950 takes 160 KB; the launch asks for no dynamic LDS): the kernel's run functions and the assist
+// waves are functions of their own, and in a non-kernel function every access to DYNAMIC LDS first loads the allocation's base
+// address from a table in memory -- a scalar load and a drained LDS queue per access (142 sites in pipe_assist alone).
+__shared__ __attribute__((aligned(16))) PipeSmem pg_pipe_smem;
+#define PM pg_pipe_smem
 
 namespace {
 
@@ -847,85 +850,33 @@ __device__ __forceinline__ void assist1_cell(gdouble_w sc, cdesc8_p psc, int d, 
 // 0..2) from L2, so that the compute waves never issue a load behind their stores.
 // Ring safety: the compute waves cannot pass d before this wave has published d, a cell reads at most PAGE-1
 // diagonals back, and step d' overwrites diagonal d'-PRK only: everything diagonal d reads is still in place.
+// ---- assist waves: the general staging code --------------------------------------------------------------------------
+// Scan of a diagonal's band for multi-edge cells, their records and model scores, every candidate that does not read diagonal
+// d-1 in the reference's order, the staging stores.  pipe_assist<false> (large tables) runs it inline for every diagonal;
+// pipe_assist<true> keeps the band's multi-edge sites in its lanes and stages values only, and calls this -- out of line,
+// so that its registers do not weigh on the usual path -- for the few diagonals that path does not take.
 template <bool TAB_LDS>
-__device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, bool reduced_terminal) {
-    const int nd = job->nd, S = job->S;
-    const gdouble_w sc_out = (gdouble_w)job->sc;
-    const gfloat_p table = (gfloat_p)job->table;
-    const float f_ng = job->ng;
-    const double go = (double)job->go, ge = (double)job->ge, ng = (double)f_ng;
-    const double tng2 = (double)(2 * f_ng), tng1 = (double)(0.0f + f_ng);
-    const int wave = PNW + a;                                      // names this wave in an abort tag
-    int rows_ld = 0, cols_ld = 0, diags_ld = 0;
-    int pw0 = -1, pw1 = -1, pw2 = -1, pw3 = -1;                   // cached progress of the compute waves
-#ifdef PG_PIPE_STATS
-    long long st_poll_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int st_poll_n[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    int *list = PM.as_list[a];
-    const double NI_ = neg_inf();
-    // Software pipeline: everything a diagonal's batch needs that does NOT come out of the ring -- its descriptor, the scan
-    // of the band for multi-edge cells, their site records, edge data and model scores -- is prepared right after the
-    // previous diagonal has been published, while the compute waves are still steps away.  What is left between "the
-    // compute waves have completed d-2" and "d is staged" is the ring reads, the candidates and the staging stores.
-    int q_d = -1, q_cls = 0, q_lo = 0, q_hi = 0, q_n = 0;          // the prepared diagonal (q_d < 0: none)
-    unsigned q_mask = 0;
-    bool q_big = false;                                            // more than 64 multi-edge cells: not prepared, done in batches
-    int q_row = 0, q_j = 0, q_kind = 0;
-    pg_i4 q_rL = {0, 0, 0, 0}, q_cR = {0, 0, 0, 0};
-    double q_tM = 0, q_tX = 0;
-    // the usual batch (class 1, every cell one multi-edge site with at most two edges) decoded down to LDS offsets of its four
-    // operand cells, weights and back-pointer words: what remains for the critical chain is 12 LDS reads and 12 candidates
-    bool q_fast = false, q_left = true;
-    int q_oa0 = 0, q_oa1 = 0, q_ob0 = 0, q_ob1 = 0, q_adjs = -1;
-    unsigned q_e0 = 0, q_e1 = 0;                                   // ADJ flag / slot bits of the two edges in an M back-pointer
-    double q_w0 = 0, q_w1 = 0;
-    // class 2 batches of the usual shape: the operand cells that left the ring, fetched from L2 while the batch is prepared
-    // (off the chain "compute waves completed d-2 -> d is staged": what remains there is the same as for class 1)
-    double q_fx[4] = {0, 0, 0, 0}, q_fy[4] = {0, 0, 0, 0}, q_fm[4] = {0, 0, 0, 0};
-    bool q_far[4] = {false, false, false, false};
-    // Small tables (scores-only hot loop): batches whose cells have at most three edges on one side opposite a simple site, or at
-    // most two on either side (kinds 1..3: all but a few) are decoded down to EIGHT operand slots per cell -- 0,1 the left
-    // site's edges that do not start at the previous site (X from (row-dL, j)), 2,3 the right site's (Y from (row, j-dR)),
-    // 4..7 the (left edge, right edge) pairs (M from (row-dL, j-dR)) with their two weights -- each an LDS offset into the
-    // ring (the all -inf cell if absent) or, for a cell that left the ring, its scores fetched from L2 HERE, off the chain
-    // "compute waves completed d-2 -> d is staged".  Only VALUES are staged (the back-pointers come from pg_backptr), so
-    // the order of the candidates does not matter: a state's value is the maximum over its edges of
-    // max(own + ge, max(other, M + ng) + go), M's over its pairs of (max(M + tM, max(X, Y) + tX) + lw) + rw (the folding
-    // tools/gen_hot_asm.py explains).
-    // The fetched cells go into a pool of PFAR_POOL cells per assist wave (the memory of spm[a][.]: nobody reads staged M
-    // back-pointers of a small-table job) and the slot's offset points there: the chain reads eight cells, wherever they are.
-    bool q_val = false, v_msL = false, v_msR = false, v_onlyL = false, v_onlyR = false;
-    bool q_three = false, q_gap2 = false, q_pair34 = false;       // wave-uniform: some cell of the batch has a third edge / a second gap operand / more than two pairs
-    int v_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double v_lw[4] = {0, 0, 0, 0}, v_rw[4] = {0, 0, 0, 0};
-    int scan_d = a;                                                // next diagonal whose descriptor has not been looked at
-
-#ifdef PG_PIPE_STATS
-    long long as_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // cycles: prepare (rest), waiting for the compute waves, compute, publish; inside prepare: scan, batch, decode, far
-    int as_n = 0;
-    // (PG_ASSIST_RUNS_ONLY: only diagonals that directly follow this wave's previous one -- the inside of a class 2 run, where the
-    // assist waves are what the compute waves wait for -- are counted; otherwise the idle time between runs dominates the averages)
-    bool as_on = true;
-    int as_prev = -100;
-#define ASTAMP(k) do { const long long t_ = __builtin_readcyclecounter(); if (as_on) as_t[k] += t_ - as_t0; as_t0 = t_; } while (0)
-    long long as_t0 = __builtin_readcyclecounter();
-#else
-#define ASTAMP(k)
-#endif
+struct AssistGen {
+    gdouble_w sc_out;
+    cdesc8_p psc;
+    gfloat_p table;
+    int *list;
+    double go, ge, ng, tng2, tng1;
+    int S, lane;
+    bool reduced_terminal;
     // classification of one multi-edge cell: 1 one multi-edge site with <= 2 edges, 2 ... with 3, 3 two multi-edge sites
     // with <= 2 edges each, 4 anything else
-    auto classify = [&](const pg_i4 &rL, const pg_i4 &cR) {
+    __device__ __forceinline__ int classify(const pg_i4 &rL, const pg_i4 &cR) const {
         const int nl = (rL.x >> PR_NE_SHIFT) & 127, nr = (cR.x >> PR_NE_SHIFT) & 127;
         const bool sL = rL.x & PR_SIMPLE, sR = cR.x & PR_SIMPLE;
         const int ne = sL ? nr : nl;
         if ((sL || sR) && (unsigned)(ne - 1) < 3u) return ne == 3 ? 2 : 1;
         if ((unsigned)(nl - 1) < 2u && (unsigned)(nr - 1) < 2u) return 3;
         return 4;
-    };
+    }
     // the ring-dependent part for one batch of cells held in registers
-    auto compute = [&](int d, int cls, unsigned resmask, bool on, int row, int j, int kind, const pg_i4 &rL, const pg_i4 &cR,
-                       double tM, double tX) {
+    __device__ __forceinline__ void compute(int d, int cls, unsigned resmask, bool on, int row, int j, int kind, const pg_i4 &rL, const pg_i4 &cR,
+                                            double tM, double tX) const {
         const int slot = d % PRK, stg = d % PST, at = row & (PNT - 1);
         if (__builtin_amdgcn_ballot_w64(on && kind >= 3) == 0) {
             // the usual batch: one multi-edge site per cell
@@ -966,9 +917,9 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
             PM.spx[stg][at] = px; PM.spy[stg][at] = py;
             if (!TAB_LDS) PM.spm[stg][at] = pm;
         }
-    };
+    }
     // one batch from the compacted list into registers
-    auto fetch_batch = [&](int d, int stg, int n, bool &on, int &row, int &j, int &kind, pg_i4 &rL, pg_i4 &cR, double &tM, double &tX) {
+    __device__ __forceinline__ void fetch_batch(int d, int stg, int n, bool &on, int &row, int &j, int &kind, pg_i4 &rL, pg_i4 &cR, double &tM, double &tX) const {
         on = lane < n;
         row = 0; j = 0; kind = 0; tM = 0; tX = 0;
         if (on) {
@@ -979,10 +930,10 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
             else { const float sm = PM.ssm[stg][row & (PNT - 1)]; tM = tng2 + (double)sm; tX = tng1 + (double)sm; }
             kind = classify(rL, cR);
         }
-    };
+    }
     // scan of a diagonal's band: model scores for large tables, the multi-edge cells compacted into `list`.  Returns their
     // number; with `flush` batches of 64 are computed as they fill up (the diagonal must be computable then).
-    auto scan = [&](int d, int cls, int lo, int hi, unsigned resmask, bool flush) {
+    __device__ __forceinline__ int scan(int d, int cls, int lo, int hi, unsigned resmask, bool flush) const {
         const int stg = d % PST;
         int n_ns = 0, total = 0;
         for (int base = lo; base <= hi; base += 64) {
@@ -1013,26 +964,473 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
             compute(d, cls, resmask, on, r_, j_, k_, a_, b_, tm_, tx_);
         }
         return flush ? total : n_ns;
+    }
+};
+
+template <bool TAB_LDS>
+__device__ __forceinline__ AssistGen<TAB_LDS> assist_gen(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, bool reduced_terminal) {
+    AssistGen<TAB_LDS> g;
+    const float f_ng = job->ng;
+    g.sc_out = (gdouble_w)job->sc; g.psc = psc; g.table = (gfloat_p)job->table; g.list = PM.as_list[a];
+    g.go = (double)job->go; g.ge = (double)job->ge; g.ng = (double)f_ng;
+    g.tng2 = (double)(2 * f_ng); g.tng1 = (double)(0.0f + f_ng);
+    g.S = job->S; g.lane = lane; g.reduced_terminal = reduced_terminal;
+    return g;
+}
+// one diagonal, start to finish (the diagonal must be computable: the compute waves have completed d-2)
+__device__ __noinline__ void assist_general_diag(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, bool reduced_terminal,
+                                                 int d, int cls, int lo, int hi, unsigned resmask) {
+    const AssistGen<true> g = assist_gen<true>(job, psc, a, lane, reduced_terminal);
+    g.scan(d, cls, lo, hi, resmask, true);
+}
+// the cells (row, j) of the lanes with `on` (the diagonal must be computable)
+__device__ __noinline__ void assist_general_cells(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, bool reduced_terminal,
+                                                  int d, int cls, unsigned resmask, bool on, int row, int j) {
+    const AssistGen<true> g = assist_gen<true>(job, psc, a, lane, reduced_terminal);
+    pg_i4 rL = {0, 0, 0, 0}, cR = {0, 0, 0, 0};
+    double tM = 0, tX = 0;
+    int kind = 0;
+    if (on) {
+        rL = PM.recL[row & (PRW - 1)]; cR = PM.recR[j & (PRW - 1)];
+        const int ti = (rL.x & 0xffff) + (cR.x & 0xffff) * g.S;
+        tM = PM.tab2[ti & 255][0]; tX = PM.tab2[ti & 255][1];
+        kind = g.classify(rL, cR);
+    }
+    g.compute(d, cls, resmask, on, row, j, kind, rL, cR, tM, tX);
+}
+
+// ---- assist waves, small model tables: the band's multi-edge SITES kept in the lanes, values only, two diagonals a pass ----
+// A multi-edge site stays in the band for as many diagonals as the band is wide, and the band only ever takes new rows at its
+// upper end (imax never falls) and new columns at d - imin (never falls either).  Instead of scanning the band of every
+// diagonal and decoding its multi-edge cells from the records, an assist wave holds one site per lane slot (side, site, state,
+// up to three edges) and, per pass, looks at the rows and columns that are new.  A cell with a multi-edge site on both sides
+// is the left site's.  The wave's two halves hold the same 32 slots and work on two diagonals at once -- this wave's next two
+// class 2 diagonals, d and d + 3, when they follow each other -- so that everything up to the ring reads (tracking, the
+// other site's record, the eight operand slots per cell, the cells fetched from L2) is done once per PAIR; the values of d
+// are staged when the compute waves have completed d - 2, those of d + 3 three diagonals later.
+//
+// Per cell EIGHT operand slots -- 0,1 the left site's edges that do not start at the previous site (X from (row-dL, j)), 2,3
+// the right site's (Y from (row, j-dR)), 4..7 the (left edge, right edge) pairs (M from (row-dL, j-dR)) with their two weights
+// -- each an LDS offset into the ring (the all -inf cell if absent) or, for a cell that left the ring, into a pool of
+// PFAR_POOL cells per assist wave (the memory of spm[a][.]: nobody reads staged M back-pointers of a small-table job) filled
+// from L2 during the preparation.  Only VALUES are staged (the back-pointers come from pg_backptr), so the order of the
+// candidates does not matter: a state's value is the maximum over its edges of max(own + ge, max(other, M + ng) + go), M's
+// over its pairs of (max(M + tM, max(X, Y) + tX) + lw) + rw (the folding tools/gen_hot_asm.py explains).  What this path does
+// not take (more than three edges at a site, three on both sides of a cell, an edge from site 0, more sites than slots, more
+// far cells than the pool holds) goes to assist_general_diag when the diagonal is due.
+__device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, bool reduced_terminal) {
+    const int nd = job->nd, S = job->S;
+    const gdouble_w sc_out = (gdouble_w)job->sc;
+    const double go = (double)job->go, ge = (double)job->ge, ng = (double)job->ng;
+    const int wave = PNW + a;                                      // names this wave in an abort tag
+    const int grp = lane >> 5;                                     // which diagonal of the pair this lane works on
+    int rows_ld = 0, cols_ld = 0, diags_ld = 0;
+    int pw0 = -1, pw1 = -1, pw2 = -1, pw3 = -1;                   // cached progress of the compute waves
+#ifdef PG_PIPE_STATS
+    long long st_poll_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int st_poll_n[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long as_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // [0] cycles outside the wait for the compute waves, [1] inside it
+    int as_n = 0, as_gen = 0, as_pairs = 0, as_cells = 0;          // diagonals staged; of those by the general code, whole; passes that held two; diagonals with cells staged by the general code
+    int as_why[6] = {0, 0, 0, 0, 0, 0};                            // passes sent to the general code: slots, site shape, other side, cell shape / site 0, recent operand off the ring, pool
+    long long as_t0 = __builtin_readcyclecounter();
+#define ASTAMP(k) do { const long long t_ = __builtin_readcyclecounter(); as_t[k] += t_ - as_t0; as_t0 = t_; } while (0)
+#else
+#define ASTAMP(k)
+#endif
+    int *list = PM.as_list[a];
+    const double NI_ = neg_inf();
+    // the lane's slot
+    int s_site = -1;                                               // the site (-1: free)
+    bool s_left = true, s_gen = false;                             // s_gen: not for this path (no edge, more than three, a saturated distance)
+    int s_n = 0, s_state = 0, s_a0 = 1, s_a1 = 1, s_a2 = 1;
+    float s_w0 = 0.0f, s_w1 = 0.0f, s_w2 = 0.0f;
+    int seen_row = 0, seen_col = 0;                                // rows / columns below these have been looked at
+    bool trk_valid = true;                                         // false: more sites than slots -- start over with the next pass
+    // the prepared pass: diagonal q_d (lanes 0..31) and, if q_d2 >= 0, q_d2 (lanes 32..63)
+    int q_d = -1, q_d2 = -1, q_cls[2] = {0, 0}, q_lo[2] = {0, 0}, q_hi[2] = {0, 0};
+    unsigned q_mask[2] = {0, 0};
+    bool q_gen[2] = {false, false};                                // the diagonal goes to the general code
+    bool q_on = false, q_bad = false;                              // this lane holds a cell / one that the general code has to stage
+    int q_j = 0;
+    bool q_gap2 = false, q_pair34 = false;                         // wave-uniform: some cell has a second gap operand / more than two pairs
+    bool v_msL = false, v_msR = false, v_onlyL = false, v_onlyR = false;
+    int q_row = 0, v_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double q_tM = 0, q_tX = 0, v_lw[4] = {0, 0, 0, 0}, v_rw[4] = {0, 0, 0, 0};
+    int scan_d = a;                                                // next diagonal whose descriptor has not been looked at
+
+    // the sites first..last of one side have entered the band: the multi-edge ones among them into free slots (both halves alike)
+    auto take_sites = [&](bool left, int first, int last) -> bool {
+        for (int base = first; base <= last; base += 64) {
+            const int s_ = base + lane;
+            bool multi = false;
+            if (s_ <= last) multi = !((left ? PM.recL : PM.recR)[s_ & (PRW - 1)].x & PR_SIMPLE);
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(multi);
+            if (mask == 0) continue;
+            const int cnt = __builtin_popcountll(mask);
+            const unsigned fmask = (unsigned)__builtin_amdgcn_ballot_w64(s_site < 0);        // (the lower half's view: the halves agree)
+            if (cnt > __builtin_popcount(fmask)) return false;
+            if (multi) list[(int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = s_;
+            if (s_site < 0) {
+                const int r = __builtin_popcount(fmask & ((1u << (lane & 31)) - 1u));
+                if (r < cnt) {
+                    const int site = list[r];
+                    const pg_i4 rec = (left ? PM.recL : PM.recR)[site & (PRW - 1)];
+                    s_site = site; s_left = left; s_n = (rec.x >> PR_NE_SHIFT) & 127; s_state = rec.x & 0xffff;
+                    s_a0 = rec.y & 0xffff; s_a1 = (int)((unsigned)rec.y >> 16);
+                    s_w0 = __int_as_float(rec.z); s_w1 = __int_as_float(rec.w);
+                    s_a2 = 1; s_w2 = 0.0f;
+                    if (s_n == 3) {
+                        const int e = (left ? PM.ebL : PM.ebR)[site & (PRW - 1)] + 2;
+                        s_a2 = site - (left ? PM.esL : PM.esR)[e & (PEC - 1)];
+                        s_w2 = (left ? PM.ewL : PM.ewR)[e & (PEC - 1)];
+                    }
+                    if (s_n < 2) { s_a1 = 1; s_w1 = 0.0f; }         // an absent edge: distance 1, as the decoding expects
+                    s_gen = s_n < 1 || s_n > 3 || s_a0 >= 65535 || s_a1 >= 65535;
+                }
+            }
+        }
+        return true;
     };
+
+    // descriptors of scan_d (lanes 0..7) and scan_d + 3 (lanes 8..15), requested a pass ahead -- as a VECTOR load: a scalar load
+    // shares its counter with the LDS operations and returns out of order, so the first LDS read behind it would wait for it
+    auto desc_req = [&](int dd) {
+        const int t = dd + ((lane >> 3) & 1) * PNA;
+        return ((PG_GLOBAL const int *)psc)[8 * (t < nd ? t : nd) + (lane & 7)];           // (the array carries one entry of padding)
+    };
+    int q_next = desc_req(a);
+
+    // looks for this wave's next class 2 diagonal (and the one after, if it follows directly) and prepares the pass
+    auto prepare = [&]() {
+        q_d = -1; q_d2 = -1;
+        while (scan_d < nd) {
+            if (flag_load(&PM.abort_flag) != 0) return;
+            const int d = scan_d, d2 = d + PNA;
+            const int ax = __builtin_amdgcn_readlane(q_next, 0), ay = __builtin_amdgcn_readlane(q_next, 1), as4 = __builtin_amdgcn_readlane(q_next, 4);
+            const int bx = __builtin_amdgcn_readlane(q_next, 8), by = __builtin_amdgcn_readlane(q_next, 9), bs4 = __builtin_amdgcn_readlane(q_next, 12);
+            const int hop_a = (int)((unsigned)as4 >> 20);           // the host's hop count: straight to this wave's next diagonal with work
+            if ((as4 & 15) != 2) { scan_d += PNA * hop_a; q_next = desc_req(scan_d); continue; }      // (class 0 / 1: the compute waves' own)
+            const bool pair = hop_a == 1 && d2 < nd && (bs4 & 15) == 2;
+            scan_d = pair ? d2 + PNA * (int)((unsigned)bs4 >> 20) : d + PNA * hop_a;
+            q_next = desc_req(scan_d);
+            // bit 4 marks a class 2 diagonal whose operands all lie in the ring (class 2 for the shape of a site): no residency test
+            q_d = d; q_cls[0] = (as4 & 16) ? 1 : 2; q_lo[0] = ax; q_hi[0] = ay; q_mask[0] = ((unsigned)as4 >> 5) & 0x7fffu;
+            q_d2 = pair ? d2 : -1; q_cls[1] = (bs4 & 16) ? 1 : 2; q_lo[1] = bx; q_hi[1] = by; q_mask[1] = ((unsigned)bs4 >> 5) & 0x7fffu;
+            q_gen[0] = false; q_gen[1] = false; q_on = false; q_bad = false;
+            const int lo_a = ax, cmin_a = d - ay;
+            const int hi_t = pair ? by : ay, cmax_t = pair ? d2 - bx : d - ax;          // the later diagonal's upper ends
+            if (rows_ld <= hi_t) rows_ld = POLL(&PM.loaded[0], hi_t + 1, 1);
+            if (cols_ld <= cmax_t) cols_ld = POLL(&PM.loaded[1], cmax_t + 1, 2);
+            // ---- the slots ----
+            if (!trk_valid) { s_site = -1; seen_row = lo_a; seen_col = cmin_a; trk_valid = true; }
+            if (s_site >= 0 && s_site < (s_left ? lo_a : cmin_a)) s_site = -1;          // the band has left this row / column behind
+            if (!take_sites(true, seen_row > lo_a ? seen_row : lo_a, hi_t) || !take_sites(false, seen_col > cmin_a ? seen_col : cmin_a, cmax_t)) {
+                trk_valid = false;
+                q_gen[0] = true; q_gen[1] = pair;
+#ifdef PG_PIPE_STATS
+                ++as_why[0];
+#endif
+                return;
+            }
+            seen_row = hi_t + 1; seen_col = cmax_t + 1;
+            // ---- this lane's cell: (site, dg - site) or (dg - site, site) ----
+            const int dg = grp ? d2 : d, lo_g = grp ? bx : ax, hi_g = grp ? by : ay;
+            const bool cls1_g = (grp ? q_cls[1] : q_cls[0]) == 1;
+            const unsigned mask_g = grp ? q_mask[1] : q_mask[0];
+            const bool act = s_site >= 0 && (grp == 0 || pair);
+            const int row = act ? (s_left ? s_site : dg - s_site) : 0, j = act ? dg - row : 0;
+            const bool inb = act && row >= lo_g && row <= hi_g;
+            pg_i4 o = {PR_SIMPLE | (1 << PR_NE_SHIFT), 1, 0, 0};
+            if (inb) o = s_left ? PM.recR[j & (PRW - 1)] : PM.recL[row & (PRW - 1)];
+            const bool oS = o.x & PR_SIMPLE;
+            const int nO = (o.x >> PR_NE_SHIFT) & 127;
+            bool on = inb && (s_left || oS);                       // (both sites multi-edge: the left site's lane)
+            // the other side's (at most two) edges come with its record; three there: not for this path
+            const int oa0 = o.y & 0xffff, oa1 = nO > 1 ? (int)((unsigned)o.y >> 16) : 1;
+            const float of0 = __int_as_float(o.z), of1 = nO > 1 ? __int_as_float(o.w) : 0.0f;
+            bool ok = !(on && (s_gen || nO < 1 || nO > 2 || oa0 >= 65535 || oa1 >= 65535));
+#ifdef PG_PIPE_STATS
+            if (__builtin_amdgcn_ballot_w64(on && s_gen) != 0) ++as_why[1];
+            else if (__builtin_amdgcn_ballot_w64(!ok) != 0) ++as_why[2];
+            const bool ok_before_slots = ok;
+            bool ok_recent = true;
+#endif
+            const int nL = on ? (s_left ? s_n : nO) : 1, nR = on ? (s_left ? nO : s_n) : 1;
+            const int dL0 = !on ? 1 : (s_left ? s_a0 : oa0), dL1 = !on ? 1 : (s_left ? s_a1 : oa1), dL2 = (on && s_left) ? s_a2 : 1;
+            const int dR0 = !on ? 1 : (s_left ? oa0 : s_a0), dR1 = !on ? 1 : (s_left ? oa1 : s_a1), dR2 = (on && !s_left) ? s_a2 : 1;
+            const float lw0 = s_left ? s_w0 : of0, lw1 = s_left ? s_w1 : of1, lw2 = s_left ? s_w2 : 0.0f;
+            const float rw0 = s_left ? of0 : s_w0, rw1 = s_left ? of1 : s_w1, rw2 = s_left ? 0.0f : s_w2;
+            q_row = row; q_j = j;
+            {
+                const int ti = ((s_left ? s_state : (o.x & 0xffff)) + (s_left ? (o.x & 0xffff) : s_state) * S) & 255;
+                q_tM = PM.tab2[ti][0]; q_tX = PM.tab2[ti][1];
+            }
+            v_msL = s_left; v_msR = s_left ? !oS : true;
+            // ---- the eight operand slots ----
+            bool any_far = false, v_far[8];
+            int f_age[8], f_p[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { f_age[k] = 0; f_p[k] = 0; v_far[k] = false; v_off[k] = (int)offsetof(PipeSmem, null_cell); }
+            {
+                const int slot = grp ? d2 % PRK : d % PRK;
+                const int null_off = (int)offsetof(PipeSmem, null_cell), ring_off = (int)offsetof(PipeSmem, sc);
+                // one operand: in the ring (all of them where the host says so), or asked of L2 below
+                auto put = [&](int k, bool present, int age, int p_) {
+                    const bool resident = cls1_g || (age < PAGE && ((mask_g >> (age & 31)) & 1u));
+                    int s_ = slot - age;
+                    s_ += s_ < 0 ? PRK : 0;
+                    const int off = ring_off + (s_ * PNT + (p_ & (PNT - 1))) * 24;
+                    v_off[k] = (present && resident) ? off : null_off;
+#ifdef PG_EXP_NOFAR                                                  // timing experiment (wrong results): operands that left the ring read as -inf
+                    const bool far = false;
+#else
+                    const bool far = present && !resident;
+#endif
+                    ok = ok && !(far && age < PAGE);               // a recent diagonal that is not in the ring (after a wide run): not landed yet
+#ifdef PG_PIPE_STATS
+                    ok_recent = ok_recent && !(far && age < PAGE);
+#endif
+                    v_far[k] = far; any_far = any_far || far; f_age[k] = age; f_p[k] = p_;
+                };
+                // gap operands: the (at most two) edges of a side that do not start at the previous site
+                const bool naL0 = dL0 != 1, naL1 = dL1 != 1, naL2 = dL2 != 1;
+                const bool naR0 = dR0 != 1, naR1 = dR1 != 1, naR2 = dR2 != 1;
+                const int cL = (int)naL0 + (int)naL1 + (int)naL2, cR_ = (int)naR0 + (int)naR1 + (int)naR2;
+                if (on && (cL > 2 || cR_ > 2 || nL * nR > 4 || nL < 1 || nR < 1)) ok = false;
+                const int gL0 = naL0 ? dL0 : (naL1 ? dL1 : dL2), gL1 = (naL0 && naL1) ? dL1 : dL2;
+                const int gR0 = naR0 ? dR0 : (naR1 ? dR1 : dR2), gR1 = (naR0 && naR1) ? dR1 : dR2;
+                put(0, on && cL >= 1, gL0, row - gL0);
+                put(2, on && cR_ >= 1, gR0, row);
+                q_gap2 = __builtin_amdgcn_ballot_w64(on && (cL >= 2 || cR_ >= 2)) != 0;
+                if (q_gap2) {
+                    put(1, on && cL >= 2, gL1, row - gL1);
+                    put(3, on && cR_ >= 2, gR1, row);
+                }
+                v_onlyL = cL == nL; v_onlyR = cR_ == nR;            // no edge from the previous site: the staged value IS the state's
+                // pairs, row-major (at most four): t -> (k1, k2)
+                q_pair34 = __builtin_amdgcn_ballot_w64(on && nL * nR > 2) != 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t >= 2 && !q_pair34) break;
+                    const int k1 = nR == 1 ? t : (nR == 2 ? t >> 1 : (t >= 3 ? 1 : 0)), k2 = t - k1 * nR;
+                    const bool present = on && t < nL * nR && k1 < 3;
+                    const int a1 = k1 == 0 ? dL0 : (k1 == 1 ? dL1 : dL2), a2 = k2 == 0 ? dR0 : (k2 == 1 ? dR1 : dR2);
+                    v_lw[t] = (double)(k1 == 0 ? lw0 : (k1 == 1 ? lw1 : lw2));
+                    v_rw[t] = (double)(k2 == 0 ? rw0 : (k2 == 1 ? rw1 : rw2));
+                    put(4 + t, present, a1 + a2, row - a1);
+                }
+                // an edge that starts at site 0 opens a gap for free (BA.h:490-513): left to the general code
+                if (on && ((naL0 && row == dL0) || (naL1 && row == dL1) || (naL2 && row == dL2) ||
+                           (naR0 && j == dR0) || (naR1 && j == dR1) || (naR2 && j == dR2))) ok = false;
+            }
+#ifdef PG_PIPE_STATS
+            if (__builtin_amdgcn_ballot_w64(on && ok_before_slots && !ok_recent) != 0) ++as_why[4];
+            else if (__builtin_amdgcn_ballot_w64(on && ok_before_slots && !ok) != 0) ++as_why[3];
+#endif
+            // a cell this path does not take: the general code stages it when its diagonal is due
+            q_bad = on && !ok;
+            on = on && ok;
+            if (__builtin_amdgcn_ballot_w64(on && any_far) != 0) {
+                // cells that left the ring (>= PAGE diagonals back) have landed once every wave has completed d - PAGE + PLAND
+                // (far_ask looks up the descriptors of the diagonals d - age, age >= PAGE, in the loader's window)
+                const int dl = pair ? d2 : d;
+                if (diags_ld < dl - PAGE + 1) diags_ld = POLL(&PM.loaded[2], dl - PAGE + 1, 5);
+                if (pw0 < dl - PAGE + PLAND) pw0 = POLL(&PM.progress[0], dl - PAGE + PLAND, 9);
+                if (pw1 < dl - PAGE + PLAND) pw1 = POLL(&PM.progress[1], dl - PAGE + PLAND, 9);
+                if (pw2 < dl - PAGE + PLAND) pw2 = POLL(&PM.progress[2], dl - PAGE + PLAND, 9);
+                if (pw3 < dl - PAGE + PLAND) pw3 = POLL(&PM.progress[3], dl - PAGE + PLAND, 9);
+                FarAsk fa[8];
+                pg_d2 fxy[8];
+                double fm_[8];
+                int n_pool = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    fa[k].need = false; fa[k].boff = 0; fxy[k].x = NI_; fxy[k].y = NI_; fm_[k] = NI_;
+                    if (__builtin_amdgcn_ballot_w64(on && v_far[k]) == 0) continue;      // (wave-uniform: nobody's operand k left the ring)
+                    if (on && v_far[k]) fa[k] = far_ask(psc, dg, f_age[k], f_p[k]);      // (need = false outside the band: the slot keeps -inf)
+                    // its place in the pool
+                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(fa[k].need);
+                    if (fa[k].need) {
+                        const int at_ = n_pool + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                        v_off[k] = (int)((const char *)&PM.spm[a][0] - (const char *)&PM) + 24 * at_;
+                    }
+                    n_pool += __builtin_popcountll(mk);
+                }
+#ifdef PG_PIPE_STATS
+                if (n_pool > PFAR_POOL) ++as_why[5];
+#endif
+                if (n_pool > PFAR_POOL) { q_gen[0] = true; q_gen[1] = pair; on = false; q_bad = false; }      // (more far cells than the pool holds)
+                else {
+                    far_fetch8(sc_out, fa, fxy, fm_);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (fa[k].need) {
+                            double *c = (double *)((char *)&PM + v_off[k]);
+                            c[PG_X] = fxy[k].x; c[PG_Y] = fxy[k].y; c[PG_M] = fm_[k];
+                        }
+                }
+            }
+            q_on = on;
+            return;
+        }
+    };
+
+    // one diagonal of the prepared pass: waits until it is due, stages its cells, publishes it
+    auto stage = [&](int g) {
+        const int d = g ? q_d2 : q_d;
+        ASTAMP(0);
+        // every compute wave has completed d-2 (or sleeps through it); a poll that ran into an abort returns "done" and
+        // the wave runs to the end of its list on whatever is in the ring (reads stay inside the arena)
+        if (pw0 < d - 2) pw0 = POLL(&PM.progress[0], d - 2, 9);
+        if (pw1 < d - 2) pw1 = POLL(&PM.progress[1], d - 2, 9);
+        if (pw2 < d - 2) pw2 = POLL(&PM.progress[2], d - 2, 9);
+        if (pw3 < d - 2) pw3 = POLL(&PM.progress[3], d - 2, 9);
+        ASTAMP(1);
+        if (q_gen[g]) {
+            if (q_cls[g] == 2 && diags_ld < d) diags_ld = POLL(&PM.loaded[2], d, 5);
+#ifdef PG_PIPE_STATS
+            ++as_gen;
+#endif
+            assist_general_diag(job, psc, a, lane, reduced_terminal, d, q_cls[g], q_lo[g], q_hi[g], q_mask[g]);
+        } else if (q_on && grp == g) {
+            const char *base = (const char *)&PM;
+            double cx[8], cy[8], cm[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                cx[k] = NI_; cy[k] = NI_; cm[k] = NI_;
+                if (((k == 1 || k == 3) && !q_gap2) || (k >= 6 && !q_pair34)) continue;      // (wave-uniform: no cell of the pass has it)
+                const double *c = (const double *)(base + v_off[k]);
+                cx[k] = c[PG_X]; cy[k] = c[PG_Y]; cm[k] = c[PG_M];
+            }
+            auto gapv = [&](double own, double other, double m_) { return __builtin_fmax(own + ge, __builtin_fmax(other, m_ + ng) + go); };
+            double ex = gapv(cx[0], cy[0], cm[0]), ey = gapv(cy[2], cx[2], cm[2]);
+            if (q_gap2) { ex = __builtin_fmax(ex, gapv(cx[1], cy[1], cm[1])); ey = __builtin_fmax(ey, gapv(cy[3], cx[3], cm[3])); }
+            double em = NI_;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t >= 2 && !q_pair34) break;
+                const double v = (__builtin_fmax(cm[4 + t] + q_tM, __builtin_fmax(cx[4 + t], cy[4 + t]) + q_tX) + v_lw[t]) + v_rw[t];
+                em = __builtin_fmax(em, v);
+            }
+            const int stg = a, at = q_row & (PNT - 1);              // d % PST == d % PNA == a
+            if (v_msL) { PM.sx[stg][at] = ex; PM.spx[stg][at] = v_onlyL ? PS_ONLY : 0u; }
+            if (v_msR) { PM.sy[stg][at] = ey; PM.spy[stg][at] = v_onlyR ? PS_ONLY : 0u; }
+            PM.sM[stg][at] = em;
+        }
+        if (!q_gen[g] && __builtin_amdgcn_ballot_w64(q_bad && grp == g) != 0) {
+            if (q_cls[g] == 2 && diags_ld < d) diags_ld = POLL(&PM.loaded[2], d, 5);
+#ifdef PG_PIPE_STATS
+            ++as_cells;
+#endif
+            assist_general_cells(job, psc, a, lane, reduced_terminal, d, q_cls[g], q_mask[g], q_bad && grp == g, q_row, q_j);
+        }
+        flag_store(&PM.assist_done[a], d);
+#ifdef PG_PIPE_STATS
+        ++as_n;
+#endif
+    };
+
+    prepare();
+    while (q_d >= 0) {
+        if (flag_load(&PM.abort_flag) != 0) break;
+        stage(0);
+        if (q_d2 >= 0) {
+#ifdef PG_PIPE_STATS
+            ++as_pairs;
+#endif
+            stage(1);
+        }
+        prepare();
+    }
+#ifdef PG_PIPE_STATS
+    if (lane == 0 && 3 * (job->Lx + job->Ly) >= 4096) {
+        PG_GLOBAL int *o = (PG_GLOBAL int *)job->trace + 3 * (job->Lx + job->Ly) - 1000 + 16 * a;
+        o[0] = as_n;
+        for (int k = 0; k < 12; ++k) o[1 + k] = (int)(as_t[k] >> 8);
+        o[13] = as_gen; o[14] = as_pairs; o[15] = as_cells;
+        for (int k = 0; k < 6; ++k) o[1 + 2 + k] = as_why[k];     // (in the place of the unused cycle buckets 2..7)
+    }
+#endif
+#undef ASTAMP
+}
+
+// ---- assist waves, large model tables: every multi-edge cell of the class 0..2 diagonals, staged with back-pointer words ----
+template <bool TAB_LDS>
+__device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, bool reduced_terminal) {
+    static_assert(!TAB_LDS, "small tables: pipe_assist_lean");
+    const int nd = job->nd, S = job->S;
+    const gdouble_w sc_out = (gdouble_w)job->sc;
+    const gfloat_p table = (gfloat_p)job->table;
+    const float f_ng = job->ng;
+    const double go = (double)job->go, ge = (double)job->ge, ng = (double)f_ng;
+    const double tng2 = (double)(2 * f_ng), tng1 = (double)(0.0f + f_ng);
+    const int wave = PNW + a;                                      // names this wave in an abort tag
+    int rows_ld = 0, cols_ld = 0, diags_ld = 0;
+    int pw0 = -1, pw1 = -1, pw2 = -1, pw3 = -1;                   // cached progress of the compute waves
+#ifdef PG_PIPE_STATS
+    long long st_poll_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int st_poll_n[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    int *list = PM.as_list[a];
+    const double NI_ = neg_inf();
+    // Software pipeline: everything a diagonal's batch needs that does NOT come out of the ring -- its descriptor, the scan
+    // of the band for multi-edge cells, their site records, edge data and model scores -- is prepared right after the
+    // previous diagonal has been published, while the compute waves are still steps away.  What is left between "the
+    // compute waves have completed d-2" and "d is staged" is the ring reads, the candidates and the staging stores.
+    int q_d = -1, q_cls = 0, q_lo = 0, q_hi = 0, q_n = 0;          // the prepared diagonal (q_d < 0: none)
+    unsigned q_mask = 0;
+    bool q_big = false;                                            // more than 64 multi-edge cells: not prepared, done in batches
+    int q_row = 0, q_j = 0, q_kind = 0;
+    pg_i4 q_rL = {0, 0, 0, 0}, q_cR = {0, 0, 0, 0};
+    double q_tM = 0, q_tX = 0;
+    // the usual batch (class 1, every cell one multi-edge site with at most two edges) decoded down to LDS offsets of its four
+    // operand cells, weights and back-pointer words: what remains for the critical chain is 12 LDS reads and 12 candidates
+    bool q_fast = false, q_left = true;
+    int q_oa0 = 0, q_oa1 = 0, q_ob0 = 0, q_ob1 = 0, q_adjs = -1;
+    unsigned q_e0 = 0, q_e1 = 0;                                   // ADJ flag / slot bits of the two edges in an M back-pointer
+    double q_w0 = 0, q_w1 = 0;
+    // class 2 batches of the usual shape: the operand cells that left the ring, fetched from L2 while the batch is prepared
+    // (off the chain "compute waves completed d-2 -> d is staged": what remains there is the same as for class 1)
+    double q_fx[4] = {0, 0, 0, 0}, q_fy[4] = {0, 0, 0, 0}, q_fm[4] = {0, 0, 0, 0};
+    bool q_far[4] = {false, false, false, false};
+    int scan_d = a;                                                // next diagonal whose descriptor has not been looked at
+
+#ifdef PG_PIPE_STATS
+    long long as_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // cycles: prepare (rest), waiting for the compute waves, compute, publish; inside prepare: scan, batch, decode, far
+    int as_n = 0;
+    // (PG_ASSIST_RUNS_ONLY: only diagonals that directly follow this wave's previous one -- the inside of a class 2 run, where the
+    // assist waves are what the compute waves wait for -- are counted; otherwise the idle time between runs dominates the averages)
+    bool as_on = true;
+    int as_prev = -100;
+#define ASTAMP(k) do { const long long t_ = __builtin_readcyclecounter(); if (as_on) as_t[(k) == 12 ? 0 : (k)] += t_ - as_t0; as_t0 = t_; } while (0)
+    long long as_t0 = __builtin_readcyclecounter();
+#else
+#define ASTAMP(k)
+#endif
+    const AssistGen<TAB_LDS> gen = assist_gen<TAB_LDS>(job, psc, a, lane, reduced_terminal);     // (large tables: the general code, inline)
     // looks for the next diagonal of this wave with work and prepares it
-    pg_i8 q_next = psc[a < nd ? a : 0];                            // descriptor of scan_d, requested a pass ahead (a scalar load that misses costs ~2k cycles)
+    // descriptor of scan_d, requested a pass ahead -- as a VECTOR load (lanes 0..7 one word each): a scalar load shares its
+    // counter with the LDS operations and returns out of order, so the first LDS read behind it would wait for it (~2k cycles)
+    auto desc_req = [&](int dd) { return ((PG_GLOBAL const int *)psc)[8 * (dd < nd ? dd : nd) + (lane & 7)]; };   // (the array carries one entry of padding)
+    int q_next = desc_req(a);
     auto prepare = [&]() {
         q_d = -1;
         while (scan_d < nd) {
             if (flag_load(&PM.abort_flag) != 0) return;
             const int d = scan_d;
-            const pg_i8 cur = q_next;
-            scan_d += PNA * (int)((unsigned)cur.s4 >> 20);          // the host's hop count: straight to this wave's next diagonal with work
-            q_next = psc[scan_d < nd ? scan_d : nd];                // (the array carries one entry of padding)
-            const int cls0 = cur.s4 & 15;
+            const int cur_x = __builtin_amdgcn_readlane(q_next, 0), cur_y = __builtin_amdgcn_readlane(q_next, 1);
+            const int cur_s4 = __builtin_amdgcn_readlane(q_next, 4);
+            scan_d += PNA * (int)((unsigned)cur_s4 >> 20);          // the host's hop count: straight to this wave's next diagonal with work
+            q_next = desc_req(scan_d);
+            const int cls0 = cur_s4 & 15;
             if (!(cls0 == 2 || (!TAB_LDS && cls0 <= 1))) continue;  // small tables: class 1 is the compute waves' own (hot_run)
             // small tables: bit 4 marks a class 2 diagonal whose operands all lie in the ring (class 2 for the shape of a site):
             // the ring-only code paths, as for class 1
-            const int cls = (TAB_LDS && cls0 == 2 && (cur.s4 & 16)) ? 1 : cls0;
-            const int lo = cur.x, hi = cur.y;
+            const int cls = (TAB_LDS && cls0 == 2 && (cur_s4 & 16)) ? 1 : cls0;
+            const int lo = cur_x, hi = cur_y;
             if (rows_ld <= hi) rows_ld = POLL(&PM.loaded[0], hi + 1, 1);
             if (cols_ld <= d - lo) cols_ld = POLL(&PM.loaded[1], d - lo + 1, 2);
-            q_d = d; q_cls = cls; q_lo = lo; q_hi = hi; q_mask = ((unsigned)cur.s4 >> 5) & 0x7fffu;
+            q_d = d; q_cls = cls; q_lo = lo; q_hi = hi; q_mask = ((unsigned)cur_s4 >> 5) & 0x7fffu;
             // large tables: the scan writes the model scores into staging slot d % PST, whose previous user, diagonal
             // d - PST, the compute waves must have completed
             if (!TAB_LDS) {
@@ -1042,131 +1440,15 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
                 if (pw3 < d - PST) pw3 = POLL(&PM.progress[3], d - PST, 9);
             }
             ASTAMP(0);
-            const int n = scan(d, cls, lo, hi, q_mask, false);
+            const int n = gen.scan(d, cls, lo, hi, q_mask, false);
             ASTAMP(4);
             q_big = n > 64;
             q_n = q_big ? 0 : n;
             q_fast = false;
-            q_val = false;
             if (!q_big) {
                 bool on;
-                fetch_batch(d, d % PST, q_n, on, q_row, q_j, q_kind, q_rL, q_cR, q_tM, q_tX);
+                gen.fetch_batch(d, d % PST, q_n, on, q_row, q_j, q_kind, q_rL, q_cR, q_tM, q_tX);
                 ASTAMP(5);
-                if (TAB_LDS && q_n > 0 && __builtin_amdgcn_ballot_w64(on && (q_kind < 1 || q_kind > 3)) == 0) {
-                    bool ok = true, any_far = false;
-                    int f_age[8], f_p[8];
-                    bool v_far[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) { f_age[k] = 0; f_p[k] = 0; v_far[k] = false; v_off[k] = (int)offsetof(PipeSmem, null_cell); }
-                    {
-                        // straight-line, for every lane (the ones without a cell decode zeros and keep the all -inf cell);
-                        // third edges, second gap operands and the third / fourth pair only when some cell has them
-                        const int nL = on ? (q_rL.x >> PR_NE_SHIFT) & 127 : 1, nR = on ? (q_cR.x >> PR_NE_SHIFT) & 127 : 1;
-                        int dL[3] = {1, 1, 1}, dR[3] = {1, 1, 1};
-                        double lwv[3] = {0, 0, 0}, rwv[3] = {0, 0, 0};
-                        edge_at<true>(q_rL, 0, q_row, dL[0], lwv[0]); edge_at<true>(q_rL, 1, q_row, dL[1], lwv[1]);
-                        edge_at<false>(q_cR, 0, q_j, dR[0], rwv[0]); edge_at<false>(q_cR, 1, q_j, dR[1], rwv[1]);
-                        if (!on || nL < 1) dL[0] = 1;
-                        if (!on || nL < 2) dL[1] = 1;
-                        if (!on || nR < 1) dR[0] = 1;
-                        if (!on || nR < 2) dR[1] = 1;
-                        q_three = __builtin_amdgcn_ballot_w64(on && (nL > 2 || nR > 2)) != 0;
-                        if (q_three) {
-                            if (on && nL > 2) edge_at<true>(q_rL, 2, q_row, dL[2], lwv[2]);
-                            if (on && nR > 2) edge_at<false>(q_cR, 2, q_j, dR[2], rwv[2]);
-                        }
-                        v_msL = !(q_rL.x & PR_SIMPLE); v_msR = !(q_cR.x & PR_SIMPLE);
-                        const int slot = d % PRK;
-                        const int null_off = (int)offsetof(PipeSmem, null_cell), ring_off = (int)offsetof(PipeSmem, sc);
-                        // one operand: in the ring (class 1: all of them), or -- class 2 -- asked of L2 below
-                        auto put = [&](int k, bool present, int age, int p_) {
-                            const bool resident = cls == 1 || (age < PAGE && ((q_mask >> (age & 31)) & 1u));
-                            int s_ = slot - age;
-                            s_ += s_ < 0 ? PRK : 0;
-                            const int off = ring_off + (s_ * PNT + (p_ & (PNT - 1))) * 24;
-                            v_off[k] = (present && resident) ? off : null_off;
-                            const bool far = present && !resident;
-                            ok = ok && !(far && age < PAGE);       // a recent diagonal that is not in the ring (after a wide run): not landed yet
-                            v_far[k] = far; any_far = any_far || far; f_age[k] = age; f_p[k] = p_;
-                        };
-                        // gap operands: the (at most two) edges of a side that do not start at the previous site
-                        const bool naL0 = dL[0] != 1, naL1 = dL[1] != 1, naL2 = dL[2] != 1;
-                        const bool naR0 = dR[0] != 1, naR1 = dR[1] != 1, naR2 = dR[2] != 1;
-                        const int cL = (int)naL0 + (int)naL1 + (int)naL2, cR_ = (int)naR0 + (int)naR1 + (int)naR2;
-                        if (on && (cL > 2 || cR_ > 2 || nL * nR > 4 || nL < 1 || nR < 1)) ok = false;
-                        const int gL0 = naL0 ? dL[0] : (naL1 ? dL[1] : dL[2]), gL1 = (naL0 && naL1) ? dL[1] : dL[2];
-                        const int gR0 = naR0 ? dR[0] : (naR1 ? dR[1] : dR[2]), gR1 = (naR0 && naR1) ? dR[1] : dR[2];
-                        put(0, on && cL >= 1, gL0, q_row - gL0);
-                        put(2, on && cR_ >= 1, gR0, q_row);
-                        q_gap2 = __builtin_amdgcn_ballot_w64(on && (cL >= 2 || cR_ >= 2)) != 0;
-                        if (q_gap2) {
-                            put(1, on && cL >= 2, gL1, q_row - gL1);
-                            put(3, on && cR_ >= 2, gR1, q_row);
-                        }
-                        v_onlyL = cL == nL; v_onlyR = cR_ == nR;  // no edge from the previous site: the staged value IS the state's
-                        // pairs, row-major (at most four): t -> (k1, k2)
-                        q_pair34 = __builtin_amdgcn_ballot_w64(on && nL * nR > 2) != 0;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            if (t >= 2 && !q_pair34) break;
-                            const int k1 = nR == 1 ? t : (nR == 2 ? t >> 1 : (t >= 3 ? 1 : 0)), k2 = t - k1 * nR;
-                            const bool present = on && t < nL * nR && k1 < 3;
-                            const int a1 = k1 == 0 ? dL[0] : (k1 == 1 ? dL[1] : dL[2]), a2 = k2 == 0 ? dR[0] : (k2 == 1 ? dR[1] : dR[2]);
-                            v_lw[t] = k1 == 0 ? lwv[0] : (k1 == 1 ? lwv[1] : lwv[2]);
-                            v_rw[t] = k2 == 0 ? rwv[0] : (k2 == 1 ? rwv[1] : rwv[2]);
-                            put(4 + t, present, a1 + a2, q_row - a1);
-                        }
-                        // an edge that starts at site 0 opens a gap for free (BA.h:490-513): left to the general code
-                        if (on && ((naL0 && q_row == dL[0]) || (naL1 && q_row == dL[1]) || (naL2 && q_row == dL[2]) ||
-                                   (naR0 && q_j == dR[0]) || (naR1 && q_j == dR[1]) || (naR2 && q_j == dR[2]))) ok = false;
-                    }
-                    ASTAMP(6);
-                    if (__builtin_amdgcn_ballot_w64(on && !ok) == 0) {
-                        q_val = true;
-                        if (__builtin_amdgcn_ballot_w64(on && any_far) != 0) {
-                            // cells that left the ring (>= PAGE diagonals back) have landed once every wave has completed d - PAGE + PLAND
-                            // (far_ask looks up the descriptors of the diagonals d - age, age >= PAGE, in the loader's window)
-                            if (diags_ld < d - PAGE + 1) diags_ld = POLL(&PM.loaded[2], d - PAGE + 1, 5);
-                            ASTAMP(11);
-                            if (pw0 < d - PAGE + PLAND) pw0 = POLL(&PM.progress[0], d - PAGE + PLAND, 9);
-                            if (pw1 < d - PAGE + PLAND) pw1 = POLL(&PM.progress[1], d - PAGE + PLAND, 9);
-                            if (pw2 < d - PAGE + PLAND) pw2 = POLL(&PM.progress[2], d - PAGE + PLAND, 9);
-                            if (pw3 < d - PAGE + PLAND) pw3 = POLL(&PM.progress[3], d - PAGE + PLAND, 9);
-                            ASTAMP(8);
-                            FarAsk fa[8];
-                            pg_d2 fxy[8];
-                            double fm_[8];
-                            int n_pool = 0;
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) {
-                                fa[k].need = false; fa[k].boff = 0; fxy[k].x = NI_; fxy[k].y = NI_; fm_[k] = NI_;
-                                if (on && v_far[k]) fa[k] = far_ask(psc, d, f_age[k], f_p[k]);   // (need = false outside the band: the slot keeps -inf)
-                                // its place in the pool
-                                const unsigned long long mk = __builtin_amdgcn_ballot_w64(fa[k].need);
-                                if (fa[k].need) {
-                                    const int at_ = n_pool + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                                    v_off[k] = (int)((const char *)&PM.spm[a][0] - (const char *)&PM) + 24 * at_;
-                                }
-                                n_pool += __builtin_popcountll(mk);
-                            }
-                            ASTAMP(9);
-                            if (n_pool > PFAR_POOL) { q_val = false; }       // (more far cells than the pool holds: the general code)
-                            else {
-                                far_fetch8(sc_out, fa, fxy, fm_);
-                                ASTAMP(10);
-#pragma unroll
-                                for (int k = 0; k < 8; ++k)
-                                    if (fa[k].need) {
-                                        double *c = (double *)((char *)&PM + v_off[k]);
-                                        c[PG_X] = fxy[k].x; c[PG_Y] = fxy[k].y; c[PG_M] = fm_[k];
-                                    }
-                            }
-                            ASTAMP(7);
-                        }
-                        if (q_val) return;
-                    }
-                }
-                // (small tables: the eight-slot decoding above replaces this one; what it declined goes to the general code)
                 q_fast = !TAB_LDS && cls == 1 && q_n > 0 && __builtin_amdgcn_ballot_w64(on && q_kind != 1) == 0;
                 if (q_fast) {
                     bool ok = true, any_far = false;
@@ -1239,7 +1521,7 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
     while (q_d >= 0) {
         const int d = q_d;
         if (flag_load(&PM.abort_flag) != 0) break;
-        ASTAMP(0);
+        ASTAMP(12);                                                // (the loop's top: bucket 0)
         // every compute wave has completed d-2 (or sleeps through it); a poll that ran into an abort returns "done" and
         // the wave runs to the end of its list on whatever is in the ring (reads stay inside the arena)
         if (pw0 < d - 2) pw0 = POLL(&PM.progress[0], d - 2, 9);
@@ -1248,34 +1530,7 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
         if (pw3 < d - 2) pw3 = POLL(&PM.progress[3], d - 2, 9);
         if (q_cls == 2 && diags_ld < d) diags_ld = POLL(&PM.loaded[2], d, 5);
         ASTAMP(1);
-        if (q_big) scan(d, q_cls, q_lo, q_hi, q_mask, true);
-        else if (q_val) {
-            if (lane < q_n) {
-                const char *base = (const char *)&PM;
-                double cx[8], cy[8], cm[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    cx[k] = NI_; cy[k] = NI_; cm[k] = NI_;
-                    if (((k == 1 || k == 3) && !q_gap2) || (k >= 6 && !q_pair34)) continue;      // (wave-uniform: no cell of the batch has it)
-                    const double *c = (const double *)(base + v_off[k]);
-                    cx[k] = c[PG_X]; cy[k] = c[PG_Y]; cm[k] = c[PG_M];
-                }
-                auto gapv = [&](double own, double other, double m_) { return __builtin_fmax(own + ge, __builtin_fmax(other, m_ + ng) + go); };
-                double ex = gapv(cx[0], cy[0], cm[0]), ey = gapv(cy[2], cx[2], cm[2]);
-                if (q_gap2) { ex = __builtin_fmax(ex, gapv(cx[1], cy[1], cm[1])); ey = __builtin_fmax(ey, gapv(cy[3], cx[3], cm[3])); }
-                double em = NI_;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (t >= 2 && !q_pair34) break;
-                    const double v = (__builtin_fmax(cm[4 + t] + q_tM, __builtin_fmax(cx[4 + t], cy[4 + t]) + q_tX) + v_lw[t]) + v_rw[t];
-                    em = __builtin_fmax(em, v);
-                }
-                const int stg = a, at = q_row & (PNT - 1);          // d % PST == d % PNA == a
-                if (v_msL) { PM.sx[stg][at] = ex; PM.spx[stg][at] = v_onlyL ? PS_ONLY : 0u; }
-                if (v_msR) { PM.sy[stg][at] = ey; PM.spy[stg][at] = v_onlyR ? PS_ONLY : 0u; }
-                PM.sM[stg][at] = em;
-            }
-        }
+        if (q_big) gen.scan(d, q_cls, q_lo, q_hi, q_mask, true);
         else if (q_fast) {
             if (lane < q_n) {
                 const char *base = (const char *)&PM;
@@ -1306,7 +1561,7 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
                 PM.sM[stg][at] = em; PM.spm[stg][at] = pm;
             }
         }
-        else if (q_n > 0) compute(d, q_cls, q_mask, lane < q_n, q_row, q_j, q_kind, q_rL, q_cR, q_tM, q_tX);
+        else if (q_n > 0) gen.compute(d, q_cls, q_mask, lane < q_n, q_row, q_j, q_kind, q_rL, q_cR, q_tM, q_tX);
         ASTAMP(2);
         flag_store(&PM.assist_done[a], d);
         ASTAMP(3);
@@ -1987,7 +2242,12 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
         return;
     }
     if (tid >= PNT) {
-        pipe_assist<TAB_LDS>(job, psc, __builtin_amdgcn_readfirstlane((tid - PNT) >> 6), lane, !(flags & 2u));
+#ifdef PG_ASSIST_IDLE                                          // timing experiment (wrong results): nothing staged, everything "done"
+        if (lane == 0) flag_store(&PM.assist_done[(tid - PNT) >> 6], 0x7ffffff0);
+        return;
+#endif
+        if constexpr (TAB_LDS) pipe_assist_lean(job, psc, __builtin_amdgcn_readfirstlane((tid - PNT) >> 6), lane, !(flags & 2u));
+        else pipe_assist<false>(job, psc, __builtin_amdgcn_readfirstlane((tid - PNT) >> 6), lane, !(flags & 2u));
         return;
     }
 

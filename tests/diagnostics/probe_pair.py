@@ -60,6 +60,9 @@ if os.environ.get("PG_STAMPS"):
         print("assist %d: %d diagonals; cycles/diagonal: prepare (descriptors, loader) %.0f, wait for compute waves %.0f, compute %.0f, publish %.0f; "
               "inside prepare: scan %.0f, batch %.0f, decode %.0f, far: pool writes %.0f, polls for landed cells %.0f, addresses %.0f, L2 loads %.0f, poll for the descriptor window %.0f" %
               ((a_, n) + tuple(t[:12])))
+        print("assist %d: %d of its diagonals went to the general code whole, %d had cells staged by it; %d passes held two diagonals; passes sent there for: slots %d, a site's shape %d, "
+              "the other side %d, the cell's shape or an edge from site 0 %d, a recent operand off the ring %d, the pool %d" %
+              ((a_, int(b5[16 * a_ + 13]), int(b5[16 * a_ + 15]), int(b5[16 * a_ + 14])) + tuple(int(x) for x in b5[16 * a_ + 3: 16 * a_ + 9])))
 if os.environ.get("PG_STAMPS"):
     b6 = raw[n_int - 1100: n_int - 1092].astype(np.int64)
     print("waves 0-3 compute, 4-6 assist, 7 loader: (wave slot, SIMD, CU) =", [(int(x & 15), int((x >> 4) & 3), int((x >> 8) & 15)) for x in b6])

@@ -9,7 +9,9 @@ for x in "$@"; do
     python - "$x" <<'PY'
 import importlib.util, sys
 spec = importlib.util.spec_from_file_location("_b", "pagan2-msa_amd/build.py"); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
-print(m.build(force=True, out=m.HERE + "/libpagan_dp_exp_%s.so" % sys.argv[1]))
+import os
+m.FLAGS += os.environ.get("PG_EXP_DEFS", "").split()     # e.g. PG_EXP_DEFS=-DPG_ASSIST_IDLE (assist waves return at once: only with variants that wait for none)
+print(m.build(force=True, out=m.HERE + "/libpagan_dp_exp_%s%s.so" % (sys.argv[1], os.environ.get("PG_EXP_TAG", ""))))
 PY
 done
 python tools/gen_hot_asm.py

@@ -226,11 +226,19 @@ def class2(E, k):
     a("v_readfirstlane_b32 s68, v223")
     a("s_cmp_lt_i32 s68, %[d]")
     a("s_cbranch_scc0 .Lpg_c2ok%s" % sfx)
-    a("s_sleep 1")                                              # the assist wave is, as a rule, nearly there
+    # not staged yet: watch the flag alone (one broadcast read per look: the six reads above, repeated by every waiting
+    # wave, take LDS cycles from the assist waves everybody is waiting for), then read the batch again
+    a(".Lpg_c2spin%s:" % sfx)
+    a("s_sleep 1")
     a("s_sub_i32 s72, s72, 1")
-    a("s_cmp_lg_u32 s72, 0")
-    a("s_cbranch_scc1 .Lpg_c2read%s" % sfx)
-    a("s_branch .Lpg_exit%s" % sfx)                             # nothing of this step is committed: the caller's poll takes over
+    a("s_cmp_eq_u32 s72, 0")
+    a("s_cbranch_scc1 .Lpg_exit%s" % sfx)                      # nothing of this step is committed: the caller's poll takes over
+    a("ds_read_b32 v223, v217")
+    a("s_waitcnt lgkmcnt(0)")
+    a("v_readfirstlane_b32 s68, v223")
+    a("s_cmp_lt_i32 s68, %[d]")
+    a("s_cbranch_scc1 .Lpg_c2spin%s" % sfx)
+    a("s_branch .Lpg_c2read%s" % sfx)
     a(".Lpg_c2ok%s:" % sfx)
     a("v_and_b32_e32 v217, 0x10000, v%d" % RL)
     a("v_and_b32_e32 v218, 0x10000, v%d" % CR)
@@ -357,20 +365,23 @@ def step(E, k):
     if "k" in EXP:
         a("s_add_u32 %[k1], %[k1], 1")
     a("s_sleep 8" if "z" in EXP else "s_sleep 1")
-    a("ds_read_b32 v223, %[fup]")
-    a("ds_read2_b64 v[%d:%d], v217 offset1:1" % (A[0], A[0] + 3))
-    a("ds_read_b64 %s, v217 offset:16" % pr(A[2]))
+    a("ds_read_b32 v223, %[fup]")                              # the flag alone (a broadcast read), the operand once it is there
     a("s_waitcnt lgkmcnt(0)")
     a("v_readfirstlane_b32 s68, v223")
     a("s_max_i32 %[pup], %[pup], s68")
     a("s_cmp_lt_i32 %[pup], s69")
-    a("s_cbranch_scc0 .Lpg_upok%s" % sfx)
+    a("s_cbranch_scc0 .Lpg_upgot%s" % sfx)
     a("s_sub_i32 s72, s72, 1")
     a("s_cmp_lg_u32 s72, 0")
     a("s_cbranch_scc1 .Lpg_upretry%s" % sfx)
     if "k" in EXP:
         a("s_add_u32 %[k0], %[k0], 0x10000")
     a("s_branch .Lpg_exit%s" % sfx)
+    a(".Lpg_upgot%s:" % sfx)
+    a("ds_read2_b64 v[%d:%d], v217 offset1:1" % (A[0], A[0] + 3))
+    a("ds_read_b64 %s, v217 offset:16" % pr(A[2]))
+    a("s_waitcnt lgkmcnt(0)")
+    a("s_branch .Lpg_upok%s" % sfx)
     E.cur = E.L
     # row hand-over
     a("v_cmp_gt_i32_e32 vcc, s%d, %%[row]" % lo)
