@@ -1023,7 +1023,6 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
     const gdouble_w sc_out = (gdouble_w)job->sc;
     const double go = (double)job->go, ge = (double)job->ge, ng = (double)job->ng;
     const int wave = PNW + a;                                      // names this wave in an abort tag
-    const int grp = lane >> 5;                                     // which diagonal of the pair this lane works on
     int rows_ld = 0, cols_ld = 0, diags_ld = 0;
     int pw0 = -1, pw1 = -1, pw2 = -1, pw3 = -1;                   // cached progress of the compute waves
 #ifdef PG_PIPE_STATS
@@ -1050,6 +1049,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
     int q_d = -1, q_d2 = -1, q_cls[2] = {0, 0}, q_lo[2] = {0, 0}, q_hi[2] = {0, 0};
     unsigned q_mask[2] = {0, 0};
     bool q_gen[2] = {false, false};                                // the diagonal goes to the general code
+    int grp = 0;                                                   // which diagonal of the pass this lane works on (two diagonals: lane >> 5)
     bool q_on = false, q_bad = false;                              // this lane holds a cell / one that the general code has to stage
     int q_j = 0;
     bool q_gap2 = false, q_pair34 = false;                         // wave-uniform: some cell has a second gap operand / more than two pairs
@@ -1058,7 +1058,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
     double q_tM = 0, q_tX = 0, v_lw[4] = {0, 0, 0, 0}, v_rw[4] = {0, 0, 0, 0};
     int scan_d = a;                                                // next diagonal whose descriptor has not been looked at
 
-    // the sites first..last of one side have entered the band: the multi-edge ones among them into free slots (both halves alike)
+    // the sites first..last of one side have entered the band: the multi-edge ones among them into free slots
     auto take_sites = [&](bool left, int first, int last) -> bool {
         for (int base = first; base <= last; base += 64) {
             const int s_ = base + lane;
@@ -1067,11 +1067,11 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(multi);
             if (mask == 0) continue;
             const int cnt = __builtin_popcountll(mask);
-            const unsigned fmask = (unsigned)__builtin_amdgcn_ballot_w64(s_site < 0);        // (the lower half's view: the halves agree)
-            if (cnt > __builtin_popcount(fmask)) return false;
+            const unsigned long long fmask = __builtin_amdgcn_ballot_w64(s_site < 0);
+            if (cnt > __builtin_popcountll(fmask)) return false;
             if (multi) list[(int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = s_;
             if (s_site < 0) {
-                const int r = __builtin_popcount(fmask & ((1u << (lane & 31)) - 1u));
+                const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask, 0u));
                 if (r < cnt) {
                     const int site = list[r];
                     const pg_i4 rec = (left ? PM.recL : PM.recR)[site & (PRW - 1)];
@@ -1110,15 +1110,13 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
             const int bx = __builtin_amdgcn_readlane(q_next, 8), by = __builtin_amdgcn_readlane(q_next, 9), bs4 = __builtin_amdgcn_readlane(q_next, 12);
             const int hop_a = (int)((unsigned)as4 >> 20);           // the host's hop count: straight to this wave's next diagonal with work
             if ((as4 & 15) != 2) { scan_d += PNA * hop_a; q_next = desc_req(scan_d); continue; }      // (class 0 / 1: the compute waves' own)
-            const bool pair = hop_a == 1 && d2 < nd && (bs4 & 15) == 2;
-            scan_d = pair ? d2 + PNA * (int)((unsigned)bs4 >> 20) : d + PNA * hop_a;
-            q_next = desc_req(scan_d);
+            const bool pair_d = hop_a == 1 && d2 < nd && (bs4 & 15) == 2;               // the descriptors allow two diagonals
             // bit 4 marks a class 2 diagonal whose operands all lie in the ring (class 2 for the shape of a site): no residency test
             q_d = d; q_cls[0] = (as4 & 16) ? 1 : 2; q_lo[0] = ax; q_hi[0] = ay; q_mask[0] = ((unsigned)as4 >> 5) & 0x7fffu;
-            q_d2 = pair ? d2 : -1; q_cls[1] = (bs4 & 16) ? 1 : 2; q_lo[1] = bx; q_hi[1] = by; q_mask[1] = ((unsigned)bs4 >> 5) & 0x7fffu;
+            q_d2 = -1; q_cls[1] = (bs4 & 16) ? 1 : 2; q_lo[1] = bx; q_hi[1] = by; q_mask[1] = ((unsigned)bs4 >> 5) & 0x7fffu;
             q_gen[0] = false; q_gen[1] = false; q_on = false; q_bad = false;
             const int lo_a = ax, cmin_a = d - ay;
-            const int hi_t = pair ? by : ay, cmax_t = pair ? d2 - bx : d - ax;          // the later diagonal's upper ends
+            const int hi_t = pair_d ? by : ay, cmax_t = pair_d ? d2 - bx : d - ax;      // the later diagonal's upper ends
             if (rows_ld <= hi_t) rows_ld = POLL(&PM.loaded[0], hi_t + 1, 1);
             if (cols_ld <= cmax_t) cols_ld = POLL(&PM.loaded[1], cmax_t + 1, 2);
             // ---- the slots ----
@@ -1126,46 +1124,75 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
             if (s_site >= 0 && s_site < (s_left ? lo_a : cmin_a)) s_site = -1;          // the band has left this row / column behind
             if (!take_sites(true, seen_row > lo_a ? seen_row : lo_a, hi_t) || !take_sites(false, seen_col > cmin_a ? seen_col : cmin_a, cmax_t)) {
                 trk_valid = false;
-                q_gen[0] = true; q_gen[1] = pair;
+                q_gen[0] = true;
+                scan_d = d + PNA * hop_a; q_next = desc_req(scan_d);
 #ifdef PG_PIPE_STATS
                 ++as_why[0];
 #endif
                 return;
             }
             seen_row = hi_t + 1; seen_col = cmax_t + 1;
+            // two diagonals if the band's sites fit one half of the wave: the halves then look at the same sites (a lane's view e_*
+            // of the slot with its rank), each on its own diagonal; otherwise every lane its own slot, on d
+            const unsigned long long amask = __builtin_amdgcn_ballot_w64(s_site >= 0);
+            const int n_act = __builtin_popcountll(amask);
+            const bool pair = pair_d && n_act <= 32;
+            scan_d = pair ? d2 + PNA * (int)((unsigned)bs4 >> 20) : d + PNA * hop_a;
+            q_next = desc_req(scan_d);
+            q_d2 = pair ? d2 : -1;
+            int e_site = s_site, e_a0 = s_a0, e_a1 = s_a1, e_a2 = s_a2, e_n = s_n, e_state = s_state;
+            bool e_left = s_left, e_gen = s_gen;
+            float e_w0 = s_w0, e_w1 = s_w1, e_w2 = s_w2;
+            grp = 0;
+            if (pair) {
+                grp = lane >> 5;
+                if (s_site >= 0) list[(int)__builtin_amdgcn_mbcnt_hi((unsigned)(amask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)amask, 0u))] = lane;
+                const int idx = lane & 31;
+                const bool have = idx < n_act;
+                const int src4 = 4 * (have ? list[idx] : lane);
+                const int pk = (int)s_left | ((int)s_gen << 1) | (s_n << 2) | (s_state << 9);
+                const int pk_ = __builtin_amdgcn_ds_bpermute(src4, pk);
+                const int site_ = __builtin_amdgcn_ds_bpermute(src4, s_site);      // (every lane takes part: a lane that is off cannot be read from)
+                e_site = have ? site_ : -1;
+                e_left = pk_ & 1; e_gen = (pk_ >> 1) & 1; e_n = (pk_ >> 2) & 127; e_state = (pk_ >> 9) & 0xffff;
+                e_a0 = __builtin_amdgcn_ds_bpermute(src4, s_a0); e_a1 = __builtin_amdgcn_ds_bpermute(src4, s_a1); e_a2 = __builtin_amdgcn_ds_bpermute(src4, s_a2);
+                e_w0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(s_w0)));
+                e_w1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(s_w1)));
+                e_w2 = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(s_w2)));
+            }
             // ---- this lane's cell: (site, dg - site) or (dg - site, site) ----
             const int dg = grp ? d2 : d, lo_g = grp ? bx : ax, hi_g = grp ? by : ay;
             const bool cls1_g = (grp ? q_cls[1] : q_cls[0]) == 1;
             const unsigned mask_g = grp ? q_mask[1] : q_mask[0];
-            const bool act = s_site >= 0 && (grp == 0 || pair);
-            const int row = act ? (s_left ? s_site : dg - s_site) : 0, j = act ? dg - row : 0;
+            const bool act = e_site >= 0;
+            const int row = act ? (e_left ? e_site : dg - e_site) : 0, j = act ? dg - row : 0;
             const bool inb = act && row >= lo_g && row <= hi_g;
             pg_i4 o = {PR_SIMPLE | (1 << PR_NE_SHIFT), 1, 0, 0};
-            if (inb) o = s_left ? PM.recR[j & (PRW - 1)] : PM.recL[row & (PRW - 1)];
+            if (inb) o = e_left ? PM.recR[j & (PRW - 1)] : PM.recL[row & (PRW - 1)];
             const bool oS = o.x & PR_SIMPLE;
             const int nO = (o.x >> PR_NE_SHIFT) & 127;
-            bool on = inb && (s_left || oS);                       // (both sites multi-edge: the left site's lane)
+            bool on = inb && (e_left || oS);                       // (both sites multi-edge: the left site's lane)
             // the other side's (at most two) edges come with its record; three there: not for this path
             const int oa0 = o.y & 0xffff, oa1 = nO > 1 ? (int)((unsigned)o.y >> 16) : 1;
             const float of0 = __int_as_float(o.z), of1 = nO > 1 ? __int_as_float(o.w) : 0.0f;
-            bool ok = !(on && (s_gen || nO < 1 || nO > 2 || oa0 >= 65535 || oa1 >= 65535));
+            bool ok = !(on && (e_gen || nO < 1 || nO > 2 || oa0 >= 65535 || oa1 >= 65535));
 #ifdef PG_PIPE_STATS
-            if (__builtin_amdgcn_ballot_w64(on && s_gen) != 0) ++as_why[1];
+            if (__builtin_amdgcn_ballot_w64(on && e_gen) != 0) ++as_why[1];
             else if (__builtin_amdgcn_ballot_w64(!ok) != 0) ++as_why[2];
             const bool ok_before_slots = ok;
             bool ok_recent = true;
 #endif
-            const int nL = on ? (s_left ? s_n : nO) : 1, nR = on ? (s_left ? nO : s_n) : 1;
-            const int dL0 = !on ? 1 : (s_left ? s_a0 : oa0), dL1 = !on ? 1 : (s_left ? s_a1 : oa1), dL2 = (on && s_left) ? s_a2 : 1;
-            const int dR0 = !on ? 1 : (s_left ? oa0 : s_a0), dR1 = !on ? 1 : (s_left ? oa1 : s_a1), dR2 = (on && !s_left) ? s_a2 : 1;
-            const float lw0 = s_left ? s_w0 : of0, lw1 = s_left ? s_w1 : of1, lw2 = s_left ? s_w2 : 0.0f;
-            const float rw0 = s_left ? of0 : s_w0, rw1 = s_left ? of1 : s_w1, rw2 = s_left ? 0.0f : s_w2;
+            const int nL = on ? (e_left ? e_n : nO) : 1, nR = on ? (e_left ? nO : e_n) : 1;
+            const int dL0 = !on ? 1 : (e_left ? e_a0 : oa0), dL1 = !on ? 1 : (e_left ? e_a1 : oa1), dL2 = (on && e_left) ? e_a2 : 1;
+            const int dR0 = !on ? 1 : (e_left ? oa0 : e_a0), dR1 = !on ? 1 : (e_left ? oa1 : e_a1), dR2 = (on && !e_left) ? e_a2 : 1;
+            const float lw0 = e_left ? e_w0 : of0, lw1 = e_left ? e_w1 : of1, lw2 = e_left ? e_w2 : 0.0f;
+            const float rw0 = e_left ? of0 : e_w0, rw1 = e_left ? of1 : e_w1, rw2 = e_left ? 0.0f : e_w2;
             q_row = row; q_j = j;
             {
-                const int ti = ((s_left ? s_state : (o.x & 0xffff)) + (s_left ? (o.x & 0xffff) : s_state) * S) & 255;
+                const int ti = ((e_left ? e_state : (o.x & 0xffff)) + (e_left ? (o.x & 0xffff) : e_state) * S) & 255;
                 q_tM = PM.tab2[ti][0]; q_tX = PM.tab2[ti][1];
             }
-            v_msL = s_left; v_msR = s_left ? !oS : true;
+            v_msL = e_left; v_msR = e_left ? !oS : true;
             // ---- the eight operand slots ----
             bool any_far = false, v_far[8];
             int f_age[8], f_p[8];
