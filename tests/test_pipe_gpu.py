@@ -131,3 +131,18 @@ def test_backpointer_pass_under_the_option_bits(pg, oracle, monkeypatch, flags):
             same(b.fetch()[0], oracle.dp_align(*job, flags=flags))
         b.close()
     assert np.array_equal(words["fill"], words["pass"])
+
+
+@pytest.mark.parametrize("seed", [0, 2])
+def test_a_codon_sized_table_on_the_banded_kernel(pg, oracle, seed):
+    """1892 states -- the size of the reference's codon alphabet (61 codons, NNN, 1830 codon pairs;
+    model_factory.cpp:839-897) -- i.e. a 14 MB score table that stays in HBM / L2: the banded kernel's large-table path
+    (model scores gathered per diagonal by the assist waves), class 0..4 diagonals included."""
+    S = 1892
+    left, right, _, band = banded_job(seed, max_span=40 if seed < 2 else 8)
+    rng = np.random.default_rng(100 + seed)
+    left.state[1:-1] = rng.integers(0, S, left.n_sites - 2)
+    right.state[1:-1] = rng.integers(0, S, right.n_sites - 2)
+    model = synth.random_model(S, seed)
+    assert pg.debug_route(left, right, model, band)[0] == "pg_fill_pipe (large table)"
+    same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band), "seed %d" % seed)

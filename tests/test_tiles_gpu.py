@@ -225,3 +225,13 @@ def test_dead_sites_at_the_matrix_edges(pg, oracle, seed):
     model = synth.random_model(15, 31 + seed)
     for flags in (0, abi.OPT_NO_TERMINAL_EDGES, abi.OPT_NO_REDUCED_TERMINAL_PEN):
         same(pg.align(left2, right2, model, flags=flags), oracle.dp_align(left2, right2, model, flags=flags), "seed %d flags %d" % (seed, flags))
+
+
+def test_a_codon_sized_table_on_the_tiled_kernel(pg, oracle):
+    """1892 states (the codon alphabet's size, model_factory.cpp:839-897): a tile stages the 64 x 64 scores of its state pairs
+    out of a 14 MB table."""
+    S = 1892
+    left, right = synth.random_graph(300, S, 5, p_extra=0.2, max_span=12), synth.random_graph(280, S, 6, p_extra=0.2, max_span=12)
+    model = synth.random_model(S, 3)
+    assert pg.debug_route(left, right, model, None)[0] == "pg_fill_tiles_flow"
+    same(pg.align(left, right, model), oracle.dp_align(left, right, model), "codon-sized table")
