@@ -1773,6 +1773,9 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                     if (slot < cap) {
                         PG_GLOBAL int *o = tb + r0 + 16 + 4 * (slot * 4 + wave);
                         o[0] = d_in; o[1] = __builtin_amdgcn_readfirstlane(d) | ((k0 >> 16) ? 0x40000000 : 0); o[2] = (int)(st_t_in >> 4); o[3] = (int)(st_t_out >> 4);
+#ifdef PG_RUN_LOOKS                                                // (diagnostic: looks at the upstream flag / waits for the downstream wave in the place of the clocks' low bits)
+                        o[2] = (int)((st_t_out - st_t_in) >> 4); o[3] = k1 | ((k2 & 0xffff) << 20);
+#endif
                     }
                 }
             }
@@ -1799,6 +1802,8 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                 const int lo = cur.x, hi = cur.y;
                 if (d > ok_until) {
                     int need = hi + 3 < Lx - 1 ? hi + 3 : Lx - 1;
+                    // (the loader's progress read afresh: a margin worked out from a stale value shrinks by half from one look to the next)
+                    rows_ld = flag_load(&PM.loaded[0]); cols_ld = flag_load(&PM.loaded[1]);
                     if (rows_ld <= need) rows_ld = POLLX(&PM.loaded[0], need + 1, 1);
                     int margin = rows_ld >= Lx ? nd : rows_ld - 1 - need;
                     need = d + 2 - lo < Ly - 1 ? d + 2 - lo : Ly - 1;
@@ -1828,6 +1833,8 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
         // ---- flow control: flags are read only when the cached values stop covering this step (see step()) ----
         if (d > ok_until) {
             int need = hi + 3 < Lx - 1 ? hi + 3 : Lx - 1;
+            // (the loader's progress read afresh: a margin worked out from a stale value shrinks by half from one look to the next)
+            rows_ld = flag_load(&PM.loaded[0]); cols_ld = flag_load(&PM.loaded[1]);
             if (rows_ld <= need) rows_ld = POLLX(&PM.loaded[0], need + 1, 1);
             int margin = rows_ld >= Lx ? nd : rows_ld - 1 - need;
             need = d + 2 - lo < Ly - 1 ? d + 2 - lo : Ly - 1;
@@ -2402,6 +2409,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
             // ---- flow control: flags are read only when the cached values stop covering this step ----
             if (d > ok_until) {
                 int need = hi + 3 < Lx - 1 ? hi + 3 : Lx - 1;
+                rows_ld = flag_load(&PM.loaded[0]); cols_ld = flag_load(&PM.loaded[1]);      // (afresh: see hot_run)
                 if (rows_ld <= need) rows_ld = POLL(&PM.loaded[0], need + 1, 1);
                 int margin = rows_ld >= Lx ? nd : rows_ld - 1 - need;
                 need = d + 2 - lo < Ly - 1 ? d + 2 - lo : Ly - 1;
