@@ -1709,7 +1709,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
     int ti0 = ((rLc.x & 0xffff) + __umul24(cR0.x & 0xffff, S)) & 255;
     double tMc = PM.tab2[ti0][0], tXc = PM.tab2[ti0][1];
     const int tid24 = tid * 24, bpos24 = bslot * 24;
-    const int null_off = (int)offsetof(PipeSmem, null_cell);
+    const int null_off = (int)offsetof(PipeSmem, null_cell) - (int)offsetof(PipeSmem, sc);      // (ring_cell's offsets count from the ring's first byte)
     // LDS addresses the class 0 loop below works with
     typedef __attribute__((address_space(3))) char lds_char;
     const unsigned lds_ring = (unsigned)(unsigned long long)(lds_char *)&PM.sc[0][0][0];
@@ -2110,7 +2110,7 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             auto rd = [&](bool need, int age, int p_, pg_d2 &xy, double &m) {
                 int rb = wsb - age * PWROW_BYTES;
                 rb += rb < 0 ? PWK * PWROW_BYTES : 0;
-                const int off = need ? rb + (p_ & (PWPOS - 1)) * 24 : (int)offsetof(PipeSmem, null_cell);
+                const int off = need ? rb + (p_ & (PWPOS - 1)) * 24 : (int)offsetof(PipeSmem, null_cell) - (int)offsetof(PipeSmem, sc);
                 const double *c = (const double *)((const char *)&PM.sc[0][0][0] + off);
                 xy.x = c[PG_X]; xy.y = c[PG_Y]; m = c[PG_M];
             };

@@ -26,7 +26,7 @@ Register plan (fixed registers are in the asm statement's clobber list; operands
   class 1: v[236:239] / v[240:243] the row's / column's site record, v244/v245 kL/kR, v[246:253] the four edge weights,
            v254 the left other-edge's ring column, v[140:157] W1 W2 W3, v[160:171] U V operand cells, v[172:179] temporaries
   s[36:43] / s[44:51]  descriptor of this diagonal / of the next one (roles swap)
-  s[52:59] scratch masks, s[60:61] in-band lanes, s[62:63] saved exec, s[64:65] store base, s66 the previous ring row,
+  s[52:59] scratch masks, s[60:61] in-band lanes, s[62:63] saved exec, s[64:65] store base, s66 / %[sb] the previous and this diagonal's ring rows (they swap from half to half),
   s68/s69/s72/s73 scratch, s[70:71] descriptor pointer, s[74:75] l2, s[76:77] r2, s[78:79] lS, s[80:81] rS, s[82:83] l2 & r2,
   s[84:87] scratch masks
 Hazards observed by construction (the assembler inserts nothing): two wait states between a VALU compare and the VALU
@@ -63,6 +63,7 @@ class Emit:
         self.L = []
         self.ool = []          # out-of-line blocks, emitted behind the loop
         self.cur = self.L
+        self.cursb = "%[sb]"   # the SGPR that holds this diagonal's ring row (byte offset); "%[sb]" and s66 swap roles from half to half
 
     def a(self, s):
         self.cur.append(s)
@@ -71,7 +72,7 @@ class Emit:
         """dst = LDS address of the ring cell `age_bytes` (VGPR: age * 0x1800) back from this diagonal's row in ring column
         `col` (VGPR: absolute LDS address of the column in ring row 0), or the all -inf null cell where `present` is off"""
         a = self.a
-        a("v_sub_u32_e32 v%d, %%[sb], v%d" % (dst, age_bytes))
+        a("v_sub_u32_e32 v%d, %s, v%d" % (dst, self.cursb, age_bytes))
         a("v_add_u32_e32 v223, 0x16800, v%d" % dst)
         a("v_min_u32_e32 v%d, v%d, v223" % (dst, dst))
         a("v_add_u32_e32 v%d, v%d, %s" % (dst, dst, col))
@@ -268,9 +269,11 @@ def step(E, k):
     tmx, tmn = TMX[k], TMX[1 - k]
     lo, hi, zlo, zhi, s4, s7 = cur, cur + 1, cur + 2, cur + 3, cur + 4, cur + 7
     sfx = "%d_%%=" % k
+    cursb, prevsb = ("%[sb]", "s66") if k == 0 else ("s66", "%[sb]")
+    E.cursb = cursb
     a("; ---- diagonal, half %d ----" % k)
     # LDS batch: upstream flag, lane 0's operand, the column record two steps ahead, next step's match terms, the row record
-    a("v_add_u32_e32 v217, s66, %[bpos24]")                    # ring row of d-1
+    a("v_add_u32_e32 v217, %s, %%[bpos24]" % prevsb)           # ring row of d-1
     if "A" in EXP:
         a("s_mov_b64 exec, 1")                                   # only lane 0 keeps what it reads here (the shift overwrites the others)
     a("ds_read_b32 v223, %[fup]")
@@ -397,7 +400,7 @@ def step(E, k):
         for q in range(0, 8, 2):
             a("s_mov_b64 s[%d:%d], s[%d:%d]" % (nxt + q, nxt + q + 1, cur + q, cur + q + 1))
     else:
-        a("s_load_dwordx8 s[%d:%d], s[70:71], 0x20" % (nxt, nxt + 7))
+        a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
     a(".Lpg_shift%s:" % sfx)
     E.cur = E.ool
     a(".Lpg_recs%s:" % sfx)
@@ -434,11 +437,11 @@ def step(E, k):
     a("s_cmp_eq_u32 s73, 2")
     a("s_cbranch_scc1 .Lpg_c2%s" % sfx)
     class1(E, k)
-    a("s_load_dwordx8 s[%d:%d], s[70:71], 0x20" % (nxt, nxt + 7))
+    a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
     a("s_branch .Lpg_commit%s" % sfx)
     a(".Lpg_c2%s:" % sfx)
     class2(E, k)
-    a("s_load_dwordx8 s[%d:%d], s[70:71], 0x20" % (nxt, nxt + 7))
+    a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
     a("s_branch .Lpg_commit%s" % sfx)
     E.cur = E.L
     # results: -inf outside the band
@@ -446,7 +449,7 @@ def step(E, k):
     a("v_min_f64 %s, %s, %s" % (pr(P[0]), pr(BX), pr(LIM)))
     a("v_min_f64 %s, %s, %s" % (pr(P[1]), pr(BY), pr(LIM)))
     a("v_min_f64 %s, %s, %s" % (pr(P[2]), pr(BM), pr(LIM)))
-    a("v_add_u32_e32 v219, %[sb], %[tid24]")
+    a("v_add_u32_e32 v219, %s, %%[tid24]" % cursb)
     a("v_mul_u32_u24_e32 v218, 24, v217")
     a("v_mov_b32_e32 v220, %[d]")
     if "R" in EXP or "Q" in EXP:   # timing experiments: ring writes by the in-band lanes only (R) / by lane 63 only (Q)
@@ -471,12 +474,12 @@ def step(E, k):
     a("ds_write_b32 %[fme], v220")                             # progress: after the ring writes (a wave's LDS operations execute in order)
     # next diagonal
     a("s_add_i32 %[d], %[d], 1")
-    a("s_mov_b32 s66, %[sb]")
-    a("s_add_i32 %[sb], %[sb], 0x1800")
-    a("s_cmp_eq_u32 %[sb], 0x16800")
-    a("s_cselect_b32 %[sb], 0, %[sb]")
-    a("s_add_u32 s70, s70, 0x20")
-    a("s_addc_u32 s71, s71, 0")
+    a("s_add_i32 %s, %s, 0x1800" % (prevsb, cursb))            # the next diagonal's ring row, into the register that held the previous one's
+    a("s_cmp_eq_u32 %s, 0x16800" % prevsb)
+    a("s_cselect_b32 %s, 0, %s" % (prevsb, prevsb))
+    if k == 1:                                                  # the descriptor pointer moves once per pair (half 0 reads at +0x20, half 1 at +0x40)
+        a("s_add_u32 s70, s70, 0x40")
+        a("s_addc_u32 s71, s71, 0")
 
 
 def main():
@@ -510,6 +513,7 @@ def main():
         a("v_mov_b64_e32 %%[c%d], %s" % (c, pr(Q[1][c])))
     a("s_branch .Lpg_done_%=")
     a(".Lpg_exit1_%=:")
+    a("s_mov_b32 %[sb], s66")                                  # (half 1's ring row)
     for c in range(3):
         a("v_mov_b64_e32 %%[c%d], %s" % (c, pr(Q[0][c])))
     a(".Lpg_done_%=:")
