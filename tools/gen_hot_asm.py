@@ -23,8 +23,9 @@ Register plan (fixed registers are in the asm statement's clobber list; operands
   v[188:191] / v[192:195]  tM, tX of this step / of the next one (roles swap)
   v[196:207] temporaries of the base step; v[208:213] BX BY BM; v[214:215] the band limit (+inf inside, -inf outside)
   v217..v223 addresses and scratch
-  class 1: v[236:239] / v[240:243] the row's / column's site record, v244/v245 kL/kR, v[246:253] the four edge weights,
-           v254 the left other-edge's ring column, v[140:157] W1 W2 W3, v[160:171] U V operand cells, v[172:179] temporaries
+  class 1: v[236:239] / v[240:243] (half 0) and v[136:139] / v[244:247] (half 1) the row's / column's site record, v158/v159
+           kL/kR, v[186:187] v[248:253] the four edge weights, v216 the left other-edge's ring column, v[140:157] W1 W2 W3,
+           v[160:171] U V operand cells, v[172:179] temporaries; s67 the diagonal whose records a class 1 step has read ahead
   s[36:43] / s[44:51]  descriptor of this diagonal / of the next one (roles swap)
   s[52:59] scratch masks, s[60:61] in-band lanes, s[62:63] saved exec, s[64:65] store base, s66 / %[sb] the previous and this diagonal's ring rows (they swap from half to half),
   s68/s69/s72/s73 scratch, s[70:71] descriptor pointer, s[74:75] l2, s[76:77] r2, s[78:79] lS, s[80:81] rS, s[82:83] l2 & r2,
@@ -47,10 +48,11 @@ W2 = (146, 148, 150)
 W3 = (152, 154, 156)
 U = (160, 162, 164)
 V = (166, 168, 170)
-RL, CR = 236, 240                        # site records: x, y, z, w
-KL, KR = 244, 245
-LWA, LWS, RWA, RWS = 246, 248, 250, 252
-POSL = 254
+RLK, CRK = (236, 136), (240, 244)        # site records (x, y, z, w) of this step's cell: one set per half of the unrolled pair --
+                                         # a class 1 step reads the NEXT step's records into the other half's set
+KL, KR = 158, 159
+LWA, LWS, RWA, RWS = 186, 248, 250, 252
+POSL = 216
 T = [172, 174, 176, 178, 196, 198, 200, 202, 204, 206]     # temporary pairs of the class 1 / 2 parts
 
 
@@ -105,23 +107,39 @@ class Emit:
 EXP = os.environ.get("PG_HOT_EXP", "")
 
 
-def class1(E, k):
-    """The multi-edge part of a class 1 step (dp_pipe.hip, hot_run): entered with the base values done (BX, BY from the
-    previous-site edges; BM from the pair of the two previous-site edges, without their weights), leaves BX / BY / BM
-    final.  "Easy" sites only (the host sends every other shape to the assist waves as class 2): the edge from the previous
-    site alone (with a weight) or beside ONE other edge, every operand in the ring."""
+def c1_test(E, k, wait):
+    """Does this wave hold a multi-edge cell of the diagonal?  Branches to .Lpg_c1done (nothing to do) if not."""
     a = E.a
-    tmx = TMX[k]
+    RL, CR = RLK[k], CRK[k]
     sfx = "%d_%%=" % k
     a("; ---- class 1: this wave's own multi-edge cells ----")
-    a("s_waitcnt lgkmcnt(0)")                                   # the two site records
+    if wait:
+        a("s_waitcnt lgkmcnt(0)")                               # the two site records
     a("v_and_b32_e32 v217, v%d, v%d" % (RL, CR))
     a("v_and_b32_e32 v217, 0x10000, v217")
     a("v_cmp_eq_u32_e32 vcc, 0, v217")                          # not (both simple)
     a("s_and_b64 vcc, vcc, s[60:61]")
-    a("s_cbranch_vccz .Lpg_c1done%s" % sfx)                     # none of the diagonal's multi-edge cells is this wave's
-    if "c" in EXP:
-        a("s_branch .Lpg_c1done%s" % sfx)
+
+
+def c1_ahead(E, k):
+    """The NEXT step's two site records into the other half's registers (they come back with whatever this step waits for
+    next, or with the next step's own batch); s67 = the diagonal they belong to."""
+    a = E.a
+    a("s_add_i32 s67, %[d], 1")
+    a("v_and_b32_e32 v217, 0x1ff, %[row]")
+    a("v_sub_u32_e32 v218, s67, %[row]")
+    a("v_lshl_add_u32 v217, v217, 4, %[bL]")
+    a("v_and_b32_e32 v218, 0x1ff, v218")
+    a("ds_read_b128 v[%d:%d], v217" % (RLK[1 - k], RLK[1 - k] + 3))
+    a("v_lshl_add_u32 v218, v218, 4, %[bR]")
+    a("ds_read_b128 v[%d:%d], v218" % (CRK[1 - k], CRK[1 - k] + 3))
+
+
+def c1_issue(E, k, tag):
+    """Decode of the two records, every operand cell of the blocks requested in one batch, the next step's records behind it."""
+    a = E.a
+    RL, CR = RLK[k], CRK[k]
+    sfx = "%s%d_%%=" % (tag, k)
     # decode: two edges? the other edge listed first? its distance, the two weights (previous-site edge / other edge)
     for (rec, l2, lS, kk, wA, wS, t0, t1) in ((RL, "s[74:75]", "s[78:79]", KL, LWA, LWS, 217, 218), (CR, "s[76:77]", "s[80:81]", KR, RWA, RWS, 219, 220)):
         a("v_bfe_u32 v%d, v%d, 17, 7" % (t0, rec))
@@ -139,7 +157,7 @@ def class1(E, k):
     a("s_and_b64 s[82:83], s[74:75], s[76:77]")
     # ---- every operand cell of the blocks below requested in ONE batch (each block only if a lane of the wave needs it):
     #   right site's other edge: (row, j-kR) -> U, (row-1, j-kR) -> V; left site's: (row-kL, j) -> W1, (row-kL, j-1) -> W2;
-    #   both: (row-kL, j-kR) -> W3.  The weights of the two previous-site edges go onto BM while they are in flight.
+    #   both: (row-kL, j-kR) -> W3.
     a("s_cmp_eq_u64 s[76:77], 0")
     a("s_cbranch_scc1 .Lpg_rdL%s" % sfx)
     a("v_mul_u32_u24_e32 v217, 0x1800, v%d" % KR)
@@ -167,6 +185,14 @@ def class1(E, k):
     E.ring_addr(220, 217, "v%d" % POSL, "s[82:83]")
     E.read_cell(W3, 220)
     a(".Lpg_rdX%s:" % sfx)
+    c1_ahead(E, k)
+
+
+def c1_math(E, k, tag):
+    """The blocks' arithmetic, behind the wait for their operands: leaves BX / BY / BM final."""
+    a = E.a
+    tmx = TMX[k]
+    sfx = "%s%d_%%=" % (tag, k)
     # the pair of the two previous-site edges: its weights (the base step left them out; + 0.0 for a simple site)
     a("v_add_f64 %s, %s, %s" % (pr(BM), pr(BM), pr(LWA)))
     a("v_add_f64 %s, %s, %s" % (pr(BM), pr(BM), pr(RWA)))
@@ -192,7 +218,6 @@ def class1(E, k):
     E.pair_value(W3, tmx, LWS, RWS, T[5], T[6])
     a("v_max_f64 %s, %s, %s" % (pr(BM), pr(BM), pr(T[5])))
     a(".Lpg_noL%s:" % sfx)
-    a(".Lpg_c1done%s:" % sfx)
 
 
 def class2(E, k):
@@ -241,8 +266,8 @@ def class2(E, k):
     a("s_cbranch_scc1 .Lpg_c2spin%s" % sfx)
     a("s_branch .Lpg_c2read%s" % sfx)
     a(".Lpg_c2ok%s:" % sfx)
-    a("v_and_b32_e32 v217, 0x10000, v%d" % RL)
-    a("v_and_b32_e32 v218, 0x10000, v%d" % CR)
+    a("v_and_b32_e32 v217, 0x10000, v%d" % RLK[k])
+    a("v_and_b32_e32 v218, 0x10000, v%d" % CRK[k])
     a("v_cmp_eq_u32_e64 s[74:75], 0, v217")                     # msL: the left site is a multi-edge one
     a("v_cmp_eq_u32_e64 s[76:77], 0, v218")                     # msR
     a("v_cmp_gt_i32_e64 s[78:79], 0, v220")                     # PS_ONLY of the staged X (bit 31)
@@ -402,33 +427,56 @@ def step(E, k):
     else:
         a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
     a(".Lpg_shift%s:" % sfx)
+
+    def shift_and_x():
+        # shift: lane n takes lane n-1's cell, lane 0 keeps what it read from the ring
+        for c in range(3):
+            if "p" in EXP:   # timing experiment: plain moves instead of the DPP shift
+                a("v_mov_b32_e32 v%d, v%d" % (A[c], P[c]))
+                a("v_mov_b32_e32 v%d, v%d" % (A[c] + 1, P[c] + 1))
+                continue
+            a("v_mov_b32_dpp v%d, v%d wave_shr:1 row_mask:0xf bank_mask:0xf" % (A[c], P[c]))
+            a("v_mov_b32_dpp v%d, v%d wave_shr:1 row_mask:0xf bank_mask:0xf" % (A[c] + 1, P[c] + 1))
+        # X from A; the band limit of this lane
+        a("v_add_f64 v[196:197], %s, %%[ng]" % pr(A[2]))          # AM + ng
+        a("v_add_f64 v[200:201], %s, %%[ge]" % pr(A[0]))          # AX + ge
+        a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)          # active: row <= hi
+        a("v_max_f64 v[196:197], %s, v[196:197]" % pr(A[1]))      # max(AY, AM + ng)
+        a("v_add_f64 v[196:197], v[196:197], %[go]")
+        a("v_cndmask_b32_e64 v%d, %%[nihi], %%[pihi], s[60:61]" % (LIM + 1))
+        a("v_max_f64 %s, v[200:201], v[196:197]" % pr(BX))
+
     E.cur = E.ool
+    # Class 1 / 2: the two site records of this step's cell.  A class 1 step reads the next step's ahead (c1_ahead): if the
+    # step before did (s67 == d), they are here and the step takes the short way -- no read, no wait for one; decode, every
+    # operand cell and the records after next requested at once; the shift and the X candidates while those are in flight; one
+    # wait.  Otherwise: the records now, shift and X candidates while they come, then the same parts behind their waits.
     a(".Lpg_recs%s:" % sfx)
+    a("s_cmp_eq_u32 s67, %[d]")
+    a("s_cbranch_scc1 .Lpg_have%s" % sfx)
     a("v_and_b32_e32 v218, 0x1ff, %[row]")
     a("v_sub_u32_e32 v219, %[d], %[row]")
     a("v_lshl_add_u32 v218, v218, 4, %[bL]")
     a("v_and_b32_e32 v219, 0x1ff, v219")
-    a("ds_read_b128 v[%d:%d], v218" % (RL, RL + 3))
+    a("ds_read_b128 v[%d:%d], v218" % (RLK[k], RLK[k] + 3))
     a("v_lshl_add_u32 v219, v219, 4, %[bR]")
-    a("ds_read_b128 v[%d:%d], v219" % (CR, CR + 3))
+    a("ds_read_b128 v[%d:%d], v219" % (CRK[k], CRK[k] + 3))
     a("s_branch .Lpg_shift%s" % sfx)
+    a(".Lpg_have%s:" % sfx)
+    a("s_cmp_eq_u32 s73, 2")
+    a("s_cbranch_scc1 .Lpg_shift%s" % sfx)                     # (class 2: the usual way, minus the read)
+    if "y" in EXP:           # timing experiment / debugging: never the short way
+        a("s_branch .Lpg_shift%s" % sfx)
+    a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)          # active: row <= hi (the X part works it out again)
+    c1_test(E, k, wait=False)
+    a("s_cbranch_vccz .Lpg_shift%s" % sfx)                     # no multi-edge cell in this wave: the usual way sees to the rest
+    c1_issue(E, k, "f")
+    shift_and_x()
+    c1_math(E, k, "f")
+    a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
+    a("s_branch .Lpg_commit%s" % sfx)
     E.cur = E.L
-    # shift: lane n takes lane n-1's cell, lane 0 keeps what it read from the ring
-    for c in range(3):
-        if "p" in EXP:   # timing experiment: plain moves instead of the DPP shift
-            a("v_mov_b32_e32 v%d, v%d" % (A[c], P[c]))
-            a("v_mov_b32_e32 v%d, v%d" % (A[c] + 1, P[c] + 1))
-            continue
-        a("v_mov_b32_dpp v%d, v%d wave_shr:1 row_mask:0xf bank_mask:0xf" % (A[c], P[c]))
-        a("v_mov_b32_dpp v%d, v%d wave_shr:1 row_mask:0xf bank_mask:0xf" % (A[c] + 1, P[c] + 1))
-    # X from A; the band limit of this lane
-    a("v_add_f64 v[196:197], %s, %%[ng]" % pr(A[2]))          # AM + ng
-    a("v_add_f64 v[200:201], %s, %%[ge]" % pr(A[0]))          # AX + ge
-    a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)          # active: row <= hi
-    a("v_max_f64 v[196:197], %s, v[196:197]" % pr(A[1]))      # max(AY, AM + ng)
-    a("v_add_f64 v[196:197], v[196:197], %[go]")
-    a("v_cndmask_b32_e64 v%d, %%[nihi], %%[pihi], s[60:61]" % (LIM + 1))
-    a("v_max_f64 %s, v[200:201], v[196:197]" % pr(BX))
+    shift_and_x()
     a("s_cmp_lg_u32 s73, 0")
     a("s_cbranch_scc1 .Lpg_c1%s" % sfx)
     a(".Lpg_commit%s:" % sfx)
@@ -436,7 +484,16 @@ def step(E, k):
     a(".Lpg_c1%s:" % sfx)
     a("s_cmp_eq_u32 s73, 2")
     a("s_cbranch_scc1 .Lpg_c2%s" % sfx)
-    class1(E, k)
+    c1_test(E, k, wait=True)
+    a("s_cbranch_vccnz .Lpg_c1go%s" % sfx)
+    c1_ahead(E, k)                                             # none of the diagonal's multi-edge cells is this wave's: the next step's records all the same
+    a("s_branch .Lpg_c1done%s" % sfx)
+    a(".Lpg_c1go%s:" % sfx)
+    if "c" in EXP:
+        a("s_branch .Lpg_c1done%s" % sfx)
+    c1_issue(E, k, "s")
+    c1_math(E, k, "s")
+    a(".Lpg_c1done%s:" % sfx)
     a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
     a("s_branch .Lpg_commit%s" % sfx)
     a(".Lpg_c2%s:" % sfx)
@@ -493,6 +550,7 @@ def main():
     a("v_mov_b64_e32 %s, %%[tx]" % pr(TMX[0] + 2))
     a("v_mov_b32_e32 v%d, 0" % LIM)
     a("s_mov_b64 s[70:71], %[dptr]")
+    a("s_mov_b32 s67, -1")                                      # no site records read ahead
     a("s_load_dwordx8 s[36:43], s[70:71], 0x0")
     a("s_sub_i32 s66, %[sb], 0x1800")                           # ring row of the diagonal before
     a("s_cmp_lt_i32 s66, 0")
