@@ -1755,7 +1755,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                   [tid24] "v"(a_tid24), [bpos24] "v"(a_bpos24), [fup] "v"(a_fup), [fme] "v"(a_fme),
                   [nulla] "v"(a_null), [tid] "v"(tid), [ringb] "s"(lds_ring),
                   [asd] "s"(a_asd), [stx] "v"(a_stx), [spxa] "v"(a_spx),
-                  [stop] "s"(stop), [S] "s"(S), [fdn] "v"(a_fdn),
+                  [stopm1] "s"(stop - 1), [S] "s"(S), [fdn] "v"(a_fdn),
                   [bR] "s"(a_recR), [bL] "s"(a_recL), [bT] "s"(a_table),
                   [sclo] "s"(sc_lo), [schi] "s"(sc_hi)
                 : "memory", "vcc", "scc",

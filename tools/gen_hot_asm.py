@@ -322,6 +322,13 @@ def step(E, k):
         a("v_and_b32_e32 v221, 0x1ff, %[row]")
         a("v_lshl_add_u32 v221, v221, 4, %[bL]")
         a("ds_read_u16 %[rowx], v221")
+    if "B" in EXP:           # timing experiment: four branches that are never taken (what does one cost?)
+        a("s_cmp_eq_u32 s67, -2")
+        for q in range(4):
+            a("s_cbranch_scc1 .Lpg_exit%s" % sfx)
+    if "N" in EXP:           # timing experiment: four scalar instructions
+        for q in range(4):
+            a("s_cmp_eq_u32 s67, -2")
     # Y from P, M from C (no shift needed)
     a("v_add_f64 v[196:197], %s, %%[ng]" % pr(P[2]))          # PM + ng
     a("v_add_f64 v[200:201], %s, %%[ge]" % pr(P[1]))          # PY + ge
@@ -334,21 +341,50 @@ def step(E, k):
     a("v_max_f64 %s, v[200:201], v[196:197]" % pr(BY))
     # the LDS batch and the descriptor of this diagonal (requested a step ago) are here
     a("s_waitcnt lgkmcnt(0)")
+    # Four things can keep the step from running -- the diagonal is not class 0..2; the wave's interval ends here or the
+    # loader's flags have to be looked at; the downstream wave has not yet read the ring row this step overwrites; the upstream
+    # wave has not completed d-1 -- and as a rule none does: ONE branch for the four (a branch that is not taken costs as much as
+    # seven scalar instructions here: tools/probe_one_wave.py with the timing variants B and N), on the sign of the OR of four
+    # differences; which of them it was is sorted out off the path.
     a("s_and_b32 s73, s%d, 15" % s4)
-    a("s_cmp_gt_u32 s73, 2")
-    a("s_cbranch_scc1 .Lpg_exit%s" % sfx)                      # not class 0 .. 2
+    upchk = "f" not in EXP and "u" not in EXP
+    dnchk = "f" not in EXP and "n" not in EXP
+    if upchk:
+        a("v_readfirstlane_b32 s68, v223")
+    a("s_sub_i32 s72, 2, s73")                                 # < 0: not class 0 .. 2
+    a("s_sub_i32 s69, %[stopm1], %[d]")                        # < 0: d >= stop
+    a("s_or_b32 s72, s72, s69")
+    if dnchk:
+        a("s_sub_i32 s69, %%[pdn], s%d" % s7)                   # < 0: the downstream wave's flag has to be looked at
+        a("s_or_b32 s72, s72, s69")
+    a("s_sub_i32 s69, %[d], 1")
+    if upchk:
+        a("s_max_i32 %[pup], %[pup], s68")
+        a("s_sub_i32 s68, %[pup], s69")                        # < 0: the upstream wave has not completed d-1
+        a("s_or_b32 s72, s72, s68")
     if "b" in EXP:
         a("s_mov_b32 s73, 0")
     if "d" in EXP:
         a("s_cmp_eq_u32 s73, 2")
         a("s_cselect_b32 s73, 0, s73")
-    a("s_cmp_ge_i32 %[d], %[stop]")
+    a("s_cmp_lt_i32 s72, 0")
+    a("s_cbranch_scc1 .Lpg_attn%s" % sfx)
+    a(".Lpg_upok%s:" % sfx)
+    E.cur = E.ool
+    a(".Lpg_attn%s:" % sfx)
+    a("s_and_b32 s72, s%d, 15" % s4)
+    a("s_cmp_gt_u32 s72, 2")
+    a("s_cbranch_scc1 .Lpg_exit%s" % sfx)                      # not class 0 .. 2
+    a("s_cmp_gt_i32 %[d], %[stopm1]")
     a("s_cbranch_scc1 .Lpg_exit%s" % sfx)                      # the wave's interval ends, or the loader's flags have to be looked at
-    if "f" not in EXP and "n" not in EXP:
+    if dnchk:
         a("s_cmp_gt_i32 s%d, %%[pdn]" % s7)
         a("s_cbranch_scc1 .Lpg_dnwait%s" % sfx)                # the downstream wave's flag has to be looked at
     a(".Lpg_dnok%s:" % sfx)
-    E.cur = E.ool
+    if upchk:
+        a("s_cmp_lt_i32 %[pup], s69")
+        a("s_cbranch_scc1 .Lpg_upwait%s" % sfx)
+    a("s_branch .Lpg_upok%s" % sfx)
     # ring row reuse: the downstream wave must have completed the last diagonal that reads the row this step overwrites.
     # Where long edges are about it may lag two diagonals at most: look at its flag here, a few times, before giving up
     a(".Lpg_dnwait%s:" % sfx)
@@ -369,17 +405,8 @@ def step(E, k):
     if "k" in EXP:
         a("s_add_u32 %[k2], %[k2], 0x10000")
     a("s_branch .Lpg_exit%s" % sfx)
-    E.cur = E.L
-    if "f" not in EXP and "u" not in EXP:
-        a("v_readfirstlane_b32 s68, v223")
-        a("s_max_i32 %[pup], %[pup], s68")
-        a("s_sub_i32 s69, %[d], 1")
-        a("s_cmp_lt_i32 %[pup], s69")
-        a("s_cbranch_scc1 .Lpg_upwait%s" % sfx)
-    a(".Lpg_upok%s:" % sfx)
-    E.cur = E.ool
     # the upstream wave has not completed d-1 yet: it is, as a rule, a fraction of a step away.  Look again a few times
-    # (flag first, then lane 0's operand: LDS executes in order) before handing the wait to the caller's poll.
+    # (the flag alone, then lane 0's operand: LDS executes in order) before handing the wait to the caller's poll.
     a(".Lpg_upwait%s:" % sfx)
     if "k" in EXP:
         a("s_add_u32 %[k0], %[k0], 1")
