@@ -46,13 +46,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_CELL = 36            # 3 states x (f64 score + u32 back-pointer), SURVEY.md s.8(d)
 # Latency floors of one anti-diagonal step of the banded kernel.  The recurrence's true chain per diagonal
 # is two dependent fp64 operations (add -> max): ~2 x 8.4 cycles.  THIS FORMULATION's floor is what its class 0 step costs
-# a wave that waits for nobody: 82 instructions of which 9 are LDS operations (tools/ubench/lds_rate.hip: 5.2 cycles per
-# VALU / SALU instruction issued by one wave, 6-28 per LDS instruction), MEASURED on an alignment whose every diagonal lies in
-# one wave's rows and holds simple sites only (tools/probe_one_wave.py): 527 cycles per diagonal at 2.4 GHz.  (Round 2 and
-# the first half of round 3 quoted 389 cycles from a build with the flag checks removed: in such a build the waves do not wait
+# a wave that waits for nobody: ~78 instructions (42 vector ones at 5 cycles, 9 LDS operations, two stores, ~25 scalar ones at
+# about a cycle each, two branches that are not taken at 7 each), MEASURED on an alignment whose every diagonal lies in one
+# wave's rows and holds simple sites only (tools/probe_one_wave.py): 489 cycles per diagonal at 2.4 GHz.  (Round 2 and the
+# first half of round 3 quoted 389 cycles from a build with the flag checks removed: in such a build the waves do not wait
 # for each other and overlap their intervals -- a number about something else.)
 CHAIN_FLOOR_US = 2 * 8.4 / 2400.0
-STEP_FLOOR_US = 527 / 2400.0
+STEP_FLOOR_US = 489 / 2400.0
 PMC_PROFILE = os.path.join("profiles", "r03_pmc_fill.json")
 KERNELS = ("pg_fill_pipe", "pg_backptr", "pg_fill_tiles_flow", "pg_fill_wavefront")
 
@@ -349,7 +349,7 @@ def bench_one_gpu(args, device):
                                  "note": "steps = anti-diagonals on the critical path (longest alignment of every level; banded "
                                          "workloads).  chain floor: the recurrence's two dependent fp64 operations per diagonal; "
                                          "formulation floor: this kernel's class 0 step with no wave waiting for another "
-                                         "(82 instructions, 9 of them LDS operations: 527 cycles measured on a one-wave alignment, "
+                                         "(~78 instructions, 9 of them LDS operations: 489 cycles measured on a one-wave alignment, "
                                          "tools/probe_one_wave.py)"}},
         "kernels_ms": {"fill": fill_step_ms, "end_and_trace": float(trace_ms.mean(axis=0).sum()),
                        "end_and_trace_by_level": [float(x) for x in trace_ms.mean(axis=0)]},
