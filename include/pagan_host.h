@@ -210,6 +210,9 @@ int  pagan_define_tunnel(const char *s1, const char *s2, const char *gapped1, co
  * pagan_force_gap: Viterbi_alignment::replace_largest_tunnel_block_with_gap_tunnel (viterbi_alignment.cpp:467-553)
  *   on the last (largest) block; returns 1 if it was replaced, 0 if no block of at least `threshold` cells is left. */
 int  pagan_prefix_hits(const char *s1, const char *s2, int32_t min_length, int32_t *hits, int32_t cap);
+/* diagnostic: how often the prefix-anchor finder ran on the device (csrc/dp_anchors.hip: suffix array by prefix doubling on the
+ * GPU; PAGAN_ANCHORS=host keeps it on the host, which is also where it runs without a device)                               */
+long long pagan_anchors_device_calls(void);
 int  pagan_drop_bad_hits(int32_t *hits, int32_t n, int32_t thr_total, int32_t thr_partly);
 int  pagan_define_tunnel_overlapping(const int32_t *hits, int32_t n, const char *gapped1, const char *gapped2, int32_t width,
                                      int32_t *upper, int32_t *lower, int32_t *blocks, int32_t cap);

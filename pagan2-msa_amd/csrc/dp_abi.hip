@@ -23,6 +23,7 @@
 #include <vector>
 #include <unordered_map>
 
+#include "host_anchors.h"
 #include "../../include/pagan_dp.h"
 #include "dp_device.h"
 #include "dp_band.h"
@@ -1584,6 +1585,7 @@ int pagan_dp_align(const pagan_graph *left, const pagan_graph *right, const paga
 }
 
 void pagan_dp_release_cache(void) {
+    pagan::anchors_release_cache();
     arena_pool.clear(-1);
     gpu_pool.release();
     std::lock_guard<std::mutex> g(stage_pool.m);

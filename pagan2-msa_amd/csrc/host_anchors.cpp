@@ -12,6 +12,7 @@
 #include "host_anchors.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -77,8 +78,37 @@ void drop_overlapping(std::vector<Hit> *hits, int len1, int len2) {
 
 } // namespace
 
+// PAGAN_ANCHORS=host keeps the finder on the host; otherwise the suffix array is built on the calling thread's device
+// (dp_anchors.hip) and the host's builder below only runs where there is no device
+std::atomic<long long> device_finder_calls{0};                  // (diagnostic: pagan_anchors_device_calls)
+static bool anchors_on_device() {
+    const char *e = std::getenv("PAGAN_ANCHORS");
+    return !(e && std::strcmp(e, "host") == 0);
+}
+
 void prefix_hits(const std::string &a, const std::string &b, int min_length, std::vector<Hit> *hits) {
     const int len1 = (int)a.size(), len2 = (int)b.size();
+    // The device's finder wins on long sequences (2 x 100 kb: 2.9 ms against 11 ms on one host thread) and loses on short ones
+    // (launch overheads: 2 x 3 kb 0.75 against 0.22 ms); a wide tree level prepares its nodes on as many host threads at once,
+    // which then beat a device they would have to share: at most four finders on the device at a time.
+    struct InFlight {
+        std::atomic<int> &c; const bool ok;
+        explicit InFlight(std::atomic<int> &c_) : c(c_), ok(c_.fetch_add(1) < 4) {}
+        ~InFlight() { c.fetch_sub(1); }
+    };
+    static std::atomic<int> on_device{0};
+    bool done = false;
+    if (anchors_on_device() && len1 + len2 >= 16384) {
+        InFlight slot(on_device);
+        done = slot.ok && prefix_hits_device(a, b, min_length, hits);
+    }
+    if (done) {
+        device_finder_calls.fetch_add(1);
+        std::sort(hits->begin(), hits->end(), [](Hit p, Hit q) { return p.len > q.len; });   // :87
+        drop_overlapping(hits, len1, len2);
+        return;
+    }
+    hits->clear();
     const int n = len1 + len2 + 2;
     std::vector<int> t(n);
     for (int i = 0; i < len1; ++i) t[i] = (unsigned char)a[i] + 2;

@@ -9,6 +9,7 @@
 // reproduced; the band arrays are an INPUT of the aligner ABI for that reason.
 #pragma once
 #include <cstdint>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,11 @@ struct AnchorSettings {
 };
 
 void prefix_hits(const std::string &a, const std::string &b, int min_length, std::vector<Hit> *hits);
+// the same list before its sort by length and overlap filter, from a suffix array built on the device (dp_anchors.hip);
+// false where there is no device
+extern std::atomic<long long> device_finder_calls;    // how often prefix_hits took the device's finder
+void anchors_release_cache();                          // frees the device finder's idle scratch (pagan_dp_release_cache)
+bool prefix_hits_device(const std::string &a, const std::string &b, int min_length, std::vector<Hit> *hits);
 void resolve_conflicts(int len1, int len2, int trim, std::vector<Hit> *hits);
 void hits_to_band(const std::vector<Hit> &hits, const std::string &gapped1, const std::string &gapped2, int width,
                   std::vector<int32_t> *upper, std::vector<int32_t> *lower);

@@ -937,6 +937,8 @@ int pagan_prefix_hits(const char *s1, const char *s2, int32_t min_length, int32_
     return (int)v.size();
 }
 
+long long pagan_anchors_device_calls(void) { return device_finder_calls.load(); }
+
 int pagan_drop_bad_hits(int32_t *hits, int32_t n, int32_t thr_total, int32_t thr_partly) {
     if (n < 0 || (n > 0 && !hits)) return PAGAN_E_ARG;
     std::vector<Hit> v(n);

@@ -113,6 +113,8 @@ def _lib():
         L.pagan_assign_units.restype = None
         L.pagan_prefix_hits.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, _i32p, C.c_int32]
         L.pagan_prefix_hits.restype = C.c_int
+        L.pagan_anchors_device_calls.argtypes = []
+        L.pagan_anchors_device_calls.restype = C.c_longlong
         L.pagan_drop_bad_hits.argtypes = [_i32p, C.c_int32, C.c_int32, C.c_int32]
         L.pagan_drop_bad_hits.restype = C.c_int
         L.pagan_define_tunnel_overlapping.argtypes = [_i32p, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32, _i32p, _i32p,
@@ -183,7 +185,7 @@ HOST_EXPORTED = ["pagan_assign_units", "pagan_msa_default_opts", "pagan_msa_crea
                  "pagan_msa_node_graph",
                  "pagan_msa_destroy", "pagan_hgraph_leaf", "pagan_hgraph_parent", "pagan_hgraph_view",
                  "pagan_hgraph_attrs", "pagan_hgraph_fwd", "pagan_hgraph_string", "pagan_hgraph_free",
-                 "pagan_define_tunnel", "pagan_prefix_hits", "pagan_drop_bad_hits", "pagan_define_tunnel_overlapping",
+                 "pagan_define_tunnel", "pagan_prefix_hits", "pagan_anchors_device_calls", "pagan_drop_bad_hits", "pagan_define_tunnel_overlapping",
                  "pagan_force_gap", "pagan_dna_model", "pagan_protein_model", "pagan_model_prob_table", "pagan_model_alphabets",
                  "pagan_eigen_qrev", "pagan_msa_ready", "pagan_msa_remaining", "pagan_msa_node_cost",
                  "pagan_msa_align_nodes", "pagan_msa_export_result", "pagan_msa_import_result", "pagan_msa_finish",
@@ -303,6 +305,11 @@ def prefix_hits(s1, s2, min_length=30):
     out = np.zeros((cap, 4), np.int32)
     n = _lib().pagan_prefix_hits(s1.encode(), s2.encode(), min_length, _ip(out), cap)
     return out[:n].copy()
+
+
+def anchors_device_calls():
+    """how often the prefix-anchor finder has run on the device in this process"""
+    return int(_lib().pagan_anchors_device_calls())
 
 
 def drop_bad_hits(hits, thr_total=50, thr_partly=400):
