@@ -44,7 +44,10 @@ typedef struct pagan_msa_opts {
     int64_t  device_mem_budget;  /* bytes of HBM one batch may use; 0 = 80% of free memory       */
     int32_t  data_type;          /* 0 = guess (Fasta_reader::check_sequence_data_type,
                                     fasta_reader.cpp:1303-1336), 1 = DNA, 2 = protein (WAG,
-                                    211-letter alphabet, model_factory.cpp:304-632,1478-1595)     */
+                                    211-letter alphabet, model_factory.cpp:304-632,1478-1595),
+                                    3 = DNA read as codons (--codons: 1892 states, rows of three
+                                    characters per column; aligned over the full matrix, the
+                                    anchoring of translated codon strings is not built)           */
     int32_t  pileup_rates;       /* ins = del = 0.25: --454/--homopolymer with --pileup-alignment
                                     (model_factory.cpp:1901-1905)                                  */
     int32_t  anchor_mode;        /* 0 = order-conflict filter + Find_anchors::define_tunnel
@@ -180,6 +183,10 @@ void pagan_pileup_destroy(pagan_pileup *p);
 /* ---- host graphs on their own ---------------------------------------------------------- */
 typedef struct pagan_hgraph pagan_hgraph;
 pagan_hgraph *pagan_hgraph_leaf(const char *residues, const char *full_alphabet, int32_t flags);
+/* Sequence::create_codon_sequence (src/main/sequence.cpp:306-359): one site per triplet of the nucleotide string,
+ * state 61 (NNN) for what is not a sense codon; a plain chain.  pagan_hgraph_string on such a graph (and on its
+ * parents) takes the three-letter names of pagan_codon_alphabet and writes three characters per site.            */
+pagan_hgraph *pagan_hgraph_leaf_codon(const char *nucleotides);
 /* flags: bit0 reads/keep-all-edges settings, bit1 --no-reduced-terminal-penalties            */
 pagan_hgraph *pagan_hgraph_parent(pagan_hgraph *left, pagan_hgraph *right, const pagan_result *res,
                                   float left_branch, float right_branch, const int32_t *parsimony,
@@ -226,8 +233,21 @@ int  pagan_dna_model(const float base_freq[4], double distance, float *table, fl
 /* Protein (WAG) Evol_model for a distance: table [a + b*211] (211x211 floats), params as above,
  * parsimony [i + j*211] (model_factory.cpp:304-541, 1478-1595, 1871-1960, 2155-2219).              */
 int  pagan_protein_model(double distance, float *table, float *params, int32_t *parsimony);
+/* Codon (Kosiol & Goldman's empirical model) Evol_model for a distance: 1892 states = 61 sense codons, NNN,
+ * 1830 codon pairs; table [a + b*1892], params as above, parsimony [i + j*1892]
+ * (Model_factory::define_codon_alphabet / codon_model / alignment_model, model_factory.cpp:839-1217, 1599-1805,
+ * 1871-1960, 2022-2092).                                                                                       */
+int  pagan_codon_model(double distance, float *table, float *params, int32_t *parsimony);
+/* names: 3 characters per state (>= 3*1892 + 1 bytes) -- what a state prints as (the ancestral character
+ * alphabet, model_factory.cpp:1739-1803; its first 62 entries are the leaf alphabet, model_factory.h:209-221);
+ * mostcommon [i + j*61] (model_factory.cpp:1208-1217).  Either may be NULL.  Returns the number of states.      */
+int  pagan_codon_alphabet(char *names, int32_t *mostcommon);
+/* Leaf states of a nucleotide string read as codons (sequence.cpp:318-336); states holds (strlen+2)/3 entries.
+ * Returns the number of states.                                                                                */
+int  pagan_codon_states(const char *nucleotides, int32_t *states);
 /* The same model in probability space, what the forward/backward pass takes (pagan_model_prob):
- * score [a + b*S] = Evol_model::score, params[3] = gap_open, gap_ext, non_gap.  data_type 1 DNA, 2 protein. */
+ * score [a + b*S] = Evol_model::score, params[3] = gap_open, gap_ext, non_gap.  data_type 1 DNA, 2 protein,
+ * 3 codon.                                                                                                    */
 int  pagan_model_prob_table(int32_t data_type, const float *base_freq, double distance, float *score, float *params);
 /* Alphabets of a data type (1 DNA, 2 protein): leaf_alphabet (state = position of the residue,
  * Sequence::full_char_alphabet) and ancestral_alphabet (the character an internal state prints as,

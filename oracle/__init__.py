@@ -78,6 +78,12 @@ def lib():
         L.oracle_dna_model.restype = C.c_int
         L.oracle_protein_model.argtypes = [C.c_double, f32p, f32p, i32p]
         L.oracle_protein_model.restype = C.c_int
+        L.oracle_codon_model.argtypes = [C.c_double, f32p, f32p, i32p]
+        L.oracle_codon_model.restype = C.c_int
+        L.oracle_codon_alphabet.argtypes = [C.c_char_p, i32p]
+        L.oracle_codon_alphabet.restype = C.c_int
+        L.oracle_codon_states.argtypes = [C.c_char_p, i32p]
+        L.oracle_codon_states.restype = C.c_int
         L.oracle_eigen_qrev.argtypes = [f64p, f64p, C.c_int, f64p, f64p, f64p]
         L.oracle_eigen_qrev.restype = C.c_int
         L.oracle_model_prob.argtypes = [C.c_int, f32p, C.c_double, f32p, f32p]
@@ -218,9 +224,38 @@ def protein_model(dist):
     return abi.Model(table.reshape(211, 211).T, *params), pars
 
 
+CODON_STATES = 61 + 1 + 1830                    # sense codons, NNN, one code per unordered codon pair
+
+
+def codon_model(dist):
+    """(abi.Model, parsimony[1892*1892]) of Model_factory::codon_model (Kosiol & Goldman) + alignment_model."""
+    S = CODON_STATES
+    table = np.zeros(S * S, np.float32)
+    params = np.zeros(4, np.float32)
+    pars = np.zeros(S * S, np.int32)
+    lib().oracle_codon_model(float(dist), _fp(table), _fp(params), _ip(pars))
+    return abi.Model(table.reshape(S, S).T, *params), pars
+
+
+def codon_alphabet():
+    """(the 1892 three-letter names an ancestral state prints as, mostcommon[61*61])"""
+    buf = C.create_string_buffer(3 * CODON_STATES + 1)
+    mc = np.zeros(61 * 61, np.int32)
+    n = lib().oracle_codon_alphabet(buf, _ip(mc))
+    txt = buf.value.decode()
+    return [txt[3 * k:3 * k + 3] for k in range(n)], mc
+
+
+def codon_states(nucleotides):
+    """Sequence::create_codon_sequence: the state of every triplet (61 = NNN for what is not a sense codon)."""
+    out = np.zeros(len(nucleotides) // 3 + 2, np.int32)
+    n = lib().oracle_codon_states(nucleotides.encode(), _ip(out))
+    return out[:n].copy()
+
+
 def model_prob(data_type, dist, base_freq=None):
     """abi.ModelProb (Evol_model::score / gap_open / gap_ext / non_gap) restated in oracle_model.cpp."""
-    S = 211 if data_type == 2 else 15
+    S = CODON_STATES if data_type == 3 else 211 if data_type == 2 else 15
     score = np.zeros(S * S, np.float32)
     params = np.zeros(3, np.float32)
     bf = np.ascontiguousarray(base_freq if base_freq is not None else [0.25] * 4, np.float32)

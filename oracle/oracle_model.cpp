@@ -11,11 +11,15 @@
 //   Factory::dna()          <- Model_factory::dna_model                     src/utils/model_factory.cpp:1344-1474
 //   Factory::protein()      <- Model_factory::define_protein_alphabet       model_factory.cpp:304-632
 //                              Model_factory::protein_model                 model_factory.cpp:1502-1595
+//   Factory::codon()        <- Model_factory::define_codon_alphabet         model_factory.cpp:839-1217
+//                              Model_factory::codon_model                   model_factory.cpp:1624-1805
 //   Factory::alignment()    <- Model_factory::alignment_model               model_factory.cpp:1871-2230
+//   codon_states()          <- Sequence::create_codon_sequence              src/main/sequence.cpp:306-359
 //
 // The product's producer (pagan2-msa_amd/csrc/host_model.cpp) is written differently (one
 // solver object, dense index maps for the pi == 0 case); tests compare the two bit for bit and
 // both against numpy/scipy (expm) within a tolerance.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -23,6 +27,7 @@
 #include <string>
 #include <vector>
 
+#include "codon_data.h"
 #include "wag_data.h"
 
 namespace {
@@ -225,7 +230,9 @@ struct Symbol { int index, n_units, first_residue, second_residue; std::string r
 
 struct Factory {
     int char_as = 0, char_fas = 0;
-    bool is_protein = false;
+    bool is_protein = false;                                  // protein OR codon: the pair-code alphabets
+    std::vector<std::string> ancestral;                       // codon: ancestral_character_alphabet
+    std::vector<int> mostcommon;                              // codon: g(i,j) = [i + j*char_as]
     std::vector<double> charPi, charU, charV, charRoot;       // [i*char_as + j]
     std::vector<int> parsimony;                               // g(i,j) = [i + j*char_fas]
     std::vector<Symbol> symbols;
@@ -345,6 +352,100 @@ struct Factory {
         build(Q);
     }
 
+    // Model_factory::codon_full_alpha (model_factory.cpp:841, :1741, model_factory.h:213): the 61 sense codons, then NNN
+    static const char *codon_full_alpha() {
+        return "AAAAACAAGAATACAACCACGACTAGAAGCAGGAGTATAATCATGATTCAACACCAGCATCCACCCCCGCCTCGACGCCGGCGTCTACTCCTGCTTGAAGACGAGGATGCAGCCGCG"
+               "GCTGGAGGCGGGGGTGTAGTCGTGGTTTACTATTCATCCTCGTCTTGCTGGTGTTTATTCTTGTTTNNN";
+    }
+
+    void codon() {
+        is_protein = true; char_as = 61;                       // the Codon_symbol fields are the Char_symbol fields under other names
+        ins_rate = 0.01f; del_rate = 0.01f; ext_prob = 0.5f; end_ext_prob = 0.75f;      // :1601-1618
+        const std::string full_alpha = codon_full_alpha();
+        symbols.clear();
+        int count = 0;
+        for (int i = 0; i < 61; i++) { symbols.push_back({i, 1, i, -1, full_alpha.substr(i * 3, 3)}); count++; }
+        symbols.push_back({61, 1, 61, -1, "NNN"});             // n_units 1 (:870)
+        count++;
+        for (int i = 0; i < 60; i++)
+            for (int j = i + 1; j < 61; j++) {
+                symbols.push_back({count, 2, i, j, "nnn"});
+                count++;
+            }
+        char_fas = count;
+        const double *tmp_pi = oracle_codon::kCodonPi, *tmp_q = oracle_codon::kCodonQ;
+        auto cQ = [&](int j, int i) { return tmp_q[j * char_as + i]; };
+        parsimony.assign(char_fas * char_fas, 0);
+        auto set = [&](int v, int i, int j) { parsimony[i + j * char_fas] = v; };
+        for (int i = 0; i < char_fas; i++) {
+            for (int j = 0; j < char_fas; j++) {
+                if (i == j) { set(i, i, j); continue; }
+                Symbol *codon1 = &symbols.at(i), *codon2 = &symbols.at(j);
+                if (codon1->index == char_as) set(j, i, j);
+                else if (codon2->index == char_as) set(i, i, j);
+                else if (codon1->n_units == 1 && codon2->n_units == 1) {
+                    int c1 = std::min(codon1->first_residue, codon2->first_residue);
+                    int c2 = std::max(codon1->first_residue, codon2->first_residue);
+                    int add = char_as - 2, sum = char_as;
+                    for (int loop = 0; loop < c1; loop++) { sum += add; add--; }
+                    sum += c2;
+                    set(sum, i, j);
+                } else if (codon1->n_units == 1 && codon2->n_units == 2 &&
+                           (codon1->first_residue == codon2->first_residue || codon1->first_residue == codon2->second_residue))
+                    set(codon1->first_residue, i, j);
+                else if (codon2->n_units == 1 && codon1->n_units == 2 &&
+                         (codon2->first_residue == codon1->first_residue || codon2->first_residue == codon1->second_residue))
+                    set(codon2->first_residue, i, j);
+                else {
+                    int m = codon1->first_residue, n = codon2->first_residue;
+                    float maxQ = cQ(m, n);
+                    int maxl1 = m, maxl2 = n;
+                    if (codon2->n_units == 2) {
+                        m = codon1->first_residue; n = codon2->second_residue;
+                        if (cQ(m, n) > maxQ) { maxQ = cQ(m, n); maxl1 = codon1->first_residue; maxl2 = codon2->second_residue; }
+                    }
+                    if (codon1->n_units == 2) {
+                        m = codon1->second_residue; n = codon2->first_residue;
+                        if (cQ(m, n) > maxQ) { maxQ = cQ(m, n); maxl1 = codon1->second_residue; maxl2 = codon2->first_residue; }
+                    }
+                    if (codon1->n_units == 2 && codon2->n_units == 2) {
+                        m = codon1->second_residue; n = codon2->second_residue;
+                        if (cQ(m, n) > maxQ) { maxQ = cQ(m, n); maxl1 = codon1->second_residue; maxl2 = codon2->second_residue; }
+                    }
+                    int c1 = std::min(maxl1, maxl2), c2 = std::max(maxl1, maxl2);
+                    int add = char_as - 2, sum = char_as;
+                    for (int loop = 0; loop < c1; loop++) { sum += add; add--; }
+                    sum += c2;
+                    set(sum, i, j);
+                }
+            }
+        }
+        mostcommon.assign(char_as * char_as, 0);               // :1208-1217
+        for (int i = 0; i < char_as; i++)
+            for (int j = 0; j < char_as; j++) {
+                mostcommon[i + j * char_as] = j;
+                if (tmp_pi[i] > tmp_pi[j]) mostcommon[i + j * char_as] = i;
+            }
+        charPi.assign(char_fas, 0);                            // :1640-1645
+        for (int j = 0; j < char_as; j++) charPi[j] = tmp_pi[j];
+        std::vector<double> Q(tmp_q, tmp_q + 3721);
+        build(Q);
+        ancestral.clear();                                     // :1739-1803
+        for (int i = 0; i < 62; i++) ancestral.push_back(full_alpha.substr(i * 3, 3));
+        const std::string alpha = "xACxGxxxT", ambiguity = "xxAMCRSxGWYxKxxxT";
+        for (int i = 0; i < 60; i++)
+            for (int j = i + 1; j < 61; j++) {
+                std::string cod;
+                for (int pos = 0; pos < 3; pos++) {
+                    std::string c1 = full_alpha.substr(i * 3 + pos, 1), c2 = full_alpha.substr(j * 3 + pos, 1);
+                    std::string::size_type loc1 = alpha.find(c1, 0), loc2 = alpha.find(c2, 0);
+                    if (loc1 != std::string::npos && loc2 != std::string::npos) cod += ambiguity.at(int(loc1 + loc2));
+                    else cod += "N";
+                }
+                ancestral.push_back(cod);
+            }
+    }
+
     // alignment_model: table[a + b*char_fas] as floats (Evol_model::log_score returns float), params[4]
     void alignment(double distance, bool pileup, float *table, float *params, float *prob = nullptr, float *prob_params = nullptr) const {
         const int as = char_as, fas = char_fas;
@@ -389,6 +490,8 @@ struct Factory {
                     LPR(i, j) = log(max);
                 }
         } else {
+            // protein, the small-group path (:2155-2219), and codon (:2026-2090): the same statements over
+            // Char_symbol::first_residue / second_residue and Codon_symbol::first_codon / second_codon
             for (int i = 0; i < fas; i++)
                 for (int j = 0; j < fas; j++) {
                     if (i < as && j < as) continue;
@@ -439,7 +542,47 @@ int oracle_protein_model(double distance, float *table, float *params, int32_t *
     return 0;
 }
 
+static Factory *codon_factory() {
+    static Factory *f = nullptr;
+    if (!f) { f = new Factory(); f->codon(); }
+    return f;
+}
+
+// table and parsimony: 1892 x 1892
+int oracle_codon_model(double distance, float *table, float *params, int32_t *parsimony) {
+    Factory *f = codon_factory();
+    f->alignment(distance, false, table, params);
+    if (parsimony) for (size_t k = 0; k < f->parsimony.size(); k++) parsimony[k] = f->parsimony[k];
+    return 0;
+}
+
+// ancestral: 1892 * 3 characters (+ NUL); mostcommon: 61 x 61
+int oracle_codon_alphabet(char *ancestral, int32_t *mostcommon) {
+    Factory *f = codon_factory();
+    if (ancestral) { for (size_t k = 0; k < f->ancestral.size(); k++) std::memcpy(ancestral + 3 * k, f->ancestral[k].data(), 3); ancestral[3 * f->ancestral.size()] = 0; }
+    if (mostcommon) for (size_t k = 0; k < f->mostcommon.size(); k++) mostcommon[k] = f->mostcommon[k];
+    return (int)f->ancestral.size();
+}
+
+// Sequence::create_codon_sequence, sequence.cpp:318-336: the state of every triplet (a last partial one included)
+int oracle_codon_states(const char *sequence, int32_t *states) {
+    const std::string seq = sequence, full_alpha = Factory::codon_full_alpha();
+    int n = 0;
+    for (int i = 0; i < (int)seq.length(); i += 3) {
+        int state = 61;
+        std::string cod = seq.substr(i, 3);
+        for (int k = 0; k < 62; k++) if (full_alpha.substr(k * 3, 3) == cod) { state = k; break; }
+        states[n++] = state;
+    }
+    return n;
+}
+
 int oracle_model_prob(int data_type, const float *bf, double distance, float *score, float *params) {
+    if (data_type == 3) {
+        std::vector<float> table(1892 * 1892), lp(4);
+        codon_factory()->alignment(distance, false, table.data(), lp.data(), score, params);
+        return 0;
+    }
     std::vector<float> table(211 * 211), lp(4);
     if (data_type == 2) { Factory f; f.protein(); f.alignment(distance, false, table.data(), lp.data(), score, params); }
     else { Factory f; f.dna(bf, 2.0f, 1.0f); f.alignment(distance, false, table.data(), lp.data(), score, params); }

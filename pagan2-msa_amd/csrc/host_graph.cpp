@@ -99,16 +99,25 @@ void push_site(SeqGraph &g, int state, int type, int pstate, int cl, int cr) {
 } // namespace
 
 SeqGraph make_leaf(const std::string &residues, const std::string &alphabet, int flags) {
-    SeqGraph g;
-    g.terminal = true;
-    reserve_sites(g, residues.size() + 2);
-    g.symbols.reserve(residues.size());
-    push_site(g, -1, kStartSite, kEnds, -1, -1);
+    std::vector<int32_t> states;
+    std::string symbols;
+    states.reserve(residues.size()); symbols.reserve(residues.size());
     for (char c : residues) {
         if (c == '0') continue;                                   // sequence.cpp:173-176
-        push_site(g, (int)alphabet.find(c), kRealSite, kTerminal, -1, -1);
-        g.symbols.push_back(c);
+        states.push_back((int32_t)alphabet.find(c));
+        symbols.push_back(c);
     }
+    return make_leaf_states(states, std::move(symbols), 1, flags);
+}
+
+SeqGraph make_leaf_states(const std::vector<int32_t> &states, std::string symbols, int sym_width, int flags) {
+    SeqGraph g;
+    g.terminal = true;
+    g.sym_width = sym_width;
+    reserve_sites(g, states.size() + 2);
+    g.symbols = std::move(symbols);
+    push_site(g, -1, kStartSite, kEnds, -1, -1);
+    for (int32_t st : states) push_site(g, st, kRealSite, kTerminal, -1, -1);
     push_site(g, -1, kStopSite, kEnds, -1, -1);
     const int n = g.n_sites();
     Chains ch(g);
@@ -152,6 +161,7 @@ SeqGraph make_parent(SeqGraph &left, SeqGraph &right, const pagan_result &res, f
     for (int k = 0; k < res.n_right_used; ++k) right.e_used[res.right_used[k]] = 1;
 
     SeqGraph g;
+    g.sym_width = left.sym_width;
     const int n = res.n_cols + 2;
     g.state.reserve(n);
     // ---- sites: create_ancestral_sequence, basic_alignment.cpp:61-179 ----
@@ -296,12 +306,12 @@ SeqGraph make_parent(SeqGraph &left, SeqGraph &right, const pagan_result &res, f
 std::string sequence_string(const SeqGraph &g, bool with_gaps, const std::string &alphabet) {
     if (g.terminal) return g.symbols;
     std::string out;
-    const int n = g.n_sites();
-    out.reserve(n);
+    const int n = g.n_sites(), w = g.sym_width;
+    out.reserve((size_t)n * w);
     for (int j = 1; j < n - 1; ++j) {
         const int ps = g.path_state[j];
-        if (ps != kXSkipped && ps != kYSkipped && g.site_type[j] != kNonReal) out.push_back(alphabet[g.state[j]]);
-        else if (with_gaps) out.push_back('-');
+        if (ps != kXSkipped && ps != kYSkipped && g.site_type[j] != kNonReal) out.append(alphabet, (size_t)g.state[j] * w, w);
+        else if (with_gaps) out.append(w, '-');                  // "---" for codons, sequence.cpp:731-734
     }
     return out;
 }

@@ -37,7 +37,8 @@ struct SeqGraph {
     std::vector<float>   bwd_logw;           // = e_logw[bwd_eid]    (device input)
     std::vector<int32_t> fwd_off, fwd_eid;
     bool terminal = false;                   // leaf (Sequence::is_terminal_sequence)
-    std::string symbols;                     // leaf residues, sites 1..n-2
+    std::string symbols;                     // leaf residues, sites 1..n-2 (sym_width characters each)
+    int sym_width = 1;                       // characters a state prints as: 1, or 3 for codon graphs
 
     int n_sites() const { return (int)state.size(); }
     int n_edges() const { return (int)e_start.size(); }
@@ -63,6 +64,9 @@ enum LeafFlags { kLeaf454 = 1, kLeafHomopolymer = 2 };
 
 // Sequence::create_default_sequence (src/main/sequence.cpp:152-303)
 SeqGraph make_leaf(const std::string &residues, const std::string &full_alphabet, int flags);
+// the same from states already looked up; symbols holds sym_width characters per state.  Codon leaves
+// (Sequence::create_codon_sequence, sequence.cpp:306-359) come this way with flags 0: a plain chain.
+SeqGraph make_leaf_states(const std::vector<int32_t> &states, std::string symbols, int sym_width, int flags);
 
 // Basic_alignment::build_ancestral_sequence (src/main/basic_alignment.cpp:36-59): path -> parent.
 // Marks `left`/`right` edges used from the result first (the traceback's side effect,

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "codon_data.h"
 #include "wag_data.h"
 
 namespace pagan {
@@ -319,6 +320,90 @@ void ModelFactory::init_protein() {
     eigen_qrev(kWagQ, pi.data(), 20, root.data(), U.data(), V.data());
 }
 
+const char *ModelFactory::codon_alphabet() {
+    return "AAAAACAAGAATACAACCACGACTAGAAGCAGGAGTATAATCATGATTCAACACCAGCATCCACCCCCGCCTCGACGCCGGCGTCTACTCCTGCTTGAAGACGAGGATGCAGCCGCG"
+           "GCTGGAGGCGGGGGTGTAGTCGTGGTTTACTATTCATCCTCGTCTTGCTGGTGTTTATTCTTGTTTNNN";
+}
+
+namespace {
+inline int base_code(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+}
+
+std::vector<int32_t> ModelFactory::codon_states(const std::string &nt, std::string *symbols) {
+    // triplet -> state through a 64-entry table (the three stop codons stay 61)
+    int8_t of_triplet[64];
+    for (auto &v : of_triplet) v = 61;
+    const char *names = codon_alphabet();
+    for (int k = 0; k < 61; ++k)
+        of_triplet[base_code(names[3 * k]) * 16 + base_code(names[3 * k + 1]) * 4 + base_code(names[3 * k + 2])] = (int8_t)k;
+    std::vector<int32_t> out;
+    out.reserve(nt.size() / 3 + 1);
+    if (symbols) { symbols->clear(); symbols->reserve(nt.size() + 3); }
+    for (size_t i = 0; i < nt.size(); i += 3) {
+        int st = 61;
+        if (i + 3 <= nt.size()) {
+            const int a = base_code(nt[i]), b = base_code(nt[i + 1]), c = base_code(nt[i + 2]);
+            if (a >= 0 && b >= 0 && c >= 0) st = of_triplet[a * 16 + b * 4 + c];
+        }
+        out.push_back(st);
+        if (symbols) { if (st == 61) symbols->append("NNN"); else symbols->append(nt, i, 3); }
+    }
+    return out;
+}
+
+// Model_factory::define_codon_alphabet + codon_model, model_factory.cpp:839-1217, 1599-1805.
+void ModelFactory::init_codon() {
+    type = kCodon; char_as = 61; S = 61 + 1 + 1830;
+    ins_rate = del_rate = 0.01f; ext_prob = 0.5f; end_ext_prob = 0.75f;                  // :1601-1618
+    leaf_alphabet.clear(); ancestral_alphabet.clear();
+    pi.assign(kCodonPi, kCodonPi + 61);
+    // The code of the unordered pair lo < hi: pairs are numbered row by row after NNN (:879-896), which is what the
+    // reference's running sum computes (:1011-1021): 61 + sum_{l<lo} (59 - l) + hi
+    auto pair_code = [](int a, int b) { const int lo = std::min(a, b), hi = std::max(a, b); return 61 + lo * 59 - lo * (lo - 1) / 2 + hi; };
+    res1.assign(S, -1); res2.assign(S, -1);
+    for (int i = 0; i < 61; ++i) res1[i] = (int16_t)i;
+    res1[61] = 61;
+    for (int i = 0; i < 60; ++i)
+        for (int j = i + 1; j < 61; ++j) { const int code = pair_code(i, j); res1[code] = (int16_t)i; res2[code] = (int16_t)j; }
+    // names: a pair prints as the IUPAC code of its two bases, position by position (:1756-1800)
+    const char *names = codon_alphabet();
+    codon_names.assign(names, 62 * 3);
+    codon_names.resize((size_t)S * 3, 'N');
+    static const char iupac_of_mask[16] = {'N', 'A', 'C', 'M', 'G', 'R', 'S', 'N', 'T', 'W', 'Y', 'N', 'K', 'N', 'N', 'N'};
+    for (int code = 62; code < S; ++code)
+        for (int p = 0; p < 3; ++p)
+            codon_names[(size_t)code * 3 + p] = iupac_of_mask[(1 << base_code(names[3 * res1[code] + p])) | (1 << base_code(names[3 * res2[code] + p]))];
+    // parsimony table (:986-1109)
+    parsimony.assign((size_t)S * S, 0);
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) {
+            int v;
+            if (i == j) v = i;
+            else if (i == 61) v = j;
+            else if (j == 61) v = i;
+            else if (i < 61 && j < 61) v = pair_code(i, j);
+            else if (i < 61 && (i == res1[j] || i == res2[j])) v = i;
+            else if (j < 61 && (j == res1[i] || j == res2[i])) v = j;
+            else {
+                // the exchange with the largest rate among the member pairs: the running maximum is a float that starts
+                // at the first pair's rate, and only a strictly larger rate replaces it (:1044-1088)
+                int b1 = res1[i], b2 = res1[j];
+                float best = (float)kCodonQ[b1 * 61 + b2];
+                auto consider = [&](int m, int n) { if (kCodonQ[m * 61 + n] > best) { best = (float)kCodonQ[m * 61 + n]; b1 = m; b2 = n; } };
+                if (j > 61) consider(res1[i], res2[j]);
+                if (i > 61) consider(res2[i], res1[j]);
+                if (i > 61 && j > 61) consider(res2[i], res2[j]);
+                v = pair_code(b1, b2);
+            }
+            parsimony[i + (size_t)j * S] = v;
+        }
+    mc_dim = 61;                                                   // :1208-1217
+    mostcommon.assign(61 * 61, 0);
+    for (int i = 0; i < 61; ++i) for (int j = 0; j < 61; ++j) mostcommon[i + j * 61] = kCodonPi[i] > kCodonPi[j] ? i : j;
+    U.assign(61 * 61, 0.0); V.assign(61 * 61, 0.0); root.assign(61, 0.0);
+    eigen_qrev(kCodonQ, pi.data(), 61, root.data(), U.data(), V.data());
+}
+
 EvolModel ModelFactory::alignment_model(double distance, bool pileup_rates) const {
     EvolModel m;
     m.S = S; m.char_as = char_as;
@@ -367,8 +452,8 @@ EvolModel ModelFactory::alignment_model(double distance, bool pileup_rates) cons
                 logpr[i + (size_t)j * S] = std::log(mx);
             }
     } else {
-        // protein, the small-group path (:2155-2219); rows in order, so X against an ambiguity code reads
-        // entries this loop has already extended
+        // protein, the small-group path (:2155-2219), and codons (:2026-2090) -- the same extension over the pair
+        // codes; rows in order, so X / NNN against an ambiguity code reads entries this loop has already extended
         for (int i = 0; i < S; ++i)
             for (int j = 0; j < S; ++j) {
                 if (i < n && j < n) continue;

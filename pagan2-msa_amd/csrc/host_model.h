@@ -1,8 +1,8 @@
-// host_model.h -- per-alignment scoring model (the reference's Evol_model) for DNA and protein.
+// host_model.h -- per-alignment scoring model (the reference's Evol_model) for DNA, protein and codons.
 //
-// ModelFactory restates Model_factory::dna_model / protein_model
-// (src/utils/model_factory.cpp:1299-1474, 1478-1595), the alphabets and parsimony tables
-// (model_factory.cpp:118-227 DNA, 304-541 protein) and Model_factory::alignment_model
+// ModelFactory restates Model_factory::dna_model / protein_model / codon_model
+// (src/utils/model_factory.cpp:1299-1474, 1478-1595, 1599-1805), the alphabets and parsimony tables
+// (model_factory.cpp:118-227 DNA, 304-541 protein, 839-1217 codon) and Model_factory::alignment_model
 // (model_factory.cpp:1871-2230): Q and pi, the time-reversible eigen solution
 // (Eigen::eigenQREV -> Householder tridiagonalisation -> implicit QL, src/utils/eigen.cpp:39-295,
 // same operation order, so U, V and the roots carry the same doubles), P(t) = U exp(t Lambda) V
@@ -40,7 +40,7 @@ struct EvolModel {
     }
 };
 
-enum DataType { kDna = 0, kProtein = 1 };                 // Model_factory::dna / ::protein
+enum DataType { kDna = 0, kProtein = 1, kCodon = 2 };     // Model_factory::dna / ::protein / ::codon
 
 struct ModelFactory {
     int type = kDna;
@@ -52,7 +52,11 @@ struct ModelFactory {
     std::vector<int32_t> parsimony;                       // [i + j*S]
     std::vector<int32_t> mostcommon;                      // [i + j*mc_dim] (--mostcommon)
     int mc_dim = 0;
-    std::vector<int16_t> res1, res2;                      // protein: Char_symbol::first_residue / second_residue
+    std::vector<int16_t> res1, res2;                      // protein: Char_symbol::first_residue / second_residue;
+                                                          // codon: Codon_symbol::first_codon / second_codon
+    // codon: three characters per state -- the 61 sense codons, NNN, then per codon pair the IUPAC merge of the two,
+    // position by position (Model_factory::ancestral_character_alphabet for codons, model_factory.cpp:1739-1803)
+    std::string codon_names;
 
     static const char *dna_full_alphabet() { return "ACGTRYMKWSBDHVN"; }          // model_factory.cpp:103
     static const char *protein_alphabet() { return "ARNDCQEGHILKMFPSTWYV"; }      // model_factory.cpp:104
@@ -63,6 +67,12 @@ struct ModelFactory {
     static void base_frequencies(const std::vector<std::string> &seqs, float out[4]);
     void init_dna(const float base_freq[4], float kappa = 2.0f, float rho = 1.0f);
     void init_protein();
+    void init_codon();                                    // Kosiol & Goldman's empirical codon model, 61 + 1 + 1830 states
+    // the 61 sense codons in the model's order, then NNN (model_factory.h:209-221), three characters each
+    static const char *codon_alphabet();
+    // Sequence::create_codon_sequence (src/main/sequence.cpp:318-336): one state per triplet, 61 (NNN) for anything that
+    // is not a sense codon -- a last partial triplet included.  symbols (optional) gets the triplet or "NNN" per state.
+    static std::vector<int32_t> codon_states(const std::string &nucleotides, std::string *symbols = nullptr);
     // ins = del = 0.25 for --454/--homopolymer with --pileup-alignment (model_factory.cpp:1901-1905)
     EvolModel alignment_model(double distance, bool pileup_rates = false) const;
 };

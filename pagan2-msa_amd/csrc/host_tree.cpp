@@ -207,8 +207,9 @@ void build_rows(pagan_msa *m) {
     std::vector<std::vector<int32_t>> col(m->graph.size());
     col[root_id].resize(width + 2);
     for (int s = 0; s < width + 2; ++s) col[root_id][s] = s - 1;
-    m->rows.assign(m->graph.size(), std::string(width, '-'));
-    const std::string &anc = m->mf.ancestral_alphabet;
+    const int w = m->mf.type == kCodon ? 3 : 1;                 // characters per column ("---" gaps for codons)
+    m->rows.assign(m->graph.size(), std::string((size_t)width * w, '-'));
+    const std::string &anc = m->mf.type == kCodon ? m->mf.codon_names : m->mf.ancestral_alphabet;
     // internal ids grow in post-order, so walking them downwards visits parents first
     for (int id = (int)m->graph.size() - 1; id >= n; --id) {
         const TreeNode &t = m->tree[m->tree_of_id[id]];
@@ -223,14 +224,21 @@ void build_rows(pagan_msa *m) {
             // state's character, a gap where the site is skipped or was deleted
             const int ps = g.path_state[s];
             if (!(ps == PAGAN_XSKIPPED || ps == PAGAN_YSKIPPED || g.site_type[s] == kNonReal) && g.state[s] >= 0)
-                m->rows[id][col[id][s]] = anc[g.state[s]];
+                m->rows[id].replace((size_t)col[id][s] * w, w, anc, (size_t)g.state[s] * w, w);
         }
         col[id].clear(); col[id].shrink_to_fit();
     }
     for (int id = 0; id < n; ++id) {
         const SeqGraph &g = m->graph[id]->g;
-        for (int s = 1; s < g.n_sites() - 1; ++s) m->rows[id][col[id][s]] = g.symbols[s - 1];
+        for (int s = 1; s < g.n_sites() - 1; ++s) m->rows[id].replace((size_t)col[id][s] * w, w, g.symbols, (size_t)(s - 1) * w, w);
     }
+}
+
+const ModelFactory &codon_factory() {             // the empirical model's eigen solution and 1892 x 1892 tables: made once
+    static ModelFactory mf;
+    static std::once_flag once;
+    std::call_once(once, [] { mf.init_codon(); });
+    return mf;
 }
 
 } // namespace
@@ -292,14 +300,15 @@ int pagan_msa_create(int32_t n_seqs, const char *const *names, const char *const
         }
         m->seqs[k].swap(s);
     });
-    int type = m->opts.data_type == 1 ? kDna : m->opts.data_type == 2 ? kProtein : ModelFactory::guess_type(m->seqs);
+    // data_type 3: --codons on DNA input (input_output_parser.cpp:517, sequence.cpp:135-136)
+    int type = m->opts.data_type == 1 ? kDna : m->opts.data_type == 2 ? kProtein : m->opts.data_type == 3 ? kCodon : ModelFactory::guess_type(m->seqs);
     // Fasta_reader::check_alphabet, fasta_reader.cpp:1180-1297: DNA U->T; protein U->X; what is outside the
     // full alphabet is dropped
     over_leaves([&](int k) {
         std::string s;
-        const char *keep = type == kDna ? ModelFactory::dna_full_alphabet() : ModelFactory::protein_alphabet();
+        const char *keep = type != kProtein ? ModelFactory::dna_full_alphabet() : ModelFactory::protein_alphabet();
         for (char c : m->seqs[k]) {
-            if (type == kDna) { if (c == 'U') c = 'T'; if (std::strchr(keep, c)) s.push_back(c); }
+            if (type != kProtein) { if (c == 'U') c = 'T'; if (std::strchr(keep, c)) s.push_back(c); }
             else { if (c == 'U') c = 'X'; if (c == 'X' || std::strchr(keep, c)) s.push_back(c); }
         }
         m->seqs[k].swap(s);
@@ -334,6 +343,9 @@ int pagan_msa_create(int32_t n_seqs, const char *const *names, const char *const
         float bf[4];
         ModelFactory::base_frequencies(m->seqs, bf);
         m->mf.init_dna(bf);
+    } else if (type == kCodon) {
+        m->mf.init_codon();
+        m->opts.use_anchors = 0;      // the reference anchors codon graphs on their translation (viterbi_alignment.cpp:54-60); not built: full matrix
     } else {
         m->mf.init_protein();
     }
@@ -343,7 +355,13 @@ int pagan_msa_create(int32_t n_seqs, const char *const *names, const char *const
             for (int j = 0; j < m->mf.mc_dim; ++j) m->state_table[i + (size_t)j * m->mf.S] = m->mf.mostcommon[i + j * m->mf.mc_dim];
     over_leaves([&](int k) {
         m->graph[k].reset(new pagan_hgraph());
-        m->graph[k]->g = make_leaf(m->seqs[k], m->mf.leaf_alphabet, m->opts.leaf_flags);
+        if (type == kCodon) {
+            std::string symbols;
+            const std::vector<int32_t> states = ModelFactory::codon_states(m->seqs[k], &symbols);
+            m->graph[k]->g = make_leaf_states(states, std::move(symbols), 3, 0);
+        } else {
+            m->graph[k]->g = make_leaf(m->seqs[k], m->mf.leaf_alphabet, m->opts.leaf_flags);
+        }
     });
     m->work.resize(n_seqs - 1);
     m->done.assign(2 * n_seqs - 1, 0);
@@ -875,6 +893,15 @@ pagan_hgraph *pagan_hgraph_leaf(const char *residues, const char *alphabet, int3
     return h;
 }
 
+pagan_hgraph *pagan_hgraph_leaf_codon(const char *nucleotides) {
+    if (!nucleotides) return nullptr;
+    pagan_hgraph *h = new pagan_hgraph();
+    std::string symbols;
+    const std::vector<int32_t> states = ModelFactory::codon_states(nucleotides, &symbols);
+    h->g = make_leaf_states(states, std::move(symbols), 3, 0);
+    return h;
+}
+
 pagan_hgraph *pagan_hgraph_parent(pagan_hgraph *l, pagan_hgraph *r, const pagan_result *res, float lbl, float rbl,
                                   const int32_t *parsimony, int32_t S, int32_t char_as, int32_t flags) {
     BuildSettings bs;
@@ -997,12 +1024,37 @@ int pagan_protein_model(double distance, float *table, float *params, int32_t *p
     return PAGAN_OK;
 }
 
+int pagan_codon_model(double distance, float *table, float *params, int32_t *parsimony) {
+    if (!table || !params) return PAGAN_E_ARG;
+    const ModelFactory &mf = codon_factory();
+    const EvolModel em = mf.alignment_model(distance);
+    std::memcpy(table, em.log_score.data(), sizeof(float) * em.log_score.size());
+    params[0] = em.log_gap_open; params[1] = em.log_gap_ext; params[2] = em.log_gap_end_ext; params[3] = em.log_non_gap;
+    if (parsimony) std::memcpy(parsimony, mf.parsimony.data(), sizeof(int32_t) * mf.parsimony.size());
+    return PAGAN_OK;
+}
+
+int pagan_codon_alphabet(char *names, int32_t *mostcommon) {
+    const ModelFactory &mf = codon_factory();
+    if (names) std::memcpy(names, mf.codon_names.c_str(), mf.codon_names.size() + 1);
+    if (mostcommon) std::memcpy(mostcommon, mf.mostcommon.data(), sizeof(int32_t) * mf.mostcommon.size());
+    return mf.S;
+}
+
+int pagan_codon_states(const char *nucleotides, int32_t *states) {
+    if (!nucleotides || !states) return PAGAN_E_ARG;
+    const std::vector<int32_t> st = ModelFactory::codon_states(nucleotides);
+    if (!st.empty()) std::memcpy(states, st.data(), sizeof(int32_t) * st.size());
+    return (int)st.size();
+}
+
 // Probability-space view of the same model (Evol_model::score / gap_open / gap_ext / non_gap): score [a + b*S],
-// params[3] = gap_open, gap_ext, non_gap.  data_type 1: DNA (base_freq needed), 2: protein.
+// params[3] = gap_open, gap_ext, non_gap.  data_type 1: DNA (base_freq needed), 2: protein, 3: codon.
 int pagan_model_prob_table(int32_t data_type, const float *base_freq, double distance, float *score, float *params) {
-    if (!score || !params || (data_type != 2 && !base_freq)) return PAGAN_E_ARG;
-    ModelFactory mf;
-    if (data_type == 2) mf.init_protein(); else mf.init_dna(base_freq);
+    if (!score || !params || (data_type != 2 && data_type != 3 && !base_freq)) return PAGAN_E_ARG;
+    ModelFactory own;
+    if (data_type == 2) own.init_protein(); else if (data_type != 3) own.init_dna(base_freq);
+    const ModelFactory &mf = data_type == 3 ? codon_factory() : own;
     const EvolModel em = mf.alignment_model(distance);
     std::memcpy(score, em.score.data(), sizeof(float) * em.score.size());
     params[0] = em.gap_open; params[1] = em.gap_ext; params[2] = em.non_gap;
@@ -1034,6 +1086,6 @@ int pagan_msa_node_device(const pagan_msa *m, int32_t k) {
     return m->work[k].device;
 }
 
-int pagan_msa_data_type(const pagan_msa *m) { return m ? (m->mf.type == kProtein ? 2 : 1) : PAGAN_E_ARG; }
+int pagan_msa_data_type(const pagan_msa *m) { return m ? (m->mf.type == kCodon ? 3 : m->mf.type == kProtein ? 2 : 1) : PAGAN_E_ARG; }
 
 } // extern "C"

@@ -126,6 +126,14 @@ def _lib():
         L.pagan_dna_model.restype = C.c_int
         L.pagan_protein_model.argtypes = [C.c_double, _f32p, _f32p, _i32p]
         L.pagan_protein_model.restype = C.c_int
+        L.pagan_codon_model.argtypes = [C.c_double, _f32p, _f32p, _i32p]
+        L.pagan_codon_model.restype = C.c_int
+        L.pagan_codon_alphabet.argtypes = [C.c_char_p, _i32p]
+        L.pagan_codon_alphabet.restype = C.c_int
+        L.pagan_codon_states.argtypes = [C.c_char_p, _i32p]
+        L.pagan_codon_states.restype = C.c_int
+        L.pagan_hgraph_leaf_codon.argtypes = [C.c_char_p]
+        L.pagan_hgraph_leaf_codon.restype = vp
         L.pagan_model_prob_table.argtypes = [C.c_int32, _f32p, C.c_double, _f32p, _f32p]
         L.pagan_model_prob_table.restype = C.c_int
         L.pagan_model_alphabets.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
@@ -187,6 +195,7 @@ HOST_EXPORTED = ["pagan_assign_units", "pagan_msa_default_opts", "pagan_msa_crea
                  "pagan_hgraph_attrs", "pagan_hgraph_fwd", "pagan_hgraph_string", "pagan_hgraph_free",
                  "pagan_define_tunnel", "pagan_prefix_hits", "pagan_anchors_device_calls", "pagan_drop_bad_hits", "pagan_define_tunnel_overlapping",
                  "pagan_force_gap", "pagan_dna_model", "pagan_protein_model", "pagan_model_prob_table", "pagan_model_alphabets",
+                 "pagan_codon_model", "pagan_codon_alphabet", "pagan_codon_states", "pagan_hgraph_leaf_codon",
                  "pagan_eigen_qrev", "pagan_msa_ready", "pagan_msa_remaining", "pagan_msa_node_cost",
                  "pagan_msa_align_nodes", "pagan_msa_export_result", "pagan_msa_import_result", "pagan_msa_finish",
                  "pagan_msa_data_type", "pagan_msa_node_device", "pagan_msa_set_batch_backend",
@@ -227,6 +236,11 @@ class HGraph:
     @classmethod
     def leaf(cls, seq, alphabet=DNA_FULL, flags=0):
         return cls(_lib().pagan_hgraph_leaf(seq.encode(), alphabet.encode(), flags))
+
+    @classmethod
+    def codon_leaf(cls, nucleotides):
+        """One site per triplet (Sequence::create_codon_sequence)."""
+        return cls(_lib().pagan_hgraph_leaf_codon(nucleotides.encode()))
 
     @classmethod
     def parent(cls, left, right, result, lbl, rbl, parsimony, char_as, flags=0):
@@ -278,7 +292,7 @@ class HGraph:
         v = abi.CGraph()
         L = _lib()
         L.pagan_hgraph_view(self.h, C.byref(v))
-        buf = C.create_string_buffer(v.n_sites + 1)
+        buf = C.create_string_buffer(3 * v.n_sites + 1)              # codon graphs write three characters per site
         n = L.pagan_hgraph_string(self.h, 1 if with_gaps else 0, alphabet.encode(), buf)
         return buf.raw[:n].decode()
 
@@ -363,9 +377,40 @@ def protein_model(dist):
     return abi.Model(table.reshape(211, 211).T, *params), pars
 
 
+CODON_STATES = 61 + 1 + 1830
+
+
+def codon_model(dist):
+    """(abi.Model, parsimony[1892*1892]) for a codon alignment (Kosiol & Goldman's empirical model) at distance `dist`."""
+    S = CODON_STATES
+    table = np.zeros(S * S, np.float32)
+    params = np.zeros(4, np.float32)
+    pars = np.zeros(S * S, np.int32)
+    rc = _lib().pagan_codon_model(float(dist), _fp(table), _fp(params), _ip(pars))
+    if rc != 0:
+        raise RuntimeError("pagan_codon_model failed: %d" % rc)
+    return abi.Model(table.reshape(S, S).T, *params), pars
+
+
+def codon_alphabet():
+    """(flat string of three-letter state names -- the first 62 are the leaf codons and NNN --, mostcommon[61*61])"""
+    buf = C.create_string_buffer(3 * CODON_STATES + 1)
+    mc = np.zeros(61 * 61, np.int32)
+    _lib().pagan_codon_alphabet(buf, _ip(mc))
+    return buf.value.decode(), mc
+
+
+def codon_states(nucleotides):
+    out = np.zeros(len(nucleotides) // 3 + 2, np.int32)
+    n = _lib().pagan_codon_states(nucleotides.encode(), _ip(out))
+    if n < 0:
+        raise RuntimeError("pagan_codon_states failed: %d" % n)
+    return out[:n].copy()
+
+
 def model_prob(data_type, dist, base_freq=None):
     """abi.ModelProb for a distance: the probability-space view (Evol_model::score, gap_open, gap_ext, non_gap)."""
-    S = 211 if data_type == 2 else 15
+    S = CODON_STATES if data_type == 3 else 211 if data_type == 2 else 15
     score = np.zeros(S * S, np.float32)
     params = np.zeros(3, np.float32)
     bf = np.ascontiguousarray(base_freq if base_freq is not None else [0.25] * 4, np.float32)
