@@ -529,6 +529,7 @@ struct pagan_batch {
     int bp_pass = 1;             // pg_fill_pipe's jobs: 1 back-pointers by pg_backptr after the fill (its hot loop stores scores only),
                                  // 2 (PAGAN_DP_BP=verify, diagnostic builds that still write them in the fill) pg_backptr compares
     int max_bound = 0;           // largest traceback boundary count of any job
+    int max_entries = 0;         // most traceback table entries of any job (tb[n_bound + 1])
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     // per-kernel brackets inside the fill (pagan_batch_last_ms_detail): 0/1 around the banded kernel, 2 behind pg_backptr,
@@ -1170,6 +1171,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         if (rc != PAGAN_OK) return rc;
         b->cells += b->compact[k].on ? b->compact[k].cells0 : b->jobs[k].dx.cells;       // the caller's cells
         if (b->jobs[k].n_bound > b->max_bound) b->max_bound = b->jobs[k].n_bound;
+        if (b->jobs[k].n_bound > 0 && b->jobs[k].tb[b->jobs[k].n_bound + 1] > b->max_entries) b->max_entries = b->jobs[k].tb[b->jobs[k].n_bound + 1];
         if (b->jobs[k].ring_ok && !force_v1) {
             (eff[k].model->n_states <= 16 ? which_ring : which_ring_big).push_back(k);
             continue;
@@ -1384,8 +1386,8 @@ int pagan_batch_run(pagan_batch *b) {
         const int *gave_up = flow ? b->d_flow + 1 + ((int)b->tile_off.size() - 1) + b->tile_off.back() : nullptr;
         hipLaunchKernelGGL(pg_end_corner, dim3(b->n), dim3(64), 0, b->stream, b->d_jobs, gave_up);
     }
-    if (b->max_bound > 0)
-        hipLaunchKernelGGL(pg_trace_spec, dim3(b->max_bound, b->n), dim3(128), 0, b->stream, b->d_jobs);
+    if (b->max_bound > 0 && b->max_entries > 0)
+        hipLaunchKernelGGL(pg_trace_spec, dim3((b->max_entries + 127) / 128, b->n), dim3(128), 0, b->stream, b->d_jobs);
     hipLaunchKernelGGL(pg_trace_compose, dim3(b->n), dim3(64), 0, b->stream, b->d_jobs);
     if (b->max_bound > 0)
         hipLaunchKernelGGL(pg_trace_emit, dim3((2 * b->max_bound + 8 + 63) / 64, b->n), dim3(64), 0, b->stream, b->d_jobs);

@@ -549,13 +549,16 @@ __device__ __forceinline__ bool trace_step(const View &J, TNode &n, int &w, TCac
     const int mn = D.x, mx = D.y;
     if (n.i < mn || n.i > mx) return false;
     const long long ix = (((long long)D.w << 32) | (unsigned)D.z) + (n.i - mn);
+    // the sites' list offsets are asked for together with the back-pointer (they do not depend on it): a move through a
+    // long edge then costs two dependent round trips, not three
+    const int oL = J.offL[n.i], oR = J.offR[n.j];
     const unsigned b = J.bp[3 * ix + n.vit];
     w = (int)((unsigned)n.vit | (b & ~3u));
     const unsigned from = b & 3u;
     if (from == PG_BP_NONE) return false;
     const int k1 = (int)((b >> 4) & 16383u), k2 = (int)(b >> 18);
-    if (n.vit != PG_Y) n.i = (b & PG_BP_ADJL) ? n.i - 1 : J.srcL[J.offL[n.i] + k1];
-    if (n.vit != PG_X) n.j = (b & PG_BP_ADJR) ? n.j - 1 : J.srcR[J.offR[n.j] + k2];
+    if (n.vit != PG_Y) n.i = (b & PG_BP_ADJL) ? n.i - 1 : J.srcL[oL + k1];
+    if (n.vit != PG_X) n.j = (b & PG_BP_ADJR) ? n.j - 1 : J.srcR[oR + k2];
     n.vit = (int)from;
     return true;
 }
@@ -634,17 +637,24 @@ __global__ void pg_end_corner(const PgDevJob *__restrict__ jobs, const int *__re
     else if (tiles_gave_up && tiles_gave_up[0] != 0) ec[0] = 0x40000000 | 0x7e;
 }
 
-// grid (K_max, n_jobs): block b.x handles boundary k = b.x + 1 of job b.y
+// grid (ceil(most table entries of a job / 128), n_jobs): one thread per table entry, i.e. per (cell, state) of a boundary
+// pair -- a workgroup per boundary left the widest boundaries' lanes with ten and more chases one after the other, and the
+// kernel as long as the longest of those queues
 __global__ __launch_bounds__(128) void pg_trace_spec(const PgDevJob *__restrict__ jobs) {
     const View J = load_view(jobs + blockIdx.y);
-    const int k = blockIdx.x + 1;
-    if (k > J.n_bound || J.endcell[0] != 0) return;
+    if (J.n_bound < 1 || J.endcell[0] != 0) return;
+    const int eg = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (eg >= J.tb[J.n_bound + 1]) return;
+    int k = 1;                                                     // the last boundary whose first entry is <= eg
+    for (int hi = J.n_bound; k < hi;) { const int mid = (k + hi + 1) >> 1; if (J.tb[mid] <= eg) k = mid; else hi = mid - 1; }
     const int D = k * PG_SEG;
     const int mnA = J.imin[D], wA = max(J.imax[D] - mnA + 1, 0);
     const int mnB = J.imin[D - 1], wB = max(J.imax[D - 1] - mnB + 1, 0);
     const int n_entries = 3 * (wA + wB);
     gint_w tab = J.ttab + 8 * (long long)J.tb[k];
-    for (int e = threadIdx.x; e < n_entries; e += blockDim.x) {
+    {
+        const int e = eg - J.tb[k];
+        if (e >= n_entries) return;                                // (cannot happen: tb[k + 1] - tb[k] = n_entries)
         TNode n;
         if (e < 3 * wA) { n.i = mnA + e / 3; n.j = D - n.i; } else { n.i = mnB + (e - 3 * wA) / 3; n.j = D - 1 - n.i; }
         n.vit = e % 3;
