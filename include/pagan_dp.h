@@ -215,6 +215,9 @@ int  pagan_batch_debug_scores(pagan_batch *b, int32_t k, double *dst, int64_t co
 int  pagan_batch_debug_backptrs(pagan_batch *b, int32_t k, uint32_t *dst, int64_t count);
 /* diagnostic: overwrite all device outputs with 0xFF (NaN scores) before a run           */
 int  pagan_batch_debug_poison(pagan_batch *b);
+/* Diagnostic: counts[0] = chunks of 16 diagonals of job k whose back-pointers the follower workgroups of the banded fill
+ * wrote while the fill was running, counts[1] = all chunks of the job (0 of 0 for a job of another kernel).          */
+int  pagan_batch_debug_followed(pagan_batch *b, int32_t k, int32_t *counts);
 
 /* The library keeps up to two idle device arenas per device and a few host staging buffers for the next
  * batch (a level of a tree walk is followed by the next; freeing and re-allocating GBs costs tens of ms).

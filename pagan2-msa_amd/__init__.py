@@ -296,6 +296,13 @@ class Batch:
                "pagan_batch_debug_backptrs")
         return out
 
+    def debug_followed(self, k):
+        """Diagnostic: (chunks of 16 diagonals of job k whose back-pointers were written behind the banded fill by its
+        follower workgroups, all chunks of the job); (0, 0) for a job of another kernel."""
+        c = (C.c_int32 * 2)()
+        _check(self._L.pagan_batch_debug_followed(self._h, k, c), "pagan_batch_debug_followed")
+        return int(c[0]), int(c[1])
+
     def cells_of(self, k):
         left, right, _, band = self.jobs[k]
         return self._L.pagan_dp_count_cells(left.n_sites, right.n_sites, C.byref(band.c) if band is not None else None)

@@ -30,7 +30,7 @@
 
 template <int BLOCK> __global__ void pg_fill_wavefront(const PgDevJob *jobs, const int *which, unsigned flags);
 template <bool TAB_LDS> __global__ void pg_fill_ring(const PgDevJob *jobs, const int *which, unsigned flags);
-template <bool TAB_LDS> __global__ void pg_fill_pipe(const PgDevJob *jobs, const int *which, unsigned flags);
+template <bool TAB_LDS> __global__ void pg_fill_pipe(const PgDevJob *jobs, const int *which, unsigned flags, int n_fill);
 __global__ void pg_fill_tiles(const PgDevJob *jobs, const int *tiles, unsigned flags);
 __global__ void pg_fill_tiles_flow(const PgDevJob *jobs, const int *tiles, int n_tiles, int n_diag, int *flow, unsigned flags, int use_water);
 __global__ void pg_end_corner(const PgDevJob *jobs, const int *tiles_gave_up);
@@ -530,6 +530,7 @@ struct pagan_batch {
                                  // 2 (PAGAN_DP_BP=verify, diagnostic builds that still write them in the fill) pg_backptr compares
     int max_bound = 0;           // largest traceback boundary count of any job
     int max_entries = 0;         // most traceback table entries of any job (tb[n_bound + 1])
+    size_t follow_begin = 0, follow_bytes = 0;     // PgDevJob::follow / bp_done of the banded jobs, one block zeroed per launch
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     // per-kernel brackets inside the fill (pagan_batch_last_ms_detail): 0/1 around the banded kernel, 2 behind pg_backptr,
@@ -667,6 +668,19 @@ void carve_ends(Carver &c, int n, PgDevJob *dj) {
     }
 }
 
+// PgDevJob::follow and bp_done of every job of the banded kernel, in one block (zeroed before every launch)
+void carve_follow(Carver &c, int n, const std::vector<HostJob> &jobs, PgDevJob *dj, size_t *begin, size_t *bytes) {
+    *begin = (c.cur + 255) & ~(size_t)255;
+    c.cur = *begin;
+    for (int k = 0; k < n; ++k) {
+        dj[k].follow = nullptr; dj[k].bp_done = nullptr;
+        if (jobs[k].cls.empty()) continue;
+        dj[k].follow = c.take<int>(4);
+        dj[k].bp_done = c.take<unsigned char>((((size_t)dj[k].nd + PG_FOLLOW_CHUNK - 1) / PG_FOLLOW_CHUNK + 15) & ~(size_t)15);
+    }
+    *bytes = c.cur - *begin;
+}
+
 // Host staging buffers are reused across batches: a level's upload is hundreds of MB, and fresh zeroed pages
 // for it every time cost more than filling them (46 -> 20 ms for the 244 MB of cfg4's leaf level).
 struct StagePool {
@@ -755,12 +769,21 @@ int launch_fill(pagan_batch *b) {
         const int n_small = b->n_ring_small, n_big = b->n_ring - b->n_ring_small;
         HIP_TRY(hipEventRecord(b->evk[0], b->stream)); b->evk_set[0] = true;
         if (b->use_pipe) {
+            // Follower workgroups behind the fill's (dp_pipe.hip, pipe_follower): they write the back-pointers of the diagonals
+            // whose scores have landed while the fill goes on, on compute units the banded fill leaves idle.  Workgroup g of
+            // a dispatch runs on XCD g % 8 and a follower serves the fill workgroups of its own XCD (it shares their L2), so
+            // eight followers per round of eight jobs are the unit; what they do not get to is left to pg_backptr below.
+            bool follow = b->bp_pass == 1 && b->follow_bytes > 0;
+            if (const char *f = std::getenv("PAGAN_DP_FOLLOW")) follow = follow && std::strcmp(f, "0") != 0;
+            if (b->follow_bytes > 0) HIP_TRY(hipMemsetAsync(b->arena.dev + b->follow_begin, 0, b->follow_bytes, b->stream));
+            // (a dispatch of more than 32 jobs fills the chip by itself: pg_backptr afterwards, on every unit, is the faster pass)
+            auto followers = [&](int n_fill) { return follow && n_fill <= 32 ? std::min(96, 48 * ((n_fill + 7) / 8)) : 0; };
             if (n_small > 0)
-                hipLaunchKernelGGL(pg_fill_pipe<true>, dim3(n_small), dim3(pg_pipe_block()), 0 /* its LDS is static */, b->stream,
-                                   b->d_jobs, b->d_which, b->flags);
+                hipLaunchKernelGGL(pg_fill_pipe<true>, dim3(n_small + followers(n_small)), dim3(pg_pipe_block()), 0 /* its LDS is static */, b->stream,
+                                   b->d_jobs, b->d_which, b->flags, n_small);
             if (n_big > 0)
-                hipLaunchKernelGGL(pg_fill_pipe<false>, dim3(n_big), dim3(pg_pipe_block()), 0, b->stream,
-                                   b->d_jobs, b->d_which + n_small, b->flags);
+                hipLaunchKernelGGL(pg_fill_pipe<false>, dim3(n_big + followers(n_big)), dim3(pg_pipe_block()), 0, b->stream,
+                                   b->d_jobs, b->d_which + n_small, b->flags, n_big);
             HIP_TRY(hipEventRecord(b->evk[1], b->stream)); b->evk_set[1] = true;
             if (b->bp_pass) {
                 int max_nd = 1, max_w = 1;
@@ -1253,6 +1276,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     b->out_begin = in_bytes;
     for (int k = 0; k < n; ++k) carve_outputs(sizer, b->jobs[k], &b->dj[k]);
     carve_ends(sizer, n, b->dj.data());
+    carve_follow(sizer, n, b->jobs, b->dj.data(), &b->follow_begin, &b->follow_bytes);
     b->arena.size = sizer.cur;
     b->arena.dev = arena_pool.take(b->device, b->arena.size, &b->arena.cap);
     if (!b->arena.dev) {
@@ -1337,6 +1361,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         rebase(d.table); rebase(d.imin); rebase(d.imax); rebase(d.doff); rebase(d.tb); rebase(d.dsc); if (d.psc) { rebase(d.psc); rebase(d.sched); } rebase(d.fill_status);
         rebase(d.sc); rebase(d.bp);
         rebase(d.trace); rebase(d.endcell); rebase(d.endscore); rebase(d.segs); rebase(d.ttab);
+        if (d.follow) { rebase(d.follow); rebase(d.bp_done); }
     }
     std::memcpy(stage.data() + reinterpret_cast<size_t>(jobs_off), b->dj.data(), sizeof(PgDevJob) * n);
     std::memcpy(stage.data() + reinterpret_cast<size_t>(which_off), which_ring.data(), sizeof(int) * n);
@@ -1515,6 +1540,22 @@ int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
 int pagan_batch_debug_poison(pagan_batch *b) {
     if (!b) return PAGAN_E_ARG;
     HIP_TRY(hipMemsetAsync(b->arena.dev + b->out_begin, 0xFF, b->arena.size - b->out_begin, b->stream));
+    return PAGAN_OK;
+}
+
+// Diagnostic: how many of job k's chunks of PG_FOLLOW_CHUNK diagonals had their back-pointers written behind the fill by
+// the follower workgroups of pg_fill_pipe (the rest were left to pg_backptr); counts[0] = those, counts[1] = all chunks.
+// A job of another kernel reports 0 of 0.
+int pagan_batch_debug_followed(pagan_batch *b, int32_t k, int32_t *counts) {
+    if (!b || k < 0 || k >= b->n || !counts) return PAGAN_E_ARG;
+    counts[0] = counts[1] = 0;
+    if (!b->dj[k].bp_done) return PAGAN_OK;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    const size_t n = ((size_t)b->dj[k].nd + PG_FOLLOW_CHUNK - 1) / PG_FOLLOW_CHUNK;
+    std::vector<unsigned char> flags(n);
+    HIP_TRY(hipMemcpy(flags.data(), b->dj[k].bp_done, n, hipMemcpyDeviceToHost));
+    counts[1] = (int32_t)n;
+    for (unsigned char f : flags) counts[0] += f != 0;
     return PAGAN_OK;
 }
 

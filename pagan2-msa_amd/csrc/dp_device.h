@@ -33,9 +33,10 @@
 #define PG_BP_ADJL 4u
 #define PG_BP_ADJR 8u
 #define PG_MAX_SLOT 16383
-#define PG_SEG 128           // diagonals per traceback segment
+#define PG_SEG 256           // diagonals per traceback segment
 #define PG_BP_DIAGS 64        // diagonals per workgroup of the back-pointer pass (pg_backptr)
 #define PG_BP_CELLS 1024      // ... and cells of each of them (grid.z covers the rest of a wide diagonal)
+#define PG_FOLLOW_CHUNK 16    // diagonals a follower wave of pg_fill_pipe claims at a time (dp_pipe.hip, pipe_follower)
 
 // Geometry of the banded fill kernel (dp_pipe.hip) that the host-side planner (dp_abi.hip:
 // classify_diagonals, schedule_waves) has to agree with.
@@ -89,4 +90,9 @@ struct PgDevJob {
     int *ttab;               // [total][8]: exit i, exit j, exit matrix | kind<<2, cells visited (-1: dead entry),
                              //             the exit cell's own entry (absolute index, -1: none), 3 x pad
     int *segs;               // [2K+8][6]: start i, j, matrix, cells, output offset, pad
+    // back-pointers behind the banded fill (dp_pipe.hip, pipe_follower; null for jobs of the other kernels): zeroed before
+    // every launch
+    int *follow;             // [4]: diagonals whose scores have landed in L2 + 1, the fill workgroup's XCC id + 1, next
+                             //      chunk of PG_FOLLOW_CHUNK diagonals to claim, pad
+    unsigned char *bp_done;  // [ceil(nd / PG_FOLLOW_CHUNK)] 1: the chunk's back-pointers are written (pg_backptr skips it)
 };

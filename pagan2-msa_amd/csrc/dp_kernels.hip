@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void pg_backptr(const PgDevJob *__restrict__ j
     const bool verify = flags & 0x100u;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int end = first + diags_per_block < J.nd ? first + diags_per_block : J.nd;
+    PG_GLOBAL const unsigned char *done = verify ? nullptr : (PG_GLOBAL const unsigned char *)job->bp_done;
     for (int d = first + wave; d < end; d += 4) {
+        if (done && done[d / PG_FOLLOW_CHUNK]) continue;           // written behind the fill (dp_pipe.hip, pipe_follower)
         const pg_i4 cur = J.dsc[d];
         const int lo = cur.x, hi = cur.y;
         if (hi < lo) continue;
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(128) void pg_trace_spec(const PgDevJob *__restrict_
                 while (kb >= 1 && dd < low - 1) { --kb; low -= PG_SEG; }
                 if (kb >= 1 && dd <= low) { kind = EXIT_ENTRY; break; }           // (dd is low or low - 1 now)
             }
-            if (steps >= 4 * PG_SEG) { kind = EXIT_MISS; break; }                 // far enough for one entry: pg_trace_compose walks on from here
+            if (steps >= 2 * PG_SEG) { kind = EXIT_MISS; break; }                 // far enough for one entry: pg_trace_compose walks on from here
             if (!trace_step(J, n, w, tc)) { ok = false; break; }
             ++steps;
         }

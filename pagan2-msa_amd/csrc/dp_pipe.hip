@@ -224,14 +224,20 @@ __device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_
 // far as the diagonal PLOOK ahead needs; the descriptor window follows PLOOK diagonals ahead.  One chunk of rows and one of
 // columns per round, each published as it lands.
 #define PREC_BACK 72              // 64 (a chunk) + 8: the records up to 8 sites before the slowest diagonal's first stay
-__device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lane) {
-    int rows = 0, cols = 0, diags = 0;
+// follow[0] = 1 + the last diagonal whose scores have landed in L2 (PgDevJob::follow; what the follower workgroups wait
+// for): a wave's stores of diagonal d have landed once it completed d + PLAND; published every 16 diagonals or so
+__device__ __forceinline__ void publish_landed(PG_GLOBAL int *follow, int lane, int landed) {
+    if (follow && lane == 0) asm volatile("global_store_dword %0, %1, off" :: "v"(follow), "v"(landed + 1) : "memory");
+}
+__device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lane, PG_GLOBAL int *follow) {
+    int rows = 0, cols = 0, diags = 0, published = -1;
     for (;;) {
         int pmin = flag_load(&PM.progress[0]);
         for (int w = 1; w < PNW; ++w) { const int p = flag_load(&PM.progress[w]); pmin = p < pmin ? p : pmin; }
-        if (flag_load(&PM.abort_flag) != 0) return;
+        if (flag_load(&PM.abort_flag) != 0) { publish_landed(follow, lane, J.nd - 1); return; }   // (the job fails: the followers need not wait)
         const int dcur = pmin + 1;                                 // the slowest wave may be computing this one
-        if (dcur >= J.nd) return;
+        if (dcur >= J.nd) { publish_landed(follow, lane, J.nd - 1); return; }                     // every wave drained before its last flag
+        if (pmin - PLAND >= published + PG_FOLLOW_CHUNK) { published = pmin - PLAND; publish_landed(follow, lane, published); }
         const int da = dcur + PLOOK < J.nd - 1 ? dcur + PLOOK : J.nd - 1;
         const pg_i8 ds = psc[da], dc = psc[dcur];
         int want_rows = ds.y + 5, want_cols = da - ds.x + 4;       // rows <= hi+4, columns <= jmax+3 of diagonal da
@@ -2239,10 +2245,125 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
 #define PSTAMP(k)
 #endif
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Follower workgroups (blockIdx.x >= n_fill of the same dispatch): back-pointers behind the fill.
+//
+// The fill stores scores only; the back-pointers are a function of the stored scores (pg_backptr, dp_kernels.hip) that needs
+// no wave of the dependency chain.  A banded fill occupies 1 - 31 compute units for 45 - 170 ms, so the pass runs WHILE the
+// fill goes on, on units it leaves idle: every wave of a follower workgroup claims chunks of PG_FOLLOW_CHUNK diagonals of a
+// job (an atomic counter per job), waits until the scores of the chunk's predecessors have landed (follow[0], published by
+// the job's loader wave) and writes the chunk's back-pointers.  The kernel ends a few microseconds after the last fill
+// workgroup instead of being followed by a pass over every cell.
+//
+// Scores are read from L2 (sc1 loads: a line of the frontier may sit in this unit's L1 from an earlier diagonal).  L2 is per
+// XCD: a follower serves only fill workgroups of its own XCD.  Workgroups of a dispatch go round the XCDs by index, so
+// follower g looks at the jobs w with w % 8 == g % 8 and checks the XCC id the fill workgroup published; a job whose id
+// differs, or never shows, is left alone.  Every wait is bounded; what no follower wrote (bp_done[chunk] == 0) pg_backptr
+// writes after the kernel, so a follower that gives up costs time, not results.
+__device__ __forceinline__ int peek_l2(PG_GLOBAL const int *p) {
+    int v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ unsigned my_xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 15u;
+}
+
+__device__ __noinline__ void follow_chunk(const PgDevJob *__restrict__ job, int chunk, int lane, unsigned flags) {
+    const View J = load_view(job);
+    const bool no_terminal_edges = flags & 1u;
+    const bool reduced_terminal = !(flags & 2u);
+    const int first = chunk * PG_FOLLOW_CHUNK, end = first + PG_FOLLOW_CHUNK < J.nd ? first + PG_FOLLOW_CHUNK : J.nd;
+    for (int d = first; d < end; ++d) {
+        const pg_i4 cur = J.dsc[d];
+        const int lo = cur.x, hi = cur.y;
+        if (hi < lo) continue;
+        const long long base = ((long long)cur.w << 32) | (unsigned)cur.z;
+        Diag d1 = {0, -1, 0}, d2 = {0, -1, 0};
+        if (d > 0) { const pg_i4 p = J.dsc[d - 1]; d1 = {p.x, p.y, ((long long)p.w << 32) | (unsigned)p.z}; }
+        if (d > 1) { const pg_i4 p = J.dsc[d - 2]; d2 = {p.x, p.y, ((long long)p.w << 32) | (unsigned)p.z}; }
+        for (int i = lo + lane; i <= hi; i += 64) {
+            const int j = d - i;
+            const long long at = base + (i - lo);
+            int l0 = 0, l1 = 0, r0 = 0, r1 = 0;
+            if (i > 0) { l0 = J.offL[i]; l1 = J.offL[i + 1]; }
+            if (j > 0) { r0 = J.offR[j]; r1 = J.offR[j + 1]; }
+            float sm = 0.0f;
+            if (i > 0 && j > 0 && l1 > l0 && r1 > r0) sm = J.table[J.stL[i] + J.stR[j] * J.S];       // VA:1363
+            double bx, by, bm;
+            unsigned px, py, pm;
+            cell_any(J, i, j, l1 - l0, r1 - r0, sm, no_terminal_edges, reduced_terminal,
+                     [&](int p, int q, double &xs, double &ys, double &ms) {
+                         const long long ix = hbm_index(J, d, d1, d2, p, q);
+                         xs = ys = ms = neg_inf();
+                         if (ix >= 0) far_cell((PG_GLOBAL const double *)(J.sc + 3 * ix), xs, ys, ms);
+                     },
+                     [&](int k, int &p, double &lw) { p = J.srcL[l0 + k]; lw = (double)J.lwL[l0 + k]; },
+                     [&](int k, int &q, double &rw) { q = J.srcR[r0 + k]; rw = (double)J.lwR[r0 + k]; },
+                     bx, by, bm, px, py, pm);
+            typedef unsigned u3 __attribute__((ext_vector_type(3)));
+            u3 b; b.x = px; b.y = py; b.z = pm;
+            *(PG_GLOBAL u3 *)(J.bp + 3 * at) = b;
+        }
+    }
+    if (lane == 0) ((PG_GLOBAL unsigned char *)job->bp_done)[chunk] = 1;
+}
+
+__device__ __noinline__ void pipe_follower(const PgDevJob *__restrict__ jobs, const int *__restrict__ which, int n_fill, unsigned flags) {
+    const int lane = threadIdx.x & 63;
+    const unsigned xcc = my_xcc_id();
+    // the jobs of this dispatch whose fill workgroup runs on this XCD (at most four: 31 jobs a dispatch)
+    int mine[4], n_mine = 0;
+    for (int w = (int)(blockIdx.x & 7u); w < n_fill && n_mine < 4; w += 8) {
+        const PgDevJob *__restrict__ job = jobs + which[w];
+        if (!job->follow) continue;
+        int id = 0;
+        for (int spin = 0; spin < 20000 && (id = peek_l2((PG_GLOBAL const int *)job->follow + 1)) == 0; ++spin) __builtin_amdgcn_s_sleep(32);
+        if (id == (int)xcc + 1) mine[n_mine++] = which[w];
+    }
+    unsigned left = (1u << n_mine) - 1u;
+    int idle = 0;
+    const int start = (int)(threadIdx.x >> 6);                    // the waves of a workgroup start at different jobs
+    while (left != 0 && idle < 200000) {
+        bool worked = false;
+        for (int t = 0; t < n_mine; ++t) {
+            const int k = (t + start) % n_mine;
+            if (!(left & (1u << k))) continue;
+            const PgDevJob *__restrict__ job = jobs + mine[k];
+            PG_GLOBAL int *fw = (PG_GLOBAL int *)job->follow;
+            const int nd = job->nd, n_chunks = (nd + PG_FOLLOW_CHUNK - 1) / PG_FOLLOW_CHUNK;
+            const int next = peek_l2(fw + 2);
+            if (next >= n_chunks) { left &= ~(1u << k); continue; }
+            // a chunk's cells read the diagonals below its last one: claim it once those have landed
+            const int last = (next + 1) * PG_FOLLOW_CHUNK - 1 < nd - 1 ? (next + 1) * PG_FOLLOW_CHUNK - 1 : nd - 1;
+            if (peek_l2(fw) < last) continue;                      // (follow[0] = landed + 1 >= last: diagonals <= last - 1 are there)
+            int c = 0;
+            if (lane == 0) c = __hip_atomic_fetch_add(fw + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c = __builtin_amdgcn_readfirstlane(c);
+            if (c >= n_chunks) { left &= ~(1u << k); continue; }
+            // (another wave may have taken `next` in between: c is a later chunk, wait for it)
+            const int lastc = (c + 1) * PG_FOLLOW_CHUNK - 1 < nd - 1 ? (c + 1) * PG_FOLLOW_CHUNK - 1 : nd - 1;
+            int spin = 0;
+            while (peek_l2(fw) < lastc && spin < 200000) { __builtin_amdgcn_s_sleep(32); ++spin; }
+            if (spin >= 200000) return;                            // the fill stopped publishing: pg_backptr writes this chunk
+            follow_chunk(job, c, lane, flags);
+            worked = true;
+        }
+        if (worked) idle = 0; else { __builtin_amdgcn_s_sleep(64); ++idle; }
+    }
+}
+
 template <bool TAB_LDS>
 __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restrict__ jobs, const int *__restrict__ which,
-                                                         unsigned flags) {
+                                                         unsigned flags, int n_fill) {
+    if ((int)blockIdx.x >= n_fill) { pipe_follower(jobs, which, n_fill, flags); return; }
     const PgDevJob *__restrict__ job = jobs + which[blockIdx.x];
+    if (threadIdx.x == 0 && job->follow) {
+        const int id = (int)my_xcc_id() + 1;
+        asm volatile("global_store_dword %0, %1, off" :: "v"((PG_GLOBAL int *)job->follow + 1), "v"(id) : "memory");
+    }
     const cdesc8_p psc = (cdesc8_p)job->psc;
     const bool no_terminal_edges = flags & 1u;
     const bool reduced_terminal = !(flags & 2u);
@@ -2272,7 +2393,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
 #endif
     if (tid >= PNT + 64 * PNA) {
         const View J = load_view(job);
-        pipe_loader(J, psc, lane);
+        pipe_loader(J, psc, lane, (PG_GLOBAL int *)job->follow);
         return;
     }
     if (tid >= PNT) {
@@ -2721,5 +2842,5 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
     }
 }
 
-template __global__ void pg_fill_pipe<true>(const PgDevJob *, const int *, unsigned);
-template __global__ void pg_fill_pipe<false>(const PgDevJob *, const int *, unsigned);
+template __global__ void pg_fill_pipe<true>(const PgDevJob *, const int *, unsigned, int);
+template __global__ void pg_fill_pipe<false>(const PgDevJob *, const int *, unsigned, int);

@@ -146,3 +146,29 @@ def test_a_codon_sized_table_on_the_banded_kernel(pg, oracle, seed):
     model = synth.random_model(S, seed)
     assert pg.debug_route(left, right, model, band)[0] == "pg_fill_pipe (large table)"
     same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band), "seed %d" % seed)
+
+
+def test_back_pointers_are_written_behind_the_fill_and_equal_the_pass_afterwards(pg, oracle, monkeypatch):
+    """The follower workgroups of pg_fill_pipe write the back-pointers of the diagonals whose scores have landed while the
+    fill is still running (poisoned arena: a chunk read too early would see NaN scores); pg_backptr afterwards only writes
+    what they left.  Same words as with the followers switched off (PAGAN_DP_FOLLOW=0: pg_backptr writes everything), and
+    most chunks must have come from the followers."""
+    jobs = [banded_job(s) for s in (0, 1, 3)] + [banded_job(2, max_span=8)]
+    words, followed = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PAGAN_DP_FOLLOW", mode)
+        b = pg.Batch(jobs)
+        for rep in range(2):                             # the second run finds the first one's flags and words in the arena
+            pg.lib().pagan_batch_debug_poison(b._h)
+            b.run(); b.sync()
+        words[mode] = [b.debug_backptrs(k) for k in range(len(jobs))]
+        followed[mode] = [b.debug_followed(k) for k in range(len(jobs))]
+        res = b.fetch()
+        for k, (left, right, model, band) in enumerate(jobs):
+            same(res[k], oracle.dp_align(left, right, model, band), "job %d, followers %s" % (k, mode))
+        b.close()
+    for k in range(len(jobs)):
+        assert np.array_equal(words["0"][k], words["1"][k]), "job %d" % k
+        assert followed["0"][k][0] == 0 and followed["0"][k][1] > 50
+        done, total = followed["1"][k]
+        assert total == followed["0"][k][1] and done >= 0.9 * total, "job %d: the followers wrote %d of %d chunks" % (k, done, total)
