@@ -294,6 +294,10 @@ def bench_one_gpu(args, device):
         route = pg.debug_route(left, right, model, band)[0].split(" ")[0]
         routed[route] = routed.get(route, 0) + int(infos[k].cells)
     kmean = kern_ms.mean(axis=0)                               # [level, kernel]
+    # the banded fill's dispatches of at most 32 alignments carry follower workgroups that write the back-pointers while the
+    # fill runs (dp_pipe.hip, pipe_follower; PAGAN_DP_FOLLOW=0 switches them off); a workload with wider levels is accounted
+    # as if it had none
+    follow_on = os.environ.get("PAGAN_DP_FOLLOW") != "0" and max(len(ks) for ks in by_level) <= 32
     per_kernel = []
     for q, name in enumerate(KERNELS):
         t_ms = float(kmean[:, q].sum())
@@ -302,8 +306,13 @@ def bench_one_gpu(args, device):
             continue
         kcells = cells if name == "pg_backptr" else routed.get(name, 0)
         if name == "pg_backptr":
-            kcells = routed.get("pg_fill_pipe", 0) + routed.get("pg_fill_tiles_flow", 0)
+            # (behind a banded fill with follower workgroups it only looks at the chunks' flags)
+            kcells = (0 if follow_on else routed.get("pg_fill_pipe", 0)) + routed.get("pg_fill_tiles_flow", 0)
+            if kcells == 0:
+                continue
             kbytes = 36                                        # 24 B of scores read (neighbours out of L2) + 12 B written per cell
+        elif name == "pg_fill_pipe" and follow_on:
+            kbytes = 36                                        # scores by the fill's workgroups + back-pointers by its follower workgroups (they read the scores out of L2)
         else:
             kbytes = BYTES_PER_CELL if name == "pg_fill_wavefront" else 24    # the banded and the tiled fill store scores only since round 3
         ach = kbytes * kcells / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0

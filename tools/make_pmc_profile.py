@@ -85,8 +85,9 @@ def main():
         "kernels": per_kernel,
         "note": "FETCH_SIZE left uncorrected (the x2 gfx950 correction of MI355X_MICROARCH.md is calibrated on 16 B/lane streaming "
                 "reads; these kernels read scalars, 4-24 B records and cells): fetch_bytes_* are raw counter sums.  Round 3: the "
-                "fill kernels store 24 B of scores per cell, pg_backptr reads them back (mostly out of L2) and writes the 12 B of "
-                "back-pointers.",
+                "fill kernels store 24 B of scores per cell; the 12 B of back-pointers are written by the banded fill's follower "
+                "workgroups while it runs (they read the scores back out of L2), by pg_backptr afterwards for the tiled fill "
+                "and for what the followers left.",
     }
     json.dump(out, open(dst, "w"), indent=1)
     for p in per_kernel:
