@@ -581,16 +581,14 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
             widest = std::max(widest, e);
         }
         hj->tb[hj->n_bound + 1] = run;
-        // The segmented traceback chases from EVERY cell of every boundary: worth it for a narrow
-        // band over a long path (2 x 100 kb: 2.6e5 chases of 128 cells against one chase of 2e5),
-        // wasteful for a short path through a full matrix (thousands of cells per boundary).  Fall
-        // back to the single serial chase (pg_trace_compose with no boundaries) in that case.
-        // Measured: a chase of PG_SEG cells takes ~PG_SEG us (a chain of dependent L2 / HBM reads) and a boundary's entries are
-        // dealt over the 128 threads of one workgroup; the serial chase costs 0.3 - 1.4 us per cell of the path.  So: short
-        // paths serially; paths under 20,000 cells segmented only through a narrow band (512 leaves of 10 kb: 13.7 -> 4.7 ms;
-        // 16 x 2 kb full matrices stay serial: 2 ms against 12); anything whose speculative work dwarfs the path serially.
+        // The segmented traceback chases from EVERY cell of every boundary: 2 x cells chase steps of speculative work, dealt
+        // one table entry per thread over the whole chip (pg_trace_spec), against one lane's serial chase of Lx + Ly
+        // dependent reads at 0.3 - 1.4 us each (pg_trace_compose with no boundaries).  Measured (round 3, one thread per
+        // entry): 16 x 2 kb full matrices 2.0 -> 0.8 ms per level, the full-matrix top levels of 512 x 10 kb 13 -> 7 ms;
+        // only very short paths, or matrices ten thousand cells wide on average, are left to the serial chase.
         const long long speculative = (long long)run / 3 * PG_SEG, serial = (long long)hj->Lx + hj->Ly;
-        if (serial < 2000 || (serial < 20000 && widest > 3000) || speculative > 2000 * serial) {
+        (void)widest;
+        if (serial < 2000 || speculative > 20000 * serial) {
             hj->n_bound = 0;
             hj->tb.assign(2, 0);
         }
@@ -1139,8 +1137,8 @@ int64_t pagan_dp_count_cells(int32_t left_sites, int32_t right_sites, const paga
 }
 
 // Device bytes for one alignment (an upper bound of what carve_job / carve_outputs lay out): 36 B per in-band
-// cell (3 x (f64 score + u32 back-pointer)) + 1.5 B per cell of traceback tables (32 B per state of the two
-// boundary diagonals in every PG_SEG = 128) + per diagonal 64 B of band index, descriptors and plan + per site 12 B of
+// cell (3 x (f64 score + u32 back-pointer)) + at most 1.5 B per cell of traceback tables (32 B per state of the two
+// boundary diagonals in every PG_SEG = 256: 0.75 B) + per diagonal 64 B of band index, descriptors and plan + per site 12 B of
 // trace buffer and ~20 B of graph arrays (one to two bwd edges per site), all 256-byte aligned.
 int64_t pagan_dp_predict_bytes(int32_t left_sites, int32_t right_sites, const pagan_band *band) {
     int64_t cells = pagan_dp_count_cells(left_sites, right_sites, band);
