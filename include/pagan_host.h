@@ -46,8 +46,8 @@ typedef struct pagan_msa_opts {
                                     fasta_reader.cpp:1303-1336), 1 = DNA, 2 = protein (WAG,
                                     211-letter alphabet, model_factory.cpp:304-632,1478-1595),
                                     3 = DNA read as codons (--codons: 1892 states, rows of three
-                                    characters per column; aligned over the full matrix, the
-                                    anchoring of translated codon strings is not built)           */
+                                    characters per column; anchors are found in the codon
+                                    strings' translation, viterbi_alignment.cpp:54-60)            */
     int32_t  pileup_rates;       /* ins = del = 0.25: --454/--homopolymer with --pileup-alignment
                                     (model_factory.cpp:1901-1905)                                  */
     int32_t  anchor_mode;        /* 0 = order-conflict filter + Find_anchors::define_tunnel
@@ -242,6 +242,10 @@ int  pagan_codon_model(double distance, float *table, float *params, int32_t *pa
  * alphabet, model_factory.cpp:1739-1803; its first 62 entries are the leaf alphabet, model_factory.h:209-221);
  * mostcommon [i + j*61] (model_factory.cpp:1208-1217).  Either may be NULL.  Returns the number of states.      */
 int  pagan_codon_alphabet(char *names, int32_t *mostcommon);
+/* Codon_translation::gapped_DNA_to_protein (src/utils/codon_translation.cpp:32-107): one amino-acid letter per triplet of
+ * a codon string ("---" -> '-', X for what the table does not hold) -- the strings the anchors of a codon walk are found in
+ * (viterbi_alignment.cpp:54-60, 141-145).  out holds strlen/3 + 2 bytes.  Returns the number of letters.               */
+int  pagan_codon_translate(const char *codons, char *out);
 /* Leaf states of a nucleotide string read as codons (sequence.cpp:318-336); states holds (strlen+2)/3 entries.
  * Returns the number of states.                                                                                */
 int  pagan_codon_states(const char *nucleotides, int32_t *states);

@@ -82,6 +82,8 @@ def lib():
         L.oracle_codon_model.restype = C.c_int
         L.oracle_codon_alphabet.argtypes = [C.c_char_p, i32p]
         L.oracle_codon_alphabet.restype = C.c_int
+        L.oracle_codon_translate.argtypes = [C.c_char_p, C.c_char_p]
+        L.oracle_codon_translate.restype = C.c_int
         L.oracle_codon_states.argtypes = [C.c_char_p, i32p]
         L.oracle_codon_states.restype = C.c_int
         L.oracle_eigen_qrev.argtypes = [f64p, f64p, C.c_int, f64p, f64p, f64p]
@@ -251,6 +253,13 @@ def codon_states(nucleotides):
     out = np.zeros(len(nucleotides) // 3 + 2, np.int32)
     n = lib().oracle_codon_states(nucleotides.encode(), _ip(out))
     return out[:n].copy()
+
+
+def codon_translate(codon_string):
+    """Codon_translation::gapped_DNA_to_protein: one letter per triplet, X for what the table does not hold."""
+    buf = C.create_string_buffer(len(codon_string) // 3 + 2)
+    n = lib().oracle_codon_translate(codon_string.encode(), buf)
+    return buf.raw[:n].decode()
 
 
 def model_prob(data_type, dist, base_freq=None):

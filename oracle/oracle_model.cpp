@@ -15,6 +15,8 @@
 //                              Model_factory::codon_model                   model_factory.cpp:1624-1805
 //   Factory::alignment()    <- Model_factory::alignment_model               model_factory.cpp:1871-2230
 //   codon_states()          <- Sequence::create_codon_sequence              src/main/sequence.cpp:306-359
+//   oracle_codon_translate  <- Codon_translation::define_translation_tables / gapped_DNA_to_protein
+//                                                                           src/utils/codon_translation.cpp:32-107
 //
 // The product's producer (pagan2-msa_amd/csrc/host_model.cpp) is written differently (one
 // solver object, dense index maps for the pi == 0 case); tests compare the two bit for bit and
@@ -24,6 +26,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -575,6 +578,48 @@ int oracle_codon_states(const char *sequence, int32_t *states) {
         states[n++] = state;
     }
     return n;
+}
+
+// Codon_translation::gapped_DNA_to_protein (codon_translation.cpp:88-107) over the table of
+// define_translation_tables (:32-86): 167 (codon, amino acid) pairs incl. IUPAC-degenerate codons, put into a std::map
+// with insert() -- the FIRST entry of a duplicate key stays ("CTR" is listed under V before L).  out: one character per triplet.
+int oracle_codon_translate(const char *sequence, char *out) {
+    static std::map<std::string, std::string> codon_to_aa;
+    if (codon_to_aa.empty()) {
+        const std::string aa[167] = {"M", "W", "F", "F", "F", "Y", "Y", "Y", "C", "C", "C", "H", "H", "H", "Q", "Q", "Q", "N", "N", "N",
+            "K", "K", "K", "D", "D", "D", "E", "E", "E", "I", "I", "I", "I", "I", "I", "I",
+            "P", "P", "P", "P", "P", "P", "P", "P", "P", "P", "P", "P", "P", "P", "P",
+            "T", "T", "T", "T", "T", "T", "T", "T", "T", "T", "T", "T", "T", "T", "T",
+            "V", "V", "V", "V", "V", "V", "V", "V", "V", "V", "V", "V", "V", "V", "V",
+            "A", "A", "A", "A", "A", "A", "A", "A", "A", "A", "A", "A", "A", "A", "A",
+            "G", "G", "G", "G", "G", "G", "G", "G", "G", "G", "G", "G", "G", "G", "G",
+            "S", "S", "S", "S", "S", "S", "S", "S", "S", "S", "S", "S", "S", "S", "S", "S", "S", "S",
+            "L", "L", "L", "L", "L", "L", "L", "L", "L", "L", "L", "L", "L", "L", "L", "L", "L", "L",
+            "R", "R", "R", "R", "R", "R", "R", "R", "R", "R", "R", "R", "R", "R", "R", "R", "R", "R",
+            "X", "-"};
+        const std::string cod[167] = {"ATG", "TGG", "TTT", "TTC", "TTY", "TAT", "TAC", "TAY", "TGT", "TGC", "TGY", "CAT", "CAC", "CAY",
+            "CAA", "CAG", "CAR", "AAT", "AAC", "AAY", "AAA", "AAG", "AAR", "GAT", "GAC", "GAY", "GAA", "GAG", "GAR",
+            "ATT", "ATC", "ATH", "ATA", "ATY", "ATW", "ATM",
+            "CCT", "CCC", "CCA", "CCG", "CCN", "CCY", "CCR", "CCM", "CCK", "CCS", "CCW", "CCB", "CCD", "CCH", "CCV",
+            "ACT", "ACC", "ACA", "ACG", "ACN", "ACY", "ACR", "ACM", "ACK", "ACS", "ACW", "ACB", "ACD", "ACH", "ACV",
+            "GTT", "GTC", "GTA", "GTG", "GTN", "GTY", "CTR", "GTM", "GTK", "GTS", "GTW", "GTB", "GTD", "GTH", "GTV",
+            "GCT", "GCC", "GCA", "GCG", "GCN", "GCY", "GCR", "GCM", "GCK", "GCS", "GCW", "GCB", "GCD", "GCH", "GCV",
+            "GGT", "GGC", "GGA", "GGG", "GGN", "GGY", "GGR", "GGM", "GGK", "GGS", "GGW", "GGB", "GGD", "GGH", "GGV",
+            "TCT", "TCC", "TCA", "TCG", "AGT", "AGC", "TCN", "TCY", "TCR", "TCM", "TCK", "TCS", "TCW", "TCB", "TCD", "TCH", "TCV", "AGY",
+            "TTA", "TTG", "CTT", "CTC", "CTA", "CTG", "CTN", "CTY", "CTR", "CTM", "CTK", "CTS", "CTW", "CTB", "CTD", "CTH", "CTV", "TTR",
+            "CGT", "CGC", "CGA", "CGG", "AGA", "AGG", "CGN", "CGY", "CGR", "CGM", "CGK", "CGS", "CGW", "CGB", "CGD", "CGH", "CGV", "AGR",
+            "NNN", "---"};
+        for (int i = 0; i < 167; i++) codon_to_aa.insert(std::make_pair(cod[i], aa[i]));
+    }
+    const std::string seq = sequence;
+    std::string prot;
+    for (unsigned int j = 0; j < seq.length(); j += 3) {
+        std::string codon = seq.substr(j, 3);
+        if (codon_to_aa.find(codon) == codon_to_aa.end()) prot += "X";
+        else prot += codon_to_aa.find(codon)->second;
+    }
+    std::memcpy(out, prot.c_str(), prot.size() + 1);
+    return (int)prot.size();
 }
 
 int oracle_model_prob(int data_type, const float *bf, double distance, float *score, float *params) {

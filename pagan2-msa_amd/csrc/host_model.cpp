@@ -351,6 +351,52 @@ std::vector<int32_t> ModelFactory::codon_states(const std::string &nt, std::stri
     return out;
 }
 
+std::string ModelFactory::translate_codons(const std::string &cs) {
+    // The reference's table as "amino acid: its codons" in the table's order; a codon listed twice keeps its FIRST amino
+    // acid (std::map::insert, codon_translation.cpp:83-86): CTR is V there (and GTR is missing).  Packed into a 15^3 lookup
+    // over the IUPAC letters once.
+    static const char *const groups[] = {
+        "M ATG", "W TGG", "F TTT TTC TTY", "Y TAT TAC TAY", "C TGT TGC TGY", "H CAT CAC CAY", "Q CAA CAG CAR", "N AAT AAC AAY",
+        "K AAA AAG AAR", "D GAT GAC GAY", "E GAA GAG GAR", "I ATT ATC ATH ATA ATY ATW ATM",
+        "P CCT CCC CCA CCG CCN CCY CCR CCM CCK CCS CCW CCB CCD CCH CCV",
+        "T ACT ACC ACA ACG ACN ACY ACR ACM ACK ACS ACW ACB ACD ACH ACV",
+        "V GTT GTC GTA GTG GTN GTY CTR GTM GTK GTS GTW GTB GTD GTH GTV",
+        "A GCT GCC GCA GCG GCN GCY GCR GCM GCK GCS GCW GCB GCD GCH GCV",
+        "G GGT GGC GGA GGG GGN GGY GGR GGM GGK GGS GGW GGB GGD GGH GGV",
+        "S TCT TCC TCA TCG AGT AGC TCN TCY TCR TCM TCK TCS TCW TCB TCD TCH TCV AGY",
+        "L TTA TTG CTT CTC CTA CTG CTN CTY CTR CTM CTK CTS CTW CTB CTD CTH CTV TTR",
+        "R CGT CGC CGA CGG AGA AGG CGN CGY CGR CGM CGK CGS CGW CGB CGD CGH CGV AGR",
+        "X NNN"};
+    static const char letters[] = "ACGTRYMKWSBDHVN";
+    struct Table {
+        char aa[15 * 15 * 15];
+        static int code(char c) { const char *p = c ? std::strchr(letters, c) : nullptr; return p ? (int)(p - letters) : -1; }
+        Table() {
+            std::memset(aa, 0, sizeof(aa));
+            for (const char *g : groups)
+                for (const char *p = g + 2; *p; p += (p[3] ? 4 : 3)) {
+                    char &slot = aa[(code(p[0]) * 15 + code(p[1])) * 15 + code(p[2])];
+                    if (!slot) slot = g[0];
+                }
+        }
+    };
+    static const Table table;
+    std::string out;
+    out.reserve(cs.size() / 3 + 1);
+    for (size_t j = 0; j < cs.size(); j += 3) {
+        char a = 'X';
+        if (j + 3 <= cs.size()) {
+            if (cs[j] == '-' && cs[j + 1] == '-' && cs[j + 2] == '-') a = '-';
+            else {
+                const int x = Table::code(cs[j]), y = Table::code(cs[j + 1]), z = Table::code(cs[j + 2]);
+                if (x >= 0 && y >= 0 && z >= 0 && table.aa[(x * 15 + y) * 15 + z]) a = table.aa[(x * 15 + y) * 15 + z];
+            }
+        }
+        out.push_back(a);
+    }
+    return out;
+}
+
 // Model_factory::define_codon_alphabet + codon_model, model_factory.cpp:839-1217, 1599-1805.
 void ModelFactory::init_codon() {
     type = kCodon; char_as = 61; S = 61 + 1 + 1830;

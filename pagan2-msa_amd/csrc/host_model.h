@@ -73,6 +73,10 @@ struct ModelFactory {
     // Sequence::create_codon_sequence (src/main/sequence.cpp:318-336): one state per triplet, 61 (NNN) for anything that
     // is not a sense codon -- a last partial triplet included.  symbols (optional) gets the triplet or "NNN" per state.
     static std::vector<int32_t> codon_states(const std::string &nucleotides, std::string *symbols = nullptr);
+    // Codon_translation::gapped_DNA_to_protein (src/utils/codon_translation.cpp:32-107): one amino-acid letter per triplet
+    // of a codon string ("---" -> '-', IUPAC-degenerate codons that still name one amino acid -> that one, anything else
+    // X) -- what the reference anchors codon graphs on (viterbi_alignment.cpp:54-60, 141-145)
+    static std::string translate_codons(const std::string &codon_string);
     // ins = del = 0.25 for --454/--homopolymer with --pileup-alignment (model_factory.cpp:1901-1905)
     EvolModel alignment_model(double distance, bool pileup_rates = false) const;
 };

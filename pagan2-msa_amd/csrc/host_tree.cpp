@@ -345,7 +345,6 @@ int pagan_msa_create(int32_t n_seqs, const char *const *names, const char *const
         m->mf.init_dna(bf);
     } else if (type == kCodon) {
         m->mf.init_codon();
-        m->opts.use_anchors = 0;      // the reference anchors codon graphs on their translation (viterbi_alignment.cpp:54-60); not built: full matrix
     } else {
         m->mf.init_protein();
     }
@@ -410,21 +409,24 @@ void prepare_node(pagan_msa *m, int id, int round) {
     if (m->opts.use_anchors) {
         AnchorSettings as;
         as.offset = m->opts.anchors_offset; as.prefix_hit_length = m->opts.prefix_hit_length; as.hit_trim = m->opts.hit_trim;
-        const std::string &alpha = m->mf.ancestral_alphabet;
+        // what the anchors are looked for in: the graph's string, or -- codon graphs -- its translation, one letter per site
+        // (viterbi_alignment.cpp:54-60, 141-145)
+        const bool codons = m->mf.type == kCodon;
+        const std::string &alpha = codons ? m->mf.codon_names : m->mf.ancestral_alphabet;
+        auto str = [&](const SeqGraph &g, bool with_gaps) {
+            return codons ? ModelFactory::translate_codons(sequence_string(g, with_gaps, alpha)) : sequence_string(g, with_gaps, alpha);
+        };
         if (m->opts.anchor_mode == 1) {
             // the reference's BLAST branch from the hit list onwards (viterbi_alignment.cpp:148-157): hits here are the
             // prefix anchors, sorted by length as find_long_substrings leaves them
             std::vector<Hit> hits;
-            prefix_hits(sequence_string(gl, false, alpha), sequence_string(gr, false, alpha), as.prefix_hit_length, &hits);
+            prefix_hits(str(gl, false), str(gr, false), as.prefix_hit_length, &hits);
             drop_bad_hits(&hits, (unsigned)m->opts.overlap_total, (unsigned)m->opts.overlap_partly);
             w.upper.clear(); w.lower.clear(); w.blocks.clear();
-            hits_to_band_overlapping(hits, sequence_string(gl, true, alpha), sequence_string(gr, true, alpha), as.offset,
-                                     &w.upper, &w.lower, &w.blocks);
+            hits_to_band_overlapping(hits, str(gl, true), str(gr, true), as.offset, &w.upper, &w.lower, &w.blocks);
             w.n_hits = (int)hits.size();
         } else {
-            w.n_hits = define_tunnel(sequence_string(gl, false, alpha), sequence_string(gr, false, alpha),
-                                     sequence_string(gl, true, alpha), sequence_string(gr, true, alpha), as,
-                                     &w.upper, &w.lower);
+            w.n_hits = define_tunnel(str(gl, false), str(gr, false), str(gl, true), str(gr, true), as, &w.upper, &w.lower);
         }
         w.pb.n = (int32_t)w.upper.size(); w.pb.upper = w.upper.data(); w.pb.lower = w.lower.data();
         w.banded = true;
@@ -1039,6 +1041,13 @@ int pagan_codon_alphabet(char *names, int32_t *mostcommon) {
     if (names) std::memcpy(names, mf.codon_names.c_str(), mf.codon_names.size() + 1);
     if (mostcommon) std::memcpy(mostcommon, mf.mostcommon.data(), sizeof(int32_t) * mf.mostcommon.size());
     return mf.S;
+}
+
+int pagan_codon_translate(const char *codons, char *out) {
+    if (!codons || !out) return PAGAN_E_ARG;
+    const std::string p = ModelFactory::translate_codons(codons);
+    std::memcpy(out, p.c_str(), p.size() + 1);
+    return (int)p.size();
 }
 
 int pagan_codon_states(const char *nucleotides, int32_t *states) {

@@ -130,6 +130,8 @@ def _lib():
         L.pagan_codon_model.restype = C.c_int
         L.pagan_codon_alphabet.argtypes = [C.c_char_p, _i32p]
         L.pagan_codon_alphabet.restype = C.c_int
+        L.pagan_codon_translate.argtypes = [C.c_char_p, C.c_char_p]
+        L.pagan_codon_translate.restype = C.c_int
         L.pagan_codon_states.argtypes = [C.c_char_p, _i32p]
         L.pagan_codon_states.restype = C.c_int
         L.pagan_hgraph_leaf_codon.argtypes = [C.c_char_p]
@@ -195,7 +197,7 @@ HOST_EXPORTED = ["pagan_assign_units", "pagan_msa_default_opts", "pagan_msa_crea
                  "pagan_hgraph_attrs", "pagan_hgraph_fwd", "pagan_hgraph_string", "pagan_hgraph_free",
                  "pagan_define_tunnel", "pagan_prefix_hits", "pagan_anchors_device_calls", "pagan_drop_bad_hits", "pagan_define_tunnel_overlapping",
                  "pagan_force_gap", "pagan_dna_model", "pagan_protein_model", "pagan_model_prob_table", "pagan_model_alphabets",
-                 "pagan_codon_model", "pagan_codon_alphabet", "pagan_codon_states", "pagan_hgraph_leaf_codon",
+                 "pagan_codon_model", "pagan_codon_alphabet", "pagan_codon_states", "pagan_codon_translate", "pagan_hgraph_leaf_codon",
                  "pagan_eigen_qrev", "pagan_msa_ready", "pagan_msa_remaining", "pagan_msa_node_cost",
                  "pagan_msa_align_nodes", "pagan_msa_export_result", "pagan_msa_import_result", "pagan_msa_finish",
                  "pagan_msa_data_type", "pagan_msa_node_device", "pagan_msa_set_batch_backend",
@@ -398,6 +400,15 @@ def codon_alphabet():
     mc = np.zeros(61 * 61, np.int32)
     _lib().pagan_codon_alphabet(buf, _ip(mc))
     return buf.value.decode(), mc
+
+
+def codon_translate(codon_string):
+    """One amino-acid letter per triplet (Codon_translation::gapped_DNA_to_protein)."""
+    buf = C.create_string_buffer(len(codon_string) // 3 + 2)
+    n = _lib().pagan_codon_translate(codon_string.encode(), buf)
+    if n < 0:
+        raise RuntimeError("pagan_codon_translate failed: %d" % n)
+    return buf.raw[:n].decode()
 
 
 def codon_states(nucleotides):

@@ -6,44 +6,37 @@ import pytest
 
 from pagan2_msa_amd import host, synth
 
-from test_codon_cpu import CODONS, evolve_codons, oracle_codon_leaf
+from test_codon_cpu import CODONS, evolve_codons, oracle_codon_walk
 from test_host_cpu import same_graph
 from test_pipe_gpu import banded_job, same
 
 pytestmark = pytest.mark.gpu
 
 
-def test_tree_walk_on_codons_on_the_device(pg, oracle):
-    """16 leaves of ~250 codons: every node's alignment (full matrix, the tiled kernel staging scores out of the 1892 x 1892
-    table) against the oracle on the node's own inputs AND against the same walk made from the oracle's pieces."""
-    names, seqs, nwk = evolve_codons(16, 250, seed=12, branch=0.05, sub=0.08, indel_start=0.012, mean_len=3)
+@pytest.mark.parametrize("anchors", [0, 1])
+def test_tree_walk_on_codons_on_the_device(pg, oracle, anchors):
+    """16 leaves of ~250 codons: every node's alignment (the 1892 x 1892 table stays in HBM / L2: the tiled kernel stages
+    scores out of it, the banded kernel's assist waves gather them) against the same walk made from the oracle's pieces;
+    with anchors the bands come from the translated codon strings."""
+    names, seqs, nwk = evolve_codons(16, 250, seed=12, branch=0.03, sub=0.04, indel_start=0.012, mean_len=3)
     seqs[4] = seqs[4][:60] + "TAA" + seqs[4][63:]
     seqs[9] = seqs[9] + "AC"                                            # a last partial triplet
-    msa = host.Msa(names, seqs, nwk, data_type=3).align()
+    msa = host.Msa(names, seqs, nwk, data_type=3, use_anchors=anchors, prefix_hit_length=8, anchors_offset=6).align()
     assert msa.data_type == 3
-    by_name = dict(zip(names, seqs))
-    scores = []
-
-    def rec(t):
-        if t[0] == "leaf":
-            return oracle_codon_leaf(oracle, by_name[t[1]]), (min(max(t[2], 0.001), 0.2) if t[2] > 0 else 0.001)
-        ol, dl = rec(t[1])
-        orr, dr = rec(t[2])
-        model, opars = oracle.codon_model(dl + dr)
-        res = oracle.dp_align(ol.flatten(), orr.flatten(), model, None)
-        scores.append(res)
-        d = t[3]
-        return oracle.OGraph.parent(ol, orr, res, dl, dr, opars, 61, 0), (0.001 if d <= 0 else min(d, 0.2))
-    root, _ = rec(synth.parse_newick(nwk))
-    assert msa.n_internal == len(scores) == 15
-    states = set()
-    for k, want in enumerate(scores):
+    results, root, banded = oracle_codon_walk(oracle, names, seqs, nwk, anchors=bool(anchors), hit_length=8, trim=5, offset=6)
+    assert msa.n_internal == len(results) == 15
+    states, routes = set(), set()
+    for k, want in enumerate(results):
         got = msa.node_result(k)
         assert got.same_alignment(want), "node %d differs" % k
         left, right, model, band = msa.node_job(k)
-        assert band is None and model.n_states == 1892
+        assert (band is not None) == bool(anchors) and model.n_states == 1892
+        routes.add(pg.debug_route(left, right, model, band)[0])
         states.update(left.state.tolist())
     assert max(states) > 61                                              # pair codes entered later alignments
+    assert routes <= {"pg_fill_pipe (large table)", "pg_fill_tiles_flow"}
+    if anchors:
+        assert banded >= 8 and "pg_fill_pipe (large table)" in routes
     same_graph(msa.node_graph(30), root, "root")
     for r, s in zip(msa.alignment(), seqs):
         cod = [r[i:i + 3] for i in range(0, len(r), 3)]
