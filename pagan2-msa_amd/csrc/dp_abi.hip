@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <type_traits>
@@ -1593,7 +1594,31 @@ void pagan_batch_destroy(pagan_batch *b) {
         gpu_pool.give(b->device, o);
     }
     if (b->arena.dev) arena_pool.give(b->device, b->arena.dev, b->arena.cap);
-    delete b;
+    // What is left is host memory only (plans, band indices, compaction maps: megabytes per alignment, milliseconds of
+    // unmapping per level of a tree walk): freed by a background thread, off the caller's path.
+    struct Reaper {
+        std::mutex m;
+        std::condition_variable cv;
+        std::vector<pagan_batch *> q;
+        bool stop = false;
+        std::thread th;
+        Reaper() : th([this] {
+            for (;;) {
+                std::vector<pagan_batch *> take;
+                {
+                    std::unique_lock<std::mutex> l(m);
+                    cv.wait(l, [this] { return stop || !q.empty(); });
+                    take.swap(q);
+                    if (take.empty() && stop) return;
+                }
+                for (pagan_batch *x : take) delete x;
+            }
+        }) {}
+        ~Reaper() { { std::lock_guard<std::mutex> l(m); stop = true; } cv.notify_one(); th.join(); }
+        void give(pagan_batch *x) { { std::lock_guard<std::mutex> l(m); q.push_back(x); } cv.notify_one(); }
+    };
+    static Reaper reaper;
+    reaper.give(b);
 }
 
 int pagan_dp_align_batch(int32_t n, const pagan_job *jobs, const pagan_opts *opts, pagan_result *out) {

@@ -114,6 +114,32 @@ SeqGraph make_leaf_states(const std::vector<int32_t> &states, std::string symbol
     SeqGraph g;
     g.terminal = true;
     g.sym_width = sym_width;
+    if (!(flags & (kLeaf454 | kLeafHomopolymer))) {
+        // A plain leaf is a chain: site k's one bwd edge is edge k from site k-1 (edge 0 is the reference's unlinked first
+        // edge, sequence.cpp:164-165), its one fwd edge is edge k+1.  Written straight into the arrays -- what the general
+        // code below builds edge by edge (a 100 kb leaf: 11 ms there, 32 of them per walk).
+        const int n = (int)states.size() + 2;
+        g.symbols = std::move(symbols);
+        g.state.resize(n); g.state[0] = -1; g.state[n - 1] = -1;
+        std::copy(states.begin(), states.end(), g.state.begin() + 1);
+        g.site_type.assign(n, (int8_t)kRealSite); g.site_type[0] = (int8_t)kStartSite; g.site_type[n - 1] = (int8_t)kStopSite;
+        g.path_state.assign(n, (int8_t)kTerminal); g.path_state[0] = (int8_t)kEnds; g.path_state[n - 1] = (int8_t)kEnds;
+        g.child_l.assign(n, -1); g.child_r.assign(n, -1);
+        g.count_since_used.assign(n, 0); g.dist_since_used.assign(n, 0.0f); g.ambiguous.assign(n, 0);
+        g.e_start.resize(n); g.e_end.resize(n);
+        for (int e = 0; e < n; ++e) { g.e_start[e] = e - 1; g.e_end[e] = e; }
+        g.e_w.assign(n, 1.0f); g.e_logw.assign(n, 0.0f);
+        g.e_count_since_used.assign(n, 0); g.e_count_as_skipped.assign(n, 0); g.e_dist_since_used.assign(n, 0.0f); g.e_used.assign(n, 0);
+        g.bwd_off.resize(n + 1); g.fwd_off.resize(n + 1);
+        g.bwd_off[0] = 0;
+        for (int k = 1; k <= n; ++k) g.bwd_off[k] = k - 1;
+        for (int k = 0; k < n; ++k) g.fwd_off[k] = k;
+        g.fwd_off[n] = n - 1;
+        g.bwd_eid.resize(n - 1); g.fwd_eid.resize(n - 1); g.bwd_src.resize(n - 1);
+        for (int k = 0; k < n - 1; ++k) { g.bwd_eid[k] = k + 1; g.fwd_eid[k] = k + 1; g.bwd_src[k] = k; }
+        g.bwd_logw.assign(n - 1, 0.0f);
+        return g;
+    }
     reserve_sites(g, states.size() + 2);
     g.symbols = std::move(symbols);
     push_site(g, -1, kStartSite, kEnds, -1, -1);

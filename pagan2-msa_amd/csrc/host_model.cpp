@@ -198,27 +198,25 @@ int eigen_qrev(const double *Q, const double *pi, int n, double *root, double *U
 }
 
 int ModelFactory::guess_type(const std::vector<std::string> &seqs) {
+    // (one table look-up per character; the counts are what the reference's two find() calls per character give)
+    bool is_dna[256] = {false}, is_protein[256] = {false};
+    for (const char *p = "ACGTUN"; *p; ++p) is_dna[(unsigned char)*p] = true;
+    for (const char *p = protein_alphabet(); *p; ++p) is_protein[(unsigned char)*p] = true;
     long dna = 0, protein = 0;
     for (const std::string &s : seqs)
-        for (char c : s) {
-            if (std::strchr("ACGTUN", c) && c) ++dna;
-            if (std::strchr(protein_alphabet(), c) && c) ++protein;
-        }
+        for (char c : s) { dna += is_dna[(unsigned char)c]; protein += is_protein[(unsigned char)c]; }
     return ((float)dna) / (float)protein > 0.9 ? kDna : kProtein;
 }
 
 void ModelFactory::base_frequencies(const std::vector<std::string> &seqs, float out[4]) {
-    float c[4] = {0, 0, 0, 0};
+    // The reference counts in floats: a counter stops growing at 2^24 (x + 1.0f rounds back to x there), below that it is
+    // the integer count.
+    long n[256] = {0};
     for (const std::string &s : seqs)
-        for (char ch : s) {
-            switch (ch) {
-            case 'A': c[0]++; break;
-            case 'C': c[1]++; break;
-            case 'G': c[2]++; break;
-            case 'T': c[3]++; break;
-            default: break;
-            }
-        }
+        for (char ch : s) ++n[(unsigned char)ch];
+    float c[4];
+    const char base[4] = {'A', 'C', 'G', 'T'};
+    for (int k = 0; k < 4; ++k) c[k] = (float)std::min(n[(unsigned char)base[k]], 16777216l);
     const float tot = c[0] + c[1] + c[2] + c[3];
     for (int k = 0; k < 4; ++k) out[k] = c[k] / tot;
 }

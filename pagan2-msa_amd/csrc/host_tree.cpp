@@ -294,6 +294,7 @@ int pagan_msa_create(int32_t n_seqs, const char *const *names, const char *const
     // fasta_reader.cpp:138-160: upper case, no gaps, no line ends
     over_leaves([&](int k) {
         std::string s;
+        s.reserve(std::strlen(seqs[k]));
         for (const char *p = seqs[k]; *p; ++p) {
             const char c = (char)std::toupper((unsigned char)*p);
             if (c != '-' && c != '\r' && c != '\n') s.push_back(c);
@@ -304,15 +305,19 @@ int pagan_msa_create(int32_t n_seqs, const char *const *names, const char *const
     int type = m->opts.data_type == 1 ? kDna : m->opts.data_type == 2 ? kProtein : m->opts.data_type == 3 ? kCodon : ModelFactory::guess_type(m->seqs);
     // Fasta_reader::check_alphabet, fasta_reader.cpp:1180-1297: DNA U->T; protein U->X; what is outside the
     // full alphabet is dropped
-    over_leaves([&](int k) {
-        std::string s;
-        const char *keep = type != kProtein ? ModelFactory::dna_full_alphabet() : ModelFactory::protein_alphabet();
-        for (char c : m->seqs[k]) {
-            if (type != kProtein) { if (c == 'U') c = 'T'; if (std::strchr(keep, c)) s.push_back(c); }
-            else { if (c == 'U') c = 'X'; if (c == 'X' || std::strchr(keep, c)) s.push_back(c); }
-        }
-        m->seqs[k].swap(s);
-    });
+    {
+        char keep[256];                                            // 0: dropped, else the character it becomes
+        std::memset(keep, 0, sizeof(keep));
+        for (const char *p = type != kProtein ? ModelFactory::dna_full_alphabet() : ModelFactory::protein_alphabet(); *p; ++p)
+            keep[(unsigned char)*p] = *p;
+        if (type != kProtein) keep[(unsigned char)'U'] = 'T'; else keep[(unsigned char)'U'] = keep[(unsigned char)'X'] = 'X';
+        over_leaves([&](int k) {
+            std::string &s = m->seqs[k];
+            size_t w = 0;
+            for (size_t r = 0; r < s.size(); ++r) { const char c = keep[(unsigned char)s[r]]; if (c) s[w++] = c; }
+            s.resize(w);
+        });
+    }
     Newick nw{newick, &m->tree};
     m->root = nw.parse();
     if (!nw.ok || m->root < 0) return PAGAN_E_TREE;
