@@ -189,7 +189,7 @@ SeqGraph make_parent(SeqGraph &left, SeqGraph &right, const pagan_result &res, f
     SeqGraph g;
     g.sym_width = left.sym_width;
     const int n = res.n_cols + 2;
-    g.state.reserve(n);
+    reserve_sites(g, n);
     // ---- sites: create_ancestral_sequence, basic_alignment.cpp:61-179 ----
     std::vector<int32_t> lci(left.n_sites()), rci(right.n_sites());   // child site -> parent site
     push_site(g, -1, kStartSite, kEnds, 0, 0);
@@ -225,7 +225,7 @@ SeqGraph make_parent(SeqGraph &left, SeqGraph &right, const pagan_result &res, f
 
     // ---- edges: create_ancestral_edges, basic_alignment.cpp:181-368 ----
     Chains ch(g);
-    g.e_start.reserve(left.n_edges() + right.n_edges());
+    ch.reserve_edges((size_t)left.n_edges() + right.n_edges() + 16);
     // transfer_child_edge, basic_alignment.cpp:510-653 (weight_edges / pair_end_reads off)
     auto transfer = [&](const SeqGraph &child, int ce, const std::vector<int32_t> &ci, float branch_length) {
         int s = ci[child.e_start[ce]], e = ci[child.e_end[ce]];
