@@ -39,6 +39,11 @@ WORKLOADS = {
     "cfg3_64x500aa_protein_full": (3, 64, 500, 0.05, 0.04, 0.004, 4.0, 0, "ARNDCQEGHILKMFPSTWYV"),
     "cfg5_512x10kb_dna_anchored": (5, 512, 10000, 0.02, 0.016, 0.0016, 4.0, 1, "ACGT"),
     "smoke_8x3kb_dna_anchored": (0, 8, 3000, 0.01, 0.008, 0.0008, 4.0, 1, "ACGT"),
+    # DNA read as codons (--codons): the empirical codon model's 1892 states, a 14 MB score table per node that stays in
+    # HBM / L2 (the banded kernel's assist waves gather the scores, the tiled kernel stages 64 x 64 of them per tile);
+    # length in codons, anchors found in the translation
+    "codon_16x1500_anchored": (6, 16, 1500, 0.03, 0.04, 0.004, 3.0, 1, "CODON"),
+    "codon_16x1500_full": (6, 16, 1500, 0.03, 0.04, 0.004, 3.0, 0, "CODON"),
     # forward/backward (--full-probability) over the 15 node pairs of cfg2's tree
     "fb_cfg2_16x2kb_dna_full": (2, 16, 2000, 0.05, 0.04, 0.004, 4.0, 0, "ACGT"),
 }
@@ -60,6 +65,13 @@ KERNELS = ("pg_fill_pipe", "pg_backptr", "pg_fill_tiles_flow", "pg_fill_wavefron
 def make_inputs(workload):
     from pagan2_msa_amd import synth
     cfg, leaves, length, branch, sub, indel, mean_len, anchors, alphabet = WORKLOADS[workload]
+    if alphabet == "CODON":
+        # evolved over 61 letters, one per sense codon (the model's order: lexical without TAA, TAG, TGA), written out as triplets
+        codons = [a + b + c for a in "ACGT" for b in "ACGT" for c in "ACGT" if a + b + c not in ("TAA", "TAG", "TGA")]
+        letters = "".join(chr(64 + k) for k in range(61))
+        names, seqs, newick = synth.evolve_balanced(leaves, length, branch=branch, sub=sub, indel_start=indel, mean_len=mean_len,
+                                                    seed=20240807 + cfg, alphabet=letters)
+        return names, ["".join(codons[ord(ch) - 64] for ch in sq) for sq in seqs], newick
     return synth.evolve_balanced(leaves, length, branch=branch, sub=sub, indel_start=indel, mean_len=mean_len,
                                  seed=20240807 + cfg, alphabet=alphabet)
 
@@ -203,13 +215,14 @@ def bench_one_gpu(args, device):
 
     # ---- untimed setup: whole progressive alignment on the GPU (twice: the first walk also pays the process's
     # one-off costs -- code object load, first hipMalloc, staging buffers) ----
+    data_type = 3 if alphabet == "CODON" else 0               # 0: guessed from the residues, as the reference does
     t0 = time.time()
-    msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=device, n_devices=1)
+    msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=device, n_devices=1, data_type=data_type)
     msa.align()
     e2e_wall_cold = time.time() - t0
     del msa
     t0 = time.time()
-    msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=device, n_devices=1)
+    msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=device, n_devices=1, data_type=data_type)
     msa.align()
     e2e_wall = time.time() - t0
     tm = msa.timing()
@@ -337,7 +350,7 @@ def bench_one_gpu(args, device):
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": workload, "leaves": leaves, "length": length, "branch": branch,
-                   "data_type": "protein" if len(alphabet) == 20 else "dna",
+                   "data_type": "codon (1892 states)" if alphabet == "CODON" else "protein" if len(alphabet) == 20 else "dna",
                    "anchors": "prefix, offset 15" if anchors else "none", "node_alignments": n_nodes,
                    "levels": [len(ks) for ks in by_level], "cells_per_step": int(cells),
                    "order": "guide-tree levels one after the other (a parent needs its children)"},
