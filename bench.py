@@ -283,6 +283,14 @@ def bench_one_gpu(args, device):
         ok = ok and rc == 0 and all(abi.Result(res[a]).same_alignment(msa.node_result(k)) for a, k in enumerate(ks))
         for a in range(len(ks)):
             L.pagan_result_free(C.byref(res[a]))
+    # how much of the back-pointer work the banded fill's follower workgroups did in the last timed pass (chunks of 16
+    # diagonals written while the fill ran / all chunks of the banded alignments; the rest was pg_backptr's)
+    followed = [0, 0]
+    for ks, hb in zip(by_level, batches):
+        for a in range(len(ks)):
+            cnt = (C.c_int32 * 2)()
+            if L.pagan_batch_debug_followed(hb, a, cnt) == 0:
+                followed[0] += int(cnt[0]); followed[1] += int(cnt[1])
     for hb in batches:
         L.pagan_batch_destroy(hb)
 
@@ -365,6 +373,7 @@ def bench_one_gpu(args, device):
                      "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_cell"] * dom["cells"] / dom["launches_per_step"],
                      "algorithmic_bytes_per_cell_whole_fill": BYTES_PER_CELL,
                      "kernels": per_kernel,
+                     "back_pointer_chunks_by_followers": {"written_while_the_fill_ran": followed[0], "of": followed[1]},
                      "latency": {"steps": crit_steps, "us_per_step": us_per_step,
                                  "chain_floor_us_per_step": CHAIN_FLOOR_US, "formulation_floor_us_per_step": STEP_FLOOR_US,
                                  "floor_us_per_step": STEP_FLOOR_US, "frac_of_floor": STEP_FLOOR_US / us_per_step,
