@@ -77,7 +77,7 @@ __device__ __forceinline__ long long cell_at(const PgFbJob &J, int p, int q) {
 
 __device__ __forceinline__ double rd(const double *A, long long at, int s) { return at >= 0 ? A[3 * at + s] : ninf(); }
 
-__global__ void pg_fb_forward(const PgFbJob *jobs) {
+__global__ __launch_bounds__(1024) void pg_fb_forward(const PgFbJob *jobs) {
     const PgFbJob J = jobs[blockIdx.x];
     for (int d = 0; d < J.nd; ++d) {
         const int mn = J.imin[d], mx = J.imax[d];
@@ -139,7 +139,7 @@ __global__ void pg_fb_forward(const PgFbJob *jobs) {
     }
 }
 
-__global__ void pg_fb_backward(const PgFbJob *jobs) {
+__global__ __launch_bounds__(1024) void pg_fb_backward(const PgFbJob *jobs) {
     const PgFbJob J = jobs[blockIdx.x];
     for (long long k = threadIdx.x; k < 3 * J.cells; k += blockDim.x) J.B[k] = ninf();
     __syncthreads();
@@ -315,7 +315,10 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     std::memcpy(stage.data() + o_job, &J, sizeof(J));
     fb->dF = J.F; fb->dB = J.B;
     FB_TRY(hipMemcpy(fb->arena, stage.data(), in_bytes, hipMemcpyHostToDevice));
-    const int block = fb->dx.max_width >= 192 ? 256 : (fb->dx.max_width >= 96 ? 128 : 64);
+    // a thread per cell of the widest diagonal, up to the 1024 of a workgroup (a cell is ~20 exp / log1p calls: a thread with
+    // eight cells of a 2,000-cell diagonal was the whole sweep's pace)
+    const int mw = fb->dx.max_width;
+    const int block = mw >= 768 ? 1024 : mw >= 384 ? 512 : mw >= 192 ? 256 : (mw >= 96 ? 128 : 64);
     // the two sweeps are independent of each other: side by side on two streams (a workgroup each)
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     hipStream_t s1 = nullptr, s2 = nullptr;
