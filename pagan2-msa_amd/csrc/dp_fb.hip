@@ -68,6 +68,18 @@ __device__ __forceinline__ double lse(double a, double b) {
     return hi + log1p(exp(lo - hi));
 }
 
+// log(exp(a) + exp(b) + exp(c)) with one log1p: the largest term is factored out, the other two cost an exp each (the chain
+// lse(lse(a, b), c) costs two exp and two log1p; the sums agree to the last few ulps, the tests compare logs to 1e-9)
+__device__ __forceinline__ double lse3(double a, double b, double c) {
+    const double hi = fmax(a, fmax(b, c));
+    if (hi == ninf()) return hi;
+    double rest;
+    if (a == hi) rest = exp(b - hi) + exp(c - hi);
+    else if (b == hi) rest = exp(a - hi) + exp(c - hi);
+    else rest = exp(a - hi) + exp(b - hi);
+    return hi + log1p(rest);
+}
+
 __device__ __forceinline__ long long cell_at(const PgFbJob &J, int p, int q) {
     if (p < 0 || q < 0 || p >= J.Lx || q >= J.Ly) return -1;
     const int d = p + q;
@@ -91,16 +103,14 @@ __global__ __launch_bounds__(1024) void pg_fb_forward(const PgFbJob *jobs) {
                 if (i > 0)
                     for (int k = J.offL[i]; k < J.offL[i + 1]; ++k) {
                         const long long at = cell_at(J, J.srcL[k], j);
-                        fx = lse(fx, rd(J.F, at, 0) + J.l_ext);                    // VA:2153
-                        fx = lse(fx, rd(J.F, at, 1) + J.l_open);                   // VA:2184 (gap_close = 1)
-                        fx = lse(fx, rd(J.F, at, 2) + J.l_ng + J.l_open);          // VA:2215
+                        fx = lse(fx, lse3(rd(J.F, at, 0) + J.l_ext,                 // VA:2153
+                                          rd(J.F, at, 1) + J.l_open,                // VA:2184 (gap_close = 1)
+                                          rd(J.F, at, 2) + J.l_ng + J.l_open));     // VA:2215
                     }
                 if (j > 0)
                     for (int k = J.offR[j]; k < J.offR[j + 1]; ++k) {
                         const long long at = cell_at(J, i, J.srcR[k]);
-                        fy = lse(fy, rd(J.F, at, 1) + J.l_ext);
-                        fy = lse(fy, rd(J.F, at, 0) + J.l_open);
-                        fy = lse(fy, rd(J.F, at, 2) + J.l_ng + J.l_open);
+                        fy = lse(fy, lse3(rd(J.F, at, 1) + J.l_ext, rd(J.F, at, 0) + J.l_open, rd(J.F, at, 2) + J.l_ng + J.l_open));
                     }
                 if (i > 0 && j > 0) {
                     const double sc = J.ltab[J.stL[i] + (long long)J.stR[j] * J.S];
@@ -109,9 +119,9 @@ __global__ __launch_bounds__(1024) void pg_fb_forward(const PgFbJob *jobs) {
                         for (int k2 = J.offR[j]; k2 < J.offR[j + 1]; ++k2) {
                             const long long at = cell_at(J, J.srcL[k1], J.srcR[k2]);
                             const double w = (double)J.lwL[k1] + (double)J.lwR[k2];
-                            fm = lse(fm, rd(J.F, at, 2) + mm + w);                 // VA:2051
-                            fm = lse(fm, rd(J.F, at, 0) + xm + w);                 // VA:2080
-                            fm = lse(fm, rd(J.F, at, 1) + xm + w);                 // VA:2108
+                            fm = lse(fm, lse3(rd(J.F, at, 2) + mm + w,              // VA:2051
+                                              rd(J.F, at, 0) + xm + w,              // VA:2080
+                                              rd(J.F, at, 1) + xm + w));            // VA:2108
                         }
                 }
             }
