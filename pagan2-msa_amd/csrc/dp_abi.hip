@@ -1480,12 +1480,21 @@ int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
         std::memcpy(&f.endscore, ends.data() + kEndStride * (size_t)k + 32, sizeof(double));
         const int nt = f.endcell[0] == 0 ? f.endcell[6] : 0;
         if (nt < 0 || nt > b->jobs[k].Lx + b->jobs[k].Ly) return PAGAN_E_INTERNAL;
-        f.trace.resize(3 * (size_t)nt + 3);
-        if (nt > 0)
-            HIP_TRY(hipMemcpy(f.trace.data(), b->arena.dev + b->trace_off[k], sizeof(int) * 3 * (size_t)nt, hipMemcpyDeviceToHost));
     }
     std::vector<int> rcs(b->n, PAGAN_OK);
     parallel_jobs(b->n, [&](int k) {
+        // (a job's path comes over in its own thread: the copies' host sides -- page pinning, the staging copy -- overlap)
+        {
+            Fetched &f = got[k];
+            const int nt = f.endcell[0] == 0 ? f.endcell[6] : 0;
+            f.trace.resize(3 * (size_t)nt + 3);
+            if (nt > 0) (void)hipSetDevice(b->device);              // (a new thread starts on device 0)
+            if (nt > 0 && hipMemcpy(f.trace.data(), b->arena.dev + b->trace_off[k], sizeof(int) * 3 * (size_t)nt, hipMemcpyDeviceToHost) != hipSuccess) {
+                (void)hipGetLastError();
+                rcs[k] = PAGAN_E_NODEVICE;
+                return;
+            }
+        }
         const CompactJob &cj = b->compact[k];
         if (cj.on && (got[k].endcell[0] == 0 || got[k].endcell[0] == 1)) {
             // the device's path in the caller's site numbers and edge-list positions, then the usual replay on the caller's graphs
