@@ -14,11 +14,12 @@ exactly as a progressive alignment has to (a parent's inputs come from its child
 value = in-band DP cells of the tree / time of that pass.  The same nodes launched side by side as one
 batch (no dependency order; the round-1 headline) are reported as value_resident_batch.
 
-N > 1 GPUs (workload = configs[4]: 512 x 10 kb, branch 0.02, anchored): ONE tree, its ready nodes dealt
-over the N ranks round by round (pagan2_msa_amd.dist.align_sharded: each rank runs model + anchors + DP +
-parent graph for its share on its own GPU, the finished paths are all-gathered, every rank rebuilds the
-other ranks' parents).  A step is one whole progressive alignment; value = cells of the tree / wall-clock
-of the walk (max over ranks): "strong" scaling.  Rank 0 also times the same walk alone on its GPU
+N > 1 GPUs (workload = configs[4]: 512 x 10 kb, branch 0.02, anchored): ONE tree whose ready nodes the N
+ranks take from a dynamic queue in the job's key-value store (pagan2_msa_amd.dist.align_sharded: a rank claims
+ready nodes with an atomic counter per node, runs model + anchors + DP + parent graph for them on its own GPU,
+posts the finished paths under the nodes' keys and imports what the others have posted when it next looks; no
+collective on the data path, no round barrier).  A step is one whole progressive alignment; value = cells of
+the tree / wall-clock of the walk (max over ranks): "strong" scaling.  Rank 0 also times the same walk alone on its GPU
 (value_one_gpu_same_workload) so that a speed-up can be read off one line.  Without torchrun,
 `--gpus N` runs the in-process work queue over N devices of this process instead (one feeder thread
 per device, pagan_msa_align with n_devices = N).
@@ -58,7 +59,7 @@ BYTES_PER_CELL = 36            # 3 states x (f64 score + u32 back-pointer), SURV
 # for each other and overlap their intervals -- a number about something else.)
 CHAIN_FLOOR_US = 2 * 8.4 / 2400.0
 STEP_FLOOR_US = 489 / 2400.0
-PMC_PROFILE = os.path.join("profiles", "r03_pmc_fill.json")
+PMC_PROFILE = os.path.join("profiles", "r04_pmc_fill.json")
 KERNELS = ("pg_fill_pipe", "pg_backptr", "pg_fill_tiles_flow", "pg_fill_wavefront")
 
 
@@ -91,7 +92,8 @@ def main():
     ap.add_argument("--allow-stale-traffic", action="store_true", help="(accepted for older scripts: this is the default now)")
     ap.add_argument("--strict-traffic", action="store_true",
                     help="fail instead of reporting roofline.traffic = null when %s does not describe this run "
-                         "(the profiling scripts use it)" % PMC_PROFILE)
+                         "(for the line that is committed after tools/make_pmc_profile.py; the profiling passes themselves "
+                         "run without it: they are what the profile is made from)" % PMC_PROFILE)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,7 +168,7 @@ def bench_forward_backward(args, device):
     out = {
         "metric": "DP cells/sec of the forward + backward sweeps (--full-probability), %s node pairs" % workload,
         "value": cells / dev_s, "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dev_s, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "ms_per_step": 1e3 * dev_s, "higher_is_better": True, "scaling": None, "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": workload, "leaves": leaves, "length": length, "node_pairs": n_nodes, "cells_per_step": int(cells),
                    "note": "value = cells / wall-clock of a pass with all node pairs in flight at once (2 workgroups per pair); the per-kernel ms are sums of the kernels' own durations; wall per pass incl. allocation and upload: %.1f ms" % (1e3 * elapsed / args.steps)},
@@ -309,16 +311,25 @@ def bench_one_gpu(args, device):
     us_per_step = 1e3 * fill_step_ms / crit_steps
     # per kernel: its cells (the planner's routing of every node, host only), its launches, its time.  The dominant kernel's
     # figures are the roofline object's top-level fields; every kernel of the workload is listed under roofline.kernels.
-    routed = {}
+    routed, route_of = {}, {}
     for k in range(n_nodes):
         left, right, model, band = msa.node_job(k)
-        route = pg.debug_route(left, right, model, band)[0].split(" ")[0]
+        full = pg.debug_route(left, right, model, band)[0]
+        route_of[k] = full
+        route = full.split(" ")[0]
         routed[route] = routed.get(route, 0) + int(infos[k].cells)
     kmean = kern_ms.mean(axis=0)                               # [level, kernel]
-    # the banded fill's dispatches of at most 32 alignments carry follower workgroups that write the back-pointers while the
-    # fill runs (dp_pipe.hip, pipe_follower; PAGAN_DP_FOLLOW=0 switches them off); a workload with wider levels is accounted
-    # as if it had none
-    follow_on = os.environ.get("PAGAN_DP_FOLLOW") != "0" and max(len(ks) for ks in by_level) <= 32
+    # A banded-fill DISPATCH of at most 32 alignments carries follower workgroups that write the back-pointers while the fill
+    # runs (dp_pipe.hip, pipe_follower; PAGAN_DP_FOLLOW=0 switches them off); dp_abi.hip: launch_fill decides per dispatch --
+    # a level's small-table jobs and its large-table jobs are a dispatch each -- and so does the accounting here.
+    followed_cells = 0
+    if os.environ.get("PAGAN_DP_FOLLOW") != "0":
+        for ks in by_level:
+            for kind in ("pg_fill_pipe", "pg_fill_pipe (large table)"):
+                js = [k for k in ks if route_of[k] == kind]
+                if 0 < len(js) <= 32:
+                    followed_cells += sum(int(infos[k].cells) for k in js)
+    pipe_cells = routed.get("pg_fill_pipe", 0)
     per_kernel = []
     for q, name in enumerate(KERNELS):
         t_ms = float(kmean[:, q].sum())
@@ -327,13 +338,14 @@ def bench_one_gpu(args, device):
             continue
         kcells = cells if name == "pg_backptr" else routed.get(name, 0)
         if name == "pg_backptr":
-            # (behind a banded fill with follower workgroups it only looks at the chunks' flags)
-            kcells = (0 if follow_on else routed.get("pg_fill_pipe", 0)) + routed.get("pg_fill_tiles_flow", 0)
+            # (behind a banded dispatch with follower workgroups it only looks at the chunks' flags)
+            kcells = (pipe_cells - followed_cells) + routed.get("pg_fill_tiles_flow", 0)
             if kcells == 0:
                 continue
             kbytes = 36                                        # 24 B of scores read (neighbours out of L2) + 12 B written per cell
-        elif name == "pg_fill_pipe" and follow_on:
-            kbytes = 36                                        # scores by the fill's workgroups + back-pointers by its follower workgroups (they read the scores out of L2)
+        elif name == "pg_fill_pipe":
+            # scores by the fill's workgroups (24 B) + back-pointers by its follower workgroups where the dispatch had them (12 B)
+            kbytes = 24 + 12 * followed_cells / max(pipe_cells, 1)
         else:
             kbytes = BYTES_PER_CELL if name == "pg_fill_wavefront" else 24    # the banded and the tiled fill store scores only since round 3
         ach = kbytes * kcells / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
@@ -353,7 +365,7 @@ def bench_one_gpu(args, device):
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": None,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -519,7 +531,8 @@ def pmc_traffic(workload, cells, kernel, launches, strict):
     """HBM bytes per launch of the dominant fill kernel from the committed rocprofv3 --pmc passes of this same command
     (WRITE_SIZE and FETCH_SIZE need separate profiler passes, they cannot be read from inside the bench).  The
     profile names its workload, kernel and cells; a mismatch means it was taken on something else: traffic = null and
-    a warning (--strict-traffic: an error -- the profiling scripts use it)."""
+    a warning (--strict-traffic: an error; meant for the bench line committed next to a fresh profile -- the profiling
+    passes of tools/profile_bench.sh run without it, they are what the profile is made FROM)."""
     path = os.path.join(ROOT, PMC_PROFILE)
     try:
         prof = json.load(open(path))

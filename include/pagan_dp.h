@@ -218,6 +218,13 @@ int  pagan_batch_debug_poison(pagan_batch *b);
 /* Diagnostic: counts[0] = chunks of 16 diagonals of job k whose back-pointers the follower workgroups of the banded fill
  * wrote while the fill was running, counts[1] = all chunks of the job (0 of 0 for a job of another kernel).          */
 int  pagan_batch_debug_followed(pagan_batch *b, int32_t k, int32_t *counts);
+/* Test hook for the path check (every cell the traceback visited is re-evaluated from the stored scores and compared with
+ * the stored score and back-pointer, always; a difference makes pagan_batch_fetch run the batch once more with every
+ * back-pointer written after the fill, and report PAGAN_E_INTERNAL if it stays; PAGAN_DP_RERUN=0: report at once):
+ * state `vit` (0 X, 1 Y, 2 M) of cell (i, j) of job k gets `word` as its back-pointer after the NEXT run's fill, once.  */
+int  pagan_batch_debug_poke_bp(pagan_batch *b, int32_t k, int32_t i, int32_t j, int32_t vit, uint32_t word);
+/* how often pagan_batch_fetch has run this batch again after a failed path check           */
+int  pagan_batch_debug_reruns(pagan_batch *b);
 
 /* The library keeps up to two idle device arenas per device and a few host staging buffers for the next
  * batch (a level of a tree walk is followed by the next; freeing and re-allocating GBs costs tens of ms).

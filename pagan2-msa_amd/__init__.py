@@ -303,6 +303,21 @@ class Batch:
         _check(self._L.pagan_batch_debug_followed(self._h, k, c), "pagan_batch_debug_followed")
         return int(c[0]), int(c[1])
 
+    def debug_poke_bp(self, k, i, j, vit, word):
+        """Test hook: after the next run's fill, state `vit` of cell (i, j) of job k gets `word` as its back-pointer (once)."""
+        _check(self._L.pagan_batch_debug_poke_bp(self._h, k, i, j, vit, word), "pagan_batch_debug_poke_bp")
+
+    def debug_reruns(self):
+        """How often fetch() ran the batch again after a failed path check."""
+        return int(self._L.pagan_batch_debug_reruns(self._h))
+
+    def debug_trace(self, k, n_cells):
+        """Diagnostic: the first n_cells visited cells of job k's last traceback as [n, 3] int32 rows (i, j, word)."""
+        import numpy as np
+        out = np.empty((n_cells, 3), np.int32)
+        _check(self._L.pagan_batch_debug_trace(self._h, k, out.ctypes.data_as(C.c_void_p), out.nbytes), "pagan_batch_debug_trace")
+        return out
+
     def cells_of(self, k):
         left, right, _, band = self.jobs[k]
         return self._L.pagan_dp_count_cells(left.n_sites, right.n_sites, C.byref(band.c) if band is not None else None)

@@ -39,6 +39,8 @@ __global__ void pg_backptr(const PgDevJob *jobs, const int *which, unsigned flag
 __global__ void pg_trace_spec(const PgDevJob *jobs);
 __global__ void pg_trace_compose(const PgDevJob *jobs);
 __global__ void pg_trace_emit(const PgDevJob *jobs);
+__global__ void pg_trace_check(const PgDevJob *jobs, unsigned flags);
+__global__ void pg_debug_poke_bp(const PgDevJob *jobs, int k, int i, int j, int vit, unsigned word);
 
 // limits of the LDS-staged kernel (dp_kernels.hip: RW site window, EC edge ring)
 #define PG_RING_MAX_WIDTH 256
@@ -541,6 +543,10 @@ struct pagan_batch {
     int64_t cells = 0;
     size_t out_begin = 0;        // arena offset where the output arrays start
     bool ran = false;
+    int max_path = 0;            // longest possible path of any job (Lx + Ly): pg_trace_check's grid
+    bool no_follow = false;      // the re-run after a failed path check: every back-pointer by pg_backptr
+    int reruns = 0;              // how often pagan_batch_fetch ran the batch again (pagan_batch_debug_reruns)
+    int poke[6] = {-1, 0, 0, 0, 0, 0};     // test hook: {job, i, j, state, word, _}, applied once between fill and traceback
     // D2H staging (pinned)
     std::vector<size_t> trace_off;   // byte offsets of trace/endcell/endscore inside the arena
     std::vector<size_t> end_off, score_off;
@@ -772,7 +778,7 @@ int launch_fill(pagan_batch *b) {
             // whose scores have landed while the fill goes on, on compute units the banded fill leaves idle.  Workgroup g of
             // a dispatch runs on XCD g % 8 and a follower serves the fill workgroups of its own XCD (it shares their L2), so
             // eight followers per round of eight jobs are the unit; what they do not get to is left to pg_backptr below.
-            bool follow = b->bp_pass == 1 && b->follow_bytes > 0;
+            bool follow = b->bp_pass == 1 && b->follow_bytes > 0 && !b->no_follow;
             if (const char *f = std::getenv("PAGAN_DP_FOLLOW")) follow = follow && std::strcmp(f, "0") != 0;
             if (b->follow_bytes > 0) HIP_TRY(hipMemsetAsync(b->arena.dev + b->follow_begin, 0, b->follow_bytes, b->stream));
             // (a dispatch of more than 32 jobs fills the chip by itself: pg_backptr afterwards, on every unit, is the faster pass)
@@ -1167,6 +1173,9 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     // A/B switch: PAGAN_DP_FILL=ring runs the barrier-per-diagonal LDS kernel instead of the register wavefront
     if (const char *f = std::getenv("PAGAN_DP_FILL")) b->use_pipe = std::strcmp(f, "ring") != 0;
     if (const char *f = std::getenv("PAGAN_DP_BP")) b->bp_pass = std::strcmp(f, "verify") == 0 ? 2 : (std::strcmp(f, "fill") == 0 ? 0 : 1);
+    // ("fill" = the fill kernel writes its own back-pointers: true of the ring kernel only -- pg_fill_pipe's loop stores scores
+    //  and nothing else, so with it the pass always runs)
+    if (b->use_pipe && b->bp_pass == 0) b->bp_pass = 1;
     if (const char *f = std::getenv("PAGAN_DP_DEBUG_FLAGS")) b->flags |= (uint32_t)std::strtoul(f, nullptr, 0) & 0xff00u;
     // A/B switch: PAGAN_DP_WIDE=wavefront sends the wide jobs to the one-workgroup HBM wavefront instead of the tiles
     const char *wide_env = std::getenv("PAGAN_DP_WIDE");
@@ -1193,6 +1202,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         if (rc != PAGAN_OK) return rc;
         b->cells += b->compact[k].on ? b->compact[k].cells0 : b->jobs[k].dx.cells;       // the caller's cells
         if (b->jobs[k].n_bound > b->max_bound) b->max_bound = b->jobs[k].n_bound;
+        b->max_path = std::max(b->max_path, b->jobs[k].Lx + b->jobs[k].Ly);
         if (b->jobs[k].n_bound > 0 && b->jobs[k].tb[b->jobs[k].n_bound + 1] > b->max_entries) b->max_entries = b->jobs[k].tb[b->jobs[k].n_bound + 1];
         if (b->jobs[k].ring_ok && !force_v1) {
             (eff[k].model->n_states <= 16 ? which_ring : which_ring_big).push_back(k);
@@ -1404,6 +1414,10 @@ int pagan_batch_run(pagan_batch *b) {
     int rc = launch_fill(b);
     if (rc != PAGAN_OK) return rc;
     HIP_TRY(hipEventRecord(b->ev[1], b->stream));
+    if (b->poke[0] >= 0 && b->poke[0] < b->n) {
+        hipLaunchKernelGGL(pg_debug_poke_bp, dim3(1), dim3(64), 0, b->stream, b->d_jobs, b->poke[0], b->poke[1], b->poke[2], b->poke[3], (unsigned)b->poke[4]);
+        b->poke[0] = -1;
+    }
     {
         // (pg_fill_tiles_flow's give-up word sits behind its per-diagonal counters and per-tile flags)
         const bool flow = b->tile_off.size() > 1 && b->tiles_flow;
@@ -1415,6 +1429,10 @@ int pagan_batch_run(pagan_batch *b) {
     hipLaunchKernelGGL(pg_trace_compose, dim3(b->n), dim3(64), 0, b->stream, b->d_jobs);
     if (b->max_bound > 0)
         hipLaunchKernelGGL(pg_trace_emit, dim3((2 * b->max_bound + 8 + 63) / 64, b->n), dim3(64), 0, b->stream, b->d_jobs);
+    // every visited cell re-evaluated from the stored scores (always on: a back-pointer written from a score that had
+    // not landed yet would otherwise be a valid-looking pointer to the wrong cell)
+    if (b->max_path > 0)
+        hipLaunchKernelGGL(pg_trace_check, dim3((b->max_path + 255) / 256, b->n), dim3(256), 0, b->stream, b->d_jobs, b->flags & 0xffu);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[2], b->stream));
     b->ran = true;
@@ -1474,6 +1492,28 @@ int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
     std::vector<Fetched> got(b->n);
     std::vector<char> ends(kEndStride * (size_t)b->n);
     if (b->n > 0) HIP_TRY(hipMemcpy(ends.data(), b->arena.dev + b->end_off[0], ends.size(), hipMemcpyDeviceToHost));
+    {
+        // A visited cell whose stored back-pointer (or score) is not what its predecessors' scores give (pg_trace_check), or
+        // a chase that ran into an impossible word: the batch runs once more with every back-pointer written by pg_backptr
+        // after the fill -- the follower workgroups' early reads are the one thing a second run can take out.  What fails
+        // again is reported.  PAGAN_DP_RERUN=0: report at once.
+        bool again = false;
+        for (int k = 0; k < b->n; ++k) {
+            const int st = *reinterpret_cast<const int *>(ends.data() + kEndStride * (size_t)k);
+            again = again || st == PG_STATUS_PATH_CHECK || st == 2;
+        }
+        const char *re = std::getenv("PAGAN_DP_RERUN");
+        if (again && !(re && std::strcmp(re, "0") == 0)) {             // (once per fetch; the batch stays without followers)
+            if (std::getenv("PAGAN_DP_VERBOSE")) std::fprintf(stderr, "pagan_dp: path check failed: running the batch again without follower workgroups\n");
+            b->no_follow = true;
+            ++b->reruns;
+            int rc = pagan_batch_run(b);
+            if (rc != PAGAN_OK) return rc;
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            pagan_batch_last_ms(b, ms);
+            HIP_TRY(hipMemcpy(ends.data(), b->arena.dev + b->end_off[0], ends.size(), hipMemcpyDeviceToHost));
+        }
+    }
     for (int k = 0; k < b->n; ++k) {
         Fetched &f = got[k];
         std::memcpy(f.endcell, ends.data() + kEndStride * (size_t)k, sizeof(f.endcell));
@@ -1550,6 +1590,16 @@ int pagan_batch_debug_poison(pagan_batch *b) {
     HIP_TRY(hipMemsetAsync(b->arena.dev + b->out_begin, 0xFF, b->arena.size - b->out_begin, b->stream));
     return PAGAN_OK;
 }
+
+// Test hook: after the NEXT run's fill and before its traceback, state `vit` of cell (i, j) of job k gets `word` as its
+// back-pointer (once).  tests/test_pipe_gpu.py corrupts a pointer on the path with it and expects the path check to see it.
+int pagan_batch_debug_poke_bp(pagan_batch *b, int32_t k, int32_t i, int32_t j, int32_t vit, uint32_t word) {
+    if (!b || k < 0 || k >= b->n) return PAGAN_E_ARG;
+    b->poke[0] = k; b->poke[1] = i; b->poke[2] = j; b->poke[3] = vit; b->poke[4] = (int)word;
+    return PAGAN_OK;
+}
+// How often pagan_batch_fetch ran the batch again after a failed path check.
+int pagan_batch_debug_reruns(pagan_batch *b) { return b ? b->reruns : PAGAN_E_ARG; }
 
 // Diagnostic: how many of job k's chunks of PG_FOLLOW_CHUNK diagonals had their back-pointers written behind the fill by
 // the follower workgroups of pg_fill_pipe (the rest were left to pg_backptr); counts[0] = those, counts[1] = all chunks.

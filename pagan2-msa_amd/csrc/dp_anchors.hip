@@ -148,11 +148,11 @@ void anchors_release_cache() {
     }
 }
 
-bool prefix_hits_device(const std::string &a, const std::string &b, int min_length, std::vector<Hit> *hits) {
+bool prefix_hits_device(const std::string &a, const std::string &b, int min_length, std::vector<Hit> *hits, int device) {
     const int len1 = (int)a.size(), len2 = (int)b.size(), n = len1 + len2 + 2;
     if (n >= (1 << 20) - 1 || min_length < 1) return false;               // (20-bit ranks in the sort key)
-    int device = 0;
-    HIPA(hipGetDevice(&device));
+    // (a thread made for one level of the walk starts on device 0: the unit's device is handed down, host_tree.cpp)
+    if (device >= 0) HIPA(hipSetDevice(device)); else HIPA(hipGetDevice(&device));
     ScratchLease lease(device);
     Scratch &S = lease.s;
     if (!S.stream) HIPA(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));

@@ -36,6 +36,7 @@
 #define PG_SEG 256           // diagonals per traceback segment
 #define PG_BP_DIAGS 64        // diagonals per workgroup of the back-pointer pass (pg_backptr)
 #define PG_BP_CELLS 1024      // ... and cells of each of them (grid.z covers the rest of a wide diagonal)
+#define PG_STATUS_PATH_CHECK 3 // endcell[0]: a visited cell's stored score / back-pointer differs from its re-evaluation (pg_trace_check)
 #define PG_FOLLOW_CHUNK 16    // diagonals a follower wave of pg_fill_pipe claims at a time (dp_pipe.hip, pipe_follower)
 
 // Geometry of the banded fill kernel (dp_pipe.hip) that the host-side planner (dp_abi.hip:

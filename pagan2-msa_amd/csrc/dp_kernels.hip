@@ -761,3 +761,68 @@ __global__ __launch_bounds__(64) void pg_trace_emit(const PgDevJob *__restrict__
         tr[3 * t] = ci; tr[3 * t + 1] = cj; tr[3 * t + 2] = w;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// The emitted path, checked cell by cell (always on; O(path), not O(cells)).
+//
+// A back-pointer is written off the fill's dependency chain -- by pg_backptr after the fill, or by pg_fill_pipe's follower
+// workgroups WHILE it runs, from scores they read out of L2 on the strength of "a wave's stores of diagonal d have landed
+// once it completed d + 8" (dp_pipe.hip).  A word computed from a score read too early would be a valid-looking pointer to
+// the wrong predecessor: the host's replay validates indices, not choices.  So every cell the traceback visited is
+// re-evaluated here from the stored scores with the comparing kernels' own function (cell_any: candidates in the
+// reference's order, strict >, basic_alignment.h:449-462, VA:1038-1189 for what the walk reads) and both the visited
+// state's score and its back-pointer must be what is stored, bit for bit.  A difference sets the job's status to
+// PG_STATUS_PATH_CHECK; pagan_batch_fetch then runs the batch once more with pg_backptr writing every pointer and, if the
+// difference stays, reports PAGAN_E_INTERNAL.
+// grid (ceil(longest path / 256), n_jobs), one thread per visited cell.
+__global__ __launch_bounds__(256) void pg_trace_check(const PgDevJob *__restrict__ jobs, unsigned flags) {
+    const View J = load_view(jobs + blockIdx.y);
+    if (J.endcell[0] != 0) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= J.endcell[6]) return;
+    const int i = J.trace[3 * t], j = J.trace[3 * t + 1];
+    const unsigned w = (unsigned)J.trace[3 * t + 2];
+    const int vit = (int)(w & 3u);
+    bool ok = vit <= 2 && i >= 0 && j >= 0 && i < J.Lx && j < J.Ly;
+    if (ok) {
+        const int d = i + j;
+        const int lo = J.imin[d], hi = J.imax[d];
+        ok = i >= lo && i <= hi;
+        if (ok) {
+            const long long at = J.doff[d] + (i - lo);
+            const Diag none = {0, -1, 0};
+            int l0 = 0, l1 = 0, r0 = 0, r1 = 0;
+            if (i > 0) { l0 = J.offL[i]; l1 = J.offL[i + 1]; }
+            if (j > 0) { r0 = J.offR[j]; r1 = J.offR[j + 1]; }
+            float sm = 0.0f;
+            if (i > 0 && j > 0 && l1 > l0 && r1 > r0) sm = J.table[J.stL[i] + J.stR[j] * J.S];       // VA:1363
+            double b3[3];
+            unsigned p3[3];
+            cell_any(J, i, j, l1 - l0, r1 - r0, sm, (flags & 1u) != 0, !(flags & 2u),
+                     [&](int p, int q, double &xs, double &ys, double &ms) {
+                         const long long ix = hbm_index(J, -10, none, none, p, q);
+                         xs = ys = ms = neg_inf();
+                         if (ix >= 0) { xs = J.sc[3 * ix + PG_X]; ys = J.sc[3 * ix + PG_Y]; ms = J.sc[3 * ix + PG_M]; }
+                     },
+                     [&](int k, int &p, double &lw) { p = J.srcL[l0 + k]; lw = (double)J.lwL[l0 + k]; },
+                     [&](int k, int &q, double &rw) { q = J.srcR[r0 + k]; rw = (double)J.lwR[r0 + k]; },
+                     b3[PG_X], b3[PG_Y], b3[PG_M], p3[PG_X], p3[PG_Y], p3[PG_M]);
+            double bs = b3[PG_X];
+            unsigned ps = p3[PG_X];
+            if (vit == PG_Y) { bs = b3[PG_Y]; ps = p3[PG_Y]; } else if (vit == PG_M) { bs = b3[PG_M]; ps = p3[PG_M]; }
+            ok = __double_as_longlong(bs) == __double_as_longlong(J.sc[3 * at + vit]) && ps == J.bp[3 * at + vit] &&
+                 (ps & ~3u) == (w & ~3u);
+        }
+    }
+    if (!ok) J.endcell[0] = PG_STATUS_PATH_CHECK;
+}
+
+// Test hook (pagan_batch_debug_poke_bp): one back-pointer word overwritten between the fill and the traceback.
+__global__ void pg_debug_poke_bp(const PgDevJob *__restrict__ jobs, int k, int i, int j, int vit, unsigned word) {
+    const View J = load_view(jobs + k);
+    const int d = i + j;
+    if (threadIdx.x != 0 || d < 0 || d >= J.nd || vit < 0 || vit > 2) return;
+    const int lo = J.imin[d], hi = J.imax[d];
+    if (i < lo || i > hi) return;
+    J.bp[3 * (J.doff[d] + (i - lo)) + vit] = word;
+}

@@ -235,9 +235,13 @@ __device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lan
         int pmin = flag_load(&PM.progress[0]);
         for (int w = 1; w < PNW; ++w) { const int p = flag_load(&PM.progress[w]); pmin = p < pmin ? p : pmin; }
         if (flag_load(&PM.abort_flag) != 0) { publish_landed(follow, lane, J.nd - 1); return; }   // (the job fails: the followers need not wait)
-        const int dcur = pmin + 1;                                 // the slowest wave may be computing this one
-        if (dcur >= J.nd) { publish_landed(follow, lane, J.nd - 1); return; }                     // every wave drained before its last flag
+        // A compute wave's flag for the LAST diagonal goes up as after any other step -- with its stores still in flight -- so
+        // the tail is published like the middle, PLAND behind the slowest wave, and the last diagonals only once every wave
+        // has said "drained for good": progress = nd, stored behind the s_waitcnt vmcnt(0) that ends its last interval.
+        if (pmin >= J.nd) { publish_landed(follow, lane, J.nd - 1); return; }
         if (pmin - PLAND >= published + PG_FOLLOW_CHUNK) { published = pmin - PLAND; publish_landed(follow, lane, published); }
+        if (pmin + 1 >= J.nd) { __builtin_amdgcn_s_sleep(8); continue; }                          // nothing left to stage
+        const int dcur = pmin + 1;                                 // the slowest wave may be computing this one
         const int da = dcur + PLOOK < J.nd - 1 ? dcur + PLOOK : J.nd - 1;
         const pg_i8 ds = psc[da], dc = psc[dcur];
         int want_rows = ds.y + 5, want_cols = da - ds.x + 4;       // rows <= hi+4, columns <= jmax+3 of diagonal da
@@ -2442,8 +2446,10 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
         // asleep until `wake`: this wave's ring columns are -inf at every depth, its stores have retired
         // and it reads nothing
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        flag_store(&PM.arrived[wave], wake - 1);
-        flag_store(&PM.progress[wave], wake - 1);
+        // (wake >= nd: the wave's last interval is behind it and so are its stores -- `nd`, one more than any diagonal's
+        //  flag, is what tells the loader that the last diagonals have landed too: pipe_loader)
+        flag_store(&PM.arrived[wave], wake >= nd ? nd : wake - 1);
+        flag_store(&PM.progress[wave], wake >= nd ? nd : wake - 1);
         if (wake >= nd || flag_load(&PM.abort_flag) != 0) break;
 
         cdesc8_p pp = psc + wake;                                  // descriptor last requested

@@ -81,6 +81,11 @@ void drop_overlapping(std::vector<Hit> *hits, int len1, int len2) {
 // PAGAN_ANCHORS=host keeps the finder on the host; otherwise the suffix array is built on the calling thread's device
 // (dp_anchors.hip) and the host's builder below only runs where there is no device
 std::atomic<long long> device_finder_calls{0};                  // (diagnostic: pagan_anchors_device_calls)
+// The device the calling thread's finders run on.  The tree walk prepares a unit's nodes on fresh threads, and a new thread's
+// HIP device is 0 whatever device the unit belongs to: run_unit says which one it is (-1: whatever is current).
+static thread_local int tl_anchor_device = -1;
+void set_anchor_device(int device) { tl_anchor_device = device; }
+int anchor_device() { return tl_anchor_device; }
 static bool anchors_on_device() {
     const char *e = std::getenv("PAGAN_ANCHORS");
     return !(e && std::strcmp(e, "host") == 0);
@@ -96,11 +101,12 @@ void prefix_hits(const std::string &a, const std::string &b, int min_length, std
         explicit InFlight(std::atomic<int> &c_) : c(c_), ok(c_.fetch_add(1) < 4) {}
         ~InFlight() { c.fetch_sub(1); }
     };
-    static std::atomic<int> on_device{0};
+    static std::atomic<int> on_device[64];                         // per device: the cap is about sharing ONE device
     bool done = false;
     if (anchors_on_device() && len1 + len2 >= 16384) {
-        InFlight slot(on_device);
-        done = slot.ok && prefix_hits_device(a, b, min_length, hits);
+        const int dev = anchor_device();
+        InFlight slot(on_device[(dev < 0 ? 0 : dev) & 63]);
+        done = slot.ok && prefix_hits_device(a, b, min_length, hits, dev);
     }
     if (done) {
         device_finder_calls.fetch_add(1);

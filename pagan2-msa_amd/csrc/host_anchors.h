@@ -28,7 +28,11 @@ void prefix_hits(const std::string &a, const std::string &b, int min_length, std
 // false where there is no device
 extern std::atomic<long long> device_finder_calls;    // how often prefix_hits took the device's finder
 void anchors_release_cache();                          // frees the device finder's idle scratch (pagan_dp_release_cache)
-bool prefix_hits_device(const std::string &a, const std::string &b, int min_length, std::vector<Hit> *hits);
+// device < 0: the calling thread's current device
+bool prefix_hits_device(const std::string &a, const std::string &b, int min_length, std::vector<Hit> *hits, int device = -1);
+// which device prefix_hits() on this thread builds its suffix arrays on (host_tree.cpp: run_unit's device)
+void set_anchor_device(int device);
+int anchor_device();
 void resolve_conflicts(int len1, int len2, int trim, std::vector<Hit> *hits);
 void hits_to_band(const std::vector<Hit> &hits, const std::string &gapped1, const std::string &gapped2, int width,
                   std::vector<int32_t> *upper, std::vector<int32_t> *lower);

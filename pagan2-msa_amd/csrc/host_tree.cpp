@@ -504,7 +504,7 @@ int build_parent(pagan_msa *m, int id) {
 int run_unit(pagan_msa *m, const std::vector<int> &ids, int dev, int round, int threads) {
     const int n = m->n_leaves;
     double t0 = now_s();
-    parallel_for((int)ids.size(), threads, [&](int r) { prepare_node(m, ids[r], round); });
+    parallel_for((int)ids.size(), threads, [&](int r) { set_anchor_device(dev); prepare_node(m, ids[r], round); });
     const double t_prep = now_s() - t0;
     t0 = now_s();
     std::vector<int> ks(ids.size());

@@ -2,24 +2,29 @@
 the CPU tests).
 
 The path shards by independent units -- guide-tree nodes whose two children are finished
-(Node::start_openmp_alignment / build_queues, src/main/node.cpp:227-285) -- and the reference runs
-them from a shared-memory queue.  With one process per GPU there is no shared memory, so every rank
-holds the whole (small) tree state and the queue is replayed in rounds:
+(Node::start_threaded_alignment / build_queues, src/main/node.cpp:196-223, 273-345) -- and the reference runs
+them from a shared-memory queue: a thread takes the next ready node, and a parent becomes ready the moment its
+two children are done, whoever aligned them.  With one process per GPU there is no shared memory, so every rank
+holds the whole (small) tree state and the queue lives in the job's key-value store (the rendezvous store
+torch.distributed was initialised with):
 
-    ready = msa.ready()                      the same list on every rank
-    mine  = the units the work-queue rule (pagan_assign_units, largest first) gives this rank
-    msa.align_nodes(mine)                    model, anchors, DP on this rank's GPU, parent graphs
-    post(exported results of `mine`)         into the job's key-value store (the rendezvous store torch.distributed
-                                             was initialised with): path columns + used child edges of the nodes a
-                                             rank aligned, ~1 byte per alignment column
-    fetch + msa.import_result(...)           the other ranks' nodes of the round, as they appear; builds those
-                                             parents locally
+    exchange="queue" (default)   a DYNAMIC queue.  A rank's ready set comes from what it has aligned itself plus what
+                                 it has imported; it CLAIMS ready nodes, largest first, with an atomic counter per node
+                                 (store.add: the first rank to ask owns the node), aligns them on its GPU (model, anchors,
+                                 DP, parent graphs), posts the finished paths (node key, then an entry in a posting log)
+                                 and imports what the others have posted since it last looked -- without waiting.  It only
+                                 blocks when it has nothing ready and nothing to import, and then on the NEXT posting of
+                                 whoever finishes first.  A slow rank holds up the parents of its own nodes and nothing
+                                 else; there is no round and no barrier.
+    exchange="store"             level-synchronous rounds with the store as a mailbox (round 3): the ready list is the same
+                                 on every rank, pagan_assign_units deals it statically, every rank reads every other
+                                 rank's nodes of the round before the next round starts.
+    exchange="collective"        the same rounds with two all-gathers per round (round 2), for comparison.
 
-NO collective on the data path (north_star: "an embarrassingly-parallel work queue (no RCCL collectives)"): a finished
-path is posted under its node's key and read by whoever needs it -- a mailbox, point to point through the store, and a
-rank waits only for the nodes it has not aligned itself.  (Round 2 exchanged the same bytes with two all-gathers per
-round; that is kept behind exchange="collective" for comparison.)  The ranks still meet in torch.distributed for what the
-bench contract asks: the barrier around the timed region and the maximum of the elapsed time.
+NO collective on the data path in the first two (north_star: "an embarrassingly-parallel work queue (no RCCL
+collectives)"): what travels is a finished path, ~1 byte per alignment column plus the used edge ids.  The ranks still
+meet in torch.distributed for what the bench contract asks: the barrier around the timed region and the maximum of the
+elapsed time.
 """
 import numpy as np
 import torch
@@ -88,9 +93,7 @@ def all_gather_bytes(chunks, device="cpu"):
 
 
 _walks = [0]
-_posted = {}                      # walk -> keys this rank posted (deleted two walks later: by then every rank has read them --
-                                  # a rank starts walk k only after it has received every other rank's nodes of walk k-1, which
-                                  # those ranks posted after finishing walk k-2)
+_posted = {}                      # walk -> keys this rank posted; deleted once every rank has acknowledged the walk
 
 
 def _store():
@@ -98,22 +101,98 @@ def _store():
     return c10d._get_default_store()
 
 
-def align_sharded(msa, assign, device="cpu", on_round=None, exchange="store"):
-    """The whole progressive alignment of `msa` (a host.Msa, created identically on every rank) with the
-    ready nodes of each round dealt over the ranks.  `assign(costs, n_workers)` is the work-queue rule
-    (host.assign_units).  Returns per-round records [(n_ready, n_mine, bytes exchanged)]."""
+def _reap(store, w):
+    """Deletes this rank's keys of earlier walks that EVERY rank has finished reading (each rank adds 1 to the walk's
+    `done` counter when it has imported everything): no assumption about who posted what in which walk."""
+    for old in list(_posted):
+        try:
+            if store.add("pagan/%d/done" % old, 0) < w:
+                continue
+            for key in _posted.pop(old):
+                store.delete_key(key)
+        except Exception:              # (a store without delete: the keys just stay)
+            _posted.pop(old, None)
+
+
+def _align_queue(msa, store, walk, w, r, on_round, quota):
+    P = "pagan/%d/" % walk
+    mine_all, lost = set(), set()
+    seen = 0                      # entries of the posting log this rank has gone through
+    rounds = []
+
+    def drain(block):
+        """Imports what has been posted since the last look, in posting order (a parent is always posted after its
+        children: its poster had both before it could align it).  block: wait for the next posting first."""
+        nonlocal seen
+        moved = 0
+        cnt = int(store.add(P + "count", 0))
+        if block and cnt == seen:
+            cnt = seen + 1
+        while seen < cnt:
+            seen += 1
+            n = int(store.get(P + "log/%d" % seen))              # (blocks until the poster has written the entry)
+            if n in mine_all:
+                continue
+            buf = np.frombuffer(store.get(P + "node/%d" % n), np.uint8)
+            msa.import_result(buf)
+            lost.discard(n)
+            moved += int(buf.shape[0])
+        return moved
+
+    while msa.remaining > 0:
+        moved = drain(False)
+        ready = [n for n in msa.ready() if n not in lost]
+        if not ready:
+            moved += drain(True)
+            rounds.append((0, 0, moved))
+            continue
+        ready.sort(key=lambda n: -msa.node_cost(n))
+        q = quota if quota else max(1, -(-len(ready) // w))
+        start = (r * q) % len(ready)          # ranks start at different places of the same list: fewer lost claims
+        mine = []
+        for k in range(len(ready)):
+            if len(mine) >= q:
+                break
+            n = ready[(start + k) % len(ready)]
+            if int(store.add(P + "claim/%d" % n, 1)) == 1:
+                mine.append(n)
+            else:
+                lost.add(n)                   # its owner will post it
+        if mine:
+            msa.align_nodes(mine)
+            for n in mine:
+                mine_all.add(n)
+                store.set(P + "node/%d" % n, msa.export_result(n).tobytes())
+                idx = int(store.add(P + "count", 1))
+                store.set(P + "log/%d" % idx, str(n))
+                _posted[walk] += [P + "node/%d" % n, P + "log/%d" % idx, P + "claim/%d" % n]
+        rounds.append((len(ready), len(mine), moved))
+        if on_round:
+            on_round(len(rounds) - 1, ready, mine)
+    return rounds
+
+
+def align_sharded(msa, assign, device="cpu", on_round=None, exchange="queue", walk=None, quota=None):
+    """The whole progressive alignment of `msa` (a host.Msa, created identically on every rank) sharded over the ranks.
+    exchange: "queue" (dynamic claims through the store), "store" / "collective" (level-synchronous rounds dealt by
+    `assign(costs, n_workers)`, the work-queue rule host.assign_units) -- see the module text.  `walk` names the key space
+    of this call in the store; None: a per-process call counter, which is only right when every rank calls this the same
+    number of times.  `quota`: most nodes a rank claims at a time in queue mode (None: its share of what is ready).
+    Returns per-round records [(n_ready, n_mine, bytes imported)]."""
     w, r = world(), rank()
     rounds = []
-    walk = _walks[0]              # (every rank calls this the same number of times: the keys of one walk never meet another's)
-    _walks[0] += 1
-    store = _store() if (w > 1 and exchange == "store") else None
+    if walk is None:
+        walk = _walks[0]
+        _walks[0] += 1
+    store = _store() if (w > 1 and exchange in ("store", "queue")) else None
     if store is not None:
-        for key in _posted.pop(walk - 2, []):
-            try:
-                store.delete_key(key)
-            except Exception:          # (a store without delete: the keys just stay)
-                pass
+        _reap(store, w)
         _posted[walk] = []
+    if store is not None and exchange == "queue":
+        rounds = _align_queue(msa, store, walk, w, r, on_round, quota)
+        store.add("pagan/%d/done" % walk, 1)
+        msa.finish()
+        return rounds
     while msa.remaining > 0:
         ready = msa.ready()
         if not ready:
@@ -145,5 +224,7 @@ def align_sharded(msa, assign, device="cpu", on_round=None, exchange="store"):
         rounds.append((len(ready), len(mine), moved))
         if on_round:
             on_round(len(rounds) - 1, ready, mine)
+    if store is not None:
+        store.add("pagan/%d/done" % walk, 1)
     msa.finish()
     return rounds

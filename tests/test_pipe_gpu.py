@@ -172,3 +172,47 @@ def test_back_pointers_are_written_behind_the_fill_and_equal_the_pass_afterwards
         assert followed["0"][k][0] == 0 and followed["0"][k][1] > 50
         done, total = followed["1"][k]
         assert total == followed["0"][k][1] and done >= 0.9 * total, "job %d: the followers wrote %d of %d chunks" % (k, done, total)
+
+
+def _poke_on_path(pg, b, t):
+    """Asks for the back-pointer of the t-th visited cell of job 0's last traceback to name another predecessor state."""
+    tr = b.debug_trace(0, t + 2)
+    i, j, w = (int(x) for x in tr[t])
+    vit, frm = w & 3, int(tr[t + 1][2]) & 3              # a cell's `from` label is the next visited cell's matrix
+    word = ((w & 0xffffffff) & ~3) | ((frm + 1) % 3)
+    b.debug_poke_bp(0, i, j, vit, word)
+    return i, j, vit
+
+
+@pytest.mark.parametrize("kind", ["banded", "tiled"])
+def test_a_wrong_back_pointer_on_the_path_is_seen_and_the_batch_runs_again(pg, oracle, monkeypatch, kind):
+    """Every cell the traceback visited is re-evaluated from the stored scores (pg_trace_check): a back-pointer that names
+    another predecessor than the scores give -- what a follower workgroup reading a score too early would write -- must not
+    become an alignment.  fetch() runs the batch once more with every pointer written after the fill; the hook's word is
+    gone by then, so the result is the oracle's and one re-run is counted."""
+    job = banded_job(3, box=False) if kind == "banded" else banded_job(3, box=False)[:3] + (None,)
+    want = oracle.dp_align(*job)
+    b = pg.Batch([job])
+    b.run(); b.sync()
+    same(b.fetch()[0], want)
+    assert b.debug_reruns() == 0
+    for t in (5, 200, 650):
+        before = b.debug_reruns()
+        _poke_on_path(pg, b, t)
+        b.run(); b.sync()
+        same(b.fetch()[0], want, "cell %d of the path" % t)
+        assert b.debug_reruns() == before + 1, "the corrupted pointer of visited cell %d went unnoticed" % t
+    b.close()
+
+
+def test_a_wrong_back_pointer_is_an_error_when_the_rerun_is_switched_off(pg, monkeypatch):
+    job = banded_job(3, box=False)
+    b = pg.Batch([job])
+    b.run(); b.sync(); b.fetch()
+    _poke_on_path(pg, b, 300)
+    monkeypatch.setenv("PAGAN_DP_RERUN", "0")
+    b.run(); b.sync()
+    with pytest.raises(pg.PaganError) as e:
+        b.fetch()
+    assert e.value.code == abi.PAGAN_E_INTERNAL
+    b.close()

@@ -126,8 +126,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank(rank, world, port, out_dir):
+def _rank(rank, world, port, out_dir, exchange, slow_rank):
     sys.path.insert(0, ROOT)
+    import time
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -138,29 +139,64 @@ def _rank(rank, world, port, out_dir):
     names, seqs, nwk = sy.evolve_balanced(16, 260, branch=0.02, sub=0.02, indel_start=0.006, mean_len=4, seed=14)
     log = []
     msa = h.Msa(names, seqs, nwk, use_anchors=1, prefix_hit_length=20)
-    msa.set_batch_backend(oracle_backend(oracle, log))
-    rounds = pdist.align_sharded(msa, h.assign_units)
+    inner = oracle_backend(oracle, log)
+
+    def backend(n, jobs, opts, out, user):
+        if rank == slow_rank:
+            time.sleep(3.0)                     # a rank whose device is busy with something else
+        return inner(n, jobs, opts, out, user)
+    msa.set_batch_backend(backend)
+    stamps = []                                 # (wall-clock when the nodes were done and posted, nodes) per claim
+    rounds = pdist.align_sharded(msa, h.assign_units, exchange=exchange, walk=7, quota=1 if slow_rank >= 0 else None,
+                                 on_round=lambda k, ready, mine: stamps.append((time.time(), list(mine))))
     mine = [k for k in range(msa.n_internal) if msa.node_device(k) >= 0]
     np.save(os.path.join(out_dir, "rows%d.npy" % rank), np.array(msa.alignment()))
     np.save(os.path.join(out_dir, "scores%d.npy" % rank), np.array([msa.node_info(k).score for k in range(msa.n_internal)]))
     np.save(os.path.join(out_dir, "mine%d.npy" % rank), np.array(mine))
     np.save(os.path.join(out_dir, "rounds%d.npy" % rank), np.array(rounds))
+    np.save(os.path.join(out_dir, "stamps%d.npy" % rank), np.array([(t, n) for t, ns in stamps for n in ns], np.float64).reshape(-1, 2))
+    dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_ranks_shard_one_tree_and_exchange_paths(tmp_path, oracle, pg, world):
-    mp.spawn(_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+def _one_rank_walk(oracle):
     names, seqs, nwk = synth.evolve_balanced(16, 260, branch=0.02, sub=0.02, indel_start=0.006, mean_len=4, seed=14)
     one = walk(oracle, names, seqs, nwk, use_anchors=1, prefix_hit_length=20).align()
-    want_rows = np.array(one.alignment())
-    want_scores = np.array([one.node_info(k).score for k in range(one.n_internal)])
+    return np.array(one.alignment()), np.array([one.node_info(k).score for k in range(one.n_internal)])
+
+
+@pytest.mark.parametrize("world,exchange", [(2, "queue"), (3, "queue"), (2, "store"), (3, "store")])
+def test_ranks_shard_one_tree_and_exchange_paths(tmp_path, oracle, pg, world, exchange):
+    mp.spawn(_rank, args=(world, _free_port(), str(tmp_path), exchange, -1), nprocs=world, join=True)
+    want_rows, want_scores = _one_rank_walk(oracle)
     owned = []
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / ("rows%d.npy" % r)), want_rows)          # every rank ends with the whole MSA
         assert np.array_equal(np.load(tmp_path / ("scores%d.npy" % r)), want_scores)
         owned += np.load(tmp_path / ("mine%d.npy" % r)).tolist()
         rounds = np.load(tmp_path / ("rounds%d.npy" % r))
-        assert rounds[:, 0].tolist() == [8, 4, 2, 1]                                       # the tree's levels
-        assert rounds[0, 1] in (8 // world, 8 // world + 1)                                # level 1 is split
+        if exchange == "store":
+            assert rounds[:, 0].tolist() == [8, 4, 2, 1]                                   # the tree's levels
+            assert rounds[0, 1] in (8 // world, 8 // world + 1)                            # level 1 is split
     assert sorted(owned) == list(range(15))                                                # every node aligned exactly once
+
+
+def test_a_slow_rank_holds_up_only_the_parents_of_its_own_nodes(tmp_path, oracle, pg):
+    """The queue in the store is dynamic (node.cpp:196-223, 273-345: a thread takes the next ready node; a parent is ready
+    when its two children are done, whoever aligned them).  Rank 1 takes three seconds over every batch and claims one
+    node at a time; rank 0 must meanwhile align everything that does not descend from rank 1's node -- the other seven
+    nodes of level 1, three of level 2, one of level 3 -- instead of waiting at a round's end."""
+    mp.spawn(_rank, args=(2, _free_port(), str(tmp_path), "queue", 1), nprocs=2, join=True)
+    want_rows, want_scores = _one_rank_walk(oracle)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / ("rows%d.npy" % r)), want_rows)
+        assert np.array_equal(np.load(tmp_path / ("scores%d.npy" % r)), want_scores)
+    fast, slow = np.load(tmp_path / "stamps0.npy"), np.load(tmp_path / "stamps1.npy")
+    assert sorted(fast[:, 1].tolist() + slow[:, 1].tolist()) == [float(n) for n in range(16, 31)]
+    t_slow_first = slow[:, 0].min()
+    before = fast[fast[:, 0] < t_slow_first]
+    assert before.shape[0] >= 11, "rank 0 aligned only %d nodes while rank 1 was busy with its first" % before.shape[0]
+    # (internal nodes are numbered in post-order, node.h:479-495: 16 17 | 18, 19 20 | 21, 22, ...)
+    levels = {n: 1 for n in (16, 17, 19, 20, 23, 24, 26, 27)}
+    levels.update({18: 2, 21: 2, 25: 2, 28: 2, 22: 3, 29: 3, 30: 4})
+    assert {levels[int(n)] for n in before[:, 1]} >= {1, 2, 3}, "rank 0 never left level 1 before rank 1 posted"

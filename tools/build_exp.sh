@@ -4,6 +4,8 @@
 # schedule), then regenerates the product's loop.  Use with PAGAN_DP_LIB=... tests/diagnostics/probe_pair.py.
 set -e
 cd "$(dirname "$0")/.."
+# whatever happens below, csrc/ ends up with the PRODUCT's loop again (a variant that fails to build must not stay there)
+trap 'python tools/gen_hot_asm.py' EXIT
 for x in "$@"; do
     PG_HOT_EXP=$x python tools/gen_hot_asm.py
     python - "$x" <<'PY'
@@ -14,4 +16,3 @@ m.FLAGS += os.environ.get("PG_EXP_DEFS", "").split()     # e.g. PG_EXP_DEFS=-DPG
 print(m.build(force=True, out=m.HERE + "/libpagan_dp_exp_%s%s.so" % (sys.argv[1], os.environ.get("PG_EXP_TAG", ""))))
 PY
 done
-python tools/gen_hot_asm.py

@@ -3,7 +3,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r03
+O=$R/gpurun_out/prof_r04
 mkdir -p $O
 cd $R
 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_under_stats.json 2> $O/stats.err
