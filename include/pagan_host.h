@@ -191,6 +191,16 @@ pagan_hgraph *pagan_hgraph_leaf_codon(const char *nucleotides);
 pagan_hgraph *pagan_hgraph_parent(pagan_hgraph *left, pagan_hgraph *right, const pagan_result *res,
                                   float left_branch, float right_branch, const int32_t *parsimony,
                                   int32_t n_states, int32_t char_as, int32_t flags);
+/* The same parent built on the current HIP device (csrc/dp_parent.hip: Basic_alignment::build_ancestral_sequence,
+ * basic_alignment.cpp:36-653, as maps, scans and per-site loops).  Field for field the graph
+ * pagan_hgraph_parent returns; NULL without a device or on a HIP error (never a host-built graph in its place).
+ * info[5] (may be NULL): runs of skipped sites, rounds of the boundary pass's fixpoint, deleted sites, edge weights outside
+ * the log-weight table, log weights the host had to correct.  The tree walk uses it for nodes of 20,000 columns and more
+ * (PAGAN_PARENTS=host / device forces either); pagan_parents_device_calls counts those.                            */
+pagan_hgraph *pagan_hgraph_parent_device(pagan_hgraph *left, pagan_hgraph *right, const pagan_result *res,
+                                         float left_branch, float right_branch, const int32_t *parsimony,
+                                         int32_t n_states, int32_t char_as, int32_t flags, int32_t *info);
+long long pagan_parents_device_calls(void);
 void pagan_hgraph_view(const pagan_hgraph *g, pagan_graph *out);
 /* site_attr [n_sites][8] = state,type,path_state,left,right,count_since_used,ambiguous,n_fwd;
  * site_dist [n_sites]; edge_attr [n_edges][6] = start,end,used,count_since_used,

@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpagan_dp.so")
-SOURCES = ["dp_abi.hip", "dp_kernels.hip", "dp_pipe.hip", "dp_tiles.hip", "dp_fb.hip", "dp_anchors.hip", "host_model.cpp", "host_graph.cpp",
+SOURCES = ["dp_abi.hip", "dp_kernels.hip", "dp_pipe.hip", "dp_tiles.hip", "dp_fb.hip", "dp_anchors.hip", "dp_parent.hip", "host_model.cpp", "host_graph.cpp",
            "host_anchors.cpp", "host_tree.cpp", "host_pileup.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-pthread"]

@@ -7,6 +7,7 @@
 // are in the order the reference appends/iterates them, because that order decides DP ties.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -39,6 +40,9 @@ struct SeqGraph {
     bool terminal = false;                   // leaf (Sequence::is_terminal_sequence)
     std::string symbols;                     // leaf residues, sites 1..n-2 (sym_width characters each)
     int sym_width = 1;                       // characters a state prints as: 1, or 3 for codon graphs
+    // the graph's copy on a device, where the parent-graph builder of dp_parent.hip reads a child and leaves a parent (opaque
+    // here; released with the last copy of the graph).  The host arrays stay the authority for everything on the host.
+    std::shared_ptr<void> dev;
 
     int n_sites() const { return (int)state.size(); }
     int n_edges() const { return (int)e_start.size(); }
@@ -74,6 +78,15 @@ SeqGraph make_leaf_states(const std::vector<int32_t> &states, std::string symbol
 SeqGraph make_parent(SeqGraph &left, SeqGraph &right, const pagan_result &res, float left_branch,
                      float right_branch, const int32_t *parsimony, int n_states, int char_as,
                      const BuildSettings &bs);
+
+// The same graph built on a device (dp_parent.hip): sites as a map over the path's columns, a site's
+// edges by one thread, ids and lists by scans, the boundary pass as a fixpoint over runs of skipped sites.  Returns false
+// (and leaves *out alone) without a device or on a HIP error: the caller then takes make_parent.  device < 0: the current one.
+struct ParentBuildInfo { int runs = 0, rounds = 0, deleted_sites = 0, weights_outside_table = 0, log_weights_patched = 0; };
+bool make_parent_device(SeqGraph &left, SeqGraph &right, const pagan_result &res, float left_branch, float right_branch,
+                        const int32_t *parsimony, int n_states, int char_as, const BuildSettings &bs, int device, SeqGraph *out,
+                        ParentBuildInfo *info = nullptr);
+void parent_release_cache();
 
 // Sequence::get_sequence_string (src/main/sequence.cpp:704-740)
 std::string sequence_string(const SeqGraph &g, bool with_gaps, const std::string &full_alphabet);

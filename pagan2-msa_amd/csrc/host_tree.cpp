@@ -481,6 +481,8 @@ void fix_ambiguous_states(pagan_msa *m, int id) {
     }
 }
 
+std::atomic<long long> parents_on_device{0};                     // (diagnostic: pagan_parents_device_calls)
+
 // add_ancestral_sequence(va.get_simple_sequence()) (node.cpp:166): the parent graph from the path.
 int build_parent(pagan_msa *m, int id) {
     NodeWork &w = m->work[id - m->n_leaves];
@@ -491,8 +493,28 @@ int build_parent(pagan_msa *m, int id) {
     const TreeNode &t = m->tree[m->tree_of_id[id]];
     SeqGraph &gl = m->graph[m->id_of_tree[t.left]]->g, &gr = m->graph[m->id_of_tree[t.right]]->g;
     m->graph[id].reset(new pagan_hgraph());
-    m->graph[id]->g = make_parent(gl, gr, w.res, (float)m->tree[t.left].dist, (float)m->tree[t.right].dist,
-                                  m->state_table.data(), m->mf.S, m->mf.char_as, bs);
+    // The parent on the device the node was aligned on (dp_parent.hip; its copy there stays for the build one level up) when
+    // the graphs are long enough for a dozen launches to beat one host thread's walk over the columns; PAGAN_PARENTS=host /
+    // device forces either.  --mostcommon rewrites states below the node afterwards (fix_ambiguous_states): host only.
+    bool on_device = false;
+    if (!m->backend && !m->opts.mostcommon && w.device >= 0) {
+        const char *e = std::getenv("PAGAN_PARENTS");
+        const bool force_host = e && std::strcmp(e, "host") == 0, force_dev = e && std::strcmp(e, "device") == 0;
+        if (!force_host && (force_dev || w.res.n_cols >= 20000)) {
+            SeqGraph g;
+            if (make_parent_device(gl, gr, w.res, (float)m->tree[t.left].dist, (float)m->tree[t.right].dist, m->state_table.data(),
+                                   m->mf.S, m->mf.char_as, bs, w.device, &g)) {
+                m->graph[id]->g = std::move(g);
+                on_device = true;
+                parents_on_device.fetch_add(1);
+            }
+        }
+    }
+    if (!on_device)
+        m->graph[id]->g = make_parent(gl, gr, w.res, (float)m->tree[t.left].dist, (float)m->tree[t.right].dist,
+                                      m->state_table.data(), m->mf.S, m->mf.char_as, bs);
+    // (grandchildren's device copies are no longer needed: their parents are built)
+    gl.dev.reset(); gr.dev.reset();
     if (m->opts.mostcommon) fix_ambiguous_states(m, id);
     return PAGAN_OK;
 }
@@ -918,6 +940,22 @@ pagan_hgraph *pagan_hgraph_parent(pagan_hgraph *l, pagan_hgraph *r, const pagan_
     h->g = make_parent(l->g, r->g, *res, lbl, rbl, parsimony, S, char_as, bs);
     return h;
 }
+
+// The same graph built on the current device (dp_parent.hip).  NULL without a device or on a HIP error -- never a host-built
+// graph in its place.  info (may be NULL): runs of skipped sites, fixpoint rounds of the boundary pass, deleted sites, edge
+// weights outside the log table, log weights the host had to put right.
+pagan_hgraph *pagan_hgraph_parent_device(pagan_hgraph *l, pagan_hgraph *r, const pagan_result *res, float lbl, float rbl,
+                                         const int32_t *parsimony, int32_t S, int32_t char_as, int32_t flags, int32_t *info) {
+    BuildSettings bs;
+    if (flags & 1) bs.reads_mode();
+    if (flags & 2) bs.reduced_terminal = false;
+    pagan_hgraph *h = new pagan_hgraph();
+    ParentBuildInfo pi;
+    if (!make_parent_device(l->g, r->g, *res, lbl, rbl, parsimony, S, char_as, bs, -1, &h->g, &pi)) { delete h; return nullptr; }
+    if (info) { info[0] = pi.runs; info[1] = pi.rounds; info[2] = pi.deleted_sites; info[3] = pi.weights_outside_table; info[4] = pi.log_weights_patched; }
+    return h;
+}
+long long pagan_parents_device_calls(void) { return parents_on_device.load(); }
 
 void pagan_hgraph_view(const pagan_hgraph *g, pagan_graph *out) { *out = g->g.view(); }
 

@@ -96,6 +96,11 @@ def _lib():
         L.pagan_hgraph_parent.argtypes = [vp, vp, C.POINTER(abi.CResult), C.c_float, C.c_float, _i32p, C.c_int32,
                                           C.c_int32, C.c_int32]
         L.pagan_hgraph_parent.restype = vp
+        L.pagan_hgraph_parent_device.argtypes = [vp, vp, C.POINTER(abi.CResult), C.c_float, C.c_float, _i32p, C.c_int32,
+                                                 C.c_int32, C.c_int32, _i32p]
+        L.pagan_hgraph_parent_device.restype = vp
+        L.pagan_parents_device_calls.argtypes = []
+        L.pagan_parents_device_calls.restype = C.c_longlong
         L.pagan_hgraph_view.argtypes = [vp, C.POINTER(abi.CGraph)]
         L.pagan_hgraph_view.restype = None
         L.pagan_hgraph_attrs.argtypes = [vp, _i32p, _f32p, _i32p, _f32p]
@@ -193,7 +198,7 @@ HOST_EXPORTED = ["pagan_assign_units", "pagan_msa_default_opts", "pagan_msa_crea
                  "pagan_msa_node_info", "pagan_msa_node_job", "pagan_msa_node_result", "pagan_msa_timing_get",
                  "pagan_msa_alignment_length", "pagan_msa_alignment_row", "pagan_msa_write_fasta", "pagan_msa_write_fasta_nodes",
                  "pagan_msa_node_graph",
-                 "pagan_msa_destroy", "pagan_hgraph_leaf", "pagan_hgraph_parent", "pagan_hgraph_view",
+                 "pagan_msa_destroy", "pagan_hgraph_leaf", "pagan_hgraph_parent", "pagan_hgraph_parent_device", "pagan_parents_device_calls", "pagan_hgraph_view",
                  "pagan_hgraph_attrs", "pagan_hgraph_fwd", "pagan_hgraph_string", "pagan_hgraph_free",
                  "pagan_define_tunnel", "pagan_prefix_hits", "pagan_anchors_device_calls", "pagan_drop_bad_hits", "pagan_define_tunnel_overlapping",
                  "pagan_force_gap", "pagan_dna_model", "pagan_protein_model", "pagan_model_prob_table", "pagan_model_alphabets",
@@ -258,6 +263,29 @@ class HGraph:
         pars = np.ascontiguousarray(parsimony, np.int32)
         S = int(round(pars.size ** 0.5))
         return cls(_lib().pagan_hgraph_parent(left.h, right.h, C.byref(r), lbl, rbl, _ip(pars), S, char_as, flags))
+
+    @classmethod
+    def parent_device(cls, left, right, result, lbl, rbl, parsimony, char_as, flags=0):
+        """The same parent built on the current HIP device (csrc/dp_parent.hip).  Raises without a device: there is no
+        host graph in its place.  The returned graph carries `.build_info` = (runs of skipped sites, rounds of the boundary
+        pass, deleted sites, weights outside the log table, log weights corrected by the host)."""
+        r = abi.CResult()
+        cols = np.ascontiguousarray(result.cols, np.int32)
+        lu = np.ascontiguousarray(result.left_used, np.int32)
+        ru = np.ascontiguousarray(result.right_used, np.int32)
+        r.n_cols = int(cols.shape[0])
+        r.cols = C.cast(_ip(cols), C.POINTER(abi.CCol))
+        r.n_left_used, r.left_used = int(lu.shape[0]), _ip(lu)
+        r.n_right_used, r.right_used = int(ru.shape[0]), _ip(ru)
+        pars = np.ascontiguousarray(parsimony, np.int32)
+        S = int(round(pars.size ** 0.5))
+        info = np.zeros(8, np.int32)
+        h = _lib().pagan_hgraph_parent_device(left.h, right.h, C.byref(r), lbl, rbl, _ip(pars), S, char_as, flags, _ip(info))
+        if not h:
+            raise RuntimeError("pagan_hgraph_parent_device failed: no HIP device, or a HIP error")
+        g = cls(h)
+        g.build_info = tuple(int(x) for x in info[:5])
+        return g
 
     def __del__(self):
         if getattr(self, "owned", False) and self.h:

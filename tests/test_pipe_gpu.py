@@ -196,7 +196,8 @@ def test_a_wrong_back_pointer_on_the_path_is_seen_and_the_batch_runs_again(pg, o
     b.run(); b.sync()
     same(b.fetch()[0], want)
     assert b.debug_reruns() == 0
-    for t in (5, 200, 650):
+    n_real = int(np.isin(want.cols[:, 2], (2, 3, 4)).sum())       # the traceback visits one cell per real column
+    for t in (5, 200, n_real - 40):
         before = b.debug_reruns()
         _poke_on_path(pg, b, t)
         b.run(); b.sync()
