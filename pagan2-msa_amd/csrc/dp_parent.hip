@@ -30,7 +30,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -510,6 +512,9 @@ StreamPool pp_streams;
 // takes the host builder.  The parent's device copy stays with it (SeqGraph::dev) for the build one level up.
 bool make_parent_device(SeqGraph &left, SeqGraph &right, const pagan_result &res, float lbl, float rbl, const int32_t *parsimony,
                         int S, int char_as, const BuildSettings &bs, int device, SeqGraph *out, ParentBuildInfo *info_out) {
+    const bool verbose = std::getenv("PAGAN_DP_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     if (device < 0) { if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return false; } }
     else PPHIP(hipSetDevice(device));
     for (int k = 0; k < res.n_left_used; ++k) left.e_used[res.left_used[k]] = 1;
@@ -522,6 +527,7 @@ bool make_parent_device(SeqGraph &left, SeqGraph &right, const pagan_result &res
     const bool r_was = right.dev && static_cast<DevGraph *>(right.dev.get())->device == device;
     if (!resident(left, device, st, &dl) || !resident(right, device, st, &dr)) return false;
 
+    const double t1 = now();
     const int n = res.n_cols + 2;
     const int nbL = left.bwd_off[left.n_sites()], nbR = right.bwd_off[right.n_sites()];
     const int e_cap = nbL + nbR + 2 * n;
@@ -612,8 +618,10 @@ bool make_parent_device(SeqGraph &left, SeqGraph &right, const pagan_result &res
     hipLaunchKernelGGL(pp_final_lists, dim3((n + 255) / 256), dim3(256), 0, st, A);
     PPHIP(hipGetLastError());
     int32_t info[16];
+    const double t2 = now();
     PPHIP(hipMemcpyAsync(info, A.info, sizeof(info), hipMemcpyDeviceToHost, st));
     PPHIP(hipStreamSynchronize(st));
+    const double t3 = now();
     const int E = info[0], nbw = info[1], nfw = info[2];
     if (E < 0 || E > e_cap || nbw < 0 || nbw > E || nfw < 0 || nfw > E) return false;
     pd->n_edges = E;
@@ -637,6 +645,9 @@ bool make_parent_device(SeqGraph &left, SeqGraph &right, const pagan_result &res
                     down(g.bwd_logw.data(), pd->bwd_logw, 4 * (size_t)nbw) && down(g.fwd_eid.data(), pd->fwd_eid, 4 * (size_t)nfw);
     if (!ok) { (void)hipGetLastError(); return false; }
     PPHIP(hipStreamSynchronize(st));
+    if (verbose)
+        std::fprintf(stderr, "pagan_dp: parent of %d sites on device %d: children resident %.2f ms (%d %d), launches %.2f ms, kernels %.2f ms, download %.2f ms\n",
+                     n, device, 1e3 * (t1 - t0), (int)l_was, (int)r_was, 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (now() - t3));
     // the host's logf is the authority for a weight's logarithm (the table covers what the rules produce; a weight outside
     // it is counted, and put right here and on the device)
     int patched = 0;

@@ -484,7 +484,7 @@ void fix_ambiguous_states(pagan_msa *m, int id) {
 std::atomic<long long> parents_on_device{0};                     // (diagnostic: pagan_parents_device_calls)
 
 // add_ancestral_sequence(va.get_simple_sequence()) (node.cpp:166): the parent graph from the path.
-int build_parent(pagan_msa *m, int id) {
+int build_parent(pagan_msa *m, int id, int unit_nodes) {
     NodeWork &w = m->work[id - m->n_leaves];
     if (!w.has_res || w.res.status != PAGAN_DP_REACHED) return PAGAN_E_INTERNAL;
     BuildSettings bs;
@@ -500,7 +500,10 @@ int build_parent(pagan_msa *m, int id) {
     if (!m->backend && !m->opts.mostcommon && w.device >= 0) {
         const char *e = std::getenv("PAGAN_PARENTS");
         const bool force_host = e && std::strcmp(e, "host") == 0, force_dev = e && std::strcmp(e, "device") == 0;
-        if (!force_host && (force_dev || w.res.n_cols >= 20000)) {
+        // (a wide level's parents are built side by side on the host's threads, and as many uploads of leaf-sized children
+        //  at once cost more than they save: measured on 32 x 100 kb, 16 nodes 17 ms on the device against 7 on 16 threads,
+        //  one node 3 ms against 8-15; so the device takes the levels of at most four long nodes)
+        if (!force_host && (force_dev || (w.res.n_cols >= 20000 && unit_nodes <= 4))) {
             SeqGraph g;
             if (make_parent_device(gl, gr, w.res, (float)m->tree[t.left].dist, (float)m->tree[t.right].dist, m->state_table.data(),
                                    m->mf.S, m->mf.char_as, bs, w.device, &g)) {
@@ -570,7 +573,7 @@ int run_unit(pagan_msa *m, const std::vector<int> &ids, int dev, int round, int 
     const double t_dp = now_s() - t0;
     t0 = now_s();
     std::atomic<int> bad(0);
-    parallel_for((int)ids.size(), threads, [&](int r) { if (build_parent(m, ids[r]) != PAGAN_OK) bad = 1; });
+    parallel_for((int)ids.size(), threads, [&](int r) { if (build_parent(m, ids[r], (int)ids.size()) != PAGAN_OK) bad = 1; });
     const double t_build = now_s() - t0;
     {
         std::lock_guard<std::mutex> g(m->mu);
@@ -817,7 +820,7 @@ int pagan_msa_import_result(pagan_msa *m, const void *buf, int64_t bytes) {
     w.has_res = true; w.has_job = false; w.device = -1; w.node = id; w.level = m->rounds;
     w.imp_l = gl.n_sites(); w.imp_r = gr.n_sites();         // (no job was prepared here: node_info reports the children's sizes from these)
     const double t0 = now_s();
-    const int rc = build_parent(m, id);
+    const int rc = build_parent(m, id, 1 << 20);          // (imported: w.device is -1, the host builder)
     m->tm.build_s += now_s() - t0;
     if (rc != PAGAN_OK) return rc;
     m->done[id] = 1; --m->remaining;
