@@ -10,9 +10,11 @@
 // quantity is a logarithm (product = sum, sum = log-sum-exp in fp64).  Same cell layout as the Viterbi kernels
 // (diagonal-major, [cell][X, Y, M]), same anti-diagonal wavefront: forward sweeps d = 0 .. nd-1 reading predecessor
 // cells through the bwd edge lists, backward sweeps d = nd-1 .. 0 reading successor cells through the fwd edge lists
-// (built on the host from the bwd CSR: a site's fwd list is its outgoing edges in creation order).  One workgroup per
-// alignment, a __syncthreads() per anti-diagonal, operands in HBM/L2: this is the plain formulation (the "next" row f3
-// of the scope table), not the latency-tuned one of dp_pipe.hip.
+// (built on the host from the bwd CSR: a site's fwd list is its outgoing edges in creation order).  Operands in HBM/L2.
+// Schedule: an alignment whose diagonals are narrow (a band) is one workgroup with a __syncthreads() per anti-diagonal;
+// a wide one (round 4) is cut into 64 x 64 blocks that a grid of one-wave workgroups works through block anti-diagonal by
+// block anti-diagonal (see pg_fb_forward_tiled below).  The sums here need to agree with the reference's to 1e-9, not bit
+// for bit (log-sum-exp in place of its products), so unlike the Viterbi kernels nothing constrains the order of evaluation.
 //
 // Reference quirks kept (see oracle/oracle_fb.cpp, which restates the same rules on the CPU): full-probability terms
 // use gap_ext for every gap (no end-gap extension) and the plain gap-open probability; edge weights enter matches only;
@@ -26,7 +28,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../include/pagan_dp.h"
@@ -60,24 +64,58 @@ namespace {
 
 __device__ __forceinline__ double ninf() { return -__builtin_huge_val(); }
 
-// log(exp(a) + exp(b))
-__device__ __forceinline__ double lse(double a, double b) {
-    if (b == ninf()) return a;
-    if (a == ninf()) return b;
-    const double hi = a > b ? a : b, lo = a > b ? b : a;
-    return hi + log1p(exp(lo - hi));
+// The sums' transcendental functions.  A log-sum-exp only ever asks for exp(x) with x <= 0 and for log(z) with
+// 1 <= z <= 3 (the largest term factored out, at most two more), and it needs them to ~1e-16 ABSOLUTE: the library's
+// exp / log1p -- correct to an ulp over their whole domain, special cases and all -- were ~3,000 of the instructions of a
+// cell (the sweep's chain is latency of exactly these).  Here: exp by the usual reduction x = n ln2 + r and a degree-13
+// Taylor polynomial in r (|r| <= 0.347: remainder 4e-18), log by z = 2^k m, m in (0.707, 1.415], s = (m - 1) / (m + 1),
+// log m = 2 atanh s as a polynomial of degree 11 in s^2 (s^2 <= 0.0295: remainder 6e-19).  fma() explicitly: the file is
+// compiled without contraction.
+__device__ __forceinline__ double fb_exp_neg(double x) {
+    x = fmax(x, -60.0);                                            // (e^-60 = 9e-27 beside a term of 1: nothing; and no -inf - -inf below)
+    const double n = rint(x * 1.4426950408889634074);
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                             // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);  p = fma(p, r, 2.505210838544172e-08); p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.755731922398589e-06); p = fma(p, r, 2.48015873015873e-05);  p = fma(p, r, 1.984126984126984e-04);
+    p = fma(p, r, 1.388888888888889e-03); p = fma(p, r, 8.333333333333333e-03); p = fma(p, r, 4.1666666666666664e-02);
+    p = fma(p, r, 1.6666666666666666e-01); p = fma(p, r, 0.5); p = fma(p, r, 1.0); p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+__device__ __forceinline__ double fb_log_1to3(double z) {
+    const bool k1 = z > 1.4142135623730951, k2 = z > 2.8284271247461903;
+    const double m = k2 ? 0.25 * z : (k1 ? 0.5 * z : z);
+    const double kl = k2 ? 1.3862943611198906 : (k1 ? 0.6931471805599453 : 0.0);
+    const double den = m + 1.0;
+    double y = __builtin_amdgcn_rcp(den);
+    y = fma(fma(-den, y, 1.0), y, y);
+    y = fma(fma(-den, y, 1.0), y, y);
+    const double num = m - 1.0;
+    double sq = num * y;
+    sq = fma(fma(-den, sq, num), y, sq);                           // one more correction of the quotient itself
+    const double w = sq * sq;
+    double p = 1.0 / 23.0;
+    p = fma(p, w, 1.0 / 21.0); p = fma(p, w, 1.0 / 19.0); p = fma(p, w, 1.0 / 17.0); p = fma(p, w, 1.0 / 15.0);
+    p = fma(p, w, 1.0 / 13.0); p = fma(p, w, 1.0 / 11.0); p = fma(p, w, 1.0 / 9.0);  p = fma(p, w, 1.0 / 7.0);
+    p = fma(p, w, 1.0 / 5.0);  p = fma(p, w, 1.0 / 3.0);  p = fma(p, w, 1.0);
+    return fma(2.0 * sq, p, kl);
 }
 
-// log(exp(a) + exp(b) + exp(c)) with one log1p: the largest term is factored out, the other two cost an exp each (the chain
-// lse(lse(a, b), c) costs two exp and two log1p; the sums agree to the last few ulps, the tests compare logs to 1e-9)
+// log(exp(a) + exp(b))
+__device__ __forceinline__ double lse(double a, double b) {
+    const double hi = fmax(a, b), lo = fmin(a, b);
+    if (hi == ninf()) return hi;
+    return hi + fb_log_1to3(1.0 + fb_exp_neg(lo - hi));
+}
+
+// log(exp(a) + exp(b) + exp(c)): the largest term is factored out, the other two cost an exp each
 __device__ __forceinline__ double lse3(double a, double b, double c) {
     const double hi = fmax(a, fmax(b, c));
     if (hi == ninf()) return hi;
-    double rest;
-    if (a == hi) rest = exp(b - hi) + exp(c - hi);
-    else if (b == hi) rest = exp(a - hi) + exp(c - hi);
-    else rest = exp(a - hi) + exp(b - hi);
-    return hi + log1p(rest);
+    // the two that are not the (first) largest
+    const double u = a == hi ? b : a, v = (a == hi || b == hi) ? c : b;
+    return hi + fb_log_1to3(1.0 + (fb_exp_neg(u - hi) + fb_exp_neg(v - hi)));
 }
 
 __device__ __forceinline__ long long cell_at(const PgFbJob &J, int p, int q) {
@@ -189,6 +227,310 @@ __global__ __launch_bounds__(1024) void pg_fb_backward(const PgFbJob *jobs) {
     if (threadIdx.x == 0) J.totals[1] = rd(J.B, cell_at(J, 0, 0), 2);
 }
 
+// ---- wide alignments: 64 x 64 blocks on a block-anti-diagonal schedule ----
+// Block (a, b) needs blocks (a', b') <= (a, b) only (bwd edges point to earlier sites), so the blocks of one block
+// anti-diagonal are independent: workgroup g of the sweep's grid takes the blocks g, g + G, ... of block diagonal t, one
+// wave each, and all workgroups meet at a counter barrier before t + 1 -- Lx/64 + Ly/64 barriers per sweep where a barrier
+// per cell diagonal cost more than the cells (14 us per diagonal measured: written-through stores, loads from beyond the
+// L2).  Inside a block the wave sweeps the block's own 127 anti-diagonals, lane r on row i0 + r: the last FB_RING of them
+// live in LDS, and so do the row above / column left of the block (forward) or the row below / column right of it
+// (backward); anything else -- an edge that reaches further -- is a load from L2/HBM.  The wave's own stores go out
+// unwaited-for; only a read of a cell of its own block that has left the ring waits for them.
+// Barrier (MI355X_MICROARCH.md, "Valid forms", producer / consumer with fences): the wave's s_waitcnt vmcnt(0), the
+// workgroup barrier, lane 0's agent release + wait, its relaxed agent add; lane 0 polls (relaxed, agent), then agent
+// acquire + wait, workgroup barrier, plain loads.
+#define FB_T 64
+#define FB_RING 16
+#define FB_MAX_GROUPS 32
+#define FB_SPIN_LIMIT (1 << 22)
+typedef __attribute__((address_space(1))) int *fb_gi;
+
+struct FbSmem {
+    double ring[FB_RING][FB_T][3];
+    double ha[FB_T + 1][3];          // forward: cells (i0-1, j0-1+k); backward: (i0+64, j0+k)
+    double hb[FB_T + 1][3];          // forward: cells (i0-1+k, j0-1); backward: (i0+k, j0+64)
+    // what a step reads besides cells, staged per block: nothing of the common path is a load from memory (a load would
+    // queue behind the wave's stores in flight: vector memory operations complete in order)
+    int dmin[2 * FB_T], dmax[2 * FB_T];      // band interval of the block's diagonals
+    long long doff[2 * FB_T];
+    int c_off[FB_T + 1], c_n[FB_T + 1], c_e0[FB_T + 1], c_st[FB_T + 1];   // columns j0 + k: first list entry, entries, the first entry's other end, state
+    float c_lw0[FB_T + 1];
+    double ltab[256];                // the model's log scores when S * S <= 256
+};
+
+// sync[0] arrivals, sync[1] nonzero: a workgroup gave up (a logic error becomes a status instead of a hung GPU).
+__device__ __forceinline__ bool fb_barrier(int *sync, int target) {
+    __shared__ int ok;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        fb_gi g = (fb_gi)(unsigned long long)sync;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0, good = 1;
+        while (__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 255) == 0 && (spins > FB_SPIN_LIMIT || __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                __hip_atomic_store(g + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ok = good;
+    }
+    __syncthreads();
+    return ok != 0;
+}
+
+// does block (a, b) hold a cell of the band?
+__device__ __forceinline__ bool fb_block_live(const PgFbJob &J, int i0, int j0, int r) {
+    bool any = false;
+    for (int u = 0; u < 2; ++u) {
+        const int d = i0 + j0 + r + 64 * u;
+        if (d >= J.nd || r + 64 * u > 2 * FB_T - 2) continue;
+        const int lo = max(max(J.imin[d], i0), d - (j0 + FB_T - 1)), hi = min(min(J.imax[d], i0 + FB_T - 1), d - j0);
+        any = any || lo <= hi;
+    }
+    return __builtin_amdgcn_ballot_w64(any) != 0;
+}
+
+// LDS traffic of the one wave is in order; this keeps the compiler from moving it and waits for nothing in memory
+__device__ __forceinline__ void fb_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ void fb_stage_diagonals(const PgFbJob &J, FbSmem &M, int dbase, int r) {
+    for (int k = r; k < 2 * FB_T; k += 64) {
+        const int d = dbase + k;
+        const bool in = d < J.nd;
+        M.dmin[k] = in ? J.imin[d] : 0; M.dmax[k] = in ? J.imax[d] : -1; M.doff[k] = in ? J.doff[d] : 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs, int *sync) {
+    __shared__ FbSmem M;
+    const PgFbJob J = jobs[0];
+    const int G = (int)gridDim.x, r = (int)threadIdx.x;
+    const int nbr = (J.Lx + FB_T - 1) / FB_T, nbc = (J.Ly + FB_T - 1) / FB_T;
+    const double NI = ninf();
+    const bool tab_lds = J.S * J.S <= 256;
+    if (tab_lds) for (int k = r; k < J.S * J.S; k += 64) M.ltab[k] = J.ltab[k];
+    for (int t = 0; t < nbr + nbc - 1; ++t) {
+        const int a_lo = max(0, t - (nbc - 1)), a_hi = min(t, nbr - 1);
+        for (int a = a_lo + (int)blockIdx.x; a <= a_hi; a += G) {
+            const int i0 = a * FB_T, j0 = (t - a) * FB_T, dbase = i0 + j0;
+            if (!fb_block_live(J, i0, j0, r)) continue;
+            __syncthreads();                                                       // (the block before is done with the staging arrays)
+            // halo: the row above (with the corner) and the column to the left; the columns' records; the diagonals' intervals
+            for (int k = r; k <= FB_T; k += 64) {
+                const long long ta = cell_at(J, i0 - 1, j0 - 1 + k), tb = cell_at(J, i0 - 1 + k, j0 - 1);
+                for (int q = 0; q < 3; ++q) { M.ha[k][q] = rd(J.F, ta, q); M.hb[k][q] = rd(J.F, tb, q); }
+            }
+            {
+                const int jc = j0 + r;
+                const bool cv = jc < J.Ly && jc > 0;
+                const int o0 = cv ? J.offR[jc] : 0, o1 = cv ? J.offR[jc + 1] : 0;
+                M.c_off[r] = o0; M.c_n[r] = o1 - o0; M.c_st[r] = jc < J.Ly ? J.stR[jc] : 0;
+                M.c_e0[r] = o1 > o0 ? J.srcR[o0] : 0; M.c_lw0[r] = o1 > o0 ? J.lwR[o0] : 0.0f;
+            }
+            fb_stage_diagonals(J, M, dbase, r);
+            for (int k = r; k < FB_RING * FB_T; k += 64) { double *c = &M.ring[0][0][0] + 3 * k; c[0] = NI; c[1] = NI; c[2] = NI; }
+            const int i = i0 + r;
+            const bool rv = i < J.Lx && i > 0;
+            const int l0 = rv ? J.offL[i] : 0, nl = rv ? J.offL[i + 1] - l0 : 0;
+            const int p0 = nl > 0 ? J.srcL[l0] : 0, stl = i < J.Lx ? J.stL[i] : 0;
+            const double lwl0 = nl > 0 ? (double)J.lwL[l0] : 0.0;
+            __syncthreads();
+            for (int s = 0; s <= 2 * FB_T - 2; ++s) {
+                const int d = dbase + s;
+                if (d >= J.nd) break;
+                const int j = d - i, jj = s - r;
+                const int mn = M.dmin[s], mx = M.dmax[s];
+                const bool active = jj >= 0 && jj < FB_T && i < J.Lx && j < J.Ly && i >= mn && i <= mx;
+                double fx = NI, fy = NI, fm = NI;
+                if (active) {
+                    auto fetch = [&](int p, int q, double &x, double &y, double &m) {
+                        x = NI; y = NI; m = NI;
+                        if (p < 0 || q < 0) return;
+                        const double *c = nullptr;
+                        if (p >= i0 && q >= j0) {
+                            if (d - (p + q) < FB_RING) c = M.ring[(p + q) % FB_RING][p - i0];
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // a cell of this block that left the ring: the wave's own store
+                        } else if (p == i0 - 1 && q >= j0 - 1) c = M.ha[q - (j0 - 1)];
+                        else if (q == j0 - 1 && p >= i0 - 1) c = M.hb[p - (i0 - 1)];
+                        if (c) { x = c[0]; y = c[1]; m = c[2]; return; }
+                        const long long at = cell_at(J, p, q);
+                        x = rd(J.F, at, 0); y = rd(J.F, at, 1); m = rd(J.F, at, 2);
+                    };
+                    if (i == 0 && j == 0) {
+                        fm = 0.0;                                                  // fwd_score = 1, VA:730
+                    } else {
+                        double x, y, m;
+                        const int r0 = M.c_off[jj], nr = M.c_n[jj], q0 = M.c_e0[jj];
+                        const double lwr0 = (double)M.c_lw0[jj];
+                        for (int k = 0; k < nl; ++k) {
+                            fetch(k == 0 ? p0 : J.srcL[l0 + k], j, x, y, m);
+                            fx = lse(fx, lse3(x + J.l_ext, y + J.l_open, m + J.l_ng + J.l_open));              // VA:2153, 2184, 2215
+                        }
+                        for (int k = 0; k < nr; ++k) {
+                            fetch(i, k == 0 ? q0 : J.srcR[r0 + k], x, y, m);
+                            fy = lse(fy, lse3(y + J.l_ext, x + J.l_open, m + J.l_ng + J.l_open));
+                        }
+                        if (nl > 0 && nr > 0) {
+                            const int ti = stl + M.c_st[jj] * J.S;
+                            const double sc = tab_lds ? M.ltab[ti] : J.ltab[stl + (long long)M.c_st[jj] * J.S];
+                            const double mm = J.l_ng + J.l_ng + sc, xm = J.l_ng + sc;                         // VA:1383-1391
+                            for (int k1 = 0; k1 < nl; ++k1)
+                                for (int k2 = 0; k2 < nr; ++k2) {
+                                    fetch(k1 == 0 ? p0 : J.srcL[l0 + k1], k2 == 0 ? q0 : J.srcR[r0 + k2], x, y, m);
+                                    const double w = (k1 == 0 ? lwl0 : (double)J.lwL[l0 + k1]) + (k2 == 0 ? lwr0 : (double)J.lwR[r0 + k2]);
+                                    fm = lse(fm, lse3(m + mm + w, x + xm + w, y + xm + w));                   // VA:2051, 2080, 2108
+                                }
+                        }
+                    }
+                    double *o = J.F + 3 * (M.doff[s] + (i - mn));
+                    o[0] = fx; o[1] = fy; o[2] = fm;
+                }
+                double *c = M.ring[d % FB_RING][r];
+                c[0] = fx; c[1] = fy; c[2] = fm;
+                fb_lds_fence();
+            }
+        }
+        if (!fb_barrier(sync, G * (t + 1))) return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // end corner, VA:1440-1552
+        double acc = NI;
+        const int l0 = J.offL[J.Lx], l1 = J.offL[J.Lx + 1], r0 = J.offR[J.Ly], r1 = J.offR[J.Ly + 1];
+        auto mt = [&](int k1, int k2) { return rd(J.F, cell_at(J, J.srcL[k1], J.srcR[k2]), 2) + J.l_ng + (double)J.lwL[k1] + (double)J.lwR[k2]; };
+        auto xc = [&](int k1) { return rd(J.F, cell_at(J, J.srcL[k1], J.Ly - 1), 0); };
+        auto yc = [&](int k2) { return rd(J.F, cell_at(J, J.Lx - 1, J.srcR[k2]), 1); };
+        if (l1 > l0 && r1 > r0) {
+            acc = lse(acc, mt(l0, r0)); acc = lse(acc, xc(l0)); acc = lse(acc, yc(r0));
+            for (int k2 = r0 + 1; k2 < r1; ++k2) { acc = lse(acc, mt(l0, k2)); acc = lse(acc, yc(k2)); }
+            for (int k1 = l0 + 1; k1 < l1; ++k1) {
+                acc = lse(acc, mt(k1, r0)); acc = lse(acc, xc(k1));
+                for (int k2 = r0 + 1; k2 < r1; ++k2) { acc = lse(acc, mt(k1, k2)); acc = lse(acc, yc(k2)); }
+            }
+        }
+        J.totals[0] = acc;
+    }
+}
+
+__global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs, int *sync) {
+    __shared__ FbSmem M;
+    const PgFbJob J = jobs[0];
+    const int G = (int)gridDim.x, r = (int)threadIdx.x;
+    const int nbr = (J.Lx + FB_T - 1) / FB_T, nbc = (J.Ly + FB_T - 1) / FB_T;
+    const double NI = ninf();
+    const bool tab_lds = J.S * J.S <= 256;
+    if (tab_lds) for (int k = r; k < J.S * J.S; k += 64) M.ltab[k] = J.ltab[k];
+    // (no fill of B: every cell of the band is written by the sweep before anything reads it; what
+    //  initialise_array_corner_bwd assigns -- a handful of cells at the end corner, VA:740-854 -- is laid over the -inf a
+    //  cell starts from, in the blocks that hold such a cell)
+    int round = 0;
+    for (int t = nbr + nbc - 2; t >= 0; --t) {
+        const int a_lo = max(0, t - (nbc - 1)), a_hi = min(t, nbr - 1);
+        for (int a = a_lo + (int)blockIdx.x; a <= a_hi; a += G) {
+            const int i0 = a * FB_T, j0 = (t - a) * FB_T, dbase = i0 + j0;
+            if (!fb_block_live(J, i0, j0, r)) continue;
+            __syncthreads();
+            // halo: the row below and the column to the right (with the corner at [64]); the columns' fwd records (one more
+            // column than the block has: a match moves to column j + 1); the diagonals' intervals
+            for (int k = r; k <= FB_T; k += 64) {
+                const long long ta = cell_at(J, i0 + FB_T, j0 + k), tb = cell_at(J, i0 + k, j0 + FB_T);
+                for (int q = 0; q < 3; ++q) { M.ha[k][q] = rd(J.B, ta, q); M.hb[k][q] = rd(J.B, tb, q); }
+                const int jc = j0 + k;
+                const bool cv = jc < J.Ly;
+                const int o0 = cv ? J.foffR[jc] : 0, o1 = cv ? J.foffR[jc + 1] : 0;
+                M.c_off[k] = o0; M.c_n[k] = o1 - o0; M.c_st[k] = cv ? J.stR[jc] : 0;
+                M.c_e0[k] = o1 > o0 ? J.fdstR[o0] : 0; M.c_lw0[k] = o1 > o0 ? J.flwR[o0] : 0.0f;
+            }
+            fb_stage_diagonals(J, M, dbase, r);
+            for (int k = r; k < FB_RING * FB_T; k += 64) { double *c = &M.ring[0][0][0] + 3 * k; c[0] = NI; c[1] = NI; c[2] = NI; }
+            const int i = i0 + r;
+            // does an assignment of initialise_array_corner_bwd fall into this block?  (lane r looks at the block's diagonals r, r + 64)
+            bool init_here = false;
+            for (int u = 0; u < 2 && J.n_init > 0; ++u) {
+                const int sd = r + 64 * u, d_ = dbase + sd;
+                if (sd > 2 * FB_T - 2 || d_ >= J.nd) continue;
+                const int mn_ = J.imin[d_], lo = max(max(mn_, i0), d_ - (j0 + FB_T - 1)), hi = min(min(J.imax[d_], i0 + FB_T - 1), d_ - j0);
+                if (lo > hi) continue;
+                const long long first = 3 * (J.doff[d_] + (lo - mn_)), last = 3 * (J.doff[d_] + (hi - mn_)) + 2;
+                for (int k = 0; k < J.n_init; ++k) init_here = init_here || (J.init_at[k] >= first && J.init_at[k] <= last);
+            }
+            const bool blk_init = __builtin_amdgcn_ballot_w64(init_here) != 0;
+            const bool rv = i < J.Lx;
+            const int l0 = rv ? J.foffL[i] : 0, nl = rv ? J.foffL[i + 1] - l0 : 0;
+            const int t0 = nl > 0 ? J.fdstL[l0] : 0;
+            const int st_t0 = nl > 0 && t0 < J.Lx ? J.stL[t0] : 0;
+            const double lwl0 = nl > 0 ? (double)J.flwL[l0] : 0.0;
+            __syncthreads();
+            for (int s = 2 * FB_T - 2; s >= 0; --s) {
+                const int d = dbase + s;
+                if (d >= J.nd) continue;
+                const int j = d - i, jj = s - r;
+                const int mn = M.dmin[s], mx = M.dmax[s];
+                const bool active = jj >= 0 && jj < FB_T && i < J.Lx && j < J.Ly && i >= mn && i <= mx;
+                double bx = NI, by = NI, bm = NI;
+                if (active) {
+                    // state q of cell (t_, u) >= (i, j)
+                    auto fetch = [&](int t_, int u, int q) -> double {
+                        if (t_ >= J.Lx || u >= J.Ly) return NI;
+                        if (t_ < i0 + FB_T && u < j0 + FB_T) {
+                            if ((t_ + u) - d < FB_RING) return M.ring[(t_ + u) % FB_RING][t_ - i0][q];
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // a cell of this block that left the ring: the wave's own store
+                        } else if (t_ == i0 + FB_T && u <= j0 + FB_T) return M.ha[u - j0][q];
+                        else if (u == j0 + FB_T && t_ <= i0 + FB_T) return M.hb[t_ - i0][q];
+                        return rd(J.B, cell_at(J, t_, u), q);
+                    };
+                    double *o = J.B + 3 * (M.doff[s] + (i - mn));
+                    if (blk_init) {
+                        const long long at3 = 3 * (M.doff[s] + (i - mn));
+                        for (int k = 0; k < J.n_init; ++k) {
+                            const long long w = J.init_at[k] - at3;
+                            if (w == 0) bx = J.init_val[k]; else if (w == 1) by = J.init_val[k]; else if (w == 2) bm = J.init_val[k];
+                        }
+                    }
+                    const int r0 = M.c_off[jj], nr = M.c_n[jj], u0 = M.c_e0[jj];
+                    const double lwr0 = (double)M.c_lw0[jj];
+                    for (int k = 0; k < nl; ++k) {                                 // iterate_fwd_edges_for_gap, left site
+                        const int t_ = k == 0 ? t0 : J.fdstL[l0 + k];
+                        if (t_ >= J.Lx) continue;                                  // VA:1580
+                        const double nx = fetch(t_, j, 0);
+                        bx = lse(bx, nx + J.l_ext); by = lse(by, nx + J.l_open); bm = lse(bm, nx + J.l_ng + J.l_open);   // VA:2281-2303
+                    }
+                    for (int k = 0; k < nr; ++k) {
+                        const int u = k == 0 ? u0 : J.fdstR[r0 + k];
+                        if (u >= J.Ly) continue;
+                        const double ny = fetch(i, u, 1);
+                        by = lse(by, ny + J.l_ext); bx = lse(bx, ny + J.l_open); bm = lse(bm, ny + J.l_ng + J.l_open);
+                    }
+                    for (int k1 = 0; k1 < nl; ++k1)                                // iterate_fwd_edges_for_match
+                        for (int k2 = 0; k2 < nr; ++k2) {
+                            const int t_ = k1 == 0 ? t0 : J.fdstL[l0 + k1], u = k2 == 0 ? u0 : J.fdstR[r0 + k2];
+                            if (t_ >= J.Lx || u >= J.Ly) continue;
+                            const int sl = k1 == 0 ? st_t0 : J.stL[t_];
+                            const int sr = (u >= j0 && u <= j0 + FB_T) ? M.c_st[u - j0] : J.stR[u];
+                            const double sc = tab_lds ? M.ltab[sl + sr * J.S] : J.ltab[sl + (long long)sr * J.S];
+                            const double thru = fetch(t_, u, 2) + sc + (k1 == 0 ? lwl0 : (double)J.flwL[l0 + k1]) +
+                                                (k2 == 0 ? lwr0 : (double)J.flwR[r0 + k2]);               // VA:2269-2271
+                            bx = lse(bx, thru + J.l_ng); by = lse(by, thru + J.l_ng); bm = lse(bm, thru + J.l_ng + J.l_ng);
+                        }
+                    o[0] = bx; o[1] = by; o[2] = bm;
+                }
+                double *c = M.ring[d % FB_RING][r];
+                c[0] = bx; c[1] = by; c[2] = bm;
+                fb_lds_fence();
+            }
+        }
+        ++round;
+        if (!fb_barrier(sync, G * round)) return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) J.totals[1] = rd(J.B, cell_at(J, 0, 0), 2);
+}
+
 struct FwdLists { std::vector<int> off, dst, slot; std::vector<float> lw; };
 
 // A site's fwd list = its outgoing edges in creation order (Edge::index); the log weight is the bwd CSR's.
@@ -224,6 +566,7 @@ struct pagan_fb {
     double *dF = nullptr, *dB = nullptr;
     double totals[2] = {0, 0};
     float kernel_ms[2] = {0, 0};                        // pg_fb_forward, pg_fb_backward (HIP events)
+    int groups = 1;                                     // workgroups a diagonal's cells were spread over
     std::vector<double> hF;                             // downloaded lazily
     long long at(int i, int j) const {
         if (i < 0 || j < 0 || i >= Lx || j >= Ly) return -1;
@@ -294,6 +637,7 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     const size_t o_imin = take(4 * (size_t)nd), o_imax = take(4 * (size_t)nd), o_doff = take(8 * (size_t)nd);
     const size_t o_iat = take(8 * init_at.size()), o_ival = take(8 * init_val.size());
     const size_t o_tot = take(16);
+    const size_t o_sync = take(64);                      // two barrier counters + give-up words of the wide sweeps (zero)
     const size_t in_bytes = cur;
     const size_t o_F = take(24 * (size_t)cells), o_B = take(24 * (size_t)cells);
     FB_TRY(hipMalloc((void **)&fb->arena, cur));
@@ -335,10 +679,36 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     FB_TRY(hipStreamCreate(&s1)); FB_TRY(hipStreamCreate(&s2));
     FB_TRY(hipEventCreate(&e0)); FB_TRY(hipEventCreate(&e1)); FB_TRY(hipEventCreate(&e2)); FB_TRY(hipEventCreate(&e3));
     FB_TRY(hipEventRecord(e0, s1));
-    hipLaunchKernelGGL(pg_fb_forward, dim3(1), dim3(block), 0, s1, (const PgFbJob *)(b + o_job));
+    // wide diagonals: 64 x 64 blocks over as many workgroups as a block anti-diagonal has blocks; PAGAN_FB_GROUPS=1 keeps the
+    // one-workgroup sweeps
+    int groups = mw > 256 ? std::min({FB_MAX_GROUPS, (Lx + FB_T - 1) / FB_T, (Ly + FB_T - 1) / FB_T}) : 1;
+    if (const char *e = std::getenv("PAGAN_FB_GROUPS")) groups = std::max(1, std::min(FB_MAX_GROUPS, std::atoi(e)));
+    fb->groups = groups;
+    // A sweep whose workgroups meet at a counter barrier needs ALL of them on the chip at once; a caller may have any number
+    // of alignments in flight from as many threads, and workgroups of one sweep holding compute units while they wait for
+    // siblings that other waiting sweeps keep out would never end (the barrier's spin limit would turn that into an error,
+    // seconds later).  So the tiled sweeps of a device share a budget of workgroup slots well inside what the device holds
+    // at this kernel's LDS size (4 per compute unit); a pair that does not fit waits here, on the host.
+    struct Slots {
+        std::mutex m; std::condition_variable cv; int used = 0;
+        void take(int n, int cap) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return used == 0 || used + n <= cap; }); used += n; }
+        void give(int n) { { std::lock_guard<std::mutex> l(m); used -= n; } cv.notify_all(); }
+    };
+    static Slots slots_of[64];
+    Slots &slots = slots_of[fb->device & 63];
+    int slot_cap = 512;
+    {
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, fb->device) == hipSuccess && n_cu > 0) slot_cap = 3 * n_cu;
+    }
+    struct SlotLease { Slots *s; int n; ~SlotLease() { if (n > 0) s->give(n); } } lease{&slots, groups > 1 ? 2 * groups : 0};
+    if (groups > 1) slots.take(2 * groups, slot_cap);
+    if (groups > 1) hipLaunchKernelGGL(pg_fb_forward_tiled, dim3(groups), dim3(64), 0, s1, (const PgFbJob *)(b + o_job), (int *)(b + o_sync));
+    else hipLaunchKernelGGL(pg_fb_forward, dim3(1), dim3(block), 0, s1, (const PgFbJob *)(b + o_job));
     FB_TRY(hipEventRecord(e1, s1));
     FB_TRY(hipEventRecord(e2, s2));
-    hipLaunchKernelGGL(pg_fb_backward, dim3(1), dim3(block), 0, s2, (const PgFbJob *)(b + o_job));
+    if (groups > 1) hipLaunchKernelGGL(pg_fb_backward_tiled, dim3(groups), dim3(64), 0, s2, (const PgFbJob *)(b + o_job), (int *)(b + o_sync) + 8);
+    else hipLaunchKernelGGL(pg_fb_backward, dim3(1), dim3(block), 0, s2, (const PgFbJob *)(b + o_job));
     FB_TRY(hipEventRecord(e3, s2));
     FB_TRY(hipGetLastError());
     FB_TRY(hipStreamSynchronize(s1)); FB_TRY(hipStreamSynchronize(s2));
@@ -347,6 +717,11 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
     (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2);
     FB_TRY(hipMemcpy(fb->totals, b + o_tot, 16, hipMemcpyDeviceToHost));
+    {
+        int sy[16];
+        FB_TRY(hipMemcpy(sy, b + o_sync, sizeof(sy), hipMemcpyDeviceToHost));
+        if (sy[1] != 0 || sy[9] != 0) return PAGAN_E_INTERNAL;      // a barrier of a wide sweep ran into its limit
+    }
     *out = guard.release();
     return PAGAN_OK;
 }

@@ -95,3 +95,22 @@ def test_errors(pg):
     with pytest.raises(pgm.PaganError) as e:
         pgm.FullProbability(g, g, bad)
     assert e.value.code == abi.PAGAN_E_MODEL
+
+
+def test_wide_pairs_spread_a_diagonal_over_several_workgroups(pg, oracle, monkeypatch):
+    """Full matrices of internal nodes (multi-edge sites, ~900-cell diagonals): the sweeps spread every diagonal's cells over
+    four workgroups with a counter barrier per diagonal (dp_fb.hip, pg_fb_*_wide); same logs as the oracle and as the
+    one-workgroup sweeps (PAGAN_FB_GROUPS=1) to the comparison's tolerance, forward total = backward total."""
+    names, seqs, nwk = synth.evolve_balanced(4, 900, branch=0.04, sub=0.04, indel_start=0.01, mean_len=4, seed=45)
+    msa = host.Msa(names, seqs, nwk, use_anchors=0).align()
+    bf = np.array([sum(s.count(x) for s in seqs) for x in "ACGT"], np.float32)
+    bf /= bf.sum()
+    left, right, _model, band = msa.node_job(2)           # the root: graph against graph
+    assert band is None and left.n_sites > 850 and (np.diff(left.bwd_off) > 1).sum() > 0
+    mp = host.model_prob(1, msa.node_info(2).dist, base_freq=bf)
+    fb, _post, logf = check_pair(oracle, left, right, mp)
+    assert abs(fb.log_fwd - fb.log_bwd) <= 1e-7 * abs(fb.log_fwd)
+    wide_f, wide_b = fb.log_forward().copy(), fb.log_backward().copy()
+    monkeypatch.setenv("PAGAN_FB_GROUPS", "1")
+    one = pgm.FullProbability(left, right, mp)
+    assert close_logs(one.log_forward(), wide_f) and close_logs(one.log_backward(), wide_b)
