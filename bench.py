@@ -102,6 +102,11 @@ def main():
     if world > 1 and args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    if (args.workload or "").startswith("fb_"):
+        # The forward/backward workload keeps 15 pairs x 2 sweeps in flight, a kernel each; the HIP runtime deals a process's
+        # streams onto 4 hardware queues unless told otherwise, and kernels of one queue run one after the other
+        # (measured: 4 queues 1.39e8 cells/s, 8 queues 2.68e8, 16 the same).  Has to be in the environment before HIP starts.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the aligner has no CPU path")
@@ -171,7 +176,8 @@ def bench_forward_backward(args, device):
         "ms_per_step": 1e3 * dev_s, "higher_is_better": True, "scaling": None, "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": workload, "leaves": leaves, "length": length, "node_pairs": n_nodes, "cells_per_step": int(cells),
-                   "note": "value = cells / wall-clock of a pass with all node pairs in flight at once (2 workgroups per pair); the per-kernel ms are sums of the kernels' own durations; wall per pass incl. allocation and upload: %.1f ms" % (1e3 * elapsed / args.steps)},
+                   "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "note": "value = cells / wall-clock of a pass with all node pairs in flight at once (wide pairs: two block-scheduled sweeps of up to 64 one-wave workgroups each); the per-kernel ms are sums of the kernels' own durations; wall per pass incl. allocation and upload: %.1f ms" % (1e3 * elapsed / args.steps)},
         "roofline": {"bound": "hbm", "achieved": 48 * cells / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": 48 * cells / dev_s / 1e9 / HBM_PEAK_GBS, "kernel": "pg_fb_forward + pg_fb_backward",
                      "algorithmic_bytes_per_cell": 48, "traffic": None,

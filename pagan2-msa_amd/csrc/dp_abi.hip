@@ -25,6 +25,7 @@
 #include <unordered_map>
 
 #include "host_anchors.h"
+#include "host_graph.h"
 #include "../../include/pagan_dp.h"
 #include "dp_device.h"
 #include "dp_band.h"
@@ -1709,8 +1710,11 @@ int pagan_dp_align(const pagan_graph *left, const pagan_graph *right, const paga
     return pagan_dp_align_batch(1, &jb, opts, out);
 }
 
+void pagan_fb_internal_release_cache();                        // dp_fb.hip
 void pagan_dp_release_cache(void) {
     pagan::anchors_release_cache();
+    pagan::parent_release_cache();
+    pagan_fb_internal_release_cache();
     arena_pool.clear(-1);
     gpu_pool.release();
     std::lock_guard<std::mutex> g(stage_pool.m);

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -240,21 +241,26 @@ __global__ __launch_bounds__(1024) void pg_fb_backward(const PgFbJob *jobs) {
 // workgroup barrier, lane 0's agent release + wait, its relaxed agent add; lane 0 polls (relaxed, agent), then agent
 // acquire + wait, workgroup barrier, plain loads.
 #define FB_T 64
-#define FB_RING 16
-#define FB_MAX_GROUPS 32
+#define FB_RING 12
+#define FB_H 8                   // halo depth: rows above / columns left of a block (forward), below / right of it (backward) kept in LDS
+#define FB_MAX_GROUPS 64
 #define FB_SPIN_LIMIT (1 << 22)
 typedef __attribute__((address_space(1))) int *fb_gi;
 
 struct FbSmem {
     double ring[FB_RING][FB_T][3];
-    double ha[FB_T + 1][3];          // forward: cells (i0-1, j0-1+k); backward: (i0+64, j0+k)
-    double hb[FB_T + 1][3];          // forward: cells (i0-1+k, j0-1); backward: (i0+k, j0+64)
+    // forward: ha[u][k] = cell (i0 - FB_H + u, j0 - FB_H + k), the FB_H rows above with the corner; hb[k][u] = cell (i0 + k, j0 - FB_H + u),
+    // the FB_H columns to the left.  backward: ha[u][k] = cell (i0 + 64 + u, j0 + k), the rows below with the corner at k >= 64;
+    // hb[k][u] = cell (i0 + k, j0 + 64 + u), the columns to the right
+    double ha[FB_H][FB_T + FB_H][3];
+    double hb[FB_T][FB_H][3];
     // what a step reads besides cells, staged per block: nothing of the common path is a load from memory (a load would
     // queue behind the wave's stores in flight: vector memory operations complete in order)
     int dmin[2 * FB_T], dmax[2 * FB_T];      // band interval of the block's diagonals
     long long doff[2 * FB_T];
-    int c_off[FB_T + 1], c_n[FB_T + 1], c_e0[FB_T + 1], c_st[FB_T + 1];   // columns j0 + k: first list entry, entries, the first entry's other end, state
-    float c_lw0[FB_T + 1];
+    // columns j0 + k: first list entry, entries, the first two entries' other ends and log weights, state (backward: one more column)
+    int c_off[FB_T + 1], c_n[FB_T + 1], c_e0[FB_T + 1], c_e1[FB_T + 1], c_st[FB_T + 1];
+    float c_lw0[FB_T + 1], c_lw1[FB_T + 1];
     double ltab[256];                // the model's log scores when S * S <= 256
 };
 
@@ -297,6 +303,14 @@ __device__ __forceinline__ bool fb_block_live(const PgFbJob &J, int i0, int j0, 
     return __builtin_amdgcn_ballot_w64(any) != 0;
 }
 
+// lane n takes lane n-1's v; lane 0 keeps `lane0`
+__device__ __forceinline__ double fb_shr1(double v, double lane0) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(lane0), lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0), hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // LDS traffic of the one wave is in order; this keeps the compiler from moving it and waits for nothing in memory
 __device__ __forceinline__ void fb_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -321,11 +335,20 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs, i
         for (int a = a_lo + (int)blockIdx.x; a <= a_hi; a += G) {
             const int i0 = a * FB_T, j0 = (t - a) * FB_T, dbase = i0 + j0;
             if (!fb_block_live(J, i0, j0, r)) continue;
+#ifdef PG_FB_STATS
+            const unsigned long long st0 = __builtin_readcyclecounter();
+#endif
             __syncthreads();                                                       // (the block before is done with the staging arrays)
-            // halo: the row above (with the corner) and the column to the left; the columns' records; the diagonals' intervals
-            for (int k = r; k <= FB_T; k += 64) {
-                const long long ta = cell_at(J, i0 - 1, j0 - 1 + k), tb = cell_at(J, i0 - 1 + k, j0 - 1);
-                for (int q = 0; q < 3; ++q) { M.ha[k][q] = rd(J.F, ta, q); M.hb[k][q] = rd(J.F, tb, q); }
+            // halo: the rows above (with the corner) and the columns to the left; the columns' records; the diagonals' intervals
+            for (int k = r; k < FB_H * (FB_T + FB_H); k += 64) {
+                const int u = k / (FB_T + FB_H), c_ = k % (FB_T + FB_H);
+                const long long at = cell_at(J, i0 - FB_H + u, j0 - FB_H + c_);
+                for (int q = 0; q < 3; ++q) M.ha[u][c_][q] = rd(J.F, at, q);
+            }
+            for (int k = r; k < FB_T * FB_H; k += 64) {
+                const int row_ = k / FB_H, u = k % FB_H;
+                const long long at = cell_at(J, i0 + row_, j0 - FB_H + u);
+                for (int q = 0; q < 3; ++q) M.hb[row_][u][q] = rd(J.F, at, q);
             }
             {
                 const int jc = j0 + r;
@@ -333,15 +356,26 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs, i
                 const int o0 = cv ? J.offR[jc] : 0, o1 = cv ? J.offR[jc + 1] : 0;
                 M.c_off[r] = o0; M.c_n[r] = o1 - o0; M.c_st[r] = jc < J.Ly ? J.stR[jc] : 0;
                 M.c_e0[r] = o1 > o0 ? J.srcR[o0] : 0; M.c_lw0[r] = o1 > o0 ? J.lwR[o0] : 0.0f;
+                M.c_e1[r] = o1 > o0 + 1 ? J.srcR[o0 + 1] : 0; M.c_lw1[r] = o1 > o0 + 1 ? J.lwR[o0 + 1] : 0.0f;
             }
             fb_stage_diagonals(J, M, dbase, r);
             for (int k = r; k < FB_RING * FB_T; k += 64) { double *c = &M.ring[0][0][0] + 3 * k; c[0] = NI; c[1] = NI; c[2] = NI; }
             const int i = i0 + r;
             const bool rv = i < J.Lx && i > 0;
             const int l0 = rv ? J.offL[i] : 0, nl = rv ? J.offL[i + 1] - l0 : 0;
-            const int p0 = nl > 0 ? J.srcL[l0] : 0, stl = i < J.Lx ? J.stL[i] : 0;
-            const double lwl0 = nl > 0 ? (double)J.lwL[l0] : 0.0;
+            const int p0 = nl > 0 ? J.srcL[l0] : 0, p1 = nl > 1 ? J.srcL[l0 + 1] : 0, stl = i < J.Lx ? J.stL[i] : 0;
+            const double lwl0 = nl > 0 ? (double)J.lwL[l0] : 0.0, lwl1 = nl > 1 ? (double)J.lwL[l0 + 1] : 0.0;
             __syncthreads();
+#ifdef PG_FB_STATS
+            const unsigned long long st1 = __builtin_readcyclecounter();
+#endif
+            // The cells a SIMPLE cell reads -- one bwd edge per site, from the previous site -- stay in registers, as in the
+            // Viterbi kernels: P this lane's cell of the step before (i, j-1), A the wave shift of P (i-1, j), C the A of the
+            // step before (i-1, j-1); a lane starts from the column left of the block, lane 0 takes row i0-1 from the halo.
+            const bool row_simple = nl == 1 && p0 == i - 1;
+            double Px = M.hb[r][FB_H - 1][0], Py = M.hb[r][FB_H - 1][1], Pm = M.hb[r][FB_H - 1][2];
+            double Ax = M.ha[FB_H - 1][FB_H - 1][0], Ay = M.ha[FB_H - 1][FB_H - 1][1], Am = M.ha[FB_H - 1][FB_H - 1][2];   // lane 0: the corner
+            double Cx = NI, Cy = NI, Cm = NI;
             for (int s = 0; s <= 2 * FB_T - 2; ++s) {
                 const int d = dbase + s;
                 if (d >= J.nd) break;
@@ -349,6 +383,25 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs, i
                 const int mn = M.dmin[s], mx = M.dmax[s];
                 const bool active = jj >= 0 && jj < FB_T && i < J.Lx && j < J.Ly && i >= mn && i <= mx;
                 double fx = NI, fy = NI, fm = NI;
+                {   // this step's register operands
+                    const int tc = (s < FB_T ? s : FB_T - 1) + FB_H;               // halo column of (i0-1, j0+s)
+                    const double t0 = M.ha[FB_H - 1][tc][0], t1 = M.ha[FB_H - 1][tc][1], t2 = M.ha[FB_H - 1][tc][2];
+                    Cx = Ax; Cy = Ay; Cm = Am;
+                    Ax = fb_shr1(Px, t0); Ay = fb_shr1(Py, t1); Am = fb_shr1(Pm, t2);
+                }
+                const bool col_simple = active && M.c_n[jj] == 1 && M.c_e0[jj] == j - 1;
+                if (__builtin_amdgcn_ballot_w64(active && !(row_simple && col_simple)) == 0) {
+                    if (active) {
+                        const double sc = tab_lds ? M.ltab[stl + M.c_st[jj] * J.S] : J.ltab[stl + (long long)M.c_st[jj] * J.S];
+                        const double w = lwl0 + (double)M.c_lw0[jj];
+                        const double mm = J.l_ng + J.l_ng + sc + w, xm = J.l_ng + sc + w;
+                        fx = lse3(Ax + J.l_ext, Ay + J.l_open, Am + J.l_ng + J.l_open);                        // VA:2153, 2184, 2215
+                        fy = lse3(Py + J.l_ext, Px + J.l_open, Pm + J.l_ng + J.l_open);
+                        fm = lse3(Cm + mm, Cx + xm, Cy + xm);                                                  // VA:2051, 2080, 2108
+                        double *o = J.F + 3 * (M.doff[s] + (i - mn));
+                        o[0] = fx; o[1] = fy; o[2] = fm;
+                    }
+                } else
                 if (active) {
                     auto fetch = [&](int p, int q, double &x, double &y, double &m) {
                         x = NI; y = NI; m = NI;
@@ -357,8 +410,8 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs, i
                         if (p >= i0 && q >= j0) {
                             if (d - (p + q) < FB_RING) c = M.ring[(p + q) % FB_RING][p - i0];
                             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // a cell of this block that left the ring: the wave's own store
-                        } else if (p == i0 - 1 && q >= j0 - 1) c = M.ha[q - (j0 - 1)];
-                        else if (q == j0 - 1 && p >= i0 - 1) c = M.hb[p - (i0 - 1)];
+                        } else if (p < i0 && p >= i0 - FB_H && q >= j0 - FB_H) c = M.ha[p - (i0 - FB_H)][q - (j0 - FB_H)];
+                        else if (p >= i0 && q < j0 && q >= j0 - FB_H) c = M.hb[p - i0][q - (j0 - FB_H)];
                         if (c) { x = c[0]; y = c[1]; m = c[2]; return; }
                         const long long at = cell_at(J, p, q);
                         x = rd(J.F, at, 0); y = rd(J.F, at, 1); m = rd(J.F, at, 2);
@@ -367,14 +420,16 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs, i
                         fm = 0.0;                                                  // fwd_score = 1, VA:730
                     } else {
                         double x, y, m;
-                        const int r0 = M.c_off[jj], nr = M.c_n[jj], q0 = M.c_e0[jj];
-                        const double lwr0 = (double)M.c_lw0[jj];
+                        const int r0 = M.c_off[jj], nr = M.c_n[jj], q0 = M.c_e0[jj], q1 = M.c_e1[jj];
+                        const double lwr0 = (double)M.c_lw0[jj], lwr1 = (double)M.c_lw1[jj];
+                        auto srcl = [&](int k) { return k == 0 ? p0 : (k == 1 ? p1 : J.srcL[l0 + k]); };
+                        auto srcr = [&](int k) { return k == 0 ? q0 : (k == 1 ? q1 : J.srcR[r0 + k]); };
                         for (int k = 0; k < nl; ++k) {
-                            fetch(k == 0 ? p0 : J.srcL[l0 + k], j, x, y, m);
+                            fetch(srcl(k), j, x, y, m);
                             fx = lse(fx, lse3(x + J.l_ext, y + J.l_open, m + J.l_ng + J.l_open));              // VA:2153, 2184, 2215
                         }
                         for (int k = 0; k < nr; ++k) {
-                            fetch(i, k == 0 ? q0 : J.srcR[r0 + k], x, y, m);
+                            fetch(i, srcr(k), x, y, m);
                             fy = lse(fy, lse3(y + J.l_ext, x + J.l_open, m + J.l_ng + J.l_open));
                         }
                         if (nl > 0 && nr > 0) {
@@ -383,8 +438,9 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs, i
                             const double mm = J.l_ng + J.l_ng + sc, xm = J.l_ng + sc;                         // VA:1383-1391
                             for (int k1 = 0; k1 < nl; ++k1)
                                 for (int k2 = 0; k2 < nr; ++k2) {
-                                    fetch(k1 == 0 ? p0 : J.srcL[l0 + k1], k2 == 0 ? q0 : J.srcR[r0 + k2], x, y, m);
-                                    const double w = (k1 == 0 ? lwl0 : (double)J.lwL[l0 + k1]) + (k2 == 0 ? lwr0 : (double)J.lwR[r0 + k2]);
+                                    fetch(srcl(k1), srcr(k2), x, y, m);
+                                    const double w = (k1 == 0 ? lwl0 : (k1 == 1 ? lwl1 : (double)J.lwL[l0 + k1])) +
+                                                     (k2 == 0 ? lwr0 : (k2 == 1 ? lwr1 : (double)J.lwR[r0 + k2]));
                                     fm = lse(fm, lse3(m + mm + w, x + xm + w, y + xm + w));                   // VA:2051, 2080, 2108
                                 }
                         }
@@ -394,10 +450,24 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs, i
                 }
                 double *c = M.ring[d % FB_RING][r];
                 c[0] = fx; c[1] = fy; c[2] = fm;
+                if (active) { Px = fx; Py = fy; Pm = fm; } else if (jj >= 0) { Px = NI; Py = NI; Pm = NI; }
                 fb_lds_fence();
             }
+#ifdef PG_FB_STATS
+            if (r == 0) {     // sync[16..]: blocks, prologue cycles, step cycles (diagnostic build)
+                const unsigned long long st2 = __builtin_readcyclecounter();
+                atomicAdd((unsigned long long *)(sync + 16), 1ull); atomicAdd((unsigned long long *)(sync + 18), st1 - st0);
+                atomicAdd((unsigned long long *)(sync + 20), st2 - st1);
+            }
+#endif
         }
+#ifdef PG_FB_STATS
+        const unsigned long long sb0 = __builtin_readcyclecounter();
+#endif
         if (!fb_barrier(sync, G * (t + 1))) return;
+#ifdef PG_FB_STATS
+        if (r == 0) atomicAdd((unsigned long long *)(sync + 22), __builtin_readcyclecounter() - sb0);
+#endif
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // end corner, VA:1440-1552
@@ -436,16 +506,25 @@ __global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs, 
             const int i0 = a * FB_T, j0 = (t - a) * FB_T, dbase = i0 + j0;
             if (!fb_block_live(J, i0, j0, r)) continue;
             __syncthreads();
-            // halo: the row below and the column to the right (with the corner at [64]); the columns' fwd records (one more
-            // column than the block has: a match moves to column j + 1); the diagonals' intervals
+            // halo: the rows below (with the corner) and the columns to the right; the columns' fwd records (one more column than
+            // the block has: a match moves to column j + 1); the diagonals' intervals
+            for (int k = r; k < FB_H * (FB_T + FB_H); k += 64) {
+                const int u = k / (FB_T + FB_H), c_ = k % (FB_T + FB_H);
+                const long long at = cell_at(J, i0 + FB_T + u, j0 + c_);
+                for (int q = 0; q < 3; ++q) M.ha[u][c_][q] = rd(J.B, at, q);
+            }
+            for (int k = r; k < FB_T * FB_H; k += 64) {
+                const int row_ = k / FB_H, u = k % FB_H;
+                const long long at = cell_at(J, i0 + row_, j0 + FB_T + u);
+                for (int q = 0; q < 3; ++q) M.hb[row_][u][q] = rd(J.B, at, q);
+            }
             for (int k = r; k <= FB_T; k += 64) {
-                const long long ta = cell_at(J, i0 + FB_T, j0 + k), tb = cell_at(J, i0 + k, j0 + FB_T);
-                for (int q = 0; q < 3; ++q) { M.ha[k][q] = rd(J.B, ta, q); M.hb[k][q] = rd(J.B, tb, q); }
                 const int jc = j0 + k;
                 const bool cv = jc < J.Ly;
                 const int o0 = cv ? J.foffR[jc] : 0, o1 = cv ? J.foffR[jc + 1] : 0;
                 M.c_off[k] = o0; M.c_n[k] = o1 - o0; M.c_st[k] = cv ? J.stR[jc] : 0;
                 M.c_e0[k] = o1 > o0 ? J.fdstR[o0] : 0; M.c_lw0[k] = o1 > o0 ? J.flwR[o0] : 0.0f;
+                M.c_e1[k] = o1 > o0 + 1 ? J.fdstR[o0 + 1] : 0; M.c_lw1[k] = o1 > o0 + 1 ? J.flwR[o0 + 1] : 0.0f;
             }
             fb_stage_diagonals(J, M, dbase, r);
             for (int k = r; k < FB_RING * FB_T; k += 64) { double *c = &M.ring[0][0][0] + 3 * k; c[0] = NI; c[1] = NI; c[2] = NI; }
@@ -463,9 +542,9 @@ __global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs, 
             const bool blk_init = __builtin_amdgcn_ballot_w64(init_here) != 0;
             const bool rv = i < J.Lx;
             const int l0 = rv ? J.foffL[i] : 0, nl = rv ? J.foffL[i + 1] - l0 : 0;
-            const int t0 = nl > 0 ? J.fdstL[l0] : 0;
-            const int st_t0 = nl > 0 && t0 < J.Lx ? J.stL[t0] : 0;
-            const double lwl0 = nl > 0 ? (double)J.flwL[l0] : 0.0;
+            const int t0 = nl > 0 ? J.fdstL[l0] : 0, t1 = nl > 1 ? J.fdstL[l0 + 1] : 0;
+            const int st_t0 = nl > 0 && t0 < J.Lx ? J.stL[t0] : 0, st_t1 = nl > 1 && t1 < J.Lx ? J.stL[t1] : 0;
+            const double lwl0 = nl > 0 ? (double)J.flwL[l0] : 0.0, lwl1 = nl > 1 ? (double)J.flwL[l0 + 1] : 0.0;
             __syncthreads();
             for (int s = 2 * FB_T - 2; s >= 0; --s) {
                 const int d = dbase + s;
@@ -481,8 +560,8 @@ __global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs, 
                         if (t_ < i0 + FB_T && u < j0 + FB_T) {
                             if ((t_ + u) - d < FB_RING) return M.ring[(t_ + u) % FB_RING][t_ - i0][q];
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // a cell of this block that left the ring: the wave's own store
-                        } else if (t_ == i0 + FB_T && u <= j0 + FB_T) return M.ha[u - j0][q];
-                        else if (u == j0 + FB_T && t_ <= i0 + FB_T) return M.hb[t_ - i0][q];
+                        } else if (t_ >= i0 + FB_T && t_ < i0 + FB_T + FB_H && u < j0 + FB_T + FB_H) return M.ha[t_ - (i0 + FB_T)][u - j0][q];
+                        else if (t_ < i0 + FB_T && u >= j0 + FB_T && u < j0 + FB_T + FB_H) return M.hb[t_ - i0][u - (j0 + FB_T)][q];
                         return rd(J.B, cell_at(J, t_, u), q);
                     };
                     double *o = J.B + 3 * (M.doff[s] + (i - mn));
@@ -493,29 +572,31 @@ __global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs, 
                             if (w == 0) bx = J.init_val[k]; else if (w == 1) by = J.init_val[k]; else if (w == 2) bm = J.init_val[k];
                         }
                     }
-                    const int r0 = M.c_off[jj], nr = M.c_n[jj], u0 = M.c_e0[jj];
-                    const double lwr0 = (double)M.c_lw0[jj];
+                    const int r0 = M.c_off[jj], nr = M.c_n[jj], u0 = M.c_e0[jj], u1 = M.c_e1[jj];
+                    const double lwr0 = (double)M.c_lw0[jj], lwr1 = (double)M.c_lw1[jj];
+                    auto dstl = [&](int k) { return k == 0 ? t0 : (k == 1 ? t1 : J.fdstL[l0 + k]); };
+                    auto dstr = [&](int k) { return k == 0 ? u0 : (k == 1 ? u1 : J.fdstR[r0 + k]); };
                     for (int k = 0; k < nl; ++k) {                                 // iterate_fwd_edges_for_gap, left site
-                        const int t_ = k == 0 ? t0 : J.fdstL[l0 + k];
+                        const int t_ = dstl(k);
                         if (t_ >= J.Lx) continue;                                  // VA:1580
                         const double nx = fetch(t_, j, 0);
                         bx = lse(bx, nx + J.l_ext); by = lse(by, nx + J.l_open); bm = lse(bm, nx + J.l_ng + J.l_open);   // VA:2281-2303
                     }
                     for (int k = 0; k < nr; ++k) {
-                        const int u = k == 0 ? u0 : J.fdstR[r0 + k];
+                        const int u = dstr(k);
                         if (u >= J.Ly) continue;
                         const double ny = fetch(i, u, 1);
                         by = lse(by, ny + J.l_ext); bx = lse(bx, ny + J.l_open); bm = lse(bm, ny + J.l_ng + J.l_open);
                     }
                     for (int k1 = 0; k1 < nl; ++k1)                                // iterate_fwd_edges_for_match
                         for (int k2 = 0; k2 < nr; ++k2) {
-                            const int t_ = k1 == 0 ? t0 : J.fdstL[l0 + k1], u = k2 == 0 ? u0 : J.fdstR[r0 + k2];
+                            const int t_ = dstl(k1), u = dstr(k2);
                             if (t_ >= J.Lx || u >= J.Ly) continue;
-                            const int sl = k1 == 0 ? st_t0 : J.stL[t_];
+                            const int sl = k1 == 0 ? st_t0 : (k1 == 1 ? st_t1 : J.stL[t_]);
                             const int sr = (u >= j0 && u <= j0 + FB_T) ? M.c_st[u - j0] : J.stR[u];
                             const double sc = tab_lds ? M.ltab[sl + sr * J.S] : J.ltab[sl + (long long)sr * J.S];
-                            const double thru = fetch(t_, u, 2) + sc + (k1 == 0 ? lwl0 : (double)J.flwL[l0 + k1]) +
-                                                (k2 == 0 ? lwr0 : (double)J.flwR[r0 + k2]);               // VA:2269-2271
+                            const double thru = fetch(t_, u, 2) + sc + (k1 == 0 ? lwl0 : (k1 == 1 ? lwl1 : (double)J.flwL[l0 + k1])) +
+                                                (k2 == 0 ? lwr0 : (k2 == 1 ? lwr1 : (double)J.flwR[r0 + k2]));   // VA:2269-2271
                             bx = lse(bx, thru + J.l_ng); by = lse(by, thru + J.l_ng); bm = lse(bm, thru + J.l_ng + J.l_ng);
                         }
                     o[0] = bx; o[1] = by; o[2] = bm;
@@ -554,6 +635,46 @@ FwdLists forward_lists(const pagan_graph *g) {
 int pagan_internal_replay(const pagan_graph *L, const pagan_graph *R, int64_t cells, const int *endcell, double endscore,
                           const int *trace, pagan_result *out);     // dp_abi.hip
 
+// Arenas of finished handles are kept for the next one on the same device (a pair's two matrices are hundreds of MB:
+// allocating and freeing them -- a device-wide synchronisation -- per pair was half of a pair's wall-clock); at most eight
+// idle ones per process, pagan_fb_release_cache frees them.
+namespace {
+struct FbArenaPool {
+    std::mutex m;
+    struct Slab { int device; char *p; size_t cap; };
+    std::vector<Slab> idle;
+    char *take(int device, size_t need, size_t *cap) {
+        {
+            std::lock_guard<std::mutex> g(m);
+            int best = -1;
+            for (size_t k = 0; k < idle.size(); ++k)
+                if (idle[k].device == device && idle[k].cap >= need && (best < 0 || idle[k].cap < idle[best].cap)) best = (int)k;
+            if (best >= 0 && idle[best].cap <= 2 * need + (64u << 20)) { Slab s_ = idle[best]; idle.erase(idle.begin() + best); *cap = s_.cap; return s_.p; }
+        }
+        char *p = nullptr;
+        *cap = need + need / 16;
+        if (hipMalloc((void **)&p, *cap) != hipSuccess) {
+            (void)hipGetLastError();
+            clear();                                           // (idle arenas may be what is in the way)
+            if (hipMalloc((void **)&p, *cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
+        return p;
+    }
+    void give(int device, char *p, size_t cap) {
+        std::lock_guard<std::mutex> g(m);
+        if (idle.size() >= 8) { (void)hipSetDevice(idle.front().device); (void)hipFree(idle.front().p); idle.erase(idle.begin()); }
+        idle.push_back({device, p, cap});
+    }
+    void clear() {
+        std::lock_guard<std::mutex> g(m);
+        for (auto &s_ : idle) { (void)hipSetDevice(s_.device); (void)hipFree(s_.p); }
+        idle.clear();
+    }
+};
+FbArenaPool fb_arena_pool;
+} // namespace
+extern "C" void pagan_fb_internal_release_cache() { fb_arena_pool.clear(); }
+
 struct pagan_fb {
     int device = 0;
     int Lx = 0, Ly = 0, S = 0;
@@ -563,6 +684,7 @@ struct pagan_fb {
     DiagIndex dx;
     RowBand rb;
     char *arena = nullptr;
+    size_t arena_cap = 0;
     double *dF = nullptr, *dB = nullptr;
     double totals[2] = {0, 0};
     float kernel_ms[2] = {0, 0};                        // pg_fb_forward, pg_fb_backward (HIP events)
@@ -584,6 +706,8 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     if (rc == PAGAN_OK) rc = check_graph(right);
     if (rc != PAGAN_OK) return rc;
     const int Lx = left->n_sites - 1, Ly = right->n_sites - 1, S = model->n_states;
+    auto now_ = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double th0 = now_();
     for (int s = 1; s < Lx; ++s) if (left->state[s] < 0 || left->state[s] >= S) return PAGAN_E_MODEL;
     for (int s = 1; s < Ly; ++s) if (right->state[s] < 0 || right->state[s] >= S) return PAGAN_E_MODEL;
     if (!(model->gap_open > 0) || !(model->gap_ext > 0) || !(model->non_gap > 0)) return PAGAN_E_MODEL;
@@ -637,10 +761,12 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     const size_t o_imin = take(4 * (size_t)nd), o_imax = take(4 * (size_t)nd), o_doff = take(8 * (size_t)nd);
     const size_t o_iat = take(8 * init_at.size()), o_ival = take(8 * init_val.size());
     const size_t o_tot = take(16);
-    const size_t o_sync = take(64);                      // two barrier counters + give-up words of the wide sweeps (zero)
+    const size_t o_sync = take(256);                      // two barrier counters + give-up words of the wide sweeps (zero)
     const size_t in_bytes = cur;
     const size_t o_F = take(24 * (size_t)cells), o_B = take(24 * (size_t)cells);
-    FB_TRY(hipMalloc((void **)&fb->arena, cur));
+    const double th1 = now_();
+    fb->arena = fb_arena_pool.take(fb->device, cur, &fb->arena_cap);
+    if (!fb->arena) return PAGAN_E_NOMEM;
     std::vector<char> stage(in_bytes, 0);
     auto put = [&](size_t off, const void *src, size_t bytes) { if (bytes) std::memcpy(stage.data() + off, src, bytes); };
     put(o_stL, left->state, 4 * (size_t)left->n_sites); put(o_offL, left->bwd_off, 4 * ((size_t)left->n_sites + 1));
@@ -668,7 +794,9 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     J.totals = (double *)(b + o_tot);
     std::memcpy(stage.data() + o_job, &J, sizeof(J));
     fb->dF = J.F; fb->dB = J.B;
+    const double th2 = now_();
     FB_TRY(hipMemcpy(fb->arena, stage.data(), in_bytes, hipMemcpyHostToDevice));
+    const double th3 = now_();
     // a thread per cell of the widest diagonal, up to the 1024 of a workgroup (a cell is ~20 exp / log1p calls: a thread with
     // eight cells of a 2,000-cell diagonal was the whole sweep's pace)
     const int mw = fb->dx.max_width;
@@ -688,7 +816,7 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     // of alignments in flight from as many threads, and workgroups of one sweep holding compute units while they wait for
     // siblings that other waiting sweeps keep out would never end (the barrier's spin limit would turn that into an error,
     // seconds later).  So the tiled sweeps of a device share a budget of workgroup slots well inside what the device holds
-    // at this kernel's LDS size (4 per compute unit); a pair that does not fit waits here, on the host.
+    // at this kernel's LDS size (3 per compute unit); a pair that does not fit waits here, on the host.
     struct Slots {
         std::mutex m; std::condition_variable cv; int used = 0;
         void take(int n, int cap) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return used == 0 || used + n <= cap; }); used += n; }
@@ -699,7 +827,7 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     int slot_cap = 512;
     {
         int n_cu = 0;
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, fb->device) == hipSuccess && n_cu > 0) slot_cap = 3 * n_cu;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, fb->device) == hipSuccess && n_cu > 0) slot_cap = 5 * n_cu / 2;
     }
     struct SlotLease { Slots *s; int n; ~SlotLease() { if (n > 0) s->give(n); } } lease{&slots, groups > 1 ? 2 * groups : 0};
     if (groups > 1) slots.take(2 * groups, slot_cap);
@@ -711,17 +839,29 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     else hipLaunchKernelGGL(pg_fb_backward, dim3(1), dim3(block), 0, s2, (const PgFbJob *)(b + o_job));
     FB_TRY(hipEventRecord(e3, s2));
     FB_TRY(hipGetLastError());
+    const double th4 = now_();
     FB_TRY(hipStreamSynchronize(s1)); FB_TRY(hipStreamSynchronize(s2));
+    const double th5 = now_();
     (void)hipEventElapsedTime(&fb->kernel_ms[0], e0, e1);
     (void)hipEventElapsedTime(&fb->kernel_ms[1], e2, e3);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
     (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2);
     FB_TRY(hipMemcpy(fb->totals, b + o_tot, 16, hipMemcpyDeviceToHost));
     {
-        int sy[16];
+        int sy[64];
         FB_TRY(hipMemcpy(sy, b + o_sync, sizeof(sy), hipMemcpyDeviceToHost));
         if (sy[1] != 0 || sy[9] != 0) return PAGAN_E_INTERNAL;      // a barrier of a wide sweep ran into its limit
+#ifdef PG_FB_STATS
+        {
+            const unsigned long long *q = (const unsigned long long *)(sy + 16);
+            std::fprintf(stderr, "pagan_fb: forward: %llu blocks, prologue %.0f cycles per block, steps %.0f per block, barrier %.0f per workgroup and block diagonal (%d groups)\n",
+                         q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[0] ? (double)q[2] / q[0] : 0.0, groups ? (double)q[3] / groups / ((Lx + 63) / 64 + (Ly + 63) / 64 - 1) : 0.0, groups);
+        }
+#endif
     }
+    if (std::getenv("PAGAN_DP_VERBOSE"))
+        std::fprintf(stderr, "pagan_fb: host: band index + lists %.1f ms, arena (%.0f MB) %.1f ms, staging %.1f ms, upload %.1f ms, streams + launch (+ slot wait) %.1f ms, kernels %.1f ms, rest %.1f ms\n",
+                     1e3 * (th1 - th0), cur / 1048576.0, 1e3 * (th2 - th1) - 0.0, 0.0, 1e3 * (th3 - th2), 1e3 * (th4 - th3), 1e3 * (th5 - th4), 1e3 * (now_() - th5));
     *out = guard.release();
     return PAGAN_OK;
 }
@@ -873,7 +1013,7 @@ int pagan_fb_sample_path(pagan_fb *fb, const double *u, int32_t n_u, pagan_resul
 
 void pagan_fb_destroy(pagan_fb *fb) {
     if (!fb) return;
-    if (fb->arena) { (void)hipSetDevice(fb->device); (void)hipFree(fb->arena); }
+    if (fb->arena) fb_arena_pool.give(fb->device, fb->arena, fb->arena_cap);
     delete fb;
 }
 
