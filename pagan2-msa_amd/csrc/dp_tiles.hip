@@ -402,6 +402,18 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
         if (which < 0) return;
         flow_wait(&prog[which], need, giveup, jobs[T.x].fill_status);
     };
+    // both neighbours' progress with ONE round trip per look (two loads in flight) instead of one wait after the other
+    auto wait_prog2 = [&](int w1, int w2, int need) {
+        if (w1 < 0 || w2 < 0) { wait_prog(w1, need); wait_prog(w2, need); return; }
+        int spins = 0;
+        for (;;) {
+            const int a = __hip_atomic_load(&prog[w1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int b = __hip_atomic_load(&prog[w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a >= need && b >= need) return;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 63) == 0) { wait_prog(w1, need); wait_prog(w2, need); return; }     // (the bounded, give-up-aware wait takes over)
+        }
+    };
     for (int s = 0; s <= s_last; ++s) {
 #ifdef PG_TILE_STATS
         const unsigned long long st_a = __builtin_amdgcn_s_memtime();
@@ -412,8 +424,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
 #ifdef PG_TILE_STATS
             const unsigned long long lw0 = __builtin_amdgcn_s_memtime();
 #endif
-            wait_prog(up, need < 2 * TS - 1 ? need : TDONE);
-            wait_prog(lf, need < 2 * TS - 1 ? need : TDONE);
+            wait_prog2(up, lf, need < 2 * TS - 1 ? need : TDONE);
 #ifdef PG_TILE_STATS
             const unsigned long long lw1 = __builtin_amdgcn_s_memtime();
 #endif
