@@ -154,6 +154,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
     // diagnostic build (tools/build_stamps.sh): cycles and step counts summed over all tiles of the job at the
     // tail of its trace buffer: [0] tiles, [1] prologue, [2..4] steps simple / near / near + general, [5..7] their cycles
     unsigned long long st_n[3] = {0, 0, 0}, st_t[3] = {0, 0, 0};
+    unsigned st_far = 0, st_far_steps = 0, st_far_max = 0, st_pairs_max = 0;
     const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
 #endif
     const double NI = neg_inf();
@@ -645,6 +646,14 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                     if (i == 0 && j == 0) bm = 0.0;                                          // initialise_array_corner, VA:725-736
                 }
                 if (!near) {
+#ifdef PG_TILE_STATS
+                    const unsigned far_before = st_far;
+                    {
+                        int pr_ = active ? (int)(nl > 0 ? nl : 1) * (int)(nr > 0 ? nr : 1) : 0;
+                        for (int o_ = 32; o_ > 0; o_ >>= 1) pr_ = max(pr_, __shfl_xor(pr_, o_));
+                        st_pairs_max += pr_;
+                    }
+#endif
                     if (active) {
                         // Any number of bwd edges, anywhere: the reference's loops, edges from the
                         // LDS windows (the next one requested while the current one is worked on), operand cells from
@@ -654,6 +663,9 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                                 const int at = TAT(p, q);
                                 xs = TM.sc[at][0]; ys = TM.sc[at][1]; ms = TM.sc[at][2];
                             } else {
+#ifdef PG_TILE_STATS
+                                ++st_far;
+#endif
                                 const int w = p + q - (dbase - TDB);
                                 const pg_i4 F = w >= 0 ? TM.dsc[w] : far_desc(((PG_GLOBAL const pg_i4 *)(unsigned long long)J.dsc) + (p + q));
                                 xs = ys = ms = NI;
@@ -732,6 +744,13 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                             }
                         }
                     }
+#ifdef PG_TILE_STATS
+                    {   // fetches from beyond the LDS window in this step: the wave's largest count, and whether there was any
+                        int f_ = (int)(st_far - far_before);
+                        for (int o_ = 32; o_ > 0; o_ >>= 1) f_ = max(f_, __shfl_xor(f_, o_));
+                        st_far_max += f_; st_far_steps += f_ > 0;
+                    }
+#endif
                 }
             }
             if (active) {
@@ -777,6 +796,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
         atomicAdd(out + 0, 1ull);
         atomicAdd(out + 1, st_loop - st_begin);
         for (int k = 0; k < 3; ++k) { atomicAdd(out + 2 + k, st_n[k]); atomicAdd(out + 5 + k, st_t[k]); }
+        atomicAdd(out + 15, (unsigned long long)st_far_steps); atomicAdd(out + 16, (unsigned long long)st_far_max); atomicAdd(out + 17, (unsigned long long)st_pairs_max);
         atomicAdd(out + 8, __builtin_amdgcn_s_memtime() - st_begin);
     }
 #endif
