@@ -521,7 +521,6 @@ struct pagan_batch {
     int *d_flow = nullptr;       // pg_fill_tiles_flow's queue head, finished tiles per diagonal, done flags (zeroed per launch)
     size_t flow_ints = 0;
     bool tiles_nolag = false;    // PAGAN_DP_TILES=nolag: tiles wait for their neighbours to finish (A/B switch)
-    bool tiles_lag8 = false;     // PAGAN_DP_TILES=lag8: halo blocks of 8 steps where the chain of tile diagonals is the bound (round 3's choice)
     bool tiles_water = false;    // some job's tiles are no staircase: a tile also waits for all diagonals <= its own - 2
     bool tiles_flow = true;      // one persistent launch (default) or one launch per tile anti-diagonal (PAGAN_DP_TILES=launches)
     std::vector<int> tile_off;   // first tile of tile anti-diagonal t (tile_off.back() = total)
@@ -839,7 +838,7 @@ int launch_fill(pagan_batch *b) {
             hipLaunchKernelGGL(pg_fill_tiles_flow, dim3(waves), dim3(64), pg_tiles_lds_bytes(),
                                st, b->d_jobs, b->d_tiles, n_tiles, n_diag, b->d_flow, b->flags,
                                b->tiles_water ? 1 : (4ll * n_tiles >= 7ll * n_cu_dev[b->device & 63].load() * n_diag || b->tiles_nolag ? 2 :
-                                                      (b->tiles_lag8 && 2ll * n_tiles < (long long)n_cu_dev[b->device & 63].load() * n_diag ? 3 : 0)));
+                                                      (2ll * n_tiles < (long long)n_cu_dev[b->device & 63].load() * n_diag ? 3 : 0)));
         } else {
             for (size_t t = 0; t + 1 < b->tile_off.size(); ++t) {
                 const int cnt = b->tile_off[t + 1] - b->tile_off[t];
@@ -1263,7 +1262,6 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         }
         if (const char *f = std::getenv("PAGAN_DP_TILES")) if (std::strcmp(f, "watermark") == 0) b->tiles_water = true;
         if (const char *f = std::getenv("PAGAN_DP_TILES")) if (std::strcmp(f, "nolag") == 0) b->tiles_nolag = true;
-        if (const char *f = std::getenv("PAGAN_DP_TILES")) if (std::strcmp(f, "lag8") == 0) b->tiles_lag8 = true;
         b->flow_ints = 1 + (size_t)T + N + 1;                  // queue head, finished tiles per diagonal, progress per tile, give-up flag
         if (const char *f = std::getenv("PAGAN_DP_TILES")) b->tiles_flow = std::strcmp(f, "launches") != 0;   // A/B switch
     }

@@ -58,8 +58,6 @@ struct TileSmem {
     int eL[TEC + 64][2], eR[TEC + 64][2];   // bwd edges of the tile's rows / columns: start site, log weight (float bits)
     float sm[TS][TS];                   // model log score of row i0 + r's state against column j0 + k's: sm[r][k]
     float table[256];                   // the model table while sm[][] is built (S <= 16)
-    pg_i4 colz[TS];                     // column j0 + k of an "easy" shape, decoded: distance of its edge that is NOT from the previous
-                                        // site (0: none), 1 if it has an edge from the previous site, the two log weights (float bits)
 };
 
 // What a lane keeps about a site: x = state, y = CSR index of its first bwd edge, z = number of bwd
@@ -69,7 +67,6 @@ struct TileSmem {
 #define SITE_TWO (1 << 29)
 #define SITE_FAR0 (1 << 28)           // the first / second bwd edge starts outside the LDS window (tile + halo)
 #define SITE_FAR1 (1 << 27)
-#define SITE_EASY (1 << 26)           // at most one bwd edge from the previous site and at most one other, inside the LDS window
 #define SITE_COUNT 0xffff             // PG_MAX_SLOT < 65536
 struct SiteRec { pg_i4 r, e; };
 
@@ -81,23 +78,6 @@ struct SiteRec { pg_i4 r, e; };
 // pg_backptr (dp_kernels.hip) re-derives all of them after the fill; here a candidate only raises its state's value, so the
 // winner's code (and the compare + select that tracked it) is gone from every path of the tile step.
 #define PG_TAKE(best, bp, c, code) do { best = __builtin_fmax(best, (c)); } while (0)
-
-// lane n takes lane n-1's v; lane 0 keeps `lane0` (wave_shr:1 leaves a lane without a source untouched when bound_ctrl is off)
-__device__ __forceinline__ double tile_shr1(double v, double lane0) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(__double2loint(lane0), lo, 0x138, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0), hi, 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-// the three candidates an edge from a cell offers a gap state (own state first: VA:2116-2219), as a value
-__device__ __forceinline__ double gap3(double own, double other, double m, double ext, double go, double ng, double open) {
-    return __builtin_fmax(own + ext, __builtin_fmax(other + go, (m + ng) + open));
-}
-// the three candidates a pair of edges from a cell offers M (VA:2029-2112), as a value: fp64 addition is monotone, so the
-// maxima fold in front of the shared addends -- the same additions in the same order on whichever candidate wins
-__device__ __forceinline__ double pair3(double x, double y, double m, double tM, double tX, double lw, double rw) {
-    return (__builtin_fmax(m + tM, __builtin_fmax(x, y) + tX) + lw) + rw;
-}
 
 } // namespace
 
@@ -116,7 +96,7 @@ extern __shared__ __attribute__((aligned(16))) char pg_tiles_lds[];
 __device__ __forceinline__ void flow_wait(int *p, int need, int *giveup, int *status) {
     int spins = 0;
     while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(16);
         if ((++spins & 63) == 0) {
             if (__hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
             if (spins >= (1 << PG_FLOW_SPIN_LOG2)) {
@@ -261,24 +241,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
     rec_flags(row, i, i0);
     if (!cv) col.r.z = 0;
     if (!rv) row.r.z = 0;
-    // "easy" shape: the site's (at most two) edges are one from the previous site and / or ONE other that starts inside the LDS
-    // window; decoded once per tile -- z.x distance of the other edge (0: none), z.y 1: has the previous-site edge, z.z / z.w
-    // the log weights of the two (float bits)
-    auto rec_easy = [&](SiteRec &o, int s) {
-        const int n = o.r.z & SITE_COUNT;
-        const bool a0 = n >= 1 && o.e.x == s - 1, a1 = n >= 2 && o.e.z == s - 1;
-        const bool far = (o.r.z & (SITE_FAR0 | SITE_FAR1)) != 0;
-        pg_i4 z = pg_i4{0, 0, 0, 0};
-        if (n > 2 || far || (a0 && a1) || (n == 2 && !a0 && !a1)) return z;
-        o.r.z |= SITE_EASY;
-        z.y = (a0 || a1) ? 1 : 0;
-        z.z = a0 ? o.e.y : (a1 ? o.e.w : 0);
-        if (n >= 1 && !a0) { z.x = s - o.e.x; z.w = o.e.y; }
-        if (n >= 2 && !a1) { z.x = s - o.e.z; z.w = o.e.w; }
-        return z;
-    };
-    const pg_i4 colz0 = rec_easy(col, jc), rowz = rec_easy(row, i);
-    TM.col[r] = col.r; TM.cole[r] = col.e; TM.colz[r] = colz0;
+    TM.col[r] = col.r; TM.cole[r] = col.e;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int k = r + 64 * u;
@@ -336,23 +299,8 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
     const int s_last = (2 * TS - 2 < J.nd - 1 - dbase) ? 2 * TS - 2 : J.nd - 1 - dbase;
     // operands of a step are fetched one step ahead: the diagonal's descriptor and the column's record
     pg_i4 D = TM.dsc[TDB];
-    pg_i4 c = pg_i4{0, 0, 0, 0}, ce = pg_i4{0, 0, 0, 0}, cz = pg_i4{0, 0, 0, 0};
-    if (r == 0) { c = TM.col[0]; ce = TM.cole[0]; cz = TM.colz[0]; }
-    // Round 4: the cells a step's cell reads through the edges from the PREVIOUS sites stay in registers -- P this lane's
-    // cell of the step before, (i, j-1); A what a wave shift of P brings, (i-1, j); C the A of the step before, (i-1, j-1) --
-    // as in the banded kernel (dp_pipe.hip); the LDS window is for the other edges.  A lane starts from the column left of
-    // the tile (P; with LAG it arrives with the lane's halo block), lane 0 takes row i0-1 from the window every step.
-    const int a_left = (TH - 1) * TP + (r + TH);                      // TAT(i, j0 - 1)
-    double Px = NI, Py = NI, Pm = NI, Ax = NI, Ay = NI, Am = NI, Cx = NI, Cy = NI, Cm = NI;
-    if (!LAG) {
-        Px = TM.sc[a_left][0]; Py = TM.sc[a_left][1]; Pm = TM.sc[a_left][2];
-        Ax = TM.sc[a_left - 1][0]; Ay = TM.sc[a_left - 1][1]; Am = TM.sc[a_left - 1][2];     // lane 0: the corner (i0-1, j0-1)
-    }
-    // the row's site, decoded once (the lane keeps its row for the whole tile)
-    const bool rAdj = rowz.y != 0, rOth = rowz.x != 0;
-    const int kL = rowz.x;
-    const double lwA = (double)__int_as_float(rowz.z), lwS = (double)__int_as_float(rowz.w);
-    const double openXa = (reduced_terminal && i == 1) ? 0.0 : go, openXo = (reduced_terminal && i - kL == 0) ? 0.0 : go;   // BA.h:490-513
+    pg_i4 c = pg_i4{0, 0, 0, 0}, ce = pg_i4{0, 0, 0, 0};
+    if (r == 0) { c = TM.col[0]; ce = TM.cole[0]; }
 #ifdef PG_TILE_STATS
     const unsigned long long st_loop = __builtin_amdgcn_s_memtime();
 #endif
@@ -403,18 +351,6 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
         if (which < 0) return;
         flow_wait(&prog[which], need, giveup, jobs[T.x].fill_status);
     };
-    // both neighbours' progress with ONE round trip per look (two loads in flight) instead of one wait after the other
-    auto wait_prog2 = [&](int w1, int w2, int need) {
-        if (w1 < 0 || w2 < 0) { wait_prog(w1, need); wait_prog(w2, need); return; }
-        int spins = 0;
-        for (;;) {
-            const int a = __hip_atomic_load(&prog[w1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int b = __hip_atomic_load(&prog[w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a >= need && b >= need) return;
-            __builtin_amdgcn_s_sleep(2);
-            if ((++spins & 63) == 0) { wait_prog(w1, need); wait_prog(w2, need); return; }     // (the bounded, give-up-aware wait takes over)
-        }
-    };
     for (int s = 0; s <= s_last; ++s) {
 #ifdef PG_TILE_STATS
         const unsigned long long st_a = __builtin_amdgcn_s_memtime();
@@ -425,15 +361,14 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
 #ifdef PG_TILE_STATS
             const unsigned long long lw0 = __builtin_amdgcn_s_memtime();
 #endif
-            wait_prog2(up, lf, need < 2 * TS - 1 ? need : TDONE);
+            wait_prog(up, need < 2 * TS - 1 ? need : TDONE);
+            wait_prog(lf, need < 2 * TS - 1 ? need : TDONE);
 #ifdef PG_TILE_STATS
             const unsigned long long lw1 = __builtin_amdgcn_s_memtime();
 #endif
-            // (no L1 invalidate: what a lagged tile reads of other tiles -- halo blocks, far operands -- it reads with sc1 loads)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             halo_block(s / TB);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (r >= s && r < s + TB) { Px = TM.sc[a_left][0]; Py = TM.sc[a_left][1]; Pm = TM.sc[a_left][2]; }
-            if (s == 0) { Ax = TM.sc[a_left - 1][0]; Ay = TM.sc[a_left - 1][1]; Am = TM.sc[a_left - 1][2]; }
 #ifdef PG_TILE_STATS
             if (r == 0 && 3 * (J.Lx + J.Ly) >= 4096) {      // (long jobs only: the counters borrow the tail of the trace buffer) [13] waiting for the neighbours' progress, [14] acquire + halo block
                 unsigned long long *out = (unsigned long long *)(jobs[T.x].trace + ((3 * (J.Lx + J.Ly) - 64) & ~1));
@@ -443,17 +378,10 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
         }
         const pg_i4 Dn = TM.dsc[TDB + s + 1];
         const int jj = s - r;
-        pg_i4 cn = pg_i4{0, 0, 0, 0}, cen = pg_i4{0, 0, 0, 0}, czn = pg_i4{0, 0, 0, 0};
-        if (jj + 1 >= 0 && jj + 1 < TS) { cn = TM.col[jj + 1]; cen = TM.cole[jj + 1]; czn = TM.colz[jj + 1]; }
+        pg_i4 cn = pg_i4{0, 0, 0, 0}, cen = pg_i4{0, 0, 0, 0};
+        if (jj + 1 >= 0 && jj + 1 < TS) { cn = TM.col[jj + 1]; cen = TM.cole[jj + 1]; }
         const int mn = D.x, mx = D.y;
         const bool active = jj >= 0 && jj < TS && i >= mn && i <= mx;
-        {   // the register operands of this step: C = the shift of the step before, A = the shift of P; lane 0: (i0-1, j0+s)
-            const int a_top = ((s < TS ? s : TS - 1) + TH) * TP + (TH - 1);
-            const double t0 = TM.sc[a_top][0], t1 = TM.sc[a_top][1], t2 = TM.sc[a_top][2];
-            Cx = Ax; Cy = Ay; Cm = Am;
-            Ax = tile_shr1(Px, t0); Ay = tile_shr1(Py, t1); Am = tile_shr1(Pm, t2);
-        }
-        double bx_keep = NI, by_keep = NI, bm_keep = NI;
         if (__builtin_amdgcn_ballot_w64(active) != 0) {
             const long long off = ((long long)D.w << 32) | (unsigned)D.z;
             const int j = j0 + jj;
@@ -465,63 +393,35 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
 #ifdef PG_TILE_STATS
             st_kind = __builtin_amdgcn_ballot_w64(active && !simple) == 0 ? 0 : (__builtin_amdgcn_ballot_w64(active && !(two && !anyfar)) == 0 ? 1 : 2);
 #endif
-            const bool easy = (row.r.z & c.z & SITE_EASY) != 0;
-#ifdef PG_TILE_EXP_NOSTEP                                       // timing experiment (wrong results): no candidates at all
-            if (active) { bx = Ax; by = Py; bm = Cm; }
-            if (false) {
-#else
             if (__builtin_amdgcn_ballot_w64(active && !simple) == 0) {
-#endif
                 if (active) {
-                    // (i-1,j) = A, (i,j-1) = P, (i-1,j-1) = C: registers
+                    // (i-1,j), (i,j-1), (i-1,j-1)
+                    const int a_up = TAT(i - 1, j), a_left = TAT(i, j - 1), a_diag = TAT(i - 1, j - 1);
+                    const double ux = TM.sc[a_up][0], uy = TM.sc[a_up][1], um = TM.sc[a_up][2];
+                    const double lx = TM.sc[a_left][0], ly = TM.sc[a_left][1], lm = TM.sc[a_left][2];
+                    const double gx = TM.sc[a_diag][0], gy = TM.sc[a_diag][1], gm = TM.sc[a_diag][2];
                     const float sm = TM.sm[r][jj];   // VA:1363
                     const double rw = (double)__int_as_float(ce.y);
                     {
                         const bool end_gap = (j == J.Ly - 1) && !no_terminal_edges;          // VA:864-868 (j > 0 here)
                         const double ext = (double)(end_gap ? J.gE : J.ge);
-                        bx = gap3(Ax, Ay, Am, ext, go, ng, openX0);
+                        PG_TAKE(bx, px, ux + ext, pack_bp(PG_X, 0, 0, true, false));
+                        PG_TAKE(bx, px, (uy + 0.0) + go, pack_bp(PG_Y, 0, 0, true, false));
+                        PG_TAKE(bx, px, (um + ng) + openX0, pack_bp(PG_M, 0, 0, true, false));
                     }
                     {
                         const double open = (reduced_terminal && j == 1) ? 0.0 : go;
-                        by = gap3(Py, Px, Pm, extY, go, ng, open);
+                        PG_TAKE(by, py, ly + extY, pack_bp(PG_Y, 0, 0, false, true));
+                        PG_TAKE(by, py, (lx + 0.0) + go, pack_bp(PG_X, 0, 0, false, true));
+                        PG_TAKE(by, py, (lm + ng) + open, pack_bp(PG_M, 0, 0, false, true));
                     }
                     {
                         const double tM = (double)(2 * J.ng) + (double)sm;                   // VA:1364
                         const double tX = (double)(0.0f + J.ng) + (double)sm;                // VA:1366-1367
-                        bm = pair3(Cx, Cy, Cm, tM, tX, lw0, rw);
+                        PG_TAKE(bm, pm, ((gm + tM) + lw0) + rw, pack_bp(PG_M, 0, 0, true, true));
+                        PG_TAKE(bm, pm, ((gx + tX) + lw0) + rw, pack_bp(PG_X, 0, 0, true, true));
+                        PG_TAKE(bm, pm, ((gy + tX) + lw0) + rw, pack_bp(PG_Y, 0, 0, true, true));
                     }
-                }
-            } else if (__builtin_amdgcn_ballot_w64(active && !easy) == 0) {
-                if (active) {
-                    // Every cell of the wave has "easy" sites: per side the edge from the previous site (registers; masked off
-                    // where the site has none) and at most one other edge (its cells from the LDS window; the -inf cell where
-                    // there is none).  Candidates as values: X / Y the two edges' gap candidates, M the four pairs
-                    // (VA:1328-1349, 1396-1433); list order is pg_backptr's business.
-                    const bool cAdj = cz.y != 0, cOth = cz.x != 0;
-                    const int kR = cz.x;
-                    const double rwA = (double)__int_as_float(cz.z), rwS = (double)__int_as_float(cz.w);
-                    const int aW1 = rOth ? TAT(i - kL, j) : TNULL, aW2 = (rOth && cAdj) ? TAT(i - kL, j - 1) : TNULL;
-                    const int aU = cOth ? TAT(i, j - kR) : TNULL, aV = (cOth && rAdj) ? TAT(i - 1, j - kR) : TNULL;
-                    const int aW3 = (rOth && cOth) ? TAT(i - kL, j - kR) : TNULL;
-                    const double w1x = TM.sc[aW1][0], w1y = TM.sc[aW1][1], w1m = TM.sc[aW1][2];
-                    const double w2x = TM.sc[aW2][0], w2y = TM.sc[aW2][1], w2m = TM.sc[aW2][2];
-                    const double ux = TM.sc[aU][0], uy = TM.sc[aU][1], um = TM.sc[aU][2];
-                    const double vx = TM.sc[aV][0], vy = TM.sc[aV][1], vm = TM.sc[aV][2];
-                    const double w3x = TM.sc[aW3][0], w3y = TM.sc[aW3][1], w3m = TM.sc[aW3][2];
-                    const float sm = TM.sm[r][jj];
-                    const double extX = (double)(((j == 0 || j == J.Ly - 1) && !no_terminal_edges) ? J.gE : J.ge);   // VA:864-868
-                    const double openYa = (reduced_terminal && j == 1) ? 0.0 : go, openYo = (reduced_terminal && j - kR == 0) ? 0.0 : go;
-                    const double ax = rAdj ? Ax : NI, ay = rAdj ? Ay : NI, am = rAdj ? Am : NI;
-                    const double px_ = cAdj ? Px : NI, py_ = cAdj ? Py : NI, pm_ = cAdj ? Pm : NI;
-                    const bool both = rAdj && cAdj;
-                    const double cx_ = both ? Cx : NI, cy_ = both ? Cy : NI, cm_ = both ? Cm : NI;
-                    bx = __builtin_fmax(gap3(ax, ay, am, extX, go, ng, openXa), gap3(w1x, w1y, w1m, extX, go, ng, openXo));
-                    by = __builtin_fmax(gap3(py_, px_, pm_, extY, go, ng, openYa), gap3(uy, ux, um, extY, go, ng, openYo));
-                    const double tM = (double)(2 * J.ng) + (double)sm;                       // VA:1364
-                    const double tX = (double)(0.0f + J.ng) + (double)sm;                    // VA:1366-1367
-                    bm = __builtin_fmax(__builtin_fmax(pair3(cx_, cy_, cm_, tM, tX, lwA, rwA), pair3(vx, vy, vm, tM, tX, lwA, rwS)),
-                                        __builtin_fmax(pair3(w2x, w2y, w2m, tM, tX, lwS, rwA), pair3(w3x, w3y, w3m, tM, tX, lwS, rwS)));
-                    if (i == 0 && j == 0) bm = 0.0;                                          // initialise_array_corner, VA:725-736
                 }
             } else {
                 const int nr = c.z & SITE_COUNT;
@@ -756,30 +656,21 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
             if (active) {
                 const int at = TAT(i, j);
                 TM.sc[at][0] = bx; TM.sc[at][1] = by; TM.sc[at][2] = bm;
-                {   // 24 B of scores (the 12 B of back-pointers are pg_backptr's), written through (sc1): tiles that run lagged
-                    // behind this one read them with sc1 loads on the strength of a progress flag that follows an s_waitcnt
-                    // vmcnt(0) -- every byte handed over stored sc1, every load of it sc1 (MI355X_MICROARCH.md, "Valid forms")
+                {   // 24 B of scores (the 12 B of back-pointers are pg_backptr's)
                     typedef double d2 __attribute__((ext_vector_type(2)));
                     gdouble_w o_ = J.sc + 3 * (off + (i - mn));
                     d2 xy; xy.x = bx; xy.y = by;
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %0, %2, off offset:16 sc1"
-                                 : : "v"(o_), "v"(xy), "v"(bm) : "memory");
+                    *(PG_GLOBAL d2 *)o_ = xy;
+                    o_[2] = bm;
                 }
                 (void)px; (void)py; (void)pm;
-                bx_keep = bx; by_keep = by; bm_keep = bm;
             }
         }
-        // the lane's cell of this step for the next one: -inf where the band leaves the cell out; a lane that has not started yet
-        // keeps the cell left of the tile
-        if (active) { Px = bx_keep; Py = by_keep; Pm = bm_keep; }
-        else if (jj >= 0) { Px = NI; Py = NI; Pm = NI; }
-        D = Dn; c = cn; ce = cen; cz = czn;
+        D = Dn; c = cn; ce = cen;
         asm volatile("" ::: "memory");
         // (the first progress anybody waits for is TS + TB - 1)
         if (LAG && (s & (TB - 1)) == TB - 1 && s >= TS && s < s_last) {
-            // (round 4: no L2 write-back here -- the scores went out written through; the wave's stores have been acknowledged,
-            //  then the flag, itself an sc1 store)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (waits for the wave's stores, writes the L2 back)
             if (r == 0) __hip_atomic_store(&prog[self], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #ifdef PG_TILE_STATS
@@ -796,6 +687,8 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
         atomicAdd(out + 0, 1ull);
         atomicAdd(out + 1, st_loop - st_begin);
         for (int k = 0; k < 3; ++k) { atomicAdd(out + 2 + k, st_n[k]); atomicAdd(out + 5 + k, st_t[k]); }
+        // [15] generic steps with a fetch from beyond the LDS window, [16] such fetches of the busiest lane summed over those steps,
+        // [17] (left, right) edge pairs of the busiest lane summed over the generic steps
         atomicAdd(out + 15, (unsigned long long)st_far_steps); atomicAdd(out + 16, (unsigned long long)st_far_max); atomicAdd(out + 17, (unsigned long long)st_pairs_max);
         atomicAdd(out + 8, __builtin_amdgcn_s_memtime() - st_begin);
     }
