@@ -311,6 +311,14 @@ __device__ __forceinline__ double fb_shr1(double v, double lane0) {
     return __hiloint2double(hi, lo);
 }
 
+// lane n takes lane n+1's v; lane 63 keeps `lane63`
+__device__ __forceinline__ double fb_shl1(double v, double lane63) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(lane63), lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(lane63), hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // LDS traffic of the one wave is in order; this keeps the compiler from moving it and waits for nothing in memory
 __device__ __forceinline__ void fb_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -546,13 +554,41 @@ __global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs, 
             const int st_t0 = nl > 0 && t0 < J.Lx ? J.stL[t0] : 0, st_t1 = nl > 1 && t1 < J.Lx ? J.stL[t1] : 0;
             const double lwl0 = nl > 0 ? (double)J.flwL[l0] : 0.0, lwl1 = nl > 1 ? (double)J.flwL[l0 + 1] : 0.0;
             __syncthreads();
+            // registers, as in the forward sweep but mirrored: P this lane's cell of the step before (i, j+1), A the wave shift
+            // that brings lane r+1's P (i+1, j), C the A of the step before (i+1, j+1); a lane starts from the column right of
+            // the block, lane 63 takes row i0+64 from the halo
+            const bool row_simple = nl == 1 && t0 == i + 1 && t0 < J.Lx;
+            double Px = M.hb[r][0][0], Py = M.hb[r][0][1], Pm = M.hb[r][0][2];
+            double Ax = M.ha[0][FB_T][0], Ay = M.ha[0][FB_T][1], Am = M.ha[0][FB_T][2];      // lane 63: the corner (i0+64, j0+64)
+            double Cx = NI, Cy = NI, Cm = NI;
             for (int s = 2 * FB_T - 2; s >= 0; --s) {
                 const int d = dbase + s;
+                {   // (every step, also the ones past the matrix's last diagonal: the lanes' columns move with s)
+                    const int bc = s - (FB_T - 1);                                   // lane 63's column in the block
+                    const int bcc = bc < 0 ? 0 : bc;
+                    const double t0_ = M.ha[0][bcc][0], t1_ = M.ha[0][bcc][1], t2_ = M.ha[0][bcc][2];
+                    Cx = Ax; Cy = Ay; Cm = Am;
+                    (void)Cx; (void)Cy;                                              // (a match moves through M only: VA:2269-2271)
+                    Ax = fb_shl1(Px, t0_); Ay = fb_shl1(Py, t1_); Am = fb_shl1(Pm, t2_);
+                }
                 if (d >= J.nd) continue;
                 const int j = d - i, jj = s - r;
                 const int mn = M.dmin[s], mx = M.dmax[s];
                 const bool active = jj >= 0 && jj < FB_T && i < J.Lx && j < J.Ly && i >= mn && i <= mx;
                 double bx = NI, by = NI, bm = NI;
+                const bool col_simple = active && M.c_n[jj] == 1 && M.c_e0[jj] == j + 1 && j + 1 < J.Ly;
+                if (!blk_init && __builtin_amdgcn_ballot_w64(active && !(row_simple && col_simple)) == 0) {
+                    if (active) {
+                        const int ti = st_t0 + M.c_st[jj + 1] * J.S;
+                        const double sc = tab_lds ? M.ltab[ti] : J.ltab[st_t0 + (long long)M.c_st[jj + 1] * J.S];
+                        const double thru = Cm + sc + lwl0 + (double)M.c_lw0[jj];             // VA:2269-2271
+                        bx = lse3(Ax + J.l_ext, Py + J.l_open, thru + J.l_ng);               // VA:2281-2303
+                        by = lse3(Ax + J.l_open, Py + J.l_ext, thru + J.l_ng);
+                        bm = lse3(Ax + J.l_ng + J.l_open, Py + J.l_ng + J.l_open, thru + J.l_ng + J.l_ng);
+                        double *o = J.B + 3 * (M.doff[s] + (i - mn));
+                        o[0] = bx; o[1] = by; o[2] = bm;
+                    }
+                } else
                 if (active) {
                     // state q of cell (t_, u) >= (i, j)
                     auto fetch = [&](int t_, int u, int q) -> double {
@@ -603,6 +639,7 @@ __global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs, 
                 }
                 double *c = M.ring[d % FB_RING][r];
                 c[0] = bx; c[1] = by; c[2] = bm;
+                if (active) { Px = bx; Py = by; Pm = bm; } else if (jj < FB_T) { Px = NI; Py = NI; Pm = NI; }
                 fb_lds_fence();
             }
         }
