@@ -47,6 +47,8 @@
 #define TDB 128                    // descriptors kept for this many diagonals before the tile's first
 #define THALO (TH * (TS + TH) + TH * TS)
 #define THC 9                      // halo cells a lane has in flight at a time
+#define TNL 10                     // far lines (TileSmem::farl)
+#define TLINE_COL 0x40000000
 
 namespace {
 
@@ -56,8 +58,17 @@ struct TileSmem {
     pg_i4 cole[TS];                     // its first two bwd edges: start site, log weight (float bits), start site, log weight
     pg_i4 dsc[TDB + 2 * TS];            // descriptors of anti-diagonals i0 + j0 - TDB ...: imin, imax, doff low, doff high
     int eL[TEC + 64][2], eR[TEC + 64][2];   // bwd edges of the tile's rows / columns: start site, log weight (float bits)
-    float sm[TS][TS];                   // model log score of row i0 + r's state against column j0 + k's: sm[r][k]
-    float table[256];                   // the model table while sm[][] is built (S <= 16)
+    // model log score of row i0 + r's state against column j0 + k's, sm[r][k] -- for tables that do not fit LDS.  A small table
+    // (S <= 16: `table` below) is looked up directly, and its jobs use the 16 KB for FAR LINES (round 4): the cells of up to
+    // TNL rows above / columns left of the halo that bwd edges of the tile's sites start in -- row p as (p, j0-1 .. j0+63),
+    // column q as (i0-1 .. i0+63, q) -- loaded with the halo (blocks), so that an operand before the halo is an LDS read
+    // instead of a round trip to L2 / HBM in the middle of a step (top of a 512-leaf tree: half of the generic steps made
+    // such trips, three to four one after the other, a third of the fill).
+    union { float sm[TS][TS]; double farl[TNL][TS + 4][3]; };
+    float table[256];                   // the model table (S <= 16)
+    unsigned char lineL[TEC + 64], lineR[TEC + 64];     // far line of a bwd edge of the tile's rows / columns (>= TNL: none)
+    int line_key[TNL];                  // row lines: the row; column lines: the column | TLINE_COL
+    int n_lines;
 };
 
 // What a lane keeps about a site: x = state, y = CSR index of its first bwd edge, z = number of bwd
@@ -81,6 +92,7 @@ struct SiteRec { pg_i4 r, e; };
 
 } // namespace
 
+static_assert(sizeof(TileSmem) <= 160 * 1024, "TileSmem has to fit the 160 KB of LDS of a gfx950 compute unit");
 unsigned pg_tiles_lds_bytes() { return (unsigned)sizeof(TileSmem); }
 
 extern __shared__ __attribute__((aligned(16))) char pg_tiles_lds[];
@@ -265,7 +277,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
     }
     // the model's scores for the tile's 64 x 64 state pairs (VA:1363): from the table's LDS copy, or -- a
     // protein table is 211 x 211 floats -- from HBM/L2, sixteen loads in flight per lane
-    {
+    if (!tab_lds) {
         const bool sv = i > 0 && i < J.Lx;
         for (int k0 = 0; k0 < TS; k0 += 16) {
             int at[16];
@@ -274,13 +286,8 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
             for (int u = 0; u < 16; ++u) at[u] = TM.col[k0 + u].x;
 #pragma unroll
             for (int u = 0; u < 16; ++u) at[u] = (sv && j0 + k0 + u > 0 && j0 + k0 + u < J.Ly) ? row.r.x + at[u] * J.S : 0;
-            if (tab_lds) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = TM.table[at[u]];
-            } else {
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = J.table[at[u]];
-            }
+            for (int u = 0; u < 16; ++u) v[u] = J.table[at[u]];
 #pragma unroll
             for (int u = 0; u < 16; ++u) TM.sm[r][k0 + u] = v[u];
         }
@@ -289,6 +296,52 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
     for (int u = 0; u < THC; ++u)
         if (gv[u]) { TM.sc[gat[u]][0] = hxy[u].x; TM.sc[gat[u]][1] = hxy[u].y; TM.sc[gat[u]][2] = hm[u]; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    // ---- far lines (small tables only: the memory is sm[][] otherwise) ----
+    int n_lines = 0;
+    for (int k = r; k < TEC + 64; k += 64) { TM.lineL[k] = 255; TM.lineR[k] = 255; }
+    if (tab_lds) {
+        if (r == 0) TM.n_lines = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // a line per bwd edge that starts before the halo, as long as the line's diagonals are in the descriptor window
+        const int n_row_e = rv ? (row.r.z & SITE_COUNT) : 0, n_col_e = cv ? (col.r.z & SITE_COUNT) : 0;
+        for (int k = 0; k < n_row_e && row.r.y - eL0 + k < TEC; ++k) {
+            const int p = TM.eL[row.r.y - eL0 + k][0];
+            if (p >= i0 - TH || p + j0 - 1 < dbase - TDB) continue;
+            const int slot = __hip_atomic_fetch_add(&TM.n_lines, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (slot < TNL) { TM.line_key[slot] = p; TM.lineL[row.r.y - eL0 + k] = (unsigned char)slot; }
+        }
+        for (int k = 0; k < n_col_e && col.r.y - eR0 + k < TEC; ++k) {
+            const int q = TM.eR[col.r.y - eR0 + k][0];
+            if (q >= j0 - TH || q + i0 - 1 < dbase - TDB) continue;
+            const int slot = __hip_atomic_fetch_add(&TM.n_lines, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (slot < TNL) { TM.line_key[slot] = q | TLINE_COL; TM.lineR[col.r.y - eR0 + k] = (unsigned char)slot; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        n_lines = TM.n_lines < TNL ? TM.n_lines : TNL;
+        n_lines = __builtin_amdgcn_readfirstlane(n_lines);
+        for (int k = r; k < n_lines * (TS + 4); k += 64) { double *c_ = &TM.farl[0][0][0] + 3 * k; c_[0] = NI; c_[1] = NI; c_[2] = NI; }
+        if (!LAG) {
+            // the tiles the lines lie in are finished: every cell now
+            for (int e = r; e < n_lines * (TS + 1); e += 64) {
+                const int line = e / (TS + 1), cc = e % (TS + 1), key = TM.line_key[line];
+                const int p = (key & TLINE_COL) ? i0 - 1 + cc : key, q = (key & TLINE_COL) ? (key & ~TLINE_COL) : j0 - 1 + cc;
+                if (p < 0 || q < 0 || p >= J.Lx || q >= J.Ly) continue;
+                const pg_i4 F = TM.dsc[p + q - (dbase - TDB)];
+                if (p < F.x || p > F.y) continue;
+                const long long ix = (((long long)F.w << 32) | (unsigned)F.z) + (p - F.x);
+                TM.farl[line][cc][0] = J.sc[3 * ix]; TM.farl[line][cc][1] = J.sc[3 * ix + 1]; TM.farl[line][cc][2] = J.sc[3 * ix + 2];
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+    }
+    // the model's score of (row i0 + r, the column whose record is cw): a small table is looked up (its LDS copy), a large
+    // one was gathered into sm[][] above
+    auto model_score = [&](int jj_, int cstate) -> float {
+        if (!tab_lds) return TM.sm[r][jj_];
+        const int j_ = j0 + jj_;
+        return TM.table[(i > 0 && i < J.Lx && j_ > 0 && j_ < J.Ly) ? row.r.x + cstate * J.S : 0];
+    };
 
     const double go = (double)J.go, ng = (double)J.ng;
     const int nl = row.r.z & SITE_COUNT;
@@ -347,6 +400,47 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
         for (int u = 0; u < 5; ++u)
             if (hv_[u]) { TM.sc[hat_[u]][0] = hxy_[u].x; TM.sc[hat_[u]][1] = hxy_[u].y; TM.sc[hat_[u]][2] = hm_[u]; }
     };
+    // LAG: the far lines' cells of one block of steps -- a row line's next TB columns, a column line's next TB rows (the first
+    // block also takes the cell at j0-1 / i0-1); they lie in tiles that are further along than the halo's (rows above the
+    // halo complete before the halo's rows do, columns left of it before its columns), so the halo's wait covers them
+    auto line_block = [&](int k) {
+        if (n_lines == 0) return;
+        const int per = TB + (k == 0 ? 1 : 0), nall = n_lines * per;
+        bool hv_[3];
+        int hl_[3], hc_[3];
+        PG_GLOBAL const double *hp_[3];
+        d2 hxy_[3];
+        double hm_[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int e = r + 64 * u;
+            const int line = e < nall ? e / per : 0, w = e % per;
+            const int cc = (k == 0) ? w : TB * k + 1 + w;          // cell of the line: 0 .. TS
+            const int key = TM.line_key[line];
+            const int p = (key & TLINE_COL) ? i0 - 1 + cc : key, q = (key & TLINE_COL) ? (key & ~TLINE_COL) : j0 - 1 + cc;
+            hv_[u] = e < nall && cc <= TS && p >= 0 && q >= 0 && p < J.Lx && q < J.Ly;
+            const pg_i4 F = TM.dsc[hv_[u] ? p + q - (dbase - TDB) : TDB];
+            hv_[u] = hv_[u] && p >= F.x && p <= F.y;
+            const long long ix = hv_[u] ? (((long long)F.w << 32) | (unsigned)F.z) + (p - F.x) : 0;
+            hp_[u] = J.sc + 3 * ix;
+            hl_[u] = line; hc_[u] = cc;
+            hxy_[u].x = NI; hxy_[u].y = NI; hm_[u] = NI;
+        }
+        const unsigned long long k0 = __builtin_amdgcn_ballot_w64(hv_[0]), k1 = __builtin_amdgcn_ballot_w64(hv_[1]);
+        const unsigned long long k2 = __builtin_amdgcn_ballot_w64(hv_[2]);
+        if ((k0 | k1 | k2) == 0) return;
+        unsigned long long sv;
+#define PG_LINE_LD(n) "s_and_b64 exec, %[sv], %[k" #n "]\n\tglobal_load_dwordx4 %[x" #n "], %[p" #n "], off sc1\n\tglobal_load_dwordx2 %[u" #n "], %[p" #n "], off offset:16 sc1\n\t"
+        asm volatile("s_mov_b64 %[sv], exec\n\t" PG_LINE_LD(0) PG_LINE_LD(1) PG_LINE_LD(2)
+                     "s_mov_b64 exec, %[sv]\n\ts_waitcnt vmcnt(0)"
+                     : [x0] "+v"(hxy_[0]), [u0] "+v"(hm_[0]), [x1] "+v"(hxy_[1]), [u1] "+v"(hm_[1]), [x2] "+v"(hxy_[2]), [u2] "+v"(hm_[2]), [sv] "=&s"(sv)
+                     : [p0] "v"(hp_[0]), [p1] "v"(hp_[1]), [p2] "v"(hp_[2]), [k0] "s"(k0), [k1] "s"(k1), [k2] "s"(k2)
+                     : "memory");
+#undef PG_LINE_LD
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (hv_[u]) { TM.farl[hl_[u]][hc_[u]][0] = hxy_[u].x; TM.farl[hl_[u]][hc_[u]][1] = hxy_[u].y; TM.farl[hl_[u]][hc_[u]][2] = hm_[u]; }
+    };
     auto wait_prog = [&](int which, int need) {
         if (which < 0) return;
         flow_wait(&prog[which], need, giveup, jobs[T.x].fill_status);
@@ -368,6 +462,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
 #endif
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             halo_block(s / TB);
+            line_block(s / TB);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef PG_TILE_STATS
             if (r == 0 && 3 * (J.Lx + J.Ly) >= 4096) {      // (long jobs only: the counters borrow the tail of the trace buffer) [13] waiting for the neighbours' progress, [14] acquire + halo block
@@ -400,7 +495,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                     const double ux = TM.sc[a_up][0], uy = TM.sc[a_up][1], um = TM.sc[a_up][2];
                     const double lx = TM.sc[a_left][0], ly = TM.sc[a_left][1], lm = TM.sc[a_left][2];
                     const double gx = TM.sc[a_diag][0], gy = TM.sc[a_diag][1], gm = TM.sc[a_diag][2];
-                    const float sm = TM.sm[r][jj];   // VA:1363
+                    const float sm = model_score(jj, c.x);   // VA:1363
                     const double rw = (double)__int_as_float(ce.y);
                     {
                         const bool end_gap = (j == J.Ly - 1) && !no_terminal_edges;          // VA:864-868 (j > 0 here)
@@ -452,7 +547,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                     const double a1x = TM.sc[aA1][0], a1y = TM.sc[aA1][1], a1m = TM.sc[aA1][2];
                     const double b0x = TM.sc[aB0][0], b0y = TM.sc[aB0][1], b0m = TM.sc[aB0][2];
                     const double b1x = TM.sc[aB1][0], b1y = TM.sc[aB1][1], b1m = TM.sc[aB1][2];
-                    const float sm = (i > 0 && j > 0) ? TM.sm[r][jj] : 0.0f;
+                    const float sm = (i > 0 && j > 0) ? model_score(jj, c.x) : 0.0f;
                     const double extX = (double)(((j == 0 || j == J.Ly - 1) && !no_terminal_edges) ? J.gE : J.ge);   // VA:864-868
                     const unsigned adjG = left ? PG_BP_ADJL : PG_BP_ADJR, adjS = left ? PG_BP_ADJR : PG_BP_ADJL;
                     const unsigned selfG = left ? PG_X : PG_Y, crossG = left ? PG_Y : PG_X;
@@ -503,7 +598,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                     const int aM00 = (l0 && r0) ? TAT(p0, q0) : TNULL, aM01 = (l0 && r1) ? TAT(p0, q1) : TNULL;
                     const int aM10 = (l1 && r0) ? TAT(p1, q0) : TNULL, aM11 = (l1 && r1) ? TAT(p1, q1) : TNULL;
                     float sm = 0.0f;
-                    if (l0 && r0 && i > 0 && j > 0) sm = TM.sm[r][jj];
+                    if (l0 && r0 && i > 0 && j > 0) sm = model_score(jj, c.x);
                     {
                         const double x0 = TM.sc[aX0][0], y0 = TM.sc[aX0][1], m0 = TM.sc[aX0][2];
                         const double x1 = TM.sc[aX1][0], y1 = TM.sc[aX1][1], m1 = TM.sc[aX1][2];
@@ -558,10 +653,17 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                         // Any number of bwd edges, anywhere: the reference's loops, edges from the
                         // LDS windows (the next one requested while the current one is worked on), operand cells from
                         // the LDS window or, before the halo, from HBM.
-                        auto fetch = [&](int p, int q, double &xs, double &ys, double &ms) {
+                        // sl / sr: the far line of the left / right edge the operand comes through (>= TNL: none)
+                        auto fetch = [&](int p, int q, int sl, int sr, double &xs, double &ys, double &ms) {
                             if (p >= i0 - TH && q >= j0 - TH) {
                                 const int at = TAT(p, q);
                                 xs = TM.sc[at][0]; ys = TM.sc[at][1]; ms = TM.sc[at][2];
+                            } else if (sl < TNL && p < i0 - TH && q >= j0 - 1) {
+                                const double *c_ = TM.farl[sl][q - (j0 - 1)];
+                                xs = c_[0]; ys = c_[1]; ms = c_[2];
+                            } else if (sr < TNL && q < j0 - TH && p >= i0 - 1) {
+                                const double *c_ = TM.farl[sr][p - (i0 - 1)];
+                                xs = c_[0]; ys = c_[1]; ms = c_[2];
                             } else {
 #ifdef PG_TILE_STATS
                                 ++st_far;
@@ -569,10 +671,12 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                                 const int w = p + q - (dbase - TDB);
                                 const pg_i4 F = w >= 0 ? TM.dsc[w] : far_desc(((PG_GLOBAL const pg_i4 *)(unsigned long long)J.dsc) + (p + q));
                                 xs = ys = ms = NI;
+#ifndef PG_TILE_EXP_NOFAR                                       // (timing experiment, wrong results: what would the generic steps cost without their far loads?)
                                 if (p >= F.x && p <= F.y) {
                                     const long long ix = (((long long)F.w << 32) | (unsigned)F.z) + (p - F.x);
                                     far_cell(J.sc + 3 * ix, xs, ys, ms);
                                 }
+#endif
                             }
                         };
                         typedef int i2 __attribute__((ext_vector_type(2)));
@@ -585,11 +689,11 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                             i2 en = *(const i2 *)TM.eL[eLi + 1];
                             int p = TM.eL[eLi][0];
                             double xs, ys, ms;
-                            fetch(p, j, xs, ys, ms);
+                            fetch(p, j, TM.lineL[eLi], 255, xs, ys, ms);
                             for (int k = 0; k < nl; ++k) {
                                 const int pn = en.x;
                                 double nx = NI, ny = NI, nm = NI;
-                                if (k + 1 < nl) fetch(pn, j, nx, ny, nm);
+                                if (k + 1 < nl) fetch(pn, j, TM.lineL[eLi + k + 1], 255, nx, ny, nm);
                                 en = *(const i2 *)TM.eL[eLi + k + 2];
                                 const double open = (reduced_terminal && p == 0) ? 0.0 : go;
                                 const unsigned base = ((unsigned)k << 4) | (p == i - 1 ? PG_BP_ADJL : 0u);
@@ -603,11 +707,11 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                             i2 en = *(const i2 *)TM.eR[eRi + 1];
                             int q = TM.eR[eRi][0];
                             double xs, ys, ms;
-                            fetch(i, q, xs, ys, ms);
+                            fetch(i, q, 255, TM.lineR[eRi], xs, ys, ms);
                             for (int k = 0; k < nr; ++k) {
                                 const int qn = en.x;
                                 double nx = NI, ny = NI, nm = NI;
-                                if (k + 1 < nr) fetch(i, qn, nx, ny, nm);
+                                if (k + 1 < nr) fetch(i, qn, 255, TM.lineR[eRi + k + 1], nx, ny, nm);
                                 en = *(const i2 *)TM.eR[eRi + k + 2];
                                 const double open = (reduced_terminal && q == 0) ? 0.0 : go;
                                 const unsigned base = ((unsigned)k << 18) | (q == j - 1 ? PG_BP_ADJR : 0u);
@@ -618,7 +722,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                             }
                         }
                         if (nl > 0 && nr > 0) {                                              // M (VA:956-963, 1353-1436)
-                            const float sm = TM.sm[r][jj];
+                            const float sm = model_score(jj, c.x);
                             const double tM = (double)(2 * J.ng) + (double)sm;               // VA:1364
                             const double tX = (double)(0.0f + J.ng) + (double)sm;            // VA:1366-1367
                             // the (left edge, right edge) pairs row-major as ONE loop: the next pair's edges are requested
@@ -631,13 +735,14 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                                 const double lw = (double)__int_as_float(e1.y), rw = (double)__int_as_float(e2.y);
                                 const unsigned base = ((unsigned)k1 << 4) | ((unsigned)k2 << 18) | (p == i - 1 ? PG_BP_ADJL : 0u) |
                                                       (q == j - 1 ? PG_BP_ADJR : 0u);
+                                const int sl_ = TM.lineL[eLi + k1], sr_ = TM.lineR[eRi + k2];
                                 const bool wrap = k2 + 1 == nr;
                                 k2 = wrap ? 0 : k2 + 1;
                                 k1 = wrap ? k1 + 1 : k1;
                                 e1 = *(const i2 *)TM.eL[eLi + k1];
                                 e2 = *(const i2 *)TM.eR[eRi + k2];
                                 double xs, ys, ms;
-                                fetch(p, q, xs, ys, ms);
+                                fetch(p, q, sl_, sr_, xs, ys, ms);
                                 PG_TAKE(bm, pm, ((ms + tM) + lw) + rw, base | PG_M);
                                 PG_TAKE(bm, pm, ((xs + tX) + lw) + rw, base | PG_X);
                                 PG_TAKE(bm, pm, ((ys + tX) + lw) + rw, base | PG_Y);
@@ -730,6 +835,11 @@ __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restr
     const int *first = diag + n_tiles;
     int *fin = flow + 1, *done = flow + 1 + n_diag;
     int water = 0;                                             // every diagonal < water is complete
+    if (flags & 0x200u) {                                      // diagnostic (PAGAN_DP_DEBUG_FLAGS=0x200): the waves of XCD 0 only -- do the
+        unsigned x;                                            // reads of other tiles' cells cost what they cost because they cross XCDs?
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        if ((x & 15u) != 0) return;
+    }
     int *giveup = done + n_tiles;                              // set by a wave whose wait ran into its limit: everybody leaves
     for (;;) {
         int idx = 0;
