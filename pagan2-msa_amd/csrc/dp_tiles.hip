@@ -38,6 +38,7 @@
 #include "dp_device.h"
 
 #include "dp_kcommon.h"
+#include <type_traits>
 
 #define TS PG_TILE
 #define TH 8                       // halo depth: rows above / columns left of the tile kept in LDS
@@ -133,9 +134,11 @@ __device__ __forceinline__ void flow_wait(int *p, int need, int *giveup, int *st
 // back, which were TLAG steps ahead of those.
 #define TBLK 16                    // (TH + TBLK) * TH + TBLK * TH <= 5 * 64: halo_block's five cells per lane
 #define TDONE (1 << 20)
-template <bool LAG, int TB = TBLK>
-__device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, const pg_i4 T, unsigned flags, int *prog = nullptr,
-                                          int self = -1, int up = -1, int lf = -1, int *giveup = nullptr) {
+// TAB: the job's model table fits LDS (S <= 16) -- a compile-time fact of the body (the far lines and the table look-up exist
+// for such jobs only; a protein walk paid for the other kind's branches and look-ups in every generic step)
+template <bool LAG, int TB, bool TAB>
+__device__ __noinline__ void tile_body(const PgDevJob *__restrict__ jobs, const pg_i4 T, unsigned flags, int *prog = nullptr,
+                                       int self = -1, int up = -1, int lf = -1, int *giveup = nullptr) {
     const bool no_terminal_edges = flags & 1u;
     const bool reduced_terminal = !(flags & 2u);
     const View J = load_view(jobs + T.x);
@@ -150,7 +153,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
     const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
 #endif
     const double NI = neg_inf();
-    const bool tab_lds = J.S <= 16;      // DNA: 15 states; a protein table (211 x 211) stays in HBM/L2
+    constexpr bool tab_lds = TAB;        // DNA: 15 states; a protein table (211 x 211) stays in HBM/L2
 
     // ---- prologue: after a kernel boundary every first touch goes to memory (~1 us), so the loads are issued in
     // three dependent rounds, each round's in flight together, with the LDS-only work between issue and use ----
@@ -299,8 +302,8 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
 
     // ---- far lines (small tables only: the memory is sm[][] otherwise) ----
     int n_lines = 0;
-    for (int k = r; k < TEC + 64; k += 64) { TM.lineL[k] = 255; TM.lineR[k] = 255; }
     if (tab_lds) {
+        for (int k = r; k < TEC + 64; k += 64) { TM.lineL[k] = 255; TM.lineR[k] = 255; }
         if (r == 0) TM.n_lines = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // a line per bwd edge that starts before the halo, as long as the line's diagonals are in the descriptor window
@@ -337,10 +340,11 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
     }
     // the model's score of (row i0 + r, the column whose record is cw): a small table is looked up (its LDS copy), a large
     // one was gathered into sm[][] above
+    // (a row or column that is no site of the matrix carries state 0 in its record, and its cells have no M candidate: any
+    //  entry of the table does)
     auto model_score = [&](int jj_, int cstate) -> float {
         if (!tab_lds) return TM.sm[r][jj_];
-        const int j_ = j0 + jj_;
-        return TM.table[(i > 0 && i < J.Lx && j_ > 0 && j_ < J.Ly) ? row.r.x + cstate * J.S : 0];
+        return TM.table[row.r.x + cstate * J.S];
     };
 
     const double go = (double)J.go, ng = (double)J.ng;
@@ -649,7 +653,10 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                         st_pairs_max += pr_;
                     }
 #endif
-                    if (active) {
+                    // (compiled twice: with the far lines' look-ups for small-table jobs, without them for the others -- a protein
+                    //  walk paid 10 % for look-ups it never uses)
+                    auto loops = [&](auto with_lines) {
+                        constexpr bool LINES = decltype(with_lines)::value;
                         // Any number of bwd edges, anywhere: the reference's loops, edges from the
                         // LDS windows (the next one requested while the current one is worked on), operand cells from
                         // the LDS window or, before the halo, from HBM.
@@ -658,10 +665,10 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                             if (p >= i0 - TH && q >= j0 - TH) {
                                 const int at = TAT(p, q);
                                 xs = TM.sc[at][0]; ys = TM.sc[at][1]; ms = TM.sc[at][2];
-                            } else if (sl < TNL && p < i0 - TH && q >= j0 - 1) {
+                            } else if (LINES && sl < TNL && p < i0 - TH && q >= j0 - 1) {
                                 const double *c_ = TM.farl[sl][q - (j0 - 1)];
                                 xs = c_[0]; ys = c_[1]; ms = c_[2];
-                            } else if (sr < TNL && q < j0 - TH && p >= i0 - 1) {
+                            } else if (LINES && sr < TNL && q < j0 - TH && p >= i0 - 1) {
                                 const double *c_ = TM.farl[sr][p - (i0 - 1)];
                                 xs = c_[0]; ys = c_[1]; ms = c_[2];
                             } else {
@@ -689,11 +696,11 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                             i2 en = *(const i2 *)TM.eL[eLi + 1];
                             int p = TM.eL[eLi][0];
                             double xs, ys, ms;
-                            fetch(p, j, TM.lineL[eLi], 255, xs, ys, ms);
+                            fetch(p, j, LINES ? TM.lineL[eLi] : 255, 255, xs, ys, ms);
                             for (int k = 0; k < nl; ++k) {
                                 const int pn = en.x;
                                 double nx = NI, ny = NI, nm = NI;
-                                if (k + 1 < nl) fetch(pn, j, TM.lineL[eLi + k + 1], 255, nx, ny, nm);
+                                if (k + 1 < nl) fetch(pn, j, LINES ? TM.lineL[eLi + k + 1] : 255, 255, nx, ny, nm);
                                 en = *(const i2 *)TM.eL[eLi + k + 2];
                                 const double open = (reduced_terminal && p == 0) ? 0.0 : go;
                                 const unsigned base = ((unsigned)k << 4) | (p == i - 1 ? PG_BP_ADJL : 0u);
@@ -707,11 +714,11 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                             i2 en = *(const i2 *)TM.eR[eRi + 1];
                             int q = TM.eR[eRi][0];
                             double xs, ys, ms;
-                            fetch(i, q, 255, TM.lineR[eRi], xs, ys, ms);
+                            fetch(i, q, 255, LINES ? TM.lineR[eRi] : 255, xs, ys, ms);
                             for (int k = 0; k < nr; ++k) {
                                 const int qn = en.x;
                                 double nx = NI, ny = NI, nm = NI;
-                                if (k + 1 < nr) fetch(i, qn, 255, TM.lineR[eRi + k + 1], nx, ny, nm);
+                                if (k + 1 < nr) fetch(i, qn, 255, LINES ? TM.lineR[eRi + k + 1] : 255, nx, ny, nm);
                                 en = *(const i2 *)TM.eR[eRi + k + 2];
                                 const double open = (reduced_terminal && q == 0) ? 0.0 : go;
                                 const unsigned base = ((unsigned)k << 18) | (q == j - 1 ? PG_BP_ADJR : 0u);
@@ -735,7 +742,7 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                                 const double lw = (double)__int_as_float(e1.y), rw = (double)__int_as_float(e2.y);
                                 const unsigned base = ((unsigned)k1 << 4) | ((unsigned)k2 << 18) | (p == i - 1 ? PG_BP_ADJL : 0u) |
                                                       (q == j - 1 ? PG_BP_ADJR : 0u);
-                                const int sl_ = TM.lineL[eLi + k1], sr_ = TM.lineR[eRi + k2];
+                                const int sl_ = LINES ? TM.lineL[eLi + k1] : 255, sr_ = LINES ? TM.lineR[eRi + k2] : 255;
                                 const bool wrap = k2 + 1 == nr;
                                 k2 = wrap ? 0 : k2 + 1;
                                 k1 = wrap ? k1 + 1 : k1;
@@ -748,7 +755,8 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
                                 PG_TAKE(bm, pm, ((ys + tX) + lw) + rw, base | PG_Y);
                             }
                         }
-                    }
+                    };
+                    if (active) loops(std::integral_constant<bool, TAB>());
 #ifdef PG_TILE_STATS
                     {   // fetches from beyond the LDS window in this step: the wave's largest count, and whether there was any
                         int f_ = (int)(st_far - far_before);
@@ -803,7 +811,8 @@ __device__ __forceinline__ void tile_body(const PgDevJob *__restrict__ jobs, con
 // tiles[blockIdx.x] = {job, tile row a, tile column b, -}: one launch per tile anti-diagonal (PAGAN_DP_TILES=launches)
 __global__ __launch_bounds__(64) void pg_fill_tiles(const PgDevJob *__restrict__ jobs, const int *__restrict__ tiles,
                                                     unsigned flags) {
-    tile_body<false>(jobs, ((cdesc_p)tiles)[blockIdx.x], flags);
+    const pg_i4 T = ((cdesc_p)tiles)[blockIdx.x];
+    if (jobs[T.x].S <= 16) tile_body<false, TBLK, true>(jobs, T, flags); else tile_body<false, TBLK, false>(jobs, T, flags);
 }
 
 // ---- dataflow schedule: ONE launch for all tile anti-diagonals of the batch ----
@@ -868,9 +877,15 @@ __global__ __launch_bounds__(64) void pg_fill_tiles_flow(const PgDevJob *__restr
         const unsigned long long fs2 = __builtin_amdgcn_s_memtime();
 #endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (!lag) tile_body<false>(jobs, T, flags);
-        else if (use_water == 3) tile_body<true, 8>(jobs, T, flags, done, idx, T.w, lf, giveup);
-        else tile_body<true>(jobs, T, flags, done, idx, T.w, lf, giveup);
+        const bool small_table = jobs[T.x].S <= 16;
+        if (!lag) { if (small_table) tile_body<false, TBLK, true>(jobs, T, flags); else tile_body<false, TBLK, false>(jobs, T, flags); }
+        else if (use_water == 3) {
+            if (small_table) tile_body<true, 8, true>(jobs, T, flags, done, idx, T.w, lf, giveup);
+            else tile_body<true, 8, false>(jobs, T, flags, done, idx, T.w, lf, giveup);
+        } else {
+            if (small_table) tile_body<true, TBLK, true>(jobs, T, flags, done, idx, T.w, lf, giveup);
+            else tile_body<true, TBLK, false>(jobs, T, flags, done, idx, T.w, lf, giveup);
+        }
 #ifdef PG_TILE_STATS
         const unsigned long long fs3 = __builtin_amdgcn_s_memtime();
 #endif
