@@ -202,7 +202,7 @@ def debug_compact(left, right, band=None):
             "upper": up[:n[0] - 1].copy(), "lower": lo[:n[0] - 1].copy()}
 
 
-ROUTES = ("pg_fill_pipe", "pg_fill_pipe (large table)", "pg_fill_tiles_flow", "pg_fill_wavefront")
+ROUTES = ("pg_fill_pipe", "pg_fill_pipe (large table)", "pg_fill_tiles_flow", "pg_fill_wavefront", "pg_fill_pipe (row strips)")
 
 
 def debug_route(left, right, model, band=None):

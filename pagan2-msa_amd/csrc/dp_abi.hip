@@ -32,7 +32,7 @@
 
 template <int BLOCK> __global__ void pg_fill_wavefront(const PgDevJob *jobs, const int *which, unsigned flags);
 template <bool TAB_LDS> __global__ void pg_fill_ring(const PgDevJob *jobs, const int *which, unsigned flags);
-template <bool TAB_LDS> __global__ void pg_fill_pipe(const PgDevJob *jobs, const int *which, unsigned flags, int n_fill);
+template <bool TAB_LDS, bool STRIP> __global__ void pg_fill_pipe(const PgDevJob *jobs, const int *which, unsigned flags, int n_fill);
 __global__ void pg_fill_tiles(const PgDevJob *jobs, const int *tiles, unsigned flags);
 __global__ void pg_fill_tiles_flow(const PgDevJob *jobs, const int *tiles, int n_tiles, int n_diag, int *flow, unsigned flags, int use_water);
 __global__ void pg_end_corner(const PgDevJob *jobs, const int *tiles_gave_up);
@@ -67,6 +67,13 @@ namespace {
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// One row strip of a wide job (dp_pipe.hip, strip_feeder has the scheme): rows r0..r1, descriptors of the diagonals d0..d1-1.
+struct StripPlan {
+    int r0 = 0, r1 = 0, d0 = 0, d1 = 0, feed_wave = -1, col_first = 0;
+    std::vector<int> psc;        // [d1 - d0 + 1][8] (one entry of padding), as PgDevJob::psc
+    std::vector<int> sched;      // as PgDevJob::sched
+};
+
 struct HostJob {
     const pagan_graph *L, *R;
     int Lx, Ly;
@@ -77,6 +84,7 @@ struct HostJob {
     std::vector<int> lead_req;   // dp_pipe.hip: per diagonal, what the downstream wave must have completed first
     std::vector<uint8_t> ring2;  // dp_pipe.hip: class 2 diagonals whose operands all lie in the ring
     std::vector<int> tiles;      // dp_tiles.hip (jobs that are not ring_ok): tile row, tile column of every tile that may hold a cell
+    std::vector<struct StripPlan> strips;   // dp_pipe.hip, row strips (jobs that are not ring_ok and qualify: plan_strips); empty otherwise
     int n_bound = 0;             // traceback boundaries (dp_device.h)
     std::vector<int> tb;         // [n_bound + 2] table offsets
 };
@@ -109,9 +117,11 @@ struct SiteFeat {
     std::vector<int> no_pred;         // prefix count of sites without bwd edges
     std::vector<int> not_easy;        // prefix count of sites the compute waves of dp_pipe.hip do not evaluate themselves: anything
                                       // but one edge from the previous site (any weight), alone or beside ONE edge from further back
-    void build(const pagan_graph *g, int n) {
+    // first_simple (row strips): site 0 passes for a simple site (dp_pipe.hip, load_rec_chunk)
+    void build(const pagan_graph *g, int n, bool first_simple = false) {
         span.assign(n, 0); span_ring.assign(n, 1); not_simple.assign(n + 1, 0); no_pred.assign(n + 1, 0); not_easy.assign(n + 1, 0);
         for (int s = 0; s < n; ++s) {
+            if (s == 0 && first_simple) continue;
             const int a = g->bwd_off[s], b = g->bwd_off[s + 1];
             int sp = 0, spr = 1;
             for (int k = a; k < b; ++k) {
@@ -261,6 +271,159 @@ void schedule_waves(const DiagIndex &dx, const std::vector<uint8_t> &cls, std::v
     for (int w = 0; w < 4; ++w) {
         (*out)[w] = (int)out->size();
         out->insert(out->end(), lists[w].begin(), lists[w].end());
+    }
+}
+
+// Row strips (dp_pipe.hip, strip_feeder): a wide job as a chain of banded jobs of PG_STRIP_ROWS rows each.  Per strip the
+// diagonal descriptors pg_fill_pipe<true, true> reads (rows of the strip on the diagonal, where its first score lives in the
+// PARENT's arrays, class, ring-residency mask, assist hop, ring-reuse rule) and the wave schedule.  Classes as in
+// classify_diagonals, with what is different about a strip:
+//   * a row stays for the whole sweep, so the rules that send the first / last two rows and columns to the general step would
+//     send every diagonal there.  What is special about those is less than the rule says: the gap states extend at the terminal
+//     rate in the first / last row (y-gap) and column (x-gap) -- the lanes' own rate for the rows, PG_STRIP_TERM diagonals
+//     (C++ step) for the columns --; M(0,0) = 0 meets a free gap-open only in the cells (i,0) / (0,j) whose site has an edge
+//     from site 0; site 0 itself has no edge and is computed as a simple site whose predecessors are -inf.  General steps
+//     (class 3): diagonals 0 and 1, the diagonals of those cells, sites without edges other than site 0;
+//   * operands up to 64 rows above the strip are in the ring (the feeder wave), which covers every operand in reach of the
+//     ring (PG_PIPE_REACH - 1 diagonals back); older ones come from L2 through the parent's descriptors.
+void plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, const RowBand &rb, const DiagIndex &dx,
+                 std::vector<StripPlan> *out) {
+    const int nd = Lx + Ly - 1, REACH = PG_PIPE_REACH, RING = PG_PIPE_RING;
+    SiteFeat fl, fr;
+    fl.build(L, Lx, true); fr.build(R, Ly, true);
+    std::vector<uint8_t> from0L(Lx, 0), from0R(Ly, 0);
+    for (int i = 1; i < Lx; ++i) for (int k = L->bwd_off[i]; k < L->bwd_off[i + 1]; ++k) if (L->bwd_src[k] == 0) from0L[i] = 1;
+    for (int j = 1; j < Ly; ++j) for (int k = R->bwd_off[j]; k < R->bwd_off[j + 1]; ++k) if (R->bwd_src[k] == 0) from0R[j] = 1;
+    // prefix counts: cells (i,0) / (0,j) that meet the free gap-open, sites without edges other than site 0
+    std::vector<int> npL(Lx + 1, 0), npR(Ly + 1, 0);
+    for (int i = 0; i < Lx; ++i) npL[i + 1] = npL[i] + (i > 0 && L->bwd_off[i + 1] == L->bwd_off[i] ? 1 : 0);
+    for (int j = 0; j < Ly; ++j) npR[j + 1] = npR[j] + (j > 0 && R->bwd_off[j + 1] == R->bwd_off[j] ? 1 : 0);
+    // columns by span: cols_ge[t] = columns with span >= t (ascending), t = 2 .. REACH-1
+    std::vector<std::vector<int>> cols_ge(REACH);
+    for (int j = 0; j < Ly; ++j) for (int t = 2; t < REACH && t <= fr.span[j]; ++t) cols_ge[t].push_back(j);
+    const int n_strips = (Lx + PG_STRIP_ROWS - 1) / PG_STRIP_ROWS;
+    out->assign(n_strips, StripPlan());
+    for (int k = 0; k < n_strips; ++k) {
+        StripPlan &sp = (*out)[k];
+        const int r0 = k * PG_STRIP_ROWS, r1 = std::min(r0 + PG_STRIP_ROWS - 1, Lx - 1);
+        sp.r0 = r0; sp.r1 = r1;
+        sp.feed_wave = k == 0 ? -1 : ((r0 / 64) + 3) & 3;
+        // the diagonals on which the strip holds a cell: row + lo[row] and row + hi[row] grow with the row
+        int dlo = nd, dhi = -1;
+        for (int i = r0; i <= r1; ++i) if (rb.hi[i] >= rb.lo[i]) { dlo = std::min(dlo, i + rb.lo[i]); dhi = std::max(dhi, i + rb.hi[i]); }
+        if (dhi < dlo) { dlo = std::min(nd - 1, r0); dhi = dlo; }        // (no cell at all: one empty diagonal keeps the chain of strips whole)
+        const int D0 = std::max(0, dlo - 16), D1 = std::min(nd, dhi + 17), m = D1 - D0;
+        sp.d0 = D0; sp.d1 = D1;
+        std::vector<int> smin(m), smax(m);
+        for (int t = 0; t < m; ++t) {
+            const int d = D0 + t;
+            smin[t] = std::max(r0, dx.imin[d]); smax[t] = std::min(r1, dx.imax[d]);
+            if (smax[t] < smin[t]) smax[t] = smin[t] - 1;
+        }
+        {   // first column the loader stages: the smallest column of the strip's first diagonals, rounded down to a chunk
+            int c0 = Ly;
+            for (int t = 0; t < m; ++t) if (smax[t] >= smin[t]) { c0 = D0 + t - smax[t]; break; }
+            c0 = std::max(0, std::min(c0, Ly - 1) - 16);
+            sp.col_first = c0 & ~63;
+        }
+        // ---- cells whose operands leave the ring (by age) ----
+        std::vector<int> far(m + 1, 0);
+        auto mark = [&](int a, int b) { a = std::max(a, D0); b = std::min(b, D1 - 1); if (a <= b) { ++far[a - D0]; --far[b + 1 - D0]; } };
+        for (int i = r0; i <= r1; ++i) {
+            if (rb.hi[i] < rb.lo[i]) continue;
+            const int sl = fl.span[i];
+            if (sl >= REACH - 1) { mark(i + rb.lo[i], i + rb.hi[i]); continue; }
+            if (sl < 2) continue;
+            const std::vector<int> &cl = cols_ge[REACH - sl];             // span(j) >= REACH - span(i)
+            for (auto it = std::lower_bound(cl.begin(), cl.end(), rb.lo[i]); it != cl.end() && *it <= rb.hi[i]; ++it) mark(i + *it, i + *it);
+        }
+        for (int j : cols_ge[REACH - 1]) {
+            // rows of the strip whose band holds column j: hi[] and lo[] are monotone
+            int i1 = (int)(std::lower_bound(rb.hi.begin(), rb.hi.end(), j) - rb.hi.begin());
+            int i2 = (int)(std::upper_bound(rb.lo.begin(), rb.lo.end(), j) - rb.lo.begin()) - 1;
+            i1 = std::max(i1, r0); i2 = std::min(i2, r1);
+            if (i1 <= i2) mark(i1 + j, i2 + j);
+        }
+        // ---- classes ----
+        std::vector<uint8_t> cls(m, 0), ring2(m, 0);
+        int run = 0;
+        for (int t = 0; t < m; ++t) {
+            run += far[t];
+            const int d = D0 + t, lo = smin[t], hi = smax[t];
+            if (hi < lo) { cls[t] = 0; continue; }
+            const int jlo = d - hi, jhi = d - lo;
+            bool general = d <= 1;
+            if (d >= lo && d <= hi && d < Lx && from0L[d]) general = true;                 // cell (d, 0), an edge from site 0
+            if (lo == 0 && d < Ly && from0R[d]) general = true;                            // cell (0, d)
+            if (npL[hi + 1] - npL[lo] > 0 || npR[jhi + 1] - npR[jlo] > 0) general = true;  // a site without bwd edges (not site 0)
+            const bool multi = fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[jhi + 1] - fr.not_simple[jlo] > 0;
+            const bool hard = fl.not_easy[hi + 1] - fl.not_easy[lo] > 0 || fr.not_easy[jhi + 1] - fr.not_easy[jlo] > 0;
+            uint8_t c;
+            if (general) c = 3;
+            else if (run > 0) c = 2;
+            else if (multi) c = hard ? 2 : 1;
+            else c = 0;
+            ring2[t] = c == 2 && run == 0;
+            const bool term = (d >= lo && d <= hi) || (d - (Ly - 1) >= lo && d - (Ly - 1) <= hi);      // a cell of column 0 / column Ly-1
+            if (c <= 2 && term) c |= PG_STRIP_TERM;
+            cls[t] = c;
+        }
+        // ---- ring reuse (classify_diagonals has the reasoning) ----
+        std::vector<int> need(m, REACH - 1);
+        {
+            std::vector<int> rowsL;
+            for (int i = r0; i <= r1; ++i) if (fl.span_ring[i] >= 2) rowsL.push_back(i);
+            size_t la = 0, lb = 0;
+            for (int t = 0; t < m; ++t) {
+                const int d = D0 + t, lo = smin[t], hi = smax[t];
+                if (hi < lo || (cls[t] & 7) > 2) continue;
+                while (lb < rowsL.size() && rowsL[lb] <= hi) ++lb;
+                while (la < lb && rowsL[la] < lo) ++la;
+                int mx = 2;
+                for (size_t q = la; q < lb; ++q) {
+                    const int i = rowsL[q];
+                    if (fl.span_ring[i] > (i & 63)) mx = std::max(mx, fl.span_ring[i] + fr.span_ring[d - i]);
+                }
+                for (int i = (lo + 63) & ~63; i <= hi; i += 64) mx = std::max(mx, fl.span_ring[i] + fr.span_ring[d - i]);
+                need[t] = std::min(mx, REACH - 1);
+            }
+        }
+        std::vector<int> lead(m, -1);
+        for (int D = D0 + RING; D < D1; ++D) {
+            int req = -1;
+            for (int t = D - RING + 1; t <= D - RING + REACH - 1 && t < D1; ++t)
+                if (t >= D0 && t - need[t - D0] <= D - RING) req = t;
+            lead[D - D0] = req;
+        }
+        // ---- the wave schedule (schedule_waves over the strip's own diagonals, shifted) ----
+        {
+            DiagIndex sdx;
+            sdx.imin = smin; sdx.imax = smax;
+            std::vector<uint8_t> c7(m);
+            for (int t = 0; t < m; ++t) c7[t] = cls[t] & 7;
+            schedule_waves(sdx, c7, &sp.sched);
+            for (size_t q = 4; q < sp.sched.size(); ++q) sp.sched[q] += D0;
+        }
+        // ---- descriptors ----
+        sp.psc.assign(8 * ((size_t)m + 1), 0);
+        std::vector<int> hop(m, 0);
+        for (int t = m; t-- > 0;) {
+            const int nx = t + PG_PIPE_ASSIST;
+            if (nx >= m) { hop[t] = 4095; continue; }
+            hop[t] = (cls[nx] & 7) == 2 ? 1 : std::min(4095, hop[nx] + 1);
+        }
+        unsigned mask = 0;
+        for (int t = 0; t < m; ++t) {
+            const int d = D0 + t;
+            int *pk = sp.psc.data() + 8 * (size_t)t;
+            pk[0] = smin[t]; pk[1] = smax[t];
+            const long long boff = 24 * (dx.doff[d] + (smin[t] - dx.imin[d]));
+            pk[2] = (int)(boff & 0xffffffffLL); pk[3] = (int)(boff >> 32);
+            mask = t >= 1 ? (((mask << 1) | 2u) & (((1u << REACH) - 1u) & ~1u)) : 0u;
+            pk[4] = (int)(cls[t] | ((ring2[t] ? 1u : 0u) << 4) | (mask << 5) | ((unsigned)hop[t] << 20));
+            pk[5] = 0; pk[6] = 0;
+            pk[7] = lead[t];
+        }
     }
 }
 
@@ -516,6 +679,10 @@ struct pagan_batch {
     PgDevJob *d_jobs = nullptr;
     int *d_which = nullptr;      // [n]: ring-kernel jobs first, then the ones of the HBM wavefront kernel
     int n_ring = 0, n_wide = 0, n_tiled = 0;
+    int n_striped = 0;           // of the n_tiled jobs (listed first among them): filled as row strips by pg_fill_pipe<true, true>
+    int strip_grid = 0;          // workgroups of that launch (the strips of a job at indices of one residue mod 8, -1 padding)
+    int *d_swhich = nullptr;     // [strip_grid] strip -> its PgDevJob (behind the n jobs of the batch) or -1
+    size_t sfollow_begin = 0, sfollow_bytes = 0;     // the strips' follow words (zeroed before every launch)
     int *d_tiles = nullptr;      // dp_tiles.hip: {job, tile row, tile column, position of the tile above} of all tiled jobs, ordered by
                                  // row + column; then the positions of the tiles to the left; then tile_off (pg_fill_tiles_flow)
     int *d_flow = nullptr;       // pg_fill_tiles_flow's queue head, finished tiles per diagonal, done flags (zeroed per launch)
@@ -621,6 +788,16 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
     }
     if (!hj->ring_ok && !neg0 && edges_fit_tiles(jb.left, hj->Lx) && edges_fit_tiles(jb.right, hj->Ly))
         list_tiles(hj->Lx, *rb, &hj->tiles);
+    // Row strips on the banded kernel (dp_pipe.hip, strip_feeder): a wide job whose model table fits LDS and whose edge lists
+    // fit the kernel's windows.  PAGAN_DP_WIDE=strips asks for them (A/B switch while the route is new).
+    {
+        const char *we = std::getenv("PAGAN_DP_WIDE");
+        const bool want = we && std::strcmp(we, "strips") == 0;
+        if (want && use_pipe && !hj->ring_ok && !neg0 && !hj->tiles.empty() && jb.model->n_states * jb.model->n_states <= 256 &&
+            hj->Lx >= 2 && hj->Ly >= 2 &&
+            edges_fit_ring(jb.left, hj->Lx, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES) && edges_fit_ring(jb.right, hj->Ly, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES))
+            plan_strips(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, &hj->strips);
+    }
     return PAGAN_OK;
 }
 
@@ -738,6 +915,17 @@ static int bp_diags_per_block(int max_nd, int other_dims) {
 int launch_fill(pagan_batch *b) {
     hipStream_t tile_stream = nullptr;
     static std::atomic<int> n_cu_dev[64];
+    bool ev3_recorded = false;
+    if (b->n_striped > 0 && b->tile_off.size() <= 1) {
+        // (the strips' stream: beside the banded kernels, as the tiles')
+        hipStream_t st = b->stream;
+        if (b->stream2) {
+            HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
+            HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
+            st = b->stream2;
+        }
+        tile_stream = st;
+    }
     if (b->tile_off.size() > 1) {
         static std::atomic<bool> tiles_set_dev[64];
         std::atomic<bool> &tiles_set = tiles_set_dev[b->device & 63];
@@ -785,10 +973,10 @@ int launch_fill(pagan_batch *b) {
             // (a dispatch of more than 32 jobs fills the chip by itself: pg_backptr afterwards, on every unit, is the faster pass)
             auto followers = [&](int n_fill) { return follow && n_fill <= 32 ? std::min(96, 48 * ((n_fill + 7) / 8)) : 0; };
             if (n_small > 0)
-                hipLaunchKernelGGL(pg_fill_pipe<true>, dim3(n_small + followers(n_small)), dim3(pg_pipe_block()), 0 /* its LDS is static */, b->stream,
+                hipLaunchKernelGGL((pg_fill_pipe<true, false>), dim3(n_small + followers(n_small)), dim3(pg_pipe_block()), 0 /* its LDS is static */, b->stream,
                                    b->d_jobs, b->d_which, b->flags, n_small);
             if (n_big > 0)
-                hipLaunchKernelGGL(pg_fill_pipe<false>, dim3(n_big + followers(n_big)), dim3(pg_pipe_block()), 0, b->stream,
+                hipLaunchKernelGGL((pg_fill_pipe<false, false>), dim3(n_big + followers(n_big)), dim3(pg_pipe_block()), 0, b->stream,
                                    b->d_jobs, b->d_which + n_small, b->flags, n_big);
             HIP_TRY(hipEventRecord(b->evk[1], b->stream)); b->evk_set[1] = true;
             if (b->bp_pass) {
@@ -819,10 +1007,17 @@ int launch_fill(pagan_batch *b) {
         }
         HIP_TRY(hipEventRecord(b->evk[5], b->stream)); b->evk_set[5] = true;
     }
+    if (b->n_striped > 0) {
+        // row strips of the wide jobs on the banded kernel: one workgroup per strip, a job's strips on one XCD
+        HIP_TRY(hipEventRecord(b->evk[3], tile_stream)); b->evk_set[3] = true; ev3_recorded = true;
+        HIP_TRY(hipMemsetAsync(b->arena.dev + b->sfollow_begin, 0, b->sfollow_bytes, tile_stream));
+        hipLaunchKernelGGL((pg_fill_pipe<true, true>), dim3(b->strip_grid), dim3(pg_pipe_block()), 0, tile_stream,
+                           b->d_jobs, b->d_swhich, b->flags, b->strip_grid);
+    }
     if (b->tile_off.size() > 1) {
         // after the banded kernels: their workgroups get compute units first; the persistent waves below hold theirs
         hipStream_t st = tile_stream;
-        HIP_TRY(hipEventRecord(b->evk[3], st)); b->evk_set[3] = true;
+        if (!ev3_recorded) { HIP_TRY(hipEventRecord(b->evk[3], st)); b->evk_set[3] = true; }
         if (b->tiles_flow) {
             // one persistent wave per compute unit (a tile fills the LDS) drains the batch's tiles in dependency order
             const int n_tiles = b->tile_off.back(), n_diag = (int)b->tile_off.size() - 1;
@@ -848,19 +1043,19 @@ int launch_fill(pagan_batch *b) {
             }
         }
     }
-    if (b->tile_off.size() > 1) {
+    if (b->tile_off.size() > 1 || b->n_striped > 0) {
         HIP_TRY(hipEventRecord(b->evk[4], tile_stream)); b->evk_set[4] = true;
-        // the tiled fill stores scores only: its jobs' back-pointers by the pass, behind it on the same stream
+        // the tiled fill (and the strips) store scores only: their jobs' back-pointers by the pass, behind them on the same stream
         if (b->n_tiled > 0) {
             int max_nd = 1, max_w = 1;
-            for (int k = 0; k < b->n; ++k) if (!b->jobs[k].ring_ok && !b->jobs[k].tiles.empty()) { max_nd = std::max(max_nd, b->dj[k].nd); max_w = std::max(max_w, b->jobs[k].dx.max_width); }
+            for (int k = 0; k < b->n; ++k) if (!b->jobs[k].ring_ok && (!b->jobs[k].tiles.empty() || !b->jobs[k].strips.empty())) { max_nd = std::max(max_nd, b->dj[k].nd); max_w = std::max(max_w, b->jobs[k].dx.max_width); }
             const int zc = (max_w + PG_BP_CELLS - 1) / PG_BP_CELLS, dpb = bp_diags_per_block(max_nd, b->n_tiled * zc);
             hipLaunchKernelGGL(pg_backptr, dim3((max_nd + dpb - 1) / dpb, b->n_tiled, zc), dim3(256), 0, tile_stream,
                                b->d_jobs, b->d_which + b->n_ring + b->n_wide, b->flags & 0xffu, dpb);
             HIP_TRY(hipEventRecord(b->evk[6], tile_stream)); b->evk_set[6] = true;
         }
     }
-    if (b->tile_off.size() > 1 && b->stream2) {
+    if ((b->tile_off.size() > 1 || b->n_striped > 0) && b->stream2) {
         HIP_TRY(hipEventRecord(b->ev_join, b->stream2));
         HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
     }
@@ -1057,6 +1252,7 @@ int pagan_dp_debug_route(const pagan_graph *left, const pagan_graph *right, cons
     const char *wide_env = std::getenv("PAGAN_DP_WIDE");
     const bool use_tiles = !std::getenv("PAGAN_DP_FORCE_GLOBAL_WAVEFRONT") && !(wide_env && std::strcmp(wide_env, "wavefront") == 0);
     if (hj.ring_ok && !std::getenv("PAGAN_DP_FORCE_GLOBAL_WAVEFRONT")) return eff.model->n_states <= 16 ? 0 : 1;
+    if (use_tiles && !hj.strips.empty()) return 4;
     if (use_tiles && !hj.tiles.empty()) return 2;
     return 3;
 }
@@ -1181,7 +1377,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     // A/B switch: PAGAN_DP_WIDE=wavefront sends the wide jobs to the one-workgroup HBM wavefront instead of the tiles
     const char *wide_env = std::getenv("PAGAN_DP_WIDE");
     const bool use_tiles = !force_v1 && !(wide_env && std::strcmp(wide_env, "wavefront") == 0);
-    std::vector<int> which_ring, which_ring_big, which_wide, which_tiled;
+    std::vector<int> which_ring, which_ring_big, which_wide, which_tiled, which_striped;
     std::vector<int> job_rc(n, PAGAN_OK);
     const bool verbose = std::getenv("PAGAN_DP_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1209,6 +1405,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             (eff[k].model->n_states <= 16 ? which_ring : which_ring_big).push_back(k);
             continue;
         }
+        if (use_tiles && !b->jobs[k].ring_ok && !b->jobs[k].strips.empty()) { which_striped.push_back(k); continue; }
         if (use_tiles && !b->jobs[k].ring_ok && !b->jobs[k].tiles.empty()) { which_tiled.push_back(k); continue; }
         which_wide.push_back(k);
         if (b->jobs[k].dx.max_width > max_w) max_w = b->jobs[k].dx.max_width;
@@ -1269,16 +1466,42 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     which_ring.insert(which_ring.end(), which_ring_big.begin(), which_ring_big.end());
     b->n_ring = (int)which_ring.size(); b->n_wide = (int)which_wide.size();
     which_ring.insert(which_ring.end(), which_wide.begin(), which_wide.end());
-    b->n_tiled = (int)which_tiled.size();
+    b->n_striped = (int)which_striped.size();
+    b->n_tiled = (int)which_striped.size() + (int)which_tiled.size();
+    which_ring.insert(which_ring.end(), which_striped.begin(), which_striped.end());  // (striped and tiled jobs: one back-pointer pass behind both fills)
     which_ring.insert(which_ring.end(), which_tiled.begin(), which_tiled.end());     // (the tiled fill reaches its jobs through the tile list; pg_backptr through this)
+    // Row strips: every strip a device job of its own behind the batch's n; the strips of a job at workgroup indices of one
+    // residue mod 8 (one XCD: a strip reads what the strip above stored from that XCD's L2), in order
+    struct StripDev { int job, q; int *psc, *sched, *follow; };
+    std::vector<StripDev> sdev;
+    std::vector<int> swhich;
+    {
+        int lane_len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t sj = 0; sj < which_striped.size(); ++sj) {
+            const int k = which_striped[sj], lane = (int)(sj % 8);
+            for (size_t q = 0; q < b->jobs[k].strips.size(); ++q) {
+                const size_t at = 8 * (size_t)lane_len[lane]++ + lane;
+                if (swhich.size() <= at) swhich.resize((at / 8 + 1) * 8, -1);
+                swhich[at] = n + (int)sdev.size();
+                sdev.push_back({k, (int)q, nullptr, nullptr, nullptr});
+            }
+        }
+        b->strip_grid = (int)swhich.size();
+        b->dj.resize((size_t)n + sdev.size());
+    }
     which_ring.resize(n, 0);
     b->block = max_w <= 64 ? 64 : (max_w <= 512 ? 256 : 1024);
 
     const double tc1 = now();
     // pass 1: sizes.  Inputs first (one contiguous upload), outputs after.
     Carver sizer;
-    PgDevJob *jobs_off = sizer.take<PgDevJob>(n);
+    PgDevJob *jobs_off = sizer.take<PgDevJob>((size_t)n + sdev.size());
     int *which_off = sizer.take<int>(n);
+    int *swhich_off = sizer.take<int>(swhich.size());
+    for (StripDev &sd : sdev) {
+        const StripPlan &sp = b->jobs[sd.job].strips[sd.q];
+        sd.psc = sizer.take<int>(sp.psc.size()); sd.sched = sizer.take<int>(sp.sched.size());
+    }
     int *tiles_off = sizer.take<int>(tile_list.size());
     int *flow_off = sizer.take<int>(b->flow_ints);
     for (int k = 0; k < n; ++k) carve_job(sizer, eff[k], b->jobs[k], &b->dj[k]);
@@ -1287,6 +1510,9 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     for (int k = 0; k < n; ++k) carve_outputs(sizer, b->jobs[k], &b->dj[k]);
     carve_ends(sizer, n, b->dj.data());
     carve_follow(sizer, n, b->jobs, b->dj.data(), &b->follow_begin, &b->follow_bytes);
+    b->sfollow_begin = sizer.cur;
+    for (StripDev &sd : sdev) sd.follow = sizer.take<int>(4);
+    b->sfollow_bytes = sizer.cur - b->sfollow_begin;
     b->arena.size = sizer.cur;
     b->arena.dev = arena_pool.take(b->device, b->arena.size, &b->arena.cap);
     if (!b->arena.dev) {
@@ -1357,6 +1583,11 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         const int zero = 0;
         put(stage, d.fill_status, &zero, 1);          // the staging buffer is reused, not zeroed
     });
+    parallel_jobs((int)sdev.size(), [&](int g) {
+        const StripPlan &sp = b->jobs[sdev[g].job].strips[sdev[g].q];
+        put(stage, sdev[g].psc, sp.psc.data(), sp.psc.size());
+        put(stage, sdev[g].sched, sp.sched.data(), sp.sched.size());
+    });
     const double tc3 = now();
     b->trace_off.resize(n); b->end_off.resize(n); b->score_off.resize(n);
     char *base = b->arena.dev;
@@ -1373,8 +1604,29 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         rebase(d.trace); rebase(d.endcell); rebase(d.endscore); rebase(d.segs); rebase(d.ttab);
         if (d.follow) { rebase(d.follow); rebase(d.bp_done); }
     }
-    std::memcpy(stage.data() + reinterpret_cast<size_t>(jobs_off), b->dj.data(), sizeof(PgDevJob) * n);
+    for (size_t g = 0; g < sdev.size(); ++g) {
+        // a strip: the parent's job with its own descriptors (the pointer moved back so that psc[d] works from d_first on),
+        // schedule and follow words
+        const StripPlan &sp = b->jobs[sdev[g].job].strips[sdev[g].q];
+        PgDevJob d = b->dj[sdev[g].job];
+        d.psc = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(sdev[g].psc)) - 8 * (ptrdiff_t)sp.d0;
+        d.sched = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(sdev[g].sched));
+        d.follow = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(sdev[g].follow));
+        d.bp_done = nullptr;
+        d.nd = sp.d1;
+        d.is_strip = 1; d.strip_row0 = sp.r0; d.d_first = sp.d0; d.feed_wave = sp.feed_wave; d.col_first = sp.col_first;
+        d.pdsc = b->dj[sdev[g].job].dsc;
+        d.prev_follow = nullptr; d.prev_nd = 0;
+        if (sdev[g].q > 0) {                                      // (the strip above is the entry before: a job's strips are listed in order)
+            d.prev_follow = b->dj[(size_t)n + g - 1].follow;
+            d.prev_nd = b->dj[(size_t)n + g - 1].nd;
+        }
+        b->dj[(size_t)n + g] = d;
+    }
+    std::memcpy(stage.data() + reinterpret_cast<size_t>(jobs_off), b->dj.data(), sizeof(PgDevJob) * b->dj.size());
     std::memcpy(stage.data() + reinterpret_cast<size_t>(which_off), which_ring.data(), sizeof(int) * n);
+    if (!swhich.empty()) std::memcpy(stage.data() + reinterpret_cast<size_t>(swhich_off), swhich.data(), sizeof(int) * swhich.size());
+    b->d_swhich = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(swhich_off));
     b->d_jobs = reinterpret_cast<PgDevJob *>(base + reinterpret_cast<size_t>(jobs_off));
     b->d_which = reinterpret_cast<int *>(base + reinterpret_cast<size_t>(which_off));
     if (!tile_list.empty()) std::memcpy(stage.data() + reinterpret_cast<size_t>(tiles_off), tile_list.data(), sizeof(int) * tile_list.size());
@@ -1395,7 +1647,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         b->stream = o.stream; b->pooled_stream2 = o.stream2; b->pooled_fork = o.ev_fork; b->pooled_join = o.ev_join;
         for (int k = 0; k < 3; ++k) b->ev[k] = o.ev[k];
         for (int k = 0; k < 7; ++k) b->evk[k] = o.evk[k];
-        if (!which_tiled.empty() && b->n_ring + b->n_wide > 0) { b->stream2 = o.stream2; b->ev_fork = o.ev_fork; b->ev_join = o.ev_join; }
+        if (b->n_tiled > 0 && b->n_ring + b->n_wide > 0) { b->stream2 = o.stream2; b->ev_fork = o.ev_fork; b->ev_join = o.ev_join; }
     }
     HIP_TRY(hipMemcpyAsync(base, stage.data(), in_bytes, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));

@@ -96,4 +96,17 @@ struct PgDevJob {
     int *follow;             // [4]: diagonals whose scores have landed in L2 + 1, the fill workgroup's XCC id + 1, next
                              //      chunk of PG_FOLLOW_CHUNK diagonals to claim, pad
     unsigned char *bp_done;  // [ceil(nd / PG_FOLLOW_CHUNK)] 1: the chunk's back-pointers are written (pg_backptr skips it)
+    // Row strips of a wide job on the banded kernel (dp_pipe.hip, pg_fill_pipe<true, true>).  A strip is a
+    // job of its own -- PG_STRIP_ROWS rows of the parent's matrix, its own diagonal descriptors (psc, indexed from d_first: the
+    // pointer is moved back so that psc[d] works), schedule and follow words -- that shares the parent's graphs and output arrays.
+    int is_strip;            // 0: not a strip (every field below is then 0 / null)
+    int strip_row0;          // first row of the strip
+    int d_first;             // first diagonal the strip's waves look at (descriptors exist from here to nd)
+    int feed_wave;           // the compute wave that has no rows of the strip and feeds the 64 rows above it into the ring; -1: none (first strip)
+    int col_first;           // first right-graph site whose record the loader stages (a multiple of 64)
+    int prev_nd;             // the previous strip's nd (its last diagonal + 1): what its landed counter ends at
+    const int *prev_follow;  // the previous strip's follow words (null: first strip)
+    const int *pdsc;         // the PARENT's dsc array: the whole band's rows per diagonal, for operands in other strips
 };
+#define PG_STRIP_ROWS 192        // rows of a strip: three of dp_pipe.hip's four compute waves (the fourth feeds the rows above)
+#define PG_STRIP_TERM 8          // psc class bit of a strip diagonal that holds a cell of the first / last column (gap extension differs)

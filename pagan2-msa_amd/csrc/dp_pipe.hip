@@ -98,6 +98,7 @@ struct PipeSmem {
     unsigned spx[PST][PNT], spy[PST][PNT], spm[PST][PNT];
     int assist_done[PNA];        // last diagonal each assist wave has staged
     int as_list[PNA][64];        // rows of the multi-edge cells of the diagonal an assist wave is working on, compacted
+    const int *pdsc;             // row strips: the parent job's dsc array (null otherwise): far_ask's view of the whole band
 };
 
 static_assert(sizeof(PipeSmem) <= 160 * 1024, "PipeSmem has to fit the 160 KB of LDS of a gfx950 compute unit");
@@ -177,7 +178,7 @@ __device__ __forceinline__ double dpp_shr1(double v, double lane0) {
 
 // ---- loader wave -------------------------------------------------------------------------
 template <bool LEFT>
-__device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_p st, gint_p off, gint_p src, gfloat_p lw) {
+__device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_p st, gint_p off, gint_p src, gfloat_p lw, bool strip) {
     pg_i4 *rec = LEFT ? PM.recL : PM.recR;
     int *eb = LEFT ? PM.ebL : PM.ebR;
     int *es = LEFT ? PM.esL : PM.esR;
@@ -208,12 +209,19 @@ __device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_
         int span = d0 > d1 ? d0 : d1;
         for (int e = b + 2; e < en && e < b + 16; ++e) { const int sp = r - src[e]; span = sp > span ? sp : span; }
         if (r > 0 && ne == 1 && d0 == 1 && w0 == 0.0f) w |= PR_SIMPLE;
+
         if (ne > 16 || span > 255) span = 255;
         w |= (ne < 127 ? ne : 127) << PR_NE_SHIFT;
         w |= span << PR_SPAN_SHIFT;
         pg_i4 v;
         v.x = w; v.y = (d0 < 65535 ? d0 : 65535) | ((d1 < 65535 ? d1 : 65535) << 16);
         v.z = __float_as_int(w0); v.w = __float_as_int(w1);
+        // row strips: the first site (no bwd edge) is recorded as a SIMPLE one -- one edge of weight 1 from a site before it.
+        // Whatever a cell of row 0 (column 0) reads of the row (column) before it is -inf (a ring column no wave writes, a lane
+        // outside the band, a row outside the band for far_ask), which is what the general rules give its X and M (Y and M);
+        // its y-gap (x-gap) chain is the straight code's at the terminal rate; the diagonals 0 and 1 and the cells that meet
+        // M(0,0) through an edge from site 0 are general steps (dp_abi.hip, plan_strips), and those read no record of site 0.
+        if (strip && r == 0) { v.x = (w & 0xffff) | PR_SIMPLE | (1 << PR_NE_SHIFT) | (1 << PR_SPAN_SHIFT); v.y = 1; v.z = 0; v.w = 0; }
         rec[r & (PRW - 1)] = v;
         eb[r & (PRW - 1)] = b;
     }
@@ -229,8 +237,18 @@ __device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_
 __device__ __forceinline__ void publish_landed(PG_GLOBAL int *follow, int lane, int landed) {
     if (follow && lane == 0) asm volatile("global_store_dword %0, %1, off" :: "v"(follow), "v"(landed + 1) : "memory");
 }
-__device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lane, PG_GLOBAL int *follow) {
+// Row strips (`strip`: the PgDevJob, null otherwise): records from the strip's first halo row / first column on, the
+// descriptor window from the PARENT's array (whole-band rows per diagonal, offsets in cells there), everything from d_first.
+__device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lane, PG_GLOBAL int *follow, const PgDevJob *strip) {
     int rows = 0, cols = 0, diags = 0, published = -1;
+    PG_GLOBAL const pg_i4 *pdsc = nullptr;
+    if (strip) {
+        rows = strip->strip_row0 >= 64 ? strip->strip_row0 - 64 : 0;
+        cols = strip->col_first;
+        diags = strip->d_first >= 64 ? strip->d_first - 64 : 0;
+        published = strip->d_first - 1;
+        pdsc = (PG_GLOBAL const pg_i4 *)strip->pdsc;
+    }
     for (;;) {
         int pmin = flag_load(&PM.progress[0]);
         for (int w = 1; w < PNW; ++w) { const int p = flag_load(&PM.progress[w]); pmin = p < pmin ? p : pmin; }
@@ -259,7 +277,12 @@ __device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lan
             while (diags <= da) {
                 const int t = diags + lane;
                 if (t <= da) {
-                    const pg_i4 v = *((PG_GLOBAL const pg_i4 *)psc + 2 * t);
+                    pg_i4 v;
+                    if (pdsc) {
+                        v = pdsc[t];
+                        const long long bo = 24ll * (((long long)v.w << 32) | (unsigned)v.z);
+                        v.z = (int)(bo & 0xffffffffLL); v.w = (int)(bo >> 32);
+                    } else v = *((PG_GLOBAL const pg_i4 *)psc + 2 * t);
                     PM.dring[t & (PDR - 1)] = v;
                 }
                 diags = diags + 64 < da + 1 ? diags + 64 : da + 1;
@@ -268,12 +291,12 @@ __device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lan
             any = true;
         }
         if (rows < want_rows) {
-            load_rec_chunk<true>(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL);
+            load_rec_chunk<true>(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL, strip != nullptr);
             rows += 64; any = true;
             flag_store(&PM.loaded[0], rows);
         }
         if (cols < want_cols) {
-            load_rec_chunk<false>(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR);
+            load_rec_chunk<false>(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR, strip != nullptr);
             cols += 64; any = true;
             flag_store(&PM.loaded[1], cols);
         }
@@ -346,7 +369,12 @@ __device__ __forceinline__ FarAsk far_ask(cdesc8_p psc, int d, int age, int p) {
     const int dd = d - age;
     pg_i4 ds;
     if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
-    else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
+    else if (const int *pd = PM.pdsc) {
+        // a row strip: the strip's own descriptors hold its rows only; an operand may lie in a strip above (same arrays)
+        ds = far_desc((PG_GLOBAL const pg_i4 *)pd + dd);
+        const long long bo = 24ll * (((long long)ds.w << 32) | (unsigned)ds.z);
+        ds.z = (int)(bo & 0xffffffffLL); ds.w = (int)(bo >> 32);
+    } else ds = far_desc((PG_GLOBAL const pg_i4 *)psc + 2 * dd);
     FarAsk f;
     f.need = p >= ds.x && p <= ds.y;
     f.boff = (((long long)ds.w << 32) | (unsigned)ds.z) + 24ll * (p - ds.x);
@@ -405,7 +433,7 @@ __device__ __forceinline__ void old_cells3(gdouble_w sc, cdesc8_p psc, int d, in
 // edges, sites without edges); assist1_cell / assist2_cell are its straight-line special cases.
 template <bool FAR>
 __device__ __forceinline__ void assist_cell(gdouble_w sc, cdesc8_p psc, int d, int slot, unsigned resmask, const pg_i4 &rL,
-                                            const pg_i4 &cR, int row, int j, bool reduced_terminal, double go, double ge,
+                                            const pg_i4 &cR, int row, int j, bool reduced_terminal, double go, double gex, double gey,
                                             double ng, double tM, double tX, double &ex, double &ey, double &em,
                                             unsigned &px, unsigned &py, unsigned &pm) {
     const double NI = neg_inf();
@@ -426,14 +454,14 @@ __device__ __forceinline__ void assist_cell(gdouble_w sc, cdesc8_p psc, int d, i
         if (do_x) {                                                   // X candidates of left edge k1
             const double open = (reduced_terminal && row == dL) ? 0.0 : go;
             const unsigned w = pack_bp(0, k1, 0, false, false);
-            c = v[0][0] + ge;            if (c > ex) { ex = c; px = w | PG_X; winL = k1; }
+            c = v[0][0] + gex;            if (c > ex) { ex = c; px = w | PG_X; winL = k1; }
             c = (v[0][1] + 0.0) + go;    if (c > ex) { ex = c; px = w | PG_Y; winL = k1; }
             c = (v[0][2] + ng) + open;   if (c > ex) { ex = c; px = w | PG_M; winL = k1; }
         }
         if (do_y) {                                                   // Y candidates of right edge k2
             const double open = (reduced_terminal && j == dR) ? 0.0 : go;
             const unsigned w = pack_bp(0, 0, k2, false, false);
-            c = v[1][1] + ge;            if (c > ey) { ey = c; py = w | PG_Y; winR = k2; }
+            c = v[1][1] + gey;            if (c > ey) { ey = c; py = w | PG_Y; winR = k2; }
             c = (v[1][0] + 0.0) + go;    if (c > ey) { ey = c; py = w | PG_X; winR = k2; }
             c = (v[1][2] + ng) + open;   if (c > ey) { ey = c; py = w | PG_M; winR = k2; }
         }
@@ -470,7 +498,7 @@ __device__ __forceinline__ void cand(double c, unsigned f, double &best, unsigne
 template <bool FAR>
 __device__ __forceinline__ void multi2_cell(gdouble_w sc, cdesc8_p psc, int d, unsigned resmask, int slot, const pg_i4 &rL,
                                             const pg_i4 &cR, int row, int j, bool reduced_terminal,
-                                            double go, double ge, double ng, double tM, double tX, double &bx, double &by,
+                                            double go, double gex, double gey, double ng, double tM, double tX, double &bx, double &by,
                                             double &bm, unsigned &px, unsigned &py, unsigned &pm) {
     const double NI = neg_inf();
     const bool l1 = ((rL.x >> PR_NE_SHIFT) & 127) > 1, r1 = ((cR.x >> PR_NE_SHIFT) & 127) > 1;
@@ -532,15 +560,15 @@ __device__ __forceinline__ void multi2_cell(gdouble_w sc, cdesc8_p psc, int d, u
     {   // X: gap in the right sequence, candidates per left edge (VA:898-915)
         // (a class 1 diagonal lies PAGE rows and columns inside the matrix: no edge in reach starts at site 0)
         const double o0 = (FAR && reduced_terminal && row == dL0) ? 0.0 : go, o1 = (FAR && reduced_terminal && row == dL1) ? 0.0 : go;
-        cand(xa_x + ge, aL0 | PG_X, bx, px); cand((xa_y + 0.0) + go, aL0 | PG_Y, bx, px); cand((xa_m + ng) + o0, aL0 | PG_M, bx, px);
+        cand(xa_x + gex, aL0 | PG_X, bx, px); cand((xa_y + 0.0) + go, aL0 | PG_Y, bx, px); cand((xa_m + ng) + o0, aL0 | PG_M, bx, px);
         const unsigned w1 = aL1 | (1u << 4);
-        cand(xb_x + ge, w1 | PG_X, bx, px); cand((xb_y + 0.0) + go, w1 | PG_Y, bx, px); cand((xb_m + ng) + o1, w1 | PG_M, bx, px);
+        cand(xb_x + gex, w1 | PG_X, bx, px); cand((xb_y + 0.0) + go, w1 | PG_Y, bx, px); cand((xb_m + ng) + o1, w1 | PG_M, bx, px);
     }
     {   // Y: gap in the left sequence, candidates per right edge (VA:927-944)
         const double o0 = (FAR && reduced_terminal && j == dR0) ? 0.0 : go, o1 = (FAR && reduced_terminal && j == dR1) ? 0.0 : go;
-        cand(ya_y + ge, aR0 | PG_Y, by, py); cand((ya_x + 0.0) + go, aR0 | PG_X, by, py); cand((ya_m + ng) + o0, aR0 | PG_M, by, py);
+        cand(ya_y + gey, aR0 | PG_Y, by, py); cand((ya_x + 0.0) + go, aR0 | PG_X, by, py); cand((ya_m + ng) + o0, aR0 | PG_M, by, py);
         const unsigned w1 = aR1 | (1u << 18);
-        cand(yb_y + ge, w1 | PG_Y, by, py); cand((yb_x + 0.0) + go, w1 | PG_X, by, py); cand((yb_m + ng) + o1, w1 | PG_M, by, py);
+        cand(yb_y + gey, w1 | PG_Y, by, py); cand((yb_x + 0.0) + go, w1 | PG_X, by, py); cand((yb_m + ng) + o1, w1 | PG_M, by, py);
     }
     {   // M: (left edge, right edge) pairs row-major (VA:1396-1433)
         unsigned w = aL0 | aR0;
@@ -649,7 +677,7 @@ __device__ __attribute__((noinline)) void widest_step(const PgDevJob *job, cdesc
 // edge exactly when that edge is the SECOND one.
 template <bool FAR>
 __device__ __forceinline__ void assist2_cell(gdouble_w sc, cdesc8_p psc, int d, unsigned resmask, int slot, const pg_i4 &rL,
-                                             const pg_i4 &cR, int row, int j, bool reduced_terminal, double go, double ge,
+                                             const pg_i4 &cR, int row, int j, bool reduced_terminal, double go, double gex, double gey,
                                              double ng, double tM, double tX, double &ex, double &ey, double &em,
                                              unsigned &px, unsigned &py, unsigned &pm) {
     const double NI = neg_inf();
@@ -710,15 +738,15 @@ __device__ __forceinline__ void assist2_cell(gdouble_w sc, cdesc8_p psc, int d, 
     ex = NI; ey = NI; em = NI; px = PG_BP_NONE; py = PG_BP_NONE; pm = PG_BP_NONE;
     {   // X: the left edges that do not start at the previous site (VA:898-915); an edge in reach may start at site 0 (class 2)
         const double o0 = (FAR && reduced_terminal && row == dL0) ? 0.0 : go, o1 = (FAR && reduced_terminal && row == dL1) ? 0.0 : go;
-        cand(xa_x + ge, PG_X, ex, px); cand((xa_y + 0.0) + go, PG_Y, ex, px); cand((xa_m + ng) + o0, PG_M, ex, px);
+        cand(xa_x + gex, PG_X, ex, px); cand((xa_y + 0.0) + go, PG_Y, ex, px); cand((xa_m + ng) + o0, PG_M, ex, px);
         const unsigned w1 = 1u << 4;
-        cand(xb_x + ge, w1 | PG_X, ex, px); cand((xb_y + 0.0) + go, w1 | PG_Y, ex, px); cand((xb_m + ng) + o1, w1 | PG_M, ex, px);
+        cand(xb_x + gex, w1 | PG_X, ex, px); cand((xb_y + 0.0) + go, w1 | PG_Y, ex, px); cand((xb_m + ng) + o1, w1 | PG_M, ex, px);
     }
     {   // Y: the same for the right edges (VA:927-944)
         const double o0 = (FAR && reduced_terminal && j == dR0) ? 0.0 : go, o1 = (FAR && reduced_terminal && j == dR1) ? 0.0 : go;
-        cand(ya_y + ge, PG_Y, ey, py); cand((ya_x + 0.0) + go, PG_X, ey, py); cand((ya_m + ng) + o0, PG_M, ey, py);
+        cand(ya_y + gey, PG_Y, ey, py); cand((ya_x + 0.0) + go, PG_X, ey, py); cand((ya_m + ng) + o0, PG_M, ey, py);
         const unsigned w1 = 1u << 18;
-        cand(yb_y + ge, w1 | PG_Y, ey, py); cand((yb_x + 0.0) + go, w1 | PG_X, ey, py); cand((yb_m + ng) + o1, w1 | PG_M, ey, py);
+        cand(yb_y + gey, w1 | PG_Y, ey, py); cand((yb_x + 0.0) + go, w1 | PG_X, ey, py); cand((yb_m + ng) + o1, w1 | PG_M, ey, py);
     }
     {   // M: (left edge, right edge) pairs row-major (VA:1396-1433)
         unsigned w = aL0 | aR0;
@@ -750,11 +778,12 @@ __device__ __forceinline__ void assist2_cell(gdouble_w sc, cdesc8_p psc, int d, 
 // edge (it comes from the LDS edge window, the first two travel in the site record).
 template <bool FAR, bool THREE>
 __device__ __forceinline__ void assist1_cell(gdouble_w sc, cdesc8_p psc, int d, unsigned resmask, int slot, const pg_i4 &rL,
-                                             const pg_i4 &cR, int row, int j, bool reduced_terminal, double go, double ge,
+                                             const pg_i4 &cR, int row, int j, bool reduced_terminal, double go, double gex, double gey,
                                              double ng, double tM, double tX, double &eg, double &em, unsigned &pg,
                                              unsigned &pm, bool &left) {
     const double NI = neg_inf();
     left = !(rL.x & PR_SIMPLE);                             // the multi-edge site is the left one
+    const double gs = left ? gex : gey;                     // the gap state's extension rate (X: by column, Y: by row)
     const pg_i4 m = left ? rL : cR;
     const int site = left ? row : j;
     const int ne = (m.x >> PR_NE_SHIFT) & 127;
@@ -825,11 +854,11 @@ __device__ __forceinline__ void assist1_cell(gdouble_w sc, cdesc8_p psc, int d, 
     {   // the multi-edge side's gap state: per edge own state, the other gap state, M (VA:898-915 / 927-944)
         eg = NI; pg = PG_BP_NONE;
         const double s0 = left ? a0x : a0y, c0 = left ? a0y : a0x, s1 = left ? a1x : a1y, c1 = left ? a1y : a1x;
-        cand(s0 + ge, self, eg, pg); cand(c0 + go, cross, eg, pg); cand((a0m + ng) + o0, PG_M, eg, pg);
-        cand(s1 + ge, kk | self, eg, pg); cand(c1 + go, kk | cross, eg, pg); cand((a1m + ng) + o1, kk | PG_M, eg, pg);
+        cand(s0 + gs, self, eg, pg); cand(c0 + go, cross, eg, pg); cand((a0m + ng) + o0, PG_M, eg, pg);
+        cand(s1 + gs, kk | self, eg, pg); cand(c1 + go, kk | cross, eg, pg); cand((a1m + ng) + o1, kk | PG_M, eg, pg);
         if (THREE) {
             const double s2 = left ? a2x : a2y, c2 = left ? a2y : a2x;
-            cand(s2 + ge, 2 * kk | self, eg, pg); cand(c2 + go, 2 * kk | cross, eg, pg); cand((a2m + ng) + o2, 2 * kk | PG_M, eg, pg);
+            cand(s2 + gs, 2 * kk | self, eg, pg); cand(c2 + go, 2 * kk | cross, eg, pg); cand((a2m + ng) + o2, 2 * kk | PG_M, eg, pg);
         }
     }
     {   // M: the (left edge, right edge) pairs in list order (VA:1396-1433)
@@ -874,6 +903,11 @@ struct AssistGen {
     double go, ge, ng, tng2, tng1;
     int S, lane;
     bool reduced_terminal;
+    // row strips: a cell of the first / last column (row) extends its x-gap (y-gap) state at the terminal rate; nowhere else
+    // does a cell of those reach this code (term_on = false)
+    double gE;
+    int Lx, Ly;
+    bool term_on;
     // classification of one multi-edge cell: 1 one multi-edge site with <= 2 edges, 2 ... with 3, 3 two multi-edge sites
     // with <= 2 edges each, 4 anything else
     __device__ __forceinline__ int classify(const pg_i4 &rL, const pg_i4 &cR) const {
@@ -888,6 +922,7 @@ struct AssistGen {
     __device__ __forceinline__ void compute(int d, int cls, unsigned resmask, bool on, int row, int j, int kind, const pg_i4 &rL, const pg_i4 &cR,
                                             double tM, double tX) const {
         const int slot = d % PRK, stg = d % PST, at = row & (PNT - 1);
+        const double gxc = (term_on && (j == 0 || j == Ly - 1)) ? gE : ge, gyc = (term_on && (row == 0 || row == Lx - 1)) ? gE : ge;
         if (__builtin_amdgcn_ballot_w64(on && kind >= 3) == 0) {
             // the usual batch: one multi-edge site per cell
             double eg = 0, em = 0;
@@ -896,11 +931,11 @@ struct AssistGen {
             const bool three = __builtin_amdgcn_ballot_w64(on && kind == 2) != 0;
             if (on) {
                 if (cls == 2) {
-                    if (three) assist1_cell<true, true>(sc_out, psc, d, resmask, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, eg, em, pg, pm, left);
-                    else assist1_cell<true, false>(sc_out, psc, d, resmask, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, eg, em, pg, pm, left);
+                    if (three) assist1_cell<true, true>(sc_out, psc, d, resmask, slot, rL, cR, row, j, reduced_terminal, go, gxc, gyc, ng, tM, tX, eg, em, pg, pm, left);
+                    else assist1_cell<true, false>(sc_out, psc, d, resmask, slot, rL, cR, row, j, reduced_terminal, go, gxc, gyc, ng, tM, tX, eg, em, pg, pm, left);
                 } else {
-                    if (three) assist1_cell<false, true>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, eg, em, pg, pm, left);
-                    else assist1_cell<false, false>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, eg, em, pg, pm, left);
+                    if (three) assist1_cell<false, true>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, gxc, gyc, ng, tM, tX, eg, em, pg, pm, left);
+                    else assist1_cell<false, false>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, gxc, gyc, ng, tM, tX, eg, em, pg, pm, left);
                 }
                 if (left) { PM.sx[stg][at] = eg; PM.spx[stg][at] = pg; } else { PM.sy[stg][at] = eg; PM.spy[stg][at] = pg; }
                 PM.sM[stg][at] = em;
@@ -910,18 +945,18 @@ struct AssistGen {
             double ex, ey, em;
             unsigned px, py, pm;
             if (kind == 4) {
-                if (cls == 2) assist_cell<true>(sc_out, psc, d, slot, resmask, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, ex, ey, em, px, py, pm);
-                else assist_cell<false>(sc_out, psc, d, slot, 0u, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, ex, ey, em, px, py, pm);
+                if (cls == 2) assist_cell<true>(sc_out, psc, d, slot, resmask, rL, cR, row, j, reduced_terminal, go, gxc, gyc, ng, tM, tX, ex, ey, em, px, py, pm);
+                else assist_cell<false>(sc_out, psc, d, slot, 0u, rL, cR, row, j, reduced_terminal, go, gxc, gyc, ng, tM, tX, ex, ey, em, px, py, pm);
             } else if (kind == 2) {
                 bool left;
                 double eg;
                 unsigned pg;
-                if (cls == 2) assist1_cell<true, true>(sc_out, psc, d, resmask, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, eg, em, pg, pm, left);
-                else assist1_cell<false, true>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, eg, em, pg, pm, left);
+                if (cls == 2) assist1_cell<true, true>(sc_out, psc, d, resmask, slot, rL, cR, row, j, reduced_terminal, go, gxc, gyc, ng, tM, tX, eg, em, pg, pm, left);
+                else assist1_cell<false, true>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, gxc, gyc, ng, tM, tX, eg, em, pg, pm, left);
                 ex = ey = eg; px = py = pg;                        // the compute wave reads the multi-edge side's only
             } else {
-                if (cls == 2) assist2_cell<true>(sc_out, psc, d, resmask, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, ex, ey, em, px, py, pm);
-                else assist2_cell<false>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, ge, ng, tM, tX, ex, ey, em, px, py, pm);
+                if (cls == 2) assist2_cell<true>(sc_out, psc, d, resmask, slot, rL, cR, row, j, reduced_terminal, go, gxc, gyc, ng, tM, tX, ex, ey, em, px, py, pm);
+                else assist2_cell<false>(sc_out, psc, d, 0u, slot, rL, cR, row, j, reduced_terminal, go, gxc, gyc, ng, tM, tX, ex, ey, em, px, py, pm);
             }
             PM.sx[stg][at] = ex; PM.sy[stg][at] = ey; PM.sM[stg][at] = em;
             PM.spx[stg][at] = px; PM.spy[stg][at] = py;
@@ -978,8 +1013,10 @@ struct AssistGen {
 };
 
 template <bool TAB_LDS>
-__device__ __forceinline__ AssistGen<TAB_LDS> assist_gen(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, bool reduced_terminal) {
+__device__ __forceinline__ AssistGen<TAB_LDS> assist_gen(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, bool reduced_terminal,
+                                                          bool term_on = false) {
     AssistGen<TAB_LDS> g;
+    g.gE = (double)job->gE; g.Lx = job->Lx; g.Ly = job->Ly; g.term_on = term_on;
     const float f_ng = job->ng;
     g.sc_out = (gdouble_w)job->sc; g.psc = psc; g.table = (gfloat_p)job->table; g.list = PM.as_list[a];
     g.go = (double)job->go; g.ge = (double)job->ge; g.ng = (double)f_ng;
@@ -989,14 +1026,14 @@ __device__ __forceinline__ AssistGen<TAB_LDS> assist_gen(const PgDevJob *__restr
 }
 // one diagonal, start to finish (the diagonal must be computable: the compute waves have completed d-2)
 __device__ __noinline__ void assist_general_diag(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, bool reduced_terminal,
-                                                 int d, int cls, int lo, int hi, unsigned resmask) {
-    const AssistGen<true> g = assist_gen<true>(job, psc, a, lane, reduced_terminal);
+                                                 int d, int cls, int lo, int hi, unsigned resmask, bool term_on) {
+    const AssistGen<true> g = assist_gen<true>(job, psc, a, lane, reduced_terminal, term_on);
     g.scan(d, cls, lo, hi, resmask, true);
 }
 // the cells (row, j) of the lanes with `on` (the diagonal must be computable)
 __device__ __noinline__ void assist_general_cells(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, bool reduced_terminal,
-                                                  int d, int cls, unsigned resmask, bool on, int row, int j) {
-    const AssistGen<true> g = assist_gen<true>(job, psc, a, lane, reduced_terminal);
+                                                  int d, int cls, unsigned resmask, bool on, int row, int j, bool term_on) {
+    const AssistGen<true> g = assist_gen<true>(job, psc, a, lane, reduced_terminal, term_on);
     pg_i4 rL = {0, 0, 0, 0}, cR = {0, 0, 0, 0};
     double tM = 0, tX = 0;
     int kind = 0;
@@ -1028,10 +1065,14 @@ __device__ __noinline__ void assist_general_cells(const PgDevJob *__restrict__ j
 // over its pairs of (max(M + tM, max(X, Y) + tX) + lw) + rw (the folding tools/gen_hot_asm.py explains).  What this path does
 // not take (more than three edges at a site, three on both sides of a cell, an edge from site 0, more sites than slots, more
 // far cells than the pool holds) goes to assist_general_diag when the diagonal is due.
-__device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, bool reduced_terminal) {
-    const int nd = job->nd, S = job->S;
+template <bool STRIP>
+__device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, unsigned flags) {
+    const bool reduced_terminal = !(flags & 2u);
+    const bool term_on = STRIP && !(flags & 1u);                   // (row strips: cells of the first / last row and column come this way too)
+    constexpr int CLS = STRIP ? 7 : 15;                            // (a strip's class carries PG_STRIP_TERM beside it)
+    const int nd = job->nd, S = job->S, Lx = job->Lx, Ly = job->Ly;
     const gdouble_w sc_out = (gdouble_w)job->sc;
-    const double go = (double)job->go, ge = (double)job->ge, ng = (double)job->ng;
+    const double go = (double)job->go, ge = (double)job->ge, ng = (double)job->ng, gE = (double)job->gE;
     const int wave = PNW + a;                                      // names this wave in an abort tag
     int rows_ld = 0, cols_ld = 0, diags_ld = 0;
     int pw0 = -1, pw1 = -1, pw2 = -1, pw3 = -1;                   // cached progress of the compute waves
@@ -1067,6 +1108,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
     int q_row = 0, v_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double q_tM = 0, q_tX = 0, v_lw[4] = {0, 0, 0, 0}, v_rw[4] = {0, 0, 0, 0};
     int scan_d = a;                                                // next diagonal whose descriptor has not been looked at
+    if (STRIP) { const int d0 = job->d_first; scan_d = d0 + (a + 3 - d0 % 3) % 3; }       // (the strip's first diagonal of this wave's residue)
 
     // the sites first..last of one side have entered the band: the multi-edge ones among them into free slots
     auto take_sites = [&](bool left, int first, int last) -> bool {
@@ -1108,7 +1150,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
         const int t = dd + ((lane >> 3) & 1) * PNA;
         return ((PG_GLOBAL const int *)psc)[8 * (t < nd ? t : nd) + (lane & 7)];           // (the array carries one entry of padding)
     };
-    int q_next = desc_req(a);
+    int q_next = desc_req(scan_d);
 
     // looks for this wave's next class 2 diagonal (and the one after, if it follows directly) and prepares the pass
     auto prepare = [&]() {
@@ -1119,8 +1161,8 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
             const int ax = __builtin_amdgcn_readlane(q_next, 0), ay = __builtin_amdgcn_readlane(q_next, 1), as4 = __builtin_amdgcn_readlane(q_next, 4);
             const int bx = __builtin_amdgcn_readlane(q_next, 8), by = __builtin_amdgcn_readlane(q_next, 9), bs4 = __builtin_amdgcn_readlane(q_next, 12);
             const int hop_a = (int)((unsigned)as4 >> 20);           // the host's hop count: straight to this wave's next diagonal with work
-            if ((as4 & 15) != 2) { scan_d += PNA * hop_a; q_next = desc_req(scan_d); continue; }      // (class 0 / 1: the compute waves' own)
-            const bool pair_d = hop_a == 1 && d2 < nd && (bs4 & 15) == 2;               // the descriptors allow two diagonals
+            if ((as4 & CLS) != 2) { scan_d += PNA * hop_a; q_next = desc_req(scan_d); continue; }     // (class 0 / 1: the compute waves' own)
+            const bool pair_d = hop_a == 1 && d2 < nd && (bs4 & CLS) == 2;              // the descriptors allow two diagonals
             // bit 4 marks a class 2 diagonal whose operands all lie in the ring (class 2 for the shape of a site): no residency test
             q_d = d; q_cls[0] = (as4 & 16) ? 1 : 2; q_lo[0] = ax; q_hi[0] = ay; q_mask[0] = ((unsigned)as4 >> 5) & 0x7fffu;
             q_d2 = -1; q_cls[1] = (bs4 & 16) ? 1 : 2; q_lo[1] = bx; q_hi[1] = by; q_mask[1] = ((unsigned)bs4 >> 5) & 0x7fffu;
@@ -1328,7 +1370,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
 #ifdef PG_PIPE_STATS
             ++as_gen;
 #endif
-            assist_general_diag(job, psc, a, lane, reduced_terminal, d, q_cls[g], q_lo[g], q_hi[g], q_mask[g]);
+            assist_general_diag(job, psc, a, lane, reduced_terminal, d, q_cls[g], q_lo[g], q_hi[g], q_mask[g], term_on);
         } else if (q_on && grp == g) {
             const char *base = (const char *)&PM;
             double cx[8], cy[8], cm[8];
@@ -1339,9 +1381,10 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
                 const double *c = (const double *)(base + v_off[k]);
                 cx[k] = c[PG_X]; cy[k] = c[PG_Y]; cm[k] = c[PG_M];
             }
-            auto gapv = [&](double own, double other, double m_) { return __builtin_fmax(own + ge, __builtin_fmax(other, m_ + ng) + go); };
-            double ex = gapv(cx[0], cy[0], cm[0]), ey = gapv(cy[2], cx[2], cm[2]);
-            if (q_gap2) { ex = __builtin_fmax(ex, gapv(cx[1], cy[1], cm[1])); ey = __builtin_fmax(ey, gapv(cy[3], cx[3], cm[3])); }
+            auto gapv = [&](double own, double other, double m_, double ext) { return __builtin_fmax(own + ext, __builtin_fmax(other, m_ + ng) + go); };
+            const double gxc = (term_on && (q_j == 0 || q_j == Ly - 1)) ? gE : ge, gyc = (term_on && (q_row == 0 || q_row == Lx - 1)) ? gE : ge;
+            double ex = gapv(cx[0], cy[0], cm[0], gxc), ey = gapv(cy[2], cx[2], cm[2], gyc);
+            if (q_gap2) { ex = __builtin_fmax(ex, gapv(cx[1], cy[1], cm[1], gxc)); ey = __builtin_fmax(ey, gapv(cy[3], cx[3], cm[3], gyc)); }
             double em = NI_;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -1359,7 +1402,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
 #ifdef PG_PIPE_STATS
             ++as_cells;
 #endif
-            assist_general_cells(job, psc, a, lane, reduced_terminal, d, q_cls[g], q_mask[g], q_bad && grp == g, q_row, q_j);
+            assist_general_cells(job, psc, a, lane, reduced_terminal, d, q_cls[g], q_mask[g], q_bad && grp == g, q_row, q_j, term_on);
         }
         flag_store(&PM.assist_done[a], d);
 #ifdef PG_PIPE_STATS
@@ -1704,9 +1747,19 @@ __device__ __forceinline__ pg_i8 uniform_i8(const pg_i8 &v) {
 // basic_alignment.h:449-462): per edge / pair a first-wins maximum of its three candidates, then the groups
 // combined with "equal: the one listed first" -- the same winner.  Class 2 (any other multi-edge shape, or operands
 // that left the ring): what the diagonal's assist wave staged is merged as in step().
+// STRIP (a row strip of a wide job, see strip_feeder): a lane keeps its row, so the y-gap state's extension rate is the
+// lane's -- the first and the last row of the matrix extend at the terminal rate (VA:2116-2219: extY by row, extX by
+// column) -- and a diagonal that holds a cell of the first or the last column (PG_STRIP_TERM in its class) takes the C++
+// step below, which picks the x-gap state's rate per lane; the assembly loop leaves such a diagonal alone (its class is
+// not 0..2 to it).
+template <bool STRIP>
 __device__ __noinline__ void hot_run(WaveCtx &C_) {
     WCTX_IN(C_);
     WCTX_STATS(C_);
+    constexpr int CLS = STRIP ? 7 : 15;
+    const bool term_on = STRIP && !(C_.flags & 1u);
+    const double gE = (double)C_.job->gE;
+    const double gey = in_vgpr((term_on && (row == 0 || row == Lx - 1)) ? gE : ge);
     double PX = C_.px, PY = C_.py, PMm = C_.pm, CX = C_.cx, CY = C_.cy, CM = C_.cm;
     const pg_i4 ca = C_.ca, cb = C_.cb;
     pg_i8 dA = uniform_i8(C_.dA);
@@ -1737,7 +1790,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                   PST == 3 && PNT == 256, "the class 2 merge of dp_pipe_hot.inc addresses the staging arrays by these strides");
     for (;;) {
 #ifndef PG_NO_HOT_ASM
-        {
+        if (!STRIP || !(cur.s4 & PG_STRIP_TERM)) {
             // ---- consecutive class 0 / 1 / 2 diagonals: hand-scheduled loop (tools/gen_hot_asm.py has the register plan;
             // the C++ step below states the same arithmetic) ----
             // It runs until a diagonal needs anything else -- another class, the end of the wave's
@@ -1761,7 +1814,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                   [p0] "+v"(PX), [p1] "+v"(PY), [p2] "+v"(PMm), [c0] "+v"(CX), [c1] "+v"(CY), [c2] "+v"(CM),
                   [d] "+s"(d), [sb] "+s"(sb), [pup] "+s"(p_up), [pdn] "+s"(p_dn), [dptr] "+s"(dptr),
                   [k0] "+s"(k0), [k1] "+s"(k1), [k2] "+s"(k2)
-                : [ge] "v"(ge), [go] "v"(go), [ng] "v"(ng), [nihi] "v"(ni_hi), [pihi] "v"(0x7ff00000u),
+                : [ge] "v"(ge), [gey] "v"(gey), [go] "v"(go), [ng] "v"(ng), [nihi] "v"(ni_hi), [pihi] "v"(0x7ff00000u),
                   [tid24] "v"(a_tid24), [bpos24] "v"(a_bpos24), [fup] "v"(a_fup), [fme] "v"(a_fme),
                   [nulla] "v"(a_null), [tid] "v"(tid), [ringb] "s"(lds_ring),
                   [asd] "s"(a_asd), [stx] "v"(a_stx), [spxa] "v"(a_spx),
@@ -1801,7 +1854,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
             cR1 = PM.recR[(d + 1 - row) & (PRW - 1)];
             ti0 = ((rLc.x & 0xffff) + __umul24(cR0.x & 0xffff, S)) & 255;
             tMc = PM.tab2[ti0][0]; tXc = PM.tab2[ti0][1];
-            if ((cur.s4 & 15) > 2 || d >= sleep) { dA = cur; break; }
+            if ((cur.s4 & CLS) > 2 || d >= sleep) { dA = cur; break; }
 #ifdef PG_PIPE_STATS
             st_poll_n[7] += (__any(row <= cur.y + 1) ? 0 : 1);
 #endif
@@ -1824,7 +1877,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                 }
                 if (cur.s7 > p_dn) p_dn = POLLX(&PM.progress[dn], cur.s7, 3);
                 if (d - 1 > p_up && __any(row <= hi + 1)) p_up = POLLX(&PM.progress[up], d - 1, 4);
-                if ((cur.s4 & 15) == 2) {
+                if ((cur.s4 & CLS) == 2) {
                     if (hstg == 0) { if (as0 < d) as0 = POLLX(&PM.assist_done[0], d, 8); }
                     else if (hstg == 1) { if (as1 < d) as1 = POLLX(&PM.assist_done[1], d, 8); }
                     else { if (as2 < d) as2 = POLLX(&PM.assist_done[2], d, 8); }
@@ -1835,7 +1888,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
             continue;
         }
 #endif
-        const int lo = cur.x, hi = cur.y, cls = cur.s4 & 15;
+        const int lo = cur.x, hi = cur.y, cls = cur.s4 & CLS;
 #ifdef PG_PIPE_STATS
         const long long st_step0 = __builtin_readcyclecounter();
         const bool st_has = __any(row <= hi && row >= lo);
@@ -1877,7 +1930,10 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
         double bx, by, bm;
         unsigned px, py, pm;
         // candidates that do not need the shift first: the LDS read above is in flight
-        by = fmax3_from(PY + ge, PX + go, (PMm + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
+        by = fmax3_from(PY + gey, PX + go, (PMm + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
+        // the x-gap state's rate: the terminal one in the first and the last column
+        const int jcol = d - row;
+        const double gex = (term_on && (jcol == 0 || jcol == Ly - 1)) ? gE : ge;
         // (a class 1 diagonal none of whose multi-edge cells belongs to this wave is a class 0 diagonal to it)
         const bool own_multi = cls == 1 && __any(active && !(rLc.x & cR0.x & PR_SIMPLE));
         if (!own_multi) {
@@ -1893,7 +1949,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
             asm volatile("" : "+s"(pv) : "v"(AX), "v"(AY), "v"(AM));
             nxt = *(cdesc8_p)pv;
         }
-        bx = fmax3_from(AX + ge, AY + go, (AM + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
+        bx = fmax3_from(AX + gex, AY + go, (AM + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
         if (own_multi) {
             // ================= class 1: the lanes' own multi-edge cells =================
             const bool l2 = active && ((rLc.x >> PR_NE_SHIFT) & 127) == 2, r2 = active && ((cR0.x >> PR_NE_SHIFT) & 127) == 2;
@@ -1917,7 +1973,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                 ring_cell(r2 ? ring_back(sb, kR) + tid24 : null_off, ux, uy, um);
                 ring_cell(r2 ? ring_back(sb, kR + 1) + bpos24 : null_off, vx, vy, vm);
                 unsigned f;
-                const double ys = fmax3_from(uy + ge, ux + go, (um + ng) + go, PG_Y, PG_X, PG_M, f);
+                const double ys = fmax3_from(uy + gey, ux + go, (um + ng) + go, PG_Y, PG_X, PG_M, f);
                 take_better(by, py, ys, f | rbS, rS);
                 const double ms = fmax3_from(((vm + tM) + lwA) + rwS, ((vx + tX) + lwA) + rwS, ((vy + tX) + lwA) + rwS, PG_M, PG_X, PG_Y, f);
                 take_better(bm, pm, ms, f | PG_BP_ADJL | lbA | rbS, rS);
@@ -1928,7 +1984,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                 ring_cell(l2 ? ring_back(sb, kL) + posL : null_off, ux, uy, um);
                 ring_cell(l2 ? ring_back(sb, kL + 1) + posL : null_off, vx, vy, vm);
                 unsigned f, f2;
-                const double xs = fmax3_from(ux + ge, uy + go, (um + ng) + go, PG_X, PG_Y, PG_M, f);
+                const double xs = fmax3_from(ux + gex, uy + go, (um + ng) + go, PG_X, PG_Y, PG_M, f);
                 take_better(bx, px, xs, f | lbS, lS);
                 double m2 = fmax3_from(((vm + tM) + lwS) + rwA, ((vx + tX) + lwS) + rwA, ((vy + tX) + lwS) + rwA, PG_M, PG_X, PG_Y, f2);
                 unsigned p2 = f2 | PG_BP_ADJR | lbS | rbA;
@@ -2004,7 +2060,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
         sb = sb + PROW_BYTES == PRING_BYTES ? 0 : sb + PROW_BYTES;
         hstg = hstg + 1 == PST ? 0 : hstg + 1;
         cR0 = cR1; cR1 = cR2; tMc = tM1; tXc = tX1; rLc = rLn;
-        if ((nxt.s4 & 15) > 2 || d >= sleep) { dA = nxt; break; }        // the next diagonal is not class 0..2, or the wave's interval ends
+        if ((nxt.s4 & CLS) > 2 || d >= sleep) { dA = nxt; break; }       // the next diagonal is not class 0..2, or the wave's interval ends
         cur = nxt;
     }
     // hand the state back to step(): the column records and model score of diagonal d (the row records are reloaded there,
@@ -2359,10 +2415,88 @@ __device__ __noinline__ void pipe_follower(const PgDevJob *__restrict__ jobs, co
     }
 }
 
-template <bool TAB_LDS>
+// ---------------------------------------------------------------------------------------------------------------------
+// Row strips: a wide job (a full matrix, a band wider than the lanes) as a chain of banded jobs.
+//
+// A strip is PG_STRIP_ROWS = 192 rows of the matrix over all their columns: to this kernel a band whose first and last
+// row stand still.  Rows map to lanes as ever (row % 256), so a strip's rows fill three compute waves; the fourth -- the
+// wave "upstream" of the strip's first row -- is its FEEDER: it owns the 64 rows above the strip, computes nothing, and
+// writes their cells, read back from the scores the strip above stored, into its ring columns diagonal by diagonal,
+// publishing its progress like any compute wave.  To the strip's waves the rows above are in the ring exactly as if a
+// wave had computed them: lane 0 of the first wave takes row-1 from the feeder's lane 63 (the hot loop checks the feeder's
+// flag as it checks any upstream wave's), multi-edge cells find their operands up to 64 rows above the strip in the ring,
+// and ring rows are reused under the same per-diagonal rule.  The strips of a job run on ONE XCD (the host lays the
+// dispatch out so: workgroup g runs on XCD g % 8; checked here against the id the strip above published), a strip starts
+// when the one above has landed the diagonals its first cells read, and then follows it a few dozen diagonals behind:
+// the job's anti-diagonal sweeps all its strips at once.
+#define PFEED 8                   // diagonals the feeder requests from L2 at a time (one round trip)
+__device__ __noinline__ void strip_feeder(const PgDevJob *__restrict__ job, cdesc8_p psc, int tid, int wave) {
+    const int lane = tid & 63;
+    const int nd = job->nd, d0 = job->d_first;
+    const int row = job->strip_row0 - 64 + lane;
+    const int dn = (wave + 1) % PNW;
+    PG_GLOBAL const int *prev = (PG_GLOBAL const int *)job->prev_follow;
+    const int prev_last = job->prev_nd - 1;
+    PG_GLOBAL const pg_i4 *pdsc = (PG_GLOBAL const pg_i4 *)job->pdsc;
+    const gdouble_w sc = (gdouble_w)job->sc;
+    const double NI = neg_inf();
+    int d = d0;                                                    // (names the diagonal in an abort tag)
+    flag_store(&PM.arrived[wave], nd);                             // no stores to drain: never what a rendezvous waits for
+    {   // the strip above runs on this XCD (its scores are read from the XCD's L2)
+        int id = 0, spin = 0;
+        while ((id = peek_l2(prev + 1)) == 0 && spin < (1 << 22) && flag_load(&PM.abort_flag) == 0) { __builtin_amdgcn_s_sleep(16); ++spin; }
+        if (id != (int)my_xcc_id() + 1 && flag_load(&PM.abort_flag) == 0) flag_store(&PM.abort_flag, PTAG(11));
+    }
+    int landed1 = 0, p_dn = d0 - 1, slot = d0 % PRK;
+    for (int t0 = d0; t0 < nd && flag_load(&PM.abort_flag) == 0; t0 += PFEED) {
+        const int t1 = t0 + PFEED < nd ? t0 + PFEED : nd;
+        d = t0;
+        // what the strip above stored of the diagonals t0 .. t1-1 has landed (its counter ends at its own last diagonal)
+        const int need1 = (t1 - 1 < prev_last ? t1 - 1 : prev_last) + 1;
+        if (landed1 < need1) {
+            int spin = 0;
+            while ((landed1 = peek_l2(prev)) < need1) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spin > PSPIN_LIMIT / 8 || flag_load(&PM.abort_flag) != 0) {
+                    if (flag_load(&PM.abort_flag) == 0) flag_store(&PM.abort_flag, PTAG(12));
+                    break;
+                }
+            }
+            if (landed1 < need1) break;
+        }
+        FarAsk fa[PFEED];
+        pg_d2 xy[PFEED];
+        double m[PFEED];
+#pragma unroll
+        for (int k = 0; k < PFEED; ++k) {
+            const int t = t0 + k < nd ? t0 + k : nd - 1;
+            const pg_i4 ds = pdsc[t];                              // the whole band's rows on t, the offset (in cells) of its first
+            fa[k].need = t0 + k < t1 && row >= ds.x && row <= ds.y;
+            fa[k].boff = 24ll * ((((long long)ds.w << 32) | (unsigned)ds.z) + (row - ds.x));
+            xy[k].x = NI; xy[k].y = NI; m[k] = NI;
+        }
+        far_fetch8(sc, fa, xy, m);
+#pragma unroll
+        for (int k = 0; k < PFEED; ++k) {
+            const int t = t0 + k;
+            if (t >= t1) break;
+            d = t;
+            const int s7 = ((cint_p)psc)[8 * t + 7];               // ring row reuse: as for any wave (step())
+            if (s7 > p_dn) p_dn = POLL(&PM.progress[dn], s7, 3);
+            PM.sc[slot][tid][PG_X] = xy[k].x; PM.sc[slot][tid][PG_Y] = xy[k].y; PM.sc[slot][tid][PG_M] = m[k];
+            flag_store(&PM.progress[wave], t);
+            slot = slot + 1 == PRK ? 0 : slot + 1;
+        }
+    }
+    flag_store(&PM.progress[wave], nd);
+}
+
+template <bool TAB_LDS, bool STRIP>
 __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restrict__ jobs, const int *__restrict__ which,
                                                          unsigned flags, int n_fill) {
-    if ((int)blockIdx.x >= n_fill) { pipe_follower(jobs, which, n_fill, flags); return; }
+    static_assert(TAB_LDS || !STRIP, "row strips run with the model table in LDS");
+    if (!STRIP && (int)blockIdx.x >= n_fill) { pipe_follower(jobs, which, n_fill, flags); return; }
+    if (STRIP && which[blockIdx.x] < 0) return;                    // (padding: the strips of a job sit at workgroup indices of one residue mod 8)
     const PgDevJob *__restrict__ job = jobs + which[blockIdx.x];
     if (threadIdx.x == 0 && job->follow) {
         const int id = (int)my_xcc_id() + 1;
@@ -2378,11 +2512,13 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
         const float f_ng0 = job->ng;
         const double t2 = (double)(2 * f_ng0), t1 = (double)(0.0f + f_ng0);       // VA:1364-1367: float operations, promoted
         for (int k = tid; k < S * S; k += PBLOCK) { const float t = job->table[k]; PM.tab2[k][0] = t2 + (double)t; PM.tab2[k][1] = t1 + (double)t; }
+        // (row strips: site 0's state indexes the table like any other -- a finite term beside the -inf of its cells' operands)
+        if (STRIP) for (int k = S * S + tid; k < 256; k += PBLOCK) { PM.tab2[k][0] = 0.0; PM.tab2[k][1] = 0.0; }
     }
     for (int k = tid; k < PRK * PNT * 3; k += PBLOCK) (&PM.sc[0][0][0])[k] = neg_inf();
     if (tid < 4) PM.null_cell[tid] = neg_inf();
-    if (tid < PNW) { PM.progress[tid] = -1; PM.arrived[tid] = -1; }
-    if (tid == 0) { PM.loaded[0] = 0; PM.loaded[1] = 0; PM.loaded[2] = 0; PM.abort_flag = 0; }
+    if (tid < PNW) { PM.progress[tid] = STRIP ? job->d_first - 1 : -1; PM.arrived[tid] = STRIP ? job->d_first - 1 : -1; }
+    if (tid == 0) { PM.loaded[0] = 0; PM.loaded[1] = 0; PM.loaded[2] = 0; PM.abort_flag = 0; PM.pdsc = STRIP ? job->pdsc : nullptr; }
     if (tid < PNA) PM.assist_done[tid] = -1;
     __syncthreads();
 
@@ -2397,7 +2533,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
 #endif
     if (tid >= PNT + 64 * PNA) {
         const View J = load_view(job);
-        pipe_loader(J, psc, lane, (PG_GLOBAL int *)job->follow);
+        pipe_loader(J, psc, lane, (PG_GLOBAL int *)job->follow, STRIP ? job : nullptr);
         return;
     }
     if (tid >= PNT) {
@@ -2405,7 +2541,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
         if (lane == 0) flag_store(&PM.assist_done[(tid - PNT) >> 6], 0x7ffffff0);
         return;
 #endif
-        if constexpr (TAB_LDS) pipe_assist_lean(job, psc, __builtin_amdgcn_readfirstlane((tid - PNT) >> 6), lane, !(flags & 2u));
+        if constexpr (TAB_LDS) pipe_assist_lean<STRIP>(job, psc, __builtin_amdgcn_readfirstlane((tid - PNT) >> 6), lane, flags);
         else pipe_assist<false>(job, psc, __builtin_amdgcn_readfirstlane((tid - PNT) >> 6), lane, !(flags & 2u));
         return;
     }
@@ -2422,6 +2558,14 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
     // ================= compute waves =================
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // uniform: keeps the schedule and the step counter in SGPRs
     const int up = (wave + PNW - 1) % PNW, dn = (wave + 1) % PNW;
+    if (STRIP && wave == job->feed_wave) {
+        strip_feeder(job, psc, tid, wave);
+        if (lane == 0) {
+            const int aborted = flag_load(&PM.abort_flag);
+            if (aborted != 0) *(PG_GLOBAL int *)job->fill_status = aborted;
+        }
+        return;
+    }
     const cint_p sched = (cint_p)job->sched + ((cint_p)job->sched)[wave];     // awake intervals [a,b) of this wave
     const double NI = neg_inf();
     // the recurrence's constants live in VGPRs: a VALU instruction reads one SGPR operand at most, and the
@@ -2710,7 +2854,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
                             double tM, tX;
                             if (TAB_LDS) { tM = PM.tab2[ti & 255][0]; tX = PM.tab2[ti & 255][1]; }
                             else { const float smv = far_f32(table + ti); tM = tng2 + (double)smv; tX = tng1 + (double)smv; }
-                            multi2_cell<true>(sc_out, psc, d, resmask, slot, gl, gr, r, jj, reduced_terminal, go, ge, ng,
+                            multi2_cell<true>(sc_out, psc, d, resmask, slot, gl, gr, r, jj, reduced_terminal, go, ge, ge, ng,
                                               tM, tX, wx, wy, wm, qx, qy, qm);
                         } else {
                             gen_cell(d, slot, resmask, r, jj, wx, wy, wm, qx, qy, qm);
@@ -2775,7 +2919,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
             st_t = __builtin_readcyclecounter();
             if (st_on) st_n += 2;
 #endif
-            if (TAB_LDS && ((dA.s4 & 15) <= 2 || (dA.s4 & 15) == 4)) {           // model table in LDS: classes 0..2 and 4 run as functions of their own
+            if (TAB_LDS && (STRIP ? (dA.s4 & 7) <= 2 : ((dA.s4 & 15) <= 2 || (dA.s4 & 15) == 4))) {      // model table in LDS: classes 0..2 and 4 run as functions of their own
                 WaveCtx C_;
                 C_.job = job; C_.psc = psc; C_.sc_out = sc_out; C_.bp_out = bp_out;
                 C_.go = go; C_.ng = ng; C_.ge = ge; C_.tng2 = tng2; C_.tng1 = tng1;
@@ -2791,7 +2935,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
                 for (int k = 0; k < 10; ++k) { C_.st_poll_t[k] = st_poll_t[k]; C_.st_poll_n[k] = st_poll_n[k]; }
                 for (int k = 0; k < 4; ++k) C_.st_w[k] = st_w[k];
 #endif
-                if ((dA.s4 & 15) == 4) wide_run(C_); else hot_run(C_);
+                if (!STRIP && (dA.s4 & 15) == 4) wide_run(C_); else hot_run<STRIP>(C_);
 #ifdef PG_PIPE_STATS
                 for (int k = 0; k < 5; ++k) { st_cls_t[k] = C_.st_cls_t[k]; st_cls_n[k] = C_.st_cls_n[k]; }
                 for (int k = 0; k < 10; ++k) { st_poll_t[k] = C_.st_poll_t[k]; st_poll_n[k] = C_.st_poll_n[k]; }
@@ -2848,5 +2992,6 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
     }
 }
 
-template __global__ void pg_fill_pipe<true>(const PgDevJob *, const int *, unsigned, int);
-template __global__ void pg_fill_pipe<false>(const PgDevJob *, const int *, unsigned, int);
+template __global__ void pg_fill_pipe<true, false>(const PgDevJob *, const int *, unsigned, int);
+template __global__ void pg_fill_pipe<false, false>(const PgDevJob *, const int *, unsigned, int);
+template __global__ void pg_fill_pipe<true, true>(const PgDevJob *, const int *, unsigned, int);

@@ -85,10 +85,13 @@ class Emit:
         self.a("ds_read_b64 %s, v%d offset:16" % (pr(cell[2]), addr))
 
     def gap_value(self, cell, own, other, dst, t1, t2):
-        """dst = max(own + ge, max(other, M + ng) + go): the value an edge from `cell` offers the gap state `own`"""
+        """dst = max(own + ge, max(other, M + ng) + go): the value an edge from `cell` offers the gap state `own` (the y-gap
+        state extends at the LANE's rate, %[gey]: the first and the last row of the matrix have their own, and a lane of a row
+        strip keeps its row -- dp_pipe.hip, hot_run; the x-gap state's differs by COLUMN, and a diagonal that holds a cell of
+        the first or the last column does not run here)"""
         a = self.a
         a("v_add_f64 %s, %s, %%[ng]" % (pr(t1), pr(cell[2])))
-        a("v_add_f64 %s, %s, %%[ge]" % (pr(t2), pr(cell[own])))
+        a("v_add_f64 %s, %s, %%[%s]" % (pr(t2), pr(cell[own]), "gey" if own == 1 else "ge"))
         a("v_max_f64 %s, %s, %s" % (pr(t1), pr(cell[other]), pr(t1)))
         a("v_add_f64 %s, %s, %%[go]" % (pr(t1), pr(t1)))
         a("v_max_f64 %s, %s, %s" % (pr(dst), pr(t2), pr(t1)))
@@ -331,7 +334,7 @@ def step(E, k):
             a("s_cmp_eq_u32 s67, -2")
     # Y from P, M from C (no shift needed)
     a("v_add_f64 v[196:197], %s, %%[ng]" % pr(P[2]))          # PM + ng
-    a("v_add_f64 v[200:201], %s, %%[ge]" % pr(P[1]))          # PY + ge
+    a("v_add_f64 v[200:201], %s, %%[gey]" % pr(P[1]))         # PY + ge (the lane's own rate for the y-gap state)
     a("v_max_f64 v[202:203], %s, %s" % (pr(C[0]), pr(C[1])))  # max(CX, CY)
     a("v_add_f64 v[204:205], %s, %s" % (pr(C[2]), pr(tmx)))   # CM + tM
     a("v_max_f64 v[196:197], %s, v[196:197]" % pr(P[0]))      # max(PX, PM + ng)
