@@ -302,6 +302,7 @@ void plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
     std::vector<std::vector<int>> cols_ge(REACH);
     for (int j = 0; j < Ly; ++j) for (int t = 2; t < REACH && t <= fr.span[j]; ++t) cols_ge[t].push_back(j);
     const int n_strips = (Lx + PG_STRIP_ROWS - 1) / PG_STRIP_ROWS;
+    const bool term_cxx = std::getenv("PAGAN_DP_STRIP_TERM") != nullptr;
     out->assign(n_strips, StripPlan());
     for (int k = 0; k < n_strips; ++k) {
         StripPlan &sp = (*out)[k];
@@ -318,7 +319,9 @@ void plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
         for (int t = 0; t < m; ++t) {
             const int d = D0 + t;
             smin[t] = std::max(r0, dx.imin[d]); smax[t] = std::min(r1, dx.imax[d]);
-            if (smax[t] < smin[t]) smax[t] = smin[t] - 1;
+            // a diagonal without a cell of the strip: the first row stays where it was (it never falls, and a lane whose row
+            // fell behind it moves on by 256 rows -- beyond any last row the strip can have), no row is in the band
+            if (smax[t] < smin[t]) { smin[t] = t > 0 ? std::min(smin[t - 1], r1) : r0; smin[t] = std::max(smin[t], r0); smax[t] = smin[t] - 1; }
         }
         {   // first column the loader stages: the smallest column of the strip's first diagonals, rounded down to a chunk
             int c0 = Ly;
@@ -365,7 +368,9 @@ void plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
             else c = 0;
             ring2[t] = c == 2 && run == 0;
             const bool term = (d >= lo && d <= hi) || (d - (Ly - 1) >= lo && d - (Ly - 1) <= hi);      // a cell of column 0 / column Ly-1
-            if (c <= 2 && term) c |= PG_STRIP_TERM;
+            // (the strip's assembly loop picks the x-gap rate per lane: such a diagonal needs no path of its own; PAGAN_DP_STRIP_TERM=1
+            //  sends it to the C++ step all the same -- A/B switch)
+            if (c <= 2 && term && term_cxx) c |= PG_STRIP_TERM;
             cls[t] = c;
         }
         // ---- ring reuse (classify_diagonals has the reasoning) ----

@@ -99,6 +99,9 @@ struct PipeSmem {
     int assist_done[PNA];        // last diagonal each assist wave has staged
     int as_list[PNA][64];        // rows of the multi-edge cells of the diagonal an assist wave is working on, compacted
     const int *pdsc;             // row strips: the parent job's dsc array (null otherwise): far_ask's view of the whole band
+#ifdef PG_PIPE_STATS
+    long long far_limit;         // (statistics builds) bytes of the job's score array: a far read outside it sets the abort flag instead
+#endif
 };
 
 static_assert(sizeof(PipeSmem) <= 160 * 1024, "PipeSmem has to fit the 160 KB of LDS of a gfx950 compute unit");
@@ -159,6 +162,8 @@ __device__ __forceinline__ int poll_ge(const int *p, int need, int tag) {
 // the same as a function of its own: the run functions call it only when a cached flag stops covering a step
 __device__ __noinline__ int poll_ge_out(const int *p, int need, int tag) { return poll_ge(p, need, tag); }
 #define PTAG(kind) ((kind) | (wave << 4) | (d << 8))
+// (statistics builds) the strips of a job share its trace buffer: only the strip named in the debug flags' bits 12-15 records
+#define PG_STATS_MINE(job, flags) (!(job)->is_strip || (job)->strip_row0 / PG_STRIP_ROWS == (int)(((flags) >> 12) & 15u))
 #ifdef PG_PIPE_STATS
 #define POLLX(p, need, kind) ([&] { const long long t0_ = __builtin_readcyclecounter(); const int v_ = __builtin_amdgcn_readfirstlane(poll_ge_out(p, need, PTAG(kind))); st_poll_t[kind] += __builtin_readcyclecounter() - t0_; ++st_poll_n[kind]; return v_; }())
 #define POLL(p, need, kind) ([&] { const long long t0_ = __builtin_readcyclecounter(); const int v_ = poll_ge(p, need, PTAG(kind)); st_poll_t[kind] += __builtin_readcyclecounter() - t0_; ++st_poll_n[kind]; return v_; }())
@@ -257,7 +262,7 @@ __device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lan
         // the tail is published like the middle, PLAND behind the slowest wave, and the last diagonals only once every wave
         // has said "drained for good": progress = nd, stored behind the s_waitcnt vmcnt(0) that ends its last interval.
         if (pmin >= J.nd) { publish_landed(follow, lane, J.nd - 1); return; }
-        if (pmin - PLAND >= published + PG_FOLLOW_CHUNK) { published = pmin - PLAND; publish_landed(follow, lane, published); }
+        if (pmin - PLAND >= published + (strip ? 8 : PG_FOLLOW_CHUNK)) { published = pmin - PLAND; publish_landed(follow, lane, published); }
         if (pmin + 1 >= J.nd) { __builtin_amdgcn_s_sleep(8); continue; }                          // nothing left to stage
         const int dcur = pmin + 1;                                 // the slowest wave may be computing this one
         const int da = dcur + PLOOK < J.nd - 1 ? dcur + PLOOK : J.nd - 1;
@@ -329,6 +334,14 @@ struct FarAsk { bool need; long long boff; };                     // byte offset
                                  "global_load_dwordx2 %[" #m_ "], %[" #a "], off offset:16 sc1\n\t"
 __device__ __forceinline__ void far_fetch4(gdouble_w sc, const FarAsk &a0, const FarAsk &a1, const FarAsk &a2, const FarAsk &a3,
                                            pg_d2 &xy0, double &m0, pg_d2 &xy1, double &m1, pg_d2 &xy2, double &m2, pg_d2 &xy3, double &m3) {
+#ifdef PG_PIPE_STATS
+    {
+        const long long lim = PM.far_limit;
+        const bool bad = (a0.need && (a0.boff < 0 || a0.boff + 24 > lim)) || (a1.need && (a1.boff < 0 || a1.boff + 24 > lim)) ||
+                         (a2.need && (a2.boff < 0 || a2.boff + 24 > lim)) || (a3.need && (a3.boff < 0 || a3.boff + 24 > lim));
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) { if (PM.abort_flag == 0) PM.abort_flag = 0x7f000004; return; }
+    }
+#endif
     const unsigned long long k0 = __builtin_amdgcn_ballot_w64(a0.need), k1 = __builtin_amdgcn_ballot_w64(a1.need);
     const unsigned long long k2 = __builtin_amdgcn_ballot_w64(a2.need), k3 = __builtin_amdgcn_ballot_w64(a3.need);
     if ((k0 | k1 | k2 | k3) == 0) return;
@@ -344,6 +357,14 @@ __device__ __forceinline__ void far_fetch4(gdouble_w sc, const FarAsk &a0, const
                  : "memory");
 }
 __device__ __forceinline__ void far_fetch8(gdouble_w sc, const FarAsk (&a)[8], pg_d2 (&xy)[8], double (&m)[8]) {
+#ifdef PG_PIPE_STATS
+    {
+        const long long lim = PM.far_limit;
+        bool bad = false;
+        for (int k = 0; k < 8; ++k) bad = bad || (a[k].need && (a[k].boff < 0 || a[k].boff + 24 > lim));
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) { if (PM.abort_flag == 0) PM.abort_flag = 0x7f000008; return; }
+    }
+#endif
     const unsigned long long k0 = __builtin_amdgcn_ballot_w64(a[0].need), k1 = __builtin_amdgcn_ballot_w64(a[1].need);
     const unsigned long long k2 = __builtin_amdgcn_ballot_w64(a[2].need), k3 = __builtin_amdgcn_ballot_w64(a[3].need);
     const unsigned long long k4 = __builtin_amdgcn_ballot_w64(a[4].need), k5 = __builtin_amdgcn_ballot_w64(a[5].need);
@@ -1184,6 +1205,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
                 return;
             }
             seen_row = hi_t + 1; seen_col = cmax_t + 1;
+            ASTAMP(2);
             // two diagonals if the band's sites fit one half of the wave: the halves then look at the same sites (a lane's view e_*
             // of the slot with its rank), each on its own diagonal; otherwise every lane its own slot, on d
             const unsigned long long amask = __builtin_amdgcn_ballot_w64(s_site >= 0);
@@ -1309,6 +1331,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
             // a cell this path does not take: the general code stages it when its diagonal is due
             q_bad = on && !ok;
             on = on && ok;
+            ASTAMP(3);
             if (__builtin_amdgcn_ballot_w64(on && any_far) != 0) {
                 // cells that left the ring (>= PAGE diagonals back) have landed once every wave has completed d - PAGE + PLAND
                 // (far_ask looks up the descriptors of the diagonals d - age, age >= PAGE, in the loader's window)
@@ -1350,6 +1373,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
                 }
             }
             q_on = on;
+            ASTAMP(4);
             return;
         }
     };
@@ -1397,6 +1421,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
             if (v_msR) { PM.sy[stg][at] = ey; PM.spy[stg][at] = v_onlyR ? PS_ONLY : 0u; }
             PM.sM[stg][at] = em;
         }
+        ASTAMP(5);
         if (!q_gen[g] && __builtin_amdgcn_ballot_w64(q_bad && grp == g) != 0) {
             if (q_cls[g] == 2 && diags_ld < d) diags_ld = POLL(&PM.loaded[2], d, 5);
 #ifdef PG_PIPE_STATS
@@ -1404,6 +1429,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
 #endif
             assist_general_cells(job, psc, a, lane, reduced_terminal, d, q_cls[g], q_mask[g], q_bad && grp == g, q_row, q_j, term_on);
         }
+        ASTAMP(6);
         flag_store(&PM.assist_done[a], d);
 #ifdef PG_PIPE_STATS
         ++as_n;
@@ -1423,12 +1449,14 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
         prepare();
     }
 #ifdef PG_PIPE_STATS
-    if (lane == 0 && 3 * (job->Lx + job->Ly) >= 4096) {
+    if (lane == 0 && 3 * (job->Lx + job->Ly) >= 4096 && PG_STATS_MINE(job, flags)) {
         PG_GLOBAL int *o = (PG_GLOBAL int *)job->trace + 3 * (job->Lx + job->Ly) - 1000 + 16 * a;
         o[0] = as_n;
         for (int k = 0; k < 12; ++k) o[1 + k] = (int)(as_t[k] >> 8);
         o[13] = as_gen; o[14] = as_pairs; o[15] = as_cells;
+#ifndef PG_AS_BUCKETS                                              // (-DPG_AS_BUCKETS: the cycle buckets 2..6 of the lean path instead)
         for (int k = 0; k < 6; ++k) o[1 + 2 + k] = as_why[k];     // (in the place of the unused cycle buckets 2..7)
+#endif
     }
 #endif
 #undef ASTAMP
@@ -1808,21 +1836,38 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
             const long long st_t_in = __builtin_readcyclecounter();
 #endif
             int k0 = 0, k1 = 0, k2 = 0;        // diagnostic builds (PG_HOT_EXP=k): waits for the upstream wave, looks at its flag, waits for the downstream wave
-            asm volatile(
-#include "dp_pipe_hot.inc"
-                : [row] "+v"(row), [colx] "+v"(colx), [rowx] "+v"(rowx), [tm] "+v"(tm_io), [tx] "+v"(tx_io),
-                  [p0] "+v"(PX), [p1] "+v"(PY), [p2] "+v"(PMm), [c0] "+v"(CX), [c1] "+v"(CY), [c2] "+v"(CM),
-                  [d] "+s"(d), [sb] "+s"(sb), [pup] "+s"(p_up), [pdn] "+s"(p_dn), [dptr] "+s"(dptr),
+#define PG_HOT_OUTS [row] "+v"(row), [colx] "+v"(colx), [rowx] "+v"(rowx), [tm] "+v"(tm_io), [tx] "+v"(tx_io), \
+                  [p0] "+v"(PX), [p1] "+v"(PY), [p2] "+v"(PMm), [c0] "+v"(CX), [c1] "+v"(CY), [c2] "+v"(CM), \
+                  [d] "+s"(d), [sb] "+s"(sb), [pup] "+s"(p_up), [pdn] "+s"(p_dn), [dptr] "+s"(dptr), \
                   [k0] "+s"(k0), [k1] "+s"(k1), [k2] "+s"(k2)
-                : [ge] "v"(ge), [gey] "v"(gey), [go] "v"(go), [ng] "v"(ng), [nihi] "v"(ni_hi), [pihi] "v"(0x7ff00000u),
-                  [tid24] "v"(a_tid24), [bpos24] "v"(a_bpos24), [fup] "v"(a_fup), [fme] "v"(a_fme),
-                  [nulla] "v"(a_null), [tid] "v"(tid), [ringb] "s"(lds_ring),
-                  [asd] "s"(a_asd), [stx] "v"(a_stx), [spxa] "v"(a_spx),
-                  [stopm1] "s"(stop - 1), [S] "s"(S), [fdn] "v"(a_fdn),
-                  [bR] "s"(a_recR), [bL] "s"(a_recL), [bT] "s"(a_table),
+#define PG_HOT_INS [ge] "v"(ge), [gey] "v"(gey), [go] "v"(go), [ng] "v"(ng), [nihi] "v"(ni_hi), [pihi] "v"(0x7ff00000u), \
+                  [tid24] "v"(a_tid24), [bpos24] "v"(a_bpos24), [fup] "v"(a_fup), [fme] "v"(a_fme), \
+                  [nulla] "v"(a_null), [tid] "v"(tid), [ringb] "s"(lds_ring), \
+                  [asd] "s"(a_asd), [stx] "v"(a_stx), [spxa] "v"(a_spx), \
+                  [stopm1] "s"(stop - 1), [S] "s"(S), [fdn] "v"(a_fdn), \
+                  [bR] "s"(a_recR), [bL] "s"(a_recL), [bT] "s"(a_table), \
                   [sclo] "s"(sc_lo), [schi] "s"(sc_hi)
-                : "memory", "vcc", "scc",
-                  PG_HOT_CLOBBERS);
+            if constexpr (STRIP) {
+                // (the strip's loop picks the x-gap state's rate per lane and step: tools/gen_hot_asm.py, STRIP)
+                const double gE_ = term_on ? gE : ge;
+                const int lym1 = __builtin_amdgcn_readfirstlane(Ly - 1);
+                asm volatile(
+#include "dp_pipe_hot_strip.inc"
+                    : PG_HOT_OUTS
+                    : PG_HOT_INS, [gel] "v"(__double2loint(ge)), [geh] "v"(__double2hiint(ge)), [gEl] "v"(__double2loint(gE_)),
+                      [gEh] "v"(__double2hiint(gE_)), [lym1] "s"(lym1)
+                    : "memory", "vcc", "scc",
+                      PG_HOT_CLOBBERS);
+            } else {
+                asm volatile(
+#include "dp_pipe_hot.inc"
+                    : PG_HOT_OUTS
+                    : PG_HOT_INS
+                    : "memory", "vcc", "scc",
+                      PG_HOT_CLOBBERS);
+            }
+#undef PG_HOT_OUTS
+#undef PG_HOT_INS
             d = __builtin_amdgcn_readfirstlane(d);
             (void)d_in;
 #ifdef PG_PIPE_STATS
@@ -1830,7 +1875,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                 // waits for the upstream wave | 48-look exits << 16): upper half of the job's trace buffer, per wave
                 const long long st_t_out = __builtin_readcyclecounter();
                 const int n3 = 3 * (Lx + Ly), r0 = (n3 / 4 * 3 + 15) & ~15, cap = (n3 - 1200 - r0 - 16) / 16;
-                if (cap > 0 && n3 >= 4096 && (tid & 63) == 0) {
+                if (cap > 0 && n3 >= 4096 && (tid & 63) == 0 && PG_STATS_MINE(C_.job, C_.flags)) {
                     PG_GLOBAL int *tb = (PG_GLOBAL int *)C_.job->trace;
                     const int slot = atomicAdd((int *)(tb + r0 + wave), 1);
                     if (slot < cap) {
@@ -2421,19 +2466,24 @@ __device__ __noinline__ void pipe_follower(const PgDevJob *__restrict__ jobs, co
 // A strip is PG_STRIP_ROWS = 192 rows of the matrix over all their columns: to this kernel a band whose first and last
 // row stand still.  Rows map to lanes as ever (row % 256), so a strip's rows fill three compute waves; the fourth -- the
 // wave "upstream" of the strip's first row -- is its FEEDER: it owns the 64 rows above the strip, computes nothing, and
-// writes their cells, read back from the scores the strip above stored, into its ring columns diagonal by diagonal,
+// writes the cells of the last PHALO = 16 of them (a ring operand lies at most PAGE - 1 rows up; the other columns stay
+// -inf and are never read), read back from the scores the strip above stored, into its ring columns diagonal by diagonal,
 // publishing its progress like any compute wave.  To the strip's waves the rows above are in the ring exactly as if a
 // wave had computed them: lane 0 of the first wave takes row-1 from the feeder's lane 63 (the hot loop checks the feeder's
-// flag as it checks any upstream wave's), multi-edge cells find their operands up to 64 rows above the strip in the ring,
-// and ring rows are reused under the same per-diagonal rule.  The strips of a job run on ONE XCD (the host lays the
+// flag as it checks any upstream wave's), multi-edge cells find their ring operands above the strip in the ring, and ring
+// rows are reused under the same per-diagonal rule.  The strips of a job run on ONE XCD (the host lays the
 // dispatch out so: workgroup g runs on XCD g % 8; checked here against the id the strip above published), a strip starts
 // when the one above has landed the diagonals its first cells read, and then follows it a few dozen diagonals behind:
 // the job's anti-diagonal sweeps all its strips at once.
-#define PFEED 8                   // diagonals the feeder requests from L2 at a time (one round trip)
+#define PHALO 16                  // rows above the strip the feeder keeps in the ring: a ring operand lies at most PAGE - 1 <= 16 rows up
+#define PFEED 32                  // diagonals the feeder requests from L2 at a time: 4 per load (lane = diagonal % 4, row), 8 loads, one round trip
+static_assert(PHALO >= PAGE - 1 && 64 / PHALO * 8 == PFEED, "feeder geometry");
 __device__ __noinline__ void strip_feeder(const PgDevJob *__restrict__ job, cdesc8_p psc, int tid, int wave) {
     const int lane = tid & 63;
     const int nd = job->nd, d0 = job->d_first;
-    const int row = job->strip_row0 - 64 + lane;
+    const int hq = lane / PHALO, hr = lane % PHALO;                // this lane's diagonal (of four) and halo row in a request
+    const int row = job->strip_row0 - PHALO + hr;
+    const int col = row & (PNT - 1);                               // its ring column (the last PHALO lanes' of this wave)
     const int dn = (wave + 1) % PNW;
     PG_GLOBAL const int *prev = (PG_GLOBAL const int *)job->prev_follow;
     const int prev_last = job->prev_nd - 1;
@@ -2464,28 +2514,33 @@ __device__ __noinline__ void strip_feeder(const PgDevJob *__restrict__ job, cdes
             }
             if (landed1 < need1) break;
         }
-        FarAsk fa[PFEED];
-        pg_d2 xy[PFEED];
-        double m[PFEED];
+        FarAsk fa[8];
+        pg_d2 xy[8];
+        double m[8];
 #pragma unroll
-        for (int k = 0; k < PFEED; ++k) {
-            const int t = t0 + k < nd ? t0 + k : nd - 1;
-            const pg_i4 ds = pdsc[t];                              // the whole band's rows on t, the offset (in cells) of its first
-            fa[k].need = t0 + k < t1 && row >= ds.x && row <= ds.y;
+        for (int k = 0; k < 8; ++k) {                              // request k: the diagonals t0 + 4k .. t0 + 4k + 3, this lane's t0 + 4k + hq
+            const int t = t0 + 4 * k + hq;
+            const pg_i4 ds = pdsc[t < nd ? t : nd - 1];            // the whole band's rows on t, the offset (in cells) of its first
+            fa[k].need = t < t1 && row >= ds.x && row <= ds.y;
             fa[k].boff = 24ll * ((((long long)ds.w << 32) | (unsigned)ds.z) + (row - ds.x));
             xy[k].x = NI; xy[k].y = NI; m[k] = NI;
         }
+        // the batch's ring-reuse rule (descriptor word 7: what the downstream wave must have completed, as for any wave) in one load
+        const int s7v = ((PG_GLOBAL const int *)psc)[8 * (t0 + (lane & 31) < nd ? t0 + (lane & 31) : nd - 1) + 7];
         far_fetch8(sc, fa, xy, m);
 #pragma unroll
-        for (int k = 0; k < PFEED; ++k) {
-            const int t = t0 + k;
-            if (t >= t1) break;
-            d = t;
-            const int s7 = ((cint_p)psc)[8 * t + 7];               // ring row reuse: as for any wave (step())
-            if (s7 > p_dn) p_dn = POLL(&PM.progress[dn], s7, 3);
-            PM.sc[slot][tid][PG_X] = xy[k].x; PM.sc[slot][tid][PG_Y] = xy[k].y; PM.sc[slot][tid][PG_M] = m[k];
-            flag_store(&PM.progress[wave], t);
-            slot = slot + 1 == PRK ? 0 : slot + 1;
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int q = 0; q < 64 / PHALO; ++q) {
+                const int t = t0 + 4 * k + q;
+                if (t >= t1) break;
+                d = t;
+                const int s7 = __builtin_amdgcn_readlane(s7v, 4 * k + q);
+                if (s7 > p_dn) p_dn = poll_ge(&PM.progress[dn], s7, PTAG(3));
+                if (hq == q) { PM.sc[slot][col][PG_X] = xy[k].x; PM.sc[slot][col][PG_Y] = xy[k].y; PM.sc[slot][col][PG_M] = m[k]; }
+                flag_store_inorder(&PM.progress[wave], t);          // (behind the cell: a wave's LDS operations execute in order)
+                slot = slot + 1 == PRK ? 0 : slot + 1;
+            }
         }
     }
     flag_store(&PM.progress[wave], nd);
@@ -2519,13 +2574,16 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
     if (tid < 4) PM.null_cell[tid] = neg_inf();
     if (tid < PNW) { PM.progress[tid] = STRIP ? job->d_first - 1 : -1; PM.arrived[tid] = STRIP ? job->d_first - 1 : -1; }
     if (tid == 0) { PM.loaded[0] = 0; PM.loaded[1] = 0; PM.loaded[2] = 0; PM.abort_flag = 0; PM.pdsc = STRIP ? job->pdsc : nullptr; }
+#ifdef PG_PIPE_STATS
+    if (tid == 0) PM.far_limit = 24ll * job->cells;
+#endif
     if (tid < PNA) PM.assist_done[tid] = -1;
     __syncthreads();
 
 #ifdef PG_PIPE_STATS
-    if (tid < 4 && 3 * (job->Lx + job->Ly) >= 4096)           // slot counters of the per-run records (hot_run)
+    if (tid < 4 && 3 * (job->Lx + job->Ly) >= 4096 && PG_STATS_MINE(job, flags))           // slot counters of the per-run records (hot_run)
         ((PG_GLOBAL int *)job->trace)[((3 * (job->Lx + job->Ly) / 4 * 3 + 15) & ~15) + tid] = 0;
-    if (lane == 0 && 3 * (job->Lx + job->Ly) >= 4096) {       // which SIMD / CU every wave of the workgroup landed on
+    if (lane == 0 && 3 * (job->Lx + job->Ly) >= 4096 && PG_STATS_MINE(job, flags)) {       // which SIMD / CU every wave of the workgroup landed on
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         ((PG_GLOBAL int *)job->trace)[3 * (job->Lx + job->Ly) - 1100 + (tid >> 6)] = (int)hwid;
@@ -2970,7 +3028,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
         }
     }
 #ifdef PG_PIPE_STATS
-    if (lane == 0 && 3 * (Lx + Ly) >= 4096) {     // the counters borrow the tail of the trace buffer: long jobs only
+    if (lane == 0 && 3 * (Lx + Ly) >= 4096 && PG_STATS_MINE(job, flags)) {     // the counters borrow the tail of the trace buffer: long jobs only
         PG_GLOBAL int *o = (PG_GLOBAL int *)job->trace + 3 * (Lx + Ly) - 200 + 12 * wave;
         o[0] = st_n;
         for (int k = 0; k < 7; ++k) o[1 + k] = (int)(st_acc[k] >> 4);

@@ -36,7 +36,14 @@ store's data registers within two.
 """
 import os
 
-OUT = os.environ.get("PG_HOT_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pagan2-msa_amd", "csrc", "dp_pipe_hot.inc")
+# STRIP: the variant for row strips of wide jobs (dp_pipe_hot_strip.inc, hot_run<true>).  A strip's lanes keep their rows and
+# sweep every column, so a cell of the first or the last column sits on half of a strip's diagonals: the x-gap state's
+# extension rate is picked per lane and step -- v[254:255] = (d == row or d - (Ly-1) == row) ? gE : ge, five vector
+# instructions -- where the banded kernel sends the few diagonals with such a cell to the general step.
+STRIP = bool(os.environ.get("PG_HOT_STRIP"))
+OUT = os.environ.get("PG_HOT_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pagan2-msa_amd", "csrc",
+                                                   "dp_pipe_hot_strip.inc" if STRIP else "dp_pipe_hot.inc")
+GEX = 254
 
 P = (224, 226, 228)                      # X, Y, M (register pairs start)
 Q = ((180, 182, 184), (230, 232, 234))
@@ -91,7 +98,10 @@ class Emit:
         the first or the last column does not run here)"""
         a = self.a
         a("v_add_f64 %s, %s, %%[ng]" % (pr(t1), pr(cell[2])))
-        a("v_add_f64 %s, %s, %%[%s]" % (pr(t2), pr(cell[own]), "gey" if own == 1 else "ge"))
+        if own == 0 and STRIP:
+            a("v_add_f64 %s, %s, %s" % (pr(t2), pr(cell[own]), pr(GEX)))
+        else:
+            a("v_add_f64 %s, %s, %%[%s]" % (pr(t2), pr(cell[own]), "gey" if own == 1 else "ge"))
         a("v_max_f64 %s, %s, %s" % (pr(t1), pr(cell[other]), pr(t1)))
         a("v_add_f64 %s, %s, %%[go]" % (pr(t1), pr(t1)))
         a("v_max_f64 %s, %s, %s" % (pr(dst), pr(t2), pr(t1)))
@@ -469,11 +479,25 @@ def step(E, k):
             a("v_mov_b32_dpp v%d, v%d wave_shr:1 row_mask:0xf bank_mask:0xf" % (A[c] + 1, P[c] + 1))
         # X from A; the band limit of this lane
         a("v_add_f64 v[196:197], %s, %%[ng]" % pr(A[2]))          # AM + ng
-        a("v_add_f64 v[200:201], %s, %%[ge]" % pr(A[0]))          # AX + ge
-        a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)          # active: row <= hi
-        a("v_max_f64 v[196:197], %s, v[196:197]" % pr(A[1]))      # max(AY, AM + ng)
-        a("v_add_f64 v[196:197], v[196:197], %[go]")
-        a("v_cndmask_b32_e64 v%d, %%[nihi], %%[pihi], s[60:61]" % (LIM + 1))
+        if STRIP:
+            # the x-gap state's rate of this lane's cell: the terminal one in column 0 (d == row) and column Ly-1
+            a("s_sub_i32 s72, %[d], %[lym1]")
+            a("v_cmp_eq_u32_e32 vcc, %[d], %[row]")
+            a("v_cmp_eq_u32_e64 s[84:85], s72, %[row]")
+            a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)      # active: row <= hi
+            a("v_max_f64 v[196:197], %s, v[196:197]" % pr(A[1]))  # max(AY, AM + ng)
+            a("s_or_b64 vcc, vcc, s[84:85]")
+            a("v_add_f64 v[196:197], v[196:197], %[go]")
+            a("v_cndmask_b32_e64 v%d, %%[nihi], %%[pihi], s[60:61]" % (LIM + 1))
+            a("v_cndmask_b32_e32 v%d, %%[gel], %%[gEl], vcc" % GEX)
+            a("v_cndmask_b32_e32 v%d, %%[geh], %%[gEh], vcc" % (GEX + 1))
+            a("v_add_f64 v[200:201], %s, %s" % (pr(A[0]), pr(GEX)))    # AX + the lane's rate
+        else:
+            a("v_add_f64 v[200:201], %s, %%[ge]" % pr(A[0]))          # AX + ge
+            a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)          # active: row <= hi
+            a("v_max_f64 v[196:197], %s, v[196:197]" % pr(A[1]))      # max(AY, AM + ng)
+            a("v_add_f64 v[196:197], v[196:197], %[go]")
+            a("v_cndmask_b32_e64 v%d, %%[nihi], %%[pihi], s[60:61]" % (LIM + 1))
         a("v_max_f64 %s, v[200:201], v[196:197]" % pr(BX))
 
     E.cur = E.ool
