@@ -318,11 +318,17 @@ def bench_one_gpu(args, device):
     # per kernel: its cells (the planner's routing of every node, host only), its launches, its time.  The dominant kernel's
     # figures are the roofline object's top-level fields; every kernel of the workload is listed under roofline.kernels.
     routed, route_of = {}, {}
+    strip_cells = 0
     for k in range(n_nodes):
         left, right, model, band = msa.node_job(k)
         full = pg.debug_route(left, right, model, band)[0]
         route_of[k] = full
         route = full.split(" ")[0]
+        if full == "pg_fill_pipe (row strips)":
+            # a wide job filled as row strips by the banded kernel: timed (and counted) in the wide jobs' slot of the batch --
+            # pagan_batch_last_ms_detail brackets the strips' launch and the tiled kernel's together
+            route = "pg_fill_tiles_flow"
+            strip_cells += int(infos[k].cells)
         routed[route] = routed.get(route, 0) + int(infos[k].cells)
     kmean = kern_ms.mean(axis=0)                               # [level, kernel]
     # A banded-fill DISPATCH of at most 32 alignments carries follower workgroups that write the back-pointers while the fill
@@ -358,6 +364,10 @@ def bench_one_gpu(args, device):
         per_kernel.append({"kernel": name, "ms_per_step": t_ms, "launches_per_step": launches, "avg_launch_ms": t_ms / launches,
                            "cells": int(kcells), "algorithmic_bytes_per_cell": kbytes, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                            "launch_ms_by_level": [float(x) for x in kmean[:, q]]})
+        if name == "pg_fill_tiles_flow" and strip_cells > 0:
+            # the wide jobs' slot of a batch: row strips on pg_fill_pipe<true, true> where a job qualifies, tiles otherwise
+            per_kernel[-1]["kernel"] = "pg_fill_pipe (row strips) + pg_fill_tiles_flow" if strip_cells < kcells else "pg_fill_pipe (row strips)"
+            per_kernel[-1]["row_strip_cells"] = int(strip_cells)
     dom = max(per_kernel, key=lambda e: e["ms_per_step"])
     achieved = dom["achieved"]
     out = {

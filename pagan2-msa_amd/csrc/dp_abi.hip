@@ -286,8 +286,11 @@ void schedule_waves(const DiagIndex &dx, const std::vector<uint8_t> &cls, std::v
 //     (class 3): diagonals 0 and 1, the diagonals of those cells, sites without edges other than site 0;
 //   * operands up to 64 rows above the strip are in the ring (the feeder wave), which covers every operand in reach of the
 //     ring (PG_PIPE_REACH - 1 diagonals back); older ones come from L2 through the parent's descriptors.
-void plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, const RowBand &rb, const DiagIndex &dx,
-                 std::vector<StripPlan> *out) {
+// Returns false (and leaves *out empty) when some diagonal of some strip holds more multi-edge sites than the assist waves of
+// dp_pipe.hip keep in their lanes (64 slots; `max_sites`, default 56): every such diagonal would go through their general
+// code, several times slower than the tiled kernel's step.
+bool plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, const RowBand &rb, const DiagIndex &dx,
+                 std::vector<StripPlan> *out, int max_sites, int *sites_seen) {
     const int nd = Lx + Ly - 1, REACH = PG_PIPE_REACH, RING = PG_PIPE_RING;
     SiteFeat fl, fr;
     fl.build(L, Lx, true); fr.build(R, Ly, true);
@@ -303,6 +306,23 @@ void plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
     for (int j = 0; j < Ly; ++j) for (int t = 2; t < REACH && t <= fr.span[j]; ++t) cols_ge[t].push_back(j);
     const int n_strips = (Lx + PG_STRIP_ROWS - 1) / PG_STRIP_ROWS;
     const bool term_cxx = std::getenv("PAGAN_DP_STRIP_TERM") != nullptr;
+    {   // the multi-edge sites a diagonal of a strip holds: the strip's own rows (they stay) + the columns of its window (up to
+        // PG_STRIP_ROWS consecutive ones inside the strip's column range)
+        int worst = 0;
+        for (int k = 0; k < n_strips; ++k) {
+            const int r0 = k * PG_STRIP_ROWS, r1 = std::min(r0 + PG_STRIP_ROWS - 1, Lx - 1);
+            const int nl = fl.not_simple[r1 + 1] - fl.not_simple[r0];
+            const int c0 = rb.lo[r0], c1 = rb.hi[r1];
+            int nr = 0;
+            for (int c = c0; c <= c1; c += 32) {
+                const int e = std::min(c + PG_STRIP_ROWS - 1, c1);
+                nr = std::max(nr, fr.not_simple[e + 1] - fr.not_simple[c]);
+            }
+            worst = std::max(worst, nl + nr);
+        }
+        if (sites_seen) *sites_seen = worst;
+        if (worst > max_sites) { out->clear(); return false; }
+    }
     out->assign(n_strips, StripPlan());
     for (int k = 0; k < n_strips; ++k) {
         StripPlan &sp = (*out)[k];
@@ -430,6 +450,7 @@ void plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
             pk[7] = lead[t];
         }
     }
+    return true;
 }
 
 // Tiles of dp_tiles.hip: PG_TILE x PG_TILE squares of the matrix that the band touches.  The band is monotone,
@@ -794,14 +815,22 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
     if (!hj->ring_ok && !neg0 && edges_fit_tiles(jb.left, hj->Lx) && edges_fit_tiles(jb.right, hj->Ly))
         list_tiles(hj->Lx, *rb, &hj->tiles);
     // Row strips on the banded kernel (dp_pipe.hip, strip_feeder): a wide job whose model table fits LDS and whose edge lists
-    // fit the kernel's windows.  PAGAN_DP_WIDE=strips asks for them (A/B switch while the route is new).
+    // fit the kernel's windows, unless a diagonal of a strip would hold more multi-edge sites than the kernel's assist waves
+    // keep in their lanes (plan_strips).  PAGAN_DP_WIDE=tiles keeps every wide job on the tiled kernel (A/B switch).
     {
         const char *we = std::getenv("PAGAN_DP_WIDE");
-        const bool want = we && std::strcmp(we, "strips") == 0;
+        const bool want = !we || std::strcmp(we, "strips") == 0;
         if (want && use_pipe && !hj->ring_ok && !neg0 && !hj->tiles.empty() && jb.model->n_states * jb.model->n_states <= 256 &&
             hj->Lx >= 2 && hj->Ly >= 2 &&
             edges_fit_ring(jb.left, hj->Lx, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES) && edges_fit_ring(jb.right, hj->Ly, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES))
-            plan_strips(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, &hj->strips);
+        {
+            int max_sites = 56, seen = 0;
+            if (const char *e = std::getenv("PAGAN_DP_STRIP_SITES")) max_sites = std::atoi(e);
+            const bool ok = plan_strips(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, &hj->strips, max_sites, &seen);
+            if (std::getenv("PAGAN_DP_VERBOSE"))
+                std::fprintf(stderr, "pagan_dp: wide job %d x %d: at most %d multi-edge sites on a strip's diagonal: %s\n", hj->Lx, hj->Ly, seen,
+                             ok ? "row strips" : "tiles");
+        }
     }
     return PAGAN_OK;
 }
@@ -1481,14 +1510,35 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     std::vector<StripDev> sdev;
     std::vector<int> swhich;
     {
-        int lane_len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (size_t sj = 0; sj < which_striped.size(); ++sj) {
-            const int k = which_striped[sj], lane = (int)(sj % 8);
+        // a job to the XCD with the least work so far (largest jobs first); inside an XCD's list the strips of its jobs by
+        // first diagonal: workgroups are dispatched in index order and a strip holds its compute unit while it waits for the
+        // strip above, so what is resident should be what can run -- the fronts of all the XCD's jobs, not one job's whole
+        // chain.  (A job's strips stay in order: their first diagonals grow.)  A strip's device job is found through `where`.
+        std::vector<int> by_size(which_striped.begin(), which_striped.end());
+        std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int c) { return b->jobs[a].dx.cells > b->jobs[c].dx.cells; });
+        long long lane_cells[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        std::vector<std::vector<std::pair<int, int>>> lane_strips(8);          // (job, strip)
+        for (int k : by_size) {
+            int lane = 0;
+            for (int x = 1; x < 8; ++x) if (lane_cells[x] < lane_cells[lane]) lane = x;
+            lane_cells[lane] += b->jobs[k].dx.cells;
+            for (size_t q = 0; q < b->jobs[k].strips.size(); ++q) lane_strips[lane].push_back({k, (int)q});
+        }
+        // device jobs of the strips: job-major (a strip finds the strip above in the entry before its own)
+        std::unordered_map<long long, int> where;
+        for (int k : which_striped)
             for (size_t q = 0; q < b->jobs[k].strips.size(); ++q) {
-                const size_t at = 8 * (size_t)lane_len[lane]++ + lane;
-                if (swhich.size() <= at) swhich.resize((at / 8 + 1) * 8, -1);
-                swhich[at] = n + (int)sdev.size();
+                where[((long long)k << 20) | (long long)q] = n + (int)sdev.size();
                 sdev.push_back({k, (int)q, nullptr, nullptr, nullptr});
+            }
+        for (int lane = 0; lane < 8; ++lane) {
+            auto &ls = lane_strips[lane];
+            std::stable_sort(ls.begin(), ls.end(), [&](const std::pair<int, int> &a, const std::pair<int, int> &c) {
+                return b->jobs[a.first].strips[a.second].d0 < b->jobs[c.first].strips[c.second].d0; });
+            for (size_t pos = 0; pos < ls.size(); ++pos) {
+                const size_t at = 8 * pos + lane;
+                if (swhich.size() <= at) swhich.resize((at / 8 + 1) * 8, -1);
+                swhich[at] = where[((long long)ls[pos].first << 20) | (long long)ls[pos].second];
             }
         }
         b->strip_grid = (int)swhich.size();

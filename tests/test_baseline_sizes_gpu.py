@@ -2,7 +2,7 @@
 oracle -- score bits, alignment columns (skip columns included), used child edges -- and, per node, which fill kernel
 the library gave it (host-only planner, the same decision pagan_batch_create takes).
 
-    cfg2  16 x 2 kb DNA, no anchors        15 full matrices        tiles
+    cfg2  16 x 2 kb DNA, no anchors        15 full matrices        row strips on the banded kernel; tiles where a diagonal holds too many multi-edge sites
     cfg3  64 x 500 aa, WAG, no anchors     63 full matrices        tiles (211-state table)
     cfg4  32 x 100 kb DNA, prefix anchors  31 banded alignments    register wavefront (2e5-diagonal chains, 16-bit records)
     cfg5  512 x 10 kb DNA, prefix anchors  511 alignments, ALL of them checked (root: 1.05e9 cells, compacted, tiles; the
@@ -62,7 +62,14 @@ def check_nodes(pg, oracle, msa, nodes, expect, threads=1):
 def test_cfg2_16x2kb_dna_full_matrices(pg, oracle):
     msa = walk(pg, "cfg2_16x2kb_dna_full")
     assert msa.n_internal == 15
-    check_nodes(pg, oracle, msa, range(15), lambda k, info, route, c, w: None if route == "pg_fill_tiles_flow" else "expected the tiled kernel")
+    seen = set()
+
+    def expect(k, info, route, c, w):
+        seen.add(route)
+        return None if route in ("pg_fill_pipe (row strips)", "pg_fill_tiles_flow") else "expected row strips or the tiled kernel"
+
+    check_nodes(pg, oracle, msa, range(15), expect)
+    assert "pg_fill_pipe (row strips)" in seen, "the leaf pairs are meant to run as row strips: %s" % seen
 
 
 def test_cfg3_64x500aa_protein_full_matrices(pg, oracle):
@@ -108,4 +115,5 @@ def test_cfg5_512x10kb_dna_anchored_every_node(pg, oracle):
     order = sorted(range(511), key=lambda k: -infos[k].cells)
     check_nodes(pg, oracle, msa, order, expect, threads=max(1, min(12, (os.cpu_count() or 2) - 1)))
     assert any(r == "pg_fill_pipe" for rs in routes.values() for r, _ in rs), "the lower levels are banded alignments: %s" % routes
+    assert any(r == "pg_fill_pipe (row strips)" for rs in routes.values() for r, _ in rs), "the first wide levels are meant to run as row strips: %s" % routes
     assert any(r == "pg_fill_tiles_flow" for rs in routes.values() for r, _ in rs)

@@ -22,6 +22,7 @@ def same(a, b, what=""):
 @pytest.fixture
 def strips(monkeypatch):
     monkeypatch.setenv("PAGAN_DP_WIDE", "strips")
+    monkeypatch.setenv("PAGAN_DP_STRIP_SITES", "100000")      # (every wide job here runs as strips, however many multi-edge sites its diagonals hold)
 
 
 CASES = {

@@ -12,6 +12,13 @@ from pagan2_msa_amd import abi, synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def tiled_route(monkeypatch):
+    """wide jobs whose model table fits LDS run as row strips on the banded kernel by default (tests/test_strips_gpu.py):
+    these tests are about the tiled kernel"""
+    monkeypatch.setenv("PAGAN_DP_WIDE", "tiles")
+
+
 def same(a, b, what=""):
     assert a.status == b.status, what
     assert np.float64(a.score).tobytes() == np.float64(b.score).tobytes(), what + " score %r != %r" % (a.score, b.score)
