@@ -709,6 +709,7 @@ struct pagan_batch {
     int strip_grid = 0;          // workgroups of that launch (the strips of a job at indices of one residue mod 8, -1 padding)
     int *d_swhich = nullptr;     // [strip_grid] strip -> its PgDevJob (behind the n jobs of the batch) or -1
     size_t sfollow_begin = 0, sfollow_bytes = 0;     // the strips' follow words (zeroed before every launch)
+    bool strips_alone = false;   // the re-run after a strip found the strip above on another XCD: the strips' launch with nothing beside it
     int *d_tiles = nullptr;      // dp_tiles.hip: {job, tile row, tile column, position of the tile above} of all tiled jobs, ordered by
                                  // row + column; then the positions of the tiles to the left; then tile_off (pg_fill_tiles_flow)
     int *d_flow = nullptr;       // pg_fill_tiles_flow's queue head, finished tiles per diagonal, done flags (zeroed per launch)
@@ -950,6 +951,13 @@ int launch_fill(pagan_batch *b) {
     hipStream_t tile_stream = nullptr;
     static std::atomic<int> n_cu_dev[64];
     bool ev3_recorded = false;
+    if (b->n_striped > 0 && b->strips_alone) {
+        // (workgroup g of a dispatch runs on XCD g % 8 -- what puts a job's strips on one XCD -- when nothing else is being
+        //  dispatched beside it: first on the batch's stream, everything else behind it)
+        HIP_TRY(hipMemsetAsync(b->arena.dev + b->sfollow_begin, 0, b->sfollow_bytes, b->stream));
+        hipLaunchKernelGGL((pg_fill_pipe<true, true>), dim3(b->strip_grid), dim3(pg_pipe_block()), 0, b->stream,
+                           b->d_jobs, b->d_swhich, b->flags & ~0x800u, b->strip_grid);
+    }
     if (b->n_striped > 0 && b->tile_off.size() <= 1) {
         // (the strips' stream: beside the banded kernels, as the tiles')
         hipStream_t st = b->stream;
@@ -1041,7 +1049,7 @@ int launch_fill(pagan_batch *b) {
         }
         HIP_TRY(hipEventRecord(b->evk[5], b->stream)); b->evk_set[5] = true;
     }
-    if (b->n_striped > 0) {
+    if (b->n_striped > 0 && !b->strips_alone) {
         // row strips of the wide jobs on the banded kernel: one workgroup per strip, a job's strips on one XCD
         HIP_TRY(hipEventRecord(b->evk[3], tile_stream)); b->evk_set[3] = true; ev3_recorded = true;
         HIP_TRY(hipMemsetAsync(b->arena.dev + b->sfollow_begin, 0, b->sfollow_bytes, tile_stream));
@@ -1810,10 +1818,25 @@ int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
             const int st = *reinterpret_cast<const int *>(ends.data() + kEndStride * (size_t)k);
             again = again || st == PG_STATUS_PATH_CHECK || st == 2;
         }
+        // A strip that found the strip above on another XCD gave up (dp_pipe.hip, strip_feeder: tag 11): the strips' launch
+        // once more with nothing dispatched beside it
+        bool strips_again = false;
+        for (int k = 0; k < b->n && !b->strips_alone; ++k) {
+            const int st = *reinterpret_cast<const int *>(ends.data() + kEndStride * (size_t)k);
+            if (!b->jobs[k].strips.empty() && (st & 0x40000000) && (st & 0xf) == 11) strips_again = true;
+        }
+        if (strips_again) {
+            b->strips_alone = true;
+            for (int k = 0; k < b->n; ++k)
+                if (!b->jobs[k].strips.empty()) HIP_TRY(hipMemsetAsync(b->dj[k].fill_status, 0, sizeof(int), b->stream));
+            again = true;
+        }
         const char *re = std::getenv("PAGAN_DP_RERUN");
         if (again && !(re && std::strcmp(re, "0") == 0)) {             // (once per fetch; the batch stays without followers)
-            if (std::getenv("PAGAN_DP_VERBOSE")) std::fprintf(stderr, "pagan_dp: path check failed: running the batch again without follower workgroups\n");
-            b->no_follow = true;
+            if (std::getenv("PAGAN_DP_VERBOSE"))
+                std::fprintf(stderr, strips_again ? "pagan_dp: a row strip found the strip above on another XCD: running the batch again, the strips alone\n"
+                                                  : "pagan_dp: path check failed: running the batch again without follower workgroups\n");
+            if (!strips_again) b->no_follow = true;
             ++b->reruns;
             int rc = pagan_batch_run(b);
             if (rc != PAGAN_OK) return rc;

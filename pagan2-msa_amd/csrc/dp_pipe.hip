@@ -2478,7 +2478,7 @@ __device__ __noinline__ void pipe_follower(const PgDevJob *__restrict__ jobs, co
 #define PHALO 16                  // rows above the strip the feeder keeps in the ring: a ring operand lies at most PAGE - 1 <= 16 rows up
 #define PFEED 32                  // diagonals the feeder requests from L2 at a time: 4 per load (lane = diagonal % 4, row), 8 loads, one round trip
 static_assert(PHALO >= PAGE - 1 && 64 / PHALO * 8 == PFEED, "feeder geometry");
-__device__ __noinline__ void strip_feeder(const PgDevJob *__restrict__ job, cdesc8_p psc, int tid, int wave) {
+__device__ __noinline__ void strip_feeder(const PgDevJob *__restrict__ job, cdesc8_p psc, int tid, int wave, unsigned flags) {
     const int lane = tid & 63;
     const int nd = job->nd, d0 = job->d_first;
     const int hq = lane / PHALO, hr = lane % PHALO;                // this lane's diagonal (of four) and halo row in a request
@@ -2495,7 +2495,8 @@ __device__ __noinline__ void strip_feeder(const PgDevJob *__restrict__ job, cdes
     {   // the strip above runs on this XCD (its scores are read from the XCD's L2)
         int id = 0, spin = 0;
         while ((id = peek_l2(prev + 1)) == 0 && spin < (1 << 22) && flag_load(&PM.abort_flag) == 0) { __builtin_amdgcn_s_sleep(16); ++spin; }
-        if (id != (int)my_xcc_id() + 1 && flag_load(&PM.abort_flag) == 0) flag_store(&PM.abort_flag, PTAG(11));
+        // (debug flag 0x800, tests: as if it did not -- the host clears the bit when it launches the strips alone)
+        if ((id != (int)my_xcc_id() + 1 || (flags & 0x800u)) && flag_load(&PM.abort_flag) == 0) flag_store(&PM.abort_flag, PTAG(11));
     }
     int landed1 = 0, p_dn = d0 - 1, slot = d0 % PRK;
     for (int t0 = d0; t0 < nd && flag_load(&PM.abort_flag) == 0; t0 += PFEED) {
@@ -2617,7 +2618,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // uniform: keeps the schedule and the step counter in SGPRs
     const int up = (wave + PNW - 1) % PNW, dn = (wave + 1) % PNW;
     if (STRIP && wave == job->feed_wave) {
-        strip_feeder(job, psc, tid, wave);
+        strip_feeder(job, psc, tid, wave, flags);
         if (lane == 0) {
             const int aborted = flag_load(&PM.abort_flag);
             if (aborted != 0) *(PG_GLOBAL int *)job->fill_status = aborted;

@@ -87,3 +87,18 @@ def test_batch_of_striped_jobs(pg, oracle, strips):
     got = pg.align_batch(jobs)
     for k, (left, right, model, band) in enumerate(jobs):
         same(got[k], oracle.dp_align(left, right, model), "job %d" % k)
+
+
+def test_a_strip_on_another_xcd_runs_the_batch_again_alone(pg, oracle, strips, monkeypatch):
+    """debug flag 0x800: every feeder reports the strip above on another XCD; the fetch launches the strips once more with
+    nothing dispatched beside them (the host clears the bit for that launch) and returns that result"""
+    monkeypatch.setenv("PAGAN_DP_DEBUG_FLAGS", "0x800")
+    left = synth.random_graph(500, 15, 71, p_extra=0.08, max_deg=3, max_span=12)
+    right = synth.random_graph(450, 15, 72, p_extra=0.08, max_deg=3, max_span=12)
+    model = synth.random_model(15, 9)
+    b = pg.Batch([(left, right, model, None)])
+    b.run()
+    got = b.fetch()[0]
+    assert b.debug_reruns() == 1
+    b.close()
+    same(got, oracle.dp_align(left, right, model))
