@@ -27,6 +27,8 @@ def parse(path):
 
 
 def short(name):
+    if "pg_fill_pipeILb1ELb1E" in name:          # pg_fill_pipe<true, true>: row strips of wide jobs
+        return "pg_fill_pipe (row strips)"
     for k in ("pg_fill_pipe", "pg_backptr", "pg_fill_tiles_flow", "pg_fill_tiles", "pg_fill_wavefront", "pg_trace_spec", "pg_trace_compose",
               "pg_trace_emit", "pg_end_corner"):
         if k in name:
@@ -43,7 +45,7 @@ def main():
     kernels = {}
     for (name, grid, wg), vals in w.items():
         k = short(name)
-        if not k.startswith("pg_fill") and k != "pg_backptr":
+        if not k.startswith("pg_fill") and k != "pg_backptr":        # (the strips' name starts with pg_fill too)
             continue
         fv = f.get((name, grid, wg), [])
         # Two levels can share a grid (the tiled kernel caps it): group a grid's dispatches by size (1 %); a group with more
@@ -69,11 +71,25 @@ def main():
     for k, e in kernels.items():
         wr = 1024.0 * sum(e["WRITE_SIZE_kb_per_launch"])
         fe = 1024.0 * sum(x for x in e["FETCH_SIZE_kb_per_launch"] if x is not None)
-        kc = next((q["cells"] for q in bench["roofline"].get("kernels", []) if q["kernel"] == k), cells)
+        kc = next((q["cells"] for q in bench["roofline"].get("kernels", []) if q["kernel"] == k), None)
+        if kc is None:
+            # the wide jobs' slot of a batch: row strips where a job qualifies, tiles otherwise (bench.py names the slot by both)
+            slot = next((q for q in bench["roofline"].get("kernels", []) if k in q["kernel"].split(" + ")), None)
+            if slot is not None and "row_strip_cells" in slot:
+                kc = slot["row_strip_cells"] if k == "pg_fill_pipe (row strips)" else slot["cells"] - slot["row_strip_cells"]
+            else:
+                kc = cells
+        kc = max(int(kc), 1)
         per_kernel.append(dict(kernel=k, launches_per_step=len(e["grids"]), cells=kc, write_bytes_per_step=wr, fetch_bytes_per_step_raw=fe,
                                write_bytes_per_cell=wr / kc, fetch_bytes_per_cell=fe / kc, **e))
     dom = bench["roofline"]["kernel"]
-    main_k = next(p for p in per_kernel if p["kernel"] == dom)
+    parts = [p for p in per_kernel if p["kernel"] in dom.split(" + ")]
+    main_k = {"launches_per_step": sum(p["launches_per_step"] for p in parts),
+              "write_bytes_per_step": sum(p["write_bytes_per_step"] for p in parts),
+              "fetch_bytes_per_step_raw": sum(p["fetch_bytes_per_step_raw"] for p in parts)}
+    kcd = max(sum(p["cells"] for p in parts), 1)
+    main_k["write_bytes_per_cell"] = main_k["write_bytes_per_step"] / kcd
+    main_k["fetch_bytes_per_cell"] = main_k["fetch_bytes_per_step_raw"] / kcd
     out = {
         "command": "rocprofv3 --kernel-trace --pmc WRITE_SIZE (and, in a separate pass, FETCH_SIZE) -- python3 bench.py --workload %s --steps 2 "
                    "--warmup 1 --no-cpu-baseline (tools/profile_bench.sh / profile_cfg2.sh); per-dispatch sums by tools/rocpd_summary.py pmc, "
