@@ -186,6 +186,15 @@ int  pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, cons
                          uint8_t *cls, int32_t n_cls, int32_t *sched, int32_t sched_cap, int32_t *sched_len,
                          int32_t *lead_req /* [n_cls] or NULL: diagonal the downstream wave must have completed
                                               before diagonal d may overwrite its row of the LDS ring, -1 none */);
+/* diagnostic, host only: the row strips a wide job would be filled as (dp_pipe.hip, strip_feeder), whether
+ * or not the library would route it that way (max_sites <= 0: no bound on the multi-edge sites of a diagonal).  Returns the
+ * number of strips (0: the bound refused the job), < 0 on error.  strips[6 * k] = first row, last row, first diagonal, last
+ * diagonal + 1, feeder wave (-1: none), first column staged; for strip k and diagonal d in [first, last + 1) the entry
+ * desc[4 * (desc_off[k] + d - first)] = first row of the strip on d, last row (first - 1: none), the cell index of the first
+ * row's score in the JOB's arrays, class (0 simple .. 3 general).  desc_off[k] = entries before strip k's (n + 1 values). */
+int  pagan_dp_debug_strips(const pagan_graph *left, const pagan_graph *right, const pagan_band *band, int32_t max_sites,
+                           int32_t *strips /* [6 * cap] */, int32_t cap, int64_t *desc_off /* [cap + 1] */,
+                           int64_t *desc /* [4 * desc_cap] */, int64_t desc_cap);
 /* diagnostic, host only: the tiles the wide-matrix kernel (dp_tiles.hip) would be launched over for this
  * job, as (tile row, tile column) pairs of side *tile_side; returns the number of tiles (pairs written:
  * min(count, cap)), 0 when the job cannot be tiled (a tile's sites have too many bwd edges), < 0 on error */

@@ -216,6 +216,25 @@ def debug_route(left, right, model, band=None):
     return ROUTES[rc], bool(n[0]), int(n[1])
 
 
+def debug_strips(left, right, band=None, max_sites=0):
+    """Diagnostic (host only): the row strips a wide job would be filled as -- [(first row, last row, first diagonal, last
+    diagonal + 1, feeder wave, first column staged, desc)] with desc[d - first diagonal] = (first row on d, last row, cell index
+    of the first row's score in the job's arrays, class); [] when max_sites refuses the job."""
+    import numpy as np
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    cap = Lx // 192 + 2
+    desc_cap = (cap + 1) * (Ly + 192 + 64) + 64
+    strips = np.zeros(6 * cap, np.int32)
+    off = np.zeros(cap + 1, np.int64)
+    desc = np.zeros(4 * desc_cap, np.int64)
+    n = lib().pagan_dp_debug_strips(C.byref(left.c), C.byref(right.c), C.byref(band.c) if band is not None else None, max_sites,
+                                    strips.ctypes.data_as(C.POINTER(C.c_int32)), cap, off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                    desc.ctypes.data_as(C.POINTER(C.c_int64)), desc_cap)
+    _check(min(n, 0), "pagan_dp_debug_strips")
+    desc = desc.reshape(-1, 4)
+    return [tuple(int(v) for v in strips[6 * k: 6 * k + 6]) + (desc[off[k]: off[k + 1]].copy(),) for k in range(n)]
+
+
 def debug_plan(left, right, band=None, with_lead=False):
     """Diagnostic (host only): (classes[Lx+Ly-1] uint8, [awake intervals of wave 0..3]) the banded fill kernel
     would be given for this job; with_lead adds the per-diagonal downstream-progress requirement."""

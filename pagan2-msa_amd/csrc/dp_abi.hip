@@ -1325,6 +1325,41 @@ int pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, const
     return PAGAN_OK;
 }
 
+int pagan_dp_debug_strips(const pagan_graph *left, const pagan_graph *right, const pagan_band *band, int32_t max_sites,
+                          int32_t *strips, int32_t cap, int64_t *desc_off, int64_t *desc, int64_t desc_cap) {
+    if (!left || !right || !strips || !desc_off || !desc || cap < 0 || desc_cap < 0) return PAGAN_E_ARG;
+    int rc;
+    if ((rc = check_graph(left)) != PAGAN_OK) return rc;
+    if ((rc = check_graph(right)) != PAGAN_OK) return rc;
+    const int Lx = left->n_sites - 1, Ly = right->n_sites - 1;
+    RowBand rb;
+    if ((rc = rb.build(Lx, Ly, band)) != PAGAN_OK) return rc;
+    DiagIndex dx;
+    dx.build(Lx, Ly, rb);
+    std::vector<StripPlan> plan;
+    int seen = 0;
+    if (!plan_strips(left, right, Lx, Ly, rb, dx, &plan, max_sites > 0 ? max_sites : (1 << 30), &seen)) return 0;
+    if ((int)plan.size() > cap) return PAGAN_E_ARG;
+    int64_t at = 0;
+    for (size_t k = 0; k < plan.size(); ++k) {
+        const StripPlan &sp = plan[k];
+        int32_t *o = strips + 6 * k;
+        o[0] = sp.r0; o[1] = sp.r1; o[2] = sp.d0; o[3] = sp.d1; o[4] = sp.feed_wave; o[5] = sp.col_first;
+        desc_off[k] = at;
+        const int m = sp.d1 - sp.d0;
+        if (at + m > desc_cap) return PAGAN_E_ARG;
+        for (int t = 0; t < m; ++t) {
+            const int *pk = sp.psc.data() + 8 * (size_t)t;
+            const long long boff = ((long long)pk[3] << 32) | (unsigned)pk[2];
+            int64_t *e = desc + 4 * (at + t);
+            e[0] = pk[0]; e[1] = pk[1]; e[2] = boff / 24; e[3] = pk[4] & 7;
+        }
+        at += m;
+    }
+    desc_off[plan.size()] = at;
+    return (int)plan.size();
+}
+
 int pagan_dp_debug_tiles(const pagan_graph *left, const pagan_graph *right, const pagan_band *band, int32_t *tiles,
                          int32_t cap, int32_t *tile_side) {
     if (!left || !right || !tiles || cap < 0) return PAGAN_E_ARG;
