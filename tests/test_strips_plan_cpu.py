@@ -93,6 +93,10 @@ def test_the_site_bound_refuses_dense_jobs(pg):
     assert len(pg.debug_strips(left, right, max_sites=0)) == 4
     model = synth.random_model(15, 1)
     assert pg.debug_route(left, right, model)[0] == "pg_fill_tiles_flow"
-    sparse_l = synth.random_graph(600, 15, 8, p_extra=0.02, max_deg=3, max_span=8)
-    sparse_r = synth.random_graph(600, 15, 9, p_extra=0.02, max_deg=3, max_span=8)
+
+    def unweighted(g):       # (random_graph gives half of its edges a weight, and a weighted edge makes a site a multi-edge one)
+        return abi.Graph(g.state, g.bwd_off, g.bwd_src, np.zeros_like(g.bwd_logw), g.bwd_eid, n_edges=g.n_edges)
+
+    sparse_l = unweighted(synth.random_graph(600, 15, 8, p_extra=0.02, max_deg=3, max_span=8))
+    sparse_r = unweighted(synth.random_graph(600, 15, 9, p_extra=0.02, max_deg=3, max_span=8))
     assert pg.debug_route(sparse_l, sparse_r, model)[0] == "pg_fill_pipe (row strips)"
