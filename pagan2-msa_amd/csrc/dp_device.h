@@ -108,5 +108,7 @@ struct PgDevJob {
     const int *prev_follow;  // the previous strip's follow words (null: first strip)
     const int *pdsc;         // the PARENT's dsc array: the whole band's rows per diagonal, for operands in other strips
 };
+#ifndef PG_STRIP_ROWS
 #define PG_STRIP_ROWS 192        // rows of a strip: three of dp_pipe.hip's four compute waves (the fourth feeds the rows above)
+#endif
 #define PG_STRIP_TERM 8          // psc class bit of a strip diagonal that holds a cell of the first / last column (gap extension differs)

@@ -54,6 +54,7 @@ def main():
     sc = {}
     for kernel in ("tiles", "strips"):
         os.environ["PAGAN_DP_WIDE"] = kernel
+        os.environ["PAGAN_DP_STRIP_SITES"] = "100000"
         print(kernel, pg.debug_route(left, right, model, band))
         b = pg.Batch([(left, right, model, band)], flags=flags)
         b.run(); b.sync()
