@@ -289,8 +289,11 @@ void schedule_waves(const DiagIndex &dx, const std::vector<uint8_t> &cls, std::v
 // Returns false (and leaves *out empty) when some diagonal of some strip holds more multi-edge sites than the assist waves of
 // dp_pipe.hip keep in their lanes (64 slots; `max_sites`, default 56): every such diagonal would go through their general
 // code, several times slower than the tiled kernel's step.
+// big_table (S * S > 256): the compute waves run the C++ step and the assist waves stage EVERY multi-edge cell (and gather every
+// cell's model score) with their general code: class 1 = multi-edge cells with every operand in the ring, 2 = one past it; no bound
+// on the sites of a diagonal.
 bool plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, const RowBand &rb, const DiagIndex &dx,
-                 std::vector<StripPlan> *out, int max_sites, int *sites_seen) {
+                 std::vector<StripPlan> *out, int max_sites, int *sites_seen, bool big_table) {
     const int nd = Lx + Ly - 1, REACH = PG_PIPE_REACH, RING = PG_PIPE_RING;
     SiteFeat fl, fr;
     fl.build(L, Lx, true); fr.build(R, Ly, true);
@@ -321,7 +324,7 @@ bool plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
             worst = std::max(worst, nl + nr);
         }
         if (sites_seen) *sites_seen = worst;
-        if (worst > max_sites) { out->clear(); return false; }
+        if (worst > max_sites && !big_table) { out->clear(); return false; }
     }
     out->assign(n_strips, StripPlan());
     for (int k = 0; k < n_strips; ++k) {
@@ -384,7 +387,7 @@ bool plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
             uint8_t c;
             if (general) c = 3;
             else if (run > 0) c = 2;
-            else if (multi) c = hard ? 2 : 1;
+            else if (multi) c = (hard && !big_table) ? 2 : 1;
             else c = 0;
             ring2[t] = c == 2 && run == 0;
             const bool term = (d >= lo && d <= hi) || (d - (Ly - 1) >= lo && d - (Ly - 1) <= hi);      // a cell of column 0 / column Ly-1
@@ -435,7 +438,8 @@ bool plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
         for (int t = m; t-- > 0;) {
             const int nx = t + PG_PIPE_ASSIST;
             if (nx >= m) { hop[t] = 4095; continue; }
-            hop[t] = (cls[nx] & 7) == 2 ? 1 : std::min(4095, hop[nx] + 1);
+            const bool work = (cls[nx] & 7) == 2 || (big_table && (cls[nx] & 7) <= 1);     // (large tables: every interior diagonal's model scores)
+            hop[t] = work ? 1 : std::min(4095, hop[nx] + 1);
         }
         unsigned mask = 0;
         for (int t = 0; t < m; ++t) {
@@ -445,7 +449,9 @@ bool plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
             const long long boff = 24 * (dx.doff[d] + (smin[t] - dx.imin[d]));
             pk[2] = (int)(boff & 0xffffffffLL); pk[3] = (int)(boff >> 32);
             mask = t >= 1 ? (((mask << 1) | 2u) & (((1u << REACH) - 1u) & ~1u)) : 0u;
-            pk[4] = (int)(cls[t] | ((ring2[t] ? 1u : 0u) << 4) | (mask << 5) | ((unsigned)hop[t] << 20));
+            // bit 4: large tables -- the next step is hot too; small tables -- a class 2 diagonal with every operand in the ring
+            const unsigned pair = big_table ? (t + 1 < m && (cls[t + 1] & 7) <= 2 ? 1u : 0u) : (ring2[t] ? 1u : 0u);
+            pk[4] = (int)(cls[t] | (pair << 4) | (mask << 5) | ((unsigned)hop[t] << 20));
             pk[5] = 0; pk[6] = 0;
             pk[7] = lead[t];
         }
@@ -707,6 +713,7 @@ struct pagan_batch {
     int n_ring = 0, n_wide = 0, n_tiled = 0;
     int n_striped = 0;           // of the n_tiled jobs (listed first among them): filled as row strips by pg_fill_pipe<true, true>
     int strip_grid = 0;          // workgroups of that launch (the strips of a job at indices of one residue mod 8, -1 padding)
+    int strip_grid_big = 0;      // ... of the launch for the jobs whose model table does not fit LDS (listed behind the others' in d_swhich)
     int *d_swhich = nullptr;     // [strip_grid] strip -> its PgDevJob (behind the n jobs of the batch) or -1
     size_t sfollow_begin = 0, sfollow_bytes = 0;     // the strips' follow words (zeroed before every launch)
     bool strips_alone = false;   // the re-run after a strip found the strip above on another XCD: the strips' launch with nothing beside it
@@ -821,13 +828,19 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
     {
         const char *we = std::getenv("PAGAN_DP_WIDE");
         const bool want = !we || std::strcmp(we, "strips") == 0;
-        if (want && use_pipe && !hj->ring_ok && !neg0 && !hj->tiles.empty() && jb.model->n_states * jb.model->n_states <= 256 &&
+        // Models whose table does not fit LDS (S > 16) run as strips only on request (PAGAN_DP_STRIP_STATES = the largest model that
+        // does): correct (tests/test_strips_gpu.py) and slower than the tiles from the third level of a tree on -- the assist
+        // waves gather a model score for every cell and stage every multi-edge cell with their general code (cfg3: 23.4 -> 57.8 ms).
+        int max_states = 16;
+        if (const char *e = std::getenv("PAGAN_DP_STRIP_STATES")) max_states = std::atoi(e);
+        if (want && use_pipe && !hj->ring_ok && !neg0 && !hj->tiles.empty() && jb.model->n_states <= max_states &&
             hj->Lx >= 2 && hj->Ly >= 2 &&
             edges_fit_ring(jb.left, hj->Lx, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES) && edges_fit_ring(jb.right, hj->Ly, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES))
         {
             int max_sites = 56, seen = 0;
             if (const char *e = std::getenv("PAGAN_DP_STRIP_SITES")) max_sites = std::atoi(e);
-            const bool ok = plan_strips(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, &hj->strips, max_sites, &seen);
+            const bool ok = plan_strips(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, &hj->strips, max_sites, &seen,
+                                        jb.model->n_states * jb.model->n_states > 256);
             if (std::getenv("PAGAN_DP_VERBOSE"))
                 std::fprintf(stderr, "pagan_dp: wide job %d x %d: at most %d multi-edge sites on a strip's diagonal: %s\n", hj->Lx, hj->Ly, seen,
                              ok ? "row strips" : "tiles");
@@ -955,8 +968,12 @@ int launch_fill(pagan_batch *b) {
         // (workgroup g of a dispatch runs on XCD g % 8 -- what puts a job's strips on one XCD -- when nothing else is being
         //  dispatched beside it: first on the batch's stream, everything else behind it)
         HIP_TRY(hipMemsetAsync(b->arena.dev + b->sfollow_begin, 0, b->sfollow_bytes, b->stream));
-        hipLaunchKernelGGL((pg_fill_pipe<true, true>), dim3(b->strip_grid), dim3(pg_pipe_block()), 0, b->stream,
-                           b->d_jobs, b->d_swhich, b->flags & ~0x800u, b->strip_grid);
+        if (b->strip_grid > 0)
+            hipLaunchKernelGGL((pg_fill_pipe<true, true>), dim3(b->strip_grid), dim3(pg_pipe_block()), 0, b->stream,
+                               b->d_jobs, b->d_swhich, b->flags & ~0x800u, b->strip_grid);
+        if (b->strip_grid_big > 0)
+            hipLaunchKernelGGL((pg_fill_pipe<false, true>), dim3(b->strip_grid_big), dim3(pg_pipe_block()), 0, b->stream,
+                               b->d_jobs, b->d_swhich + b->strip_grid, b->flags & ~0x800u, b->strip_grid_big);
     }
     if (b->n_striped > 0 && b->tile_off.size() <= 1) {
         // (the strips' stream: beside the banded kernels, as the tiles')
@@ -1053,8 +1070,12 @@ int launch_fill(pagan_batch *b) {
         // row strips of the wide jobs on the banded kernel: one workgroup per strip, a job's strips on one XCD
         HIP_TRY(hipEventRecord(b->evk[3], tile_stream)); b->evk_set[3] = true; ev3_recorded = true;
         HIP_TRY(hipMemsetAsync(b->arena.dev + b->sfollow_begin, 0, b->sfollow_bytes, tile_stream));
-        hipLaunchKernelGGL((pg_fill_pipe<true, true>), dim3(b->strip_grid), dim3(pg_pipe_block()), 0, tile_stream,
-                           b->d_jobs, b->d_swhich, b->flags, b->strip_grid);
+        if (b->strip_grid > 0)
+            hipLaunchKernelGGL((pg_fill_pipe<true, true>), dim3(b->strip_grid), dim3(pg_pipe_block()), 0, tile_stream,
+                               b->d_jobs, b->d_swhich, b->flags, b->strip_grid);
+        if (b->strip_grid_big > 0)
+            hipLaunchKernelGGL((pg_fill_pipe<false, true>), dim3(b->strip_grid_big), dim3(pg_pipe_block()), 0, tile_stream,
+                               b->d_jobs, b->d_swhich + b->strip_grid, b->flags, b->strip_grid_big);
     }
     if (b->tile_off.size() > 1) {
         // after the banded kernels: their workgroups get compute units first; the persistent waves below hold theirs
@@ -1338,7 +1359,7 @@ int pagan_dp_debug_strips(const pagan_graph *left, const pagan_graph *right, con
     dx.build(Lx, Ly, rb);
     std::vector<StripPlan> plan;
     int seen = 0;
-    if (!plan_strips(left, right, Lx, Ly, rb, dx, &plan, max_sites > 0 ? max_sites : (1 << 30), &seen)) return 0;
+    if (!plan_strips(left, right, Lx, Ly, rb, dx, &plan, max_sites > 0 ? max_sites : (1 << 30), &seen, false)) return 0;
     if ((int)plan.size() > cap) return PAGAN_E_ARG;
     int64_t at = 0;
     for (size_t k = 0; k < plan.size(); ++k) {
@@ -1557,16 +1578,6 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         // first diagonal: workgroups are dispatched in index order and a strip holds its compute unit while it waits for the
         // strip above, so what is resident should be what can run -- the fronts of all the XCD's jobs, not one job's whole
         // chain.  (A job's strips stay in order: their first diagonals grow.)  A strip's device job is found through `where`.
-        std::vector<int> by_size(which_striped.begin(), which_striped.end());
-        std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int c) { return b->jobs[a].dx.cells > b->jobs[c].dx.cells; });
-        long long lane_cells[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        std::vector<std::vector<std::pair<int, int>>> lane_strips(8);          // (job, strip)
-        for (int k : by_size) {
-            int lane = 0;
-            for (int x = 1; x < 8; ++x) if (lane_cells[x] < lane_cells[lane]) lane = x;
-            lane_cells[lane] += b->jobs[k].dx.cells;
-            for (size_t q = 0; q < b->jobs[k].strips.size(); ++q) lane_strips[lane].push_back({k, (int)q});
-        }
         // device jobs of the strips: job-major (a strip finds the strip above in the entry before its own)
         std::unordered_map<long long, int> where;
         for (int k : which_striped)
@@ -1574,17 +1585,32 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
                 where[((long long)k << 20) | (long long)q] = n + (int)sdev.size();
                 sdev.push_back({k, (int)q, nullptr, nullptr, nullptr});
             }
-        for (int lane = 0; lane < 8; ++lane) {
-            auto &ls = lane_strips[lane];
-            std::stable_sort(ls.begin(), ls.end(), [&](const std::pair<int, int> &a, const std::pair<int, int> &c) {
-                return b->jobs[a.first].strips[a.second].d0 < b->jobs[c.first].strips[c.second].d0; });
-            for (size_t pos = 0; pos < ls.size(); ++pos) {
-                const size_t at = 8 * pos + lane;
-                if (swhich.size() <= at) swhich.resize((at / 8 + 1) * 8, -1);
-                swhich[at] = where[((long long)ls[pos].first << 20) | (long long)ls[pos].second];
+        // two dispatches: the jobs whose model table fits LDS (pg_fill_pipe<true, true>), then the others (<false, true>)
+        for (int big = 0; big < 2; ++big) {
+            std::vector<int> by_size;
+            for (int k : which_striped) if ((eff[k].model->n_states * eff[k].model->n_states > 256) == (big == 1)) by_size.push_back(k);
+            std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int c) { return b->jobs[a].dx.cells > b->jobs[c].dx.cells; });
+            long long lane_cells[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            std::vector<std::vector<std::pair<int, int>>> lane_strips(8);          // (job, strip)
+            for (int k : by_size) {
+                int lane = 0;
+                for (int x = 1; x < 8; ++x) if (lane_cells[x] < lane_cells[lane]) lane = x;
+                lane_cells[lane] += b->jobs[k].dx.cells;
+                for (size_t q = 0; q < b->jobs[k].strips.size(); ++q) lane_strips[lane].push_back({k, (int)q});
             }
+            const size_t first = swhich.size();                          // (a multiple of 8)
+            for (int lane = 0; lane < 8; ++lane) {
+                auto &ls = lane_strips[lane];
+                std::stable_sort(ls.begin(), ls.end(), [&](const std::pair<int, int> &a, const std::pair<int, int> &c) {
+                    return b->jobs[a.first].strips[a.second].d0 < b->jobs[c.first].strips[c.second].d0; });
+                for (size_t pos = 0; pos < ls.size(); ++pos) {
+                    const size_t at = first + 8 * pos + lane;
+                    if (swhich.size() <= at) swhich.resize(first + ((at - first) / 8 + 1) * 8, -1);
+                    swhich[at] = where[((long long)ls[pos].first << 20) | (long long)ls[pos].second];
+                }
+            }
+            (big ? b->strip_grid_big : b->strip_grid) = (int)(swhich.size() - first);
         }
-        b->strip_grid = (int)swhich.size();
         b->dj.resize((size_t)n + sdev.size());
     }
     which_ring.resize(n, 0);

@@ -1007,7 +1007,12 @@ struct AssistGen {
             bool ns = false;
             if (row <= hi) {
                 const pg_i4 rL = PM.recL[row & (PRW - 1)], cR = PM.recR[j & (PRW - 1)];
-                if (!TAB_LDS) PM.ssm[stg][row & (PNT - 1)] = far_f32(table + ((rL.x & 0xffff) + (cR.x & 0xffff) * S));
+                if (!TAB_LDS) {
+                    // (row strips: a cell of row 0 / column 0 is computed like any other; site 0 has no state, its cells' match
+                    //  terms meet -inf operands only: any finite score will do)
+                    const int sl = rL.x & 0xffff, sr = cR.x & 0xffff;
+                    PM.ssm[stg][row & (PNT - 1)] = (sl < S && sr < S) ? far_f32(table + (sl + sr * S)) : 0.0f;
+                }
                 ns = cls != 0 && !(rL.x & cR.x & PR_SIMPLE);
             }
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(ns);
@@ -1191,7 +1196,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
             const int lo_a = ax, cmin_a = d - ay;
             const int hi_t = pair_d ? by : ay, cmax_t = pair_d ? d2 - bx : d - ax;      // the later diagonal's upper ends
             if (rows_ld <= hi_t) rows_ld = POLL(&PM.loaded[0], hi_t + 1, 1);
-            if (cols_ld <= cmax_t) cols_ld = POLL(&PM.loaded[1], cmax_t + 1, 2);
+            if (cols_ld <= cmax_t && cmax_t < Ly) cols_ld = POLL(&PM.loaded[1], cmax_t + 1, 2);
             // ---- the slots ----
             if (!trk_valid) { s_site = -1; seen_row = lo_a; seen_col = cmin_a; trk_valid = true; }
             if (s_site >= 0 && s_site < (s_left ? lo_a : cmin_a)) s_site = -1;          // the band has left this row / column behind
@@ -1463,9 +1468,11 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
 }
 
 // ---- assist waves, large model tables: every multi-edge cell of the class 0..2 diagonals, staged with back-pointer words ----
-template <bool TAB_LDS>
-__device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, bool reduced_terminal) {
+template <bool TAB_LDS, bool STRIP>
+__device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, unsigned flags) {
     static_assert(!TAB_LDS, "small tables: pipe_assist_lean");
+    const bool reduced_terminal = !(flags & 2u);
+    const bool term_on = STRIP && !(flags & 1u);                   // (row strips: cells of the first / last row and column come this way too)
     const int nd = job->nd, S = job->S;
     const gdouble_w sc_out = (gdouble_w)job->sc;
     const gfloat_p table = (gfloat_p)job->table;
@@ -1502,6 +1509,7 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
     double q_fx[4] = {0, 0, 0, 0}, q_fy[4] = {0, 0, 0, 0}, q_fm[4] = {0, 0, 0, 0};
     bool q_far[4] = {false, false, false, false};
     int scan_d = a;                                                // next diagonal whose descriptor has not been looked at
+    if (STRIP) { const int d0 = job->d_first; scan_d = d0 + (a + 3 - d0 % 3) % 3; }       // (the strip's first diagonal of this wave's residue)
 
 #ifdef PG_PIPE_STATS
     long long as_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // cycles: prepare (rest), waiting for the compute waves, compute, publish; inside prepare: scan, batch, decode, far
@@ -1515,12 +1523,12 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
 #else
 #define ASTAMP(k)
 #endif
-    const AssistGen<TAB_LDS> gen = assist_gen<TAB_LDS>(job, psc, a, lane, reduced_terminal);     // (large tables: the general code, inline)
+    const AssistGen<TAB_LDS> gen = assist_gen<TAB_LDS>(job, psc, a, lane, reduced_terminal, term_on);     // (large tables: the general code, inline)
     // looks for the next diagonal of this wave with work and prepares it
     // descriptor of scan_d, requested a pass ahead -- as a VECTOR load (lanes 0..7 one word each): a scalar load shares its
     // counter with the LDS operations and returns out of order, so the first LDS read behind it would wait for it (~2k cycles)
     auto desc_req = [&](int dd) { return ((PG_GLOBAL const int *)psc)[8 * (dd < nd ? dd : nd) + (lane & 7)]; };   // (the array carries one entry of padding)
-    int q_next = desc_req(a);
+    int q_next = desc_req(scan_d);
     auto prepare = [&]() {
         q_d = -1;
         while (scan_d < nd) {
@@ -1537,7 +1545,10 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
             const int cls = (TAB_LDS && cls0 == 2 && (cur_s4 & 16)) ? 1 : cls0;
             const int lo = cur_x, hi = cur_y;
             if (rows_ld <= hi) rows_ld = POLL(&PM.loaded[0], hi + 1, 1);
-            if (cols_ld <= d - lo) cols_ld = POLL(&PM.loaded[1], d - lo + 1, 2);
+            {   // (a row strip's diagonals behind its last cell hold no row: nothing to wait for beyond the last column)
+                const int cmax = d - lo < job->Ly - 1 ? d - lo : job->Ly - 1;
+                if (hi >= lo && cols_ld <= cmax) cols_ld = POLL(&PM.loaded[1], cmax + 1, 2);
+            }
             q_d = d; q_cls = cls; q_lo = lo; q_hi = hi; q_mask = ((unsigned)cur_s4 >> 5) & 0x7fffu;
             // large tables: the scan writes the model scores into staging slot d % PST, whose previous user, diagonal
             // d - PST, the compute waves must have completed
@@ -1657,8 +1668,11 @@ __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc
                 double eg = NI_, em = NI_;
                 unsigned pg = PG_BP_NONE, pm = PG_BP_NONE;
                 const double s0 = q_left ? a0x : a0y, c0 = q_left ? a0y : a0x, s1 = q_left ? a1x : a1y, c1 = q_left ? a1y : a1x;
-                cand(s0 + ge, self, eg, pg); cand(c0 + go, cross, eg, pg); cand((a0m + ng) + go, PG_M, eg, pg);
-                cand(s1 + ge, kk | self, eg, pg); cand(c1 + go, kk | cross, eg, pg); cand((a1m + ng) + go, kk | PG_M, eg, pg);
+                // (the gap state's extension rate: the terminal one in the first / last column (X) or row (Y) -- row strips only)
+                const double gs = !term_on ? ge : (q_left ? ((q_j == 0 || q_j == job->Ly - 1) ? (double)job->gE : ge)
+                                                          : ((q_row == 0 || q_row == job->Lx - 1) ? (double)job->gE : ge));
+                cand(s0 + gs, self, eg, pg); cand(c0 + go, cross, eg, pg); cand((a0m + ng) + go, PG_M, eg, pg);
+                cand(s1 + gs, kk | self, eg, pg); cand(c1 + go, kk | cross, eg, pg); cand((a1m + ng) + go, kk | PG_M, eg, pg);
                 cand((b0m + q_tM) + q_w0, q_e0 | PG_M, em, pm); cand((b0x + q_tX) + q_w0, q_e0 | PG_X, em, pm); cand((b0y + q_tX) + q_w0, q_e0 | PG_Y, em, pm);
                 cand((b1m + q_tM) + q_w1, q_e1 | PG_M, em, pm); cand((b1x + q_tX) + q_w1, q_e1 | PG_X, em, pm); cand((b1y + q_tX) + q_w1, q_e1 | PG_Y, em, pm);
                 const int win = (int)((pg >> (q_left ? 4 : 18)) & 127u);
@@ -2550,7 +2564,6 @@ __device__ __noinline__ void strip_feeder(const PgDevJob *__restrict__ job, cdes
 template <bool TAB_LDS, bool STRIP>
 __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restrict__ jobs, const int *__restrict__ which,
                                                          unsigned flags, int n_fill) {
-    static_assert(TAB_LDS || !STRIP, "row strips run with the model table in LDS");
     if (!STRIP && (int)blockIdx.x >= n_fill) { pipe_follower(jobs, which, n_fill, flags); return; }
     if (STRIP && which[blockIdx.x] < 0) return;                    // (padding: the strips of a job sit at workgroup indices of one residue mod 8)
     const PgDevJob *__restrict__ job = jobs + which[blockIdx.x];
@@ -2601,7 +2614,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
         return;
 #endif
         if constexpr (TAB_LDS) pipe_assist_lean<STRIP>(job, psc, __builtin_amdgcn_readfirstlane((tid - PNT) >> 6), lane, flags);
-        else pipe_assist<false>(job, psc, __builtin_amdgcn_readfirstlane((tid - PNT) >> 6), lane, !(flags & 2u));
+        else pipe_assist<false, STRIP>(job, psc, __builtin_amdgcn_readfirstlane((tid - PNT) >> 6), lane, flags);
         return;
     }
 
@@ -2825,8 +2838,13 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
                 if (active) {
                     // straight-line code for the edges from the previous sites: `+ 0.0` (log_gap_close, unit edge
                     // weights) is omitted -- exact, no score is ever -0.0
-                    bx = first_max3(AX + ge, AY + go, (AM + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
-                    by = first_max3(PY + ge, PX + go, (PM_ + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
+                    // (row strips: the terminal extension rate in the first / last column (x-gap) and row (y-gap); a banded job's
+                    //  diagonals with such cells are general steps)
+                    const bool term_on = STRIP && !no_terminal_edges;
+                    const double gex = (term_on && (j == 0 || j == Ly - 1)) ? (double)f_gE : ge;
+                    const double gey = (term_on && (row == 0 || row == Lx - 1)) ? (double)f_gE : ge;
+                    bx = first_max3(AX + gex, AY + go, (AM + ng) + go, PG_X | PG_BP_ADJL, PG_Y | PG_BP_ADJL, PG_M | PG_BP_ADJL, px);
+                    by = first_max3(PY + gey, PX + go, (PM_ + ng) + go, PG_Y | PG_BP_ADJR, PG_X | PG_BP_ADJR, PG_M | PG_BP_ADJR, py);
                     const double tM = tng2 + (double)smf, tX = tng1 + (double)smf;
                     bm = first_max3(CM + tM, CX + tX, CY + tX, PG_M | PG_BP_ADJL | PG_BP_ADJR, PG_X | PG_BP_ADJL | PG_BP_ADJR,
                                     PG_Y | PG_BP_ADJL | PG_BP_ADJR, pm);
@@ -3054,3 +3072,4 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
 template __global__ void pg_fill_pipe<true, false>(const PgDevJob *, const int *, unsigned, int);
 template __global__ void pg_fill_pipe<false, false>(const PgDevJob *, const int *, unsigned, int);
 template __global__ void pg_fill_pipe<true, true>(const PgDevJob *, const int *, unsigned, int);
+template __global__ void pg_fill_pipe<false, true>(const PgDevJob *, const int *, unsigned, int);

@@ -23,6 +23,7 @@ def same(a, b, what=""):
 def strips(monkeypatch):
     monkeypatch.setenv("PAGAN_DP_WIDE", "strips")
     monkeypatch.setenv("PAGAN_DP_STRIP_SITES", "100000")      # (every wide job here runs as strips, however many multi-edge sites its diagonals hold)
+    monkeypatch.setenv("PAGAN_DP_STRIP_STATES", "100000")     # (... and however large its model table: by default only tables that fit LDS do)
 
 
 CASES = {
@@ -46,6 +47,26 @@ def test_full_matrix_as_strips(pg, oracle, strips, name):
     model = synth.random_model(15, 7)
     assert pg.debug_route(left, right, model)[0] == "pg_fill_pipe (row strips)"
     same(pg.align(left, right, model), oracle.dp_align(left, right, model), name)
+
+
+PROTEIN_CASES = {
+    # a 211-state table (not cached in LDS: the compute waves' C++ step, every model score gathered by the assist waves)
+    "plain_weighted": (400, 380, 0.0, 2, 2),
+    "multi_edge": (460, 430, 0.12, 4, 20),
+    "one_row_in_the_last_strip": (385, 300, 0.08, 3, 9),
+    "far_edges": (600, 250, 0.06, 4, 200),
+}
+
+
+@pytest.mark.parametrize("name", sorted(PROTEIN_CASES))
+@pytest.mark.parametrize("flags", [0, abi.OPT_NO_TERMINAL_EDGES])
+def test_protein_table_as_strips(pg, oracle, strips, name, flags):
+    nl, nr, p_extra, max_deg, max_span = PROTEIN_CASES[name]
+    left = synth.random_graph(nl, 211, 11, p_extra=p_extra, max_deg=max_deg, max_span=max_span)
+    right = synth.random_graph(nr, 211, 12, p_extra=p_extra, max_deg=max_deg, max_span=max_span)
+    model = synth.random_model(211, 3)
+    assert pg.debug_route(left, right, model)[0] == "pg_fill_pipe (row strips)"
+    same(pg.align(left, right, model, flags=flags), oracle.dp_align(left, right, model, flags=flags), name)
 
 
 @pytest.mark.parametrize("flags", [abi.OPT_NO_TERMINAL_EDGES, abi.OPT_NO_REDUCED_TERMINAL_PEN])

@@ -36,6 +36,14 @@ def case(name):
         left = synth.random_graph(400, 15, 5, p_extra=0.1, max_deg=3, max_span=9)
         right = synth.random_graph(370, 15, 6, p_extra=0.1, max_deg=3, max_span=9)
         model = synth.random_model(15, 3)
+    elif name == "prot":
+        left = synth.random_graph(460, 211, 101, p_extra=0.12, max_deg=4, max_span=20)
+        right = synth.random_graph(430, 211, 202, p_extra=0.12, max_deg=4, max_span=20)
+        model = synth.random_model(211, 7)
+    elif name == "protplain":
+        left = synth.random_graph(400, 211, 11, p_extra=0.0)
+        right = synth.random_graph(380, 211, 12, p_extra=0.0)
+        model = synth.random_model(211, 3)
     elif name == "skip":
         left = synth.random_graph(480, 15, 101, p_extra=0.10, max_deg=2, max_span=6)
         right = synth.random_graph(260, 15, 202, p_extra=0.10, max_deg=2, max_span=6)
@@ -59,6 +67,10 @@ def main():
         b = pg.Batch([(left, right, model, band)], flags=flags)
         b.run(); b.sync()
         sc[kernel] = b.debug_scores(0).reshape(-1, 3)
+        try:
+            print(kernel, "status", b.fetch()[0].status)
+        except Exception as e:
+            print(kernel, "fetch:", e)
         b.close()
     a, c = sc["tiles"].view(np.int64), sc["strips"].view(np.int64)
     bad = np.nonzero((a != c).any(axis=1))[0]
