@@ -1093,6 +1093,10 @@ __device__ __noinline__ void assist_general_cells(const PgDevJob *__restrict__ j
 // far cells than the pool holds) goes to assist_general_diag when the diagonal is due.
 template <bool STRIP>
 __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, unsigned flags) {
+    // (a function of its own does not know that its arguments are wave-uniform: said here, what depends on the wave's index and
+    //  the flags -- the staging slot's addresses among it -- lives in SGPRs instead of being spilled and reloaded in the staging code)
+    a = __builtin_amdgcn_readfirstlane(a);
+    flags = (unsigned)__builtin_amdgcn_readfirstlane((int)flags);
     const bool reduced_terminal = !(flags & 2u);
     const bool term_on = STRIP && !(flags & 1u);                   // (row strips: cells of the first / last row and column come this way too)
     constexpr int CLS = STRIP ? 7 : 15;                            // (a strip's class carries PG_STRIP_TERM beside it)
@@ -1471,6 +1475,8 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
 template <bool TAB_LDS, bool STRIP>
 __device__ __noinline__ void pipe_assist(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, unsigned flags) {
     static_assert(!TAB_LDS, "small tables: pipe_assist_lean");
+    a = __builtin_amdgcn_readfirstlane(a);                         // (wave-uniform arguments: see pipe_assist_lean)
+    flags = (unsigned)__builtin_amdgcn_readfirstlane((int)flags);
     const bool reduced_terminal = !(flags & 2u);
     const bool term_on = STRIP && !(flags & 1u);                   // (row strips: cells of the first / last row and column come this way too)
     const int nd = job->nd, S = job->S;
@@ -2494,6 +2500,7 @@ __device__ __noinline__ void pipe_follower(const PgDevJob *__restrict__ jobs, co
 static_assert(PHALO >= PAGE - 1 && 64 / PHALO * 8 == PFEED, "feeder geometry");
 __device__ __noinline__ void strip_feeder(const PgDevJob *__restrict__ job, cdesc8_p psc, int tid, int wave, unsigned flags) {
     const int lane = tid & 63;
+    wave = __builtin_amdgcn_readfirstlane(wave);
     const int nd = job->nd, d0 = job->d_first;
     const int hq = lane / PHALO, hr = lane % PHALO;                // this lane's diagonal (of four) and halo row in a request
     const int row = job->strip_row0 - PHALO + hr;
