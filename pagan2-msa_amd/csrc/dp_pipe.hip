@@ -1201,6 +1201,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
             const int hi_t = pair_d ? by : ay, cmax_t = pair_d ? d2 - bx : d - ax;      // the later diagonal's upper ends
             if (rows_ld <= hi_t) rows_ld = POLL(&PM.loaded[0], hi_t + 1, 1);
             if (cols_ld <= cmax_t && cmax_t < Ly) cols_ld = POLL(&PM.loaded[1], cmax_t + 1, 2);
+            ASTAMP(7);
             // ---- the slots ----
             if (!trk_valid) { s_site = -1; seen_row = lo_a; seen_col = cmin_a; trk_valid = true; }
             if (s_site >= 0 && s_site < (s_left ? lo_a : cmin_a)) s_site = -1;          // the band has left this row / column behind
@@ -1243,6 +1244,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
                 e_w1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(s_w1)));
                 e_w2 = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(s_w2)));
             }
+            ASTAMP(8);
             // ---- this lane's cell: (site, dg - site) or (dg - site, site) ----
             const int dg = grp ? d2 : d, lo_g = grp ? bx : ax, hi_g = grp ? by : ay;
             const bool cls1_g = (grp ? q_cls[1] : q_cls[0]) == 1;
