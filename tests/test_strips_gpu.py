@@ -123,3 +123,23 @@ def test_a_strip_on_another_xcd_runs_the_batch_again_alone(pg, oracle, strips, m
     assert b.debug_reruns() == 1
     b.close()
     same(got, oracle.dp_align(left, right, model))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_batches_as_strips(pg, oracle, strips, seed):
+    """random wide jobs (full matrices and wide bands, dead sites, long edges, several jobs per XCD) against the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    jobs = []
+    for k in range(int(rng.integers(2, 10))):
+        nl, nr = int(rng.integers(200, 1300)), int(rng.integers(200, 1300))
+        span = int(rng.choice([6, 30, 300]))
+        left = synth.random_graph(nl, 15, int(rng.integers(1 << 30)), p_extra=float(rng.choice([0.03, 0.1, 0.25])), max_deg=int(rng.integers(2, 6)),
+                                  max_span=span, p_dead=float(rng.choice([0.0, 0.02])))
+        right = synth.random_graph(nr, 15, int(rng.integers(1 << 30)), p_extra=float(rng.choice([0.03, 0.1, 0.25])), max_deg=int(rng.integers(2, 6)),
+                                   max_span=span, p_dead=float(rng.choice([0.0, 0.02])))
+        band = wide_band(left.n_sites - 1, right.n_sites - 1, int(rng.integers(300, 600)), seed) if rng.random() < 0.5 else None
+        jobs.append((left, right, synth.random_model(15, int(rng.integers(1 << 30))), band))
+    flags = int(rng.choice([0, abi.OPT_NO_TERMINAL_EDGES, abi.OPT_NO_REDUCED_TERMINAL_PEN]))
+    got = pg.align_batch(jobs, flags=flags)
+    for k, (left, right, model, band) in enumerate(jobs):
+        same(got[k], oracle.dp_align(left, right, model, band, flags=flags), "seed %d job %d" % (seed, k))
