@@ -14,15 +14,17 @@ exactly as a progressive alignment has to (a parent's inputs come from its child
 value = in-band DP cells of the tree / time of that pass.  The same nodes launched side by side as one
 batch (no dependency order; the round-1 headline) are reported as value_resident_batch.
 
-N > 1 GPUs (workload = configs[4]: 512 x 10 kb, branch 0.02, anchored): ONE tree whose ready nodes the N
-ranks take from a dynamic queue in the job's key-value store (pagan2_msa_amd.dist.align_sharded: a rank claims
-ready nodes with an atomic counter per node, runs model + anchors + DP + parent graph for them on its own GPU,
-posts the finished paths under the nodes' keys and imports what the others have posted when it next looks; no
-collective on the data path, no round barrier).  A step is one whole progressive alignment; value = cells of
-the tree / wall-clock of the walk (max over ranks): "strong" scaling.  Rank 0 also times the same walk alone on its GPU
-(value_one_gpu_same_workload) so that a speed-up can be read off one line.  Without torchrun,
-`--gpus N` runs the in-process work queue over N devices of this process instead (one feeder thread
-per device, pagan_msa_align with n_devices = N).
+N > 1 GPUs: ONE tree whose ready nodes the N ranks take from a dynamic queue in the job's key-value store
+(pagan2_msa_amd.dist.align_sharded: a rank claims ready nodes with an atomic counter per node, runs model + anchors +
+DP + parent graph for them on its own GPU, posts the finished paths under the nodes' keys and imports what the others
+have posted when it next looks; no collective on the data path, no round barrier).  A step is one whole progressive
+alignment; value = cells of the tree / wall-clock of the walk (max over ranks): "strong" scaling.  Without --workload
+the line is about configs[3] (cfg4, what --gpus 1 times: one workload from N = 1 to N = 8) and carries configs[4]
+(cfg5: 512 x 10 kb, branch 0.02 -- the workload whose units fill more than one GPU) in `also`; `roofline` is the
+aggregate one (36 B x cells / wall against N x 8 TB/s, the fill kernels' device time per rank beside it), `cpu_baseline`
+the oracle on rank 0's host.  Rank 0 also times the same walk alone on its GPU (value_one_gpu_same_workload) so that a
+speed-up can be read off one line.  Without torchrun, `--gpus N` runs the in-process work queue over N devices of this
+process instead (one feeder thread per device, pagan_msa_align with n_devices = N).
 """
 import argparse
 import json
@@ -429,13 +431,15 @@ def bench_one_gpu(args, device):
 
 # ---------------------------------------------------------------------------------------------------------------
 def bench_work_queue(args, rank, local_rank, world):
+    """N > 1: one guide tree farmed over N GPUs as a work queue (pagan2-msa_amd/dist.py).  A step is one whole
+    progressive alignment; `value` = cells of the tree / wall-clock of the walk (max over ranks).  Without --workload the
+    line is about BASELINE.json's headline, cfg4 -- the workload `--gpus 1` times, so that a 1 -> N curve compares one
+    workload with itself -- and carries cfg5 (the workload whose units fill more than one GPU) in `also`."""
     import torch
     import torch.distributed as dist
     import pagan2_msa_amd as pg
     from pagan2_msa_amd import dist as pdist, host
 
-    workload = args.workload or "cfg5_512x10kb_dna_anchored"
-    cfg, leaves, length, branch, sub, indel, mean_len, anchors, alphabet = WORKLOADS[workload]
     in_process = world == 1                      # no torchrun: one process feeds args.gpus devices
     pg.lib().pagan_dp_select_device(local_rank)
     xdev = "cuda" if args.dist_backend == "nccl" else "cpu"     # where the exchanged bytes live
@@ -444,59 +448,82 @@ def bench_work_queue(args, rank, local_rank, world):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-    names, seqs, newick = make_inputs(workload)  # the same tree on every rank
 
-    def walk(sharded):
-        """One progressive alignment.  Returns (wall seconds of the alignment, msa)."""
-        if in_process:
-            msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=0, n_devices=args.gpus if sharded else 1)
+    def one_workload(workload, steps, warmup, with_cpu):
+        cfg, leaves, length, branch, sub, indel, mean_len, anchors, alphabet = WORKLOADS[workload]
+        names, seqs, newick = make_inputs(workload)  # the same tree on every rank
+
+        def walk(sharded):
+            """One progressive alignment.  Returns (wall seconds of the alignment, msa)."""
+            if in_process:
+                msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=0, n_devices=args.gpus if sharded else 1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                msa.align()
+                return time.perf_counter() - t0, msa
+            msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=local_rank, n_devices=1)
+            if sharded:
+                dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            msa.align()
+            if sharded:
+                pdist.align_sharded(msa, host.assign_units, device=xdev)
+                torch.cuda.synchronize()
+                dist.barrier()
+            else:
+                msa.align()
             return time.perf_counter() - t0, msa
-        msa = host.Msa(names, seqs, newick, use_anchors=anchors, first_device=local_rank, n_devices=1)
-        if sharded:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        if sharded:
-            pdist.align_sharded(msa, host.assign_units, device=xdev)
-            torch.cuda.synchronize()
-            dist.barrier()
-        else:
-            msa.align()
-        return time.perf_counter() - t0, msa
 
-    # rank 0 alone first: the one-GPU time of the same workload (and the reference alignment for the check below)
-    solo_s, solo = None, None
-    if rank == 0:
-        walk(False)
-        solo_s, solo = walk(False)
-    for _ in range(args.warmup):
-        walk(True)
-    elapsed, msa = 0.0, None
-    for _ in range(args.steps):
-        dt, msa = walk(True)
-        elapsed += dt
-    if in_process:
-        elapsed_max = elapsed
-    else:
-        elapsed_max, _ = pdist.reduce_step(elapsed, 0, device=xdev)
-    if rank == 0:
+        # rank 0 alone first: the one-GPU time of the same workload (and the reference alignment for the check below)
+        solo_s, solo = None, None
+        if rank == 0:
+            walk(False)
+            solo_s, solo = walk(False)
+        for _ in range(warmup):
+            walk(True)
+        elapsed, msa = 0.0, None
+        for _ in range(steps):
+            dt, msa = walk(True)
+            elapsed += dt
+        tm = msa.timing()
+        if in_process:
+            elapsed_max = elapsed
+            fills = [tm["dp_fill_dev_s"]]
+            aligned = [sum(1 for k in range(msa.n_internal) if msa.node_device(k) >= 0)]
+        else:
+            elapsed_max, _ = pdist.reduce_step(elapsed, 0, device=xdev)
+            # every rank's device time in the fill kernels and the nodes it aligned itself (last walk)
+            mine_n = sum(1 for k in range(msa.n_internal) if msa.node_device(k) >= 0)
+            t = torch.zeros(2 * world, dtype=torch.float64, device=xdev)
+            t[2 * rank] = tm["dp_fill_dev_s"]; t[2 * rank + 1] = mine_n
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            fills = [float(t[2 * r].item()) for r in range(world)]
+            aligned = [int(t[2 * r + 1].item()) for r in range(world)]
+        if rank != 0:
+            return None, True
         n_nodes = msa.n_internal
         cells = sum(int(msa.node_info(k).cells) for k in range(n_nodes))
         same = msa.alignment() == solo.alignment() and all(
             msa.node_info(k).score == solo.node_info(k).score and msa.node_info(k).cells == solo.node_info(k).cells
             for k in range(n_nodes))
-        mine = sum(1 for k in range(n_nodes) if msa.node_device(k) >= 0)
+        wall = elapsed_max / steps
+        # Aggregate HBM roofline of the walk: the fill's algorithmic bytes (24 B of scores + 12 B of back-pointers per cell,
+        # DESIGN.md s.2.1) over the WALL-CLOCK of the walk against N x the chip's peak -- host work and idle devices
+        # included, which is what an end-to-end farm is worth; the fill kernels' own device time per rank beside it.
+        ach = BYTES_PER_CELL * cells / wall / 1e9
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS * args.gpus, "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * args.gpus),
+                "traffic": None, "basis": "36 B x cells of the tree / wall-clock of the walk, against %d x %.0f GB/s" % (args.gpus, HBM_PEAK_GBS),
+                "fill_device_s_by_rank": fills, "nodes_aligned_by_rank": aligned,
+                "fill_frac_of_one_gpu_peak_by_rank": [BYTES_PER_CELL * cells * (a / max(n_nodes, 1)) / f / 1e9 / HBM_PEAK_GBS if f > 0 else None
+                                                       for f, a in zip(fills, aligned)]}
         out = {
             "metric": "DP cells/sec, %s, one guide tree farmed over %d GPUs as a work queue (end-to-end walk)" % (workload, args.gpus),
-            "value": cells * args.steps / elapsed_max,
+            "value": cells * steps / elapsed_max,
             "unit": "cells/s",
             "n_gpus": args.gpus,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed_max / args.steps,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": 1e3 * wall,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -505,23 +532,39 @@ def bench_work_queue(args, rank, local_rank, world):
             "config": {"workload": workload, "leaves": leaves, "length": length, "branch": branch,
                        "anchors": "prefix, offset 15" if anchors else "none", "node_alignments": n_nodes,
                        "cells_per_step": int(cells),
-                       "parallelism": ("in-process work queue over %d devices" % args.gpus) if in_process else
-                                      ("one rank per GPU, ready nodes dealt per round, finished paths posted to / read from the job's "
-                                       "key-value store (no collective on the data path; process group: %s); "
-                                       "rank 0 aligned %d of %d nodes%s" % ("RCCL" if args.dist_backend == "nccl" else "gloo", mine, n_nodes,
-                                                                            "; REHEARSAL: ranks share a device" if args.share_device else "")),
+                       "parallelism": ("in-process ready queue over %d devices (host_tree.cpp)" % args.gpus) if in_process else
+                                      ("one rank per GPU; dynamic work queue in the job's key-value store: a rank claims ready nodes (largest "
+                                       "first) with an atomic counter, posts finished paths to a log and imports the others' as they appear -- "
+                                       "no round, no barrier, no collective on the data path (process group: %s); nodes aligned by rank: %s%s"
+                                       % ("RCCL" if args.dist_backend == "nccl" else "gloo", aligned,
+                                          "; REHEARSAL: ranks share a device" if args.share_device else "")),
                        "step": "one whole progressive alignment: model + anchors + DP + parent graphs, host work included"},
             "value_one_gpu_same_workload": cells / solo_s,
             "one_gpu_wall_s": solo_s,
-            "speedup_vs_one_gpu": solo_s / (elapsed_max / args.steps),
-            "e2e_breakdown_s_rank0": msa.timing(),
+            "speedup_vs_one_gpu": solo_s / wall,
+            "e2e_breakdown_s_rank0": tm,
             "parity_self_check": bool(same),
-            "note": "BASELINE.json's headline (cfg4, 32 x 100 kb) does not shard: its levels hold 16/8/4/2/1 banded alignments, one "
-                    "workgroup each, which one MI355X already runs side by side, and a level lasts as long as its slowest "
-                    "alignment -- expect a flat DP time at 2/4/8 GPUs (only host work shards).  cfg5 (512 x 10 kb, 256 ready "
-                    "nodes at the first level, tiled wide-band alignments above) is the workload whose units fill more than one GPU.",
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roof,
+            "cpu_baseline": cpu_baseline(solo, n_nodes, args.cpu_seconds) if with_cpu and not args.no_cpu_baseline else None,
         }
+        return out, same
+
+    if args.workload:
+        out, same = one_workload(args.workload, args.steps, args.warmup, True)
+    else:
+        out, same = one_workload("cfg4_32x100kb_dna_anchored", args.steps, args.warmup, True)
+        also, same5 = one_workload("cfg5_512x10kb_dna_anchored", max(1, min(args.steps, 2)), min(args.warmup, 1), False)
+        same = same and same5
+        if rank == 0:
+            out["also"] = {k: also[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "value_one_gpu_same_workload",
+                                                "one_gpu_wall_s", "speedup_vs_one_gpu", "parity_self_check", "roofline")}
+            out["note"] = ("cfg4 (BASELINE.json's headline, what --gpus 1 times) barely shards: its levels hold 16/8/4/2/1 banded alignments, one "
+                           "workgroup each, which one MI355X already runs side by side, and a level lasts as long as its slowest alignment -- "
+                           "expect a flat DP time at 2/4/8 GPUs (only host work shards).  `also` is cfg5 (512 x 10 kb: 256 ready nodes at the "
+                           "first level, wide-band alignments above), the workload whose units fill more than one GPU.  At N = 1 `value` is the "
+                           "device-resident pass (BASELINE's metric); here it is the whole walk's wall-clock, whose one-GPU figure is "
+                           "`value_one_gpu_same_workload`.")
+    if rank == 0:
         print(json.dumps(out))
         if not same:
             if not in_process:

@@ -961,6 +961,16 @@ static int bp_diags_per_block(int max_nd, int other_dims) {
 }
 
 int launch_fill(pagan_batch *b) {
+    // Full-matrix score check (PG_FLAG_SCORE_CHECK; dp_kernels.hip, pg_backptr): whoever writes a cell's back-pointers has just
+    // re-evaluated its three scores from the stored scores of its predecessors -- comparing them with the cell's own stored
+    // scores proves the recurrence at every cell.  On for the banded kernel's jobs (the follower workgroups do it on compute
+    // units the fill leaves idle) and for batches with row strips (scores cross workgroups on a landing rule there);
+    // PAGAN_DP_SCORE_CHECK=0 switches it off, =all extends it to every tiled job's pass.
+    unsigned chk_banded = PG_FLAG_SCORE_CHECK, chk_wide = b->n_striped > 0 ? PG_FLAG_SCORE_CHECK : 0u;
+    if (const char *e = std::getenv("PAGAN_DP_SCORE_CHECK")) {
+        if (std::strcmp(e, "0") == 0) { chk_banded = 0; chk_wide = 0; }
+        else if (std::strcmp(e, "all") == 0) chk_wide = PG_FLAG_SCORE_CHECK;
+    }
     hipStream_t tile_stream = nullptr;
     static std::atomic<int> n_cu_dev[64];
     bool ev3_recorded = false;
@@ -1033,17 +1043,17 @@ int launch_fill(pagan_batch *b) {
             auto followers = [&](int n_fill) { return follow && n_fill <= 32 ? std::min(96, 48 * ((n_fill + 7) / 8)) : 0; };
             if (n_small > 0)
                 hipLaunchKernelGGL((pg_fill_pipe<true, false>), dim3(n_small + followers(n_small)), dim3(pg_pipe_block()), 0 /* its LDS is static */, b->stream,
-                                   b->d_jobs, b->d_which, b->flags, n_small);
+                                   b->d_jobs, b->d_which, b->flags | chk_banded, n_small);
             if (n_big > 0)
                 hipLaunchKernelGGL((pg_fill_pipe<false, false>), dim3(n_big + followers(n_big)), dim3(pg_pipe_block()), 0, b->stream,
-                                   b->d_jobs, b->d_which + n_small, b->flags, n_big);
+                                   b->d_jobs, b->d_which + n_small, b->flags | chk_banded, n_big);
             HIP_TRY(hipEventRecord(b->evk[1], b->stream)); b->evk_set[1] = true;
             if (b->bp_pass) {
                 int max_nd = 1, max_w = 1;
                 for (int k = 0; k < b->n; ++k) if (b->jobs[k].ring_ok) { max_nd = std::max(max_nd, b->dj[k].nd); max_w = std::max(max_w, b->jobs[k].dx.max_width); }
                 const int zc = (max_w + PG_BP_CELLS - 1) / PG_BP_CELLS, dpb = bp_diags_per_block(max_nd, b->n_ring * zc);
                 hipLaunchKernelGGL(pg_backptr, dim3((max_nd + dpb - 1) / dpb, b->n_ring, zc), dim3(256), 0, b->stream,
-                                   b->d_jobs, b->d_which, (b->flags & 0xffu) | (b->bp_pass == 2 ? 0x100u : 0u), dpb);
+                                   b->d_jobs, b->d_which, (b->flags & 0xffu) | (b->bp_pass == 2 ? 0x100u : chk_banded), dpb);
                 HIP_TRY(hipEventRecord(b->evk[2], b->stream)); b->evk_set[2] = true;
             }
         } else {
@@ -1114,7 +1124,7 @@ int launch_fill(pagan_batch *b) {
             for (int k = 0; k < b->n; ++k) if (!b->jobs[k].ring_ok && (!b->jobs[k].tiles.empty() || !b->jobs[k].strips.empty())) { max_nd = std::max(max_nd, b->dj[k].nd); max_w = std::max(max_w, b->jobs[k].dx.max_width); }
             const int zc = (max_w + PG_BP_CELLS - 1) / PG_BP_CELLS, dpb = bp_diags_per_block(max_nd, b->n_tiled * zc);
             hipLaunchKernelGGL(pg_backptr, dim3((max_nd + dpb - 1) / dpb, b->n_tiled, zc), dim3(256), 0, tile_stream,
-                               b->d_jobs, b->d_which + b->n_ring + b->n_wide, b->flags & 0xffu, dpb);
+                               b->d_jobs, b->d_which + b->n_ring + b->n_wide, (b->flags & 0xffu) | chk_wide, dpb);
             HIP_TRY(hipEventRecord(b->evk[6], tile_stream)); b->evk_set[6] = true;
         }
     }
@@ -1874,17 +1884,21 @@ int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
         // a chase that ran into an impossible word: the batch runs once more with every back-pointer written by pg_backptr
         // after the fill -- the follower workgroups' early reads are the one thing a second run can take out.  What fails
         // again is reported.  PAGAN_DP_RERUN=0: report at once.
-        bool again = false;
+        bool again = false, score_again = false;
         for (int k = 0; k < b->n; ++k) {
             const int st = *reinterpret_cast<const int *>(ends.data() + kEndStride * (size_t)k);
             again = again || st == PG_STATUS_PATH_CHECK || st == 2;
+            // a cell whose stored scores are not what its predecessors' stored scores give (PG_FLAG_SCORE_CHECK)
+            if (st == (0x40000000 | PG_FILL_SCORE_MISMATCH)) { again = true; score_again = true; }
         }
+        if (score_again)
+            for (int k = 0; k < b->n; ++k) HIP_TRY(hipMemsetAsync(b->dj[k].fill_status, 0, sizeof(int), b->stream));
         // A strip that found the strip above on another XCD gave up (dp_pipe.hip, strip_feeder: tag 11): the strips' launch
         // once more with nothing dispatched beside it
         bool strips_again = false;
         for (int k = 0; k < b->n && !b->strips_alone; ++k) {
             const int st = *reinterpret_cast<const int *>(ends.data() + kEndStride * (size_t)k);
-            if (!b->jobs[k].strips.empty() && (st & 0x40000000) && (st & 0xf) == 11) strips_again = true;
+            if (!b->jobs[k].strips.empty() && (st & 0x40000000) && (st & PG_FILL_OTHER_XCD)) strips_again = true;
         }
         if (strips_again) {
             b->strips_alone = true;
@@ -1896,7 +1910,8 @@ int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
         if (again && !(re && std::strcmp(re, "0") == 0)) {             // (once per fetch; the batch stays without followers)
             if (std::getenv("PAGAN_DP_VERBOSE"))
                 std::fprintf(stderr, strips_again ? "pagan_dp: a row strip found the strip above on another XCD: running the batch again, the strips alone\n"
-                                                  : "pagan_dp: path check failed: running the batch again without follower workgroups\n");
+                                     : (score_again ? "pagan_dp: score check failed (a stored score is not what its predecessors give): running the batch again without follower workgroups\n"
+                                                    : "pagan_dp: path check failed: running the batch again without follower workgroups\n"));
             if (!strips_again) b->no_follow = true;
             ++b->reruns;
             int rc = pagan_batch_run(b);

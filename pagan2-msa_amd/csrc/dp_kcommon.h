@@ -194,6 +194,20 @@ __device__ __forceinline__ void fill_cell_hbm(const View &J, int d, const Diag &
     store_cell(J.sc, J.bp, at, bx, by, bm, px, py, pm);
 }
 
+// A job's status word (PgDevJob::fill_status): the FIRST report stays -- the strips of a job share their parent's word, and a
+// later report (another strip's abort, the score check over a matrix an aborted fill left unfinished) must not hide it.  A row
+// strip that found the strip above on another XCD (dp_pipe.hip, strip_feeder: tag 11) additionally sets PG_FILL_OTHER_XCD, which
+// no other report clears: the host's re-run of the strips alone hinges on it.
+__device__ __forceinline__ void report_fill_status(const PgDevJob *job, int status) {
+    PG_GLOBAL int *w = (PG_GLOBAL int *)job->fill_status;
+    status &= 0x1fffffff;                                           // (an abort tag is kind | wave << 4 | diagonal << 8)
+    if ((status & 0xf) == 11 && status != PG_FILL_SCORE_MISMATCH) __hip_atomic_fetch_or(w, PG_FILL_OTHER_XCD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int expected = 0;
+    __hip_atomic_compare_exchange_strong(w, &expected, status, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a word that holds the sticky bit only takes the report's other bits as well)
+    if (expected == PG_FILL_OTHER_XCD) __hip_atomic_compare_exchange_strong(w, &expected, status | PG_FILL_OTHER_XCD, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Loads the COMPUTE waves need only on rare paths (an edge reaching past the ring).  Issued as
 // inline asm with their own wait so that the compiler's waitcnt insertion never places a
 // vmcnt(0) -- which would also wait for every store in flight -- on the common path.

@@ -117,6 +117,16 @@ __global__ __launch_bounds__(256) void pg_backptr(const PgDevJob *__restrict__ j
                 typedef unsigned u3 __attribute__((ext_vector_type(3)));
                 u3 b; b.x = px; b.y = py; b.z = pm;
                 *(PG_GLOBAL u3 *)(J.bp + 3 * at) = b;
+                // flags bit 9 (PG_FLAG_SCORE_CHECK): the cell's stored scores are what its predecessors' stored scores give, bit
+                // for bit -- the recurrence holds at EVERY cell, so the whole matrix is the oracle's by induction from cell (0,0).
+                // The fill kernels hand scores from wave to wave and from workgroup to workgroup (row strips) on landing rules;
+                // a score that arrived through a stale read fails here, whether or not the traceback visits the cell.
+                if (flags & PG_FLAG_SCORE_CHECK) {
+                    const bool same = __double_as_longlong(bx) == __double_as_longlong(J.sc[3 * at + PG_X]) &&
+                                      __double_as_longlong(by) == __double_as_longlong(J.sc[3 * at + PG_Y]) &&
+                                      __double_as_longlong(bm) == __double_as_longlong(J.sc[3 * at + PG_M]);
+                    if (!same) report_fill_status(job, PG_FILL_SCORE_MISMATCH);
+                }
             }
         }
     }

@@ -74,11 +74,13 @@ static_assert(PNA == 3 && PST == 3 && PAGE >= PLAND + 4, "assist wave a stages t
 // site record, word x
 #define PR_SIMPLE 0x10000        // one bwd edge, from the previous site, log-weight 0
 #define PR_NE_SHIFT 17           // 7 bits: number of bwd edges (host keeps sites with > 126 off this kernel)
-#define PR_SPAN_SHIFT 24         // 8 bits: farthest bwd edge in sites, saturating
+#define PR_TWO 0x1000000         // (small model tables only) two bwd edges, exactly one of them from the previous site -- NORMALISED: that edge in slot 0,
+                                 // the other one in slot 1 whatever the list's order (the fill computes values only: tools/gen_hot_asm.py, c1_issue);
+                                 // bits 25-31 stay zero (the hand-scheduled loop tests the flag as x > 0xffffff)
 
 struct PipeSmem {
     double sc[PRK][PNT][3];      // X, Y, M
-    pg_i4 recL[PRW], recR[PRW];  // x: state | flags | n_edges | span, y: dist0 | dist1 << 16, z/w: log-weights 0/1
+    pg_i4 recL[PRW], recR[PRW];  // x: state | PR_SIMPLE | n_edges << 17 | PR_TWO, y: dist0 | dist1 << 16, z/w: log-weights 0/1
     pg_i4 dring[PDR];            // lo, hi, score byte offset (64 bit) of diagonal d at [d % PDR]
     int ebL[PRW], ebR[PRW];      // first bwd edge of the site (edge numbering of the graph)
     int esL[PEC], esR[PEC];
@@ -183,7 +185,7 @@ __device__ __forceinline__ double dpp_shr1(double v, double lane0) {
 
 // ---- loader wave -------------------------------------------------------------------------
 template <bool LEFT>
-__device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_p st, gint_p off, gint_p src, gfloat_p lw, bool strip) {
+__device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_p st, gint_p off, gint_p src, gfloat_p lw, bool strip, bool norm) {
     pg_i4 *rec = LEFT ? PM.recL : PM.recR;
     int *eb = LEFT ? PM.ebL : PM.ebR;
     int *es = LEFT ? PM.esL : PM.esR;
@@ -211,13 +213,12 @@ __device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_
         if (two) { es[(e + 64) & (PEC - 1)] = s1; ew[(e + 64) & (PEC - 1)] = x1; }
     }
     if (r < n) {
-        int span = d0 > d1 ? d0 : d1;
-        for (int e = b + 2; e < en && e < b + 16; ++e) { const int sp = r - src[e]; span = sp > span ? sp : span; }
         if (r > 0 && ne == 1 && d0 == 1 && w0 == 0.0f) w |= PR_SIMPLE;
-
-        if (ne > 16 || span > 255) span = 255;
         w |= (ne < 127 ? ne : 127) << PR_NE_SHIFT;
-        w |= span << PR_SPAN_SHIFT;
+        if (norm && ne == 2 && (d0 == 1) != (d1 == 1)) {
+            if (d0 != 1) { const int td = d0; d0 = d1; d1 = td; const float tw = w0; w0 = w1; w1 = tw; }
+            w |= PR_TWO;
+        }
         pg_i4 v;
         v.x = w; v.y = (d0 < 65535 ? d0 : 65535) | ((d1 < 65535 ? d1 : 65535) << 16);
         v.z = __float_as_int(w0); v.w = __float_as_int(w1);
@@ -226,7 +227,7 @@ __device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_
         // outside the band, a row outside the band for far_ask), which is what the general rules give its X and M (Y and M);
         // its y-gap (x-gap) chain is the straight code's at the terminal rate; the diagonals 0 and 1 and the cells that meet
         // M(0,0) through an edge from site 0 are general steps (dp_abi.hip, plan_strips), and those read no record of site 0.
-        if (strip && r == 0) { v.x = (w & 0xffff) | PR_SIMPLE | (1 << PR_NE_SHIFT) | (1 << PR_SPAN_SHIFT); v.y = 1; v.z = 0; v.w = 0; }
+        if (strip && r == 0) { v.x = (w & 0xffff) | PR_SIMPLE | (1 << PR_NE_SHIFT); v.y = 1; v.z = 0; v.w = 0; }
         rec[r & (PRW - 1)] = v;
         eb[r & (PRW - 1)] = b;
     }
@@ -244,7 +245,7 @@ __device__ __forceinline__ void publish_landed(PG_GLOBAL int *follow, int lane, 
 }
 // Row strips (`strip`: the PgDevJob, null otherwise): records from the strip's first halo row / first column on, the
 // descriptor window from the PARENT's array (whole-band rows per diagonal, offsets in cells there), everything from d_first.
-__device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lane, PG_GLOBAL int *follow, const PgDevJob *strip) {
+__device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lane, PG_GLOBAL int *follow, const PgDevJob *strip, bool norm) {
     int rows = 0, cols = 0, diags = 0, published = -1;
     PG_GLOBAL const pg_i4 *pdsc = nullptr;
     if (strip) {
@@ -296,12 +297,12 @@ __device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lan
             any = true;
         }
         if (rows < want_rows) {
-            load_rec_chunk<true>(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL, strip != nullptr);
+            load_rec_chunk<true>(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL, strip != nullptr, norm);
             rows += 64; any = true;
             flag_store(&PM.loaded[0], rows);
         }
         if (cols < want_cols) {
-            load_rec_chunk<false>(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR, strip != nullptr);
+            load_rec_chunk<false>(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR, strip != nullptr, norm);
             cols += 64; any = true;
             flag_store(&PM.loaded[1], cols);
         }
@@ -1868,7 +1869,7 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                   [asd] "s"(a_asd), [stx] "v"(a_stx), [spxa] "v"(a_spx), \
                   [stopm1] "s"(stop - 1), [S] "s"(S), [fdn] "v"(a_fdn), \
                   [bR] "s"(a_recR), [bL] "s"(a_recL), [bT] "s"(a_table), \
-                  [sclo] "s"(sc_lo), [schi] "s"(sc_hi)
+                  [sclo] "s"(sc_lo), [schi] "s"(sc_hi), [c24] "s"(0xffffffu)
             if constexpr (STRIP) {
                 // (the strip's loop picks the x-gap state's rate per lane and step: tools/gen_hot_asm.py, STRIP)
                 const double gE_ = term_on ? gE : ge;
@@ -2140,14 +2141,26 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
 
 
 // ---- wide run (model table in LDS): consecutive class 4 diagonals, 242 .. PG_PIPE_WINDOW cells ----
-// A lane takes its residue's rows lo + ((tid - lo) & 255) and that + 256.  Nothing lives in registers across steps:
-// a cell's operands come from the WIDE RING -- the ring's memory as PWK rows of 512 positions (row % 512), written
-// by every lane for both its rows, -inf outside the band -- when their diagonal belongs to this run and is at
-// most PWAGE back, and from L2 otherwise (diagonals before the run: everything landed at the rendezvous on entry;
-// older diagonals of the run: every wave keeps all but its last 30 stores, five steps' worth, retired).  Simple
-// interior cells are straight-line code; cells with "easy" multi-edge sites (hot_run) get their up to eight
-// operands in one batch; anything else goes through cell_any with one fetch per operand.  The four waves move in
-// lock step through flags: the wave above has completed d-1, the wave below d-2 (ring row reuse).
+// A lane holds the two smallest rows of its residue that are not below the band: rowA = lo + ((tid - lo) & 255) and
+// rowB = rowA + 256 (a wide diagonal has at most 512 - 160 cells, so no lane ever has a third).  As in hot_run the
+// hand-over stays in REGISTERS (round 5; before, every operand of every cell -- the three neighbours included -- was
+// read back from LDS or L2, and a step cost 15 k cycles):
+//   - per set the lane keeps its cell of the previous diagonal (P: (row, j-1)) and the shifted cell of the diagonal before
+//     (C: (row-1, j-1)); (row-1, j) comes from lane T-1 by one DPP shift per set -- lane T-1's set A holds rowA(T) - 1
+//     unless rowA(T) is the band's first row of the previous diagonal, in which case it holds rowB(T) - 1 and the lane's
+//     set A has no neighbour in the band --, lane 0 reads the upstream wave's lane 63 out of the wide ring;
+//   - a lane whose rowA fell below the band moves its set B into A (cells and all) AFTER the shift, as the narrow loop
+//     does, so that the last cell of a row that leaves the band is still handed down;
+//   - the operands of the other edges of "easy" multi-edge sites come from the WIDE RING -- the ring's memory as PWK rows
+//     of 512 positions (row % 512), written by every lane for both its rows, -inf outside the band -- when their
+//     diagonal belongs to this run and is at most PWAGE back, and from L2 otherwise (diagonals before the run: everything
+//     landed at the rendezvous on entry; older diagonals of the run: every wave keeps all but its last three steps' stores
+//     retired and no wave is more than two steps behind another: an L2 operand is at least PWAGE + 1 = 6 diagonals old);
+//     anything else (first / last rows and columns, sites with more than two edges) goes through cell_any_t with one
+//     fetch per operand;
+//   - the first step of a run takes its registers from L2 (one round trip per run).
+// The four waves move in lock step through flags: the wave above has completed d-1, the wave below d-2 (ring row reuse:
+// with those two every wave has completed d-2, and nobody reads the row of d-7 after its step d-2).
 __device__ __noinline__ void wide_run(WaveCtx &C_) {
     WCTX_IN(C_);
     WCTX_STATS(C_);
@@ -2162,8 +2175,51 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
     for (int w = 0; w < PNW; ++w) POLLX(&PM.arrived[w], d0, 7);
     p_up = d0 - 1 > p_up ? d0 - 1 : p_up;
     p_dn = d0 - 1 > p_dn ? d0 - 1 : p_dn;
-    pg_i8 cur = dA;
     const double NIw = neg_inf();
+    const int lane = tid & 63;
+    // The run's diagonals d0 .. run_end - 1: found here with vector loads of the descriptors' class words (64 per round trip);
+    // inside the loop a diagonal's rows and score offset come from the loader's LDS window (PM.dring) -- a scalar load per step
+    // shares its counter with the LDS operations and returns out of order, so the step's first LDS wait behind it waited for
+    // memory (~2 k cycles of every step)
+    int run_end = d0 + 1;
+    for (;;) {
+        const int t = run_end + lane;
+        const int c4 = ((PG_GLOBAL const int *)psc)[8 * (t < nd ? t : nd) + 4] & 15;      // (the array carries one entry of padding: class 0)
+        const unsigned long long stop = __builtin_amdgcn_ballot_w64(t >= nd || t >= sleep || c4 != 4);
+        if (stop != 0) { run_end += __builtin_ctzll(stop); break; }
+        run_end += 64;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pg_i4 cur = {dA.x, dA.y, dA.z, dA.w};                          // rows lo .. hi of the diagonal, byte offset of its first score
+    // ---- the lane's two sets: rows, P = (row, j-1) on d-1, C = (row-1, j-1) on d-2, U = (row-1, j) on d-1 (first step only:
+    // afterwards U is the shift's result) -- from L2, everything before the run has landed ----
+    int wrow[2];
+    double Px[2], Py[2], Pm[2], Cx[2], Cy[2], Cm[2], Ux[2], Uy[2], Um[2];
+    wrow[0] = cur.x + ((tid - cur.x) & (PNT - 1)); wrow[1] = wrow[0] + PNT;
+    if (diags_ld < d0) diags_ld = POLLX(&PM.loaded[2], d0, 5);
+    {
+        FarAsk fa[8];
+        pg_d2 xy[8];
+        double m[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            fa[3 * q + 0] = far_ask(psc, d0, 1, wrow[q]);          // P
+            fa[3 * q + 1] = far_ask(psc, d0, 2, wrow[q] - 1);      // C
+            fa[3 * q + 2] = far_ask(psc, d0, 1, wrow[q] - 1);      // U
+        }
+        fa[6].need = false; fa[6].boff = 0; fa[7] = fa[6];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { xy[k].x = NIw; xy[k].y = NIw; m[k] = NIw; }
+        far_fetch8(sc_out, fa, xy, m);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            Px[q] = xy[3 * q].x; Py[q] = xy[3 * q].y; Pm[q] = m[3 * q];
+            Cx[q] = xy[3 * q + 1].x; Cy[q] = xy[3 * q + 1].y; Cm[q] = m[3 * q + 1];
+            Ux[q] = xy[3 * q + 2].x; Uy[q] = xy[3 * q + 2].y; Um[q] = m[3 * q + 2];
+        }
+    }
+    int n_hist1 = 0, n_hist2 = 0;                                  // stores issued in the previous step / the one before
+    int lo_prev = cur.x;                                           // first row of the previous diagonal's band (the sets' rows are relative to it)
     for (;;) {
         const int lo = cur.x, hi = cur.y;
 #ifdef PG_PIPE_STATS
@@ -2181,11 +2237,46 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
 #ifdef PG_PIPE_STATS
         const long long st_t1 = __builtin_readcyclecounter();
 #endif
-        const pg_i8 nxt = psc[d + 1];
+        // the next diagonal's descriptor: staged by the loader (the window runs PLOOK diagonals ahead of the slowest wave)
+        if (diags_ld < d + 2 && d + 1 < nd) diags_ld = POLLX(&PM.loaded[2], d + 2, 5);
+        const pg_i4 nxt = PM.dring[(d + 1) & (PDR - 1)];
         const int amax = d - d0 < PWAGE ? d - d0 : PWAGE;               // ages 1 .. amax are in the wide ring
         const int wsb = (d % PWK) * PWROW_BYTES;
         const long long soff = ((long long)cur.w << 32) | (unsigned)cur.z;
         PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff;
+#ifdef PG_EXP_WIDE_SKIP                                             // timing experiment (WRONG RESULTS): a wide step is its flags and nothing else
+        if (true) {
+            flag_store(&PM.progress[wave], d);
+            ++d; lo_prev = lo;
+            if (d >= run_end || flag_load(&PM.abort_flag) != 0) break;
+            cur.x = __builtin_amdgcn_readfirstlane(nxt.x); cur.y = __builtin_amdgcn_readfirstlane(nxt.y);
+            cur.z = __builtin_amdgcn_readfirstlane(nxt.z); cur.w = __builtin_amdgcn_readfirstlane(nxt.w);
+            continue;
+        }
+#endif
+        if (d > d0) {
+            // ---- (row-1, j) on d-1: lane T-1's registers, lane 0 from the wide ring (the upstream wave completed d-1) ----
+            int rb1 = wsb - PWROW_BYTES;
+            rb1 += rb1 < 0 ? PWK * PWROW_BYTES : 0;
+            double ax[2], ay[2], am[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const double *c = (const double *)((const char *)&PM.sc[0][0][0] + rb1 + ((wrow[q] - 1) & (PWPOS - 1)) * 24);
+                ax[q] = dpp_shr1(Px[q], c[PG_X]); ay[q] = dpp_shr1(Py[q], c[PG_Y]); am[q] = dpp_shr1(Pm[q], c[PG_M]);
+            }
+            // lane T-1's set A holds rowA(T) - 1, its set B rowB(T) - 1 -- unless rowA(T) was the band's first row: then lane T-1's
+            // set A holds rowB(T) - 1 (lane 0 read by position: nothing to sort out)
+            const bool first = wrow[0] == lo_prev && lane != 0;
+            Ux[0] = first ? NIw : ax[0]; Uy[0] = first ? NIw : ay[0]; Um[0] = first ? NIw : am[0];
+            Ux[1] = first ? ax[0] : ax[1]; Uy[1] = first ? ay[0] : ay[1]; Um[1] = first ? am[0] : am[1];
+            // ---- row hand-over: set B becomes set A, the new set B (512 rows on: far below the band) starts from -inf ----
+            if (wrow[0] < lo) {
+                wrow[0] = wrow[1]; wrow[1] += PNT;
+                Px[0] = Px[1]; Py[0] = Py[1]; Pm[0] = Pm[1]; Cx[0] = Cx[1]; Cy[0] = Cy[1]; Cm[0] = Cm[1];
+                Ux[0] = Ux[1]; Uy[0] = Uy[1]; Um[0] = Um[1];
+                Px[1] = NIw; Py[1] = NIw; Pm[1] = NIw; Cx[1] = NIw; Cy[1] = NIw; Cm[1] = NIw; Ux[1] = NIw; Uy[1] = NIw; Um[1] = NIw;
+            }
+        }
         // one operand cell (p, d - age): read from the wide ring, or -- not there -- what to ask L2 for (the caller fetches
         // all of a step's requests in one statement); -inf outside the band
         auto wcell = [&](bool need, int age, int p_, pg_d2 &xy, double &m) -> FarAsk {
@@ -2201,25 +2292,26 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             }
             return far_ask(psc, d, age, p_);
         };
-        // Both rows of the lane in phases, so that a step pays at most ONE L2 round trip for its batched cells: request /
-        // read every operand, wait once (only if some lane asked L2: a wait also covers the wave's stores in flight),
-        // then the arithmetic; cells outside the batch (general rules) fetch one operand at a time afterwards.
-        int rr[2], kind[2];                                     // kind: 0 outside the band, 1 batched, 2 general rules
+        // Both sets in phases, so that a step pays at most ONE L2 round trip for its batched cells: read / request the operands
+        // of the other edges, wait once (only if some lane asked L2: a wait also covers the wave's stores in flight), then the
+        // arithmetic; cells outside the batch (general rules) fetch one operand at a time afterwards.
+        int kind[2];                                            // 0 outside the band, 1 batched, 2 general rules
         pg_i4 gl[2], gr[2];
         pg_d2 o_xy[2][8];
         double o_m[2][8];
         bool l2q[2], r2q[2], lSq[2], rSq[2];
-        int kLq[2], kRq[2];
         FarAsk o_f[2][8];
+        bool any_far = false;
+        int n_now = 0;                                          // stores this wave issues in this step
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int r = lo + ((tid - lo) & (PNT - 1)) + PNT * q, j = d - r;
-            rr[q] = r; kind[q] = 0;
+            const int r = wrow[q], j = d - r;
+            kind[q] = 0;
             l2q[q] = r2q[q] = lSq[q] = rSq[q] = false;
-            kLq[q] = kRq[q] = 0;
+            int kL = 0, kR = 0;
             gl[q] = pg_i4{0, 0, 0, 0}; gr[q] = pg_i4{0, 0, 0, 0};
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { o_f[q][t].need = false; o_f[q][t].boff = 0; }
+            for (int t = 0; t < 8; ++t) { o_f[q][t].need = false; o_f[q][t].boff = 0; o_xy[q][t].x = NIw; o_xy[q][t].y = NIw; o_m[q][t] = NIw; }
             if (!__any(r <= hi)) continue;                      // none of the wave's lanes has a (second) row on this diagonal
             if (r <= hi) {
                 gl[q] = PM.recL[r & (PRW - 1)]; gr[q] = PM.recR[j & (PRW - 1)];
@@ -2229,17 +2321,16 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
                 const bool easyR = nr == 1 ? dr0 == 1 : (nr == 2 && (dr0 == 1) != (dr1 == 1));
                 const bool l2 = nl == 2, r2 = nr == 2;
                 const bool lS = l2 && dl0 != 1, rS = r2 && dr0 != 1;                 // the other edge is listed first
-                const int kL = lS ? dl0 : dl1, kR = rS ? dr0 : dr1;
+                kL = lS ? dl0 : dl1; kR = rS ? dr0 : dr1;
                 // interior, and no edge in reach starts at site 0 (where the gap-open term differs)
                 const bool inner = r >= 2 && r <= Lx - 2 && j >= 2 && j <= Ly - 2 && (!l2 || r - kL >= 1) && (!r2 || j - kR >= 1);
                 kind[q] = (easyL && easyR && inner) ? 1 : 2;
-                if (kind[q] == 1) { l2q[q] = l2; r2q[q] = r2; lSq[q] = lS; rSq[q] = rS; kLq[q] = kL; kRq[q] = kR; }
+                if (kind[q] == 1) { l2q[q] = l2; r2q[q] = r2; lSq[q] = lS; rSq[q] = rS; }
             }
-            // the batched cells' operands.  Wave-uniform shortcuts: an optional operand is skipped when no lane has it, and
-            // while every operand of the wave lies in the wide ring the reads are plain LDS reads (no L2 path, no branches)
+            // the batched cells' other-edge operands.  Wave-uniform shortcuts: an operand is skipped when no lane has it, and
+            // while every lane's lies in the wide ring the reads are plain LDS reads (no L2 path, no branches)
             const bool b1 = kind[q] == 1, l2 = l2q[q], r2 = r2q[q];
-            const int kL = kLq[q], kR = kRq[q];
-            if (!__any(b1)) continue;
+            if (!__any(b1 && (l2 || r2))) continue;
             auto rd = [&](bool need, int age, int p_, pg_d2 &xy, double &m) {
                 int rb = wsb - age * PWROW_BYTES;
                 rb += rb < 0 ? PWK * PWROW_BYTES : 0;
@@ -2247,16 +2338,11 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
                 const double *c = (const double *)((const char *)&PM.sc[0][0][0] + off);
                 xy.x = c[PG_X]; xy.y = c[PG_Y]; m = c[PG_M];
             };
-            // one operand of the wave's batched cells: nothing if no lane has it, a plain LDS read while every lane's lies in
-            // the wide ring, the L2-or-ring path otherwise
             auto fetch = [&](int t, bool need, int age, int p_) {
-                if (!__any(need)) { o_xy[q][t].x = NIw; o_xy[q][t].y = NIw; o_m[q][t] = NIw; return; }
+                if (!__any(need)) return;
                 if (!__any(need && age > amax)) rd(need, age, p_, o_xy[q][t], o_m[q][t]);
-                else o_f[q][t] = wcell(need, age, p_, o_xy[q][t], o_m[q][t]);          // (-inf for the lanes without it)
+                else { o_f[q][t] = wcell(need, age, p_, o_xy[q][t], o_m[q][t]); any_far = true; }     // (-inf for the lanes without it)
             };
-            fetch(0, b1, 1, r - 1);
-            fetch(1, b1, 1, r);
-            fetch(2, b1, 2, r - 1);
             fetch(3, b1 && l2, kL, r - kL);
             fetch(4, b1 && l2, kL + 1, r - kL);
             fetch(5, b1 && r2, kR, r);
@@ -2266,16 +2352,19 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
 #ifdef PG_PIPE_STATS
         const long long st_t2 = __builtin_readcyclecounter();
 #endif
-        // what the wave asked L2 for, both rows: one statement per row, requests and wait (it does nothing if no lane asked)
-        far_fetch8(sc_out, o_f[0], o_xy[0], o_m[0]);
-        far_fetch8(sc_out, o_f[1], o_xy[1], o_m[1]);
+        // what the wave asked L2 for, both sets: one statement per set, requests and wait (it does nothing if no lane asked)
+        if (any_far) {
+            far_fetch8(sc_out, o_f[0], o_xy[0], o_m[0]);
+            far_fetch8(sc_out, o_f[1], o_xy[1], o_m[1]);
+        }
 #ifdef PG_PIPE_STATS
         const long long st_t3 = __builtin_readcyclecounter();
 #endif
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int r = rr[q], j = d - r;
+            const int r = wrow[q], j = d - r;
             const bool active = kind[q] != 0;
+            if (__any(active)) n_now += 2;
             double bx = NIw, by = NIw, bm = NIw;
             unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
             if (kind[q] == 1) {
@@ -2285,26 +2374,26 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
                 const double lw0 = (double)__int_as_float(gl[q].z), lw1 = (double)__int_as_float(gl[q].w);
                 const double rw0 = (double)__int_as_float(gr[q].z), rw1 = (double)__int_as_float(gr[q].w);
                 const double lwA = lS ? lw1 : lw0, lwS = lS ? lw0 : lw1, rwA = rS ? rw1 : rw0, rwS = rS ? rw0 : rw1;
-                const pg_d2 a_ = o_xy[q][0], p_ = o_xy[q][1], c_ = o_xy[q][2], lx_ = o_xy[q][3], lm_ = o_xy[q][4], ry_ = o_xy[q][5], rm_ = o_xy[q][6], lr_ = o_xy[q][7];
-                const double am = o_m[q][0], pmm = o_m[q][1], cm = o_m[q][2], lxm = o_m[q][3], lmm = o_m[q][4], rym = o_m[q][5], rmm = o_m[q][6], lrm = o_m[q][7];
+                const pg_d2 lx_ = o_xy[q][3], lm_ = o_xy[q][4], ry_ = o_xy[q][5], rm_ = o_xy[q][6], lr_ = o_xy[q][7];
+                const double lxm = o_m[q][3], lmm = o_m[q][4], rym = o_m[q][5], rmm = o_m[q][6], lrm = o_m[q][7];
                 // scores only (pg_backptr derives the back-pointers): a state's value is the maximum over its edges of
                 // max(own + ge, max(other, M + ng) + go), M's over its pairs of (max(M + tM, max(X, Y) + tX) + lw) + rw -- the
                 // reference's candidates with the maxima regrouped (tools/gen_hot_asm.py); absent operands are -inf
                 auto gapv = [&](double own, double other, double m_) { return __builtin_fmax(own + ge, __builtin_fmax(other, m_ + ng) + go); };
-                auto pairv = [&](const pg_d2 &xy, double m_, double lw, double rw) {
-                    return (__builtin_fmax(m_ + tM, __builtin_fmax(xy.x, xy.y) + tX) + lw) + rw;
+                auto pairv = [&](double x_, double y_, double m_, double lw, double rw) {
+                    return (__builtin_fmax(m_ + tM, __builtin_fmax(x_, y_) + tX) + lw) + rw;
                 };
-                bx = gapv(a_.x, a_.y, am);
-                by = gapv(p_.y, p_.x, pmm);
-                bm = pairv(c_, cm, lwA, rwA);
+                bx = gapv(Ux[q], Uy[q], Um[q]);
+                by = gapv(Py[q], Px[q], Pm[q]);
+                bm = pairv(Cx[q], Cy[q], Cm[q], lwA, rwA);
                 if (__any(r2)) {
                     by = __builtin_fmax(by, gapv(ry_.y, ry_.x, rym));
-                    bm = __builtin_fmax(bm, pairv(rm_, rmm, lwA, rwS));
+                    bm = __builtin_fmax(bm, pairv(rm_.x, rm_.y, rmm, lwA, rwS));
                 }
                 if (__any(l2)) {
                     bx = __builtin_fmax(bx, gapv(lx_.x, lx_.y, lxm));
-                    bm = __builtin_fmax(bm, pairv(lm_, lmm, lwS, rwA));
-                    if (__any(l2 && r2)) bm = __builtin_fmax(bm, pairv(lr_, lrm, lwS, rwS));
+                    bm = __builtin_fmax(bm, pairv(lm_.x, lm_.y, lmm, lwS, rwA));
+                    if (__any(l2 && r2)) bm = __builtin_fmax(bm, pairv(lr_.x, lr_.y, lrm, lwS, rwS));
                 }
             } else if (kind[q] == 2) {
                 // first/last rows and columns, sites without edges, more than two edges, ...: the general rules
@@ -2340,8 +2429,22 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
                 *(PG_GLOBAL pg_d2 *)(srow + off24) = xy;
                 *(PG_GLOBAL double *)(srow + off24 + 16u) = bm;
             }
+            // the next step's registers: this cell is its (row, j-1), this step's (row-1, j) its (row-1, j-1)
+            Px[q] = bx; Py[q] = by; Pm[q] = bm;
+            Cx[q] = Ux[q]; Cy[q] = Uy[q]; Cm[q] = Um[q];
         }
-        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");  // the stores of five steps ago have retired (older cells of the run are read from L2)
+        {   // all but the stores of this step and the two before it have retired (older cells of the run are read from L2): a wave
+            // issues two stores per set with a row in the band, so the count is worked out, not assumed
+            const int tot = n_now + n_hist1 + n_hist2;
+            if (tot >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (tot >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (tot >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (tot >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (tot >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (tot >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            n_hist2 = n_hist1; n_hist1 = n_now;
+        }
         flag_store(&PM.progress[wave], d);
 #ifdef PG_PIPE_STATS
         {
@@ -2351,10 +2454,12 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
         }
 #endif
         ++d;
-        dA = nxt;
-        if ((nxt.s4 & 15) != 4 || d >= sleep || flag_load(&PM.abort_flag) != 0) break;
-        cur = nxt;
+        lo_prev = lo;
+        if (d >= run_end || flag_load(&PM.abort_flag) != 0) break;
+        cur.x = __builtin_amdgcn_readfirstlane(nxt.x); cur.y = __builtin_amdgcn_readfirstlane(nxt.y);
+        cur.z = __builtin_amdgcn_readfirstlane(nxt.z); cur.w = __builtin_amdgcn_readfirstlane(nxt.w);
     }
+    dA = psc[d];                                                   // (the array carries one entry of padding)
     // back to step(): this lane's row for the narrow diagonals, nothing in registers or prefetched; the ring's
     // memory holds wide-ring rows now -- the host marks no diagonal up to here as ring-resident (dp_abi.hip)
     row = dA.x + ((tid - dA.x) & (PNT - 1));
@@ -2433,6 +2538,15 @@ __device__ __noinline__ void follow_chunk(const PgDevJob *__restrict__ job, int 
             typedef unsigned u3 __attribute__((ext_vector_type(3)));
             u3 b; b.x = px; b.y = py; b.z = pm;
             *(PG_GLOBAL u3 *)(J.bp + 3 * at) = b;
+            if (flags & PG_FLAG_SCORE_CHECK) {
+                // the recurrence holds at this cell, bit for bit (dp_kernels.hip, pg_backptr has the reasoning): the cell's own
+                // scores have landed with its diagonal (the chunk is claimed behind the landed counter)
+                double sx, sy, sm_;
+                far_cell((PG_GLOBAL const double *)(J.sc + 3 * at), sx, sy, sm_);
+                const bool same = __double_as_longlong(bx) == __double_as_longlong(sx) && __double_as_longlong(by) == __double_as_longlong(sy) &&
+                                  __double_as_longlong(bm) == __double_as_longlong(sm_);
+                if (!same) report_fill_status(job, PG_FILL_SCORE_MISMATCH);
+            }
         }
     }
     if (lane == 0) ((PG_GLOBAL unsigned char *)job->bp_done)[chunk] = 1;
@@ -2464,14 +2578,16 @@ __device__ __noinline__ void pipe_follower(const PgDevJob *__restrict__ jobs, co
             const int next = peek_l2(fw + 2);
             if (next >= n_chunks) { left &= ~(1u << k); continue; }
             // a chunk's cells read the diagonals below its last one: claim it once those have landed
-            const int last = (next + 1) * PG_FOLLOW_CHUNK - 1 < nd - 1 ? (next + 1) * PG_FOLLOW_CHUNK - 1 : nd - 1;
+            // (with the score check the chunk's own last diagonal is read too: one more)
+            const int chk = (flags & PG_FLAG_SCORE_CHECK) ? 1 : 0;
+            const int last = ((next + 1) * PG_FOLLOW_CHUNK - 1 < nd - 1 ? (next + 1) * PG_FOLLOW_CHUNK - 1 : nd - 1) + chk;
             if (peek_l2(fw) < last) continue;                      // (follow[0] = landed + 1 >= last: diagonals <= last - 1 are there)
             int c = 0;
             if (lane == 0) c = __hip_atomic_fetch_add(fw + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             c = __builtin_amdgcn_readfirstlane(c);
             if (c >= n_chunks) { left &= ~(1u << k); continue; }
             // (another wave may have taken `next` in between: c is a later chunk, wait for it)
-            const int lastc = (c + 1) * PG_FOLLOW_CHUNK - 1 < nd - 1 ? (c + 1) * PG_FOLLOW_CHUNK - 1 : nd - 1;
+            const int lastc = ((c + 1) * PG_FOLLOW_CHUNK - 1 < nd - 1 ? (c + 1) * PG_FOLLOW_CHUNK - 1 : nd - 1) + chk;
             int spin = 0;
             while (peek_l2(fw) < lastc && spin < 200000) { __builtin_amdgcn_s_sleep(32); ++spin; }
             if (spin >= 200000) return;                            // the fill stopped publishing: pg_backptr writes this chunk
@@ -2614,7 +2730,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
 #endif
     if (tid >= PNT + 64 * PNA) {
         const View J = load_view(job);
-        pipe_loader(J, psc, lane, (PG_GLOBAL int *)job->follow, STRIP ? job : nullptr);
+        pipe_loader(J, psc, lane, (PG_GLOBAL int *)job->follow, STRIP ? job : nullptr, TAB_LDS);
         return;
     }
     if (tid >= PNT) {
@@ -2643,7 +2759,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
         strip_feeder(job, psc, tid, wave, flags);
         if (lane == 0) {
             const int aborted = flag_load(&PM.abort_flag);
-            if (aborted != 0) *(PG_GLOBAL int *)job->fill_status = aborted;
+            if (aborted != 0) report_fill_status(job, aborted);
         }
         return;
     }
@@ -3074,7 +3190,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
     // on unsynchronised operands still ends here with the flag set
     if (lane == 0) {
         const int aborted = flag_load(&PM.abort_flag);
-        if (aborted != 0) *(PG_GLOBAL int *)job->fill_status = aborted;
+        if (aborted != 0) report_fill_status(job, aborted);
     }
 }
 

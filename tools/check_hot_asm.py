@@ -4,7 +4,9 @@
   1. a VALU instruction that reads a lane mask (SGPR pair or vcc) written by a VALU compare comes at least TWO
      instructions after that compare (gfx940+: VALU-writes-SGPR -> VALU-reads-SGPR needs two wait states);
   2. a DPP move does not read a VGPR written by one of the two instructions before it;
-  3. every register the text names is in the asm statement's clobber list (dp_pipe.hip) or an operand.
+  3. every register the text names is in the asm statement's clobber list (dp_pipe.hip) or an operand;
+  4. a DPP move comes at least FIVE instructions after a scalar write of exec (SALU-writes-EXEC -> VALU DPP: five wait
+     states; the class 1 blocks run under reduced exec masks since round 5).
 
 Straight-line scan: a label resets the window (the code behind a branch target is checked from there on, and the
 generator places nothing mask-dependent directly behind a label).  Exit code 1 on a finding."""
@@ -60,6 +62,7 @@ def operands(t):
 def main():
     ins = instructions()
     bad = 0
+    since_exec = 99       # instructions since the last scalar write of exec
     pending = []          # (age, set of mask registers written by a VALU compare)
     recent_vwrites = []   # VGPRs written by the last two instructions
     named = set()
@@ -67,7 +70,7 @@ def main():
         if t.endswith(":"):
             pending = []
             recent_vwrites = []
-            continue
+            continue                                  # (since_exec carries over a label: fall-through paths count)
         op = t.split()[0]
         ops = operands(t)
         for o in ops:
@@ -84,6 +87,11 @@ def main():
                 if age < 2 and reads & regs:
                     print("mask read %d instruction(s) after the compare that writes it: %s" % (age, t))
                     bad += 1
+        # --- rule 4 ---
+        if "_dpp" in op and since_exec < 5:
+            print("DPP %d instruction(s) after a scalar write of exec: %s" % (since_exec, t))
+            bad += 1
+        since_exec = 0 if (op.startswith("s_") and ("saveexec" in op or (ops and ops[0] == "exec"))) else since_exec + 1
         # --- rule 2 ---
         if "_dpp" in op:
             src = vregs(ops[1]) if len(ops) > 1 else set()

@@ -77,15 +77,20 @@ class Emit:
     def a(self, s):
         self.cur.append(s)
 
-    def ring_addr(self, dst, age_bytes, col, present):
-        """dst = LDS address of the ring cell `age_bytes` (VGPR: age * 0x1800) back from this diagonal's row in ring column
-        `col` (VGPR: absolute LDS address of the column in ring row 0), or the all -inf null cell where `present` is off"""
+    def ring_row(self, dst, age_bytes):
+        """dst = byte offset (inside the ring) of the ring row `age_bytes` (VGPR: age * 0x1800, at most the ring) back from this
+        diagonal's: sb - age, plus the ring's size where that wraps (unsigned minimum of the two)"""
         a = self.a
         a("v_sub_u32_e32 v%d, %s, v%d" % (dst, self.cursb, age_bytes))
         a("v_add_u32_e32 v223, 0x16800, v%d" % dst)
         a("v_min_u32_e32 v%d, v%d, v223" % (dst, dst))
-        a("v_add_u32_e32 v%d, v%d, %s" % (dst, dst, col))
-        a("v_cndmask_b32_e64 v%d, %%[nulla], v%d, %s" % (dst, dst, present))
+
+    def ring_row_before(self, dst, src):
+        """dst = the ring row one diagonal before the row at `src` (both byte offsets inside the ring)"""
+        a = self.a
+        a("v_subrev_u32_e32 v%d, 0x1800, v%d" % (dst, src))
+        a("v_add_u32_e32 v223, 0x16800, v%d" % dst)
+        a("v_min_u32_e32 v%d, v%d, v223" % (dst, dst))
 
     def read_cell(self, cell, addr):
         self.a("ds_read2_b64 v[%d:%d], v%d offset1:1" % (cell[0], cell[0] + 3, addr))
@@ -149,54 +154,65 @@ def c1_ahead(E, k):
 
 
 def c1_issue(E, k, tag):
-    """Decode of the two records, every operand cell of the blocks requested in one batch, the next step's records behind it."""
+    """Decode of the two records, every operand cell of the blocks requested in one batch, the next step's records behind it.
+
+    The loader NORMALISES the records of this kernel's jobs (dp_pipe.hip, load_rec_chunk<., true>): a site with two bwd edges of
+    which exactly one starts at the previous site carries that edge in slot 0, the other one in slot 1, and the PR_TWO flag
+    (bit 24; bits 25-31 are zero) -- the fill computes values only, so the order of a site's list does not matter to it.  What is
+    left of the decode: flag, the other edge's distance, two conversions per side.  Each block runs with exec = the lanes whose
+    site has the other edge: no lane without one reads or merges anything (before: an all -inf cell selected per operand)."""
     a = E.a
     RL, CR = RLK[k], CRK[k]
     sfx = "%s%d_%%=" % (tag, k)
-    # decode: two edges? the other edge listed first? its distance, the two weights (previous-site edge / other edge)
-    for (rec, l2, lS, kk, wA, wS, t0, t1) in ((RL, "s[74:75]", "s[78:79]", KL, LWA, LWS, 217, 218), (CR, "s[76:77]", "s[80:81]", KR, RWA, RWS, 219, 220)):
-        a("v_bfe_u32 v%d, v%d, 17, 7" % (t0, rec))
-        a("v_and_b32_e32 v%d, 0xffff, v%d" % (t1, rec + 1))
-        a("v_cmp_eq_u32_e64 %s, 2, v%d" % (l2, t0))
-        a("v_cmp_ne_u32_e64 %s, 1, v%d" % (lS, t1))
-        a("v_lshrrev_b32_e32 v%d, 16, v%d" % (t0, rec + 1))
-        a("s_and_b64 %s, %s, s[60:61]" % (l2, l2))
-        a("s_and_b64 %s, %s, %s" % (lS, lS, l2))
-        a("v_cndmask_b32_e64 v%d, v%d, v%d, %s" % (kk, t0, t1, lS))
-        a("v_cndmask_b32_e64 v%d, v%d, v%d, %s" % (t0, rec + 2, rec + 3, lS))
-        a("v_cndmask_b32_e64 v%d, v%d, v%d, %s" % (t1, rec + 3, rec + 2, lS))
-        a("v_cvt_f64_f32_e32 %s, v%d" % (pr(wA), t0))
-        a("v_cvt_f64_f32_e32 %s, v%d" % (pr(wS), t1))
+    a("v_cmp_lt_u32_e64 s[74:75], %%[c24], v%d" % RL)             # l2: the left site has another edge (x > 0xffffff)
+    a("v_cmp_lt_u32_e64 s[76:77], %%[c24], v%d" % CR)             # r2
+    a("v_lshrrev_b32_e32 v%d, 16, v%d" % (KL, RL + 1))
+    a("v_lshrrev_b32_e32 v%d, 16, v%d" % (KR, CR + 1))
+    a("s_and_b64 s[74:75], s[74:75], s[60:61]")
+    a("s_and_b64 s[76:77], s[76:77], s[60:61]")
+    a("v_cvt_f64_f32_e32 %s, v%d" % (pr(LWA), RL + 2))            # weights: previous-site edge / other edge
+    a("v_cvt_f64_f32_e32 %s, v%d" % (pr(LWS), RL + 3))
+    a("v_cvt_f64_f32_e32 %s, v%d" % (pr(RWA), CR + 2))
+    a("v_cvt_f64_f32_e32 %s, v%d" % (pr(RWS), CR + 3))
     a("s_and_b64 s[82:83], s[74:75], s[76:77]")
     # ---- every operand cell of the blocks below requested in ONE batch (each block only if a lane of the wave needs it):
     #   right site's other edge: (row, j-kR) -> U, (row-1, j-kR) -> V; left site's: (row-kL, j) -> W1, (row-kL, j-1) -> W2;
     #   both: (row-kL, j-kR) -> W3.
     a("s_cmp_eq_u64 s[76:77], 0")
     a("s_cbranch_scc1 .Lpg_rdL%s" % sfx)
+    a("s_and_saveexec_b64 s[62:63], s[76:77]")
     a("v_mul_u32_u24_e32 v217, 0x1800, v%d" % KR)
-    E.ring_addr(218, 217, "%[tid24]", "s[76:77]")
-    a("v_add_u32_e32 v217, 0x1800, v217")
-    E.ring_addr(219, 217, "%[bpos24]", "s[76:77]")
+    E.ring_row(218, 217)
+    E.ring_row_before(219, 218)
+    a("v_add_u32_e32 v218, v218, %[tid24]")
+    a("v_add_u32_e32 v219, v219, %[bpos24]")
     E.read_cell(U, 218)
     E.read_cell(V, 219)
+    a("s_mov_b64 exec, s[62:63]")
     a(".Lpg_rdL%s:" % sfx)
     a("s_cmp_eq_u64 s[74:75], 0")
     a("s_cbranch_scc1 .Lpg_rdX%s" % sfx)
+    a("s_and_saveexec_b64 s[62:63], s[74:75]")
     a("v_sub_u32_e32 v%d, %%[tid], v%d" % (POSL, KL))
-    a("v_and_b32_e32 v%d, 0xff, v%d" % (POSL, POSL))
-    a("v_mad_u32_u24 v%d, v%d, 24, %%[ringb]" % (POSL, POSL))
     a("v_mul_u32_u24_e32 v217, 0x1800, v%d" % KL)
-    E.ring_addr(218, 217, "v%d" % POSL, "s[74:75]")
-    a("v_add_u32_e32 v219, 0x1800, v217")
-    E.ring_addr(220, 219, "v%d" % POSL, "s[74:75]")
+    a("v_and_b32_e32 v%d, 0xff, v%d" % (POSL, POSL))
+    E.ring_row(218, 217)
+    a("v_mad_u32_u24 v%d, v%d, 24, %%[ringb]" % (POSL, POSL))
+    E.ring_row_before(220, 218)
+    a("v_add_u32_e32 v218, v218, v%d" % POSL)
+    a("v_add_u32_e32 v220, v220, v%d" % POSL)
     E.read_cell(W1, 218)
     E.read_cell(W2, 220)
     a("s_cmp_eq_u64 s[82:83], 0")
-    a("s_cbranch_scc1 .Lpg_rdX%s" % sfx)
+    a("s_cbranch_scc1 .Lpg_rdY%s" % sfx)
+    a("s_mov_b64 exec, s[82:83]")                                # (a subset of the block's lanes)
     a("v_add_u32_e32 v217, v%d, v%d" % (KL, KR))
     a("v_mul_u32_u24_e32 v217, 0x1800, v217")
-    E.ring_addr(220, 217, "v%d" % POSL, "s[82:83]")
+    E.ring_row(220, 217)
+    a("v_add_u32_e32 v220, v220, v%d" % POSL)
     E.read_cell(W3, 220)
+    a(".Lpg_rdY%s:" % sfx)
+    a("s_mov_b64 exec, s[62:63]")
     a(".Lpg_rdX%s:" % sfx)
     c1_ahead(E, k)
 
@@ -213,23 +229,29 @@ def c1_math(E, k, tag):
     # ---- the right site's other edge: Y from (row, j-kR), the pair (previous-site left edge, it) from (row-1, j-kR) ----
     a("s_cmp_eq_u64 s[76:77], 0")
     a("s_cbranch_scc1 .Lpg_noR%s" % sfx)
+    a("s_and_saveexec_b64 s[62:63], s[76:77]")
     E.gap_value(U, 1, 0, T[0], T[1], T[2])
     E.pair_value(V, tmx, LWA, RWS, T[3], T[4])
     a("v_max_f64 %s, %s, %s" % (pr(BY), pr(BY), pr(T[0])))
     a("v_max_f64 %s, %s, %s" % (pr(BM), pr(BM), pr(T[3])))
+    a("s_mov_b64 exec, s[62:63]")
     a(".Lpg_noR%s:" % sfx)
     # ---- the left site's other edge: X from (row-kL, j), the pair (it, previous-site right edge) from (row-kL, j-1) ----
     a("s_cmp_eq_u64 s[74:75], 0")
     a("s_cbranch_scc1 .Lpg_noL%s" % sfx)
+    a("s_and_saveexec_b64 s[62:63], s[74:75]")
     E.gap_value(W1, 0, 1, T[0], T[1], T[2])
     E.pair_value(W2, tmx, LWS, RWA, T[3], T[4])
     a("v_max_f64 %s, %s, %s" % (pr(BX), pr(BX), pr(T[0])))
     a("v_max_f64 %s, %s, %s" % (pr(BM), pr(BM), pr(T[3])))
     # both sites have another edge: the pair of the two, from (row-kL, j-kR)
     a("s_cmp_eq_u64 s[82:83], 0")
-    a("s_cbranch_scc1 .Lpg_noL%s" % sfx)
+    a("s_cbranch_scc1 .Lpg_noB%s" % sfx)
+    a("s_mov_b64 exec, s[82:83]")
     E.pair_value(W3, tmx, LWS, RWS, T[5], T[6])
     a("v_max_f64 %s, %s, %s" % (pr(BM), pr(BM), pr(T[5])))
+    a(".Lpg_noB%s:" % sfx)
+    a("s_mov_b64 exec, s[62:63]")
     a(".Lpg_noL%s:" % sfx)
 
 
@@ -524,9 +546,7 @@ def step(E, k):
     if "y" in EXP:           # timing experiment / debugging: never the short way
         a("s_branch .Lpg_slow%s" % sfx)
     a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)          # active: row <= hi (the X part works it out again)
-    c1_test(E, k, wait=False)
-    a("s_cbranch_vccz .Lpg_slow%s" % sfx)                      # no multi-edge cell in this wave: the usual way sees to the rest
-    c1_issue(E, k, "f")
+    c1_issue(E, k, "f")                                        # (a wave without a multi-edge cell finds its masks empty: the decode and the records after next is all it does)
     shift_and_x()
     c1_math(E, k, "f")
     a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
