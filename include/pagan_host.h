@@ -103,8 +103,13 @@ int  pagan_msa_align(pagan_msa *m);
  * pagan_assign_units over pagan_msa_node_cost, each aligns its share (pagan_msa_align_nodes:
  * model, anchors, DP on this rank's device(s), parent graph), exports what the alignment left behind
  * (pagan_msa_export_result: path columns + used child edges + max_end, a few bytes per column) and
- * imports the other ranks' results (pagan_msa_import_result builds those parents locally).
- * pagan_msa_finish after the last round.  pagan_msa_align is this loop with one rank.           */
+ * imports the other ranks' results (pagan_msa_import_result stores them; the parent graph of an
+ * imported node is built when this process needs it -- when it claims a node above, or is asked for
+ * the rows -- so the ranks shard the parent graphs as they shard the alignments: node.cpp:196-223,
+ * 273-345, a thread builds the ancestor of the node it aligned).  pagan_msa_finish after the last
+ * round builds what is pending and the rows; pagan_msa_finish_lazy leaves both to the first call
+ * that needs them (a rank that is never asked for the alignment never builds them).
+ * pagan_msa_align is this loop with one rank.                                                  */
 int     pagan_msa_ready(const pagan_msa *m, int32_t *ids, int32_t cap);    /* count (may exceed cap) */
 int     pagan_msa_remaining(const pagan_msa *m);                           /* internal nodes not yet done */
 int64_t pagan_msa_node_cost(const pagan_msa *m, int32_t node);             /* cells estimate of a ready node */
@@ -112,6 +117,8 @@ int     pagan_msa_align_nodes(pagan_msa *m, int32_t n, const int32_t *nodes);
 int64_t pagan_msa_export_result(const pagan_msa *m, int32_t node, void *buf, int64_t cap);  /* bytes needed/written */
 int     pagan_msa_import_result(pagan_msa *m, const void *buf, int64_t bytes);
 int     pagan_msa_finish(pagan_msa *m);
+int     pagan_msa_finish_lazy(pagan_msa *m);
+int     pagan_msa_parents_built(const pagan_msa *m);                       /* parent graphs this process has built so far */
 int     pagan_msa_data_type(const pagan_msa *m);                           /* 1 DNA, 2 protein */
 int     pagan_msa_node_device(const pagan_msa *m, int32_t k);              /* device internal node k ran on; -1: another rank */
 /* TEST SEAM, never set by the product: replaces pagan_dp_align_batch as the thing the work queue hands its

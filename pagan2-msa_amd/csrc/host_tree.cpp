@@ -124,6 +124,7 @@ struct NodeWork {                // everything one internal node's alignment con
     bool has_res = false;        // res is valid (aligned here, or imported from the rank that aligned it)
     bool has_job = false;        // gl/gr/pm/pb are valid: this process prepared and aligned the node
     int  device = -1;            // device the alignment ran on (-1: another rank)
+    bool parent_pending = false; // imported: the result is stored, the parent graph is built when somebody needs it (ensure_graph)
 };
 
 } // namespace
@@ -151,6 +152,10 @@ struct pagan_msa {
                                          // most-common table where it is defined (basic_alignment.cpp:146-149)
     pagan_batch_fn backend = nullptr;    // test seam (pagan_msa_set_batch_backend); null = pagan_dp_align_batch
     void *backend_user = nullptr;
+    std::atomic<int> parents_built{0};   // parent graphs this process has built (pagan_msa_parents_built)
+    std::atomic<int> lazy_err{0};        // first error of a deferred parent build (an imported result that does not fit the child graphs)
+    bool rows_built = false;             // m->rows are valid (pagan_msa_finish builds them at once, pagan_msa_finish_lazy on first use)
+    std::mutex lazy_mu;                  // deferred builds started from the accessors
     ~pagan_msa() { for (auto &w : work) if (w.has_res) pagan_result_free(&w.res); }
 };
 
@@ -391,6 +396,8 @@ bool node_ready(const pagan_msa *m, int id) {
     return m->done[m->id_of_tree[t.left]] && m->done[m->id_of_tree[t.right]];
 }
 
+int ensure_graph(pagan_msa *m, int id);
+
 // What align_sequences_this_node does before the aligner is called (node.cpp:70-152): the model for
 // dist = d_left + d_right (serialised in the reference too: omp critical, node.cpp:415-416), the
 // child graphs' views, anchors -> tunnel.
@@ -408,6 +415,11 @@ void prepare_node(pagan_msa *m, int id, int round) {
         w.model = it->second;
     }
     w.node = id; w.level = round;
+    {   // (rank mode: a child that another rank aligned gets its graph now -- and so does whatever is pending below it)
+        int rc = ensure_graph(m, m->id_of_tree[t.left]);
+        if (rc == PAGAN_OK) rc = ensure_graph(m, m->id_of_tree[t.right]);
+        if (rc != PAGAN_OK) { int zero = 0; m->lazy_err.compare_exchange_strong(zero, rc); return; }
+    }
     const SeqGraph &gl = m->graph[m->id_of_tree[t.left]]->g, &gr = m->graph[m->id_of_tree[t.right]]->g;
     w.gl = gl.view(); w.gr = gr.view(); w.pm = w.model->view();
     w.banded = false;
@@ -519,6 +531,63 @@ int build_parent(pagan_msa *m, int id, int unit_nodes) {
     // (grandchildren's device copies are no longer needed: their parents are built)
     gl.dev.reset(); gr.dev.reset();
     if (m->opts.mostcommon) fix_ambiguous_states(m, id);
+    w.parent_pending = false;
+    m->parents_built.fetch_add(1);
+    return PAGAN_OK;
+}
+
+// Sites of a node's graph -- of the graph itself, or, for an imported node whose parent graph has not been built yet, what
+// it will have: one site per alignment column plus the start and the end site (create_ancestral_sequence,
+// basic_alignment.cpp:61-179: skipped and later deleted columns stay as sites).
+int sites_of(const pagan_msa *m, int id) {
+    if (m->graph[id]) return m->graph[id]->g.n_sites();
+    return m->work[id - m->n_leaves].res.n_cols + 2;
+}
+
+// The graph of node `id`, built now if it is an imported node's that nobody has needed so far -- together with whatever is
+// pending below it, children first (iteratively: a caterpillar tree is as deep as it has leaves).  Rank mode (one process
+// per GPU): a rank builds the parents of the nodes it aligns and of the imported nodes BELOW the nodes it claims; the rest
+// only if it is asked for the rows (node.cpp:196-223, 273-345: a thread builds the ancestor of the node it aligned).
+// Ready nodes have disjoint subtrees, so the units of a round may call this side by side.
+int ensure_graph(pagan_msa *m, int id) {
+    if (m->graph[id]) return PAGAN_OK;
+    std::vector<int> stack{id};
+    while (!stack.empty()) {
+        const int cur = stack.back();
+        if (m->graph[cur]) { stack.pop_back(); continue; }
+        if (cur < m->n_leaves || !m->done[cur]) return PAGAN_E_INTERNAL;       // (a leaf always has its graph; a node that is not done has no path)
+        const TreeNode &t = m->tree[m->tree_of_id[cur]];
+        const int lid = m->id_of_tree[t.left], rid = m->id_of_tree[t.right];
+        if (!m->graph[lid] || !m->graph[rid]) {
+            if (!m->graph[lid]) stack.push_back(lid);
+            if (!m->graph[rid]) stack.push_back(rid);
+            continue;
+        }
+        NodeWork &w = m->work[cur - m->n_leaves];
+        // what pagan_msa_import_result could not check without the child graphs: a column names a child site (1 .. n_sites - 2)
+        // or none (-1) -- which of the two follows from its path state --, a used edge is an edge of the child
+        const SeqGraph &gl = m->graph[lid]->g, &gr = m->graph[rid]->g;
+        const pagan_result &r = w.res;
+        bool good = w.has_res;
+        for (int k = 0; good && k < r.n_cols; ++k) {
+            const pagan_col &c = r.cols[k];
+            const bool hl = c.path_state == PAGAN_MATCHED || c.path_state == PAGAN_XGAPPED || c.path_state == PAGAN_XSKIPPED;
+            const bool hr = c.path_state == PAGAN_MATCHED || c.path_state == PAGAN_YGAPPED || c.path_state == PAGAN_YSKIPPED;
+            if (hl ? (c.left < 1 || c.left > gl.n_sites() - 2) : c.left != -1) good = false;
+            if (hr ? (c.right < 1 || c.right > gr.n_sites() - 2) : c.right != -1) good = false;
+        }
+        for (int k = 0; good && k < r.n_left_used; ++k) if (r.left_used[k] < 0 || r.left_used[k] >= gl.n_edges()) good = false;
+        for (int k = 0; good && k < r.n_right_used; ++k) if (r.right_used[k] < 0 || r.right_used[k] >= gr.n_edges()) good = false;
+        if (!good) return PAGAN_E_ARG;
+        const double t0 = now_s();
+        const int rc = build_parent(m, cur, 1 << 20);                          // (imported: w.device is -1, the host builder)
+        {
+            std::lock_guard<std::mutex> g(m->mu);
+            m->tm.build_s += now_s() - t0;
+        }
+        if (rc != PAGAN_OK) return rc;
+        stack.pop_back();
+    }
     return PAGAN_OK;
 }
 
@@ -530,6 +599,7 @@ int run_unit(pagan_msa *m, const std::vector<int> &ids, int dev, int round, int 
     const int n = m->n_leaves;
     double t0 = now_s();
     parallel_for((int)ids.size(), threads, [&](int r) { set_anchor_device(dev); prepare_node(m, ids[r], round); });
+    if (const int e = m->lazy_err.load()) return e;
     const double t_prep = now_s() - t0;
     t0 = now_s();
     std::vector<int> ks(ids.size());
@@ -585,7 +655,7 @@ int run_unit(pagan_msa *m, const std::vector<int> &ids, int dev, int round, int 
 
 int64_t node_cost_estimate(const pagan_msa *m, int id) {
     const TreeNode &t = m->tree[m->tree_of_id[id]];
-    const int64_t lx = m->graph[m->id_of_tree[t.left]]->g.n_sites(), ly = m->graph[m->id_of_tree[t.right]]->g.n_sites();
+    const int64_t lx = sites_of(m, m->id_of_tree[t.left]), ly = sites_of(m, m->id_of_tree[t.right]);
     // before the anchors are known: a tunnel is ~ (2 * offset + a few) cells per row, a full matrix Lx * Ly
     return m->opts.use_anchors ? (lx + ly) * (int64_t)(2 * m->opts.anchors_offset + 16) : lx * ly;
 }
@@ -648,14 +718,36 @@ int pagan_msa_align_nodes(pagan_msa *m, int32_t n_ids, const int32_t *ids) {
     return PAGAN_OK;
 }
 
-int pagan_msa_finish(pagan_msa *m) {
-    if (!m || m->aligned || m->remaining != 0) return PAGAN_E_ARG;
+// The rows of the alignment need every node's graph (an ancestor's row is read off its sites; the leaves' columns follow
+// the child maps down from the root): parents still pending (imported nodes, rank mode) are built first.
+static int ensure_rows(pagan_msa *m) {
+    std::lock_guard<std::mutex> g(m->lazy_mu);
+    if (m->rows_built) return PAGAN_OK;
     const double t0 = now_s();
+    const int rc = ensure_graph(m, m->id_of_tree[m->root]);
+    if (rc != PAGAN_OK) return rc;
     build_rows(m);
     m->tm.total_s += now_s() - t0;
+    m->rows_built = true;
+    return PAGAN_OK;
+}
+
+int pagan_msa_finish(pagan_msa *m) {
+    if (!m || m->aligned || m->remaining != 0) return PAGAN_E_ARG;
+    m->aligned = true;
+    return ensure_rows(m);
+}
+
+// Rank mode: the walk is over, but this process may never be asked for the rows -- the graphs of the nodes other ranks
+// aligned above its own are then never built here.  The first call that needs them (alignment length / rows / FASTA, a
+// node's graph) builds what is pending.
+int pagan_msa_finish_lazy(pagan_msa *m) {
+    if (!m || m->aligned || m->remaining != 0) return PAGAN_E_ARG;
     m->aligned = true;
     return PAGAN_OK;
 }
+
+int pagan_msa_parents_built(const pagan_msa *m) { return m ? m->parents_built.load() : PAGAN_E_ARG; }
 
 int pagan_msa_align(pagan_msa *m) {
     if (!m || m->aligned) return PAGAN_E_ARG;
@@ -763,7 +855,9 @@ int64_t pagan_msa_export_result(const pagan_msa *m, int32_t id, void *buf, int64
     return need;
 }
 
-// Takes over a node aligned by another rank: stores the result, builds the parent graph, marks the node done.
+// Takes over a node aligned by another rank: stores the result and marks the node done.  The parent graph is NOT built here
+// (round 5; before, every rank built every parent, on the one thread that drains the posting log): ensure_graph builds it
+// when this process claims a node above it or is asked for the rows.
 int pagan_msa_import_result(pagan_msa *m, const void *buf, int64_t bytes) {
     if (!m || !buf || bytes < 12 * 4 + 16) return PAGAN_E_ARG;
     const char *p = (const char *)buf;
@@ -801,28 +895,25 @@ int pagan_msa_import_result(pagan_msa *m, const void *buf, int64_t bytes) {
     if (nl) std::memcpy(r.left_used, p, 4 * (size_t)nl);
     p += 4 * (size_t)nl;
     if (nr) std::memcpy(r.right_used, p, 4 * (size_t)nr);
-    // nothing of the payload is kept before all of it has been checked against the child graphs: a column names a child
-    // site (1 .. n_sites - 2) or none (-1), and which of the two it names follows from its path state
+    // What can be checked without the child graphs is checked now: the path states, and that a column names a child site
+    // exactly where its state says it has one.  The rest -- the sites against the children's sizes, the used edges against
+    // their edge lists -- when the parent graph is built (ensure_graph), which happens when this process needs it: when it
+    // claims a node above, or is asked for the rows.  Nothing of the payload is used as an index before that.
     const TreeNode &t = m->tree[m->tree_of_id[id]];
-    const SeqGraph &gl = m->graph[m->id_of_tree[t.left]]->g, &gr = m->graph[m->id_of_tree[t.right]]->g;
     bool good = r.status == PAGAN_DP_REACHED || r.status == PAGAN_DP_UNREACHABLE;
     for (int k = 0; good && k < n_cols; ++k) {
         const pagan_col &c = r.cols[k];
         if (c.path_state < PAGAN_MATCHED || c.path_state > PAGAN_YSKIPPED) { good = false; break; }
         const bool hl = c.path_state == PAGAN_MATCHED || c.path_state == PAGAN_XGAPPED || c.path_state == PAGAN_XSKIPPED;
         const bool hr = c.path_state == PAGAN_MATCHED || c.path_state == PAGAN_YGAPPED || c.path_state == PAGAN_YSKIPPED;
-        if (hl ? (c.left < 1 || c.left > gl.n_sites() - 2) : c.left != -1) good = false;
-        if (hr ? (c.right < 1 || c.right > gr.n_sites() - 2) : c.right != -1) good = false;
+        if (hl ? c.left < 1 : c.left != -1) good = false;
+        if (hr ? c.right < 1 : c.right != -1) good = false;
     }
-    for (int k = 0; good && k < nl; ++k) if (r.left_used[k] < 0 || r.left_used[k] >= gl.n_edges()) good = false;
-    for (int k = 0; good && k < nr; ++k) if (r.right_used[k] < 0 || r.right_used[k] >= gr.n_edges()) good = false;
     if (!good) { pagan_result_free(&r); std::memset(&r, 0, sizeof(r)); return PAGAN_E_ARG; }
     w.has_res = true; w.has_job = false; w.device = -1; w.node = id; w.level = m->rounds;
-    w.imp_l = gl.n_sites(); w.imp_r = gr.n_sites();         // (no job was prepared here: node_info reports the children's sizes from these)
-    const double t0 = now_s();
-    const int rc = build_parent(m, id, 1 << 20);          // (imported: w.device is -1, the host builder)
-    m->tm.build_s += now_s() - t0;
-    if (rc != PAGAN_OK) return rc;
+    w.imp_l = sites_of(m, m->id_of_tree[t.left]); w.imp_r = sites_of(m, m->id_of_tree[t.right]);   // (no job was prepared here: node_info reports the children's sizes from these)
+    if (r.status != PAGAN_DP_REACHED) return PAGAN_E_INTERNAL;       // (the owner retries an unreachable corner itself: it never posts one)
+    w.parent_pending = true;
     m->done[id] = 1; --m->remaining;
     return PAGAN_OK;
 }
@@ -865,10 +956,16 @@ int pagan_msa_timing_get(const pagan_msa *m, pagan_msa_timing *o) {
     return PAGAN_OK;
 }
 
-int pagan_msa_alignment_length(const pagan_msa *m) { return (m && m->aligned) ? (int)m->rows[0].size() : PAGAN_E_ARG; }
+int pagan_msa_alignment_length(const pagan_msa *m) {
+    if (!m || !m->aligned) return PAGAN_E_ARG;
+    if (const int rc = ensure_rows(const_cast<pagan_msa *>(m))) return rc;       // (pagan_msa_finish_lazy: built on first use)
+    return (int)m->rows[0].size();
+}
 
 int pagan_msa_alignment_row(const pagan_msa *m, int32_t leaf, char *buf) {
-    if (!m || !m->aligned || leaf < 0 || leaf >= (int)m->rows.size() || !buf) return PAGAN_E_ARG;
+    if (!m || !m->aligned || !buf) return PAGAN_E_ARG;
+    if (const int rc = ensure_rows(const_cast<pagan_msa *>(m))) return rc;
+    if (leaf < 0 || leaf >= (int)m->rows.size()) return PAGAN_E_ARG;
     std::memcpy(buf, m->rows[leaf].c_str(), m->rows[leaf].size() + 1);
     return PAGAN_OK;
 }
@@ -884,6 +981,7 @@ int pagan_msa_write_fasta(const pagan_msa *m, const char *path, int32_t chars_by
 // right subtree (node.h:277-290) -- internal nodes named #k# in alignment order (node.h:479-495).
 int pagan_msa_write_fasta_nodes(const pagan_msa *m, const char *path, int32_t chars_by_line, int32_t include_internal) {
     if (!m || !m->aligned || !path) return PAGAN_E_ARG;
+    if (const int rc = ensure_rows(const_cast<pagan_msa *>(m))) return rc;
     const size_t width = chars_by_line > 0 ? (size_t)chars_by_line : 60;
     std::FILE *f = std::fopen(path, "w");
     if (!f) return PAGAN_E_ARG;
@@ -913,6 +1011,11 @@ int pagan_msa_write_fasta_nodes(const pagan_msa *m, const char *path, int32_t ch
 
 void *pagan_msa_node_graph(const pagan_msa *m, int32_t node) {
     if (!m || node < 0 || node >= (int)m->graph.size()) return nullptr;
+    if (!m->graph[node] && m->done[node]) {                        // (an imported node's graph: built when somebody asks for it)
+        pagan_msa *mm = const_cast<pagan_msa *>(m);
+        std::lock_guard<std::mutex> g(mm->lazy_mu);
+        if (ensure_graph(mm, node) != PAGAN_OK) return nullptr;
+    }
     return m->graph[node].get();
 }
 

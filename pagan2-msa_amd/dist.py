@@ -26,6 +26,10 @@ collectives)"): what travels is a finished path, ~1 byte per alignment column pl
 meet in torch.distributed for what the bench contract asks: the barrier around the timed region and the maximum of the
 elapsed time.
 """
+import datetime
+import os
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -93,7 +97,7 @@ def all_gather_bytes(chunks, device="cpu"):
 
 
 _walks = [0]
-_posted = {}                      # walk -> keys this rank posted; deleted once every rank has acknowledged the walk
+_posted = {}                      # key space -> keys this rank posted; deleted once every rank has acknowledged the walk
 
 
 def _store():
@@ -101,12 +105,36 @@ def _store():
     return c10d._get_default_store()
 
 
+def _get_blocking(store, key, what):
+    """store.get(key) once the key exists.  Waits in slices (a store's own timeout would end the walk when one node's
+    alignment outlasts it) up to PAGAN_STORE_TIMEOUT_S seconds (default two hours): a rank that died after claiming a node
+    ends in an error that names the node, not in a silent hang."""
+    deadline = time.time() + float(os.environ.get("PAGAN_STORE_TIMEOUT_S", "7200"))
+    while True:
+        try:
+            store.wait([key], datetime.timedelta(seconds=20))
+            return store.get(key)
+        except RuntimeError as e:             # (torch.distributed.DistStoreError is one)
+            if "imeout" not in str(e) and "imed out" not in str(e):
+                raise
+            if time.time() > deadline:
+                raise RuntimeError("pagan2_msa_amd.dist: gave up waiting for %s (%s): did its owner die?" % (what, key)) from e
+
+
+def _key_space(store, walk, r):
+    """Key prefix of this call: the walk's name plus an EPOCH -- the number of earlier calls this rank made under the same
+    name (a counter per rank in the store).  A name reused in the same store (tests pass walk=7; a service might number
+    its jobs modulo something) starts from fresh keys instead of a stale count, stale claims and a finished log."""
+    epoch = int(store.add("pagan/%d/epoch/%d" % (walk, r), 1)) - 1
+    return "pagan/%d.%d/" % (walk, epoch)
+
+
 def _reap(store, w):
     """Deletes this rank's keys of earlier walks that EVERY rank has finished reading (each rank adds 1 to the walk's
     `done` counter when it has imported everything): no assumption about who posted what in which walk."""
     for old in list(_posted):
         try:
-            if store.add("pagan/%d/done" % old, 0) < w:
+            if store.add(old + "done", 0) < w:
                 continue
             for key in _posted.pop(old):
                 store.delete_key(key)
@@ -114,11 +142,12 @@ def _reap(store, w):
             _posted.pop(old, None)
 
 
-def _align_queue(msa, store, walk, w, r, on_round, quota):
-    P = "pagan/%d/" % walk
+def _align_queue(msa, store, P, w, r, on_round, quota):
     mine_all, lost = set(), set()
     seen = 0                      # entries of the posting log this rank has gone through
     rounds = []
+    if r == 0:
+        _posted[P] += [P + "count", P + "done"]       # (the counters themselves: rank 0 deletes them with its keys)
 
     def drain(block):
         """Imports what has been posted since the last look, in posting order (a parent is always posted after its
@@ -130,10 +159,10 @@ def _align_queue(msa, store, walk, w, r, on_round, quota):
             cnt = seen + 1
         while seen < cnt:
             seen += 1
-            n = int(store.get(P + "log/%d" % seen))              # (blocks until the poster has written the entry)
+            n = int(_get_blocking(store, P + "log/%d" % seen, "posting %d of the walk" % seen))     # (until the poster has written the entry)
             if n in mine_all:
                 continue
-            buf = np.frombuffer(store.get(P + "node/%d" % n), np.uint8)
+            buf = np.frombuffer(_get_blocking(store, P + "node/%d" % n, "node %d" % n), np.uint8)
             msa.import_result(buf)
             lost.discard(n)
             moved += int(buf.shape[0])
@@ -165,19 +194,21 @@ def _align_queue(msa, store, walk, w, r, on_round, quota):
                 store.set(P + "node/%d" % n, msa.export_result(n).tobytes())
                 idx = int(store.add(P + "count", 1))
                 store.set(P + "log/%d" % idx, str(n))
-                _posted[walk] += [P + "node/%d" % n, P + "log/%d" % idx, P + "claim/%d" % n]
+                _posted[P] += [P + "node/%d" % n, P + "log/%d" % idx, P + "claim/%d" % n]
         rounds.append((len(ready), len(mine), moved))
         if on_round:
             on_round(len(rounds) - 1, ready, mine)
     return rounds
 
 
-def align_sharded(msa, assign, device="cpu", on_round=None, exchange="queue", walk=None, quota=None):
+def align_sharded(msa, assign, device="cpu", on_round=None, exchange="queue", walk=None, quota=None, lazy_rows=True):
     """The whole progressive alignment of `msa` (a host.Msa, created identically on every rank) sharded over the ranks.
     exchange: "queue" (dynamic claims through the store), "store" / "collective" (level-synchronous rounds dealt by
     `assign(costs, n_workers)`, the work-queue rule host.assign_units) -- see the module text.  `walk` names the key space
     of this call in the store; None: a per-process call counter, which is only right when every rank calls this the same
     number of times.  `quota`: most nodes a rank claims at a time in queue mode (None: its share of what is ready).
+    lazy_rows: the parent graphs of imported nodes this rank never needed, and the rows, are left to the first call that asks
+    for them (Msa.finish(lazy=True)): the ranks shard the parent graphs as they shard the alignments.
     Returns per-round records [(n_ready, n_mine, bytes imported)]."""
     w, r = world(), rank()
     rounds = []
@@ -185,14 +216,18 @@ def align_sharded(msa, assign, device="cpu", on_round=None, exchange="queue", wa
         walk = _walks[0]
         _walks[0] += 1
     store = _store() if (w > 1 and exchange in ("store", "queue")) else None
+    P = None
     if store is not None:
         _reap(store, w)
-        _posted[walk] = []
+        P = _key_space(store, walk, r)
+        _posted[P] = []
     if store is not None and exchange == "queue":
-        rounds = _align_queue(msa, store, walk, w, r, on_round, quota)
-        store.add("pagan/%d/done" % walk, 1)
-        msa.finish()
+        rounds = _align_queue(msa, store, P, w, r, on_round, quota)
+        store.add(P + "done", 1)
+        msa.finish(lazy=lazy_rows)
         return rounds
+    if store is not None and r == 0:
+        _posted[P].append(P + "done")
     while msa.remaining > 0:
         ready = msa.ready()
         if not ready:
@@ -206,12 +241,12 @@ def align_sharded(msa, assign, device="cpu", on_round=None, exchange="queue", wa
         moved = 0
         if store is not None:
             for n, c in zip(mine, chunks):
-                store.set("pagan/%d/%d" % (walk, n), c.tobytes())
-                _posted[walk].append("pagan/%d/%d" % (walk, n))
+                store.set(P + "%d" % n, c.tobytes())
+                _posted[P].append(P + "%d" % n)
             for n, o in zip(ready, owner):
                 if int(o) == r:
                     continue
-                buf = np.frombuffer(store.get("pagan/%d/%d" % (walk, n)), np.uint8)        # (blocks until the owner has posted it)
+                buf = np.frombuffer(_get_blocking(store, P + "%d" % n, "node %d" % n), np.uint8)        # (until the owner has posted it)
                 msa.import_result(buf)
                 moved += int(buf.shape[0])
         elif w > 1:
@@ -225,6 +260,6 @@ def align_sharded(msa, assign, device="cpu", on_round=None, exchange="queue", wa
         if on_round:
             on_round(len(rounds) - 1, ready, mine)
     if store is not None:
-        store.add("pagan/%d/done" % walk, 1)
-    msa.finish()
+        store.add(P + "done", 1)
+    msa.finish(lazy=lazy_rows)
     return rounds

@@ -162,6 +162,10 @@ def _lib():
         L.pagan_msa_import_result.restype = C.c_int
         L.pagan_msa_finish.argtypes = [vp]
         L.pagan_msa_finish.restype = C.c_int
+        L.pagan_msa_finish_lazy.argtypes = [vp]
+        L.pagan_msa_finish_lazy.restype = C.c_int
+        L.pagan_msa_parents_built.argtypes = [vp]
+        L.pagan_msa_parents_built.restype = C.c_int
         L.pagan_msa_data_type.argtypes = [vp]
         L.pagan_msa_data_type.restype = C.c_int
         L.pagan_msa_node_device.argtypes = [vp, C.c_int32]
@@ -197,7 +201,7 @@ def _lib():
 HOST_EXPORTED = ["pagan_assign_units", "pagan_msa_default_opts", "pagan_msa_create", "pagan_msa_align", "pagan_msa_n_internal",
                  "pagan_msa_node_info", "pagan_msa_node_job", "pagan_msa_node_result", "pagan_msa_timing_get",
                  "pagan_msa_alignment_length", "pagan_msa_alignment_row", "pagan_msa_write_fasta", "pagan_msa_write_fasta_nodes",
-                 "pagan_msa_node_graph",
+                 "pagan_msa_node_graph", "pagan_msa_finish_lazy", "pagan_msa_parents_built",
                  "pagan_msa_destroy", "pagan_hgraph_leaf", "pagan_hgraph_parent", "pagan_hgraph_parent_device", "pagan_parents_device_calls", "pagan_hgraph_view",
                  "pagan_hgraph_attrs", "pagan_hgraph_fwd", "pagan_hgraph_string", "pagan_hgraph_free",
                  "pagan_define_tunnel", "pagan_prefix_hits", "pagan_anchors_device_calls", "pagan_drop_bad_hits", "pagan_define_tunnel_overlapping",
@@ -652,12 +656,19 @@ class Msa:
         self._backend = BATCH_FN(fn) if fn is not None else C.cast(None, BATCH_FN)
         self._L.pagan_msa_set_batch_backend(self._h, self._backend, None)
 
-    def finish(self):
-        rc = self._L.pagan_msa_finish(self._h)
+    def finish(self, lazy=False):
+        """After the last round.  lazy: the parent graphs of imported nodes that nobody needed, and the rows, are built by
+        the first call that asks for them (alignment(), write_fasta(), node_graph()) instead of now."""
+        rc = (self._L.pagan_msa_finish_lazy if lazy else self._L.pagan_msa_finish)(self._h)
         if rc != 0:
             from . import PaganError
             raise PaganError(rc, "pagan_msa_finish")
         return self
+
+    @property
+    def parents_built(self):
+        """parent graphs this process has built so far (rank mode: the nodes it aligned and the imported ones it needed)"""
+        return self._L.pagan_msa_parents_built(self._h)
 
     def node_info(self, k):
         info = CNodeInfo()

@@ -150,7 +150,11 @@ def _rank(rank, world, port, out_dir, exchange, slow_rank):
     rounds = pdist.align_sharded(msa, h.assign_units, exchange=exchange, walk=7, quota=1 if slow_rank >= 0 else None,
                                  on_round=lambda k, ready, mine: stamps.append((time.time(), list(mine))))
     mine = [k for k in range(msa.n_internal) if msa.node_device(k) >= 0]
+    # parent graphs this rank has built when the walk is over -- the nodes it aligned and the imported ones below the nodes it
+    # claimed -- and after it has been asked for the rows (which need every node's graph)
+    built_walk = msa.parents_built
     np.save(os.path.join(out_dir, "rows%d.npy" % rank), np.array(msa.alignment()))
+    np.save(os.path.join(out_dir, "built%d.npy" % rank), np.array([built_walk, msa.parents_built]))
     np.save(os.path.join(out_dir, "scores%d.npy" % rank), np.array([msa.node_info(k).score for k in range(msa.n_internal)]))
     np.save(os.path.join(out_dir, "mine%d.npy" % rank), np.array(mine))
     np.save(os.path.join(out_dir, "rounds%d.npy" % rank), np.array(rounds))
@@ -200,3 +204,54 @@ def test_a_slow_rank_holds_up_only_the_parents_of_its_own_nodes(tmp_path, oracle
     levels = {n: 1 for n in (16, 17, 19, 20, 23, 24, 26, 27)}
     levels.update({18: 2, 21: 2, 25: 2, 28: 2, 22: 3, 29: 3, 30: 4})
     assert {levels[int(n)] for n in before[:, 1]} >= {1, 2, 3}, "rank 0 never left level 1 before rank 1 posted"
+
+
+def test_ranks_shard_the_parent_graphs(tmp_path, oracle, pg):
+    """Import stores the path only; a parent graph is built by the rank that aligned the node, or by a rank that claims a
+    node above it -- not by every rank for every node on the thread that drains the posting log (node.cpp:196-223, 273-345:
+    a thread builds the ancestor of the node it aligned).  With two ranks the walk leaves each of them with fewer parents
+    built than there are nodes; asking for the rows afterwards builds the rest (every node's graph is needed for them)."""
+    mp.spawn(_rank, args=(2, _free_port(), str(tmp_path), "queue", -1), nprocs=2, join=True)
+    want_rows, _ = _one_rank_walk(oracle)
+    n_nodes = 15
+    built = [np.load(tmp_path / ("built%d.npy" % r)) for r in range(2)]
+    mine = [np.load(tmp_path / ("mine%d.npy" % r)).shape[0] for r in range(2)]
+    for r in range(2):
+        assert built[r][0] >= mine[r]                      # its own nodes' parents, at least
+        assert built[r][1] == n_nodes                      # the rows needed all of them
+        assert np.array_equal(np.load(tmp_path / ("rows%d.npy" % r)), want_rows)
+    assert min(b[0] for b in built) < n_nodes, "every rank built every parent during the walk: %s" % [b.tolist() for b in built]
+    # the root's owner needs its two children, and theirs, ...: it ends with the whole tree; the other rank does not
+    assert sum(b[0] for b in built) < 2 * n_nodes
+
+
+def _rank_twice(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pagan2_msa_amd import dist as pdist, host as h, synth as sy
+    import oracle
+    oracle.build()
+    names, seqs, nwk = sy.evolve_balanced(8, 200, branch=0.02, sub=0.02, indel_start=0.006, mean_len=4, seed=21)
+    rows = []
+    for rep in range(2):                        # the SAME walk name twice in one store: the second call must not see the first one's keys
+        msa = h.Msa(names, seqs, nwk, use_anchors=0)
+        msa.set_batch_backend(oracle_backend(oracle, []))
+        pdist.align_sharded(msa, h.assign_units, exchange="queue", walk=7)
+        rows.append(msa.alignment())
+    np.save(os.path.join(out_dir, "twice%d.npy" % rank), np.array(rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_walk_name_reused_in_the_same_store(tmp_path, oracle, pg):
+    """advisor, round 4: count / done / claim keys of a walk stayed in the store, so a second call under the same explicit
+    name started from a stale count and lost every claim.  The key space now carries an epoch per name."""
+    mp.spawn(_rank_twice, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    names, seqs, nwk = synth.evolve_balanced(8, 200, branch=0.02, sub=0.02, indel_start=0.006, mean_len=4, seed=21)
+    want = np.array(walk(oracle, names, seqs, nwk, use_anchors=0).align().alignment())
+    for r in range(2):
+        got = np.load(tmp_path / ("twice%d.npy" % r))
+        assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
