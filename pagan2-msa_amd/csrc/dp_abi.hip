@@ -152,73 +152,133 @@ struct SiteFeat {
 // `inwave` (model table in LDS): the compute waves evaluate the multi-edge cells of a class 1 diagonal themselves, which
 // covers sites with one edge from the previous site and at most one more ("easy", SiteFeat::not_easy); a diagonal that
 // holds any other multi-edge site is class 2 (the assist waves stage its candidates, ring-resident operands included).
+// f(first, last) over [0, n) cut into `threads` ranges, one thread each (the caller's thread takes the first)
+template <class F> void par_ranges(int n, int threads, F f) {
+    threads = std::max(1, std::min(threads, n / 4096));          // (a range below a few thousand items is not worth a thread)
+    if (threads <= 1) { f(0, n); return; }
+    std::vector<std::thread> pool;
+    const int step = (n + threads - 1) / threads;
+    for (int t = 1; t < threads; ++t) pool.emplace_back([&, t] { f(std::min(n, t * step), std::min(n, (t + 1) * step)); });
+    f(0, std::min(n, step));
+    for (auto &th : pool) th.join();
+}
+
+// `threads`: the plan of ONE alignment over several host threads (round 5: at the top of a guide tree a level holds one or two
+// alignments, and their plans -- 7 ms each for 2 x 100 kb -- were serial host time between two kernels).  The site features of
+// the two graphs are built side by side; the passes over the diagonals (class, ring residency, reach, ring-row reuse) run over
+// ranges of diagonals: what couples the diagonals -- the running count of far cells, the last wide diagonal -- is two prefix
+// passes done first; the sliding windows restart at a range's first diagonal by binary search.
 void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, const RowBand &rb,
                         const DiagIndex &dx, bool inwave, std::vector<uint8_t> *out, std::vector<int> *lead_req,
-                        std::vector<uint8_t> *ring2 = nullptr) {
+                        std::vector<uint8_t> *ring2 = nullptr, int threads = 1) {
     const int nd = Lx + Ly - 1;
+    static const bool prof = std::getenv("PAGAN_DP_PLAN_PROFILE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!prof) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "pagan_dp:   classify: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
     SiteFeat fl, fr;
-    fl.build(L, Lx); fr.build(R, Ly);
-    std::vector<int> far(nd + 1, 0);
-    auto mark = [&](int d0, int d1) { if (d0 <= d1) { ++far[d0]; --far[d1 + 1]; } };
+    if (threads > 1) {
+        std::thread other([&] { fr.build(R, Ly); });
+        fl.build(L, Lx);
+        other.join();
+    } else { fl.build(L, Lx); fr.build(R, Ly); }
+    lap("site features");
+    std::vector<int> far(nd + 1, 0), far2;
     std::vector<int> multi_cols;                       // columns with span >= 2, ascending
     for (int j = 0; j < Ly; ++j) if (fr.span[j] >= 2) multi_cols.push_back(j);
-    for (int i = 0; i < Lx; ++i) {
-        if (rb.hi[i] < rb.lo[i]) continue;
-        const int sl = fl.span[i];
-        if (sl >= PG_PIPE_REACH - 1) { mark(i + rb.lo[i], i + rb.hi[i]); continue; }   // any column: span(j) >= 1
-        if (sl < 2) continue;                          // with span(i) <= 1 only span(j) >= REACH-1 matters: below
-        for (auto it = std::lower_bound(multi_cols.begin(), multi_cols.end(), rb.lo[i]);
-             it != multi_cols.end() && *it <= rb.hi[i]; ++it)
-            if (sl + fr.span[*it] >= PG_PIPE_REACH) mark(i + *it, i + *it);
-    }
-    for (int j = 0; j < Ly; ++j) {
-        if (fr.span[j] < PG_PIPE_REACH - 1) continue;
-        // rows whose band holds column j: hi[] and lo[] are monotone
-        const int i1 = (int)(std::lower_bound(rb.hi.begin(), rb.hi.end(), j) - rb.hi.begin());
-        const int i2 = (int)(std::upper_bound(rb.lo.begin(), rb.lo.end(), j) - rb.lo.begin()) - 1;
-        mark(i1 + j, i2 + j);
-    }
+    auto mark_rows = [&](std::vector<int> &fa) {
+        auto mark = [&](int d0, int d1) { if (d0 <= d1) { ++fa[d0]; --fa[d1 + 1]; } };
+        for (int i = 0; i < Lx; ++i) {
+            if (rb.hi[i] < rb.lo[i]) continue;
+            const int sl = fl.span[i];
+            if (sl >= PG_PIPE_REACH - 1) { mark(i + rb.lo[i], i + rb.hi[i]); continue; }   // any column: span(j) >= 1
+            if (sl < 2) continue;                          // with span(i) <= 1 only span(j) >= REACH-1 matters: below
+            for (auto it = std::lower_bound(multi_cols.begin(), multi_cols.end(), rb.lo[i]);
+                 it != multi_cols.end() && *it <= rb.hi[i]; ++it)
+                if (sl + fr.span[*it] >= PG_PIPE_REACH) mark(i + *it, i + *it);
+        }
+    };
+    auto mark_cols = [&](std::vector<int> &fa) {
+        auto mark = [&](int d0, int d1) { if (d0 <= d1) { ++fa[d0]; --fa[d1 + 1]; } };
+        for (int j = 0; j < Ly; ++j) {
+            if (fr.span[j] < PG_PIPE_REACH - 1) continue;
+            // rows whose band holds column j: hi[] and lo[] are monotone
+            const int i1 = (int)(std::lower_bound(rb.hi.begin(), rb.hi.end(), j) - rb.hi.begin());
+            const int i2 = (int)(std::upper_bound(rb.lo.begin(), rb.lo.end(), j) - rb.lo.begin()) - 1;
+            mark(i1 + j, i2 + j);
+        }
+    };
+    if (threads > 1) {
+        far2.assign(nd + 1, 0);
+        std::thread other([&] { mark_cols(far2); });
+        mark_rows(far);
+        other.join();
+        for (int d = 0; d <= nd; ++d) far[d] += far2[d];
+    } else { mark_rows(far); mark_cols(far); }
+    lap("far marks");
     out->assign(nd, 0);
     if (ring2) ring2->assign(nd, 0);
-    int run = 0, last_wide = -1000;
-    for (int d = 0; d < nd; ++d) {
-        run += far[d];
-        const int lo = dx.imin[d], hi = dx.imax[d];
-        uint8_t c;
-        if (hi - lo + 1 > PG_PIPE_WIDTH) { c = hi - lo + 1 > PG_PIPE_WINDOW ? 5 : 4; last_wide = d; }
-        else if (d - last_wide < PG_PIPE_REACH) c = 3;
-        else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c = 3;
-        else if (run > 0) c = 2;
-        else if ((lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH) &&
-                 (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)) c = 2;
-        else if (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)
-            c = (inwave && (fl.not_easy[hi + 1] - fl.not_easy[lo] > 0 || fr.not_easy[d - lo + 1] - fr.not_easy[d - hi] > 0)) ? 2 : 1;
-        else c = 0;
-        // a class 2 diagonal whose operands all lie in the ring (it is class 2 for the shape of a site only): the assist waves
-        // take their ring-only code for it
-        if (ring2) (*ring2)[d] = c == 2 && run == 0 && !(lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH);
-        (*out)[d] = c;
+    // what couples the diagonals: far cells in flight (a running sum) and the last wide diagonal at or before d
+    std::vector<int> run_at(nd), last_wide_at(nd);
+    {
+        int run = 0, last_wide = -1000;
+        for (int d = 0; d < nd; ++d) {
+            run += far[d];
+            if (dx.imax[d] - dx.imin[d] + 1 > PG_PIPE_WIDTH) last_wide = d;
+            run_at[d] = run; last_wide_at[d] = last_wide;
+        }
     }
     // How far back in the LDS ring the cells of a diagonal read: 2 for simple cells, span(i) + span(j) for a
     // multi-edge cell (bounded here by the largest spans among the diagonal's rows and columns: sliding-window
     // maxima, both windows only move forward), the full reach for the other classes.  From that, the diagonal
     // the downstream wave must have completed before a wave may overwrite ring row D % PG_PIPE_RING with
     // diagonal D: the last diagonal that still reads D - PG_PIPE_RING.
+    //
+    // What matters for the reuse of a ring row is how far back the cells of a diagonal read IN ANOTHER
+    // WAVE'S ROWS (a wave's reads of its own rows are ordered with its own writes).  A cell (i,j) reads rows
+    // down to i - dL, so it crosses into the block of 64 rows above only if span_ring(i) > i % 64 -- lane 0
+    // always does (row i-1: its shift operand at age 1 and the M operands at ages 1 + dR).  Such a cell
+    // reaches at most span_ring(i) + span_ring(j) diagonals back in the ring (classes 1 and 2; older operands
+    // come from L2).  Candidates per diagonal: the rows with a ring-reaching skip edge (sliding window over
+    // their sorted list) and the at most four rows with i % 64 == 0.
+    lap("prefix passes");
+    std::vector<int> rowsL;
+    for (int i = 0; i < Lx; ++i) if (fl.span_ring[i] >= 2) rowsL.push_back(i);
     std::vector<int> need(nd, PG_PIPE_REACH - 1);
-    {
-        // What matters for the reuse of a ring row is how far back the cells of a diagonal read IN ANOTHER
-        // WAVE'S ROWS (a wave's reads of its own rows are ordered with its own writes).  A cell (i,j) reads rows
-        // down to i - dL, so it crosses into the block of 64 rows above only if span_ring(i) > i % 64 -- lane 0
-        // always does (row i-1: its shift operand at age 1 and the M operands at ages 1 + dR).  Such a cell
-        // reaches at most span_ring(i) + span_ring(j) diagonals back in the ring (classes 1 and 2; older operands
-        // come from L2).  Candidates per diagonal: the rows with a ring-reaching skip edge (sliding window over
-        // their sorted list) and the at most four rows with i % 64 == 0.
-        std::vector<int> rowsL;
-        for (int i = 0; i < Lx; ++i) if (fl.span_ring[i] >= 2) rowsL.push_back(i);
+    par_ranges(nd, threads, [&](int d_first, int d_last) {
+        for (int d = d_first; d < d_last; ++d) {
+            const int run = run_at[d];
+            const int lo = dx.imin[d], hi = dx.imax[d];
+            uint8_t c;
+            if (hi - lo + 1 > PG_PIPE_WIDTH) c = hi - lo + 1 > PG_PIPE_WINDOW ? 5 : 4;
+            else if (d - last_wide_at[d] < PG_PIPE_REACH) c = 3;
+            else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c = 3;
+            else if (run > 0) c = 2;
+            else if ((lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH) &&
+                     (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)) c = 2;
+            else if (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)
+                c = (inwave && (fl.not_easy[hi + 1] - fl.not_easy[lo] > 0 || fr.not_easy[d - lo + 1] - fr.not_easy[d - hi] > 0)) ? 2 : 1;
+            else c = 0;
+            // a class 2 diagonal whose operands all lie in the ring (it is class 2 for the shape of a site only): the assist waves
+            // take their ring-only code for it
+            if (ring2) (*ring2)[d] = c == 2 && run == 0 && !(lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH);
+            (*out)[d] = c;
+        }
+        // (the windows over the rows with a ring-reaching skip edge only move forward: they restart at the range's first diagonal)
         size_t la = 0, lb = 0;
-        for (int d = 0; d < nd; ++d) {
+        bool started = false;
+        for (int d = d_first; d < d_last; ++d) {
             const int lo = dx.imin[d], hi = dx.imax[d];
             if (hi < lo || (*out)[d] > 2) continue;
+            if (!started) {
+                la = (size_t)(std::lower_bound(rowsL.begin(), rowsL.end(), lo) - rowsL.begin());
+                lb = la;
+                started = true;
+            }
             while (lb < rowsL.size() && rowsL[lb] <= hi) ++lb;
             while (la < lb && rowsL[la] < lo) ++la;
             int m = 2;
@@ -229,25 +289,30 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
             for (int i = (lo + 63) & ~63; i <= hi; i += 64) m = std::max(m, fl.span_ring[i] + fr.span_ring[d - i]);
             need[d] = std::min(m, PG_PIPE_REACH - 1);
         }
-    }
+    });
+    lap("classes and reach");
     lead_req->assign(nd, -1);
-    for (int D = PG_PIPE_RING; D < nd; ++D) {
-        int req = -1;
-        for (int t = D - PG_PIPE_RING + 1; t <= D - PG_PIPE_RING + PG_PIPE_REACH - 1 && t < nd; ++t)
-            if (t - need[t] <= D - PG_PIPE_RING) req = t;
-        (*lead_req)[D] = req;
-    }
+    par_ranges(nd, threads, [&](int d_first, int d_last) {
+        for (int D = std::max(d_first, (int)PG_PIPE_RING); D < d_last; ++D) {
+            int req = -1;
+            for (int t = D - PG_PIPE_RING + 1; t <= D - PG_PIPE_RING + PG_PIPE_REACH - 1 && t < nd; ++t)
+                if (t - need[t] <= D - PG_PIPE_RING) req = t;
+            (*lead_req)[D] = req;
+        }
+    });
+    lap("ring-row reuse");
 }
 
 // Awake intervals of dp_pipe.hip's compute waves.  Wave w owns the rows r with (r % 256) / 64 == w; it
 // has to run from PG_PIPE_WAKE diagonals before one of its rows enters the band (operand prefetch
 // pipeline) until PG_PIPE_RING diagonals after the last one left (so that all its ring columns hold
 // -inf again); every wave runs on wide diagonals.  Layout: dp_device.h, PgDevJob::sched.
-void schedule_waves(const DiagIndex &dx, const std::vector<uint8_t> &cls, std::vector<int> *out) {
+// (`threads` > 1: the four waves' lists side by side.)
+void schedule_waves(const DiagIndex &dx, const std::vector<uint8_t> &cls, std::vector<int> *out, int threads = 1) {
     const int nd = (int)cls.size();
     std::vector<int> lists[4];
-    std::vector<int> next_active(nd + 1);
-    for (int w = 0; w < 4; ++w) {
+    auto one_wave = [&](int w) {
+        std::vector<int> next_active(nd + 1);
         auto active = [&](int d) {
             if (cls[d] >= 4) return true;
             const int lo = dx.imin[d], hi = dx.imax[d];
@@ -266,6 +331,13 @@ void schedule_waves(const DiagIndex &dx, const std::vector<uint8_t> &cls, std::v
         }
         if (awake) lists[w].push_back(nd);
         lists[w].push_back(nd); lists[w].push_back(nd);
+    };
+    if (threads > 1 && nd >= 16384) {
+        std::thread t1([&] { one_wave(1); }), t2([&] { one_wave(2); }), t3([&] { one_wave(3); });
+        one_wave(0);
+        t1.join(); t2.join(); t3.join();
+    } else {
+        for (int w = 0; w < 4; ++w) one_wave(w);
     }
     out->assign(4, 0);
     for (int w = 0; w < 4; ++w) {
@@ -756,9 +828,19 @@ struct pagan_batch {
 
 namespace {
 
-int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
+int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe, int threads = 1) {
     if (!jb.left || !jb.right || !jb.model) return PAGAN_E_ARG;
     int rc;
+    // (PAGAN_DP_PLAN_PROFILE: milliseconds per phase of the plan of one job, on stderr)
+    static const bool prof = std::getenv("PAGAN_DP_PLAN_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_last = now();
+    auto lap = [&](const char *what) {
+        if (!prof) return;
+        const auto t = now();
+        std::fprintf(stderr, "pagan_dp: plan %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
     if ((rc = check_graph(jb.left)) != PAGAN_OK) return rc;
     if ((rc = check_graph(jb.right)) != PAGAN_OK) return rc;
     const pagan_model *m = jb.model;
@@ -769,9 +851,12 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
         if (jb.left->state[s] < 0 || jb.left->state[s] >= m->n_states) return PAGAN_E_MODEL;
     for (int s = 1; s < hj->Ly; ++s)
         if (jb.right->state[s] < 0 || jb.right->state[s] >= m->n_states) return PAGAN_E_MODEL;
+    lap("checks");
     if ((rc = rb->build(hj->Lx, hj->Ly, jb.band)) != PAGAN_OK) return rc;
+    lap("row band");
     hj->dx.build(hj->Lx, hj->Ly, *rb);
     if (hj->dx.cells != rb->cells()) return PAGAN_E_INTERNAL;
+    lap("diagonal index");
     // The LDS-staged kernel suits banded work: most diagonals narrow.  A full matrix (or a band that is
     // mostly wider than the ring) goes to the multi-wave HBM wavefront instead.
     // traceback boundaries k = 1..K at diagonals k*PG_SEG (<= nd-1): 3 table entries per cell of
@@ -813,9 +898,12 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe) {
         hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES) &&
                       edges_fit_ring(jb.right, hj->Ly, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES);
         if (hj->ring_ok) {
+            lap("boundaries, edge windows");
             classify_diagonals(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, jb.model->n_states * jb.model->n_states <= 256,
-                               &hj->cls, &hj->lead_req, &hj->ring2);
-            schedule_waves(hj->dx, hj->cls, &hj->sched);
+                               &hj->cls, &hj->lead_req, &hj->ring2, threads);
+            lap("classify_diagonals");
+            schedule_waves(hj->dx, hj->cls, &hj->sched, threads);
+            lap("schedule_waves");
         }
     } else {
         hj->ring_ok = narrow && edges_fit_ring(jb.left, hj->Lx) && edges_fit_ring(jb.right, hj->Ly);
@@ -1340,14 +1428,29 @@ int pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, const
     if ((rc = check_graph(right)) != PAGAN_OK) return rc;
     const int Lx = left->n_sites - 1, Ly = right->n_sites - 1;
     if (n_cls != Lx + Ly - 1) return PAGAN_E_ARG;
+    static const bool prof = std::getenv("PAGAN_DP_PLAN_PROFILE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!prof) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "pagan_dp: plan %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
+    lap("checks");
     RowBand rb;
     if ((rc = rb.build(Lx, Ly, band)) != PAGAN_OK) return rc;
+    lap("row band");
     DiagIndex dx;
     dx.build(Lx, Ly, rb);
+    lap("diagonal index");
     std::vector<uint8_t> cls;
     std::vector<int> sched, lead_req;
-    classify_diagonals(left, right, Lx, Ly, rb, dx, true, &cls, &lead_req);      // the plan of a job whose model table fits LDS
-    schedule_waves(dx, cls, &sched);
+    int threads = 1;                                            // PAGAN_DP_PLAN_THREADS: the plan over several threads (tests compare with one)
+    if (const char *e = std::getenv("PAGAN_DP_PLAN_THREADS")) threads = std::max(1, std::atoi(e));
+    classify_diagonals(left, right, Lx, Ly, rb, dx, true, &cls, &lead_req, nullptr, threads);      // the plan of a job whose model table fits LDS
+    lap("classify_diagonals");
+    schedule_waves(dx, cls, &sched, threads);
+    lap("schedule_waves");
     std::memcpy(cls_out, cls.data(), cls.size());
     if (lead_req_out) std::memcpy(lead_req_out, lead_req.data(), sizeof(int) * lead_req.size());
     *sched_len = (int32_t)sched.size();
@@ -1498,10 +1601,15 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         const bool allow = !(ce && std::strcmp(ce, "0") == 0);
         parallel_jobs(n, [&](int k) { compact_job(jobs[k], allow, &b->compact[k], &eff[k]); });
     }
-    parallel_jobs(n, [&](int k) {
-        RowBand rb;
-        job_rc[k] = validate_job(eff[k], &b->jobs[k], &rb, b->use_pipe);
-    });
+    {
+        // a level of few alignments: the threads the jobs leave idle go into each job's own plan
+        const int hw = (int)std::thread::hardware_concurrency();
+        const int inner = std::max(1, std::min(8, (hw > 0 ? std::min(hw, 16) : 1) / std::max(n, 1)));
+        parallel_jobs(n, [&](int k) {
+            RowBand rb;
+            job_rc[k] = validate_job(eff[k], &b->jobs[k], &rb, b->use_pipe, inner);
+        });
+    }
     for (int k = 0; k < n; ++k) {
         const int rc = job_rc[k];
         if (rc != PAGAN_OK) return rc;

@@ -193,3 +193,31 @@ def test_a_tile_with_too_many_edges_is_not_tiled():
     right = synth.random_graph(200, 15, 4, p_extra=0.0)
     side, tiles = pg.debug_tiles(left, right)
     assert tiles == []
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_plan_over_several_threads_is_the_plan(monkeypatch, seed):
+    """round 5: the plan of one alignment runs over ranges of diagonals on several host threads (dp_abi.hip, par_ranges; the
+    sliding windows restart at a range's first diagonal).  Classes, wave schedules and ring-row reuse are those of one thread.
+    Long jobs only: a range has at least 4096 diagonals."""
+    rng = np.random.default_rng(700 + seed)
+    n = int(rng.integers(9000, 14000))
+    left = synth.random_graph(n, 15, 7000 + seed, p_extra=0.06, max_deg=4, max_span=int(rng.choice([6, 20, 40])), p_dead=0.002)
+    right = synth.random_graph(n + int(rng.integers(-300, 300)), 15, 7100 + seed, p_extra=0.06, max_deg=4, max_span=int(rng.choice([6, 20, 40])))
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    half = rng.integers(5, 90, Lx)
+    centre = np.arange(Lx) * (Ly - 1) // max(Lx - 1, 1)
+    upper = np.maximum.accumulate(np.maximum(centre - half, 0)); lower = np.maximum.accumulate(np.minimum(centre + half, Ly - 1))
+    for _ in range(3):                                             # boxes wider than the lanes / the record windows
+        a = int(rng.integers(10, Lx - 500)); b = a + int(rng.integers(40, 420))
+        upper[a:b] = upper[a]; lower[a:b] = min(lower[b - 1] + int(rng.integers(100, 450)), Ly - 1)
+    upper = np.maximum.accumulate(upper); lower = np.maximum.accumulate(lower); upper[0] = 0; lower[-1] = Ly - 1
+    band = abi.Band(upper, lower)
+    monkeypatch.setenv("PAGAN_DP_PLAN_THREADS", "1")
+    one = pg.debug_plan(left, right, band, with_lead=True)
+    for t in ("3", "8"):
+        monkeypatch.setenv("PAGAN_DP_PLAN_THREADS", t)
+        many = pg.debug_plan(left, right, band, with_lead=True)
+        assert np.array_equal(one[0], many[0])                     # classes
+        assert len(one[1]) == len(many[1]) and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(one[1], many[1]))   # wave schedules
+        assert np.array_equal(one[2], many[2])                     # ring-row reuse
