@@ -170,10 +170,8 @@ def c1_issue(E, k, tag):
     a("v_lshrrev_b32_e32 v%d, 16, v%d" % (KR, CR + 1))
     a("s_and_b64 s[74:75], s[74:75], s[60:61]")
     a("s_and_b64 s[76:77], s[76:77], s[60:61]")
-    a("v_cvt_f64_f32_e32 %s, v%d" % (pr(LWA), RL + 2))            # weights: previous-site edge / other edge
-    a("v_cvt_f64_f32_e32 %s, v%d" % (pr(LWS), RL + 3))
+    a("v_cvt_f64_f32_e32 %s, v%d" % (pr(LWA), RL + 2))            # weights of the previous-site edges (the other edges': in their blocks)
     a("v_cvt_f64_f32_e32 %s, v%d" % (pr(RWA), CR + 2))
-    a("v_cvt_f64_f32_e32 %s, v%d" % (pr(RWS), CR + 3))
     a("s_and_b64 s[82:83], s[74:75], s[76:77]")
     # ---- every operand cell of the blocks below requested in ONE batch (each block only if a lane of the wave needs it):
     #   right site's other edge: (row, j-kR) -> U, (row-1, j-kR) -> V; left site's: (row-kL, j) -> W1, (row-kL, j-1) -> W2;
@@ -182,6 +180,7 @@ def c1_issue(E, k, tag):
     a("s_cbranch_scc1 .Lpg_rdL%s" % sfx)
     a("s_and_saveexec_b64 s[62:63], s[76:77]")
     a("v_mul_u32_u24_e32 v217, 0x1800, v%d" % KR)
+    a("v_cvt_f64_f32_e32 %s, v%d" % (pr(RWS), CR + 3))
     E.ring_row(218, 217)
     E.ring_row_before(219, 218)
     a("v_add_u32_e32 v218, v218, %[tid24]")
@@ -195,6 +194,7 @@ def c1_issue(E, k, tag):
     a("s_and_saveexec_b64 s[62:63], s[74:75]")
     a("v_sub_u32_e32 v%d, %%[tid], v%d" % (POSL, KL))
     a("v_mul_u32_u24_e32 v217, 0x1800, v%d" % KL)
+    a("v_cvt_f64_f32_e32 %s, v%d" % (pr(LWS), RL + 3))
     a("v_and_b32_e32 v%d, 0xff, v%d" % (POSL, POSL))
     E.ring_row(218, 217)
     a("v_mad_u32_u24 v%d, v%d, 24, %%[ringb]" % (POSL, POSL))
@@ -490,7 +490,7 @@ def step(E, k):
         a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
     a(".Lpg_shift%s:" % sfx)
 
-    def shift_and_x():
+    def shift_and_x(have_active=False):
         # shift: lane n takes lane n-1's cell, lane 0 keeps what it read from the ring
         for c in range(3):
             if "p" in EXP:   # timing experiment: plain moves instead of the DPP shift
@@ -506,7 +506,8 @@ def step(E, k):
             a("s_sub_i32 s72, %[d], %[lym1]")
             a("v_cmp_eq_u32_e32 vcc, %[d], %[row]")
             a("v_cmp_eq_u32_e64 s[84:85], s72, %[row]")
-            a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)      # active: row <= hi
+            if not have_active:
+                a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)      # active: row <= hi
             a("v_max_f64 v[196:197], %s, v[196:197]" % pr(A[1]))  # max(AY, AM + ng)
             a("s_or_b64 vcc, vcc, s[84:85]")
             a("v_add_f64 v[196:197], v[196:197], %[go]")
@@ -516,7 +517,8 @@ def step(E, k):
             a("v_add_f64 v[200:201], %s, %s" % (pr(A[0]), pr(GEX)))    # AX + the lane's rate
         else:
             a("v_add_f64 v[200:201], %s, %%[ge]" % pr(A[0]))          # AX + ge
-            a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)          # active: row <= hi
+            if not have_active:
+                a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)          # active: row <= hi
             a("v_max_f64 v[196:197], %s, v[196:197]" % pr(A[1]))      # max(AY, AM + ng)
             a("v_add_f64 v[196:197], v[196:197], %[go]")
             a("v_cndmask_b32_e64 v%d, %%[nihi], %%[pihi], s[60:61]" % (LIM + 1))
@@ -528,8 +530,20 @@ def step(E, k):
     # operand cell and the records after next requested at once; the shift and the X candidates while those are in flight; one
     # wait.  Otherwise: the records now, shift and X candidates while they come, then the same parts behind their waits.
     a(".Lpg_recs%s:" % sfx)
-    a("s_cmp_eq_u32 s67, %[d]")
-    a("s_cbranch_scc1 .Lpg_have%s" % sfx)
+    a("s_cmp_lg_u32 s67, %[d]")
+    a("s_cbranch_scc1 .Lpg_read%s" % sfx)                      # (the step before did not read them ahead: the first step of a run)
+    a("s_cmp_eq_u32 s73, 2")
+    a("s_cbranch_scc1 .Lpg_slow%s" % sfx)                      # (class 2: the usual way, minus the read)
+    if "y" in EXP:           # timing experiment / debugging: never the short way
+        a("s_branch .Lpg_slow%s" % sfx)
+    # the steady class 1 step falls through to here
+    a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)          # active: row <= hi
+    c1_issue(E, k, "f")                                        # (a wave without a multi-edge cell finds its masks empty: the decode and the records after next is all it does)
+    shift_and_x(have_active=True)
+    c1_math(E, k, "f")
+    a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
+    a("s_branch .Lpg_commit%s" % sfx)
+    a(".Lpg_read%s:" % sfx)
     a("v_and_b32_e32 v218, 0x1ff, %[row]")
     a("v_sub_u32_e32 v219, %[d], %[row]")
     a("v_lshl_add_u32 v218, v218, 4, %[bL]")
@@ -540,17 +554,6 @@ def step(E, k):
     a(".Lpg_slow%s:" % sfx)
     shift_and_x()                                              # (a copy: the class 0 path runs into its own without a second test of the class)
     a("s_branch .Lpg_c1%s" % sfx)
-    a(".Lpg_have%s:" % sfx)
-    a("s_cmp_eq_u32 s73, 2")
-    a("s_cbranch_scc1 .Lpg_slow%s" % sfx)                      # (class 2: the usual way, minus the read)
-    if "y" in EXP:           # timing experiment / debugging: never the short way
-        a("s_branch .Lpg_slow%s" % sfx)
-    a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)          # active: row <= hi (the X part works it out again)
-    c1_issue(E, k, "f")                                        # (a wave without a multi-edge cell finds its masks empty: the decode and the records after next is all it does)
-    shift_and_x()
-    c1_math(E, k, "f")
-    a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
-    a("s_branch .Lpg_commit%s" % sfx)
     E.cur = E.L
     shift_and_x()
     a(".Lpg_commit%s:" % sfx)
