@@ -53,6 +53,8 @@ unsigned pg_pipe_lds_bytes();        // (static LDS: reported, not passed at lau
 unsigned pg_pipe_block();
 unsigned pg_tiles_lds_bytes();
 
+extern "C" void pagan_fb_internal_release_cache();             // dp_fb.hip: the forward/backward arenas kept for the next pair
+
 namespace {
 
 #define HIP_TRY(expr)                                                                            \
@@ -1762,7 +1764,9 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         if (hipMalloc((void **)&b->arena.dev, b->arena.size) != hipSuccess) {
             (void)hipGetLastError();
             b->arena.dev = nullptr;
-            arena_pool.clear(b->device);                 // the idle arenas may be what is in the way
+            arena_pool.clear(b->device);                 // the idle arenas may be what is in the way -- and the other pools' (parent
+            pagan::parent_release_cache();               // builder slabs, forward/backward arenas: round 4 advisor)
+            pagan_fb_internal_release_cache();
             HIP_TRY(hipMalloc((void **)&b->arena.dev, b->arena.size));
         }
     }
@@ -2224,7 +2228,6 @@ int pagan_dp_align(const pagan_graph *left, const pagan_graph *right, const paga
     return pagan_dp_align_batch(1, &jb, opts, out);
 }
 
-void pagan_fb_internal_release_cache();                        // dp_fb.hip
 void pagan_dp_release_cache(void) {
     pagan::anchors_release_cache();
     pagan::parent_release_cache();

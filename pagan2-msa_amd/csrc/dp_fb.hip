@@ -697,15 +697,25 @@ struct FbArenaPool {
         }
         return p;
     }
+    // idle arenas are bounded by count AND by bytes (a 10 k x 10 k pair's two matrices are 4.8 GB: eight of those idle would
+    // sit on 38 GB that the Viterbi batches of the same process may need); the calling thread stays on its device
+    static constexpr size_t kMaxIdleBytes = (size_t)8 << 30;
+    void drop_front() {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(idle.front().device); (void)hipFree(idle.front().p); idle.erase(idle.begin());
+        if (cur >= 0) (void)hipSetDevice(cur);
+    }
     void give(int device, char *p, size_t cap) {
         std::lock_guard<std::mutex> g(m);
-        if (idle.size() >= 8) { (void)hipSetDevice(idle.front().device); (void)hipFree(idle.front().p); idle.erase(idle.begin()); }
         idle.push_back({device, p, cap});
+        size_t total = 0;
+        for (auto &s_ : idle) total += s_.cap;
+        while (idle.size() > 8 || (total > kMaxIdleBytes && idle.size() > 1)) { total -= idle.front().cap; drop_front(); }
     }
     void clear() {
         std::lock_guard<std::mutex> g(m);
-        for (auto &s_ : idle) { (void)hipSetDevice(s_.device); (void)hipFree(s_.p); }
-        idle.clear();
+        while (!idle.empty()) drop_front();
     }
 };
 FbArenaPool fb_arena_pool;

@@ -26,7 +26,8 @@
 //   pp_final_*    deleted sites become non_real; every list loses the edges that touch one (:491-508), order kept.
 // float arithmetic as on the host (same operations on the same values; -ffp-contract=off); an edge's log weight is looked up
 // in a table the host makes with ITS logf for the weights the rules can produce (1, 0.9, 0.25 times powers of the skip
-// probability) -- a device logf is not glibc's; the host checks every weight != 1 after the download anyway.
+// probability) -- a device logf is not glibc's; a weight outside the table is counted by the kernels, and the host then re-derives
+// the logarithm of every weight != 1 after the download (only then: with the table complete the device's words are the host's).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -409,15 +410,20 @@ struct MemPool {
         if (!p) return;
         std::lock_guard<std::mutex> g(m);
         if (idle.size() >= 48) {                                               // (bounded: the oldest goes)
+            int cur = -1;
+            (void)hipGetDevice(&cur);                                          // (the calling thread stays on the device it was on)
             (void)hipSetDevice(idle.front().device); (void)hipFree(idle.front().p); idle.erase(idle.begin());
-            (void)hipSetDevice(device);
+            if (cur >= 0) (void)hipSetDevice(cur);
         }
         idle.push_back({device, p, cap});
     }
     void clear() {
         std::lock_guard<std::mutex> g(m);
+        int cur = -1;
+        (void)hipGetDevice(&cur);
         for (auto &s : idle) { (void)hipSetDevice(s.device); (void)hipFree(s.p); }
         idle.clear();
+        if (cur >= 0) (void)hipSetDevice(cur);
     }
 };
 MemPool pp_pool;
@@ -454,6 +460,22 @@ struct DevGraph {
 };
 
 void parent_release_cache() { pp_pool.clear(); }
+
+// The states of a graph changed on the host after it was built (--mostcommon: Node::fix_ambiguous_states, node.cpp:1610-1690,
+// rewrites the states of a node and of the ambiguous sites below it): its copy on the device -- which the build one level up
+// reads the children's states from -- takes them over.  false: the copy could not be updated (the caller drops it).
+bool parent_update_states(SeqGraph &g) {
+    DevGraph *d = static_cast<DevGraph *>(g.dev.get());
+    if (!d) return true;
+    if (d->n_sites != g.n_sites()) return false;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    bool ok = hipSetDevice(d->device) == hipSuccess &&
+              hipMemcpy(d->state, g.state.data(), sizeof(int32_t) * (size_t)d->n_sites, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    if (cur >= 0) (void)hipSetDevice(cur);
+    return ok;
+}
 
 namespace {
 
@@ -564,6 +586,10 @@ bool make_parent_device(SeqGraph &left, SeqGraph &right, const pagan_result &res
     if (!smem) return false;
     struct Scratch { int d; char *p; size_t c; ~Scratch() { pp_pool.give(d, p, c); } } scratch{device, smem, scap};
     lay(smem);
+    // Whatever way this function is left (a failed launch or copy returns early), nothing goes back to the pools -- the scratch
+    // slab, the parent's slab, the stream -- while kernels or copies queued on the stream may still touch it: this object is the
+    // last one declared, so it is destroyed first.  (round 4 advisor: the early returns handed memory in flight to the next build)
+    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); (void)hipGetLastError(); } } drain{st};
 
     A.L = child_view(*dl); A.R = child_view(*dr);
     A.cols = d_cols; A.n = n; A.lbl = lbl; A.rbl = rbl; A.pars = d_pars; A.S = S; A.char_as = char_as;

@@ -87,6 +87,7 @@ bool make_parent_device(SeqGraph &left, SeqGraph &right, const pagan_result &res
                         const int32_t *parsimony, int n_states, int char_as, const BuildSettings &bs, int device, SeqGraph *out,
                         ParentBuildInfo *info = nullptr);
 void parent_release_cache();
+bool parent_update_states(SeqGraph &g);      // g's states changed on the host (--mostcommon): its device copy takes them over
 
 // Sequence::get_sequence_string (src/main/sequence.cpp:704-740)
 std::string sequence_string(const SeqGraph &g, bool with_gaps, const std::string &full_alphabet);

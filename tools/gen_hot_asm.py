@@ -483,11 +483,14 @@ def step(E, k):
     # the descriptor after the multi-edge part (its waits would wait for the descriptor as well)
     a("s_cmp_lg_u32 s73, 0")
     a("s_cbranch_scc1 .Lpg_recs%s" % sfx)
-    if "X" in EXP:       # timing experiment: no scalar load, the descriptor is copied (wrong rows, same schedule)
-        for q in range(0, 8, 2):
-            a("s_mov_b64 s[%d:%d], s[%d:%d]" % (nxt + q, nxt + q + 1, cur + q, cur + q + 1))
-    else:
-        a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
+    def next_desc():
+        if "X" in EXP:       # timing experiment: no scalar load, the descriptor is copied (wrong rows, same schedule)
+            for q in range(0, 8, 2):
+                a("s_mov_b64 s[%d:%d], s[%d:%d]" % (nxt + q, nxt + q + 1, cur + q, cur + q + 1))
+        else:
+            a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
+
+    next_desc()
     a(".Lpg_shift%s:" % sfx)
 
     def shift_and_x(have_active=False):
@@ -538,10 +541,13 @@ def step(E, k):
         a("s_branch .Lpg_slow%s" % sfx)
     # the steady class 1 step falls through to here
     a("v_cmp_ge_i32_e64 s[60:61], s%d, %%[row]" % hi)          # active: row <= hi
+    if "E" in EXP:           # (A/B: the next descriptor requested first -- the step's one wait then covers it)
+        next_desc()
     c1_issue(E, k, "f")                                        # (a wave without a multi-edge cell finds its masks empty: the decode and the records after next is all it does)
     shift_and_x(have_active=True)
     c1_math(E, k, "f")
-    a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
+    if "E" not in EXP:
+        next_desc()
     a("s_branch .Lpg_commit%s" % sfx)
     a(".Lpg_read%s:" % sfx)
     a("v_and_b32_e32 v218, 0x1ff, %[row]")
@@ -571,11 +577,11 @@ def step(E, k):
     c1_issue(E, k, "s")
     c1_math(E, k, "s")
     a(".Lpg_c1done%s:" % sfx)
-    a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
+    next_desc()
     a("s_branch .Lpg_commit%s" % sfx)
     a(".Lpg_c2%s:" % sfx)
     class2(E, k)
-    a("s_load_dwordx8 s[%d:%d], s[70:71], %s" % (nxt, nxt + 7, "0x20" if k == 0 else "0x40"))
+    next_desc()
     a("s_branch .Lpg_commit%s" % sfx)
     E.cur = E.L
     # results: -inf outside the band
