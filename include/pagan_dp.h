@@ -186,6 +186,12 @@ int  pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, cons
                          uint8_t *cls, int32_t n_cls, int32_t *sched, int32_t sched_cap, int32_t *sched_len,
                          int32_t *lead_req /* [n_cls] or NULL: diagonal the downstream wave must have completed
                                               before diagonal d may overwrite its row of the LDS ring, -1 none */);
+/* diagnostic, host only: the far histories of a banded job (dp_abi.hip, plan_far_hist) with the classes that go with them --
+ * hfL[Lx], hfR[Ly]: flag byte of every left / right site (bit 7 reads a history line, bits 0-1 which; bit 6 writes one, bits
+ * 4-5 which); hbit[Lx+Ly-1]: 1 where a reader or writer has a cell; cls as pagan_dp_debug_plan's (which plans WITHOUT
+ * histories: its classes are those of PAGAN_DP_HIST=0).  Returns the number of far sites served (>= 0) or an error (< 0).  */
+int  pagan_dp_debug_far(const pagan_graph *left, const pagan_graph *right, const pagan_band *band,
+                        uint8_t *hfL, uint8_t *hfR, uint8_t *hbit, uint8_t *cls);
 /* diagnostic, host only: the row strips a wide job would be filled as (dp_pipe.hip, strip_feeder), whether
  * or not the library would route it that way (max_sites <= 0: no bound on the multi-edge sites of a diagonal).  Returns the
  * number of strips (0: the bound refused the job), < 0 on error.  strips[6 * k] = first row, last row, first diagonal, last

@@ -235,6 +235,21 @@ def debug_strips(left, right, band=None, max_sites=0):
     return [tuple(int(v) for v in strips[6 * k: 6 * k + 6]) + (desc[off[k]: off[k + 1]].copy(),) for k in range(n)]
 
 
+def debug_far(left, right, band=None):
+    """Diagnostic (host only): the far histories of a banded job -- (n_served, hfL[Lx], hfR[Ly], hbit[nd], classes[nd])."""
+    import numpy as np
+    L = lib()
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    nd = Lx + Ly - 1
+    hfl, hfr, hb, cls = np.zeros(Lx, np.uint8), np.zeros(Ly, np.uint8), np.zeros(nd, np.uint8), np.zeros(nd, np.uint8)
+    u8 = C.POINTER(C.c_uint8)
+    n = L.pagan_dp_debug_far(C.byref(left.c), C.byref(right.c), C.byref(band.c) if band is not None else None,
+                             hfl.ctypes.data_as(u8), hfr.ctypes.data_as(u8), hb.ctypes.data_as(u8), cls.ctypes.data_as(u8))
+    if n < 0:
+        raise PaganError(n, "pagan_dp_debug_far")
+    return n, hfl, hfr, hb, cls
+
+
 def debug_plan(left, right, band=None, with_lead=False):
     """Diagnostic (host only): (classes[Lx+Ly-1] uint8, [awake intervals of wave 0..3]) the banded fill kernel
     would be given for this job; with_lead adds the per-diagonal downstream-progress requirement."""

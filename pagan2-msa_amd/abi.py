@@ -197,6 +197,8 @@ def declare(lib):
     lib.pagan_batch_debug_trace.restype = C.c_int
     lib.pagan_dp_debug_plan.argtypes = [gp, gp, bp, C.POINTER(C.c_uint8), C.c_int32, _i32p, C.c_int32, _i32p, _i32p]
     lib.pagan_dp_debug_plan.restype = C.c_int
+    lib.pagan_dp_debug_far.argtypes = [gp, gp, bp] + [C.POINTER(C.c_uint8)] * 4
+    lib.pagan_dp_debug_far.restype = C.c_int
     lib.pagan_dp_debug_strips.argtypes = [gp, gp, bp, C.c_int32, _i32p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64]
     lib.pagan_dp_debug_strips.restype = C.c_int
     lib.pagan_dp_debug_tiles.argtypes = [gp, gp, bp, _i32p, C.c_int32, _i32p]
@@ -246,6 +248,6 @@ def declare(lib):
 EXPORTED = ["pagan_dp_align", "pagan_dp_align_batch", "pagan_result_free", "pagan_dp_predict_bytes",
             "pagan_dp_count_cells", "pagan_dp_device_count", "pagan_dp_select_device", "pagan_batch_create",
             "pagan_batch_run", "pagan_batch_sync", "pagan_batch_fetch", "pagan_batch_last_ms",
-            "pagan_batch_cells", "pagan_batch_last_ms_detail", "pagan_batch_destroy", "pagan_batch_debug_trace", "pagan_dp_debug_plan", "pagan_dp_debug_strips", "pagan_dp_debug_tiles", "pagan_dp_debug_compact", "pagan_dp_debug_tiles_staircase", "pagan_dp_release_cache", "pagan_dp_cached_device_bytes", "pagan_dp_debug_route", "pagan_batch_debug_scores", "pagan_batch_debug_backptrs", "pagan_batch_debug_poison", "pagan_batch_debug_followed", "pagan_batch_debug_poke_bp", "pagan_batch_debug_reruns",
+            "pagan_batch_cells", "pagan_batch_last_ms_detail", "pagan_batch_destroy", "pagan_batch_debug_trace", "pagan_dp_debug_plan", "pagan_dp_debug_far", "pagan_dp_debug_strips", "pagan_dp_debug_tiles", "pagan_dp_debug_compact", "pagan_dp_debug_tiles_staircase", "pagan_dp_release_cache", "pagan_dp_cached_device_bytes", "pagan_dp_debug_route", "pagan_batch_debug_scores", "pagan_batch_debug_backptrs", "pagan_batch_debug_poison", "pagan_batch_debug_followed", "pagan_batch_debug_poke_bp", "pagan_batch_debug_reruns",
             "pagan_fb_run", "pagan_fb_totals", "pagan_fb_kernel_ms", "pagan_fb_dump", "pagan_fb_posterior_cells", "pagan_fb_sample_path",
             "pagan_fb_destroy", "pagan_dp_version"]

@@ -85,6 +85,9 @@ struct HostJob {
     std::vector<int> sched;      // dp_pipe.hip: awake intervals of the four compute waves (dp_device.h)
     std::vector<int> lead_req;   // dp_pipe.hip: per diagonal, what the downstream wave must have completed first
     std::vector<uint8_t> ring2;  // dp_pipe.hip: class 2 diagonals whose operands all lie in the ring
+    // far histories (dp_pipe.hip, PipeSmem::hist; plan_far_hist below): per site of either graph a flag byte, per diagonal
+    // whether a reader or a writer of a history line has a cell on it; all empty when the job has none
+    std::vector<uint8_t> hfL, hfR, hbit;
     std::vector<int> tiles;      // dp_tiles.hip (jobs that are not ring_ok): tile row, tile column of every tile that may hold a cell
     std::vector<struct StripPlan> strips;   // dp_pipe.hip, row strips (jobs that are not ring_ok and qualify: plan_strips); empty otherwise
     int n_bound = 0;             // traceback boundaries (dp_device.h)
@@ -154,6 +157,108 @@ struct SiteFeat {
 // `inwave` (model table in LDS): the compute waves evaluate the multi-edge cells of a class 1 diagonal themselves, which
 // covers sites with one edge from the previous site and at most one more ("easy", SiteFeat::not_easy); a diagonal that
 // holds any other multi-edge site is class 2 (the assist waves stage its candidates, ring-resident operands included).
+// ---- far histories (round 5) -------------------------------------------------------------------------------------
+// A site with one edge from the previous site and ONE other edge that reaches k >= PG_PIPE_REACH - 1 sites back reads cells
+// that have left the LDS ring: until round 5 every diagonal such a site has a cell on was class 2 -- staged by an assist wave
+// from L2, 2,600 cycles a step against a class 1 step's 1,100 (cfg4's root: 30 k of its 54 k class 2 diagonals are there for
+// nothing else).  The cells such an edge reads are cells of ONE earlier row (column) -- the edge's start site p = s - k --
+// taken k diagonals after they were computed.  So the lane that computes row p (a column's cell passes from lane to lane)
+// also appends its cell, every step, to a HISTORY LINE in LDS -- 64 entries, indexed by the cell's column (row) modulo 64 --
+// and the site's lane reads its operands there: an LDS read in place of a trip to L2, in the lanes that own the cell.
+//
+// This planner names the (start site -> far site) pairs that get a line: PG_HIST_SLOTS lines exist, a pair holds one from
+// the first diagonal its start site has a cell on to the last diagonal of the far site (interval colouring in order of the
+// first diagonal; a start site that several far sites share keeps one line).  A pair is served only if
+//   * the far site is "easy" (one edge from the previous site + this one) and k <= PG_HIST_MAX_SPAN: an entry lives 64
+//     steps, the reader comes k (+1) steps after the writer, and the waves of a workgroup are up to a ring's depth apart;
+//   * the start site is not site 0 (an edge from site 0 opens a gap for free: the general rules);
+//   * every diagonal of the interval runs in the hand-scheduled loop (class <= 2): the general steps and the wide runs write
+//     no history.
+// Flags per site (hfL / hfR, uploaded beside the graph; the loader stages them with the site records and sets PR_FAR in
+// the far site's record): bit 7 reader + bits 0-1 its line, bit 6 writer + bits 4-5 its line.  hbit[d] = 1 on every
+// diagonal of a served interval: the loop looks at the flags only there.  A cell where a far site meets a site that has an
+// other edge of its own would need the pair of the two other edges as well: those single diagonals stay class 2 (marked by
+// the caller through `cross`).  What is not served is marked far as before (class 2).
+struct FarPlan {
+    std::vector<uint8_t> hfL, hfR, hbit;
+    std::vector<uint8_t> servedL, servedR;     // per site: its far edge reads a history line
+    int n_served = 0, n_hard = 0;
+};
+
+void plan_far_hist(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, const RowBand &rb, const DiagIndex &dx,
+                   const SiteFeat &fl, const SiteFeat &fr, FarPlan *out) {
+    const int nd = Lx + Ly - 1;
+    out->hfL.assign(Lx, 0); out->hfR.assign(Ly, 0); out->hbit.assign(nd, 0);
+    out->servedL.assign(Lx, 0); out->servedR.assign(Ly, 0);
+    out->n_served = out->n_hard = 0;
+    if (const char *e = std::getenv("PAGAN_DP_HIST")) if (std::strcmp(e, "0") == 0) return;      // A/B switch: every far site as before
+    // diagonals that do not run in the hand-scheduled loop whatever the sites are (classify_diagonals has the rules)
+    std::vector<int> slow(nd + 1, 0);
+    {
+        int last_wide = -1000;
+        for (int d = 0; d < nd; ++d) {
+            const int lo = dx.imin[d], hi = dx.imax[d];
+            bool c3 = false;
+            if (hi - lo + 1 > PG_PIPE_WIDTH) { c3 = true; last_wide = d; }
+            else if (d - last_wide < PG_PIPE_REACH) c3 = true;
+            else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c3 = true;
+            slow[d + 1] = slow[d] + (c3 ? 1 : 0);
+        }
+    }
+    struct Cand { int start, end, site, src; bool left; };
+    std::vector<Cand> cands;
+    auto other_edge = [](const pagan_graph *g, int s, int *k) {      // easy two-edge site: the distance of the edge that is not from s - 1
+        const int a = g->bwd_off[s], b = g->bwd_off[s + 1];
+        if (s < 1 || b - a != 2) return false;
+        const int d0 = s - g->bwd_src[a], d1 = s - g->bwd_src[a + 1];
+        if ((d0 == 1) == (d1 == 1)) return false;
+        *k = d0 == 1 ? d1 : d0;
+        return true;
+    };
+    for (int i = 1; i < Lx; ++i) {
+        int k;
+        if (fl.span[i] < PG_PIPE_REACH - 1 || rb.hi[i] < rb.lo[i]) continue;
+        if (!other_edge(L, i, &k) || k > PG_HIST_MAX_SPAN || i - k < 1 || rb.hi[i - k] < rb.lo[i - k]) { ++out->n_hard; continue; }
+        cands.push_back({(i - k) + rb.lo[i - k] - 1, i + rb.hi[i] + 1, i, i - k, true});
+    }
+    for (int j = 1; j < Ly; ++j) {
+        int k;
+        if (fr.span[j] < PG_PIPE_REACH - 1) continue;
+        // rows whose band holds a column: hi[] and lo[] are monotone
+        auto rows_of = [&](int c, int *i1, int *i2) {
+            *i1 = (int)(std::lower_bound(rb.hi.begin(), rb.hi.end(), c) - rb.hi.begin());
+            *i2 = (int)(std::upper_bound(rb.lo.begin(), rb.lo.end(), c) - rb.lo.begin()) - 1;
+        };
+        int a1, a2, b1, b2;
+        rows_of(j, &a1, &a2);
+        if (a2 < a1) continue;                                     // (the column has no cell in the band)
+        if (!other_edge(R, j, &k) || k > PG_HIST_MAX_SPAN || j - k < 1) { ++out->n_hard; continue; }
+        rows_of(j - k, &b1, &b2);
+        if (b2 < b1) { ++out->n_hard; continue; }
+        cands.push_back({b1 + (j - k) - 1, a2 + j + 1, j, j - k, false});
+    }
+    std::stable_sort(cands.begin(), cands.end(), [](const Cand &x, const Cand &y) { return x.start < y.start; });
+    struct Line { int end = -1000000; int src = -1; bool left = false; };
+    Line lines[PG_HIST_SLOTS];
+    for (const Cand &c : cands) {
+        const int s0 = std::max(c.start, 0), s1 = std::min(c.end, nd - 1);
+        int slot = -1;
+        if (slow[s1 + 1] - slow[s0] == 0) {
+            for (int q = 0; q < PG_HIST_SLOTS && slot < 0; ++q)       // the start site's line, if it has one that is still alive
+                if (lines[q].src == c.src && lines[q].left == c.left && lines[q].end >= c.start) slot = q;
+            for (int q = 0; q < PG_HIST_SLOTS && slot < 0; ++q) if (lines[q].end < c.start) slot = q;          // (a free line; what its last user left is never read: an operand in the band is always the present writer's)
+        }
+        if (slot < 0) { ++out->n_hard; continue; }
+        lines[slot].end = std::max(lines[slot].end, c.end); lines[slot].src = c.src; lines[slot].left = c.left;
+        std::vector<uint8_t> &hf = c.left ? out->hfL : out->hfR;
+        hf[c.site] = (uint8_t)((hf[c.site] & 0x7c) | 0x80 | slot);
+        hf[c.src] = (uint8_t)((hf[c.src] & 0x8f) | 0x40 | (slot << 4));
+        (c.left ? out->servedL : out->servedR)[c.site] = 1;
+        for (int d = s0; d <= s1; ++d) out->hbit[d] = 1;
+        ++out->n_served;
+    }
+}
+
 // f(first, last) over [0, n) cut into `threads` ranges, one thread each (the caller's thread takes the first)
 template <class F> void par_ranges(int n, int threads, F f) {
     threads = std::max(1, std::min(threads, n / 4096));          // (a range below a few thousand items is not worth a thread)
@@ -172,7 +277,7 @@ template <class F> void par_ranges(int n, int threads, F f) {
 // passes done first; the sliding windows restart at a range's first diagonal by binary search.
 void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, const RowBand &rb,
                         const DiagIndex &dx, bool inwave, std::vector<uint8_t> *out, std::vector<int> *lead_req,
-                        std::vector<uint8_t> *ring2 = nullptr, int threads = 1) {
+                        std::vector<uint8_t> *ring2 = nullptr, int threads = 1, FarPlan *far_plan = nullptr) {
     const int nd = Lx + Ly - 1;
     static const bool prof = std::getenv("PAGAN_DP_PLAN_PROFILE") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -189,15 +294,34 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
         other.join();
     } else { fl.build(L, Lx); fr.build(R, Ly); }
     lap("site features");
+    // far histories (plan_far_hist): which far sites read their operands from a history line instead of making their
+    // diagonals class 2 (hand-scheduled loop only: `inwave`)
+    FarPlan none;
+    FarPlan &fp = far_plan ? *far_plan : none;
+    if (far_plan && inwave) plan_far_hist(L, R, Lx, Ly, rb, dx, fl, fr, far_plan);
+    else { fp.servedL.assign(Lx, 0); fp.servedR.assign(Ly, 0); fp.hbit.assign(nd, 0); }
+    lap("far histories");
     std::vector<int> far(nd + 1, 0), far2;
     std::vector<int> multi_cols;                       // columns with span >= 2, ascending
     for (int j = 0; j < Ly; ++j) if (fr.span[j] >= 2) multi_cols.push_back(j);
+    // far_any: a far site (served by a history line or not) has a cell on the diagonal -- a class 2 diagonal then is not one
+    // "whose operands all lie in the ring" even if the lanes' own far blocks would have taken the site on a class 1 diagonal
+    std::vector<int> far_any_r(nd + 1, 0), far_any_c(nd + 1, 0);
     auto mark_rows = [&](std::vector<int> &fa) {
         auto mark = [&](int d0, int d1) { if (d0 <= d1) { ++fa[d0]; --fa[d1 + 1]; } };
+        auto mark_any = [&](int d0, int d1) { if (d0 <= d1) { ++far_any_r[d0]; --far_any_r[d1 + 1]; } };
         for (int i = 0; i < Lx; ++i) {
             if (rb.hi[i] < rb.lo[i]) continue;
             const int sl = fl.span[i];
-            if (sl >= PG_PIPE_REACH - 1) { mark(i + rb.lo[i], i + rb.hi[i]); continue; }   // any column: span(j) >= 1
+            if (sl >= PG_PIPE_REACH - 1) {
+                mark_any(i + rb.lo[i], i + rb.hi[i]);
+                if (!fp.servedL[i]) { mark(i + rb.lo[i], i + rb.hi[i]); continue; }   // any column: span(j) >= 1
+                // its other edge reads a history line: only the cells where it meets a column with an other edge of its own
+                // (the pair of the two other edges is not in the line's reach) stay with the assist waves
+                for (auto it = std::lower_bound(multi_cols.begin(), multi_cols.end(), rb.lo[i]);
+                     it != multi_cols.end() && *it <= rb.hi[i]; ++it) mark(i + *it, i + *it);
+                continue;
+            }
             if (sl < 2) continue;                          // with span(i) <= 1 only span(j) >= REACH-1 matters: below
             for (auto it = std::lower_bound(multi_cols.begin(), multi_cols.end(), rb.lo[i]);
                  it != multi_cols.end() && *it <= rb.hi[i]; ++it)
@@ -206,12 +330,15 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
     };
     auto mark_cols = [&](std::vector<int> &fa) {
         auto mark = [&](int d0, int d1) { if (d0 <= d1) { ++fa[d0]; --fa[d1 + 1]; } };
+        auto mark_any = [&](int d0, int d1) { if (d0 <= d1) { ++far_any_c[d0]; --far_any_c[d1 + 1]; } };
         for (int j = 0; j < Ly; ++j) {
             if (fr.span[j] < PG_PIPE_REACH - 1) continue;
             // rows whose band holds column j: hi[] and lo[] are monotone
             const int i1 = (int)(std::lower_bound(rb.hi.begin(), rb.hi.end(), j) - rb.hi.begin());
             const int i2 = (int)(std::upper_bound(rb.lo.begin(), rb.lo.end(), j) - rb.lo.begin()) - 1;
-            mark(i1 + j, i2 + j);
+            mark_any(i1 + j, i2 + j);
+            if (!fp.servedR[j]) { mark(i1 + j, i2 + j); continue; }
+            for (int i = std::max(i1, 0); i <= i2 && i < Lx; ++i) if (fl.span[i] >= 2) mark(i + j, i + j);     // (as for the rows: where it meets another other edge)
         }
     };
     if (threads > 1) {
@@ -225,13 +352,14 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
     out->assign(nd, 0);
     if (ring2) ring2->assign(nd, 0);
     // what couples the diagonals: far cells in flight (a running sum) and the last wide diagonal at or before d
-    std::vector<int> run_at(nd), last_wide_at(nd);
+    std::vector<int> run_at(nd), last_wide_at(nd), any_at(nd);
     {
-        int run = 0, last_wide = -1000;
+        int run = 0, last_wide = -1000, any = 0;
         for (int d = 0; d < nd; ++d) {
             run += far[d];
+            any += far_any_r[d] + far_any_c[d];
             if (dx.imax[d] - dx.imin[d] + 1 > PG_PIPE_WIDTH) last_wide = d;
-            run_at[d] = run; last_wide_at[d] = last_wide;
+            run_at[d] = run; last_wide_at[d] = last_wide; any_at[d] = any;
         }
     }
     // How far back in the LDS ring the cells of a diagonal read: 2 for simple cells, span(i) + span(j) for a
@@ -265,9 +393,10 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
             else if (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)
                 c = (inwave && (fl.not_easy[hi + 1] - fl.not_easy[lo] > 0 || fr.not_easy[d - lo + 1] - fr.not_easy[d - hi] > 0)) ? 2 : 1;
             else c = 0;
+            if (c == 0 && fp.hbit[d]) c = 1;       // a history line's writer (or reader) has a cell here: the step looks at the sites' flags
             // a class 2 diagonal whose operands all lie in the ring (it is class 2 for the shape of a site only): the assist waves
             // take their ring-only code for it
-            if (ring2) (*ring2)[d] = c == 2 && run == 0 && !(lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH);
+            if (ring2) (*ring2)[d] = c == 2 && run == 0 && any_at[d] == 0 && !(lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH);
             (*out)[d] = c;
         }
         // (the windows over the rows with a ring-reaching skip edge only move forward: they restart at the range's first diagonal)
@@ -901,8 +1030,10 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe, i
                       edges_fit_ring(jb.right, hj->Ly, PG_PIPE_EDGE_CAP, PG_PIPE_SITE_EDGES);
         if (hj->ring_ok) {
             lap("boundaries, edge windows");
+            FarPlan fp;
             classify_diagonals(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, jb.model->n_states * jb.model->n_states <= 256,
-                               &hj->cls, &hj->lead_req, &hj->ring2, threads);
+                               &hj->cls, &hj->lead_req, &hj->ring2, threads, &fp);
+            if (fp.n_served > 0) { hj->hfL.swap(fp.hfL); hj->hfR.swap(fp.hfR); hj->hbit.swap(fp.hbit); }
             lap("classify_diagonals");
             schedule_waves(hj->dx, hj->cls, &hj->sched, threads);
             lap("schedule_waves");
@@ -966,6 +1097,8 @@ void carve_job(Carver &c, const pagan_job &jb, const HostJob &hj, PgDevJob *d) {
     d->dsc = c.take<int>(4 * (size_t)d->nd);
     d->psc = hj.cls.empty() ? nullptr : c.take<int>(8 * ((size_t)d->nd + 1));     // one entry of padding
     d->sched = hj.cls.empty() ? nullptr : c.take<int>(hj.sched.size());
+    d->hfL = hj.hfL.empty() ? nullptr : c.take<unsigned char>(hj.hfL.size());
+    d->hfR = hj.hfR.empty() ? nullptr : c.take<unsigned char>(hj.hfR.size());
     d->fill_status = c.take<int>(1);
     d->cells = hj.dx.cells;
     d->n_bound = hj.n_bound;
@@ -1461,6 +1594,26 @@ int pagan_dp_debug_plan(const pagan_graph *left, const pagan_graph *right, const
     return PAGAN_OK;
 }
 
+int pagan_dp_debug_far(const pagan_graph *left, const pagan_graph *right, const pagan_band *band,
+                       uint8_t *hfL, uint8_t *hfR, uint8_t *hbit, uint8_t *cls_out) {
+    if (!left || !right || !hfL || !hfR || !hbit || !cls_out) return PAGAN_E_ARG;
+    int rc;
+    if ((rc = check_graph(left)) != PAGAN_OK) return rc;
+    if ((rc = check_graph(right)) != PAGAN_OK) return rc;
+    const int Lx = left->n_sites - 1, Ly = right->n_sites - 1;
+    RowBand rb;
+    if ((rc = rb.build(Lx, Ly, band)) != PAGAN_OK) return rc;
+    DiagIndex dx;
+    dx.build(Lx, Ly, rb);
+    std::vector<uint8_t> cls;
+    std::vector<int> lead_req;
+    FarPlan fp;
+    classify_diagonals(left, right, Lx, Ly, rb, dx, true, &cls, &lead_req, nullptr, 1, &fp);
+    std::memcpy(hfL, fp.hfL.data(), fp.hfL.size()); std::memcpy(hfR, fp.hfR.data(), fp.hfR.size());
+    std::memcpy(hbit, fp.hbit.data(), fp.hbit.size()); std::memcpy(cls_out, cls.data(), cls.size());
+    return fp.n_served;
+}
+
 int pagan_dp_debug_strips(const pagan_graph *left, const pagan_graph *right, const pagan_band *band, int32_t max_sites,
                           int32_t *strips, int32_t cap, int64_t *desc_off, int64_t *desc, int64_t desc_cap) {
     if (!left || !right || !strips || !desc_off || !desc || cap < 0 || desc_cap < 0) return PAGAN_E_ARG;
@@ -1819,11 +1972,14 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
                 mask = (t >= 1 && hj.cls[t - 1] <= 3) ? (((mask << 1) | 2u) & (((1u << PG_PIPE_REACH) - 1u) & ~1u)) : 0u;
                 // bit 4: large tables -- the next step is hot too; small tables -- a class 2 diagonal with every operand in the ring
                 const unsigned pair = big_table ? (t + 1 < hj.cls.size() && hj.cls[t + 1] <= 2 ? 1u : 0u) : (hj.ring2[t] ? 1u : 0u);
-                packed[8 * t + 4] = (int)(hj.cls[t] | (pair << 4) | (mask << 5) | ((unsigned)hop[t] << 20));
+                // bit 5 (bit 0 of the residency mask, which no age uses): a far history's writer or reader has a cell on the diagonal
+                const unsigned hb = (!hj.hbit.empty() && hj.hbit[t]) ? 1u : 0u;
+                packed[8 * t + 4] = (int)(hj.cls[t] | (pair << 4) | ((mask | hb) << 5) | ((unsigned)hop[t] << 20));
                 packed[8 * t + 5] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[8 * t + 6] = (int)(hj.dx.doff[t] >> 32);
                 packed[8 * t + 7] = hj.lead_req[t];
             }
             put(stage, d.sched, hj.sched.data(), hj.sched.size());
+            if (d.hfL) { put(stage, d.hfL, hj.hfL.data(), hj.hfL.size()); put(stage, d.hfR, hj.hfR.data(), hj.hfR.size()); }
         }
         put(stage, d.tb, hj.tb.data(), hj.tb.size());
         const int zero = 0;
@@ -1845,7 +2001,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
         b->score_off[k] = reinterpret_cast<size_t>(d.endscore);
         rebase(d.stL); rebase(d.offL); rebase(d.srcL); rebase(d.lwL);
         rebase(d.stR); rebase(d.offR); rebase(d.srcR); rebase(d.lwR);
-        rebase(d.table); rebase(d.imin); rebase(d.imax); rebase(d.doff); rebase(d.tb); rebase(d.dsc); if (d.psc) { rebase(d.psc); rebase(d.sched); } rebase(d.fill_status);
+        rebase(d.table); rebase(d.imin); rebase(d.imax); rebase(d.doff); rebase(d.tb); rebase(d.dsc); if (d.psc) { rebase(d.psc); rebase(d.sched); } if (d.hfL) { rebase(d.hfL); rebase(d.hfR); } rebase(d.fill_status);
         rebase(d.sc); rebase(d.bp);
         rebase(d.trace); rebase(d.endcell); rebase(d.endscore); rebase(d.segs); rebase(d.ttab);
         if (d.follow) { rebase(d.follow); rebase(d.bp_done); }

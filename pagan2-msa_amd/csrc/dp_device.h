@@ -44,13 +44,16 @@
 
 // Geometry of the banded fill kernel (dp_pipe.hip) that the host-side planner (dp_abi.hip:
 // classify_diagonals, schedule_waves) has to agree with.
-#define PG_PIPE_WIDTH 241        // widest diagonal computed in the lanes' registers (256 lanes - PG_PIPE_REACH)
-#define PG_PIPE_REACH 15         // a cell may read PG_PIPE_REACH-1 diagonals back in the LDS ring: the whole ring but the
+#define PG_PIPE_WIDTH 242        // widest diagonal computed in the lanes' registers (256 lanes - PG_PIPE_REACH)
+#define PG_PIPE_REACH 14         // a cell may read PG_PIPE_REACH-1 diagonals back in the LDS ring: the whole ring but the
                                  // row being written.  Older operands come from L2.  Since the multi-edge candidates are
                                  // evaluated by assist waves ahead of the compute waves (dp_pipe.hip), an L2 read is off the
                                  // critical path, and five diagonals of the ring (20 in round 1) became the staging slots
                                  // through which the assist waves hand their results over.
-#define PG_PIPE_RING 15          // ring depth in diagonals: a wave stays awake this long after its last cell
+#define PG_PIPE_RING 14          // ring depth in diagonals: a wave stays awake this long after its last cell
+#define PG_HIST_SLOTS 3           // far histories (dp_abi.hip, plan_far_hist; dp_pipe.hip, PipeSmem::hist): lines of 64 cells
+#define PG_HIST_MAX_SPAN 44      // longest edge a history line serves: an entry lives 64 steps, the reader comes k + 1 steps after the
+                                 // writer, and the writer's wave may be up to a ring's depth ahead of the reader's
 #define PG_PIPE_ASSIST 3         // assist waves: wave a takes the multi-edge cells of the diagonals d with d % 3 == a
 #define PG_PIPE_STAGE 3          // staging slots (d % 3, one per assist wave): a diagonal is staged at most two ahead of the compute waves
 #define PG_PIPE_WAKE 6           // ... and wakes this many diagonals before its first one (operand prefetch pipeline)
@@ -80,6 +83,7 @@ struct PgDevJob {
                              //   overwrites its ring row.  class: 0 simple, 1 multi-edge, 2 multi-edge with far edges, 3 general,
                              //   4 wide; bit a of the mask: diagonal d-a was computed by the lanes (is in the LDS ring)
     const int *sched;        // dp_pipe.hip: [4] offsets, then per compute wave its awake intervals a0,b0,a1,b1,...,nd,nd
+    const unsigned char *hfL, *hfR;   // dp_pipe.hip, far histories: a flag byte per left / right site (dp_abi.hip, plan_far_hist); null: none
     int *fill_status;        // [1] 0 = filled; nonzero = the fill kernel abandoned a wait (internal error)
     long long cells;
     // outputs

@@ -74,9 +74,13 @@ static_assert(PNA == 3 && PST == 3 && PAGE >= PLAND + 4, "assist wave a stages t
 // site record, word x
 #define PR_SIMPLE 0x10000        // one bwd edge, from the previous site, log-weight 0
 #define PR_NE_SHIFT 17           // 7 bits: number of bwd edges (host keeps sites with > 126 off this kernel)
-#define PR_TWO 0x1000000         // (small model tables only) two bwd edges, exactly one of them from the previous site -- NORMALISED: that edge in slot 0,
-                                 // the other one in slot 1 whatever the list's order (the fill computes values only: tools/gen_hot_asm.py, c1_issue);
-                                 // bits 25-31 stay zero (the hand-scheduled loop tests the flag as x > 0xffffff)
+// bits 24-31 of a site record's word x (small model tables only; the loader sets them, the hand-scheduled loop reads them)
+#define PR_SRC 0x1000000         // the site is the START of an edge that reads a far history line: its lane appends its cell to line (x >> 25) & 3
+#define PR_TWO 0x40000000        // two bwd edges, exactly one of them from the previous site -- NORMALISED: that edge in slot 0, the other one in
+                                 // slot 1 whatever the list's order (the fill computes values only: tools/gen_hot_asm.py, c1_issue)
+#define PR_FAR 0x80000000u       // ... and the other edge reaches past the ring: its operands come from history line (x >> 27) & 3.  The loop tests
+                                 // "other edge in the ring" as ONE signed compare, x > 0x3fffffff: PR_TWO set, PR_FAR (the sign) clear, whatever the
+                                 // bits below say
 
 struct PipeSmem {
     double sc[PRK][PNT][3];      // X, Y, M
@@ -89,6 +93,11 @@ struct PipeSmem {
     // tab2[a + b*S] = { D(2*ng) + D(s(a,b)), D(0+ng) + D(s(a,b)) } (VA:1363-1367), computed once per workgroup with the expressions every
     // other path uses; large tables: the model scores the assist waves gather per staging slot
     union { double tab2[256][2]; float ssm[PST][PNT]; };
+    // Far histories (round 5; dp_abi.hip, plan_far_hist): line q holds the last 64 cells of ONE row (indexed by column % 64)
+    // or ONE column (indexed by row % 64) that is the start site of an edge reaching past the ring -- written every step by
+    // the lane that computes the cell, read k steps later by the lane of the edge's end site, in place of a trip to L2.
+    // Who reads and who writes which line is in the site records (PR_FAR / PR_SRC, set by the loader from the host's flag bytes).
+    double hist[PG_HIST_SLOTS][64][3];
     double null_cell[4];         // -inf, -inf, -inf: what a missing second edge reads
     int progress[PNW];           // last diagonal each compute wave completed (or sleeps through)
     int arrived[PNW];            // last rendezvous diagonal each compute wave drained for
@@ -185,7 +194,8 @@ __device__ __forceinline__ double dpp_shr1(double v, double lane0) {
 
 // ---- loader wave -------------------------------------------------------------------------
 template <bool LEFT>
-__device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_p st, gint_p off, gint_p src, gfloat_p lw, bool strip, bool norm) {
+__device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_p st, gint_p off, gint_p src, gfloat_p lw, bool strip, bool norm,
+                                               PG_GLOBAL const unsigned char *hf) {
     pg_i4 *rec = LEFT ? PM.recL : PM.recR;
     int *eb = LEFT ? PM.ebL : PM.ebR;
     int *es = LEFT ? PM.esL : PM.esR;
@@ -194,7 +204,8 @@ __device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_
     // two round trips for the usual chunk: offsets and states, then the sites' first two edges together with the chunk's
     // edge list for the LDS window; a third (and on) only where a site has more than two edges
     int b = 0, en = 0, w = 0;
-    if (r < n) { b = off[r]; en = off[r + 1]; w = st[r] & 0xffff; }
+    unsigned flag = 0;                                             // far histories: the site's flag byte (0 where the job has none)
+    if (r < n) { b = off[r]; en = off[r + 1]; w = st[r] & 0xffff; if (hf) flag = hf[r]; }
     const int ne = en - b;
     const int rend = first + 64 < n ? first + 64 : n;
     const int e0 = __builtin_amdgcn_readfirstlane(b), e1 = __builtin_amdgcn_readlane(en, rend - 1 - first);
@@ -228,6 +239,9 @@ __device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_
         // its y-gap (x-gap) chain is the straight code's at the terminal rate; the diagonals 0 and 1 and the cells that meet
         // M(0,0) through an edge from site 0 are general steps (dp_abi.hip, plan_strips), and those read no record of site 0.
         if (strip && r == 0) { v.x = (w & 0xffff) | PR_SIMPLE | (1 << PR_NE_SHIFT); v.y = 1; v.z = 0; v.w = 0; }
+        // far histories (dp_abi.hip, plan_far_hist; flag byte: bit 7 reader + bits 0-1 its line, bit 6 writer + bits 4-5 its line)
+        if (flag & 0x80u) v.x |= (int)(PR_FAR | ((flag & 3u) << 27));
+        if (flag & 0x40u) v.x |= (int)(PR_SRC | (((flag >> 4) & 3u) << 25));
         rec[r & (PRW - 1)] = v;
         eb[r & (PRW - 1)] = b;
     }
@@ -245,7 +259,8 @@ __device__ __forceinline__ void publish_landed(PG_GLOBAL int *follow, int lane, 
 }
 // Row strips (`strip`: the PgDevJob, null otherwise): records from the strip's first halo row / first column on, the
 // descriptor window from the PARENT's array (whole-band rows per diagonal, offsets in cells there), everything from d_first.
-__device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lane, PG_GLOBAL int *follow, const PgDevJob *strip, bool norm) {
+__device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lane, PG_GLOBAL int *follow, const PgDevJob *strip, bool norm,
+                                            PG_GLOBAL const unsigned char *hfl, PG_GLOBAL const unsigned char *hfr) {
     int rows = 0, cols = 0, diags = 0, published = -1;
     PG_GLOBAL const pg_i4 *pdsc = nullptr;
     if (strip) {
@@ -297,12 +312,12 @@ __device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lan
             any = true;
         }
         if (rows < want_rows) {
-            load_rec_chunk<true>(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL, strip != nullptr, norm);
+            load_rec_chunk<true>(rows, lane, J.Lx, J.stL, J.offL, J.srcL, J.lwL, strip != nullptr, norm, hfl);
             rows += 64; any = true;
             flag_store(&PM.loaded[0], rows);
         }
         if (cols < want_cols) {
-            load_rec_chunk<false>(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR, strip != nullptr, norm);
+            load_rec_chunk<false>(cols, lane, J.Ly, J.stR, J.offR, J.srcR, J.lwR, strip != nullptr, norm, hfr);
             cols += 64; any = true;
             flag_store(&PM.loaded[1], cols);
         }
@@ -1835,6 +1850,9 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
     const unsigned ni_hi = 0xfff00000u;
     const unsigned a_null = (unsigned)(unsigned long long)(lds_char *)&PM.null_cell[0];
     const unsigned a_asd = (unsigned)(unsigned long long)(lds_char *)&PM.assist_done[0];
+    // far histories (tools/gen_hot_asm.py, hist_tail): the flag bytes' windows, the lines, the loader's descriptor window
+    const unsigned a_hist = (unsigned)(unsigned long long)(lds_char *)&PM.hist[0][0][0], a_dring = (unsigned)(unsigned long long)(lds_char *)&PM.dring[0];
+    static_assert(sizeof(PM.hist[0]) == 0x600 && PDR == 128, "hist_tail's address arithmetic");
     const unsigned a_stx = (unsigned)(unsigned long long)(lds_char *)&PM.sx[0][tid], a_spx = (unsigned)(unsigned long long)(lds_char *)&PM.spx[0][tid];
     static_assert(offsetof(PipeSmem, sy) - offsetof(PipeSmem, sx) == 6144 && offsetof(PipeSmem, sM) - offsetof(PipeSmem, sx) == 12288 &&
                   offsetof(PipeSmem, spy) - offsetof(PipeSmem, spx) == 3072 && offsetof(PipeSmem, spm) - offsetof(PipeSmem, spx) == 6144 &&
@@ -1869,7 +1887,8 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                   [asd] "s"(a_asd), [stx] "v"(a_stx), [spxa] "v"(a_spx), \
                   [stopm1] "s"(stop - 1), [S] "s"(S), [fdn] "v"(a_fdn), \
                   [bR] "s"(a_recR), [bL] "s"(a_recL), [bT] "s"(a_table), \
-                  [sclo] "s"(sc_lo), [schi] "s"(sc_hi), [c24] "s"(0xffffffu)
+                  [sclo] "s"(sc_lo), [schi] "s"(sc_hi), [c24] "s"(0x3fffffffu), \
+                  [histb] "v"(a_hist), [drb] "v"(a_dring)
             if constexpr (STRIP) {
                 // (the strip's loop picks the x-gap state's rate per lane and step: tools/gen_hot_asm.py, STRIP)
                 const double gE_ = term_on ? gE : ge;
@@ -1957,6 +1976,9 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
         }
 #endif
         const int lo = cur.x, hi = cur.y, cls = cur.s4 & CLS;
+        // (this C++ rendering of the step knows nothing of the far histories: a job planned with them -- PAGAN_DP_HIST is not 0 --
+        //  must run the hand-scheduled loop; a -DPG_NO_HOT_ASM build that meets one says so instead of computing something else)
+        if (!STRIP && (cur.s4 & 32)) { if (flag_load(&PM.abort_flag) == 0) flag_store(&PM.abort_flag, PTAG(13)); dA = cur; break; }
 #ifdef PG_PIPE_STATS
         const long long st_step0 = __builtin_readcyclecounter();
         const bool st_has = __any(row <= hi && row >= lo);
@@ -2730,7 +2752,8 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
 #endif
     if (tid >= PNT + 64 * PNA) {
         const View J = load_view(job);
-        pipe_loader(J, psc, lane, (PG_GLOBAL int *)job->follow, STRIP ? job : nullptr, TAB_LDS);
+        pipe_loader(J, psc, lane, (PG_GLOBAL int *)job->follow, STRIP ? job : nullptr, TAB_LDS,
+                    (TAB_LDS && !STRIP) ? (PG_GLOBAL const unsigned char *)job->hfL : nullptr, (TAB_LDS && !STRIP) ? (PG_GLOBAL const unsigned char *)job->hfR : nullptr);
         return;
     }
     if (tid >= PNT) {

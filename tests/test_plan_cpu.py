@@ -6,7 +6,17 @@ import pytest
 import pagan2_msa_amd as pg
 from pagan2_msa_amd import abi, synth
 
-REACH, WIDTH, WINDOW, RING, WAKE = 15, 241, 352, 15, 6      # dp_device.h: PG_PIPE_*
+
+
+def _geometry():
+    """PG_PIPE_* of pagan2-msa_amd/csrc/dp_device.h (the kernel's geometry the planner has to agree with)"""
+    import os, re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pagan2-msa_amd", "csrc", "dp_device.h")).read()
+    return tuple(int(re.search(r"#define\s+PG_PIPE_%s\s+(\d+)" % k, text).group(1)) for k in ("REACH", "WIDTH", "WINDOW", "RING", "WAKE"))
+
+
+REACH, WIDTH, WINDOW, RING, WAKE = _geometry()
+assert WIDTH == 256 - REACH and RING >= REACH
 
 
 def site_features(g, n):

@@ -40,6 +40,16 @@ import os
 # sweep every column, so a cell of the first or the last column sits on half of a strip's diagonals: the x-gap state's
 # extension rate is picked per lane and step -- v[254:255] = (d == row or d - (Ly-1) == row) ? gE : ge, five vector
 # instructions -- where the banded kernel sends the few diagonals with such a cell to the general step.
+def _ring_depth():
+    """PG_PIPE_RING of dp_device.h: the ring's depth in diagonals (rows of 256 cells x 24 bytes = 0x1800)"""
+    import re
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pagan2-msa_amd", "csrc", "dp_device.h")) as f:
+        return int(re.search(r"#define\s+PG_PIPE_RING\s+(\d+)", f.read()).group(1))
+
+
+RING_ROWS = _ring_depth()
+RING_BYTES = "0x%x" % (RING_ROWS * 0x1800)               # the ring
+RING_LAST = "0x%x" % ((RING_ROWS - 1) * 0x1800)          # its last row
 STRIP = bool(os.environ.get("PG_HOT_STRIP"))
 OUT = os.environ.get("PG_HOT_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pagan2-msa_amd", "csrc",
                                                    "dp_pipe_hot_strip.inc" if STRIP else "dp_pipe_hot.inc")
@@ -82,14 +92,14 @@ class Emit:
         diagonal's: sb - age, plus the ring's size where that wraps (unsigned minimum of the two)"""
         a = self.a
         a("v_sub_u32_e32 v%d, %s, v%d" % (dst, self.cursb, age_bytes))
-        a("v_add_u32_e32 v223, 0x16800, v%d" % dst)
+        a("v_add_u32_e32 v223, %s, v%d" % (RING_BYTES, dst))
         a("v_min_u32_e32 v%d, v%d, v223" % (dst, dst))
 
     def ring_row_before(self, dst, src):
         """dst = the ring row one diagonal before the row at `src` (both byte offsets inside the ring)"""
         a = self.a
         a("v_subrev_u32_e32 v%d, 0x1800, v%d" % (dst, src))
-        a("v_add_u32_e32 v223, 0x16800, v%d" % dst)
+        a("v_add_u32_e32 v223, %s, v%d" % (RING_BYTES, dst))
         a("v_min_u32_e32 v%d, v%d, v223" % (dst, dst))
 
     def read_cell(self, cell, addr):
@@ -158,14 +168,14 @@ def c1_issue(E, k, tag):
 
     The loader NORMALISES the records of this kernel's jobs (dp_pipe.hip, load_rec_chunk<., true>): a site with two bwd edges of
     which exactly one starts at the previous site carries that edge in slot 0, the other one in slot 1, and the PR_TWO flag
-    (bit 24; bits 25-31 are zero) -- the fill computes values only, so the order of a site's list does not matter to it.  What is
+    (bit 30; bit 31 is PR_FAR, bits 24-28 name the far history lines: dp_pipe.hip) -- the fill computes values only, so the order of a site's list does not matter to it.  What is
     left of the decode: flag, the other edge's distance, two conversions per side.  Each block runs with exec = the lanes whose
     site has the other edge: no lane without one reads or merges anything (before: an all -inf cell selected per operand)."""
     a = E.a
     RL, CR = RLK[k], CRK[k]
     sfx = "%s%d_%%=" % (tag, k)
-    a("v_cmp_lt_u32_e64 s[74:75], %%[c24], v%d" % RL)             # l2: the left site has another edge (x > 0xffffff)
-    a("v_cmp_lt_u32_e64 s[76:77], %%[c24], v%d" % CR)             # r2
+    a("v_cmp_lt_i32_e64 s[74:75], %%[c24], v%d" % RL)             # l2: the left site has another edge IN THE RING (signed x > 0x3fffffff: PR_TWO, and not PR_FAR)
+    a("v_cmp_lt_i32_e64 s[76:77], %%[c24], v%d" % CR)             # r2
     a("v_lshrrev_b32_e32 v%d, 16, v%d" % (KL, RL + 1))
     a("v_lshrrev_b32_e32 v%d, 16, v%d" % (KR, CR + 1))
     a("s_and_b64 s[74:75], s[74:75], s[60:61]")
@@ -253,6 +263,118 @@ def c1_math(E, k, tag):
     a(".Lpg_noB%s:" % sfx)
     a("s_mov_b64 exec, s[62:63]")
     a(".Lpg_noL%s:" % sfx)
+
+
+def hist_tail(E, k, cls2):
+    """Far histories (dp_abi.hip, plan_far_hist; PipeSmem::hist): the part of a step on a diagonal whose descriptor says that a
+    history line's reader or writer has a cell on it (word 4, bit 5).  Behind the class 1 / class 2 part, BX / BY / BM final but
+    for this:
+      * READERS (class 1 diagonals; on a class 2 diagonal the assist wave staged the far site's candidates with the rest): a
+        site whose other edge reaches k >= reach sites back (PR_FAR; flag byte bit 7, line in bits 0-1) takes that edge's two
+        operands from the line -- left site: (row-k, j) and (row-k, j-1) at entries j % 64 and (j-1) % 64 of a line indexed by
+        column; right site: (row, j-k) and (row-1, j-k) at entries row % 64 and (row-1) % 64 of a line indexed by row -- the
+        gap candidate from the first, the pair (it, the other site's previous-site edge) from the second.  An operand OUTSIDE
+        THE BAND was never written (nobody computes it): its diagonal's rows come from the loader's descriptor window and the
+        candidate of an operand outside them is left out.
+      * WRITERS (flag byte bit 6, line in bits 4-5; rows and columns alike): the lane that holds the cell of a line's row
+        (column) appends it -- the final values, in-band lanes only.
+    A cell where a far site meets a site with an other edge of its own is on a class 2 diagonal (the host sees to it): the pair of
+    the two other edges is nobody's here."""
+    a = E.a
+    RL, CR = RLK[k], CRK[k]
+    tmx = TMX[k]
+    sfx = "%d_%%=" % k
+    tag = "h2" if cls2 else "h1"
+    a("v_sub_u32_e32 v222, %[d], %[row]")                      # the cell's column j
+    if not cls2:
+        a("v_cmp_gt_i32_e32 vcc, 0, v%d" % RL)                  # farL: PR_FAR (the record's sign)
+        a("s_and_b64 s[52:53], vcc, s[60:61]")
+        a("v_cmp_gt_i32_e32 vcc, 0, v%d" % CR)                  # farR
+        a("s_and_b64 s[54:55], vcc, s[60:61]")
+        a("s_or_b64 s[56:57], s[52:53], s[54:55]")
+        a("s_cmp_eq_u64 s[56:57], 0")
+        a("s_cbranch_scc1 .Lpg_%swr%s" % (tag, sfx))
+        for (left, mask, rec, kk, wS, wA_other) in ((True, "s[52:53]", RL, KL, LWS, RWA), (False, "s[54:55]", CR, KR, RWS, LWA)):
+            side = "L" if left else "R"
+            a("s_cmp_eq_u64 %s, 0" % mask)
+            a("s_cbranch_scc1 .Lpg_%sno%s%s" % (tag, side, sfx))
+            a("s_and_saveexec_b64 s[62:63], %s" % mask)
+            a("v_bfe_u32 v217, v%d, 27, 2" % rec)                                   # the line
+            a("v_sub_u32_e32 v218, %%[d], v%d" % kk)                                 # e: the diagonal of the first operand
+            a("v_mul_u32_u24_e32 v217, 0x600, v217")
+            a("v_cvt_f64_f32_e32 %s, v%d" % (pr(wS), rec + 3))                       # the far edge's weight
+            a("v_add_u32_e32 v217, %[histb], v217")
+            # entries: left site -- column j and j - 1; right site -- row and row - 1
+            if left:
+                a("v_and_b32_e32 v221, 63, v222")
+                a("v_add_u32_e32 v223, -1, v222")
+            else:
+                a("v_and_b32_e32 v221, 63, %[row]")
+                a("v_add_u32_e32 v223, -1, %[row]")
+            a("v_mad_u32_u24 v221, v221, 24, v217")
+            a("v_and_b32_e32 v223, 63, v223")
+            E.read_cell(W1, 221)
+            a("v_mad_u32_u24 v223, v223, 24, v217")
+            E.read_cell(W2, 223)
+            # the rows of the operands' diagonals e and e - 1 (the loader's descriptor window: lo, hi)
+            a("v_and_b32_e32 v221, 0x7f, v218")
+            a("v_add_u32_e32 v223, -1, v218")
+            a("v_lshl_add_u32 v221, v221, 4, %[drb]")
+            a("v_and_b32_e32 v223, 0x7f, v223")
+            a("ds_read_b64 v[160:161], v221")
+            a("v_lshl_add_u32 v223, v223, 4, %[drb]")
+            a("ds_read_b64 v[162:163], v223")
+            # the operands' rows: left site row - k (both); right site row and row - 1
+            if left:
+                a("v_sub_u32_e32 v217, %%[row], v%d" % kk)
+                a("v_mov_b32_e32 v218, v217")
+            else:
+                a("v_mov_b32_e32 v217, %[row]")
+                a("v_add_u32_e32 v218, -1, %[row]")
+            a("s_waitcnt lgkmcnt(0)")
+            a("v_cmp_le_i32_e64 s[84:85], v160, v217")                              # lo(e) <= row of the first operand
+            a("v_cmp_ge_i32_e64 s[86:87], v161, v217")                              # ... <= hi(e)
+            a("v_cmp_le_i32_e64 s[56:57], v162, v218")
+            a("v_cmp_ge_i32_e64 s[58:59], v163, v218")
+            if left:
+                E.gap_value(W1, 0, 1, T[0], T[1], T[2])
+                E.pair_value(W2, tmx, wS, wA_other, T[3], T[4])
+            else:
+                E.gap_value(W1, 1, 0, T[0], T[1], T[2])
+                E.pair_value(W2, tmx, wA_other, wS, T[3], T[4])
+            a("s_and_b64 s[84:85], s[84:85], s[86:87]")
+            a("s_and_b64 s[56:57], s[56:57], s[58:59]")
+            a("s_and_b64 exec, exec, s[84:85]")                                     # (exec = the far lanes: those whose first operand lies in the band)
+            a("v_max_f64 %s, %s, %s" % (pr(BX if left else BY), pr(BX if left else BY), pr(T[0])))
+            a("s_and_b64 exec, %s, s[56:57]" % mask)
+            a("v_max_f64 %s, %s, %s" % (pr(BM), pr(BM), pr(T[3])))
+            a("s_mov_b64 exec, s[62:63]")
+            a(".Lpg_%sno%s%s:" % (tag, side, sfx))
+    # ---- writers ----
+    a(".Lpg_%swr%s:" % (tag, sfx))
+    a("v_and_b32_e32 v217, 0x1000000, v%d" % RL)               # PR_SRC
+    a("v_and_b32_e32 v218, 0x1000000, v%d" % CR)
+    a("v_cmp_ne_u32_e64 s[52:53], 0, v217")
+    a("v_cmp_ne_u32_e64 s[54:55], 0, v218")
+    a("s_and_b64 s[52:53], s[52:53], s[60:61]")
+    a("s_and_b64 s[54:55], s[54:55], s[60:61]")
+    for (left, mask, rec) in ((True, "s[52:53]", RL), (False, "s[54:55]", CR)):
+        side = "L" if left else "R"
+        a("s_cmp_eq_u64 %s, 0" % mask)
+        a("s_cbranch_scc1 .Lpg_%snw%s%s" % (tag, side, sfx))
+        a("s_and_saveexec_b64 s[62:63], %s" % mask)
+        a("v_bfe_u32 v217, v%d, 25, 2" % rec)                                       # the line
+        if left:
+            a("v_and_b32_e32 v221, 63, v222")                                       # a row's line: by column
+        else:
+            a("v_and_b32_e32 v221, 63, %[row]")                                     # a column's line: by row
+        a("v_mul_u32_u24_e32 v217, 0x600, v217")
+        a("v_add_u32_e32 v217, %[histb], v217")
+        a("v_mad_u32_u24 v221, v221, 24, v217")
+        a("ds_write2_b64 v221, %s, %s offset1:1" % (pr(BX), pr(BY)))
+        a("ds_write_b64 v221, %s offset:16" % pr(BM))
+        a("s_mov_b64 exec, s[62:63]")
+        a(".Lpg_%snw%s%s:" % (tag, side, sfx))
 
 
 def class2(E, k):
@@ -546,6 +668,8 @@ def step(E, k):
     c1_issue(E, k, "f")                                        # (a wave without a multi-edge cell finds its masks empty: the decode and the records after next is all it does)
     shift_and_x(have_active=True)
     c1_math(E, k, "f")
+    a("s_bitcmp1_b32 s%d, 5" % s4)                             # a far history's reader or writer has a cell on this diagonal
+    a("s_cbranch_scc1 .Lpg_hist%s" % sfx)
     if "E" not in EXP:
         next_desc()
     a("s_branch .Lpg_commit%s" % sfx)
@@ -577,10 +701,22 @@ def step(E, k):
     c1_issue(E, k, "s")
     c1_math(E, k, "s")
     a(".Lpg_c1done%s:" % sfx)
+    a("s_bitcmp1_b32 s%d, 5" % s4)
+    a("s_cbranch_scc1 .Lpg_hist%s" % sfx)
+    next_desc()
+    a("s_branch .Lpg_commit%s" % sfx)
+    a(".Lpg_hist%s:" % sfx)
+    hist_tail(E, k, cls2=False)
     next_desc()
     a("s_branch .Lpg_commit%s" % sfx)
     a(".Lpg_c2%s:" % sfx)
     class2(E, k)
+    a("s_bitcmp1_b32 s%d, 5" % s4)
+    a("s_cbranch_scc1 .Lpg_hist2%s" % sfx)
+    next_desc()
+    a("s_branch .Lpg_commit%s" % sfx)
+    a(".Lpg_hist2%s:" % sfx)
+    hist_tail(E, k, cls2=True)
     next_desc()
     a("s_branch .Lpg_commit%s" % sfx)
     E.cur = E.L
@@ -615,7 +751,7 @@ def step(E, k):
     # next diagonal
     a("s_add_i32 %[d], %[d], 1")
     a("s_add_i32 %s, %s, 0x1800" % (prevsb, cursb))            # the next diagonal's ring row, into the register that held the previous one's
-    a("s_cmp_eq_u32 %s, 0x16800" % prevsb)
+    a("s_cmp_eq_u32 %s, %s" % (prevsb, RING_BYTES))
     a("s_cselect_b32 %s, 0, %s" % (prevsb, prevsb))
     if k == 1:                                                  # the descriptor pointer moves once per pair (half 0 reads at +0x20, half 1 at +0x40)
         a("s_add_u32 s70, s70, 0x40")
@@ -637,7 +773,7 @@ def main():
     a("s_load_dwordx8 s[36:43], s[70:71], 0x0")
     a("s_sub_i32 s66, %[sb], 0x1800")                           # ring row of the diagonal before
     a("s_cmp_lt_i32 s66, 0")
-    a("s_cselect_b32 s66, 0x15000, s66")
+    a("s_cselect_b32 s66, %s, s66" % RING_LAST)
     # Device functions are 4-byte aligned: without this the loop's place in the instruction cache lines -- and with it the
     # step time, by a few percent -- moves whenever any code in front of it changes size.  (s_nop padding, run once.)
     a(".p2alignl 6, 3212836864")
