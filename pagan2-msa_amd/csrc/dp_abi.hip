@@ -88,6 +88,7 @@ struct HostJob {
     // far histories (dp_pipe.hip, PipeSmem::hist; plan_far_hist below): per site of either graph a flag byte, per diagonal
     // whether a reader or a writer of a history line has a cell on it; all empty when the job has none
     std::vector<uint8_t> hfL, hfR, hbit;
+    std::vector<uint8_t> tbit;   // per diagonal: a three-edge site the lanes take in a third pass has a cell on it (empty: none)
     std::vector<int> tiles;      // dp_tiles.hip (jobs that are not ring_ok): tile row, tile column of every tile that may hold a cell
     std::vector<struct StripPlan> strips;   // dp_pipe.hip, row strips (jobs that are not ring_ok and qualify: plan_strips); empty otherwise
     int n_bound = 0;             // traceback boundaries (dp_device.h)
@@ -122,9 +123,15 @@ struct SiteFeat {
     std::vector<int> no_pred;         // prefix count of sites without bwd edges
     std::vector<int> not_easy;        // prefix count of sites the compute waves of dp_pipe.hip do not evaluate themselves: anything
                                       // but one edge from the previous site (any weight), alone or beside ONE edge from further back
+    // (round 5) a site with THREE edges, one of them from the previous site and the other two inside the ring's reach (the pair
+    // operand of an edge k sites back is k + 1 diagonals old): the lanes evaluate it in a third pass of their class 1 blocks
+    // (tools/gen_hot_asm.py, third_pass).  not_easy3 / three: prefix counts -- not_easy without those sites, and those sites.
+    std::vector<int> not_easy3, three;
+    std::vector<uint8_t> is_three;
     // first_simple (row strips): site 0 passes for a simple site (dp_pipe.hip, load_rec_chunk)
     void build(const pagan_graph *g, int n, bool first_simple = false) {
         span.assign(n, 0); span_ring.assign(n, 1); not_simple.assign(n + 1, 0); no_pred.assign(n + 1, 0); not_easy.assign(n + 1, 0);
+        not_easy3.assign(n + 1, 0); three.assign(n + 1, 0); is_three.assign(n, 0);
         for (int s = 0; s < n; ++s) {
             if (s == 0 && first_simple) continue;
             const int a = g->bwd_off[s], b = g->bwd_off[s + 1];
@@ -142,6 +149,10 @@ struct SiteFeat {
             for (int k = a; k < b; ++k) n_adj += g->bwd_src[k] == s - 1;
             const bool easy = s > 0 && (b - a == 1 || b - a == 2) && n_adj == 1;
             not_easy[s + 1] = not_easy[s] + (easy ? 0 : 1);
+            const bool th = s > 0 && b - a == 3 && n_adj == 1 && sp <= PG_PIPE_REACH - 2;
+            is_three[s] = th;
+            three[s + 1] = three[s] + (th ? 1 : 0);
+            not_easy3[s + 1] = not_easy3[s] + ((easy || th) ? 0 : 1);
         }
     }
 };
@@ -180,6 +191,7 @@ struct SiteFeat {
 // other edge of its own would need the pair of the two other edges as well: those single diagonals stay class 2 (marked by
 // the caller through `cross`).  What is not served is marked far as before (class 2).
 struct FarPlan {
+    std::vector<uint8_t> tbit;                 // per diagonal: a three-edge site the lanes take in a third pass has a cell on it (classify_diagonals)
     std::vector<uint8_t> hfL, hfR, hbit;
     std::vector<uint8_t> servedL, servedR;     // per site: its far edge reads a history line
     int n_served = 0, n_hard = 0;
@@ -301,9 +313,14 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
     if (far_plan && inwave) plan_far_hist(L, R, Lx, Ly, rb, dx, fl, fr, far_plan);
     else { fp.servedL.assign(Lx, 0); fp.servedR.assign(Ly, 0); fp.hbit.assign(nd, 0); }
     lap("far histories");
+    // three-edge sites in the lanes (hand-scheduled loop, with a plan that can carry the per-diagonal bit)
+    const bool three_ok = far_plan && inwave && !(std::getenv("PAGAN_DP_THREE") && std::strcmp(std::getenv("PAGAN_DP_THREE"), "0") == 0);
+    const std::vector<int> &ne_l = three_ok ? fl.not_easy3 : fl.not_easy, &ne_r = three_ok ? fr.not_easy3 : fr.not_easy;
+    if (far_plan) far_plan->tbit.assign(nd, 0);
     std::vector<int> far(nd + 1, 0), far2;
-    std::vector<int> multi_cols;                       // columns with span >= 2, ascending
+    std::vector<int> multi_cols, three_cols;           // columns with span >= 2 / three-edge columns, ascending
     for (int j = 0; j < Ly; ++j) if (fr.span[j] >= 2) multi_cols.push_back(j);
+    if (three_ok) for (int j = 0; j < Ly; ++j) if (fr.is_three[j]) three_cols.push_back(j);
     // far_any: a far site (served by a history line or not) has a cell on the diagonal -- a class 2 diagonal then is not one
     // "whose operands all lie in the ring" even if the lanes' own far blocks would have taken the site on a class 1 diagonal
     std::vector<int> far_any_r(nd + 1, 0), far_any_c(nd + 1, 0);
@@ -313,6 +330,8 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
         for (int i = 0; i < Lx; ++i) {
             if (rb.hi[i] < rb.lo[i]) continue;
             const int sl = fl.span[i];
+            if (three_ok && fl.is_three[i])         // a cell where two three-edge sites meet: the pairs of their second other edges are nobody's in the lanes
+                for (auto it = std::lower_bound(three_cols.begin(), three_cols.end(), rb.lo[i]); it != three_cols.end() && *it <= rb.hi[i]; ++it) mark(i + *it, i + *it);
             if (sl >= PG_PIPE_REACH - 1) {
                 mark_any(i + rb.lo[i], i + rb.hi[i]);
                 if (!fp.servedL[i]) { mark(i + rb.lo[i], i + rb.hi[i]); continue; }   // any column: span(j) >= 1
@@ -391,8 +410,9 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
             else if ((lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH) &&
                      (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)) c = 2;
             else if (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)
-                c = (inwave && (fl.not_easy[hi + 1] - fl.not_easy[lo] > 0 || fr.not_easy[d - lo + 1] - fr.not_easy[d - hi] > 0)) ? 2 : 1;
+                c = (inwave && (ne_l[hi + 1] - ne_l[lo] > 0 || ne_r[d - lo + 1] - ne_r[d - hi] > 0)) ? 2 : 1;
             else c = 0;
+            if (three_ok && c == 1 && (fl.three[hi + 1] - fl.three[lo] > 0 || fr.three[d - lo + 1] - fr.three[d - hi] > 0)) far_plan->tbit[d] = 1;
             if (c == 0 && fp.hbit[d]) c = 1;       // a history line's writer (or reader) has a cell here: the step looks at the sites' flags
             // a class 2 diagonal whose operands all lie in the ring (it is class 2 for the shape of a site only): the assist waves
             // take their ring-only code for it
@@ -1034,6 +1054,7 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe, i
             classify_diagonals(jb.left, jb.right, hj->Lx, hj->Ly, *rb, hj->dx, jb.model->n_states * jb.model->n_states <= 256,
                                &hj->cls, &hj->lead_req, &hj->ring2, threads, &fp);
             if (fp.n_served > 0) { hj->hfL.swap(fp.hfL); hj->hfR.swap(fp.hfR); hj->hbit.swap(fp.hbit); }
+            if (std::find(fp.tbit.begin(), fp.tbit.end(), (uint8_t)1) != fp.tbit.end()) hj->tbit.swap(fp.tbit);
             lap("classify_diagonals");
             schedule_waves(hj->dx, hj->cls, &hj->sched, threads);
             lap("schedule_waves");
@@ -1610,7 +1631,8 @@ int pagan_dp_debug_far(const pagan_graph *left, const pagan_graph *right, const 
     FarPlan fp;
     classify_diagonals(left, right, Lx, Ly, rb, dx, true, &cls, &lead_req, nullptr, 1, &fp);
     std::memcpy(hfL, fp.hfL.data(), fp.hfL.size()); std::memcpy(hfR, fp.hfR.data(), fp.hfR.size());
-    std::memcpy(hbit, fp.hbit.data(), fp.hbit.size()); std::memcpy(cls_out, cls.data(), cls.size());
+    for (size_t d = 0; d < fp.hbit.size(); ++d) hbit[d] = (uint8_t)(fp.hbit[d] | (fp.tbit.size() > d && fp.tbit[d] ? 2 : 0));     // bit 1: the third pass
+    std::memcpy(cls_out, cls.data(), cls.size());
     return fp.n_served;
 }
 
@@ -1974,7 +1996,10 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
                 const unsigned pair = big_table ? (t + 1 < hj.cls.size() && hj.cls[t + 1] <= 2 ? 1u : 0u) : (hj.ring2[t] ? 1u : 0u);
                 // bit 5 (bit 0 of the residency mask, which no age uses): a far history's writer or reader has a cell on the diagonal
                 const unsigned hb = (!hj.hbit.empty() && hj.hbit[t]) ? 1u : 0u;
-                packed[8 * t + 4] = (int)(hj.cls[t] | (pair << 4) | ((mask | hb) << 5) | ((unsigned)hop[t] << 20));
+                // bit 19 (above the mask's REACH - 1 ages): a three-edge site of the lanes' third pass has a cell on the diagonal
+                const unsigned tb = (!hj.tbit.empty() && hj.tbit[t]) ? 1u : 0u;
+                static_assert(PG_PIPE_REACH <= 14, "descriptor word 4: ages 1 .. REACH - 1 in bits 6 .. 18, bit 19 for the third pass");
+                packed[8 * t + 4] = (int)(hj.cls[t] | (pair << 4) | ((mask | hb) << 5) | (tb << 19) | ((unsigned)hop[t] << 20));
                 packed[8 * t + 5] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[8 * t + 6] = (int)(hj.dx.doff[t] >> 32);
                 packed[8 * t + 7] = hj.lead_req[t];
             }

@@ -76,6 +76,9 @@ static_assert(PNA == 3 && PST == 3 && PAGE >= PLAND + 4, "assist wave a stages t
 #define PR_NE_SHIFT 17           // 7 bits: number of bwd edges (host keeps sites with > 126 off this kernel)
 // bits 24-31 of a site record's word x (small model tables only; the loader sets them, the hand-scheduled loop reads them)
 #define PR_SRC 0x1000000         // the site is the START of an edge that reads a far history line: its lane appends its cell to line (x >> 25) & 3
+#define PR_THREE 0x20000000       // (with PR_TWO) THREE bwd edges, one from the previous site, all inside the ring's reach: the lanes evaluate the third
+                                 // one -- entry 2 of the site's list in the edge window, which the loader permutes to (previous-site edge, other, other) --
+                                 // in a third pass of their class 1 blocks on the diagonals the host flags (descriptor word 4, bit 19)
 #define PR_TWO 0x40000000        // two bwd edges, exactly one of them from the previous site -- NORMALISED: that edge in slot 0, the other one in
                                  // slot 1 whatever the list's order (the fill computes values only: tools/gen_hot_asm.py, c1_issue)
 #define PR_FAR 0x80000000u       // ... and the other edge reaches past the ring: its operands come from history line (x >> 27) & 3.  The loop tests
@@ -229,6 +232,24 @@ __device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_
         if (norm && ne == 2 && (d0 == 1) != (d1 == 1)) {
             if (d0 != 1) { const int td = d0; d0 = d1; d1 = td; const float tw = w0; w0 = w1; w1 = tw; }
             w |= PR_TWO;
+        }
+        if (norm && ne == 3) {
+            // three edges, exactly one from the previous site, none past the ring's reach (dp_abi.hip, SiteFeat::is_three -- the same
+            // test): the site's list, in the record AND in the edge window, becomes (previous-site edge, other, other); values do not
+            // depend on a list's order, and every reader of the window sees the same permuted list (this lane's LDS writes follow
+            // the chunk's in the wave's order)
+            int d2 = r - src[b + 2];
+            float w2 = lw[b + 2];
+            const int n_adj = (d0 == 1) + (d1 == 1) + (d2 == 1);
+            const int far_ = d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2);
+            if (n_adj == 1 && far_ <= PAGE - 2) {
+                if (d1 == 1) { const int td = d0; d0 = d1; d1 = td; const float tw = w0; w0 = w1; w1 = tw; }
+                else if (d2 == 1) { const int td = d0; d0 = d2; d2 = td; const float tw = w0; w0 = w2; w2 = tw; }
+                es[b & (PEC - 1)] = r - d0; ew[b & (PEC - 1)] = w0;
+                es[(b + 1) & (PEC - 1)] = r - d1; ew[(b + 1) & (PEC - 1)] = w1;
+                es[(b + 2) & (PEC - 1)] = r - d2; ew[(b + 2) & (PEC - 1)] = w2;
+                w |= PR_TWO | PR_THREE;
+            }
         }
         pg_i4 v;
         v.x = w; v.y = (d0 < 65535 ? d0 : 65535) | ((d1 < 65535 ? d1 : 65535) << 16);
@@ -1852,6 +1873,11 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
     const unsigned a_asd = (unsigned)(unsigned long long)(lds_char *)&PM.assist_done[0];
     // far histories (tools/gen_hot_asm.py, hist_tail): the flag bytes' windows, the lines, the loader's descriptor window
     const unsigned a_hist = (unsigned)(unsigned long long)(lds_char *)&PM.hist[0][0][0], a_dring = (unsigned)(unsigned long long)(lds_char *)&PM.dring[0];
+    // the third pass (tools/gen_hot_asm.py, third_pass): the sites' first edge, the edge windows
+    const unsigned a_ebL = (unsigned)(unsigned long long)(lds_char *)&PM.ebL[0], a_ebR = (unsigned)(unsigned long long)(lds_char *)&PM.ebR[0];
+    const unsigned a_esL = (unsigned)(unsigned long long)(lds_char *)&PM.esL[0], a_esR = (unsigned)(unsigned long long)(lds_char *)&PM.esR[0];
+    const unsigned a_ewL = (unsigned)(unsigned long long)(lds_char *)&PM.ewL[0], a_ewR = (unsigned)(unsigned long long)(lds_char *)&PM.ewR[0];
+    static_assert(PEC == 1024 && PRW == 512, "third_pass's address arithmetic");
     static_assert(sizeof(PM.hist[0]) == 0x600 && PDR == 128, "hist_tail's address arithmetic");
     const unsigned a_stx = (unsigned)(unsigned long long)(lds_char *)&PM.sx[0][tid], a_spx = (unsigned)(unsigned long long)(lds_char *)&PM.spx[0][tid];
     static_assert(offsetof(PipeSmem, sy) - offsetof(PipeSmem, sx) == 6144 && offsetof(PipeSmem, sM) - offsetof(PipeSmem, sx) == 12288 &&
@@ -1888,7 +1914,8 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
                   [stopm1] "s"(stop - 1), [S] "s"(S), [fdn] "v"(a_fdn), \
                   [bR] "s"(a_recR), [bL] "s"(a_recL), [bT] "s"(a_table), \
                   [sclo] "s"(sc_lo), [schi] "s"(sc_hi), [c24] "s"(0x3fffffffu), \
-                  [histb] "v"(a_hist), [drb] "v"(a_dring)
+                  [histb] "v"(a_hist), [drb] "v"(a_dring), \
+                  [ebl] "v"(a_ebL), [ebr] "v"(a_ebR), [esl] "v"(a_esL), [esr] "v"(a_esR), [ewl] "v"(a_ewL), [ewr] "v"(a_ewR)
             if constexpr (STRIP) {
                 // (the strip's loop picks the x-gap state's rate per lane and step: tools/gen_hot_asm.py, STRIP)
                 const double gE_ = term_on ? gE : ge;

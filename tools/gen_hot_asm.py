@@ -265,6 +265,132 @@ def c1_math(E, k, tag):
     a(".Lpg_noL%s:" % sfx)
 
 
+def third_pass(E, k):
+    """Sites with THREE bwd edges (dp_pipe.hip, PR_THREE: one from the previous site, two others inside the ring's reach; the
+    loader keeps them as (previous-site edge, other, other) in the record and in the edge window).  The class 1 blocks above took
+    the first other edge (the site looks like a two-edge site to them); on the diagonals the host flags (descriptor word 4, bit
+    19) this pass takes the second: its distance and weight from entry 2 of the site's list in the edge window (two dependent LDS
+    reads), then the blocks' operands and arithmetic once more -- X (Y) from the edge's cell, the pair with the other site's
+    previous-site edge, and the pair with the other site's own other edge where it has one.  A cell where two such sites meet is
+    on a class 2 diagonal (the host sees to it), so a lane is in at most one of the two halves."""
+    a = E.a
+    RL, CR = RLK[k], CRK[k]
+    tmx = TMX[k]
+    sfx = "%d_%%=" % k
+    a("v_and_b32_e32 v217, 0x20000000, v%d" % RL)
+    a("v_and_b32_e32 v218, 0x20000000, v%d" % CR)
+    a("v_cmp_ne_u32_e64 s[52:53], 0, v217")                    # t3L
+    a("v_cmp_ne_u32_e64 s[54:55], 0, v218")                    # t3R
+    a("v_sub_u32_e32 v222, %[d], %[row]")                      # the cell's column j
+    a("s_and_b64 s[52:53], s[52:53], s[60:61]")
+    a("s_and_b64 s[54:55], s[54:55], s[60:61]")
+    a("s_or_b64 s[56:57], s[52:53], s[54:55]")
+    a("s_cmp_eq_u64 s[56:57], 0")
+    a("s_cbranch_scc1 .Lpg_t3end%s" % sfx)
+    a("s_and_b64 s[84:85], s[52:53], s[76:77]")                # the left site's second other edge x the right site's other edge
+    a("s_and_b64 s[86:87], s[54:55], s[74:75]")                # ... and the other way round
+    # ---- the sites' first edge (edge numbering), then entry 2 of their lists: start site and weight ----
+    a("v_and_b32_e32 v217, 0x1ff, %[row]")
+    a("v_and_b32_e32 v218, 0x1ff, v222")
+    a("v_lshl_add_u32 v217, v217, 2, %[ebl]")
+    a("v_lshl_add_u32 v218, v218, 2, %[ebr]")
+    a("ds_read_b32 v174, v217")
+    a("ds_read_b32 v175, v218")
+    a("s_waitcnt lgkmcnt(0)")
+    a("v_add_u32_e32 v174, 2, v174")
+    a("v_add_u32_e32 v175, 2, v175")
+    a("v_and_b32_e32 v174, 0x3ff, v174")
+    a("v_and_b32_e32 v175, 0x3ff, v175")
+    a("v_lshl_add_u32 v217, v174, 2, %[esl]")
+    a("v_lshl_add_u32 v218, v175, 2, %[esr]")
+    a("v_lshl_add_u32 v219, v174, 2, %[ewl]")
+    a("v_lshl_add_u32 v220, v175, 2, %[ewr]")
+    a("ds_read_b32 v174, v217")                                # start site of the left site's third edge
+    a("ds_read_b32 v175, v218")
+    a("ds_read_b32 v172, v219")                                # its weight
+    a("ds_read_b32 v173, v220")
+    a("s_waitcnt lgkmcnt(0)")
+    # ---- the operands ----
+    a("s_cmp_eq_u64 s[54:55], 0")
+    a("s_cbranch_scc1 .Lpg_t3rdL%s" % sfx)
+    a("s_and_saveexec_b64 s[62:63], s[54:55]")
+    a("v_sub_u32_e32 v%d, v222, v175" % KR)                    # kR of the second other edge
+    a("v_cvt_f64_f32_e32 %s, v173" % pr(RWS))
+    a("v_mul_u32_u24_e32 v217, 0x1800, v%d" % KR)
+    E.ring_row(218, 217)
+    E.ring_row_before(219, 218)
+    a("v_add_u32_e32 v218, v218, %[tid24]")
+    a("v_add_u32_e32 v219, v219, %[bpos24]")
+    E.read_cell(U, 218)
+    E.read_cell(V, 219)
+    a("s_cmp_eq_u64 s[86:87], 0")
+    a("s_cbranch_scc1 .Lpg_t3rdRb%s" % sfx)
+    a("s_mov_b64 exec, s[86:87]")
+    a("v_add_u32_e32 v217, v%d, v%d" % (KL, KR))
+    a("v_mul_u32_u24_e32 v217, 0x1800, v217")
+    E.ring_row(220, 217)
+    a("v_add_u32_e32 v220, v220, v%d" % POSL)                  # (the left site's other edge: its ring column is the class 1 block's)
+    E.read_cell(W3, 220)
+    a(".Lpg_t3rdRb%s:" % sfx)
+    a("s_mov_b64 exec, s[62:63]")
+    a(".Lpg_t3rdL%s:" % sfx)
+    a("s_cmp_eq_u64 s[52:53], 0")
+    a("s_cbranch_scc1 .Lpg_t3rdX%s" % sfx)
+    a("s_and_saveexec_b64 s[62:63], s[52:53]")
+    a("v_sub_u32_e32 v%d, %%[row], v174" % KL)                 # kL of the second other edge
+    a("v_cvt_f64_f32_e32 %s, v172" % pr(LWS))
+    a("v_sub_u32_e32 v%d, %%[tid], v%d" % (POSL, KL))
+    a("v_mul_u32_u24_e32 v217, 0x1800, v%d" % KL)
+    a("v_and_b32_e32 v%d, 0xff, v%d" % (POSL, POSL))
+    E.ring_row(218, 217)
+    a("v_mad_u32_u24 v%d, v%d, 24, %%[ringb]" % (POSL, POSL))
+    E.ring_row_before(220, 218)
+    a("v_add_u32_e32 v218, v218, v%d" % POSL)
+    a("v_add_u32_e32 v220, v220, v%d" % POSL)
+    E.read_cell(W1, 218)
+    E.read_cell(W2, 220)
+    a("s_cmp_eq_u64 s[84:85], 0")
+    a("s_cbranch_scc1 .Lpg_t3rdLb%s" % sfx)
+    a("s_mov_b64 exec, s[84:85]")
+    a("v_add_u32_e32 v217, v%d, v%d" % (KL, KR))
+    a("v_mul_u32_u24_e32 v217, 0x1800, v217")
+    E.ring_row(220, 217)
+    a("v_add_u32_e32 v220, v220, v%d" % POSL)
+    E.read_cell(W3, 220)
+    a(".Lpg_t3rdLb%s:" % sfx)
+    a("s_mov_b64 exec, s[62:63]")
+    a(".Lpg_t3rdX%s:" % sfx)
+    a("s_waitcnt lgkmcnt(0)")
+    # ---- the arithmetic ----
+    a("s_cmp_eq_u64 s[54:55], 0")
+    a("s_cbranch_scc1 .Lpg_t3noR%s" % sfx)
+    a("s_and_saveexec_b64 s[62:63], s[54:55]")
+    E.gap_value(U, 1, 0, T[0], T[1], T[2])
+    E.pair_value(V, tmx, LWA, RWS, T[3], T[4])
+    a("v_max_f64 %s, %s, %s" % (pr(BY), pr(BY), pr(T[0])))
+    a("v_max_f64 %s, %s, %s" % (pr(BM), pr(BM), pr(T[3])))
+    a("s_mov_b64 exec, s[62:63]")
+    a(".Lpg_t3noR%s:" % sfx)
+    a("s_cmp_eq_u64 s[52:53], 0")
+    a("s_cbranch_scc1 .Lpg_t3noL%s" % sfx)
+    a("s_and_saveexec_b64 s[62:63], s[52:53]")
+    E.gap_value(W1, 0, 1, T[0], T[1], T[2])
+    E.pair_value(W2, tmx, LWS, RWA, T[3], T[4])
+    a("v_max_f64 %s, %s, %s" % (pr(BX), pr(BX), pr(T[0])))
+    a("v_max_f64 %s, %s, %s" % (pr(BM), pr(BM), pr(T[3])))
+    a("s_mov_b64 exec, s[62:63]")
+    a(".Lpg_t3noL%s:" % sfx)
+    # the pairs of a second other edge with the other site's own other edge (either way round: a lane is in one of the two masks)
+    a("s_or_b64 s[84:85], s[84:85], s[86:87]")
+    a("s_cmp_eq_u64 s[84:85], 0")
+    a("s_cbranch_scc1 .Lpg_t3end%s" % sfx)
+    a("s_and_saveexec_b64 s[62:63], s[84:85]")
+    E.pair_value(W3, tmx, LWS, RWS, T[5], T[6])
+    a("v_max_f64 %s, %s, %s" % (pr(BM), pr(BM), pr(T[5])))
+    a("s_mov_b64 exec, s[62:63]")
+    a(".Lpg_t3end%s:" % sfx)
+
+
 def hist_tail(E, k, cls2):
     """Far histories (dp_abi.hip, plan_far_hist; PipeSmem::hist): the part of a step on a diagonal whose descriptor says that a
     history line's reader or writer has a cell on it (word 4, bit 5).  Behind the class 1 / class 2 part, BX / BY / BM final but
@@ -668,8 +794,8 @@ def step(E, k):
     c1_issue(E, k, "f")                                        # (a wave without a multi-edge cell finds its masks empty: the decode and the records after next is all it does)
     shift_and_x(have_active=True)
     c1_math(E, k, "f")
-    a("s_bitcmp1_b32 s%d, 5" % s4)                             # a far history's reader or writer has a cell on this diagonal
-    a("s_cbranch_scc1 .Lpg_hist%s" % sfx)
+    a("s_and_b32 s72, s%d, 0x80020" % s4)                      # a three-edge site (bit 19) or a far history's reader / writer (bit 5) has a cell on this diagonal
+    a("s_cbranch_scc1 .Lpg_extra%s" % sfx)
     if "E" not in EXP:
         next_desc()
     a("s_branch .Lpg_commit%s" % sfx)
@@ -701,12 +827,19 @@ def step(E, k):
     c1_issue(E, k, "s")
     c1_math(E, k, "s")
     a(".Lpg_c1done%s:" % sfx)
-    a("s_bitcmp1_b32 s%d, 5" % s4)
-    a("s_cbranch_scc1 .Lpg_hist%s" % sfx)
+    a("s_and_b32 s72, s%d, 0x80020" % s4)
+    a("s_cbranch_scc1 .Lpg_extra%s" % sfx)
     next_desc()
     a("s_branch .Lpg_commit%s" % sfx)
+    a(".Lpg_extra%s:" % sfx)
+    a("s_bitcmp1_b32 s%d, 19" % s4)
+    a("s_cbranch_scc0 .Lpg_hist%s" % sfx)
+    third_pass(E, k)
+    a("s_bitcmp1_b32 s%d, 5" % s4)
+    a("s_cbranch_scc0 .Lpg_nohist%s" % sfx)
     a(".Lpg_hist%s:" % sfx)
     hist_tail(E, k, cls2=False)
+    a(".Lpg_nohist%s:" % sfx)
     next_desc()
     a("s_branch .Lpg_commit%s" % sfx)
     a(".Lpg_c2%s:" % sfx)
