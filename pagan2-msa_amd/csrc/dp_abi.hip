@@ -532,6 +532,11 @@ bool plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
     for (int j = 0; j < Ly; ++j) for (int t = 2; t < REACH && t <= fr.span[j]; ++t) cols_ge[t].push_back(j);
     const int n_strips = (Lx + PG_STRIP_ROWS - 1) / PG_STRIP_ROWS;
     const bool term_cxx = std::getenv("PAGAN_DP_STRIP_TERM") != nullptr;
+    // three-edge sites in the lanes (round 5; classify_diagonals has the rules): small model tables only -- the hand-scheduled loop
+    const bool three_ok = !big_table && !(std::getenv("PAGAN_DP_THREE") && std::strcmp(std::getenv("PAGAN_DP_THREE"), "0") == 0);
+    const std::vector<int> &ne_l = three_ok ? fl.not_easy3 : fl.not_easy, &ne_r = three_ok ? fr.not_easy3 : fr.not_easy;
+    std::vector<int> three_cols;
+    if (three_ok) for (int j = 0; j < Ly; ++j) if (fr.is_three[j]) three_cols.push_back(j);
     {   // the multi-edge sites a diagonal of a strip holds: the strip's own rows (they stay) + the columns of its window (up to
         // PG_STRIP_ROWS consecutive ones inside the strip's column range)
         int worst = 0;
@@ -581,6 +586,8 @@ bool plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
         for (int i = r0; i <= r1; ++i) {
             if (rb.hi[i] < rb.lo[i]) continue;
             const int sl = fl.span[i];
+            if (three_ok && fl.is_three[i])         // (classify_diagonals: a cell where two three-edge sites meet stays with the assist waves)
+                for (auto it = std::lower_bound(three_cols.begin(), three_cols.end(), rb.lo[i]); it != three_cols.end() && *it <= rb.hi[i]; ++it) mark(i + *it, i + *it);
             if (sl >= REACH - 1) { mark(i + rb.lo[i], i + rb.hi[i]); continue; }
             if (sl < 2) continue;
             const std::vector<int> &cl = cols_ge[REACH - sl];             // span(j) >= REACH - span(i)
@@ -594,7 +601,7 @@ bool plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
             if (i1 <= i2) mark(i1 + j, i2 + j);
         }
         // ---- classes ----
-        std::vector<uint8_t> cls(m, 0), ring2(m, 0);
+        std::vector<uint8_t> cls(m, 0), ring2(m, 0), tbit(m, 0);
         int run = 0;
         for (int t = 0; t < m; ++t) {
             run += far[t];
@@ -606,13 +613,14 @@ bool plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
             if (lo == 0 && d < Ly && from0R[d]) general = true;                            // cell (0, d)
             if (npL[hi + 1] - npL[lo] > 0 || npR[jhi + 1] - npR[jlo] > 0) general = true;  // a site without bwd edges (not site 0)
             const bool multi = fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[jhi + 1] - fr.not_simple[jlo] > 0;
-            const bool hard = fl.not_easy[hi + 1] - fl.not_easy[lo] > 0 || fr.not_easy[jhi + 1] - fr.not_easy[jlo] > 0;
+            const bool hard = ne_l[hi + 1] - ne_l[lo] > 0 || ne_r[jhi + 1] - ne_r[jlo] > 0;
             uint8_t c;
             if (general) c = 3;
             else if (run > 0) c = 2;
             else if (multi) c = (hard && !big_table) ? 2 : 1;
             else c = 0;
             ring2[t] = c == 2 && run == 0;
+            tbit[t] = three_ok && c == 1 && (fl.three[hi + 1] - fl.three[lo] > 0 || fr.three[jhi + 1] - fr.three[jlo] > 0);
             const bool term = (d >= lo && d <= hi) || (d - (Ly - 1) >= lo && d - (Ly - 1) <= hi);      // a cell of column 0 / column Ly-1
             // (the strip's assembly loop picks the x-gap rate per lane: such a diagonal needs no path of its own; PAGAN_DP_STRIP_TERM=1
             //  sends it to the C++ step all the same -- A/B switch)
@@ -674,7 +682,7 @@ bool plan_strips(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, con
             mask = t >= 1 ? (((mask << 1) | 2u) & (((1u << REACH) - 1u) & ~1u)) : 0u;
             // bit 4: large tables -- the next step is hot too; small tables -- a class 2 diagonal with every operand in the ring
             const unsigned pair = big_table ? (t + 1 < m && (cls[t + 1] & 7) <= 2 ? 1u : 0u) : (ring2[t] ? 1u : 0u);
-            pk[4] = (int)(cls[t] | (pair << 4) | (mask << 5) | ((unsigned)hop[t] << 20));
+            pk[4] = (int)(cls[t] | (pair << 4) | (mask << 5) | ((unsigned)tbit[t] << 19) | ((unsigned)hop[t] << 20));     // (bit 19: the lanes' third pass, as in a banded job's descriptors)
             pk[5] = 0; pk[6] = 0;
             pk[7] = lead[t];
         }
