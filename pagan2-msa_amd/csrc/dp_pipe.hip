@@ -87,6 +87,12 @@ static_assert(PNA == 3 && PST == 3 && PAGE >= PLAND + 4, "assist wave a stages t
 
 struct PipeSmem {
     double sc[PRK][PNT][3];      // X, Y, M
+    // what the assist waves hand over, per staging slot (d % PST) and lane of the compute waves (row % 256):
+    // best candidate of X / Y over the bwd edges that do NOT come from the previous site, M over all edge pairs.
+    // (Directly behind the ring: a wide run uses ring + staging arrays as ONE wide ring -- the assist waves stage nothing while
+    //  the compute waves are inside a wide run: every diagonal they could stage lies behind it and its general steps.)
+    double sx[PST][PNT], sy[PST][PNT], sM[PST][PNT];
+    unsigned spx[PST][PNT], spy[PST][PNT], spm[PST][PNT];
     pg_i4 recL[PRW], recR[PRW];  // x: state | PR_SIMPLE | n_edges << 17 | PR_TWO, y: dist0 | dist1 << 16, z/w: log-weights 0/1
     pg_i4 dring[PDR];            // lo, hi, score byte offset (64 bit) of diagonal d at [d % PDR]
     int ebL[PRW], ebR[PRW];      // first bwd edge of the site (edge numbering of the graph)
@@ -106,10 +112,6 @@ struct PipeSmem {
     int arrived[PNW];            // last rendezvous diagonal each compute wave drained for
     int loaded[3];               // rows / columns / diagonal descriptors staged by the loader
     int abort_flag;
-    // what the assist waves hand over, per staging slot (d % PST) and lane of the compute waves (row % 256):
-    // best candidate of X / Y over the bwd edges that do NOT come from the previous site, M over all edge pairs
-    double sx[PST][PNT], sy[PST][PNT], sM[PST][PNT];
-    unsigned spx[PST][PNT], spy[PST][PNT], spm[PST][PNT];
     int assist_done[PNA];        // last diagonal each assist wave has staged
     int as_list[PNA][64];        // rows of the multi-edge cells of the diagonal an assist wave is working on, compacted
     const int *pdsc;             // row strips: the parent job's dsc array (null otherwise): far_ask's view of the whole band
@@ -697,13 +699,20 @@ __device__ __forceinline__ void ring_cell(int off, double &x, double &y, double 
     const double *c = (const double *)((const char *)&PM.sc[0][0][0] + off);
     x = c[PG_X]; y = c[PG_Y]; m = c[PG_M];
 }
-// wide diagonals (class 4, model table in LDS) reuse the ring's memory as PWK rows of PWPOS positions (row % 512): a lane
+// wide diagonals (class 4, model table in LDS) reuse the ring's memory as PWK rows of PWPOS positions: a lane
 // holds up to two rows of such a diagonal; a cell reads at most PWAGE diagonals back in it, older operands come from L2
-#define PWK 7
-#define PWPOS 512
-#define PWAGE 5
+// (round 5: 12 rows of 384 positions over the ring AND the assist waves' staging arrays behind it -- before, 7 rows of 512 in the
+//  ring alone: a cell read five diagonals back at most, and nearly every wide step had an operand 6 .. 12 back that cost a trip to
+//  L2.  A wide diagonal has at most PG_PIPE_WINDOW = 352 cells, and what a step reads of an earlier diagonal lies at most
+//  2 * PWAGE rows above this diagonal's first row: 384 positions tell those rows apart.  Rows 384 and more past the first row --
+//  a lane's second row can be -- are not written: they would land on the positions of rows in the band.)
+#define PWK 12
+#define PWPOS 384
+#define PWAGE 10
 #define PWROW_BYTES (PWPOS * 24)
-static_assert(PWK * PWROW_BYTES <= PRK * PNT * 24 && PWAGE + 2 <= PWK && PG_PIPE_WINDOW < PWPOS - 64, "wide ring inside the ring");
+static_assert(offsetof(PipeSmem, sx) == sizeof(double) * PRK * PNT * 3 && offsetof(PipeSmem, recL) - offsetof(PipeSmem, sx) == (size_t)PST * PNT * (3 * 8 + 3 * 4),
+              "the staging arrays directly behind the ring");
+static_assert(PWK * PWROW_BYTES <= PRK * PNT * 24 + PST * PNT * 36 && PWAGE + 2 <= PWK && PG_PIPE_WINDOW + 2 * PWAGE + 8 <= PWPOS, "wide ring inside ring + staging arrays");
 #define PRING_BYTES (PRK * PNT * 24)
 #define PROW_BYTES (PNT * 24)
 // byte offset (inside the ring) of the ring row `age` diagonals before the row at `sb`
@@ -2267,10 +2276,14 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             Ux[q] = xy[3 * q + 2].x; Uy[q] = xy[3 * q + 2].y; Um[q] = m[3 * q + 2];
         }
     }
+    // position of a row in a wide-ring row: (row - wbase) % 384, wbase a multiple-of-384 step behind the band's first row
+    int wbase = cur.x - 32;
+    auto wpos = [&](int r_) { int q_ = r_ - wbase; q_ -= q_ >= PWPOS ? PWPOS : 0; q_ -= q_ >= PWPOS ? PWPOS : 0; return q_; };
     int n_hist1 = 0, n_hist2 = 0;                                  // stores issued in the previous step / the one before
     int lo_prev = cur.x;                                           // first row of the previous diagonal's band (the sets' rows are relative to it)
     for (;;) {
         const int lo = cur.x, hi = cur.y;
+        if (lo - 2 * PWAGE - 4 - wbase >= PWPOS) wbase += PWPOS;      // (every row a step touches lies in [wbase, wbase + 3 * 384))
 #ifdef PG_PIPE_STATS
         const long long st_step0 = __builtin_readcyclecounter();
 #endif
@@ -2310,13 +2323,15 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             double ax[2], ay[2], am[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const double *c = (const double *)((const char *)&PM.sc[0][0][0] + rb1 + ((wrow[q] - 1) & (PWPOS - 1)) * 24);
+                const double *c = (const double *)((const char *)&PM.sc[0][0][0] + rb1 + wpos(wrow[q] - 1) * 24);
                 ax[q] = dpp_shr1(Px[q], c[PG_X]); ay[q] = dpp_shr1(Py[q], c[PG_Y]); am[q] = dpp_shr1(Pm[q], c[PG_M]);
             }
             // lane T-1's set A holds rowA(T) - 1, its set B rowB(T) - 1 -- unless rowA(T) was the band's first row: then lane T-1's
             // set A holds rowB(T) - 1 (lane 0 read by position: nothing to sort out)
-            const bool first = wrow[0] == lo_prev && lane != 0;
-            Ux[0] = first ? NIw : ax[0]; Uy[0] = first ? NIw : ay[0]; Um[0] = first ? NIw : am[0];
+            // (the band's first row has no row above it in the band -- for lane 0 as well: the position it read is, with 384
+            //  positions to a row, the alias of a row 384 further on, which ANOTHER wave writes, not the upstream one it waited for)
+            const bool top = wrow[0] == lo_prev, first = top && lane != 0;
+            Ux[0] = top ? NIw : ax[0]; Uy[0] = top ? NIw : ay[0]; Um[0] = top ? NIw : am[0];
             Ux[1] = first ? ax[0] : ax[1]; Uy[1] = first ? ay[0] : ay[1]; Um[1] = first ? am[0] : am[1];
             // ---- row hand-over: set B becomes set A, the new set B (512 rows on: far below the band) starts from -inf ----
             if (wrow[0] < lo) {
@@ -2335,7 +2350,7 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             if (age <= amax) {
                 int rb = wsb - age * PWROW_BYTES;
                 rb += rb < 0 ? PWK * PWROW_BYTES : 0;
-                const double *c = (const double *)((const char *)&PM.sc[0][0][0] + rb + (p_ & (PWPOS - 1)) * 24);
+                const double *c = (const double *)((const char *)&PM.sc[0][0][0] + rb + wpos(p_) * 24);
                 xy.x = c[PG_X]; xy.y = c[PG_Y]; m = c[PG_M];
                 return f;
             }
@@ -2383,7 +2398,7 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             auto rd = [&](bool need, int age, int p_, pg_d2 &xy, double &m) {
                 int rb = wsb - age * PWROW_BYTES;
                 rb += rb < 0 ? PWK * PWROW_BYTES : 0;
-                const int off = need ? rb + (p_ & (PWPOS - 1)) * 24 : (int)offsetof(PipeSmem, null_cell) - (int)offsetof(PipeSmem, sc);
+                const int off = need ? rb + wpos(p_) * 24 : (int)offsetof(PipeSmem, null_cell) - (int)offsetof(PipeSmem, sc);
                 const double *c = (const double *)((const char *)&PM.sc[0][0][0] + off);
                 xy.x = c[PG_X]; xy.y = c[PG_Y]; m = c[PG_M];
             };
@@ -2468,8 +2483,8 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
                          [&](int k, int &q_, double &rw) { int dist; edge_at<false>(gr_, k, j, dist, rw); q_ = j - dist; },
                          bx, by, bm, px, py, pm);
             }
-            {
-                double *o = (double *)((char *)&PM.sc[0][0][0] + wsb + (r & (PWPOS - 1)) * 24);
+            if (r < lo + PWPOS) {                                   // (a second row 384 and more past the band's first: never in the band, and its position is another row's)
+                double *o = (double *)((char *)&PM.sc[0][0][0] + wsb + wpos(r) * 24);
                 o[PG_X] = bx; o[PG_Y] = by; o[PG_M] = bm;
             }
             if (active) {
