@@ -1994,6 +1994,17 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
                 const bool work = hj.cls[nx] == 2 || (big_table && hj.cls[nx] <= 1);     // small tables: class 1 is the compute waves' own
                 hop[t] = work ? 1 : std::min(4095, hop[nx] + 1);
             }
+            // wide runs (consecutive class 4 diagonals): does any diagonal of the run exceed PG_PIPE_WINDOW_A cells?  (bit 4 of a class
+            // 4 diagonal's word: wide_run takes the wide-ring geometry with more positions and fewer rows then)
+            std::vector<uint8_t> wide_b(ndg, 0);
+            for (size_t t = 0; t < ndg;) {
+                if (hj.cls[t] != 4) { ++t; continue; }
+                size_t e = t;
+                int widest = 0;
+                while (e < ndg && hj.cls[e] == 4) { widest = std::max(widest, hj.dx.imax[e] - hj.dx.imin[e] + 1); ++e; }
+                if (widest > PG_PIPE_WINDOW_A) for (size_t q = t; q < e; ++q) wide_b[q] = 1;
+                t = e;
+            }
             for (size_t t = 0; t < hj.dx.imin.size(); ++t) {
                 packed[8 * t] = hj.dx.imin[t]; packed[8 * t + 1] = hj.dx.imax[t];
                 const long long boff = 24 * hj.dx.doff[t];
@@ -2001,7 +2012,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
                 // (a wide diagonal reuses the ring's memory: nothing older than it is resident afterwards)
                 mask = (t >= 1 && hj.cls[t - 1] <= 3) ? (((mask << 1) | 2u) & (((1u << PG_PIPE_REACH) - 1u) & ~1u)) : 0u;
                 // bit 4: large tables -- the next step is hot too; small tables -- a class 2 diagonal with every operand in the ring
-                const unsigned pair = big_table ? (t + 1 < hj.cls.size() && hj.cls[t + 1] <= 2 ? 1u : 0u) : (hj.ring2[t] ? 1u : 0u);
+                const unsigned pair = big_table ? (t + 1 < hj.cls.size() && hj.cls[t + 1] <= 2 ? 1u : 0u) : ((hj.ring2[t] || wide_b[t]) ? 1u : 0u);
                 // bit 5 (bit 0 of the residency mask, which no age uses): a far history's writer or reader has a cell on the diagonal
                 const unsigned hb = (!hj.hbit.empty() && hj.hbit[t]) ? 1u : 0u;
                 // bit 19 (above the mask's REACH - 1 ages): a three-edge site of the lanes' third pass has a cell on the diagonal

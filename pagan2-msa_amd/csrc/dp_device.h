@@ -57,7 +57,11 @@
 #define PG_PIPE_ASSIST 3         // assist waves: wave a takes the multi-edge cells of the diagonals d with d % 3 == a
 #define PG_PIPE_STAGE 3          // staging slots (d % 3, one per assist wave): a diagonal is staged at most two ahead of the compute waves
 #define PG_PIPE_WAKE 6           // ... and wakes this many diagonals before its first one (operand prefetch pipeline)
-#define PG_PIPE_WINDOW 352       // widest diagonal the kernel's site-record windows (512 sites) still cover
+#define PG_PIPE_WINDOW 432       // widest diagonal the kernel's site-record windows (512 sites) still cover: the loader keeps the records from 8
+                                 // sites before the slowest wave's first row (column) and stages at most 440 sites past it (round 5: 352 before,
+                                 // when it also staged a fixed 64 diagonals ahead whatever the width; cfg4's third level alone has ~2,000
+                                 // diagonals of 353 .. 922 cells, each 28 k cycles as a class 5 step against ~6 k as a wide step)
+#define PG_PIPE_WINDOW_A 352     // ... a wide run whose diagonals all stay at or below this uses the deeper of the two wide-ring geometries
 #define PG_PIPE_EDGE_CAP 1024    // bwd edges of any PG_RING_SITE_SPAN consecutive sites must fit the LDS edge window
 #define PG_PIPE_SITE_EDGES 126   // bwd edges per site (7-bit count in the site record)
 

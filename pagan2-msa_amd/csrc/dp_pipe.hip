@@ -59,7 +59,7 @@
 #define PNA PG_PIPE_ASSIST       // assist waves
 #define PST PG_PIPE_STAGE        // staging slots
 #define PBLOCK (PNT + 64 * PNA + 64)     // compute waves, assist waves, loader wave
-static_assert(PNTW == PNT - PAGE && PRK >= PAGE && PG_PIPE_WINDOW + 160 <= PRW, "kernel geometry out of step with dp_device.h");
+static_assert(PNTW == PNT - PAGE && PRK >= PAGE && PG_PIPE_WINDOW + 80 <= PRW, "kernel geometry out of step with dp_device.h");
 static_assert(PNA == 3 && PST == 3 && PAGE >= PLAND + 4, "assist wave a stages the diagonals d % 3 == a into slot a, at most two diagonals ahead; far cells have landed");
 #define PFAR_POOL ((PNT * 4) / 24)  // cells of 24 bytes in one staging slot of spm
 // staged back-pointer words: the regular bits of a back-pointer plus what the compute wave needs to merge
@@ -308,9 +308,20 @@ __device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lan
         const pg_i8 ds = psc[da], dc = psc[dcur];
         int want_rows = ds.y + 5, want_cols = da - ds.x + 4;       // rows <= hi+4, columns <= jmax+3 of diagonal da
         if (dc.y >= dc.x) {
+            // as far ahead as the windows allow -- and no further: a record may only replace the one PRW sites before it, and those
+            // of the slowest wave's diagonal (from PREC_BACK - 64 sites before its first row / column on) are still read.  (Round 5:
+            // the look-ahead of PLOOK diagonals used to win over this bound; with diagonals of up to PG_PIPE_WINDOW cells it must not.)
             const int far_rows = dc.x + PRW - PREC_BACK, far_cols = dcur - dc.y + PRW - PREC_BACK;
-            want_rows = want_rows > far_rows ? want_rows : far_rows;
-            want_cols = want_cols > far_cols ? want_cols : far_cols;
+            want_rows = far_rows;
+            want_cols = far_cols;
+            if (dc.y - dc.x + 1 > PG_PIPE_WINDOW) {
+                // a diagonal wider than the windows (class 5) takes its records from L2, but its waves still wait for "rows <= hi + 3
+                // loaded": just those, so that the first diagonal the windows cover again finds the records before its first row
+                const pg_i8 dn = psc[dcur + 1 < J.nd ? dcur + 1 : dcur];
+                const int near_rows = dn.y + 5, near_cols = dcur + 1 - dn.x + 4;
+                want_rows = want_rows > near_rows ? want_rows : near_rows;
+                want_cols = want_cols > near_cols ? want_cols : near_cols;
+            }
         }
         want_rows = want_rows < J.Lx ? want_rows : J.Lx;
         want_cols = want_cols < J.Ly ? want_cols : J.Ly;
@@ -706,13 +717,19 @@ __device__ __forceinline__ void ring_cell(int off, double &x, double &y, double 
 //  L2.  A wide diagonal has at most PG_PIPE_WINDOW = 352 cells, and what a step reads of an earlier diagonal lies at most
 //  2 * PWAGE rows above this diagonal's first row: 384 positions tell those rows apart.  Rows 384 and more past the first row --
 //  a lane's second row can be -- are not written: they would land on the positions of rows in the band.)
+//  Runs with a diagonal of more than PG_PIPE_WINDOW_A = 352 cells -- up to PG_PIPE_WINDOW = 432 -- take 9 rows of 512 positions.)
+#define PWK_A 12
+#define PWPOS_A 384
+#define PWK_B 9
+#define PWPOS_B 512
+static_assert(PWK_B * PWPOS_B * 24 <= PRK * PNT * 24 + PST * PNT * 36 && PG_PIPE_WINDOW + 2 * (PWK_B - 2) + 8 <= PWPOS_B, "the wider wide ring");
 #define PWK 12
 #define PWPOS 384
 #define PWAGE 10
 #define PWROW_BYTES (PWPOS * 24)
 static_assert(offsetof(PipeSmem, sx) == sizeof(double) * PRK * PNT * 3 && offsetof(PipeSmem, recL) - offsetof(PipeSmem, sx) == (size_t)PST * PNT * (3 * 8 + 3 * 4),
               "the staging arrays directly behind the ring");
-static_assert(PWK * PWROW_BYTES <= PRK * PNT * 24 + PST * PNT * 36 && PWAGE + 2 <= PWK && PG_PIPE_WINDOW + 2 * PWAGE + 8 <= PWPOS, "wide ring inside ring + staging arrays");
+static_assert(PWK * PWROW_BYTES <= PRK * PNT * 24 + PST * PNT * 36 && PWAGE + 2 <= PWK && PG_PIPE_WINDOW_A + 2 * PWAGE + 8 <= PWPOS, "wide ring inside ring + staging arrays");
 #define PRING_BYTES (PRK * PNT * 24)
 #define PROW_BYTES (PNT * 24)
 // byte offset (inside the ring) of the ring row `age` diagonals before the row at `sb`
@@ -2276,14 +2293,17 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             Ux[q] = xy[3 * q + 2].x; Uy[q] = xy[3 * q + 2].y; Um[q] = m[3 * q + 2];
         }
     }
-    // position of a row in a wide-ring row: (row - wbase) % 384, wbase a multiple-of-384 step behind the band's first row
+    // the run's wide-ring geometry (descriptor word 4, bit 4 of a class 4 diagonal: some diagonal of the run exceeds PG_PIPE_WINDOW_A cells)
+    const bool geo_b = (dA.s4 & 16) != 0;
+    const int wpos_n = geo_b ? PWPOS_B : PWPOS_A, wk = geo_b ? PWK_B : PWK_A, wage = wk - 2, wrow_bytes = wpos_n * 24;
+    // position of a row in a wide-ring row: (row - wbase) % positions, wbase a multiple-of-positions step behind the band's first row
     int wbase = cur.x - 32;
-    auto wpos = [&](int r_) { int q_ = r_ - wbase; q_ -= q_ >= PWPOS ? PWPOS : 0; q_ -= q_ >= PWPOS ? PWPOS : 0; return q_; };
+    auto wpos = [&](int r_) { int q_ = r_ - wbase; q_ -= q_ >= wpos_n ? wpos_n : 0; q_ -= q_ >= wpos_n ? wpos_n : 0; return q_; };
     int n_hist1 = 0, n_hist2 = 0;                                  // stores issued in the previous step / the one before
     int lo_prev = cur.x;                                           // first row of the previous diagonal's band (the sets' rows are relative to it)
     for (;;) {
         const int lo = cur.x, hi = cur.y;
-        if (lo - 2 * PWAGE - 4 - wbase >= PWPOS) wbase += PWPOS;      // (every row a step touches lies in [wbase, wbase + 3 * 384))
+        if (lo - 2 * wage - 4 - wbase >= wpos_n) wbase += wpos_n;      // (every row a step touches lies in [wbase, wbase + 3 * 384))
 #ifdef PG_PIPE_STATS
         const long long st_step0 = __builtin_readcyclecounter();
 #endif
@@ -2302,8 +2322,8 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
         // the next diagonal's descriptor: staged by the loader (the window runs PLOOK diagonals ahead of the slowest wave)
         if (diags_ld < d + 2 && d + 1 < nd) diags_ld = POLLX(&PM.loaded[2], d + 2, 5);
         const pg_i4 nxt = PM.dring[(d + 1) & (PDR - 1)];
-        const int amax = d - d0 < PWAGE ? d - d0 : PWAGE;               // ages 1 .. amax are in the wide ring
-        const int wsb = (d % PWK) * PWROW_BYTES;
+        const int amax = d - d0 < wage ? d - d0 : wage;               // ages 1 .. amax are in the wide ring
+        const int wsb = (d % wk) * wrow_bytes;
         const long long soff = ((long long)cur.w << 32) | (unsigned)cur.z;
         PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff;
 #ifdef PG_EXP_WIDE_SKIP                                             // timing experiment (WRONG RESULTS): a wide step is its flags and nothing else
@@ -2318,8 +2338,8 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
 #endif
         if (d > d0) {
             // ---- (row-1, j) on d-1: lane T-1's registers, lane 0 from the wide ring (the upstream wave completed d-1) ----
-            int rb1 = wsb - PWROW_BYTES;
-            rb1 += rb1 < 0 ? PWK * PWROW_BYTES : 0;
+            int rb1 = wsb - wrow_bytes;
+            rb1 += rb1 < 0 ? wk * wrow_bytes : 0;
             double ax[2], ay[2], am[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -2348,8 +2368,8 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             xy.x = NIw; xy.y = NIw; m = NIw;
             if (!need) return f;
             if (age <= amax) {
-                int rb = wsb - age * PWROW_BYTES;
-                rb += rb < 0 ? PWK * PWROW_BYTES : 0;
+                int rb = wsb - age * wrow_bytes;
+                rb += rb < 0 ? wk * wrow_bytes : 0;
                 const double *c = (const double *)((const char *)&PM.sc[0][0][0] + rb + wpos(p_) * 24);
                 xy.x = c[PG_X]; xy.y = c[PG_Y]; m = c[PG_M];
                 return f;
@@ -2396,8 +2416,8 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             const bool b1 = kind[q] == 1, l2 = l2q[q], r2 = r2q[q];
             if (!__any(b1 && (l2 || r2))) continue;
             auto rd = [&](bool need, int age, int p_, pg_d2 &xy, double &m) {
-                int rb = wsb - age * PWROW_BYTES;
-                rb += rb < 0 ? PWK * PWROW_BYTES : 0;
+                int rb = wsb - age * wrow_bytes;
+                rb += rb < 0 ? wk * wrow_bytes : 0;
                 const int off = need ? rb + wpos(p_) * 24 : (int)offsetof(PipeSmem, null_cell) - (int)offsetof(PipeSmem, sc);
                 const double *c = (const double *)((const char *)&PM.sc[0][0][0] + off);
                 xy.x = c[PG_X]; xy.y = c[PG_Y]; m = c[PG_M];
@@ -2483,7 +2503,7 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
                          [&](int k, int &q_, double &rw) { int dist; edge_at<false>(gr_, k, j, dist, rw); q_ = j - dist; },
                          bx, by, bm, px, py, pm);
             }
-            if (r < lo + PWPOS) {                                   // (a second row 384 and more past the band's first: never in the band, and its position is another row's)
+            if (r < lo + wpos_n) {                                   // (a second row 384 and more past the band's first: never in the band, and its position is another row's)
                 double *o = (double *)((char *)&PM.sc[0][0][0] + wsb + wpos(r) * 24);
                 o[PG_X] = bx; o[PG_Y] = by; o[PG_M] = bm;
             }
@@ -3071,7 +3091,9 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
                 PSTAMP(4);
             } else if (cls <= 3) {
                 const unsigned resmask = ((unsigned)cur.s4 >> 5) & 0x7fffu;
+#ifndef PG_EXP_GENERAL_SKIP                                         // (timing experiment, WRONG RESULTS: a general step computes nothing)
                 if (active) gen_cell(d, slot, resmask, row, j, bx, by, bm, px, py, pm);
+#endif
                 commit_cell(sc_out, bp_out, cur, slot, tid, row - lo, active, bx, by, bm, px, py, pm);
             } else if (cls == 4) {
                 // ---- wider than the lanes, but inside the record windows: every lane takes its rows row, row+256,
@@ -3146,7 +3168,9 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
                 hi_prev = -2;
             } else {
                 // ---- wider than the record windows: every cell from HBM/L2 operands, graph arrays included ----
+#ifndef PG_EXP_WIDEST_SKIP                                          // (timing experiment, WRONG RESULTS: a class 5 step is its rendezvous and nothing else)
                 widest_step(job, psc, d, lo, hi, tid, no_terminal_edges, reduced_terminal);
+#endif
                 have = false;                                      // the record window may have lapped this lane's row
                 hi_prev = -2;
             }

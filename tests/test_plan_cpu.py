@@ -154,14 +154,15 @@ def test_plan_banded_with_long_edges(seed):
     upper[0] = 0
     lower[-1] = Ly - 1
     # one box wider than the lanes in both directions, to get class 4 and the class-3 steps after it
-    rows, jump = (260, 300) if seed != 1 else (390, 420)          # seed 1: wider than the record windows too (class 5)
-    upper[300:300 + rows] = upper[300]
-    lower[300:300 + rows] = np.minimum(lower[299 + rows] + jump, Ly - 1)
+    # seed 1: wider than 352 cells (the wide ring of 9 rows x 512 positions); seed 3: wider than the record windows too (class 5)
+    at, rows, jump = {1: (300, 390, 420), 3: (200, 480, 60)}.get(seed, (300, 260, 300))
+    upper[at:at + rows] = upper[at]
+    lower[at:at + rows] = np.minimum(lower[at - 1 + rows] + jump, Ly - 1)
     lower = np.maximum.accumulate(lower); upper = np.maximum.accumulate(upper)
     check(left, right, abi.Band(upper, lower))
     cls, _ = pg.debug_plan(left, right, abi.Band(upper, lower))
     assert set(np.unique(cls)) >= ({2, 3, 4} if seed < 2 else {1, 3, 4})
-    assert (5 in cls) == (seed == 1)
+    assert (5 in cls) == (seed == 3)
 
 
 def test_tile_list_covers_exactly_the_tiles_the_band_touches():
