@@ -1987,23 +1987,27 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             // 12 bits, saturating: it looks again after a saturated hop
             const size_t ndg = hj.dx.imin.size();
             const bool big_table = d.S * d.S > 256;
-            std::vector<int> hop(ndg, 0);
-            for (size_t t = ndg; t-- > 0;) {
-                const size_t nx = t + PG_PIPE_ASSIST;
-                if (nx >= ndg) { hop[t] = 4095; continue; }
-                const bool work = hj.cls[nx] == 2 || (big_table && hj.cls[nx] <= 1);     // small tables: class 1 is the compute waves' own
-                hop[t] = work ? 1 : std::min(4095, hop[nx] + 1);
-            }
             // wide runs (consecutive class 4 diagonals): does any diagonal of the run exceed PG_PIPE_WINDOW_A cells?  (bit 4 of a class
-            // 4 diagonal's word: wide_run takes the wide-ring geometry with more positions and fewer rows then)
-            std::vector<uint8_t> wide_b(ndg, 0);
+            // 4 diagonal's word: wide_run takes the wide-ring geometry with more positions and fewer rows then.)  Bit 19: the run has
+            // at least PG_PIPE_ASSIST diagonals (small tables) -- every assist wave meets one of them, and the run is wide_run7's:
+            // the assist waves take rows of their own.  PAGAN_DP_WIDE7=0: every run stays with the four compute waves (A/B switch)
+            static const bool wide7_on = !(std::getenv("PAGAN_DP_WIDE7") && std::strcmp(std::getenv("PAGAN_DP_WIDE7"), "0") == 0);
+            std::vector<uint8_t> wide_b(ndg, 0), wide7(ndg, 0);
             for (size_t t = 0; t < ndg;) {
                 if (hj.cls[t] != 4) { ++t; continue; }
                 size_t e = t;
                 int widest = 0;
                 while (e < ndg && hj.cls[e] == 4) { widest = std::max(widest, hj.dx.imax[e] - hj.dx.imin[e] + 1); ++e; }
                 if (widest > PG_PIPE_WINDOW_A) for (size_t q = t; q < e; ++q) wide_b[q] = 1;
+                if (wide7_on && !big_table && e - t >= (size_t)PG_PIPE_ASSIST) for (size_t q = t; q < e; ++q) wide7[q] = 1;
                 t = e;
+            }
+            std::vector<int> hop(ndg, 0);
+            for (size_t t = ndg; t-- > 0;) {
+                const size_t nx = t + PG_PIPE_ASSIST;
+                if (nx >= ndg) { hop[t] = 4095; continue; }
+                const bool work = hj.cls[nx] == 2 || (big_table && hj.cls[nx] <= 1) || wide7[nx];     // small tables: class 1 is the compute waves' own
+                hop[t] = work ? 1 : std::min(4095, hop[nx] + 1);
             }
             for (size_t t = 0; t < hj.dx.imin.size(); ++t) {
                 packed[8 * t] = hj.dx.imin[t]; packed[8 * t + 1] = hj.dx.imax[t];
@@ -2016,7 +2020,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
                 // bit 5 (bit 0 of the residency mask, which no age uses): a far history's writer or reader has a cell on the diagonal
                 const unsigned hb = (!hj.hbit.empty() && hj.hbit[t]) ? 1u : 0u;
                 // bit 19 (above the mask's REACH - 1 ages): a three-edge site of the lanes' third pass has a cell on the diagonal
-                const unsigned tb = (!hj.tbit.empty() && hj.tbit[t]) ? 1u : 0u;
+                const unsigned tb = ((!hj.tbit.empty() && hj.tbit[t]) || wide7[t]) ? 1u : 0u;      // (class 4: a seven-wave wide run)
                 static_assert(PG_PIPE_REACH <= 14, "descriptor word 4: ages 1 .. REACH - 1 in bits 6 .. 18, bit 19 for the third pass");
                 packed[8 * t + 4] = (int)(hj.cls[t] | (pair << 4) | ((mask | hb) << 5) | (tb << 19) | ((unsigned)hop[t] << 20));
                 packed[8 * t + 5] = (int)(hj.dx.doff[t] & 0xffffffffLL); packed[8 * t + 6] = (int)(hj.dx.doff[t] >> 32);

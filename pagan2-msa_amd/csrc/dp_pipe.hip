@@ -110,6 +110,8 @@ struct PipeSmem {
     double null_cell[4];         // -inf, -inf, -inf: what a missing second edge reads
     int progress[PNW];           // last diagonal each compute wave completed (or sleeps through)
     int arrived[PNW];            // last rendezvous diagonal each compute wave drained for
+    int wflag[8];                // seven-wave wide runs (wide_run7): last diagonal each of the 4 compute + 3 assist waves completed
+    int warrived[8];             // ... and the run boundary (first diagonal on entry, the one behind the run on exit) each has drained for
     int loaded[3];               // rows / columns / diagonal descriptors staged by the loader
     int abort_flag;
     int assist_done[PNA];        // last diagonal each assist wave has staged
@@ -1154,6 +1156,10 @@ __device__ __noinline__ void assist_general_cells(const PgDevJob *__restrict__ j
 // over its pairs of (max(M + tM, max(X, Y) + tX) + lw) + rw (the folding tools/gen_hot_asm.py explains).  What this path does
 // not take (more than three edges at a site, three on both sides of a cell, an edge from site 0, more sites than slots, more
 // far cells than the pool holds) goes to assist_general_diag when the diagonal is due.
+// (an assist wave's part of a seven-wave wide run: wide_run7, further down)
+// (returns the diagonal behind the run and the loader's progress it saw: rows, columns, descriptors)
+__device__ __noinline__ pg_i4 assist_wide_run(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, unsigned flags, int d0,
+                                              int rows_ld, int cols_ld, int diags_ld);
 template <bool STRIP>
 __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, unsigned flags) {
     // (a function of its own does not know that its arguments are wave-uniform: said here, what depends on the wave's index and
@@ -1201,6 +1207,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
     int q_row = 0, v_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double q_tM = 0, q_tX = 0, v_lw[4] = {0, 0, 0, 0}, v_rw[4] = {0, 0, 0, 0};
     int scan_d = a;                                                // next diagonal whose descriptor has not been looked at
+    int wide_at = -1;                                              // >= 0: prepare() met a diagonal of a seven-wave wide run (wide_run7)
     if (STRIP) { const int d0 = job->d_first; scan_d = d0 + (a + 3 - d0 % 3) % 3; }       // (the strip's first diagonal of this wave's residue)
 
     // the sites first..last of one side have entered the band: the multi-edge ones among them into free slots
@@ -1254,6 +1261,8 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
             const int ax = __builtin_amdgcn_readlane(q_next, 0), ay = __builtin_amdgcn_readlane(q_next, 1), as4 = __builtin_amdgcn_readlane(q_next, 4);
             const int bx = __builtin_amdgcn_readlane(q_next, 8), by = __builtin_amdgcn_readlane(q_next, 9), bs4 = __builtin_amdgcn_readlane(q_next, 12);
             const int hop_a = (int)((unsigned)as4 >> 20);           // the host's hop count: straight to this wave's next diagonal with work
+            // a seven-wave wide run (class 4, bit 19: every diagonal of such a run is a stop of the hop counts): this wave takes its rows
+            if (!STRIP && (as4 & 15) == 4 && (as4 & (1 << 19))) { wide_at = d; return; }
             if ((as4 & CLS) != 2) { scan_d += PNA * hop_a; q_next = desc_req(scan_d); continue; }     // (class 0 / 1: the compute waves' own)
             const bool pair_d = hop_a == 1 && d2 < nd && (bs4 & CLS) == 2;              // the descriptors allow two diagonals
             // bit 4 marks a class 2 diagonal whose operands all lie in the ring (class 2 for the shape of a site): no residency test
@@ -1511,8 +1520,22 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
     };
 
     prepare();
-    while (q_d >= 0) {
+    while (q_d >= 0 || wide_at >= 0) {
         if (flag_load(&PM.abort_flag) != 0) break;
+        if (wide_at >= 0) {
+            // the run's first diagonal: this wave stopped at the first one of its residue, at most two behind it
+            int d0 = wide_at;
+            for (int k = 0; k < PNA - 1 && d0 > 0; ++k) { if ((psc[d0 - 1].s4 & 15) == 4) --d0; else break; }
+            const pg_i4 back = assist_wide_run(job, psc, a, lane, flags, d0, rows_ld, cols_ld, diags_ld);
+            const int e = __builtin_amdgcn_readfirstlane(back.x);
+            rows_ld = __builtin_amdgcn_readfirstlane(back.y); cols_ld = __builtin_amdgcn_readfirstlane(back.z); diags_ld = __builtin_amdgcn_readfirstlane(back.w);
+            scan_d = e + ((a - e) % PNA + PNA) % PNA;               // this wave's first diagonal behind the run
+            q_next = desc_req(scan_d);
+            trk_valid = false;                                     // (the band moved on without this wave looking)
+            wide_at = -1;
+            prepare();
+            continue;
+        }
         stage(0);
         if (q_d2 >= 0) {
 #ifdef PG_PIPE_STATS
@@ -2366,7 +2389,9 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
         auto wcell = [&](bool need, int age, int p_, pg_d2 &xy, double &m) -> FarAsk {
             FarAsk f = {false, 0};
             xy.x = NIw; xy.y = NIw; m = NIw;
-            if (!need) return f;
+            // (a row above the previous diagonal's band: -inf without looking -- its position in the wide ring is the alias of a row
+            //  far below the band, which a wave other than the one above this one writes, and that wave need not have completed d-1)
+            if (!need || (age == 1 && p_ < lo_prev)) return f;
             if (age <= amax) {
                 int rb = wsb - age * wrow_bytes;
                 rb += rb < 0 ? wk * wrow_bytes : 0;
@@ -2550,6 +2575,316 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
     ok_until = d - 1;
     C_.dA = dA;
     WCTX_OUT(C_);
+}
+
+// ---- seven-wave wide run (round 5): a run of at least three class 4 diagonals, ONE row per lane ----
+// In wide_run a wave with rows in both of its sets does twice the work of the others, and -- every wave waits for the one
+// above it, around the circle -- the run moves at that wave's pace.  The three assist waves have nothing to stage while the
+// compute waves are in a wide run (PipeSmem), so they join it: 7 x 64 = 448 lanes >= PG_PIPE_WINDOW = 432 cells, lane T
+// (T = the thread's index in the block: compute waves 0..255, assist waves 256..447) holds the row of residue T mod 448 that
+// is not below the band, and the step is wide_run's with a single set: P / C in registers, (row-1, j) by one DPP shift (lane 0
+// out of the wide ring, written by the wave above), other edges' operands from the wide ring (PWK rows back) or L2, the
+// general rules for whatever is not an "easy" interior cell.
+// Lock step by PM.wflag: the wave above has completed d-1 and EVERY wave d-2 -- the circle of seven does not imply the
+// second from the first two flags as the circle of four does --, so that, as in wide_run, a ring row is rewritten only when
+// its readers are done and an L2 operand (at least PWK - 1 diagonals old) has been retired by its writer (every wave keeps
+// all but its last three steps' stores retired).  Entry and exit are rendezvous of all seven (PM.warrived): the compute
+// waves' stores from before the run have landed when the first step reads them, the assist waves' from inside the run when
+// the compute waves' general steps behind it do.  The compute waves publish PM.progress as ever (loader, followers).
+// The host marks such runs (descriptor word 4, bit 19 of a class 4 diagonal: dp_abi.hip) and makes their diagonals stops
+// of the assist waves' hop counts; PAGAN_DP_WIDE7=0 leaves every wide run to wide_run (A/B switch).
+#define PW7 7
+#define PW7L (64 * PW7)
+static_assert(PW7 == PNW + PNA && PG_PIPE_WINDOW <= PW7L - 16, "seven-wave wide runs: one row per lane");
+__device__ __noinline__ void wide_run7(WaveCtx &C_) {
+    WCTX_IN(C_);
+    WCTX_STATS(C_);
+    const PgDevJob *__restrict__ job = (const PgDevJob *)uniform_u64((unsigned long long)C_.job);
+    const unsigned flags_ = __builtin_amdgcn_readfirstlane(C_.flags);
+    const bool no_terminal_edges = flags_ & 1u, reduced_terminal = !(flags_ & 2u);
+    pg_i8 dA = uniform_i8(C_.dA);
+    const View J = load_view(job);
+    const int d0 = d;
+    const int lane = tid & 63, w7 = wave, up7 = w7 == 0 ? PW7 - 1 : w7 - 1;
+    const double NIw = neg_inf();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flag_store(&PM.wflag[w7], d0 - 1);
+    flag_store(&PM.warrived[w7], d0);
+    for (int w = 0; w < PW7; ++w) POLLX(&PM.warrived[w], d0, 7);
+    p_up = d0 - 1 > p_up ? d0 - 1 : p_up;
+    p_dn = d0 - 1 > p_dn ? d0 - 1 : p_dn;
+    // the run's diagonals d0 .. run_end - 1 (the same for every wave: the class words alone)
+    int run_end = d0 + 1;
+    for (;;) {
+        const int t = run_end + lane;
+        const int c4 = ((PG_GLOBAL const int *)psc)[8 * (t < nd ? t : nd) + 4] & 15;      // (the array carries one entry of padding: class 0)
+        const unsigned long long stop = __builtin_amdgcn_ballot_w64(t >= nd || c4 != 4);
+        if (stop != 0) { run_end += __builtin_ctzll(stop); break; }
+        run_end += 64;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pg_i4 cur = {dA.x, dA.y, dA.z, dA.w};                          // rows lo .. hi of the diagonal, byte offset of its first score
+    int wr;                                                        // the lane's row
+    { int m_ = (tid - cur.x) % PW7L; m_ += m_ < 0 ? PW7L : 0; wr = cur.x + m_; }
+    if (diags_ld < d0) diags_ld = POLLX(&PM.loaded[2], d0, 5);
+    // P = (row, j-1) on d-1, C = (row-1, j-1) on d-2, U = (row-1, j) on d-1 (first step only) from L2: everything before the run has landed
+    double Px, Py, Pm, Cx, Cy, Cm, Ux, Uy, Um;
+    {
+        const FarAsk fP = far_ask(psc, d0, 1, wr), fC = far_ask(psc, d0, 2, wr - 1), fU = far_ask(psc, d0, 1, wr - 1), none = {false, 0};
+        pg_d2 a = {NIw, NIw}, b = {NIw, NIw}, c = {NIw, NIw}, e = {NIw, NIw};
+        double ma = NIw, mb = NIw, mc = NIw, me = NIw;
+        far_fetch4(sc_out, fP, fC, fU, none, a, ma, b, mb, c, mc, e, me);
+        Px = a.x; Py = a.y; Pm = ma; Cx = b.x; Cy = b.y; Cm = mb; Ux = c.x; Uy = c.y; Um = mc;
+    }
+    const bool geo_b = (dA.s4 & 16) != 0;
+    const int wpos_n = geo_b ? PWPOS_B : PWPOS_A, wk = geo_b ? PWK_B : PWK_A, wage = wk - 2, wrow_bytes = wpos_n * 24;
+    int wbase = cur.x - 32;
+    auto wpos = [&](int r_) { int q_ = r_ - wbase; q_ -= q_ >= wpos_n ? wpos_n : 0; q_ -= q_ >= wpos_n ? wpos_n : 0; return q_; };
+    int n_hist1 = 0, n_hist2 = 0;                                  // stores issued in the previous step / the one before
+    int lo_prev = cur.x;
+    for (;;) {
+        const int lo = cur.x, hi = cur.y;
+        if (lo - 2 * wage - 4 - wbase >= wpos_n) wbase += wpos_n;
+#ifdef PG_PIPE_STATS
+        const long long st_step0 = __builtin_readcyclecounter();
+#endif
+        {   // records of the diagonal's rows and columns, descriptors of every earlier diagonal
+            const int nr_ = hi + 1 < Lx ? hi + 1 : Lx, nc_ = d - lo + 1 < Ly ? d - lo + 1 : Ly;
+            if (rows_ld < nr_) rows_ld = POLLX(&PM.loaded[0], nr_, 1);
+            if (cols_ld < nc_) cols_ld = POLLX(&PM.loaded[1], nc_, 2);
+            if (diags_ld < d) diags_ld = POLLX(&PM.loaded[2], d, 5);
+        }
+        // the records and the shape of the lane's cell do not depend on the other waves: before the flags
+        // (the row the lane will hold after the hand-over below)
+        const int r = wr < lo ? wr + PW7L : wr, j = d - r;
+        int kind = 0;                                           // 0 outside the band, 1 batched, 2 general rules
+        pg_i4 gl = {0, 0, 0, 0}, gr = {0, 0, 0, 0};
+        bool l2 = false, r2 = false, lS = false, rS = false;
+        int kL = 0, kR = 0;
+        double tM = 0, tX = 0;
+        if (r <= hi) {
+            gl = PM.recL[r & (PRW - 1)]; gr = PM.recR[j & (PRW - 1)];
+            const int nl = (gl.x >> PR_NE_SHIFT) & 127, nr = (gr.x >> PR_NE_SHIFT) & 127;
+            const int dl0 = gl.y & 0xffff, dl1 = (int)((unsigned)gl.y >> 16), dr0 = gr.y & 0xffff, dr1 = (int)((unsigned)gr.y >> 16);
+            const bool easyL = nl == 1 ? dl0 == 1 : (nl == 2 && (dl0 == 1) != (dl1 == 1));
+            const bool easyR = nr == 1 ? dr0 == 1 : (nr == 2 && (dr0 == 1) != (dr1 == 1));
+            const bool l2_ = nl == 2, r2_ = nr == 2;
+            const bool lS_ = l2_ && dl0 != 1, rS_ = r2_ && dr0 != 1;               // the other edge is listed first
+            kL = lS_ ? dl0 : dl1; kR = rS_ ? dr0 : dr1;
+            // interior, and no edge in reach starts at site 0 (where the gap-open term differs)
+            const bool inner = r >= 2 && r <= Lx - 2 && j >= 2 && j <= Ly - 2 && (!l2_ || r - kL >= 1) && (!r2_ || j - kR >= 1);
+            kind = (easyL && easyR && inner) ? 1 : 2;
+            if (kind == 1) { l2 = l2_; r2 = r2_; lS = lS_; rS = rS_; }
+            if (r > 0 && j > 0 && nl > 0 && nr > 0) {
+                const int ti_ = ((gl.x & 0xffff) + __umul24(gr.x & 0xffff, S)) & 255;
+                tM = PM.tab2[ti_][0]; tX = PM.tab2[ti_][1];
+            }
+        }
+        // the next diagonal's descriptor: staged by the loader (the window runs PLOOK diagonals ahead of the slowest wave)
+        if (diags_ld < d + 2 && d + 1 < nd) diags_ld = POLLX(&PM.loaded[2], d + 2, 5);
+        const pg_i4 nxt = PM.dring[(d + 1) & (PDR - 1)];
+        const int amax = d - d0 < wage ? d - d0 : wage;               // ages 1 .. amax are in the wide ring
+        const int wsb = (d % wk) * wrow_bytes;
+        const long long soff = ((long long)cur.w << 32) | (unsigned)cur.z;
+        PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff;
+        {   // lock step: lanes 0..6 look at one wave's flag each -- the wave above has completed d-1, every wave d-2
+            int spins = 0;
+            for (;;) {
+                const int v = lane < PW7 ? flag_peek(&PM.wflag[lane]) : 0x7fffffff;
+                if (__builtin_amdgcn_ballot_w64(v < (lane == up7 ? d - 1 : d - 2)) == 0) break;
+                if ((++spins & 15) == 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (spins > PSPIN_LIMIT || flag_load(&PM.abort_flag) != 0) {
+                        if (flag_load(&PM.abort_flag) == 0) flag_store(&PM.abort_flag, PTAG(6));
+                        break;
+                    }
+                }
+            }
+        }
+#ifdef PG_PIPE_STATS
+        const long long st_t1 = __builtin_readcyclecounter();
+#endif
+        if (d > d0) {
+            // (row-1, j) on d-1: lane T-1's cell, lane 0 from the wide ring; the band's first row of d-1 has no row above it in
+            // the band (for lane 0 as well: the position it read is another row's alias -- wide_run has the story)
+            int rb1 = wsb - wrow_bytes;
+            rb1 += rb1 < 0 ? wk * wrow_bytes : 0;
+            const double *c = (const double *)((const char *)&PM.sc[0][0][0] + rb1 + wpos(wr - 1) * 24);
+            const double ax = dpp_shr1(Px, c[PG_X]), ay = dpp_shr1(Py, c[PG_Y]), am = dpp_shr1(Pm, c[PG_M]);
+            const bool top = wr == lo_prev;
+            Ux = top ? NIw : ax; Uy = top ? NIw : ay; Um = top ? NIw : am;
+            // row hand-over: the lane's next row (448 on: far below the band) starts from -inf
+            if (wr < lo) { wr += PW7L; Px = NIw; Py = NIw; Pm = NIw; Cx = NIw; Cy = NIw; Cm = NIw; Ux = NIw; Uy = NIw; Um = NIw; }
+        }
+        // one operand cell (p, d - age): read from the wide ring, or -- not there -- what to ask L2 for; -inf outside the band
+        auto wcell = [&](bool need, int age, int p_, pg_d2 &xy, double &m) -> FarAsk {
+            FarAsk f = {false, 0};
+            xy.x = NIw; xy.y = NIw; m = NIw;
+            // (a row above the previous diagonal's band: -inf without looking -- its position in the wide ring is the alias of a row
+            //  far below the band, which a wave other than the one above this one writes, and that wave need not have completed d-1)
+            if (!need || (age == 1 && p_ < lo_prev)) return f;
+            if (age <= amax) {
+                int rb = wsb - age * wrow_bytes;
+                rb += rb < 0 ? wk * wrow_bytes : 0;
+                const double *c = (const double *)((const char *)&PM.sc[0][0][0] + rb + wpos(p_) * 24);
+                xy.x = c[PG_X]; xy.y = c[PG_Y]; m = c[PG_M];
+                return f;
+            }
+            return far_ask(psc, d, age, p_);
+        };
+        pg_d2 o_xy[8];
+        double o_m[8];
+        FarAsk o_f[8];
+        bool any_far = false;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { o_f[t].need = false; o_f[t].boff = 0; o_xy[t].x = NIw; o_xy[t].y = NIw; o_m[t] = NIw; }
+        const bool b1 = kind == 1;
+        if (__any(b1 && (l2 || r2))) {
+            // the batched cells' other-edge operands.  Wave-uniform shortcuts: an operand is skipped when no lane has it, and
+            // while every lane's lies in the wide ring the reads are plain LDS reads (no L2 path, no branches)
+            auto rd = [&](bool need, int age, int p_, pg_d2 &xy, double &m) {
+                int rb = wsb - age * wrow_bytes;
+                rb += rb < 0 ? wk * wrow_bytes : 0;
+                const int off = need ? rb + wpos(p_) * 24 : (int)offsetof(PipeSmem, null_cell) - (int)offsetof(PipeSmem, sc);
+                const double *c = (const double *)((const char *)&PM.sc[0][0][0] + off);
+                xy.x = c[PG_X]; xy.y = c[PG_Y]; m = c[PG_M];
+            };
+            auto fetch = [&](int t, bool need, int age, int p_) {
+                if (!__any(need)) return;
+                if (!__any(need && age > amax)) rd(need, age, p_, o_xy[t], o_m[t]);
+                else { o_f[t] = wcell(need, age, p_, o_xy[t], o_m[t]); any_far = true; }     // (-inf for the lanes without it)
+            };
+            fetch(3, b1 && l2, kL, r - kL);
+            fetch(4, b1 && l2, kL + 1, r - kL);
+            fetch(5, b1 && r2, kR, r);
+            fetch(6, b1 && r2, kR + 1, r - 1);
+            fetch(7, b1 && l2 && r2, kL + kR, r - kL);
+        }
+#ifdef PG_PIPE_STATS
+        const long long st_t2 = __builtin_readcyclecounter();
+#endif
+        if (any_far) far_fetch8(sc_out, o_f, o_xy, o_m);           // (requests and wait in one statement; nothing if no lane asked)
+#ifdef PG_PIPE_STATS
+        const long long st_t3 = __builtin_readcyclecounter();
+#endif
+        const bool active = kind != 0;
+        const int n_now = __any(active) ? 2 : 0;                // stores this wave issues in this step
+        double bx = NIw, by = NIw, bm = NIw;
+        unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
+        if (kind == 1) {
+            const double lw0 = (double)__int_as_float(gl.z), lw1 = (double)__int_as_float(gl.w);
+            const double rw0 = (double)__int_as_float(gr.z), rw1 = (double)__int_as_float(gr.w);
+            const double lwA = lS ? lw1 : lw0, lwS = lS ? lw0 : lw1, rwA = rS ? rw1 : rw0, rwS = rS ? rw0 : rw1;
+            const pg_d2 lx_ = o_xy[3], lm_ = o_xy[4], ry_ = o_xy[5], rm_ = o_xy[6], lr_ = o_xy[7];
+            const double lxm = o_m[3], lmm = o_m[4], rym = o_m[5], rmm = o_m[6], lrm = o_m[7];
+            // scores only (pg_backptr derives the back-pointers); the reference's candidates with the maxima regrouped
+            // (tools/gen_hot_asm.py); absent operands are -inf
+            auto gapv = [&](double own, double other, double m_) { return __builtin_fmax(own + ge, __builtin_fmax(other, m_ + ng) + go); };
+            auto pairv = [&](double x_, double y_, double m_, double lw, double rw) {
+                return (__builtin_fmax(m_ + tM, __builtin_fmax(x_, y_) + tX) + lw) + rw;
+            };
+            bx = gapv(Ux, Uy, Um);
+            by = gapv(Py, Px, Pm);
+            bm = pairv(Cx, Cy, Cm, lwA, rwA);
+            if (__any(r2)) {
+                by = __builtin_fmax(by, gapv(ry_.y, ry_.x, rym));
+                bm = __builtin_fmax(bm, pairv(rm_.x, rm_.y, rmm, lwA, rwS));
+            }
+            if (__any(l2)) {
+                bx = __builtin_fmax(bx, gapv(lx_.x, lx_.y, lxm));
+                bm = __builtin_fmax(bm, pairv(lm_.x, lm_.y, lmm, lwS, rwA));
+                if (__any(l2 && r2)) bm = __builtin_fmax(bm, pairv(lr_.x, lr_.y, lrm, lwS, rwS));
+            }
+        } else if (kind == 2) {
+            // first/last rows and columns, sites without edges, more than two edges, ...: the general rules
+            const int nl = (gl.x >> PR_NE_SHIFT) & 127, nr = (gr.x >> PR_NE_SHIFT) & 127;
+            const pg_i4 gl_ = gl, gr_ = gr;
+            cell_any_t(J, r, j, r > 0 ? nl : 0, j > 0 ? nr : 0, tM, tX, no_terminal_edges, reduced_terminal,
+                     [&](int p_, int q_, double &xs, double &ys, double &ms) {
+                         pg_d2 xy; double m_;
+                         const FarAsk f = wcell(p_ >= 0 && q_ >= 0, d - (p_ + q_), p_, xy, m_);
+                         {
+                             const FarAsk none = {false, 0};
+                             pg_d2 e1 = {NIw, NIw}, e2 = {NIw, NIw}, e3 = {NIw, NIw}; double m1 = NIw, m2 = NIw, m3 = NIw;
+                             far_fetch4(sc_out, f, none, none, none, xy, m_, e1, m1, e2, m2, e3, m3);
+                         }
+                         xs = xy.x; ys = xy.y; ms = m_;
+                     },
+                     [&](int k, int &p_, double &lw) { int dist; edge_at<true>(gl_, k, r, dist, lw); p_ = r - dist; },
+                     [&](int k, int &q_, double &rw) { int dist; edge_at<false>(gr_, k, j, dist, rw); q_ = j - dist; },
+                     bx, by, bm, px, py, pm);
+        }
+        if (wr < lo + wpos_n) {                                  // (a row that many past the band's first: never in the band, and its position is another row's)
+            double *o = (double *)((char *)&PM.sc[0][0][0] + wsb + wpos(wr) * 24);
+            o[PG_X] = bx; o[PG_Y] = by; o[PG_M] = bm;
+        }
+        if (wpos_n > PW7L && wr < lo + wpos_n - PW7L) {           // (512 positions, 448 lanes: the positions of the rows lo + 448 .. lo + 511 -- -inf,
+            double *o = (double *)((char *)&PM.sc[0][0][0] + wsb + wpos(wr + PW7L) * 24);      //  what a read above an older diagonal's band lands on)
+            o[PG_X] = NIw; o[PG_Y] = NIw; o[PG_M] = NIw;
+        }
+        {   // all but the stores of the last two steps have retired (this step's are issued behind the flag)
+            const int tot = n_hist1 + n_hist2;
+            if (tot >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (tot >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            n_hist2 = n_hist1; n_hist1 = n_now;
+        }
+        flag_store(&PM.wflag[w7], d);
+        if (w7 < PNW) flag_store(&PM.progress[w7], d);
+        if (active) {
+            const unsigned off24 = __umul24((unsigned)(wr - lo), 24u);
+            pg_d2 xy; xy.x = bx; xy.y = by;
+            *(PG_GLOBAL pg_d2 *)(srow + off24) = xy;
+            *(PG_GLOBAL double *)(srow + off24 + 16u) = bm;
+        }
+        // the next step's registers: this cell is its (row, j-1), this step's (row-1, j) its (row-1, j-1)
+        Px = bx; Py = by; Pm = bm;
+        Cx = Ux; Cy = Uy; Cm = Um;
+#ifdef PG_PIPE_STATS
+        if (w7 < PNW) {
+            const long long st_t5 = __builtin_readcyclecounter();
+            st_cls_t[4] += st_t5 - st_step0; ++st_cls_n[4];
+            st_w[0] += st_t1 - st_step0; st_w[1] += st_t2 - st_t1; st_w[2] += st_t3 - st_t2; st_w[3] += st_t5 - st_t3;
+        }
+#endif
+        ++d;
+        lo_prev = lo;
+        if (d >= run_end || flag_load(&PM.abort_flag) != 0) break;
+        cur.x = __builtin_amdgcn_readfirstlane(nxt.x); cur.y = __builtin_amdgcn_readfirstlane(nxt.y);
+        cur.z = __builtin_amdgcn_readfirstlane(nxt.z); cur.w = __builtin_amdgcn_readfirstlane(nxt.w);
+    }
+    // every wave's stores of the run have landed before anyone goes on (the compute waves' general steps read them from L2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flag_store(&PM.warrived[w7], d);
+    for (int w = 0; w < PW7; ++w) POLLX(&PM.warrived[w], d, 7);
+    dA = psc[d];                                                   // (the array carries one entry of padding)
+    // back to step() (compute waves): this lane's row for the narrow diagonals, nothing in registers or prefetched
+    row = dA.x + ((tid - dA.x) & (PNT - 1));
+    ok_until = d - 1;
+    C_.dA = dA;
+    WCTX_OUT(C_);
+}
+
+__device__ __noinline__ pg_i4 assist_wide_run(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, unsigned flags, int d0,
+                                              int rows_ld, int cols_ld, int diags_ld) {
+    WaveCtx C_;
+    C_.job = job; C_.psc = psc; C_.sc_out = (gdouble_w)job->sc; C_.bp_out = (gu32_w)job->bp;
+    C_.go = (double)job->go; C_.ng = (double)job->ng; C_.ge = (double)job->ge; C_.tng2 = 0.0; C_.tng1 = 0.0;
+    C_.Lx = job->Lx; C_.Ly = job->Ly; C_.nd = job->nd; C_.S = job->S; C_.sleep = job->nd;
+    C_.tid = PNT + 64 * a + lane; C_.wave = PNW + a; C_.up = 0; C_.dn = 0; C_.bslot = 0; C_.flags = flags;
+    C_.d = d0; C_.row = 0;
+    C_.px = 0.0; C_.py = 0.0; C_.pm = 0.0; C_.cx = 0.0; C_.cy = 0.0; C_.cm = 0.0;
+    C_.ca = pg_i4{0, 0, 0, 0}; C_.cb = pg_i4{0, 0, 0, 0}; C_.smf = 0.0f;
+    C_.dA = psc[d0];
+    C_.p_up = -1; C_.p_dn = -1; C_.ok_until = -1; C_.rows_ld = rows_ld; C_.cols_ld = cols_ld; C_.diags_ld = diags_ld;
+    C_.as0 = 0; C_.as1 = 0; C_.as2 = 0;
+#ifdef PG_PIPE_STATS
+    for (int k = 0; k < 5; ++k) { C_.st_cls_t[k] = 0; C_.st_cls_n[k] = 0; }
+    for (int k = 0; k < 10; ++k) { C_.st_poll_t[k] = 0; C_.st_poll_n[k] = 0; }
+    for (int k = 0; k < 4; ++k) C_.st_w[k] = 0;
+#endif
+    wide_run7(C_);
+    return pg_i4{C_.d, C_.rows_ld, C_.cols_ld, C_.diags_ld};
 }
 
 #ifdef PG_PIPE_STATS
@@ -2797,6 +3132,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
     if (tid < 4) PM.null_cell[tid] = neg_inf();
     if (tid < PNW) { PM.progress[tid] = STRIP ? job->d_first - 1 : -1; PM.arrived[tid] = STRIP ? job->d_first - 1 : -1; }
     if (tid == 0) { PM.loaded[0] = 0; PM.loaded[1] = 0; PM.loaded[2] = 0; PM.abort_flag = 0; PM.pdsc = STRIP ? job->pdsc : nullptr; }
+    if (tid < 8) { PM.wflag[tid] = -1; PM.warrived[tid] = -1; }
 #ifdef PG_PIPE_STATS
     if (tid == 0) PM.far_limit = 24ll * job->cells;
 #endif
@@ -3226,7 +3562,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
                 for (int k = 0; k < 10; ++k) { C_.st_poll_t[k] = st_poll_t[k]; C_.st_poll_n[k] = st_poll_n[k]; }
                 for (int k = 0; k < 4; ++k) C_.st_w[k] = st_w[k];
 #endif
-                if (!STRIP && (dA.s4 & 15) == 4) wide_run(C_); else hot_run<STRIP>(C_);
+                if (!STRIP && (dA.s4 & 15) == 4) { if (dA.s4 & (1 << 19)) wide_run7(C_); else wide_run(C_); } else hot_run<STRIP>(C_);
 #ifdef PG_PIPE_STATS
                 for (int k = 0; k < 5; ++k) { st_cls_t[k] = C_.st_cls_t[k]; st_cls_n[k] = C_.st_cls_n[k]; }
                 for (int k = 0; k < 10; ++k) { st_poll_t[k] = C_.st_poll_t[k]; st_poll_n[k] = C_.st_poll_n[k]; }

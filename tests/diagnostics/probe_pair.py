@@ -44,7 +44,7 @@ if os.environ.get("PG_STAMPS"):
     b3 = raw[n_int - 600:]
     for w in range(4):
         t = b3[4 * w: 4 * w + 4].astype(np.int64) * 256
-        print("wave %d wide steps, Mcycles: drain before %.0f, rendezvous %.0f, cells %.0f, drain after %.0f" % ((w,) + tuple(t / 1e6)))
+        print("wave %d wide steps, Mcycles: loader and neighbour flags %.0f, shift + records + operands off the wide ring %.0f, L2 operands %.0f, arithmetic + stores + flag %.0f" % ((w,) + tuple(t / 1e6)))
 if os.environ.get("PG_STAMPS"):
     b4 = raw[n_int - 800:]
     kinds = {0: "asm loop entries / diagonals run in it (M)", 1: "loader rows", 2: "loader cols", 3: "downstream (ring row reuse)", 4: "upstream (row above)", 5: "descriptor window / asm: exits after 48 looks at the upstream flag (count), ... downstream (M)",

@@ -12,7 +12,7 @@ oracle.build()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 bad = 0
 hist = np.zeros(6, np.int64)
-for case in range(n_cases):
+for case in range(int(os.environ.get("PG_SWEEP_FIRST", "0")), n_cases):
     rng = np.random.default_rng(int(os.environ.get("PG_SWEEP_SEED", "1000")) + case)
     n = int(rng.integers(150, 1400))
     span = int(rng.choice([4, 8, 17, 19, 25, 40, 80]))
