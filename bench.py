@@ -108,7 +108,11 @@ def main():
         # The forward/backward workload keeps 15 pairs x 2 sweeps in flight, a kernel each; the HIP runtime deals a process's
         # streams onto 4 hardware queues unless told otherwise, and kernels of one queue run one after the other
         # (measured: 4 queues 1.39e8 cells/s, 8 queues 2.68e8, 16 the same).  Has to be in the environment before HIP starts.
+        # (Under rocprofv3 the profiler's library has initialised HIP before this line runs: tools/*.sh export the variable instead,
+        #  and the line below reports what was in the environment when the process started, not what this setdefault asked for.)
+        hw_queues_at_start = os.environ.get("GPU_MAX_HW_QUEUES")
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        os.environ["PAGAN_BENCH_HW_QUEUES_AT_START"] = hw_queues_at_start or "unset (8 requested before import torch)"
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the aligner has no CPU path")
@@ -178,7 +182,8 @@ def bench_forward_backward(args, device):
         "ms_per_step": 1e3 * dev_s, "higher_is_better": True, "scaling": None, "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": workload, "leaves": leaves, "length": length, "node_pairs": n_nodes, "cells_per_step": int(cells),
-                   "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "hip_hw_queues_requested": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "hip_hw_queues_in_environment_at_start": os.environ.get("PAGAN_BENCH_HW_QUEUES_AT_START"),
                    "note": "value = cells / wall-clock of a pass with all node pairs in flight at once (wide pairs: two block-scheduled sweeps of up to 64 one-wave workgroups each); the per-kernel ms are sums of the kernels' own durations; wall per pass incl. allocation and upload: %.1f ms" % (1e3 * elapsed / args.steps)},
         "roofline": {"bound": "hbm", "achieved": 48 * cells / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": 48 * cells / dev_s / 1e9 / HBM_PEAK_GBS, "kernel": "pg_fb_forward + pg_fb_backward",

@@ -98,8 +98,9 @@ def test_errors(pg):
 
 
 def test_wide_pairs_spread_a_diagonal_over_several_workgroups(pg, oracle, monkeypatch):
-    """Full matrices of internal nodes (multi-edge sites, ~900-cell diagonals): the sweeps spread every diagonal's cells over
-    four workgroups with a counter barrier per diagonal (dp_fb.hip, pg_fb_*_wide); same logs as the oracle and as the
+    """Full matrices of internal nodes (multi-edge sites, ~900-cell diagonals): the sweeps cut the matrix into 64 x 64 blocks that
+    a grid of one-wave workgroups works through block anti-diagonal by block anti-diagonal (dp_fb.hip, pg_fb_forward_tiled /
+    pg_fb_backward_tiled: a counter per block diagonal, no barrier per cell diagonal); same logs as the oracle and as the
     one-workgroup sweeps (PAGAN_FB_GROUPS=1) to the comparison's tolerance, forward total = backward total."""
     names, seqs, nwk = synth.evolve_balanced(4, 900, branch=0.04, sub=0.04, indel_start=0.01, mean_len=4, seed=45)
     msa = host.Msa(names, seqs, nwk, use_anchors=0).align()

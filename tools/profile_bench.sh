@@ -1,9 +1,11 @@
 # rocprofv3 passes of the headline bench command (run on the GPU box: gpurun -- bash tools/profile_bench.sh):
 # kernel trace + stats, then WRITE_SIZE and FETCH_SIZE in separate PMC passes (never combined with a trace domain).
 set -e
+# (in the environment before HIP starts -- under rocprofv3 the preloaded library initialises HIP before python runs: bench.py's own setdefault would come too late)
+export GPU_MAX_HW_QUEUES=8
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r04
+O=$R/gpurun_out/prof_r05
 mkdir -p $O
 cd $R
 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_under_stats.json 2> $O/stats.err

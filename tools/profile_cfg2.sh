@@ -1,9 +1,11 @@
 # rocprofv3 passes of the cfg2 bench command (16 x 2 kb, full matrices, tiled kernel): kernel stats + WRITE_SIZE / FETCH_SIZE
-# (separate PMC passes) -> gpurun_out/prof_r04_cfg2/
+# (separate PMC passes) -> gpurun_out/prof_r05_cfg2/
 set -e
+# (in the environment before HIP starts -- under rocprofv3 the preloaded library initialises HIP before python runs: bench.py's own setdefault would come too late)
+export GPU_MAX_HW_QUEUES=8
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r04_cfg2
+O=$R/gpurun_out/prof_r05_cfg2
 mkdir -p $O
 cd $R
 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- python3 bench.py --workload cfg2_16x2kb_dna_full --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_under_stats.json 2> $O/stats.err

@@ -1,8 +1,10 @@
-# rocprofv3 kernel statistics of the cfg5 pass (512 x 10 kb on one GPU): gpurun_out/prof_r04_cfg5/bench_cfg5_kernel_stats.csv
+# rocprofv3 kernel statistics of the cfg5 pass (512 x 10 kb on one GPU): gpurun_out/prof_r05_cfg5/bench_cfg5_kernel_stats.csv
 set -e
+# (in the environment before HIP starts -- under rocprofv3 the preloaded library initialises HIP before python runs: bench.py's own setdefault would come too late)
+export GPU_MAX_HW_QUEUES=8
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r04_cfg5
+O=$R/gpurun_out/prof_r05_cfg5
 mkdir -p $O
 cd $R
 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- python3 bench.py --workload cfg5_512x10kb_dna_anchored --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_under_stats.json 2> $O/stats.err

@@ -1,7 +1,9 @@
-# the round's bench lines, one per workload, into gpurun_out/r04/ (run on the GPU box: gpurun -- bash tools/round_benches.sh)
+# the round's bench lines, one per workload, into gpurun_out/r05/ (run on the GPU box: gpurun -- bash tools/round_benches.sh)
 set -e
+# (in the environment before HIP starts -- under rocprofv3 the preloaded library initialises HIP before python runs: bench.py's own setdefault would come too late)
+export GPU_MAX_HW_QUEUES=8
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04
+O=$R/gpurun_out/r05
 mkdir -p $O
 cd $R
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
