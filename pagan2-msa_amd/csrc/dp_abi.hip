@@ -930,6 +930,9 @@ void compact_band(const RowBand &rb0, const CompactSide &l, const CompactSide &r
     }
 }
 
+// (PAGAN_DP_CANARY: guard words behind every region of the arena -- Carver, further down)
+#define PG_CANARY_BYTES 64
+#define PG_CANARY_WORD 0x5ca1ab1eu
 struct pagan_batch {
     std::vector<CompactJob> compact;
     int n = 0;
@@ -969,6 +972,11 @@ struct pagan_batch {
     size_t follow_begin = 0, follow_bytes = 0;     // PgDevJob::follow / bp_done of the banded jobs, one block zeroed per launch
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // PAGAN_DP_CANARY=1: guard words behind every region of the arena (Carver)
+    std::vector<size_t> guards;
+    size_t *d_guards = nullptr;
+    int *d_canary = nullptr;                     // [0] guards found changed by the last run, [1] the first of them
+    unsigned canary_word = PG_CANARY_WORD;       // (PAGAN_DP_CANARY=0x...: another pattern -- what a read past a region's end then sees)
     // per-kernel brackets inside the fill (pagan_batch_last_ms_detail): 0/1 around the banded kernel, 2 behind pg_backptr,
     // 3/4 around the tiled kernel (on its own stream when the batch also has banded jobs), 5 behind the HBM wavefront
     hipEvent_t evk[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // (6: behind the tiled jobs' pg_backptr)
@@ -1100,15 +1108,30 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe, i
 }
 
 // Bump allocator over the arena: first pass sizes it, second pass hands out pointers.
+// PAGAN_DP_CANARY=1 (debug): PG_CANARY_BYTES of a known pattern behind EVERY region of the arena, written before each run's
+// kernels and checked after them (pg_canary, below): a store past the end of a region -- by any kernel of the batch -- turns
+// up as an error of the run instead of as another region's corrupted content (or, at the arena's end, as a memory fault).
 struct Carver {
     size_t cur = 0;
     char *base = nullptr;
+    std::vector<size_t> *guards = nullptr;       // (canary mode) offsets of the guard words, in carving order
     template <class T> T *take(size_t count) {
         size_t off = cur;
         cur = align_up(cur + sizeof(T) * (count ? count : 1));
+        if (guards) { guards->push_back(cur); cur = align_up(cur + PG_CANARY_BYTES); }
         return base ? reinterpret_cast<T *>(base + off) : reinterpret_cast<T *>(off);
     }
 };
+// check == nullptr: writes the pattern; otherwise counts the guards that no longer hold it (and names the first one)
+__global__ void pg_canary(char *base, const size_t *offs, int n, int *check, unsigned word) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    unsigned *w = reinterpret_cast<unsigned *>(base + offs[g]);
+    if (!check) { for (int k = 0; k < PG_CANARY_BYTES / 4; ++k) w[k] = word; return; }
+    bool bad = false;
+    for (int k = 0; k < PG_CANARY_BYTES / 4; ++k) bad = bad || w[k] != word;
+    if (bad) { atomicAdd(check, 1); atomicMin(check + 1, g); }
+}
 
 // Lays one job out in the arena.  With `base == nullptr` only sizes are accumulated.
 void carve_job(Carver &c, const pagan_job &jb, const HostJob &hj, PgDevJob *d) {
@@ -1922,6 +1945,10 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     const double tc1 = now();
     // pass 1: sizes.  Inputs first (one contiguous upload), outputs after.
     Carver sizer;
+    if (const char *cm = std::getenv("PAGAN_DP_CANARY")) if (std::strcmp(cm, "0") != 0) {
+        sizer.guards = &b->guards;
+        if (cm[0] == '0' && cm[1] == 'x') b->canary_word = (unsigned)std::strtoul(cm, nullptr, 16);
+    }
     PgDevJob *jobs_off = sizer.take<PgDevJob>((size_t)n + sdev.size());
     int *which_off = sizer.take<int>(n);
     int *swhich_off = sizer.take<int>(swhich.size());
@@ -1952,6 +1979,14 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             pagan_fb_internal_release_cache();
             HIP_TRY(hipMalloc((void **)&b->arena.dev, b->arena.size));
         }
+    }
+    if (!b->guards.empty()) {
+        // (the follow words are zeroed in one sweep per run, guards and all: those regions go unguarded)
+        auto zeroed = [&](size_t o) { return (o >= b->follow_begin && o < b->follow_begin + b->follow_bytes) || (o >= b->sfollow_begin && o < b->sfollow_begin + b->sfollow_bytes); };
+        b->guards.erase(std::remove_if(b->guards.begin(), b->guards.end(), zeroed), b->guards.end());
+        HIP_TRY(hipMalloc((void **)&b->d_guards, b->guards.size() * sizeof(size_t)));
+        HIP_TRY(hipMalloc((void **)&b->d_canary, 2 * sizeof(int)));
+        HIP_TRY(hipMemcpy(b->d_guards, b->guards.data(), b->guards.size() * sizeof(size_t), hipMemcpyHostToDevice));
     }
     const double tc2 = now();
 
@@ -2113,6 +2148,12 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
 int pagan_batch_run(pagan_batch *b) {
     if (!b) return PAGAN_E_ARG;
     HIP_TRY(hipSetDevice(b->device));
+    if (b->d_guards) {
+        // (on the batch's stream, ahead of everything the run launches there; the tiled jobs' stream waits for an event of this one)
+        const int init[2] = {0, 0x7fffffff};
+        HIP_TRY(hipMemcpyAsync(b->d_canary, init, sizeof init, hipMemcpyHostToDevice, b->stream));
+        hipLaunchKernelGGL(pg_canary, dim3(((int)b->guards.size() + 255) / 256), dim3(256), 0, b->stream, b->arena.dev, b->d_guards, (int)b->guards.size(), (int *)nullptr, b->canary_word);
+    }
     HIP_TRY(hipEventRecord(b->ev[0], b->stream));
     int rc = launch_fill(b);
     if (rc != PAGAN_OK) return rc;
@@ -2138,14 +2179,27 @@ int pagan_batch_run(pagan_batch *b) {
         hipLaunchKernelGGL(pg_trace_check, dim3((b->max_path + 255) / 256, b->n), dim3(256), 0, b->stream, b->d_jobs, b->flags & 0xffu);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[2], b->stream));
+    if (b->d_guards)
+        hipLaunchKernelGGL(pg_canary, dim3(((int)b->guards.size() + 255) / 256), dim3(256), 0, b->stream, b->arena.dev, b->d_guards, (int)b->guards.size(), b->d_canary, b->canary_word);
     b->ran = true;
     return PAGAN_OK;
+}
+
+// (canary mode) after the run's kernels: PAGAN_OK, or PAGAN_E_INTERNAL with the first changed guard named on stderr
+static int canary_verdict(pagan_batch *b) {
+    if (!b->d_guards || !b->ran) return PAGAN_OK;
+    int got[2] = {0, 0};
+    HIP_TRY(hipMemcpy(got, b->d_canary, sizeof got, hipMemcpyDeviceToHost));
+    if (got[0] == 0) return PAGAN_OK;
+    std::fprintf(stderr, "pagan_dp: CANARY: %d of %zu guard words changed during the run; the first is guard %d at arena offset %zu (arena of %zu bytes, outputs from %zu)\n",
+                 got[0], b->guards.size(), got[1], b->guards[(size_t)got[1]], b->arena.size, b->out_begin);
+    return PAGAN_E_INTERNAL;
 }
 
 int pagan_batch_sync(pagan_batch *b) {
     if (!b) return PAGAN_E_ARG;
     HIP_TRY(hipStreamSynchronize(b->stream));
-    return PAGAN_OK;
+    return canary_verdict(b);
 }
 
 int pagan_batch_last_ms(pagan_batch *b, double ms[2]) {
@@ -2187,6 +2241,7 @@ int64_t pagan_batch_cells(const pagan_batch *b) { return b ? b->cells : 0; }
 int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
     if (!b || !out || !b->ran) return PAGAN_E_ARG;
     HIP_TRY(hipStreamSynchronize(b->stream));
+    if (const int cv = canary_verdict(b)) return cv;
     double ms[2] = {0, 0};
     pagan_batch_last_ms(b, ms);
     for (int k = 0; k < b->n; ++k) std::memset(&out[k], 0, sizeof(pagan_result));
@@ -2376,6 +2431,7 @@ void pagan_batch_destroy(pagan_batch *b) {
         gpu_pool.give(b->device, o);
     }
     if (b->arena.dev) arena_pool.give(b->device, b->arena.dev, b->arena.cap);
+    if (b->d_guards) { (void)hipFree(b->d_guards); (void)hipFree(b->d_canary); b->d_guards = nullptr; b->d_canary = nullptr; }
     // What is left is host memory only (plans, band indices, compaction maps: megabytes per alignment, milliseconds of
     // unmapping per level of a tree walk): freed by a background thread, off the caller's path.
     struct Reaper {

@@ -440,6 +440,9 @@ __device__ __forceinline__ void far_fetch8(gdouble_w sc, const FarAsk (&a)[8], p
 // the L2 address of cell (p, d - age), or "not wanted" when it lies outside the band (the caller keeps -inf)
 __device__ __forceinline__ FarAsk far_ask(cdesc8_p psc, int d, int age, int p) {
     const int dd = d - age;
+    // (an operand of a real cell lies on a diagonal >= 0; after an abort the waves run on without waiting for the loader, a
+    //  site record may be another site's, and a distance from it may reach before the first diagonal: no descriptor is read for that)
+    if (dd < 0) { FarAsk none = {false, 0}; return none; }
     pg_i4 ds;
     if (age <= PDR_REACH) ds = PM.dring[dd & (PDR - 1)];
     else if (const int *pd = PM.pdsc) {
