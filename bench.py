@@ -61,7 +61,7 @@ BYTES_PER_CELL = 36            # 3 states x (f64 score + u32 back-pointer), SURV
 # for each other and overlap their intervals -- a number about something else.)
 CHAIN_FLOOR_US = 2 * 8.4 / 2400.0
 STEP_FLOOR_US = 489 / 2400.0
-PMC_PROFILE = os.path.join("profiles", "r04_pmc_fill.json")
+PMC_PROFILE = os.path.join("profiles", "r05_pmc_fill.json")
 KERNELS = ("pg_fill_pipe", "pg_backptr", "pg_fill_tiles_flow", "pg_fill_wavefront")
 
 

@@ -2707,6 +2707,17 @@ __device__ __noinline__ void wide_run7(WaveCtx &C_) {
 #ifdef PG_PIPE_STATS
         const long long st_t1 = __builtin_readcyclecounter();
 #endif
+#ifdef PG_EXP_WIDE_SKIP                                             // timing experiment (WRONG RESULTS): a wide step is its flags and nothing else
+        if (true) {
+            flag_store(&PM.wflag[w7], d);
+            if (w7 < PNW) flag_store(&PM.progress[w7], d);
+            ++d; lo_prev = lo;
+            if (d >= run_end || flag_load(&PM.abort_flag) != 0) break;
+            cur.x = __builtin_amdgcn_readfirstlane(nxt.x); cur.y = __builtin_amdgcn_readfirstlane(nxt.y);
+            cur.z = __builtin_amdgcn_readfirstlane(nxt.z); cur.w = __builtin_amdgcn_readfirstlane(nxt.w);
+            continue;
+        }
+#endif
         if (d > d0) {
             // (row-1, j) on d-1: lane T-1's cell, lane 0 from the wide ring; the band's first row of d-1 has no row above it in
             // the band (for lane 0 as well: the position it read is another row's alias -- wide_run has the story)
