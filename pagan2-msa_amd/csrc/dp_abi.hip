@@ -46,6 +46,12 @@ __global__ void pg_debug_poke_bp(const PgDevJob *jobs, int k, int i, int j, int 
 // limits of the LDS-staged kernel (dp_kernels.hip: RW site window, EC edge ring)
 #define PG_RING_MAX_WIDTH 256
 #define PG_RING_SITE_SPAN 576
+// a diagonal fewer than this behind a wide one is a general step (classify_diagonals); PAGAN_DP_AFTER_WIDE=reach: REACH, as before round 5 (A/B switch)
+static int pg_after_wide() {
+    static const int v = (std::getenv("PAGAN_DP_AFTER_WIDE") && std::strcmp(std::getenv("PAGAN_DP_AFTER_WIDE"), "reach") == 0) ? PG_PIPE_REACH : 3;
+    return v;
+}
+#define PG_AFTER_WIDE pg_after_wide()
 #define PG_RING_EDGE_CAP 2048
 unsigned pg_ring_lds_bytes();
 // limits of the register-wavefront kernel: PG_PIPE_* in dp_device.h, shared with dp_pipe.hip
@@ -212,7 +218,7 @@ void plan_far_hist(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, c
             const int lo = dx.imin[d], hi = dx.imax[d];
             bool c3 = false;
             if (hi - lo + 1 > PG_PIPE_WIDTH) { c3 = true; last_wide = d; }
-            else if (d - last_wide < PG_PIPE_REACH) c3 = true;
+            else if (d - last_wide < PG_AFTER_WIDE) c3 = true;
             else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c3 = true;
             slow[d + 1] = slow[d] + (c3 ? 1 : 0);
         }
@@ -403,11 +409,17 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
             const int run = run_at[d];
             const int lo = dx.imin[d], hi = dx.imax[d];
             uint8_t c;
+            // Behind a wide diagonal (the ring's memory was the wide ring): PG_AFTER_WIDE - 1 general steps -- the first leaves the
+            // lane's cell in registers and in the ring, the second also the shifted cell of the one before, which is what the
+            // hand-scheduled loop starts from --, then the loop again (round 5; it used to be REACH - 1 general steps, ~5.6 us each):
+            // a diagonal less than REACH behind the wide one that holds a multi-edge cell is class 2, and its residency mask
+            // (descriptor word 4) sends the operands older than the general steps to L2 through the assist waves.
+            const bool near_wide = d - last_wide_at[d] < PG_PIPE_REACH;
             if (hi - lo + 1 > PG_PIPE_WIDTH) c = hi - lo + 1 > PG_PIPE_WINDOW ? 5 : 4;
-            else if (d - last_wide_at[d] < PG_PIPE_REACH) c = 3;
+            else if (d - last_wide_at[d] < PG_AFTER_WIDE) c = 3;
             else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c = 3;
             else if (run > 0) c = 2;
-            else if ((lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH) &&
+            else if ((lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH || near_wide) &&
                      (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)) c = 2;
             else if (fl.not_simple[hi + 1] - fl.not_simple[lo] > 0 || fr.not_simple[d - lo + 1] - fr.not_simple[d - hi] > 0)
                 c = (inwave && (ne_l[hi + 1] - ne_l[lo] > 0 || ne_r[d - lo + 1] - ne_r[d - hi] > 0)) ? 2 : 1;
@@ -416,7 +428,7 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
             if (c == 0 && fp.hbit[d]) c = 1;       // a history line's writer (or reader) has a cell here: the step looks at the sites' flags
             // a class 2 diagonal whose operands all lie in the ring (it is class 2 for the shape of a site only): the assist waves
             // take their ring-only code for it
-            if (ring2) (*ring2)[d] = c == 2 && run == 0 && any_at[d] == 0 && !(lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH);
+            if (ring2) (*ring2)[d] = c == 2 && run == 0 && any_at[d] == 0 && !(lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH) && !near_wide;
             (*out)[d] = c;
         }
         // (the windows over the rows with a ring-reaching skip edge only move forward: they restart at the range's first diagonal)
