@@ -233,22 +233,31 @@ void build_rows(pagan_msa *m) {
     }
     const int threads = host_threads_of(m);
     for (const std::vector<int> &ids : by_depth) {
-        parallel_for((int)ids.size(), threads, [&](int r) {
-            const int id = ids[r];
+        // the upper depths hold 1, 2, 4 nodes of 10^5 sites each: a node's sites in `parts` ranges (every site writes its own
+        // column of its own row and its own entries of the children's column maps)
+        const int parts = std::max(1, std::min(threads, (2 * threads) / std::max(1, (int)ids.size())));
+        for (int id : ids)
+            if (id >= n) {
+                const TreeNode &t = m->tree[m->tree_of_id[id]];
+                col[m->id_of_tree[t.left]].assign(m->graph[m->id_of_tree[t.left]]->g.n_sites(), -1);
+                col[m->id_of_tree[t.right]].assign(m->graph[m->id_of_tree[t.right]]->g.n_sites(), -1);
+            }
+        parallel_for((int)ids.size() * parts, threads, [&](int task) {
+            const int id = ids[task / parts], part = task % parts;
             const SeqGraph &g = m->graph[id]->g;
             std::string &row = m->rows[id];
             const std::vector<int32_t> &mine = col[id];
+            const int n_in = g.n_sites() - 2;                      // sites 1 .. n_in
+            const int s_first = 1 + (int)((long long)n_in * part / parts), s_last = 1 + (int)((long long)n_in * (part + 1) / parts);
             if (id < n) {                                          // a leaf: its residues at its columns
-                for (int s = 1; s < g.n_sites() - 1; ++s)
+                for (int s = s_first; s < s_last; ++s)
                     for (int c = 0; c < w; ++c) row[(size_t)mine[s] * w + c] = g.symbols[(size_t)(s - 1) * w + c];
                 return;
             }
             const TreeNode &t = m->tree[m->tree_of_id[id]];
             const int lid = m->id_of_tree[t.left], rid = m->id_of_tree[t.right];
             std::vector<int32_t> &cl = col[lid], &cr = col[rid];
-            cl.assign(m->graph[lid]->g.n_sites(), -1);
-            cr.assign(m->graph[rid]->g.n_sites(), -1);
-            for (int s = 1; s < g.n_sites() - 1; ++s) {
+            for (int s = s_first; s < s_last; ++s) {
                 if (g.child_l[s] >= 0) cl[g.child_l[s]] = mine[s];
                 if (g.child_r[s] >= 0) cr[g.child_r[s]] = mine[s];
                 // the ancestor's own row (get_alignment_column_at with include_internal_nodes, node.cpp:808-818): its

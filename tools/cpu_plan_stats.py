@@ -53,6 +53,9 @@ for k in nodes:
     l, r, m, b = msa.node_job(k)
     Lx, Ly = l.n_sites - 1, r.n_sites - 1
     cls, _ = pg.debug_plan(l, r, b)
+    n_served, _hfl, _hfr, hb_, cls_far = pg.debug_far(l, r, b)       # the batch path's plan: with the far histories and the third pass
+    print("node %d level %d: classes as planned for the kernel %s | served far sites %d, diagonals with a history reader / writer %d, with a third pass %d"
+          % (k, msa.node_info(k).level, np.bincount(cls_far & 15, minlength=6).tolist(), n_served, int((hb_ & 1).sum()), int(((hb_ >> 1) & 1).sum())), flush=True)
     up = np.maximum(b.upper[:Lx].astype(np.int64), 0)
     lw = np.minimum(b.lower[:Lx].astype(np.int64), Ly - 1)
     ii = np.arange(Lx)
@@ -61,7 +64,7 @@ for k in nodes:
     imin = np.searchsorted(ii + lw, d, side="left")
     imax = np.searchsorted(ii + up, d, side="right") - 1
     w = imax - imin + 1
-    print("node %d level %d: nd %d cells %d | classes %s | width mean %.1f p50 %d p90 %d p99 %d max %d | >241: %d, >352: %d"
+    print("node %d level %d: nd %d cells %d | classes without far histories / third pass (pagan_dp_debug_plan) %s | width mean %.1f p50 %d p90 %d p99 %d max %d | >241: %d, >352: %d"
           % (k, msa.node_info(k).level, nd, int(w.sum()), np.bincount(cls & 15, minlength=6).tolist(), w.mean(),
              np.percentile(w, 50), np.percentile(w, 90), np.percentile(w, 99), w.max(), (w > 241).sum(), (w > 352).sum()), flush=True)
     jlo, jhi = d - imax, d - imin
