@@ -945,6 +945,8 @@ void compact_band(const RowBand &rb0, const CompactSide &l, const CompactSide &r
 // (PAGAN_DP_CANARY: guard words behind every region of the arena -- Carver, further down)
 #define PG_CANARY_BYTES 64
 #define PG_CANARY_WORD 0x5ca1ab1eu
+// pagan_dp_align_batch's third attempt (below): the batch is planned again with every wide job on the tiled kernel
+static thread_local bool tl_no_strips = false;
 struct pagan_batch {
     std::vector<CompactJob> compact;
     int n = 0;
@@ -988,6 +990,7 @@ struct pagan_batch {
     std::vector<size_t> guards;
     size_t *d_guards = nullptr;
     int *d_canary = nullptr;                     // [0] guards found changed by the last run, [1] the first of them
+    bool strip_xcd_failure = false;              // pagan_batch_fetch: a strip found the strip above on another XCD in the launch of the strips alone, too
     unsigned canary_word = PG_CANARY_WORD;       // (PAGAN_DP_CANARY=0x...: another pattern -- what a read past a region's end then sees)
     // per-kernel brackets inside the fill (pagan_batch_last_ms_detail): 0/1 around the banded kernel, 2 behind pg_backptr,
     // 3/4 around the tiled kernel (on its own stream when the batch also has banded jobs), 5 behind the HBM wavefront
@@ -1097,7 +1100,7 @@ int validate_job(const pagan_job &jb, HostJob *hj, RowBand *rb, bool use_pipe, i
     // keep in their lanes (plan_strips).  PAGAN_DP_WIDE=tiles keeps every wide job on the tiled kernel (A/B switch).
     {
         const char *we = std::getenv("PAGAN_DP_WIDE");
-        const bool want = !we || std::strcmp(we, "strips") == 0;
+        const bool want = (!we || std::strcmp(we, "strips") == 0) && !tl_no_strips;
         // Models whose table does not fit LDS (S > 16) run as strips only on request (PAGAN_DP_STRIP_STATES = the largest model that
         // does): correct (tests/test_strips_gpu.py) and slower than the tiles from the third level of a tree on -- the assist
         // waves gather a model score for every cell and stage every multi-edge cell with their general code (cfg3: 23.4 -> 57.8 ms).
@@ -1267,10 +1270,10 @@ int launch_fill(pagan_batch *b) {
         HIP_TRY(hipMemsetAsync(b->arena.dev + b->sfollow_begin, 0, b->sfollow_bytes, b->stream));
         if (b->strip_grid > 0)
             hipLaunchKernelGGL((pg_fill_pipe<true, true>), dim3(b->strip_grid), dim3(pg_pipe_block()), 0, b->stream,
-                               b->d_jobs, b->d_swhich, b->flags & ~0x800u, b->strip_grid);
+                               b->d_jobs, b->d_swhich, (b->flags & 0x400u) ? b->flags : (b->flags & ~0x800u), b->strip_grid);
         if (b->strip_grid_big > 0)
             hipLaunchKernelGGL((pg_fill_pipe<false, true>), dim3(b->strip_grid_big), dim3(pg_pipe_block()), 0, b->stream,
-                               b->d_jobs, b->d_swhich + b->strip_grid, b->flags & ~0x800u, b->strip_grid_big);
+                               b->d_jobs, b->d_swhich + b->strip_grid, (b->flags & 0x400u) ? b->flags : (b->flags & ~0x800u), b->strip_grid_big);
     }
     if (b->n_striped > 0 && b->tile_off.size() <= 1) {
         // (the strips' stream: beside the banded kernels, as the tiles')
@@ -2305,6 +2308,10 @@ int pagan_batch_fetch(pagan_batch *b, pagan_result *out) {
         }
     }
     for (int k = 0; k < b->n; ++k) {
+        const int st = *reinterpret_cast<const int *>(ends.data() + kEndStride * (size_t)k);
+        if (b->strips_alone && !b->jobs[k].strips.empty() && (st & 0x40000000) && (st & PG_FILL_OTHER_XCD)) b->strip_xcd_failure = true;
+    }
+    for (int k = 0; k < b->n; ++k) {
         Fetched &f = got[k];
         std::memcpy(f.endcell, ends.data() + kEndStride * (size_t)k, sizeof(f.endcell));
         std::memcpy(&f.endscore, ends.data() + kEndStride * (size_t)k + 32, sizeof(double));
@@ -2487,7 +2494,18 @@ int pagan_dp_align_batch(int32_t n, const pagan_job *jobs, const pagan_opts *opt
     if (rc == PAGAN_OK) rc = pagan_batch_fetch(b, out);
     const double t3 = now();
     if (rc != PAGAN_OK) for (int k = 0; k < n; ++k) pagan_result_free(&out[k]);   // a failed batch hands back nothing
+    // Third attempt (round 4's advisor): row strips are only right when a job's strips run on one XCD, and the launch of the strips
+    // "alone" is alone only within its batch -- another batch, thread or process on the device can still change where workgroups
+    // land.  If that launch failed the same way, the batch is planned again with every wide job on the tiled kernel.
+    const bool no_strips_now = rc == PAGAN_E_INTERNAL && b->strip_xcd_failure && !tl_no_strips;
     pagan_batch_destroy(b);
+    if (no_strips_now) {
+        if (verbose) std::fprintf(stderr, "pagan_dp: the strips alone met another XCD again: the batch once more with its wide jobs on the tiled kernel\n");
+        tl_no_strips = true;
+        rc = pagan_dp_align_batch(n, jobs, opts, out);
+        tl_no_strips = false;
+        return rc;
+    }
     if (verbose)
         std::fprintf(stderr, "pagan_dp: batch of %d: create %.1f ms, kernels %.1f ms, fetch+replay %.1f ms, destroy %.1f ms\n", n,
                      1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (now() - t3));

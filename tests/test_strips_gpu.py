@@ -6,6 +6,7 @@ jobs in one batch, and matrices of one, two and many strips."""
 import numpy as np
 import pytest
 
+import pagan2_msa_amd as pgm
 from pagan2_msa_amd import abi, synth
 
 pytestmark = pytest.mark.gpu
@@ -123,6 +124,23 @@ def test_a_strip_on_another_xcd_runs_the_batch_again_alone(pg, oracle, strips, m
     assert b.debug_reruns() == 1
     b.close()
     same(got, oracle.dp_align(left, right, model))
+
+
+def test_strips_that_fail_alone_too_go_to_the_tiled_kernel(pg, oracle, strips, monkeypatch):
+    """debug flags 0x800 | 0x400: the launch of the strips alone reports another XCD as well.  A resident batch hands the
+    error to its caller; pagan_dp_align_batch plans the batch a third time with every wide job on the tiled kernel and
+    returns that result (round 4's advisor: the 'alone' launch is alone only within its own batch)."""
+    monkeypatch.setenv("PAGAN_DP_DEBUG_FLAGS", "0xc00")
+    left = synth.random_graph(500, 15, 73, p_extra=0.08, max_deg=3, max_span=12)
+    right = synth.random_graph(450, 15, 74, p_extra=0.08, max_deg=3, max_span=12)
+    model = synth.random_model(15, 10)
+    b = pg.Batch([(left, right, model, None)])
+    b.run()
+    with pytest.raises(pgm.PaganError) as e:
+        b.fetch()
+    assert e.value.code == abi.PAGAN_E_INTERNAL and b.debug_reruns() == 1
+    b.close()
+    same(pg.align(left, right, model), oracle.dp_align(left, right, model))
 
 
 @pytest.mark.parametrize("seed", range(6))
