@@ -47,11 +47,10 @@ __global__ void pg_debug_poke_bp(const PgDevJob *jobs, int k, int i, int j, int 
 #define PG_RING_MAX_WIDTH 256
 #define PG_RING_SITE_SPAN 576
 // a diagonal fewer than this behind a wide one is a general step (classify_diagonals); PAGAN_DP_AFTER_WIDE=reach: REACH, as before round 5 (A/B switch)
-static int pg_after_wide() {
-    static const int v = (std::getenv("PAGAN_DP_AFTER_WIDE") && std::strcmp(std::getenv("PAGAN_DP_AFTER_WIDE"), "reach") == 0) ? PG_PIPE_REACH : 3;
-    return v;
+static int pg_after_wide() {      // (read per plan, not once per process: the tests switch it)
+    const char *e = std::getenv("PAGAN_DP_AFTER_WIDE");
+    return (e && std::strcmp(e, "reach") == 0) ? PG_PIPE_REACH : 3;
 }
-#define PG_AFTER_WIDE pg_after_wide()
 #define PG_RING_EDGE_CAP 2048
 unsigned pg_ring_lds_bytes();
 // limits of the register-wavefront kernel: PG_PIPE_* in dp_device.h, shared with dp_pipe.hip
@@ -213,12 +212,13 @@ void plan_far_hist(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, c
     // diagonals that do not run in the hand-scheduled loop whatever the sites are (classify_diagonals has the rules)
     std::vector<int> slow(nd + 1, 0);
     {
+        const int after_wide = pg_after_wide();
         int last_wide = -1000;
         for (int d = 0; d < nd; ++d) {
             const int lo = dx.imin[d], hi = dx.imax[d];
             bool c3 = false;
             if (hi - lo + 1 > PG_PIPE_WIDTH) { c3 = true; last_wide = d; }
-            else if (d - last_wide < PG_AFTER_WIDE) c3 = true;
+            else if (d - last_wide < after_wide) c3 = true;
             else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c3 = true;
             slow[d + 1] = slow[d] + (c3 ? 1 : 0);
         }
@@ -404,19 +404,20 @@ void classify_diagonals(const pagan_graph *L, const pagan_graph *R, int Lx, int 
     std::vector<int> rowsL;
     for (int i = 0; i < Lx; ++i) if (fl.span_ring[i] >= 2) rowsL.push_back(i);
     std::vector<int> need(nd, PG_PIPE_REACH - 1);
+    const int after_wide = pg_after_wide();
     par_ranges(nd, threads, [&](int d_first, int d_last) {
         for (int d = d_first; d < d_last; ++d) {
             const int run = run_at[d];
             const int lo = dx.imin[d], hi = dx.imax[d];
             uint8_t c;
-            // Behind a wide diagonal (the ring's memory was the wide ring): PG_AFTER_WIDE - 1 general steps -- the first leaves the
+            // Behind a wide diagonal (the ring's memory was the wide ring): pg_after_wide() - 1 = two general steps -- the first leaves the
             // lane's cell in registers and in the ring, the second also the shifted cell of the one before, which is what the
             // hand-scheduled loop starts from --, then the loop again (round 5; it used to be REACH - 1 general steps, ~5.6 us each):
             // a diagonal less than REACH behind the wide one that holds a multi-edge cell is class 2, and its residency mask
             // (descriptor word 4) sends the operands older than the general steps to L2 through the assist waves.
             const bool near_wide = d - last_wide_at[d] < PG_PIPE_REACH;
             if (hi - lo + 1 > PG_PIPE_WIDTH) c = hi - lo + 1 > PG_PIPE_WINDOW ? 5 : 4;
-            else if (d - last_wide_at[d] < PG_AFTER_WIDE) c = 3;
+            else if (d - last_wide_at[d] < after_wide) c = 3;
             else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c = 3;
             else if (run > 0) c = 2;
             else if ((lo < PG_PIPE_REACH || d - hi < PG_PIPE_REACH || near_wide) &&
@@ -2041,7 +2042,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
             // 4 diagonal's word: wide_run takes the wide-ring geometry with more positions and fewer rows then.)  Bit 19: the run has
             // at least PG_PIPE_ASSIST diagonals (small tables) -- every assist wave meets one of them, and the run is wide_run7's:
             // the assist waves take rows of their own.  PAGAN_DP_WIDE7=0: every run stays with the four compute waves (A/B switch)
-            static const bool wide7_on = !(std::getenv("PAGAN_DP_WIDE7") && std::strcmp(std::getenv("PAGAN_DP_WIDE7"), "0") == 0);
+            const bool wide7_on = !(std::getenv("PAGAN_DP_WIDE7") && std::strcmp(std::getenv("PAGAN_DP_WIDE7"), "0") == 0);
             std::vector<uint8_t> wide_b(ndg, 0), wide7(ndg, 0);
             for (size_t t = 0; t < ndg;) {
                 if (hj.cls[t] != 4) { ++t; continue; }

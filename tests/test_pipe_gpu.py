@@ -48,6 +48,17 @@ def test_far_edges_general_steps_and_a_wide_box(pg, oracle, seed):
     same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band), "seed %d" % seed)
 
 
+@pytest.mark.parametrize("env", [{"PAGAN_DP_WIDE7": "0"}, {"PAGAN_DP_AFTER_WIDE": "reach"}, {"PAGAN_DP_HIST": "0", "PAGAN_DP_THREE": "0"}])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_wide_boxes_with_the_round_4_paths(pg, oracle, monkeypatch, env, seed):
+    """The A/B switches keep round 4's paths alive: wide runs on the four compute waves only (what short runs still take),
+    REACH - 1 general steps behind a wide run, no far histories / third pass -- each against the oracle on the box jobs."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    left, right, model, band = banded_job(seed, max_span=40)
+    same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band), "seed %d %s" % (seed, env))
+
+
 @pytest.mark.parametrize("seed,p_dead,max_span", [(11, 0.05, 6), (12, 0.2, 6), (13, 0.4, 30), (14, 0.1, 40)])
 def test_sites_without_bwd_edges_stay_on_the_multi_edge_paths(pg, oracle, seed, p_dead, max_span):
     """Upper levels of deep trees: 18-40 % of the sites have no bwd edge (tools/probe_plan.py on cfg5); their

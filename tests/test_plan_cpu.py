@@ -163,6 +163,34 @@ def test_plan_banded_with_long_edges(seed):
     cls, _ = pg.debug_plan(left, right, abi.Band(upper, lower))
     assert set(np.unique(cls)) >= ({2, 3, 4} if seed < 2 else {1, 3, 4})
     assert (5 in cls) == (seed == 3)
+    # the far plan (histories, third pass) the batch path uses has the same general and wide steps
+    cls_far = pg.debug_far(left, right, abi.Band(upper, lower))[4] & 15
+    assert np.array_equal(cls_far == 3, cls == 3) and np.array_equal(cls_far >= 4, cls >= 4)
+
+
+@pytest.mark.parametrize("p_extra", [0.0, 0.3])
+def test_two_general_steps_behind_a_wide_run(p_extra):
+    """Behind a wide run the loop restarts after TWO general steps (the lane's cell and its shifted predecessor are back in
+    registers); until the ring holds REACH - 1 diagonals again a diagonal of simple sites is class 0 and one with any other site class 2
+    (its residency mask sends the older operands to L2), never class 1.  A box in the middle of the matrix, away from its borders."""
+    n = 1300
+    left = synth.random_graph(n, 15, 31, p_extra=p_extra, p_dead=0.0, max_span=6)
+    right = synth.random_graph(n, 15, 32, p_extra=p_extra, p_dead=0.0, max_span=6)
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    centre = np.arange(Lx) * (Ly - 1) // max(Lx - 1, 1)
+    upper = np.maximum(centre - 20, 0); lower = np.minimum(centre + 20, Ly - 1)
+    upper[400:700] = upper[400]; lower[400:700] = lower[699] + 40
+    upper = np.maximum.accumulate(upper); lower = np.maximum.accumulate(lower)
+    upper[0] = 0; lower[-1] = Ly - 1
+    band = abi.Band(upper, lower)
+    for cls in (pg.debug_plan(left, right, band)[0], pg.debug_far(left, right, band)[4] & 15):
+        wide = np.nonzero(cls >= 4)[0]
+        assert len(wide) > 100
+        last = int(wide[-1])
+        assert cls[last + 1] == 3 and cls[last + 2] == 3
+        near = cls[last + 3: last + REACH]
+        assert np.all((near == 0) | (near == 2)) and np.any(near == 2), near       # (these graphs' edges carry weights: no site is "simple")
+        if p_extra == 0.0: assert np.any(cls[last + REACH: last + REACH + 40] == 1)      # ... and class 1 again once the ring is full
 
 
 def test_tile_list_covers_exactly_the_tiles_the_band_touches():
