@@ -213,12 +213,17 @@ void plan_far_hist(const pagan_graph *L, const pagan_graph *R, int Lx, int Ly, c
     std::vector<int> slow(nd + 1, 0);
     {
         const int after_wide = pg_after_wide();
-        int last_wide = -1000;
+        // (round 5) the wide runs and the general steps behind them append to the history lines like the loop does (wide_run7,
+        // wide_run, the kernel's general step): an interval may cross them; only class 5 diagonals -- and the steps behind THOSE --
+        // write no history.  PAGAN_DP_HIST=narrow: as before (A/B).
+        const char *he = std::getenv("PAGAN_DP_HIST");
+        const bool hist_wide = !(he && std::strcmp(he, "narrow") == 0);
+        int last_wide = -1000, last_wide5 = -1000;
         for (int d = 0; d < nd; ++d) {
             const int lo = dx.imin[d], hi = dx.imax[d];
             bool c3 = false;
-            if (hi - lo + 1 > PG_PIPE_WIDTH) { c3 = true; last_wide = d; }
-            else if (d - last_wide < after_wide) c3 = true;
+            if (hi - lo + 1 > PG_PIPE_WIDTH) { c3 = hist_wide ? hi - lo + 1 > PG_PIPE_WINDOW : true; last_wide = d; if (hi - lo + 1 > PG_PIPE_WINDOW) last_wide5 = d; }
+            else if (d - last_wide < after_wide) c3 = !hist_wide || d - last_wide5 < after_wide;
             else if (!(lo >= 2 && hi <= Lx - 2 && d - hi >= 2 && d - lo <= Ly - 2)) c3 = true;
             slow[d + 1] = slow[d] + (c3 ? 1 : 0);
         }

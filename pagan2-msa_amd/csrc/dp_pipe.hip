@@ -1871,6 +1871,15 @@ __device__ __forceinline__ pg_i8 uniform_i8(const pg_i8 &v) {
     PG_V8(21), PG_V8(22), PG_V8(23), PG_V8(24), "v250", "v251", "v252", "v253", "v254", "v255", \
     "s36", "s37", "s38", "s39", PG_S8(4), PG_S8(5), PG_S8(6), PG_S8(7), "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87"
 
+// Far histories outside the hand-scheduled loop (round 5): the wide runs and the general steps append the cells of a line's row /
+// column as the loop's writers do (tools/gen_hot_asm.py, hist_tail: the lane that holds the cell, in-band lanes only; a row's line
+// is indexed by column, a column's by row), so that a history interval may cross them (dp_abi.hip, plan_far_hist).  gl / gr: the
+// cell's site records (PR_SRC: bit 24, the line in bits 25-26).
+__device__ __forceinline__ void hist_append(const pg_i4 &gl, const pg_i4 &gr, int r, int j, double bx, double by, double bm) {
+    if (gl.x & PR_SRC) { double *h = &PM.hist[(gl.x >> 25) & 3][j & 63][0]; h[PG_X] = bx; h[PG_Y] = by; h[PG_M] = bm; }
+    if (gr.x & PR_SRC) { double *h = &PM.hist[(gr.x >> 25) & 3][r & 63][0]; h[PG_X] = bx; h[PG_Y] = by; h[PG_M] = bm; }
+}
+
 // ---- hot run (model table in LDS): the diagonals from d on while their class is 0, 1 or 2 ----
 // One iteration per diagonal.  Across iterations only the lane's cell of the previous diagonal (P), the shifted
 // cell of the diagonal before (C) and the operand pipeline (row record, two column records, model score) live in
@@ -2531,6 +2540,7 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
                          [&](int k, int &q_, double &rw) { int dist; edge_at<false>(gr_, k, j, dist, rw); q_ = j - dist; },
                          bx, by, bm, px, py, pm);
             }
+            if (__any(active && ((gl[q].x | gr[q].x) & PR_SRC))) { if (active) hist_append(gl[q], gr[q], r, j, bx, by, bm); }
             if (r < lo + wpos_n) {                                   // (a second row 384 and more past the band's first: never in the band, and its position is another row's)
                 double *o = (double *)((char *)&PM.sc[0][0][0] + wsb + wpos(r) * 24);
                 o[PG_X] = bx; o[PG_Y] = by; o[PG_M] = bm;
@@ -2832,6 +2842,7 @@ __device__ __noinline__ void wide_run7(WaveCtx &C_) {
             double *o = (double *)((char *)&PM.sc[0][0][0] + wsb + wpos(wr) * 24);
             o[PG_X] = bx; o[PG_Y] = by; o[PG_M] = bm;
         }
+        if (__any(kind != 0 && ((gl.x | gr.x) & PR_SRC))) { if (kind != 0) hist_append(gl, gr, r, j, bx, by, bm); }
         if (wpos_n > PW7L && wr < lo + wpos_n - PW7L) {           // (512 positions, 448 lanes: the positions of the rows lo + 448 .. lo + 511 -- -inf,
             double *o = (double *)((char *)&PM.sc[0][0][0] + wsb + wpos(wr + PW7L) * 24);      //  what a read above an older diagonal's band lands on)
             o[PG_X] = NIw; o[PG_Y] = NIw; o[PG_M] = NIw;
@@ -3445,6 +3456,8 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
                 if (active) gen_cell(d, slot, resmask, row, j, bx, by, bm, px, py, pm);
 #endif
                 commit_cell(sc_out, bp_out, cur, slot, tid, row - lo, active, bx, by, bm, px, py, pm);
+                if (TAB_LDS && !STRIP && (cur.s4 & 32) && active)      // (a history interval crosses this general step: hist_append)
+                    hist_append(PM.recL[row & (PRW - 1)], PM.recR[j & (PRW - 1)], row, j, bx, by, bm);
             } else if (cls == 4) {
                 // ---- wider than the lanes, but inside the record windows: every lane takes its rows row, row+256,
                 // ...; cells come from L2 (all waves are here and drained), simple interior cells with their
