@@ -2672,22 +2672,45 @@ __device__ __noinline__ void wide_run7(WaveCtx &C_) {
         const int r = wr < lo ? wr + PW7L : wr, j = d - r;
         int kind = 0;                                           // 0 outside the band, 1 batched, 2 general rules
         pg_i4 gl = {0, 0, 0, 0}, gr = {0, 0, 0, 0};
-        bool l2 = false, r2 = false, lS = false, rS = false;
-        int kL = 0, kR = 0;
+        bool l2 = false, r2 = false, l3 = false, r3 = false;   // the site has an other edge / a second other edge (three edges: the third pass below)
+        int kL = 1, kR = 1, kL3 = 1, kR3 = 1;
+        double lwA = 0, lwS = 0, lwT = 0, rwA = 0, rwS = 0, rwT = 0;       // log weights: the previous-site edge's, the other edge's, the second other edge's
         double tM = 0, tX = 0;
         if (r <= hi) {
             gl = PM.recL[r & (PRW - 1)]; gr = PM.recR[j & (PRW - 1)];
             const int nl = (gl.x >> PR_NE_SHIFT) & 127, nr = (gr.x >> PR_NE_SHIFT) & 127;
-            const int dl0 = gl.y & 0xffff, dl1 = (int)((unsigned)gl.y >> 16), dr0 = gr.y & 0xffff, dr1 = (int)((unsigned)gr.y >> 16);
-            const bool easyL = nl == 1 ? dl0 == 1 : (nl == 2 && (dl0 == 1) != (dl1 == 1));
-            const bool easyR = nr == 1 ? dr0 == 1 : (nr == 2 && (dr0 == 1) != (dr1 == 1));
-            const bool l2_ = nl == 2, r2_ = nr == 2;
-            const bool lS_ = l2_ && dl0 != 1, rS_ = r2_ && dr0 != 1;               // the other edge is listed first
-            kL = lS_ ? dl0 : dl1; kR = rS_ ? dr0 : dr1;
+            // one site's edges: exactly one from the previous site, beside it none, one or two others (three edges: the third from
+            // the edge window, rare -- one site in a thousand at the top of cfg4's tree, but half of the root's wide diagonals hold one,
+            // and the general rules it used to take are a loop of single fetches)
+            auto shape = [&](auto left_tag, const pg_i4 &rec, int site, int n, bool &two, bool &three, int &k1, int &k3, double &wA, double &w1, double &w3) -> bool {
+                constexpr bool LEFT = decltype(left_tag)::value;
+                const int e0 = rec.y & 0xffff, e1 = (int)((unsigned)rec.y >> 16);
+                const double f0 = (double)__int_as_float(rec.z), f1 = (double)__int_as_float(rec.w);
+                two = false; three = false; k1 = 1; k3 = 1; wA = f0; w1 = 0.0; w3 = 0.0;
+                if (n == 1) return e0 == 1;
+                if (n == 2) {
+                    two = true;
+                    if (e0 == 1) { wA = f0; k1 = e1; w1 = f1; } else { wA = f1; k1 = e0; w1 = f0; }
+                    return (e0 == 1) != (e1 == 1);
+                }
+                if (n == 3) {
+                    int e2; double f2;
+                    edge_at<LEFT>(rec, 2, site, e2, f2);
+                    two = true; three = true;
+                    if (e0 == 1) { wA = f0; k1 = e1; w1 = f1; k3 = e2; w3 = f2; }
+                    else if (e1 == 1) { wA = f1; k1 = e0; w1 = f0; k3 = e2; w3 = f2; }
+                    else { wA = f2; k1 = e0; w1 = f0; k3 = e1; w3 = f1; }
+                    return ((e0 == 1) + (e1 == 1) + (e2 == 1)) == 1;
+                }
+                return false;
+            };
+            bool l2_, l3_, r2_, r3_;
+            const bool easyL = shape(std::true_type(), gl, r, nl, l2_, l3_, kL, kL3, lwA, lwS, lwT);
+            const bool easyR = shape(std::false_type(), gr, j, nr, r2_, r3_, kR, kR3, rwA, rwS, rwT);
             // interior, and no edge in reach starts at site 0 (where the gap-open term differs)
-            const bool inner = r >= 2 && r <= Lx - 2 && j >= 2 && j <= Ly - 2 && (!l2_ || r - kL >= 1) && (!r2_ || j - kR >= 1);
-            kind = (easyL && easyR && inner) ? 1 : 2;
-            if (kind == 1) { l2 = l2_; r2 = r2_; lS = lS_; rS = rS_; }
+            const bool inner = r >= 2 && r <= Lx - 2 && j >= 2 && j <= Ly - 2 && r - kL >= 1 && j - kR >= 1 && r - kL3 >= 1 && j - kR3 >= 1;
+            kind = (easyL && easyR && inner && !(l3_ && r3_)) ? 1 : 2;
+            if (kind == 1) { l2 = l2_; r2 = r2_; l3 = l3_; r3 = r3_; }
             if (r > 0 && j > 0 && nl > 0 && nr > 0) {
                 const int ti_ = ((gl.x & 0xffff) + __umul24(gr.x & 0xffff, S)) & 255;
                 tM = PM.tab2[ti_][0]; tX = PM.tab2[ti_][1];
@@ -2796,9 +2819,6 @@ __device__ __noinline__ void wide_run7(WaveCtx &C_) {
         double bx = NIw, by = NIw, bm = NIw;
         unsigned px = PG_BP_NONE, py = PG_BP_NONE, pm = PG_BP_NONE;
         if (kind == 1) {
-            const double lw0 = (double)__int_as_float(gl.z), lw1 = (double)__int_as_float(gl.w);
-            const double rw0 = (double)__int_as_float(gr.z), rw1 = (double)__int_as_float(gr.w);
-            const double lwA = lS ? lw1 : lw0, lwS = lS ? lw0 : lw1, rwA = rS ? rw1 : rw0, rwS = rS ? rw0 : rw1;
             const pg_d2 lx_ = o_xy[3], lm_ = o_xy[4], ry_ = o_xy[5], rm_ = o_xy[6], lr_ = o_xy[7];
             const double lxm = o_m[3], lmm = o_m[4], rym = o_m[5], rmm = o_m[6], lrm = o_m[7];
             // scores only (pg_backptr derives the back-pointers); the reference's candidates with the maxima regrouped
@@ -2818,6 +2838,32 @@ __device__ __noinline__ void wide_run7(WaveCtx &C_) {
                 bx = __builtin_fmax(bx, gapv(lx_.x, lx_.y, lxm));
                 bm = __builtin_fmax(bm, pairv(lm_.x, lm_.y, lmm, lwS, rwA));
                 if (__any(l2 && r2)) bm = __builtin_fmax(bm, pairv(lr_.x, lr_.y, lrm, lwS, rwS));
+            }
+            // ---- third pass: a site's SECOND other edge (three-edge sites; not on both sides of a cell).  Its gap candidate, its pair
+            // with the other side's previous-site edge and -- if the other side has an other edge -- with that: three operand cells,
+            // from the wide ring or, past it, from L2 in one fetch ----
+            if (__any(l3 || r3)) {
+                const bool t3 = l3 || r3;
+                const int k3 = l3 ? kL3 : kR3;
+                const bool needC = l3 ? r2 : (r3 && l2);
+                pg_d2 txy[3]; double tm_[3];
+                const FarAsk fA = wcell(t3, k3, l3 ? r - kL3 : r, txy[0], tm_[0]);
+                const FarAsk fB = wcell(t3, k3 + 1, l3 ? r - kL3 : r - 1, txy[1], tm_[1]);
+                const FarAsk fC = wcell(needC, l3 ? kL3 + kR : kL + kR3, l3 ? r - kL3 : r - kL, txy[2], tm_[2]);
+                {
+                    const FarAsk none = {false, 0};
+                    pg_d2 e = {NIw, NIw}; double me = NIw;
+                    far_fetch4(sc_out, fA, fB, fC, none, txy[0], tm_[0], txy[1], tm_[1], txy[2], tm_[2], e, me);
+                }
+                if (l3) {
+                    bx = __builtin_fmax(bx, gapv(txy[0].x, txy[0].y, tm_[0]));
+                    bm = __builtin_fmax(bm, pairv(txy[1].x, txy[1].y, tm_[1], lwT, rwA));
+                    bm = __builtin_fmax(bm, pairv(txy[2].x, txy[2].y, tm_[2], lwT, rwS));      // (-inf without the other side's other edge)
+                } else if (r3) {
+                    by = __builtin_fmax(by, gapv(txy[0].y, txy[0].x, tm_[0]));
+                    bm = __builtin_fmax(bm, pairv(txy[1].x, txy[1].y, tm_[1], lwA, rwT));
+                    bm = __builtin_fmax(bm, pairv(txy[2].x, txy[2].y, tm_[2], lwS, rwT));
+                }
             }
         } else if (kind == 2) {
             // first/last rows and columns, sites without edges, more than two edges, ...: the general rules
