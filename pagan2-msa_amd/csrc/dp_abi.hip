@@ -2058,6 +2058,14 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
                 if (wide7_on && !big_table && e - t >= (size_t)PG_PIPE_ASSIST) for (size_t q = t; q < e; ++q) wide7[q] = 1;
                 t = e;
             }
+            // ... and the runs of class 5 diagonals (widest_run7: the same cells over 448 lanes)
+            for (size_t t = 0; t < ndg && wide7_on && !big_table;) {
+                if (hj.cls[t] != 5) { ++t; continue; }
+                size_t e = t;
+                while (e < ndg && hj.cls[e] == 5) ++e;
+                if (e - t >= (size_t)PG_PIPE_ASSIST) for (size_t q = t; q < e; ++q) wide7[q] = 1;
+                t = e;
+            }
             std::vector<int> hop(ndg, 0);
             for (size_t t = ndg; t-- > 0;) {
                 const size_t nx = t + PG_PIPE_ASSIST;

@@ -746,14 +746,14 @@ __device__ __forceinline__ int ring_back(int sb, int age) {
 
 // A class 5 step: out of line -- it is rare, and the kernel is as large as the instruction cache.
 __device__ __attribute__((noinline)) void widest_step(const PgDevJob *job, cdesc8_p psc, int d, int lo, int hi, int tid,
-                                                      bool no_terminal_edges, bool reduced_terminal) {
+                                                      bool no_terminal_edges, bool reduced_terminal, int stride = PNT) {
     const View J = load_view(job);
     const pg_i8 cur = psc[d];
     const pg_i8 p1 = psc[d > 0 ? d - 1 : 0], p2 = psc[d > 1 ? d - 2 : 0];
     const Diag g1 = {p1.x, d > 0 ? p1.y : p1.x - 1, ((long long)p1.s6 << 32) | (unsigned)p1.s5};
     const Diag g2 = {p2.x, d > 1 ? p2.y : p2.x - 1, ((long long)p2.s6 << 32) | (unsigned)p2.s5};
     const long long base = ((long long)cur.s6 << 32) | (unsigned)cur.s5;
-    for (int i = lo + tid; i <= hi; i += PNT)
+    for (int i = lo + tid; i <= hi; i += stride)
         fill_cell_hbm(J, d, g1, g2, i, d - i, base + (i - lo), no_terminal_edges, reduced_terminal);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1265,7 +1265,7 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
             const int bx = __builtin_amdgcn_readlane(q_next, 8), by = __builtin_amdgcn_readlane(q_next, 9), bs4 = __builtin_amdgcn_readlane(q_next, 12);
             const int hop_a = (int)((unsigned)as4 >> 20);           // the host's hop count: straight to this wave's next diagonal with work
             // a seven-wave wide run (class 4, bit 19: every diagonal of such a run is a stop of the hop counts): this wave takes its rows
-            if (!STRIP && (as4 & 15) == 4 && (as4 & (1 << 19))) { wide_at = d; return; }
+            if (!STRIP && ((as4 & 15) == 4 || (as4 & 15) == 5) && (as4 & (1 << 19))) { wide_at = d; return; }
             if ((as4 & CLS) != 2) { scan_d += PNA * hop_a; q_next = desc_req(scan_d); continue; }     // (class 0 / 1: the compute waves' own)
             const bool pair_d = hop_a == 1 && d2 < nd && (bs4 & CLS) == 2;              // the descriptors allow two diagonals
             // bit 4 marks a class 2 diagonal whose operands all lie in the ring (class 2 for the shape of a site): no residency test
@@ -1528,7 +1528,8 @@ __device__ __noinline__ void pipe_assist_lean(const PgDevJob *__restrict__ job, 
         if (wide_at >= 0) {
             // the run's first diagonal: this wave stopped at the first one of its residue, at most two behind it
             int d0 = wide_at;
-            for (int k = 0; k < PNA - 1 && d0 > 0; ++k) { if ((psc[d0 - 1].s4 & 15) == 4) --d0; else break; }
+            const int run_cls = psc[wide_at].s4 & 15;              // (a run of class 4 may follow one of class 5 directly, or the other way)
+            for (int k = 0; k < PNA - 1 && d0 > 0; ++k) { if ((psc[d0 - 1].s4 & 15) == run_cls) --d0; else break; }
             const pg_i4 back = assist_wide_run(job, psc, a, lane, flags, d0, rows_ld, cols_ld, diags_ld);
             const int e = __builtin_amdgcn_readfirstlane(back.x);
             rows_ld = __builtin_amdgcn_readfirstlane(back.y); cols_ld = __builtin_amdgcn_readfirstlane(back.z); diags_ld = __builtin_amdgcn_readfirstlane(back.w);
@@ -2936,6 +2937,75 @@ __device__ __noinline__ void wide_run7(WaveCtx &C_) {
     WCTX_OUT(C_);
 }
 
+// ---- seven-wave run of class 5 diagonals (wider than the record windows: every operand, graph arrays included, from L2) ----
+// widest_step's cells over 448 lanes instead of 256: a diagonal of 433 .. 922 cells is two passes instead of three or four, and a
+// pass is four dependent trips to L2.  Same entry / exit rendezvous and flags as wide_run7; a step starts when EVERY wave has
+// completed the one before with its stores retired (each waits for its own before its flag), as the kernel's general steps do
+// among the four compute waves.  The host marks runs of at least three such diagonals (bit 19, as for class 4).
+__device__ __noinline__ void widest_run7(WaveCtx &C_) {
+    WCTX_IN(C_);
+    WCTX_STATS(C_);
+    const PgDevJob *__restrict__ job = (const PgDevJob *)uniform_u64((unsigned long long)C_.job);
+    const unsigned flags_ = __builtin_amdgcn_readfirstlane(C_.flags);
+    const bool no_terminal_edges = flags_ & 1u, reduced_terminal = !(flags_ & 2u);
+    pg_i8 dA = uniform_i8(C_.dA);
+    const int d0 = d;
+    const int lane = tid & 63, w7 = wave;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flag_store(&PM.wflag[w7], d0 - 1);
+    flag_store(&PM.warrived[w7], d0);
+    for (int w = 0; w < PW7; ++w) POLLX(&PM.warrived[w], d0, 7);
+    p_up = d0 - 1 > p_up ? d0 - 1 : p_up;
+    p_dn = d0 - 1 > p_dn ? d0 - 1 : p_dn;
+    int run_end = d0 + 1;
+    for (;;) {
+        const int t = run_end + lane;
+        const int c5 = ((PG_GLOBAL const int *)psc)[8 * (t < nd ? t : nd) + 4] & 15;      // (the array carries one entry of padding: class 0)
+        const unsigned long long stop = __builtin_amdgcn_ballot_w64(t >= nd || c5 != 5);
+        if (stop != 0) { run_end += __builtin_ctzll(stop); break; }
+        run_end += 64;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (;;) {
+        {   // every wave has completed d - 1 (and retired its stores before saying so)
+            int spins = 0;
+            for (;;) {
+                const int v = lane < PW7 ? flag_peek(&PM.wflag[lane]) : 0x7fffffff;
+                if (__builtin_amdgcn_ballot_w64(v < d - 1) == 0) break;
+                if ((++spins & 15) == 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (spins > PSPIN_LIMIT || flag_load(&PM.abort_flag) != 0) {
+                        if (flag_load(&PM.abort_flag) == 0) flag_store(&PM.abort_flag, PTAG(6));
+                        break;
+                    }
+                }
+            }
+        }
+        const pg_i8 cur = psc[d];
+#ifdef PG_PIPE_STATS
+        const long long st_step0 = __builtin_readcyclecounter();
+#endif
+#ifndef PG_EXP_WIDEST_SKIP                                          // (timing experiment, WRONG RESULTS: a class 5 step is its flags and nothing else)
+        widest_step(job, psc, d, cur.x, cur.y, tid, no_terminal_edges, reduced_terminal, PW7L);
+#endif
+        flag_store(&PM.wflag[w7], d);
+        if (w7 < PNW) flag_store(&PM.progress[w7], d);
+#ifdef PG_PIPE_STATS
+        if (w7 < PNW) { st_cls_t[4] += __builtin_readcyclecounter() - st_step0; ++st_cls_n[4]; }
+#endif
+        ++d;
+        if (d >= run_end || flag_load(&PM.abort_flag) != 0) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flag_store(&PM.warrived[w7], d);
+    for (int w = 0; w < PW7; ++w) POLLX(&PM.warrived[w], d, 7);
+    dA = psc[d];                                                   // (the array carries one entry of padding)
+    row = dA.x + ((tid - dA.x) & (PNT - 1));
+    ok_until = d - 1;
+    C_.dA = dA;
+    WCTX_OUT(C_);
+}
+
 __device__ __noinline__ pg_i4 assist_wide_run(const PgDevJob *__restrict__ job, cdesc8_p psc, int a, int lane, unsigned flags, int d0,
                                               int rows_ld, int cols_ld, int diags_ld) {
     WaveCtx C_;
@@ -2954,7 +3024,7 @@ __device__ __noinline__ pg_i4 assist_wide_run(const PgDevJob *__restrict__ job, 
     for (int k = 0; k < 10; ++k) { C_.st_poll_t[k] = 0; C_.st_poll_n[k] = 0; }
     for (int k = 0; k < 4; ++k) C_.st_w[k] = 0;
 #endif
-    wide_run7(C_);
+    if ((C_.dA.s4 & 15) == 5) widest_run7(C_); else wide_run7(C_);
     return pg_i4{C_.d, C_.rows_ld, C_.cols_ld, C_.diags_ld};
 }
 
@@ -3619,7 +3689,7 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
             st_t = __builtin_readcyclecounter();
             if (st_on) st_n += 2;
 #endif
-            if (TAB_LDS && (STRIP ? (dA.s4 & 7) <= 2 : ((dA.s4 & 15) <= 2 || (dA.s4 & 15) == 4))) {      // model table in LDS: classes 0..2 and 4 run as functions of their own
+            if (TAB_LDS && (STRIP ? (dA.s4 & 7) <= 2 : ((dA.s4 & 15) <= 2 || (dA.s4 & 15) == 4 || ((dA.s4 & 15) == 5 && (dA.s4 & (1 << 19)))))) {      // model table in LDS: classes 0..2, 4 and seven-wave runs of 5 as functions of their own
                 WaveCtx C_;
                 C_.job = job; C_.psc = psc; C_.sc_out = sc_out; C_.bp_out = bp_out;
                 C_.go = go; C_.ng = ng; C_.ge = ge; C_.tng2 = tng2; C_.tng1 = tng1;
@@ -3635,7 +3705,8 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
                 for (int k = 0; k < 10; ++k) { C_.st_poll_t[k] = st_poll_t[k]; C_.st_poll_n[k] = st_poll_n[k]; }
                 for (int k = 0; k < 4; ++k) C_.st_w[k] = st_w[k];
 #endif
-                if (!STRIP && (dA.s4 & 15) == 4) { if (dA.s4 & (1 << 19)) wide_run7(C_); else wide_run(C_); } else hot_run<STRIP>(C_);
+                if (!STRIP && (dA.s4 & 15) == 5) widest_run7(C_);
+                else if (!STRIP && (dA.s4 & 15) == 4) { if (dA.s4 & (1 << 19)) wide_run7(C_); else wide_run(C_); } else hot_run<STRIP>(C_);
 #ifdef PG_PIPE_STATS
                 for (int k = 0; k < 5; ++k) { st_cls_t[k] = C_.st_cls_t[k]; st_cls_n[k] = C_.st_cls_n[k]; }
                 for (int k = 0; k < 10; ++k) { st_poll_t[k] = C_.st_poll_t[k]; st_poll_n[k] = C_.st_poll_n[k]; }
