@@ -834,11 +834,13 @@ def step(E, k):
     a(".Lpg_extra%s:" % sfx)
     a("s_bitcmp1_b32 s%d, 19" % s4)
     a("s_cbranch_scc0 .Lpg_hist%s" % sfx)
-    third_pass(E, k)
+    if "t" not in EXP:           # (timing experiment 't', WRONG RESULTS: no third pass)
+        third_pass(E, k)
     a("s_bitcmp1_b32 s%d, 5" % s4)
     a("s_cbranch_scc0 .Lpg_nohist%s" % sfx)
     a(".Lpg_hist%s:" % sfx)
-    hist_tail(E, k, cls2=False)
+    if "h" not in EXP:           # (timing experiment 'h', WRONG RESULTS: no history readers / writers on class 1 diagonals)
+        hist_tail(E, k, cls2=False)
     a(".Lpg_nohist%s:" % sfx)
     next_desc()
     a("s_branch .Lpg_commit%s" % sfx)
