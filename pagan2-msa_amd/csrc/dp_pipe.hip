@@ -2404,7 +2404,9 @@ __device__ __noinline__ void wide_run(WaveCtx &C_) {
             xy.x = NIw; xy.y = NIw; m = NIw;
             // (a row above the previous diagonal's band: -inf without looking -- its position in the wide ring is the alias of a row
             //  far below the band, which a wave other than the one above this one writes, and that wave need not have completed d-1)
-            if (!need || (age == 1 && p_ < lo_prev)) return f;
+            // (not on the run's first diagonal: lo_prev is the previous diagonal's first row from the second step on, and the first
+            //  step's operands all come from L2, where the descriptor says what lies in the band)
+            if (!need || (age == 1 && d > d0 && p_ < lo_prev)) return f;
             if (age <= amax) {
                 int rb = wsb - age * wrow_bytes;
                 rb += rb < 0 ? wk * wrow_bytes : 0;
@@ -2770,7 +2772,9 @@ __device__ __noinline__ void wide_run7(WaveCtx &C_) {
             xy.x = NIw; xy.y = NIw; m = NIw;
             // (a row above the previous diagonal's band: -inf without looking -- its position in the wide ring is the alias of a row
             //  far below the band, which a wave other than the one above this one writes, and that wave need not have completed d-1)
-            if (!need || (age == 1 && p_ < lo_prev)) return f;
+            // (not on the run's first diagonal: lo_prev is the previous diagonal's first row from the second step on, and the first
+            //  step's operands all come from L2, where the descriptor says what lies in the band)
+            if (!need || (age == 1 && d > d0 && p_ < lo_prev)) return f;
             if (age <= amax) {
                 int rb = wsb - age * wrow_bytes;
                 rb += rb < 0 ? wk * wrow_bytes : 0;

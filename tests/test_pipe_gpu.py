@@ -48,6 +48,41 @@ def test_far_edges_general_steps_and_a_wide_box(pg, oracle, seed):
     same(pg.align(left, right, model, band), oracle.dp_align(left, right, model, band), "seed %d" % seed)
 
 
+def sweep_case(seed, case):
+    """the job tests/diagnostics/sweep_parity.py makes for (PG_SWEEP_SEED, case)"""
+    rng = np.random.default_rng(seed + case)
+    n = int(rng.integers(150, 1400))
+    span = int(rng.choice([4, 8, 17, 19, 25, 40, 80]))
+    p_extra = float(rng.choice([0.02, 0.08, 0.3]))
+    left = synth.random_graph(n, 15, 3000 + case, p_extra=p_extra, max_deg=int(rng.integers(2, 5)), max_span=span, p_dead=float(rng.choice([0, 0, 0.01])))
+    right = synth.random_graph(n + int(rng.integers(-40, 60)), 15, 4000 + case, p_extra=p_extra, max_deg=int(rng.integers(2, 5)), max_span=span)
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    half = rng.integers(3, 60, Lx)
+    centre = np.arange(Lx) * (Ly - 1) // max(Lx - 1, 1)
+    upper = np.maximum.accumulate(np.maximum(centre - half, 0))
+    lower = np.maximum.accumulate(np.minimum(centre + half, Ly - 1))
+    for _ in range(int(rng.integers(0, 3))):
+        a = int(rng.integers(10, max(11, Lx - 450))); rows = int(rng.integers(30, 440)); jump = int(rng.integers(30, 460))
+        b = min(a + rows, Lx - 1)
+        upper[a:b] = upper[a]; lower[a:b] = min(lower[b - 1] + jump, Ly - 1)
+    upper = np.maximum.accumulate(upper); lower = np.maximum.accumulate(lower)
+    upper[0] = 0; lower[-1] = Ly - 1
+    flags = int(rng.choice([0, 0, abi.OPT_NO_TERMINAL_EDGES, abi.OPT_NO_REDUCED_TERMINAL_PEN]))
+    return left, right, synth.random_model(15, case), abi.Band(upper, lower), flags
+
+
+def test_a_wide_run_whose_first_row_moved_on_its_first_diagonal(pg, oracle):
+    """Found by a fresh seed of the sweep (5000 / 739) at the end of round 5: a run of class 4 diagonals directly behind a run of
+    class 5 ones, the band's first row one further than on the diagonal before, and in that row a cell of the general rules (the
+    last column).  "A row above the previous diagonal's band reads -inf" compared with the run's own first row on the run's
+    first diagonal and dropped the cell's operand (i-1, j)."""
+    left, right, model, band, flags = sweep_case(5000, 739)
+    cls = pg.debug_far(left, right, band)[4] & 15
+    first4 = [d for d in range(1, len(cls)) if cls[d] == 4 and cls[d - 1] == 5]
+    assert first4, "the case is meant to have a class 4 run directly behind a class 5 run"
+    same(pg.align(left, right, model, band, flags=flags), oracle.dp_align(left, right, model, band, flags=flags))
+
+
 @pytest.mark.parametrize("env", [{"PAGAN_DP_WIDE7": "0"}, {"PAGAN_DP_AFTER_WIDE": "reach"}, {"PAGAN_DP_HIST": "0", "PAGAN_DP_THREE": "0"}])
 @pytest.mark.parametrize("seed", [0, 1])
 def test_wide_boxes_with_the_round_4_paths(pg, oracle, monkeypatch, env, seed):
