@@ -13,7 +13,7 @@ from pagan2_msa_amd import abi, synth
 import oracle
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-rng = np.random.default_rng(54321)
+rng = np.random.default_rng(int(os.environ.get("PG_STRESS_SEED", "54321")))   # (PG_STRESS_SEED: another stream of batches)
 bad = 0
 for rd in range(rounds):
     jobs = []

@@ -11,7 +11,7 @@ from pagan2_msa_amd import abi, synth
 import oracle
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(os.environ.get("PG_STRESS_SEED", "12345")))   # (PG_STRESS_SEED: another stream of batches)
 bad = 0
 for rd in range(rounds):
     jobs = []
