@@ -5,7 +5,8 @@ No GPU: pagan_dp_debug_far is host code.  Invariants the kernel's hist_tail / th
     carries the writer flag with the SAME line; two pairs whose intervals overlap never share a line unless they share the
     start site;
   * the flagged diagonals (bit 0 of hbit) cover every diagonal from the start site's first cell to the far site's last, and all
-    of them run in the hand-scheduled loop (class <= 2);
+    of them run where the writers' cells are appended to the line: the hand-scheduled loop (class <= 2), a wide run (class 4:
+    wide_run7 / wide_run) or one of the two general steps behind one (hist_append) -- never a class 5 diagonal;
   * a cell where a served far site meets a site with an other edge of its own lies on a class 2 diagonal (the pair of the two
     other edges is nobody's in the lanes);
   * the third-pass bit is only set on class 1 diagonals that hold a three-edge site with one edge from the previous site and
@@ -67,7 +68,9 @@ def test_far_history_plan_invariants(seed):
             rows_src = np.nonzero((lo <= src) & (src <= hi))[0]; rows_s = np.nonzero((lo <= s) & (s <= hi))[0]
             d0, d1 = int(rows_src[0]) + src, int(rows_s[-1]) + s
         assert (hb[d0:d1 + 1] & 1).all(), "every diagonal of the pair's life is flagged"
-        assert (cls[d0:d1 + 1] <= 2).all(), "... and runs in the hand-scheduled loop"
+        assert (cls[d0:d1 + 1] != 5).all(), "... and none of them is a class 5 diagonal (nobody appends there)"
+        for d in np.nonzero(cls[d0:d1 + 1] == 3)[0] + d0:
+            assert (cls[max(d - 2, 0):d] == 4).any(), "a general step inside an interval is one of the two behind a wide run"
         intervals.append((d0, d1, int(hf[s] & 3), is_left, src))
         # crossings: where the far site meets a site with an other edge of its own
         if is_left:
@@ -83,6 +86,31 @@ def test_far_history_plan_invariants(seed):
             x, y = intervals[a], intervals[b]
             if x[2] == y[2] and not (x[1] < y[0] or y[1] < x[0]):
                 assert x[3] == y[3] and x[4] == y[4], "two pairs share a line at the same time only through their start site"
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_an_interval_may_cross_a_wide_run(seed, monkeypatch):
+    """A box wider than the lanes in the middle of the band: far sites whose life crosses its wide run keep their line (the wide
+    runs append the writers' cells); with PAGAN_DP_HIST=narrow, as before round 5's item 11, they have none."""
+    rng = np.random.default_rng(50 + seed)
+    n = 1800
+    left = synth.random_graph(n, 15, 300 + seed, p_extra=0.03, max_deg=3, max_span=30)
+    right = synth.random_graph(n, 15, 400 + seed, p_extra=0.03, max_deg=3, max_span=30)
+    Lx, Ly = left.n_sites - 1, right.n_sites - 1
+    centre = np.arange(Lx) * (Ly - 1) // max(Lx - 1, 1)
+    upper = np.maximum(centre - 25, 0); lower = np.minimum(centre + 25, Ly - 1)
+    upper[600:900] = upper[600]; lower[600:900] = lower[899] + 30
+    upper = np.maximum.accumulate(upper); lower = np.maximum.accumulate(lower)
+    upper[0] = 0; lower[-1] = Ly - 1
+    band = abi.Band(upper, lower)
+    n_all, hfl, hfr, hb, cls = pg.debug_far(left, right, band)
+    cls = cls & 15
+    assert (cls == 4).sum() > 100 and not (cls == 5).any()
+    crossing = int(((hb & 1) != 0)[cls == 4].sum())
+    assert crossing > 0, "some served interval is meant to cross the wide run"
+    monkeypatch.setenv("PAGAN_DP_HIST", "narrow")
+    n_narrow, _, _, hb2, cls2 = pg.debug_far(left, right, band)
+    assert n_narrow < n_all and not ((hb2 & 1) != 0)[(cls2 & 15) == 4].any()
 
 
 @pytest.mark.parametrize("seed", range(4))
