@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="N > 1 under torchrun: nccl (= RCCL, the default) or gloo (rehearsal on a box with fewer GPUs than ranks)")
+    ap.add_argument("--fb-one-by-one", action="store_true",
+                    help="forward/backward workloads: one pagan_fb_run per pair from a thread pool instead of one pagan_fb_run_batch")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: rank r uses device r %% device_count instead of device r (numbers are meaningless)")
     ap.add_argument("--allow-stale-traffic", action="store_true", help="(accepted for older scripts: this is the default now)")
@@ -163,7 +165,16 @@ def bench_forward_backward(args, device):
 
     def one_pass():
         t0 = time.perf_counter()
-        rs = list(pool.map(one_pair, jobs))
+        if args.fb_one_by_one:
+            rs = list(pool.map(one_pair, jobs))
+        else:
+            # round 5: every pair of the tree in ONE call -- the forward sweeps of all wide pairs in one launch, the backward sweeps in
+            # another (pagan_fb_run_batch); --fb-one-by-one: a call per pair from a thread pool, as before (the HIP runtime's
+            # hardware queues then decide how many sweeps run side by side)
+            fbs = pg.full_probability_batch(jobs, device=device)
+            rs = [(fb.forward_ms, fb.backward_ms, fb.cells, (fb.log_fwd, fb.log_bwd)) for fb in fbs]
+            for fb in fbs:
+                fb.close()
         wall = time.perf_counter() - t0
         return sum(r[0] for r in rs), sum(r[1] for r in rs), sum(r[2] for r in rs), [r[3] for r in rs], wall
 
@@ -184,7 +195,8 @@ def bench_forward_backward(args, device):
         "config": {"workload": workload, "leaves": leaves, "length": length, "node_pairs": n_nodes, "cells_per_step": int(cells),
                    "hip_hw_queues_requested": os.environ.get("GPU_MAX_HW_QUEUES"),
                    "hip_hw_queues_in_environment_at_start": os.environ.get("PAGAN_BENCH_HW_QUEUES_AT_START"),
-                   "note": "value = cells / wall-clock of a pass with all node pairs in flight at once (wide pairs: two block-scheduled sweeps of up to 64 one-wave workgroups each); the per-kernel ms are sums of the kernels' own durations; wall per pass incl. allocation and upload: %.1f ms" % (1e3 * elapsed / args.steps)},
+                   "call": "one pagan_fb_run per pair from a thread pool" if args.fb_one_by_one else "one pagan_fb_run_batch for all pairs (the wide pairs' forward sweeps in one launch, their backward sweeps in another)",
+                   "note": "value = cells / wall-clock of a pass with all node pairs in flight at once (wide pairs: block-scheduled sweeps of one-wave workgroups, each pair its share of the device's workgroup slots); the per-kernel ms are the launches' own durations (one by one: their sums); wall per pass incl. allocation and upload: %.1f ms" % (1e3 * elapsed / args.steps)},
         "roofline": {"bound": "hbm", "achieved": 48 * cells / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": 48 * cells / dev_s / 1e9 / HBM_PEAK_GBS, "kernel": "pg_fb_forward + pg_fb_backward",
                      "algorithmic_bytes_per_cell": 48, "traffic": None,

@@ -265,6 +265,15 @@ typedef struct pagan_fb pagan_fb;   /* forward and backward matrices of one alig
 /* Runs both passes.  left/right must stay valid until pagan_fb_destroy (sample_path reads them).          */
 int  pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_model_prob *model,
                   const pagan_band *band, const pagan_opts *opts, pagan_fb **out);
+/* The same pass for n alignments at once (the reference runs compute_full_score node by node, viterbi_alignment.cpp:329-371; a
+ * caller that holds several independent node pairs -- a level of the guide tree -- hands them over together): the forward sweeps
+ * of all wide pairs in ONE launch and the backward sweeps in another, so that how many run side by side is what the device holds,
+ * not what the runtime's hardware queues allow.  band may be null (no pair has a band) or hold null entries.  out[k] as from
+ * pagan_fb_run (pagan_fb_kernel_ms: the launches' times at the batch's first wide pair, 0 at the others); on an error nothing
+ * is handed back.                                                                                                        */
+int  pagan_fb_run_batch(int32_t n, const pagan_graph *const *left, const pagan_graph *const *right,
+                        const pagan_model_prob *const *model, const pagan_band *const *band, const pagan_opts *opts,
+                        pagan_fb **out);
 /* log of max_end.fwd_score ("full probability", VA:1562-1563) and of match[0][0].bwd_score (VA:345-349);
  * the reference checks their ratio (VA:351-355).                                                          */
 int  pagan_fb_totals(const pagan_fb *fb, double *log_fwd, double *log_bwd, int64_t *cells);

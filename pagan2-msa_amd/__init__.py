@@ -96,16 +96,19 @@ class FullProbability:
         fb.sample_path(u)               Result with the shape of a Viterbi result
     """
 
-    def __init__(self, left, right, model_prob, band=None, device=-1):
+    def __init__(self, left, right, model_prob, band=None, device=-1, _handle=None):
         import numpy as np
         self._np = np
         self._L = lib()
         self.left, self.right, self.model, self.band = left, right, model_prob, band     # keep the arrays alive
-        opts = abi.COpts(0, device)
-        self._h = C.c_void_p()
-        _check(self._L.pagan_fb_run(C.byref(left.c), C.byref(right.c), C.byref(model_prob.c),
-                                    C.byref(band.c) if band is not None else None, C.byref(opts), C.byref(self._h)),
-               "pagan_fb_run")
+        if _handle is not None:                          # (full_probability_batch: the pair ran in a batch's launches)
+            self._h = _handle
+        else:
+            opts = abi.COpts(0, device)
+            self._h = C.c_void_p()
+            _check(self._L.pagan_fb_run(C.byref(left.c), C.byref(right.c), C.byref(model_prob.c),
+                                        C.byref(band.c) if band is not None else None, C.byref(opts), C.byref(self._h)),
+                   "pagan_fb_run")
         a, b, c = C.c_double(), C.c_double(), C.c_int64()
         _check(self._L.pagan_fb_totals(self._h, C.byref(a), C.byref(b), C.byref(c)), "pagan_fb_totals")
         self.log_fwd, self.log_bwd, self.cells = a.value, b.value, c.value
@@ -233,6 +236,22 @@ def debug_strips(left, right, band=None, max_sites=0):
     _check(min(n, 0), "pagan_dp_debug_strips")
     desc = desc.reshape(-1, 4)
     return [tuple(int(v) for v in strips[6 * k: 6 * k + 6]) + (desc[off[k]: off[k + 1]].copy(),) for k in range(n)]
+
+
+def full_probability_batch(pairs, device=-1):
+    """pagan_fb_run_batch: [(left, right, model_prob, band or None), ...] -> [FullProbability, ...]; the wide pairs' forward sweeps
+    run in one launch and their backward sweeps in another (all pairs side by side on the device)."""
+    L = lib()
+    n = len(pairs)
+    gp, mpp, bp = C.POINTER(abi.CGraph), C.POINTER(abi.CModelProb), C.POINTER(abi.CBand)
+    lefts = (gp * n)(*[C.pointer(p[0].c) for p in pairs])
+    rights = (gp * n)(*[C.pointer(p[1].c) for p in pairs])
+    models = (mpp * n)(*[C.pointer(p[2].c) for p in pairs])
+    bands = (bp * n)(*[(C.pointer(p[3].c) if p[3] is not None else bp()) for p in pairs])
+    outs = (C.c_void_p * n)()
+    opts = abi.COpts(0, device)
+    _check(L.pagan_fb_run_batch(n, lefts, rights, models, bands, C.byref(opts), outs), "pagan_fb_run_batch")
+    return [FullProbability(p[0], p[1], p[2], p[3], device=device, _handle=C.c_void_p(outs[k])) for k, p in enumerate(pairs)]
 
 
 def debug_far(left, right, band=None):

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -32,6 +33,7 @@
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/pagan_dp.h"
@@ -50,6 +52,10 @@ struct PgFbJob {
     double *F, *B;                           // [cells][3] log forward / log backward
     int n_init; const long long *init_at; const double *init_val;   // initialise_array_corner_bwd
     double *totals;                          // [2]: log fwd_end, log bwd(M,0,0)
+    // the tiled sweeps (round 5: one launch may carry the sweeps of SEVERAL pairs, grid = (most workgroups of any pair, pairs) --
+    // pagan_fb_run_batch): the pair's own workgroup count and barrier words
+    int groups, groups_b;                    // workgroups of this pair's forward / backward sweep (blockIdx.x beyond: nothing to do)
+    int *sync;                               // [64] ints: forward barrier at [0..7], backward at [8..15], diagnostics behind
 };
 
 namespace {
@@ -330,10 +336,12 @@ __device__ __forceinline__ void fb_stage_diagonals(const PgFbJob &J, FbSmem &M, 
     }
 }
 
-__global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs, int *sync) {
+__global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs) {
     __shared__ FbSmem M;
-    const PgFbJob J = jobs[0];
-    const int G = (int)gridDim.x, r = (int)threadIdx.x;
+    const PgFbJob J = jobs[blockIdx.y];
+    const int G = J.groups, r = (int)threadIdx.x;
+    if ((int)blockIdx.x >= G) return;                              // (a launch is as wide as its widest pair)
+    int *sync = J.sync;
     const int nbr = (J.Lx + FB_T - 1) / FB_T, nbc = (J.Ly + FB_T - 1) / FB_T;
     const double NI = ninf();
     const bool tab_lds = J.S * J.S <= 256;
@@ -496,10 +504,12 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs, i
     }
 }
 
-__global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs, int *sync) {
+__global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs) {
     __shared__ FbSmem M;
-    const PgFbJob J = jobs[0];
-    const int G = (int)gridDim.x, r = (int)threadIdx.x;
+    const PgFbJob J = jobs[blockIdx.y];
+    const int G = J.groups_b, r = (int)threadIdx.x;
+    if ((int)blockIdx.x >= G) return;
+    int *sync = J.sync + 8;
     const int nbr = (J.Lx + FB_T - 1) / FB_T, nbc = (J.Ly + FB_T - 1) / FB_T;
     const double NI = ninf();
     const bool tab_lds = J.S * J.S <= 256;
@@ -673,7 +683,7 @@ int pagan_internal_replay(const pagan_graph *L, const pagan_graph *R, int64_t ce
                           const int *trace, pagan_result *out);     // dp_abi.hip
 
 // Arenas of finished handles are kept for the next one on the same device (a pair's two matrices are hundreds of MB:
-// allocating and freeing them -- a device-wide synchronisation -- per pair was half of a pair's wall-clock); at most eight
+// allocating and freeing them -- a device-wide synchronisation -- per pair was half of a pair's wall-clock); at most 32 (a batch of a tree level's pairs returns that many at once; eight until round 5)
 // idle ones per process, pagan_fb_release_cache frees them.
 namespace {
 struct FbArenaPool {
@@ -711,7 +721,7 @@ struct FbArenaPool {
         idle.push_back({device, p, cap});
         size_t total = 0;
         for (auto &s_ : idle) total += s_.cap;
-        while (idle.size() > 8 || (total > kMaxIdleBytes && idle.size() > 1)) { total -= idle.front().cap; drop_front(); }
+        while (idle.size() > 32 || (total > kMaxIdleBytes && idle.size() > 1)) { total -= idle.front().cap; drop_front(); }
     }
     void clear() {
         std::lock_guard<std::mutex> g(m);
@@ -746,9 +756,23 @@ struct pagan_fb {
 
 extern "C" {
 
-int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_model_prob *model, const pagan_band *band,
-                 const pagan_opts *opts, pagan_fb **out) {
-    if (!left || !right || !model || !out || !model->score || model->n_states < 1) return PAGAN_E_ARG;
+} // extern "C"
+
+namespace {
+// One pair up to the upload of its inputs: validation, band index, lists, arena, the job record with its workgroup count
+// (`groups_cap`: what the caller's launch leaves this pair) -- what pagan_fb_run and pagan_fb_run_batch share.
+struct FbStaged {
+    pagan_fb *fb = nullptr;
+    const PgFbJob *d_job = nullptr;          // the pair's job record on the device
+    PgFbJob job;                             // ... and what it holds
+    char *d_tot = nullptr, *d_sync = nullptr;
+    int groups = 1, groups_b = 1, block = 64;
+    double t_host[4] = {0, 0, 0, 0};         // band index + lists, arena, staging, upload (seconds)
+    size_t arena_bytes = 0;
+};
+static int fb_stage(const pagan_graph *left, const pagan_graph *right, const pagan_model_prob *model, const pagan_band *band,
+                    const pagan_opts *opts, int groups_cap, int groups_cap_b, FbStaged *st) {
+    if (!left || !right || !model || !st || !model->score || model->n_states < 1) return PAGAN_E_ARG;
     int rc = check_graph(left);
     if (rc == PAGAN_OK) rc = check_graph(right);
     if (rc != PAGAN_OK) return rc;
@@ -826,6 +850,14 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     put(o_imin, fb->dx.imin.data(), 4 * (size_t)nd); put(o_imax, fb->dx.imax.data(), 4 * (size_t)nd); put(o_doff, fb->dx.doff.data(), 8 * (size_t)nd);
     put(o_iat, init_at.data(), 8 * init_at.size()); put(o_ival, init_val.data(), 8 * init_val.size());
     char *b = fb->arena;
+    // wide diagonals: 64 x 64 blocks over as many workgroups as a block anti-diagonal has blocks; PAGAN_FB_GROUPS=1 keeps the
+    // one-workgroup sweeps
+    const int mw = fb->dx.max_width;
+    int groups = mw > 256 ? std::min({FB_MAX_GROUPS, (Lx + FB_T - 1) / FB_T, (Ly + FB_T - 1) / FB_T}) : 1;
+    if (const char *e = std::getenv("PAGAN_FB_GROUPS")) groups = std::max(1, std::min(FB_MAX_GROUPS, std::atoi(e)));
+    const int groups_b = groups > 1 ? std::max(2, std::min(groups, groups_cap_b)) : 1;
+    if (groups > 1) groups = std::max(2, std::min(groups, groups_cap));
+    fb->groups = groups;
     PgFbJob J;
     J.Lx = Lx; J.Ly = Ly; J.nd = nd; J.S = S;
     J.l_ext = std::log((double)model->gap_ext); J.l_open = std::log((double)model->gap_open); J.l_ng = l_ng;
@@ -839,6 +871,7 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     J.F = (double *)(b + o_F); J.B = (double *)(b + o_B);
     J.n_init = (int)init_at.size(); J.init_at = (const long long *)(b + o_iat); J.init_val = (const double *)(b + o_ival);
     J.totals = (double *)(b + o_tot);
+    J.groups = groups; J.groups_b = groups_b; J.sync = (int *)(b + o_sync);
     std::memcpy(stage.data() + o_job, &J, sizeof(J));
     fb->dF = J.F; fb->dB = J.B;
     const double th2 = now_();
@@ -846,70 +879,211 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     const double th3 = now_();
     // a thread per cell of the widest diagonal, up to the 1024 of a workgroup (a cell is ~20 exp / log1p calls: a thread with
     // eight cells of a 2,000-cell diagonal was the whole sweep's pace)
-    const int mw = fb->dx.max_width;
-    const int block = mw >= 768 ? 1024 : mw >= 384 ? 512 : mw >= 192 ? 256 : (mw >= 96 ? 128 : 64);
-    // the two sweeps are independent of each other: side by side on two streams (a workgroup each)
+    st->block = mw >= 768 ? 1024 : mw >= 384 ? 512 : mw >= 192 ? 256 : (mw >= 96 ? 128 : 64);
+    st->groups = groups; st->groups_b = groups_b;
+    st->d_job = (const PgFbJob *)(b + o_job); st->d_tot = b + o_tot; st->d_sync = b + o_sync; st->job = J;
+    st->t_host[0] = th1 - th0; st->t_host[1] = th2 - th1; st->t_host[2] = 0.0; st->t_host[3] = th3 - th2;
+    st->arena_bytes = cur;
+    st->fb = guard.release();
+    return PAGAN_OK;
+}
+
+// ... and behind the kernels: the totals, the barriers' give-up words
+static int fb_finish(FbStaged *st, float fwd_ms, float bwd_ms) {
+    pagan_fb *fb = st->fb;
+    fb->kernel_ms[0] = fwd_ms; fb->kernel_ms[1] = bwd_ms;
+    FB_TRY(hipMemcpy(fb->totals, st->d_tot, 16, hipMemcpyDeviceToHost));
+    int sy[64];
+    FB_TRY(hipMemcpy(sy, st->d_sync, sizeof(sy), hipMemcpyDeviceToHost));
+    if (sy[1] != 0 || sy[9] != 0) return PAGAN_E_INTERNAL;          // a barrier of a wide sweep ran into its limit
+#ifdef PG_FB_STATS
+    {
+        const unsigned long long *q = (const unsigned long long *)(sy + 16);
+        std::fprintf(stderr, "pagan_fb: forward: %llu blocks, prologue %.0f cycles per block, steps %.0f per block, barrier %.0f per workgroup and block diagonal (%d groups)\n",
+                     q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[0] ? (double)q[2] / q[0] : 0.0,
+                     st->groups ? (double)q[3] / st->groups / ((fb->Lx + 63) / 64 + (fb->Ly + 63) / 64 - 1) : 0.0, st->groups);
+    }
+#endif
+    return PAGAN_OK;
+}
+
+// A sweep whose workgroups meet at a counter barrier needs ALL of them on the chip at once; a caller may have any number
+// of alignments in flight from as many threads, and workgroups of one sweep holding compute units while they wait for
+// siblings that other waiting sweeps keep out would never end (the barrier's spin limit would turn that into an error,
+// seconds later).  So the tiled sweeps of a device share a budget of workgroup slots well inside what the device holds
+// at this kernel's LDS size (3 per compute unit); a launch that does not fit waits here, on the host.
+struct FbSlots {
+    std::mutex m; std::condition_variable cv; int used = 0;
+    void take(int n, int cap) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return used == 0 || used + n <= cap; }); used += n; }
+    void give(int n) { { std::lock_guard<std::mutex> l(m); used -= n; } cv.notify_all(); }
+};
+static FbSlots fb_slots_of[64];
+static int fb_slot_cap(int device) {
+    int n_cu = 0, per_cu_x16 = 46;                              // 2.9 workgroups per compute unit of the 3 that fit (PAGAN_FB_SLOTS_X16: A/B; 2.5 until round 5)
+    if (const char *e = std::getenv("PAGAN_FB_SLOTS_X16")) per_cu_x16 = std::max(8, std::min(48, std::atoi(e)));
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) return per_cu_x16 * n_cu / 16;
+    return 512;
+}
+struct FbSlotLease { FbSlots *s; int n; ~FbSlotLease() { if (n > 0) s->give(n); } };
+
+} // namespace
+
+extern "C" {
+
+int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_model_prob *model, const pagan_band *band,
+                 const pagan_opts *opts, pagan_fb **out) {
+    if (!out) return PAGAN_E_ARG;
+    auto now_ = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    FbStaged st;
+    int rc = fb_stage(left, right, model, band, opts, FB_MAX_GROUPS, FB_MAX_GROUPS, &st);
+    if (rc != PAGAN_OK) return rc;
+    pagan_fb *fb = st.fb;
+    std::unique_ptr<pagan_fb, void (*)(pagan_fb *)> guard(fb, [](pagan_fb *p) { pagan_fb_destroy(p); });
+    const double th3 = now_();
+    const int groups = st.groups, block = st.block;
+    // the two sweeps are independent of each other: side by side on two streams
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     hipStream_t s1 = nullptr, s2 = nullptr;
     FB_TRY(hipStreamCreate(&s1)); FB_TRY(hipStreamCreate(&s2));
     FB_TRY(hipEventCreate(&e0)); FB_TRY(hipEventCreate(&e1)); FB_TRY(hipEventCreate(&e2)); FB_TRY(hipEventCreate(&e3));
     FB_TRY(hipEventRecord(e0, s1));
-    // wide diagonals: 64 x 64 blocks over as many workgroups as a block anti-diagonal has blocks; PAGAN_FB_GROUPS=1 keeps the
-    // one-workgroup sweeps
-    int groups = mw > 256 ? std::min({FB_MAX_GROUPS, (Lx + FB_T - 1) / FB_T, (Ly + FB_T - 1) / FB_T}) : 1;
-    if (const char *e = std::getenv("PAGAN_FB_GROUPS")) groups = std::max(1, std::min(FB_MAX_GROUPS, std::atoi(e)));
-    fb->groups = groups;
-    // A sweep whose workgroups meet at a counter barrier needs ALL of them on the chip at once; a caller may have any number
-    // of alignments in flight from as many threads, and workgroups of one sweep holding compute units while they wait for
-    // siblings that other waiting sweeps keep out would never end (the barrier's spin limit would turn that into an error,
-    // seconds later).  So the tiled sweeps of a device share a budget of workgroup slots well inside what the device holds
-    // at this kernel's LDS size (3 per compute unit); a pair that does not fit waits here, on the host.
-    struct Slots {
-        std::mutex m; std::condition_variable cv; int used = 0;
-        void take(int n, int cap) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return used == 0 || used + n <= cap; }); used += n; }
-        void give(int n) { { std::lock_guard<std::mutex> l(m); used -= n; } cv.notify_all(); }
-    };
-    static Slots slots_of[64];
-    Slots &slots = slots_of[fb->device & 63];
-    int slot_cap = 512;
-    {
-        int n_cu = 0;
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, fb->device) == hipSuccess && n_cu > 0) slot_cap = 5 * n_cu / 2;
-    }
-    struct SlotLease { Slots *s; int n; ~SlotLease() { if (n > 0) s->give(n); } } lease{&slots, groups > 1 ? 2 * groups : 0};
-    if (groups > 1) slots.take(2 * groups, slot_cap);
-    if (groups > 1) hipLaunchKernelGGL(pg_fb_forward_tiled, dim3(groups), dim3(64), 0, s1, (const PgFbJob *)(b + o_job), (int *)(b + o_sync));
-    else hipLaunchKernelGGL(pg_fb_forward, dim3(1), dim3(block), 0, s1, (const PgFbJob *)(b + o_job));
+    FbSlots &slots = fb_slots_of[fb->device & 63];
+    FbSlotLease lease{&slots, groups > 1 ? 2 * groups : 0};
+    if (groups > 1) slots.take(2 * groups, fb_slot_cap(fb->device));
+    if (groups > 1) hipLaunchKernelGGL(pg_fb_forward_tiled, dim3(groups, 1), dim3(64), 0, s1, st.d_job);
+    else hipLaunchKernelGGL(pg_fb_forward, dim3(1), dim3(block), 0, s1, st.d_job);
     FB_TRY(hipEventRecord(e1, s1));
     FB_TRY(hipEventRecord(e2, s2));
-    if (groups > 1) hipLaunchKernelGGL(pg_fb_backward_tiled, dim3(groups), dim3(64), 0, s2, (const PgFbJob *)(b + o_job), (int *)(b + o_sync) + 8);
-    else hipLaunchKernelGGL(pg_fb_backward, dim3(1), dim3(block), 0, s2, (const PgFbJob *)(b + o_job));
+    if (groups > 1) hipLaunchKernelGGL(pg_fb_backward_tiled, dim3(groups, 1), dim3(64), 0, s2, st.d_job);
+    else hipLaunchKernelGGL(pg_fb_backward, dim3(1), dim3(block), 0, s2, st.d_job);
     FB_TRY(hipEventRecord(e3, s2));
     FB_TRY(hipGetLastError());
     const double th4 = now_();
     FB_TRY(hipStreamSynchronize(s1)); FB_TRY(hipStreamSynchronize(s2));
     const double th5 = now_();
-    (void)hipEventElapsedTime(&fb->kernel_ms[0], e0, e1);
-    (void)hipEventElapsedTime(&fb->kernel_ms[1], e2, e3);
+    float fwd_ms = 0, bwd_ms = 0;
+    (void)hipEventElapsedTime(&fwd_ms, e0, e1);
+    (void)hipEventElapsedTime(&bwd_ms, e2, e3);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
     (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2);
-    FB_TRY(hipMemcpy(fb->totals, b + o_tot, 16, hipMemcpyDeviceToHost));
-    {
-        int sy[64];
-        FB_TRY(hipMemcpy(sy, b + o_sync, sizeof(sy), hipMemcpyDeviceToHost));
-        if (sy[1] != 0 || sy[9] != 0) return PAGAN_E_INTERNAL;      // a barrier of a wide sweep ran into its limit
-#ifdef PG_FB_STATS
-        {
-            const unsigned long long *q = (const unsigned long long *)(sy + 16);
-            std::fprintf(stderr, "pagan_fb: forward: %llu blocks, prologue %.0f cycles per block, steps %.0f per block, barrier %.0f per workgroup and block diagonal (%d groups)\n",
-                         q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[0] ? (double)q[2] / q[0] : 0.0, groups ? (double)q[3] / groups / ((Lx + 63) / 64 + (Ly + 63) / 64 - 1) : 0.0, groups);
-        }
-#endif
-    }
+    rc = fb_finish(&st, fwd_ms, bwd_ms);
+    if (rc != PAGAN_OK) return rc;
     if (std::getenv("PAGAN_DP_VERBOSE"))
-        std::fprintf(stderr, "pagan_fb: host: band index + lists %.1f ms, arena (%.0f MB) %.1f ms, staging %.1f ms, upload %.1f ms, streams + launch (+ slot wait) %.1f ms, kernels %.1f ms, rest %.1f ms\n",
-                     1e3 * (th1 - th0), cur / 1048576.0, 1e3 * (th2 - th1) - 0.0, 0.0, 1e3 * (th3 - th2), 1e3 * (th4 - th3), 1e3 * (th5 - th4), 1e3 * (now_() - th5));
+        std::fprintf(stderr, "pagan_fb: host: band index + lists %.1f ms, arena (%.0f MB) %.1f ms, upload %.1f ms, streams + launch (+ slot wait) %.1f ms, kernels %.1f ms, rest %.1f ms\n",
+                     1e3 * st.t_host[0], st.arena_bytes / 1048576.0, 1e3 * st.t_host[1], 1e3 * st.t_host[3], 1e3 * (th4 - th3), 1e3 * (th5 - th4), 1e3 * (now_() - th5));
     *out = guard.release();
+    return PAGAN_OK;
+}
+
+// Several pairs at once (round 5): the sweeps of ALL the pairs' wide matrices in ONE launch per direction, grid = (most workgroups
+// of any pair, pairs) -- concurrency is no longer what the HIP runtime's hardware queues allow (eight kernels at a time: four
+// pairs), but what the chip holds.  Every tiled pair gets an equal share of the device's workgroup slots (its sweeps may then
+// take a block anti-diagonal in two or three turns); pairs whose diagonals are narrow keep their one-workgroup kernels, a
+// stream each.  out[k] as from pagan_fb_run; on an error nothing is handed back.
+int pagan_fb_run_batch(int32_t n, const pagan_graph *const *left, const pagan_graph *const *right, const pagan_model_prob *const *model,
+                       const pagan_band *const *band, const pagan_opts *opts, pagan_fb **out) {
+    if (n < 0 || (n > 0 && (!left || !right || !model || !out))) return PAGAN_E_ARG;
+    for (int k = 0; k < n; ++k) out[k] = nullptr;
+    if (n == 0) return PAGAN_OK;
+    int device = 0;
+    if (opts && opts->device >= 0) device = opts->device; else if (hipGetDevice(&device) != hipSuccess) return PAGAN_E_NODEVICE;
+    const int cap = fb_slot_cap(device);
+    std::vector<FbStaged> st(n);
+    std::vector<int> rcs(n, PAGAN_OK);
+    int done = 0, rc = PAGAN_OK;
+    auto cleanup = [&]() { for (int k = 0; k < n; ++k) if (st[k].fb) { pagan_fb_destroy(st[k].fb); st[k].fb = nullptr; } };
+    while (done < n && rc == PAGAN_OK) {
+        // a chunk of pairs whose tiled sweeps fit the slot budget with at least eight workgroups a sweep
+        const int chunk = std::min(n - done, std::max(1, cap / 16));
+        // the backward sweep is the slower of the two when a block anti-diagonal takes several turns: it gets the larger share
+        // of the slots (PAGAN_FB_SPLIT: the forward sweeps' per cent, A/B)
+        int split = 40;
+        if (const char *e = std::getenv("PAGAN_FB_SPLIT")) split = std::max(20, std::min(80, std::atoi(e)));
+        const int per_pair = std::max(4, cap / chunk);            // slots of one pair, both sweeps
+        const int groups_cap = std::max(2, (per_pair * split + 50) / 100), groups_cap_b = std::max(2, per_pair - groups_cap);
+        {
+            std::vector<std::thread> pool;
+            const int nt = std::min(chunk, 16);
+            std::atomic<int> next{0};
+            for (int t = 0; t < nt; ++t) pool.emplace_back([&] {
+                if (opts && opts->device >= 0) (void)hipSetDevice(opts->device);
+                for (int q; (q = next.fetch_add(1)) < chunk;) {
+                    const int k = done + q;
+                    rcs[k] = fb_stage(left[k], right[k], model[k], band ? band[k] : nullptr, opts, groups_cap, groups_cap_b, &st[k]);
+                }
+            });
+            for (auto &th : pool) th.join();
+        }
+        for (int q = 0; q < chunk; ++q) if (rcs[done + q] != PAGAN_OK) rc = rcs[done + q];
+        if (rc != PAGAN_OK) break;
+        std::vector<PgFbJob> tiled;
+        std::vector<int> tiled_k, small_k;
+        int gmax = 0, gmax_b = 0, slots_needed = 0;
+        for (int q = 0; q < chunk; ++q) {
+            const int k = done + q;
+            if (st[k].groups > 1) {
+                tiled.push_back(st[k].job); tiled_k.push_back(k);
+                gmax = std::max(gmax, st[k].groups); gmax_b = std::max(gmax_b, st[k].groups_b); slots_needed += st[k].groups + st[k].groups_b;
+            } else small_k.push_back(k);
+        }
+        if (rc != PAGAN_OK) break;
+        PgFbJob *d_jobs = nullptr;
+        hipStream_t s1 = nullptr, s2 = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+        std::vector<hipStream_t> small_s(2 * small_k.size(), nullptr);
+        auto release = [&]() {
+            if (d_jobs) (void)hipFree(d_jobs);
+            if (s1) (void)hipStreamDestroy(s1);
+            if (s2) (void)hipStreamDestroy(s2);
+            for (hipEvent_t e : {e0, e1, e2, e3}) if (e) (void)hipEventDestroy(e);
+            for (hipStream_t x : small_s) if (x) (void)hipStreamDestroy(x);
+        };
+        auto body = [&]() -> int {
+            FB_TRY(hipStreamCreate(&s1)); FB_TRY(hipStreamCreate(&s2));
+            FB_TRY(hipEventCreate(&e0)); FB_TRY(hipEventCreate(&e1)); FB_TRY(hipEventCreate(&e2)); FB_TRY(hipEventCreate(&e3));
+            FbSlots &slots = fb_slots_of[device & 63];
+            FbSlotLease lease{&slots, slots_needed};
+            if (slots_needed > 0) slots.take(slots_needed, cap);
+            if (!tiled.empty()) {
+                FB_TRY(hipMalloc((void **)&d_jobs, tiled.size() * sizeof(PgFbJob)));
+                FB_TRY(hipMemcpy(d_jobs, tiled.data(), tiled.size() * sizeof(PgFbJob), hipMemcpyHostToDevice));
+                const bool bwd_first = std::getenv("PAGAN_FB_BWD_FIRST") != nullptr;      // (A/B: which sweep's workgroups are dealt out first)
+                if (bwd_first) {
+                    FB_TRY(hipEventRecord(e2, s2));
+                    hipLaunchKernelGGL(pg_fb_backward_tiled, dim3(gmax_b, (unsigned)tiled.size()), dim3(64), 0, s2, (const PgFbJob *)d_jobs);
+                    FB_TRY(hipEventRecord(e3, s2));
+                }
+                FB_TRY(hipEventRecord(e0, s1));
+                hipLaunchKernelGGL(pg_fb_forward_tiled, dim3(gmax, (unsigned)tiled.size()), dim3(64), 0, s1, (const PgFbJob *)d_jobs);
+                FB_TRY(hipEventRecord(e1, s1));
+                if (!bwd_first) {
+                    FB_TRY(hipEventRecord(e2, s2));
+                    hipLaunchKernelGGL(pg_fb_backward_tiled, dim3(gmax_b, (unsigned)tiled.size()), dim3(64), 0, s2, (const PgFbJob *)d_jobs);
+                    FB_TRY(hipEventRecord(e3, s2));
+                }
+            }
+            for (size_t q = 0; q < small_k.size(); ++q) {
+                const FbStaged &x = st[small_k[q]];
+                FB_TRY(hipStreamCreate(&small_s[2 * q])); FB_TRY(hipStreamCreate(&small_s[2 * q + 1]));
+                hipLaunchKernelGGL(pg_fb_forward, dim3(1), dim3(x.block), 0, small_s[2 * q], x.d_job);
+                hipLaunchKernelGGL(pg_fb_backward, dim3(1), dim3(x.block), 0, small_s[2 * q + 1], x.d_job);
+            }
+            FB_TRY(hipGetLastError());
+            FB_TRY(hipStreamSynchronize(s1)); FB_TRY(hipStreamSynchronize(s2));
+            for (hipStream_t x : small_s) FB_TRY(hipStreamSynchronize(x));
+            float fwd_ms = 0, bwd_ms = 0;
+            if (!tiled.empty()) { (void)hipEventElapsedTime(&fwd_ms, e0, e1); (void)hipEventElapsedTime(&bwd_ms, e2, e3); }
+            // (the launch's kernel times go to its first pair; the others report 0: a sum over the batch is the launch's)
+            for (size_t q = 0; q < tiled_k.size(); ++q) { const int r_ = fb_finish(&st[tiled_k[q]], q == 0 ? fwd_ms : 0.0f, q == 0 ? bwd_ms : 0.0f); if (r_ != PAGAN_OK) return r_; }
+            for (int k : small_k) { const int r_ = fb_finish(&st[k], 0.0f, 0.0f); if (r_ != PAGAN_OK) return r_; }
+            return PAGAN_OK;
+        };
+        rc = body();
+        release();
+        done += chunk;
+    }
+    if (rc != PAGAN_OK) { cleanup(); return rc; }
+    for (int k = 0; k < n; ++k) out[k] = st[k].fb;
     return PAGAN_OK;
 }
 

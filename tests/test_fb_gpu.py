@@ -115,3 +115,35 @@ def test_wide_pairs_spread_a_diagonal_over_several_workgroups(pg, oracle, monkey
     monkeypatch.setenv("PAGAN_FB_GROUPS", "1")
     one = pgm.FullProbability(left, right, mp)
     assert close_logs(one.log_forward(), wide_f) and close_logs(one.log_backward(), wide_b)
+
+
+def test_a_batch_of_pairs_in_one_launch_per_sweep(pg, oracle):
+    """pagan_fb_run_batch: the forward sweeps of all wide pairs of a tree in ONE launch, the backward sweeps in another (a pair's
+    workgroup count cut to its share of the device), the narrow pairs beside them on their own kernels -- every pair's logs
+    equal the one-pair call's to the comparison's tolerance, its totals the oracle's."""
+    names, seqs, nwk = synth.evolve_balanced(8, 700, branch=0.04, sub=0.04, indel_start=0.01, mean_len=4, seed=46)
+    msa = host.Msa(names, seqs, nwk, use_anchors=0).align()
+    bf = np.array([sum(s.count(x) for s in seqs) for x in "ACGT"], np.float32)
+    bf /= bf.sum()
+    pairs = []
+    for k in range(msa.n_internal):
+        left, right, _model, band = msa.node_job(k)
+        pairs.append((left, right, host.model_prob(1, msa.node_info(k).dist, base_freq=bf), band))
+    # a narrow (banded) pair among them: the first leaf pair again behind a band of 40 columns
+    l0, r0, mp0, _ = pairs[0]
+    Lx, Ly = l0.n_sites - 1, r0.n_sites - 1
+    centre = np.arange(Lx) * (Ly - 1) // max(Lx - 1, 1)
+    upper = np.maximum(centre - 20, 0); lower = np.minimum(centre + 20, Ly - 1)
+    upper[0] = 0; lower[-1] = Ly - 1
+    pairs.append((l0, r0, mp0, abi.Band(upper, lower)))
+    batch = pgm.full_probability_batch(pairs)
+    assert len(batch) == len(pairs)
+    for k, (left, right, mp, band) in enumerate(pairs):
+        one = pgm.FullProbability(left, right, mp, band)
+        assert close_logs(batch[k].log_forward(), one.log_forward()) and close_logs(batch[k].log_backward(), one.log_backward()), k
+        assert abs(batch[k].log_fwd - one.log_fwd) <= 1e-9 * abs(one.log_fwd) and abs(batch[k].log_bwd - one.log_bwd) <= 1e-9 * abs(one.log_bwd)
+        lf, lb, _post, _logf = oracle.fb(left, right, mp, band=band)
+        assert abs(batch[k].log_fwd - lf) <= LOG_TOL * max(1, abs(lf)) and abs(batch[k].log_bwd - lb) <= LOG_TOL * max(1, abs(lb)), k
+        one.close()
+    for fb in batch:
+        fb.close()
