@@ -147,3 +147,18 @@ def test_a_batch_of_pairs_in_one_launch_per_sweep(pg, oracle):
         one.close()
     for fb in batch:
         fb.close()
+
+
+def test_a_batch_larger_than_one_launch_holds(pg, oracle):
+    """more wide pairs than one launch takes at eight workgroups a sweep (the batch goes in chunks): every pair's totals the oracle's"""
+    mp = host.model_prob(1, 0.1, base_freq=[0.3, 0.2, 0.2, 0.3])
+    pairs = []
+    for k in range(52):
+        _, seqs, _ = synth.evolve_balanced(2, 270 + 3 * k, branch=0.05, sub=0.06, indel_start=0.01, mean_len=3, seed=500 + k)
+        gl, gr = (host.HGraph.leaf(s).flatten() for s in seqs)
+        pairs.append((gl, gr, mp, None))
+    batch = pgm.full_probability_batch(pairs)
+    for k, (gl, gr, mp_, band) in enumerate(pairs):
+        lf, lb, _post, _logf = oracle.fb(gl, gr, mp_, band=band, matrices=False)
+        assert abs(batch[k].log_fwd - lf) <= LOG_TOL * max(1, abs(lf)) and abs(batch[k].log_bwd - lb) <= LOG_TOL * max(1, abs(lb)), k
+        batch[k].close()
