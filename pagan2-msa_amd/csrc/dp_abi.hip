@@ -970,6 +970,7 @@ struct pagan_batch {
     int strip_grid_big = 0;      // ... of the launch for the jobs whose model table does not fit LDS (listed behind the others' in d_swhich)
     int *d_swhich = nullptr;     // [strip_grid] strip -> its PgDevJob (behind the n jobs of the batch) or -1
     size_t sfollow_begin = 0, sfollow_bytes = 0;     // the strips' follow words (zeroed before every launch)
+    bool strips_spread = true;   // a job's strips on any XCD (PAGAN_DP_STRIP_SPREAD=0: on one, round 4's placement, checked by the feeders)
     bool strips_alone = false;   // the re-run after a strip found the strip above on another XCD: the strips' launch with nothing beside it
     int *d_tiles = nullptr;      // dp_tiles.hip: {job, tile row, tile column, position of the tile above} of all tiled jobs, ordered by
                                  // row + column; then the positions of the tiles to the left; then tile_off (pg_fill_tiles_flow)
@@ -1267,6 +1268,7 @@ int launch_fill(pagan_batch *b) {
         if (std::strcmp(e, "0") == 0) { chk_banded = 0; chk_wide = 0; }
         else if (std::strcmp(e, "all") == 0) chk_wide = PG_FLAG_SCORE_CHECK;
     }
+    const unsigned spread = b->strips_spread ? PG_FLAG_STRIPS_SPREAD : 0u;
     hipStream_t tile_stream = nullptr;
     static std::atomic<int> n_cu_dev[64];
     bool ev3_recorded = false;
@@ -1276,10 +1278,10 @@ int launch_fill(pagan_batch *b) {
         HIP_TRY(hipMemsetAsync(b->arena.dev + b->sfollow_begin, 0, b->sfollow_bytes, b->stream));
         if (b->strip_grid > 0)
             hipLaunchKernelGGL((pg_fill_pipe<true, true>), dim3(b->strip_grid), dim3(pg_pipe_block()), 0, b->stream,
-                               b->d_jobs, b->d_swhich, (b->flags & 0x400u) ? b->flags : (b->flags & ~0x800u), b->strip_grid);
+                               b->d_jobs, b->d_swhich, ((b->flags & 0x400u) ? b->flags : (b->flags & ~0x800u)) | spread, b->strip_grid);
         if (b->strip_grid_big > 0)
             hipLaunchKernelGGL((pg_fill_pipe<false, true>), dim3(b->strip_grid_big), dim3(pg_pipe_block()), 0, b->stream,
-                               b->d_jobs, b->d_swhich + b->strip_grid, (b->flags & 0x400u) ? b->flags : (b->flags & ~0x800u), b->strip_grid_big);
+                               b->d_jobs, b->d_swhich + b->strip_grid, ((b->flags & 0x400u) ? b->flags : (b->flags & ~0x800u)) | spread, b->strip_grid_big);
     }
     if (b->n_striped > 0 && b->tile_off.size() <= 1) {
         // (the strips' stream: beside the banded kernels, as the tiles')
@@ -1378,10 +1380,10 @@ int launch_fill(pagan_batch *b) {
         HIP_TRY(hipMemsetAsync(b->arena.dev + b->sfollow_begin, 0, b->sfollow_bytes, tile_stream));
         if (b->strip_grid > 0)
             hipLaunchKernelGGL((pg_fill_pipe<true, true>), dim3(b->strip_grid), dim3(pg_pipe_block()), 0, tile_stream,
-                               b->d_jobs, b->d_swhich, b->flags, b->strip_grid);
+                               b->d_jobs, b->d_swhich, b->flags | spread, b->strip_grid);
         if (b->strip_grid_big > 0)
             hipLaunchKernelGGL((pg_fill_pipe<false, true>), dim3(b->strip_grid_big), dim3(pg_pipe_block()), 0, tile_stream,
-                               b->d_jobs, b->d_swhich + b->strip_grid, b->flags, b->strip_grid_big);
+                               b->d_jobs, b->d_swhich + b->strip_grid, b->flags | spread, b->strip_grid_big);
     }
     if (b->tile_off.size() > 1) {
         // after the banded kernels: their workgroups get compute units first; the persistent waves below hold theirs
@@ -1801,6 +1803,7 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
     struct Guard { pagan_batch *b; ~Guard() { if (b) pagan_batch_destroy(b); } } guard{b};
     b->n = n;
     b->flags = opts ? opts->flags : 0;
+    if (const char *e = std::getenv("PAGAN_DP_STRIP_SPREAD")) b->strips_spread = std::atoi(e) != 0;
     if (opts && opts->device >= 0) HIP_TRY(hipSetDevice(opts->device));
     HIP_TRY(hipGetDevice(&b->device));
     b->jobs.resize(n);
@@ -1946,6 +1949,19 @@ int pagan_batch_create(int32_t n, const pagan_job *jobs, const pagan_opts *opts,
                 for (size_t q = 0; q < b->jobs[k].strips.size(); ++q) lane_strips[lane].push_back({k, (int)q});
             }
             const size_t first = swhich.size();                          // (a multiple of 8)
+            if (b->strips_spread) {
+                // PAGAN_DP_STRIP_SPREAD (the default, round 5): a job's strips on ANY XCD -- they store their scores through to
+                // memory and read the strip above's with sc1 loads (dp_pipe.hip, store_scores / strip_feeder), so a single wide job
+                // (the root of a tree) has the whole chip, not one XCD's 32 units.  All strips of the launch in the order of their
+                // first diagonals: the order they can start in (a job's own strips stay in order: their first diagonals grow).
+                std::vector<std::pair<int, int>> all;
+                for (int lane = 0; lane < 8; ++lane) all.insert(all.end(), lane_strips[lane].begin(), lane_strips[lane].end());
+                std::stable_sort(all.begin(), all.end(), [&](const std::pair<int, int> &a, const std::pair<int, int> &c) {
+                    const int da = b->jobs[a.first].strips[a.second].d0, dc = b->jobs[c.first].strips[c.second].d0;
+                    return da != dc ? da < dc : (a.first != c.first ? a.first < c.first : a.second < c.second); });
+                for (const auto &js : all) swhich.push_back(where[((long long)js.first << 20) | (long long)js.second]);
+                while (swhich.size() % 8) swhich.push_back(-1);
+            } else
             for (int lane = 0; lane < 8; ++lane) {
                 auto &ls = lane_strips[lane];
                 std::stable_sort(ls.begin(), ls.end(), [&](const std::pair<int, int> &a, const std::pair<int, int> &c) {

@@ -38,6 +38,7 @@
 #define PG_BP_CELLS 1024      // ... and cells of each of them (grid.z covers the rest of a wide diagonal)
 #define PG_STATUS_PATH_CHECK 3 // endcell[0]: a visited cell's stored score / back-pointer differs from its re-evaluation (pg_trace_check)
 #define PG_FLAG_SCORE_CHECK 0x200u   // kernel flag: pg_backptr / the follower workgroups compare every cell's re-evaluated scores with the stored ones
+#define PG_FLAG_STRIPS_SPREAD 0x10000u   // kernel flag (pg_fill_pipe<., true>): a job's strips run on any XCD (strip_feeder does not ask where the strip above runs)
 #define PG_FILL_SCORE_MISMATCH 0x7c  // fill_status: ... and found a difference (pagan_batch_fetch runs the batch once more without followers, then reports)
 #define PG_FILL_OTHER_XCD 0x20000000  // fill_status, sticky: a row strip found the strip above on another XCD (the abort tags stay below bit 28)
 #define PG_FOLLOW_CHUNK 16    // diagonals a follower wave of pg_fill_pipe claims at a time (dp_pipe.hip, pipe_follower)

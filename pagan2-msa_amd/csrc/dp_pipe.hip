@@ -279,8 +279,12 @@ __device__ __forceinline__ void load_rec_chunk(int first, int lane, int n, gint_
 #define PREC_BACK 72              // 64 (a chunk) + 8: the records up to 8 sites before the slowest diagonal's first stay
 // follow[0] = 1 + the last diagonal whose scores have landed in L2 (PgDevJob::follow; what the follower workgroups wait
 // for): a wave's stores of diagonal d have landed once it completed d + PLAND; published every 16 diagonals or so
-__device__ __forceinline__ void publish_landed(PG_GLOBAL int *follow, int lane, int landed) {
-    if (follow && lane == 0) asm volatile("global_store_dword %0, %1, off" :: "v"(follow), "v"(landed + 1) : "memory");
+// (wt, row strips: written through -- the strip below may poll from another XCD)
+__device__ __forceinline__ void publish_landed(PG_GLOBAL int *follow, int lane, int landed, bool wt = false) {
+    if (follow && lane == 0) {
+        if (wt) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(follow), "v"(landed + 1) : "memory");
+        else asm volatile("global_store_dword %0, %1, off" :: "v"(follow), "v"(landed + 1) : "memory");
+    }
 }
 // Row strips (`strip`: the PgDevJob, null otherwise): records from the strip's first halo row / first column on, the
 // descriptor window from the PARENT's array (whole-band rows per diagonal, offsets in cells there), everything from d_first.
@@ -298,12 +302,12 @@ __device__ __forceinline__ void pipe_loader(const View &J, cdesc8_p psc, int lan
     for (;;) {
         int pmin = flag_load(&PM.progress[0]);
         for (int w = 1; w < PNW; ++w) { const int p = flag_load(&PM.progress[w]); pmin = p < pmin ? p : pmin; }
-        if (flag_load(&PM.abort_flag) != 0) { publish_landed(follow, lane, J.nd - 1); return; }   // (the job fails: the followers need not wait)
+        if (flag_load(&PM.abort_flag) != 0) { publish_landed(follow, lane, J.nd - 1, strip != nullptr); return; }   // (the job fails: the followers need not wait)
         // A compute wave's flag for the LAST diagonal goes up as after any other step -- with its stores still in flight -- so
         // the tail is published like the middle, PLAND behind the slowest wave, and the last diagonals only once every wave
         // has said "drained for good": progress = nd, stored behind the s_waitcnt vmcnt(0) that ends its last interval.
-        if (pmin >= J.nd) { publish_landed(follow, lane, J.nd - 1); return; }
-        if (pmin - PLAND >= published + (strip ? 8 : PG_FOLLOW_CHUNK)) { published = pmin - PLAND; publish_landed(follow, lane, published); }
+        if (pmin >= J.nd) { publish_landed(follow, lane, J.nd - 1, strip != nullptr); return; }
+        if (pmin - PLAND >= published + (strip ? 8 : PG_FOLLOW_CHUNK)) { published = pmin - PLAND; publish_landed(follow, lane, published, strip != nullptr); }
         if (pmin + 1 >= J.nd) { __builtin_amdgcn_s_sleep(8); continue; }                          // nothing left to stage
         const int dcur = pmin + 1;                                 // the slowest wave may be computing this one
         const int da = dcur + PLOOK < J.nd - 1 ? dcur + PLOOK : J.nd - 1;
@@ -669,20 +673,31 @@ __device__ __forceinline__ double in_vgpr(double x) {
 
 // Commit of one step: EVERY lane writes its column of the ring row (-inf outside the band); cells
 // inside the band go to HBM, 24 B of scores + 12 B of back-pointers at the diagonal's offset.
+// A cell's three scores to the score matrix.  WT (row strips): written through to memory (sc1) -- the strip below, and a strip
+// whose far operand this is, may run on another XCD, whose L2 is not this one's (strip_feeder).  Two instructions either way
+// (the s_waitcnt vmcnt(n) behind a step counts on that).
+template <bool WT>
+__device__ __forceinline__ void store_scores(PG_GLOBAL char *p, double bx, double by, double bm) {
+    pg_d2 xy; xy.x = bx; xy.y = by;
+    if (WT) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %0, %2, off offset:16 sc1" :: "v"(p), "v"(xy), "v"(bm) : "memory");
+    } else {
+        *(PG_GLOBAL pg_d2 *)p = xy;
+        *(PG_GLOBAL double *)(p + 16) = bm;
+    }
+}
+template <bool WT>
 __device__ __forceinline__ void commit_cell(gdouble_w sc_out, gu32_w bp_out, const pg_i8 &cur, int slot, int tid, int off,
                                             bool active, double bx, double by, double bm, unsigned px, unsigned py, unsigned pm) {
     PM.sc[slot][tid][PG_X] = bx;
     PM.sc[slot][tid][PG_Y] = by;
     PM.sc[slot][tid][PG_M] = bm;
     if (active) {
-        typedef double d2 __attribute__((ext_vector_type(2)));
         typedef unsigned u3 __attribute__((ext_vector_type(3)));
         const long long soff = ((long long)cur.w << 32) | (unsigned)cur.z;     // 24 * first cell of the diagonal
         PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff;
         PG_GLOBAL char *brow = (PG_GLOBAL char *)bp_out + (soff >> 1);
-        d2 xy; xy.x = bx; xy.y = by;
-        *(PG_GLOBAL d2 *)(srow + 24u * (unsigned)off) = xy;
-        *(PG_GLOBAL double *)(srow + 24u * (unsigned)off + 16u) = bm;
+        store_scores<WT>(srow + 24u * (unsigned)off, bx, by, bm);
         u3 b3; b3.x = px; b3.y = py; b3.z = pm;
         *(PG_GLOBAL u3 *)(brow + 12u * (unsigned)off) = b3;
     }
@@ -2209,10 +2224,8 @@ __device__ __noinline__ void hot_run(WaveCtx &C_) {
             PG_GLOBAL char *srow = (PG_GLOBAL char *)sc_out + soff;
             PG_GLOBAL char *brow = (PG_GLOBAL char *)bp_out + (soff >> 1);
             const unsigned off = (unsigned)(row - lo);
-            pg_d2 xy; xy.x = bx; xy.y = by;
             const unsigned off12 = __umul24(off, 12u);
-            *(PG_GLOBAL pg_d2 *)(srow + 2u * off12) = xy;
-            *(PG_GLOBAL double *)(srow + 2u * off12 + 16u) = bm;
+            store_scores<STRIP>(srow + 2u * off12, bx, by, bm);
             u3 b3; b3.x = px; b3.y = py; b3.z = pm;
             *(PG_GLOBAL u3 *)(brow + off12) = b3;
         }
@@ -3173,10 +3186,13 @@ __device__ __noinline__ void pipe_follower(const PgDevJob *__restrict__ jobs, co
 // publishing its progress like any compute wave.  To the strip's waves the rows above are in the ring exactly as if a
 // wave had computed them: lane 0 of the first wave takes row-1 from the feeder's lane 63 (the hot loop checks the feeder's
 // flag as it checks any upstream wave's), multi-edge cells find their ring operands above the strip in the ring, and ring
-// rows are reused under the same per-diagonal rule.  The strips of a job run on ONE XCD (the host lays the
-// dispatch out so: workgroup g runs on XCD g % 8; checked here against the id the strip above published), a strip starts
-// when the one above has landed the diagonals its first cells read, and then follows it a few dozen diagonals behind:
-// the job's anti-diagonal sweeps all its strips at once.
+// rows are reused under the same per-diagonal rule.  A strip starts when the one above has landed the diagonals its first
+// cells read, and then follows it a few dozen diagonals behind: the job's anti-diagonal sweeps all its strips at once.
+// Strip -> strip visibility (round 5): a strip's scores and its "landed" counter are written THROUGH to memory (sc1 stores:
+// store_scores, the strips' assembly loop, publish_landed) and read with sc1 loads (far_fetch*, peek_l2), so the strips of a
+// job run on whatever XCD the dispatcher gives them -- HIP promises no placement.  Round 4's form is behind
+// PAGAN_DP_STRIP_SPREAD=0: a job's strips at workgroup indices of one residue mod 8 (one XCD as dispatches are observed to
+// go), each strip publishing its XCC id and the feeder below checking it (tag 11; the host's re-runs: dp_abi.hip).
 #define PHALO 16                  // rows above the strip the feeder keeps in the ring: a ring operand lies at most PAGE - 1 <= 16 rows up
 #define PFEED 32                  // diagonals the feeder requests from L2 at a time: 4 per load (lane = diagonal % 4, row), 8 loads, one round trip
 static_assert(PHALO >= PAGE - 1 && 64 / PHALO * 8 == PFEED, "feeder geometry");
@@ -3195,7 +3211,8 @@ __device__ __noinline__ void strip_feeder(const PgDevJob *__restrict__ job, cdes
     const double NI = neg_inf();
     int d = d0;                                                    // (names the diagonal in an abort tag)
     flag_store(&PM.arrived[wave], nd);                             // no stores to drain: never what a rendezvous waits for
-    {   // the strip above runs on this XCD (its scores are read from the XCD's L2)
+    if (!(flags & PG_FLAG_STRIPS_SPREAD)) {
+        // PAGAN_DP_STRIP_SPREAD=0 (round 4's placement): the strip above runs on this XCD
         int id = 0, spin = 0;
         while ((id = peek_l2(prev + 1)) == 0 && spin < (1 << 22) && flag_load(&PM.abort_flag) == 0) { __builtin_amdgcn_s_sleep(16); ++spin; }
         // (debug flag 0x800, tests: as if it did not -- the host clears the bit when it launches the strips alone)
@@ -3258,7 +3275,8 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
     const PgDevJob *__restrict__ job = jobs + which[blockIdx.x];
     if (threadIdx.x == 0 && job->follow) {
         const int id = (int)my_xcc_id() + 1;
-        asm volatile("global_store_dword %0, %1, off" :: "v"((PG_GLOBAL int *)job->follow + 1), "v"(id) : "memory");
+        if (STRIP) asm volatile("global_store_dword %0, %1, off sc1" :: "v"((PG_GLOBAL int *)job->follow + 1), "v"(id) : "memory");
+        else asm volatile("global_store_dword %0, %1, off" :: "v"((PG_GLOBAL int *)job->follow + 1), "v"(id) : "memory");
     }
     const cdesc8_p psc = (cdesc8_p)job->psc;
     const bool no_terminal_edges = flags & 1u;
@@ -3568,14 +3586,14 @@ __global__ __launch_bounds__(PBLOCK) void pg_fill_pipe(const PgDevJob *__restric
                     }
                 }
                 PSTAMP(3);
-                commit_cell(sc_out, bp_out, cur, slot, tid, row - lo, active, bx, by, bm, px, py, pm);
+                commit_cell<STRIP>(sc_out, bp_out, cur, slot, tid, row - lo, active, bx, by, bm, px, py, pm);
                 PSTAMP(4);
             } else if (cls <= 3) {
                 const unsigned resmask = ((unsigned)cur.s4 >> 5) & 0x7fffu;
 #ifndef PG_EXP_GENERAL_SKIP                                         // (timing experiment, WRONG RESULTS: a general step computes nothing)
                 if (active) gen_cell(d, slot, resmask, row, j, bx, by, bm, px, py, pm);
 #endif
-                commit_cell(sc_out, bp_out, cur, slot, tid, row - lo, active, bx, by, bm, px, py, pm);
+                commit_cell<STRIP>(sc_out, bp_out, cur, slot, tid, row - lo, active, bx, by, bm, px, py, pm);
                 if (TAB_LDS && !STRIP && (cur.s4 & 32) && active)      // (a history interval crosses this general step: hist_append)
                     hist_append(PM.recL[row & (PRW - 1)], PM.recR[j & (PRW - 1)], row, j, bx, by, bm);
             } else if (cls == 4) {

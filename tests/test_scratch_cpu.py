@@ -53,6 +53,7 @@ def test_kernel_spill_counts(report):
         if big_table:
             assert v["vgpr_spill_count"] == 0, (k, v)
         else:
-            # bodies of the small-table kernels: general steps and set-up only (round 5: 11 / 35 VGPRs)
-            assert v["vgpr_spill_count"] <= 40, (k, v)
+            # bodies of the small-table kernels: general steps and set-up only (round 5: 11 / 43 VGPRs -- the strips' body with its
+            # written-through score stores)
+            assert v["vgpr_spill_count"] <= 48, (k, v)
         assert v["private_segment_fixed_size"] <= 1536, (k, v)

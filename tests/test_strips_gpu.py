@@ -20,8 +20,11 @@ def same(a, b, what=""):
     assert np.array_equal(a.left_used, b.left_used) and np.array_equal(a.right_used, b.right_used), what
 
 
-@pytest.fixture
-def strips(monkeypatch):
+@pytest.fixture(params=["any_xcd", "one_xcd"])
+def strips(monkeypatch, request):
+    """any_xcd (the default): a job's strips wherever the dispatcher puts them, scores written through to memory;
+    one_xcd (PAGAN_DP_STRIP_SPREAD=0, round 4's placement): a job's strips at workgroup indices of one residue mod 8"""
+    monkeypatch.setenv("PAGAN_DP_STRIP_SPREAD", "1" if request.param == "any_xcd" else "0")
     monkeypatch.setenv("PAGAN_DP_WIDE", "strips")
     monkeypatch.setenv("PAGAN_DP_STRIP_SITES", "100000")      # (every wide job here runs as strips, however many multi-edge sites its diagonals hold)
     monkeypatch.setenv("PAGAN_DP_STRIP_STATES", "100000")     # (... and however large its model table: by default only tables that fit LDS do)
@@ -115,6 +118,7 @@ def test_a_strip_on_another_xcd_runs_the_batch_again_alone(pg, oracle, strips, m
     """debug flag 0x800: every feeder reports the strip above on another XCD; the fetch launches the strips once more with
     nothing dispatched beside them (the host clears the bit for that launch) and returns that result"""
     monkeypatch.setenv("PAGAN_DP_DEBUG_FLAGS", "0x800")
+    monkeypatch.setenv("PAGAN_DP_STRIP_SPREAD", "0")          # (only this placement asks where the strip above runs)
     left = synth.random_graph(500, 15, 71, p_extra=0.08, max_deg=3, max_span=12)
     right = synth.random_graph(450, 15, 72, p_extra=0.08, max_deg=3, max_span=12)
     model = synth.random_model(15, 9)
@@ -131,6 +135,7 @@ def test_strips_that_fail_alone_too_go_to_the_tiled_kernel(pg, oracle, strips, m
     error to its caller; pagan_dp_align_batch plans the batch a third time with every wide job on the tiled kernel and
     returns that result (round 4's advisor: the 'alone' launch is alone only within its own batch)."""
     monkeypatch.setenv("PAGAN_DP_DEBUG_FLAGS", "0xc00")
+    monkeypatch.setenv("PAGAN_DP_STRIP_SPREAD", "0")
     left = synth.random_graph(500, 15, 73, p_extra=0.08, max_deg=3, max_span=12)
     right = synth.random_graph(450, 15, 74, p_extra=0.08, max_deg=3, max_span=12)
     model = synth.random_model(15, 10)

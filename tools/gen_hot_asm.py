@@ -878,8 +878,10 @@ def step(E, k):
         a("ds_write_b64 v219, %s offset:16" % pr(P[2]))
     if "s" not in EXP:   # (timing experiment s: no HBM stores)
         a("s_and_saveexec_b64 s[62:63], s[60:61]")
-        a("global_store_dwordx4 v218, v[%d:%d], s[64:65]" % (P[0], P[0] + 3))
-        a("global_store_dwordx2 v218, %s, s[64:65] offset:16" % pr(P[2]))
+        # (row strips: written through to memory -- the strip below may run on another XCD, whose L2 is not this one's)
+        wt = " sc1" if STRIP else ""
+        a("global_store_dwordx4 v218, v[%d:%d], s[64:65]%s" % (P[0], P[0] + 3, wt))
+        a("global_store_dwordx2 v218, %s, s[64:65] offset:16%s" % (pr(P[2]), wt))
         a("s_mov_b64 exec, s[62:63]")
         a("s_waitcnt vmcnt(16)")                               # all but the last 8 steps' stores have retired (far reads rely on it)
     a("ds_write_b32 %[fme], v220")                             # progress: after the ring writes (a wave's LDS operations execute in order)
