@@ -211,11 +211,13 @@ void build_rows(pagan_msa *m) {
     const int n = m->n_leaves;
     const int root_id = m->id_of_tree[m->root];
     const int width = m->graph[root_id]->g.n_sites() - 2;
-    std::vector<std::vector<int32_t>> col(m->graph.size());
-    col[root_id].resize(width + 2);
+    // a node's column map: site -> column of the alignment (-1: none).  Storage that the host's threads touch first (round 5:
+    // the maps' 27 MB and the rows' 8 MB of a 32 x 100 kb walk, allocated and filled by one thread, were most of this function's time)
+    std::vector<std::unique_ptr<int32_t[]>> col(m->graph.size());
+    col[root_id].reset(new int32_t[width + 2]);
     for (int s = 0; s < width + 2; ++s) col[root_id][s] = s - 1;
     const int w = m->mf.type == kCodon ? 3 : 1;                 // characters per column ("---" gaps for codons)
-    m->rows.assign(m->graph.size(), std::string((size_t)width * w, '-'));
+    m->rows.assign(m->graph.size(), std::string());
     const std::string &anc = m->mf.type == kCodon ? m->mf.codon_names : m->mf.ancestral_alphabet;
     // A node's columns follow from its parent's: the tree is walked by DEPTH, the nodes of one depth side by side on the
     // host's threads (round 5: one thread walking all 2n - 1 nodes was 25 ms of a 0.7 s walk of 32 x 100 kb).
@@ -232,34 +234,55 @@ void build_rows(pagan_msa *m) {
         }
     }
     const int threads = host_threads_of(m);
+    parallel_for((int)m->rows.size(), threads, [&](int id) { m->rows[id].assign((size_t)width * w, '-'); });
     for (const std::vector<int> &ids : by_depth) {
         // the upper depths hold 1, 2, 4 nodes of 10^5 sites each: a node's sites in `parts` ranges (every site writes its own
         // column of its own row and its own entries of the children's column maps)
         const int parts = std::max(1, std::min(threads, (2 * threads) / std::max(1, (int)ids.size())));
+        std::vector<int> kids;
         for (int id : ids)
             if (id >= n) {
                 const TreeNode &t = m->tree[m->tree_of_id[id]];
-                col[m->id_of_tree[t.left]].assign(m->graph[m->id_of_tree[t.left]]->g.n_sites(), -1);
-                col[m->id_of_tree[t.right]].assign(m->graph[m->id_of_tree[t.right]]->g.n_sites(), -1);
+                for (int kid : {m->id_of_tree[t.left], m->id_of_tree[t.right]}) {
+                    if (kid < n) continue;                     // (a leaf has no map: its parent writes the leaf's row, below)
+                    col[kid].reset(new int32_t[m->graph[kid]->g.n_sites()]);
+                    kids.push_back(kid);
+                }
             }
+        parallel_for((int)kids.size() * parts, threads, [&](int task) {
+            const int kid = kids[task / parts], part = task % parts, ns = m->graph[kid]->g.n_sites();
+            std::fill(col[kid].get() + (long long)ns * part / parts, col[kid].get() + (long long)ns * (part + 1) / parts, -1);
+        });
         parallel_for((int)ids.size() * parts, threads, [&](int task) {
             const int id = ids[task / parts], part = task % parts;
             const SeqGraph &g = m->graph[id]->g;
             std::string &row = m->rows[id];
-            const std::vector<int32_t> &mine = col[id];
+            const int32_t *mine = col[id].get();
             const int n_in = g.n_sites() - 2;                      // sites 1 .. n_in
             const int s_first = 1 + (int)((long long)n_in * part / parts), s_last = 1 + (int)((long long)n_in * (part + 1) / parts);
-            if (id < n) {                                          // a leaf: its residues at its columns
+            if (id < n) {                                          // a leaf: its residues at its columns (only a tree of one leaf comes here)
+                if (!mine) return;
                 for (int s = s_first; s < s_last; ++s)
                     for (int c = 0; c < w; ++c) row[(size_t)mine[s] * w + c] = g.symbols[(size_t)(s - 1) * w + c];
                 return;
             }
             const TreeNode &t = m->tree[m->tree_of_id[id]];
             const int lid = m->id_of_tree[t.left], rid = m->id_of_tree[t.right];
-            std::vector<int32_t> &cl = col[lid], &cr = col[rid];
+            int32_t *cl = col[lid].get(), *cr = col[rid].get();
+            // a child that is a leaf has no map of its own (half of a tree's nodes, and of the maps' pages): its residues go to
+            // its row from here, site c of the leaf at this site's column
+            const SeqGraph *gl = lid < n ? &m->graph[lid]->g : nullptr, *gr = rid < n ? &m->graph[rid]->g : nullptr;
+            std::string *rl = lid < n ? &m->rows[lid] : nullptr, *rr = rid < n ? &m->rows[rid] : nullptr;
             for (int s = s_first; s < s_last; ++s) {
-                if (g.child_l[s] >= 0) cl[g.child_l[s]] = mine[s];
-                if (g.child_r[s] >= 0) cr[g.child_r[s]] = mine[s];
+                const int a = g.child_l[s], b = g.child_r[s];
+                if (a >= 0) {
+                    if (gl) { for (int c = 0; c < w; ++c) (*rl)[(size_t)mine[s] * w + c] = gl->symbols[(size_t)(a - 1) * w + c]; }
+                    else cl[a] = mine[s];
+                }
+                if (b >= 0) {
+                    if (gr) { for (int c = 0; c < w; ++c) (*rr)[(size_t)mine[s] * w + c] = gr->symbols[(size_t)(b - 1) * w + c]; }
+                    else cr[b] = mine[s];
+                }
                 // the ancestor's own row (get_alignment_column_at with include_internal_nodes, node.cpp:808-818): its
                 // state's character, a gap where the site is skipped or was deleted
                 const int ps = g.path_state[s];
@@ -267,7 +290,7 @@ void build_rows(pagan_msa *m) {
                     for (int c = 0; c < w; ++c) row[(size_t)mine[s] * w + c] = anc[(size_t)g.state[s] * w + c];
             }
         });
-        for (int id : ids) if (id >= n) { col[id].clear(); col[id].shrink_to_fit(); }
+        for (int id : ids) col[id].reset();
     }
 }
 
