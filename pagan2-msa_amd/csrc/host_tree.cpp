@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <sched.h>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -440,8 +441,32 @@ int pagan_msa_create(int32_t n_seqs, const char *const *names, const char *const
 
 namespace {
 
+// The threads the host-side phases use when the caller names none: what this process may actually run on -- the hardware's
+// threads, cut down to the affinity mask and to the cgroup's CPU quota -- and at most 16 (round 5: a GPU box reports 256
+// hardware threads to a process that owns a 16-core share; 256 threads per phase there made the rows 85-97 ms instead of 20,
+// and every phase is memory- or allocation-bound well before 16).
+int default_host_threads() {
+    static const int cached = [] {
+        long long t = (long long)std::thread::hardware_concurrency();
+        if (t < 1) t = 1;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) t = std::min<long long>(t, CPU_COUNT(&set));
+        long long quota = -1, period = 0;
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {                     // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0};
+            if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atoll(q);
+            std::fclose(f);
+        } else {                                                                       // cgroup v1
+            if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(g, "%lld", &quota) != 1) quota = -1; std::fclose(g); }
+            if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(g, "%lld", &period) != 1) period = 0; std::fclose(g); }
+        }
+        if (quota > 0 && period > 0) t = std::min(t, std::max(1ll, (quota + period - 1) / period));
+        return (int)std::max(1ll, std::min(t, 16ll));
+    }();
+    return cached;
+}
 int host_threads_of(const pagan_msa *m) {
-    int threads = m->opts.host_threads > 0 ? m->opts.host_threads : (int)std::thread::hardware_concurrency();
+    const int threads = m->opts.host_threads > 0 ? m->opts.host_threads : default_host_threads();
     return threads < 1 ? 1 : threads;
 }
 
