@@ -49,6 +49,9 @@ WORKLOADS = {
     "codon_16x1500_full": (6, 16, 1500, 0.03, 0.04, 0.004, 3.0, 0, "CODON"),
     # forward/backward (--full-probability) over the 15 node pairs of cfg2's tree
     "fb_cfg2_16x2kb_dna_full": (2, 16, 2000, 0.05, 0.04, 0.004, 4.0, 0, "ACGT"),
+    # forward/backward inside the tunnel: the 16 leaf pairs of cfg4's tree (2 x 100 kb each, the band define_tunnel gives them);
+    # narrow diagonals, so the sweeps are pg_fb_forward / pg_fb_backward themselves (one workgroup per pair and direction)
+    "fb_cfg4_leafpairs_banded": (4, 32, 100000, 0.01, 0.008, 0.0008, 4.0, 1, "ACGT"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_CELL = 36            # 3 states x (f64 score + u32 back-pointer), SURVEY.md s.8(d)
@@ -149,7 +152,11 @@ def bench_forward_backward(args, device):
     bf /= bf.sum()
     n_nodes = msa.n_internal
     jobs = []
+    leaf_pairs_only = "leafpairs" in workload
     for k in range(n_nodes):
+        info = msa.node_info(k)
+        if leaf_pairs_only and not (info.left < leaves and info.right < leaves):
+            continue
         left, right, _model, band = msa.node_job(k)
         jobs.append((left, right, host.model_prob(1 if len(alphabet) == 4 else 2, msa.node_info(k).dist, base_freq=bf), band))
 
@@ -176,7 +183,7 @@ def bench_forward_backward(args, device):
             for fb in fbs:
                 fb.close()
         wall = time.perf_counter() - t0
-        return sum(r[0] for r in rs), sum(r[1] for r in rs), sum(r[2] for r in rs), [r[3] for r in rs], wall
+        return sum(r[0] for r in rs), sum(r[1] for r in rs), sum(r[2] for r in rs), [r[3] for r in rs], wall, [r[2] for r in rs]
 
     for _ in range(args.warmup):
         one_pass()
@@ -192,7 +199,7 @@ def bench_forward_backward(args, device):
         "value": cells / dev_s, "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dev_s, "higher_is_better": True, "scaling": None, "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": workload, "leaves": leaves, "length": length, "node_pairs": n_nodes, "cells_per_step": int(cells),
+        "config": {"workload": workload, "leaves": leaves, "length": length, "node_pairs": len(jobs), "cells_per_step": int(cells),
                    "hip_hw_queues_requested": os.environ.get("GPU_MAX_HW_QUEUES"),
                    "hip_hw_queues_in_environment_at_start": os.environ.get("PAGAN_BENCH_HW_QUEUES_AT_START"),
                    "call": "one pagan_fb_run per pair from a thread pool" if args.fb_one_by_one else "one pagan_fb_run_batch for all pairs (the wide pairs' forward sweeps in one launch, their backward sweeps in another)",
@@ -209,17 +216,18 @@ def bench_forward_backward(args, device):
         oracle.build()
         t0 = time.perf_counter()
         c_cells, used, agree = 0, 0, True
-        for (left, right, mp, band), (lf, lb) in zip(jobs, totals):
+        per_pair = acc[-1][5]
+        for (left, right, mp, band), (lf, lb), pair_cells in zip(jobs, totals, per_pair):
             if time.perf_counter() - t0 > args.cpu_seconds:
                 break
             olf, olb, _p, _f = oracle.fb(left, right, mp, band=band, matrices=False)
             agree = agree and abs(olf - lf) <= 1e-9 * abs(olf) and abs(olb - lb) <= 1e-9 * abs(olb)
-            c_cells += (left.n_sites - 1) * (right.n_sites - 1) if band is None else 0
+            c_cells += pair_cells            # (the cells of the pair's matrix, or of its tunnel: what the GPU counted for it)
             used += 1
         secs = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": c_cells / secs if secs > 0 else 0.0, "unit": "cells/s", "cores": 1, "kind": "port",
                                "sample": "%d of %d node pairs, log-space restatement of the reference's forward + backward, %.1f s, single thread"
-                                         % (used, n_nodes, secs), "matches_gpu": bool(agree)}
+                                         % (used, len(jobs), secs), "matches_gpu": bool(agree)}
         ok = ok and agree
     print(json.dumps(out))
     if not ok:

@@ -89,14 +89,18 @@ template <class P> struct Pass {
     ProbModel m;
     int Lx, Ly;
     std::vector<int> lo, hi;                 // band per row
-    std::vector<P> fw, bw;                   // [(i*Ly + j)*3 + state], state 0 X, 1 Y, 2 M
+    std::vector<size_t> roff;                // cells of the rows above row i: only the band's cells are stored (a 2 x 100 kb tunnel
+                                             // is 9e6 cells of a 1e10-cell matrix)
+    std::vector<int> cmin, cmax;             // first / last row whose band holds column j (cmax < cmin: none)
+    std::vector<P> fw, bw;                   // [(roff[i] + j - lo[i])*3 + state], state 0 X, 1 Y, 2 M
     P fwd_end = P::zero();
 
     bool in(int i, int j) const { return i >= 0 && i < Lx && j >= lo[i] && j <= hi[i]; }
-    P F(int s, int i, int j) const { return in(i, j) ? fw[((size_t)i * Ly + j) * 3 + s] : P::zero(); }
-    P B(int s, int i, int j) const { return in(i, j) ? bw[((size_t)i * Ly + j) * 3 + s] : P::zero(); }
-    P &Fw(int s, int i, int j) { return fw[((size_t)i * Ly + j) * 3 + s]; }
-    P &Bw(int s, int i, int j) { return bw[((size_t)i * Ly + j) * 3 + s]; }
+    size_t at(int s, int i, int j) const { return (roff[i] + (size_t)(j - lo[i])) * 3 + s; }
+    P F(int s, int i, int j) const { return in(i, j) ? fw[at(s, i, j)] : P::zero(); }
+    P B(int s, int i, int j) const { return in(i, j) ? bw[at(s, i, j)] : P::zero(); }
+    P &Fw(int s, int i, int j) { return fw[at(s, i, j)]; }
+    P &Bw(int s, int i, int j) { return bw[at(s, i, j)]; }
     // get_edge_weight (probability space) is the float posterior weight w; the CSR carries logf(w), so the weight
     // used here is exp((double) logf(w)) = w (1 +- 6e-8) for the few edges with w != 1 (w = 1 is exact)
     P lw(int k) const { return P::from_log((double)L->bwd_logw[k]); }
@@ -107,12 +111,18 @@ template <class P> struct Pass {
         Lx = l->n_sites - 1; Ly = r->n_sites - 1;
         lo.assign(Lx, 0); hi.assign(Lx, Ly - 1);
         if (band) for (int i = 0; i < Lx; i++) { lo[i] = std::max(0, band->upper[i]); hi[i] = std::min(band->lower[i], Ly - 1); }
-        fw.assign((size_t)Lx * Ly * 3, P::zero()); bw = fw;
+        roff.assign(Lx + 1, 0);
+        cmin.assign(Ly, Lx); cmax.assign(Ly, -1);
+        for (int i = 0; i < Lx; i++) {
+            roff[i + 1] = roff[i] + (size_t)std::max(0, hi[i] - lo[i] + 1);
+            for (int j = lo[i]; j <= hi[i]; j++) { cmin[j] = std::min(cmin[j], i); cmax[j] = std::max(cmax[j], i); }
+        }
+        fw.assign(roff[Lx] * 3, P::zero()); bw = fw;
     }
 
     void forward() {
         const P ext = P::of(m.gap_ext), open = P::of(m.gap_open), ng = P::of(m.non_gap), close = P::of(1.0f);
-        Fw(2, 0, 0) = P::of(1.0);                                                      // VA:730
+        if (in(0, 0)) Fw(2, 0, 0) = P::of(1.0);                                        // VA:730
         for (int i = 0; i < Lx; i++)
             for (int j = lo[i]; j <= hi[i]; j++) {
                 if (i == 0 && j == 0) continue;
@@ -183,7 +193,7 @@ template <class P> struct Pass {
         for (int k1 = l0; k1 < l1; k1++) if (in(L->bwd_src[k1], Ly - 1)) Bw(0, L->bwd_src[k1], Ly - 1) = close;
         for (int k2 = r0; k2 < r1; k2++) if (in(Lx - 1, R->bwd_src[k2])) Bw(1, Lx - 1, R->bwd_src[k2]) = close;
         for (int j = Ly - 1; j >= 0; j--)
-            for (int i = Lx - 1; i >= 0; i--) {
+            for (int i = cmax[j]; i >= cmin[j]; i--) {          // (the rows of the column's band cells, last first: the same order as over all rows)
                 if (!in(i, j)) continue;
                 P bx = Bw(0, i, j), by = Bw(1, i, j), bm = Bw(2, i, j);
                 for (int k = fl.off[i]; k < fl.off[i + 1]; k++) {                      // iterate_fwd_edges_for_gap, left
@@ -219,9 +229,16 @@ int run(const pagan_graph *l, const pagan_graph *r, const ProbModel &pm, const p
     ps.backward();
     *log_fwd = ps.fwd_end.log();
     *log_bwd = ps.B(2, 0, 0).log();
-    const size_t n = (size_t)ps.Lx * ps.Ly * 3;
-    if (post) for (size_t k = 0; k < n; k++) post[k] = std::exp(ps.fw[k].log() + ps.bw[k].log() - ps.fwd_end.log());   // VA:1029-1034
-    if (log_f) for (size_t k = 0; k < n; k++) log_f[k] = ps.fw[k].log();
+    // (outside the band: probability 0 -- posterior 0, log forward -inf -- as the stored zeros gave before)
+    if (post || log_f)
+        for (int i = 0; i < ps.Lx; i++)
+            for (int j = 0; j < ps.Ly; j++)
+                for (int st = 0; st < 3; st++) {
+                    const size_t k = ((size_t)i * ps.Ly + j) * 3 + st;
+                    const bool in = ps.in(i, j);
+                    if (post) post[k] = in ? std::exp(ps.F(st, i, j).log() + ps.B(st, i, j).log() - ps.fwd_end.log()) : 0.0;   // VA:1029-1034
+                    if (log_f) log_f[k] = in ? ps.F(st, i, j).log() : -HUGE_VAL;
+                }
     return 0;
 }
 

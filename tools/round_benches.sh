@@ -8,7 +8,7 @@ mkdir -p $O
 cd $R
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
 tail -c 1500 $O/bench_final.json
-for w in cfg2_16x2kb_dna_full cfg3_64x500aa_protein_full cfg5_512x10kb_dna_anchored codon_16x1500_full codon_16x1500_anchored fb_cfg2_16x2kb_dna_full; do
+for w in cfg2_16x2kb_dna_full cfg3_64x500aa_protein_full cfg5_512x10kb_dna_anchored codon_16x1500_full codon_16x1500_anchored fb_cfg2_16x2kb_dna_full fb_cfg4_leafpairs_banded; do
     python bench.py --workload $w --steps 5 --warmup 1 > $O/bench_$w.json 2> $O/bench_$w.err
     python - $O/bench_$w.json <<'PY'
 import json, sys
