@@ -234,6 +234,8 @@ def declare(lib):
     lib.pagan_fb_totals.restype = C.c_int
     lib.pagan_fb_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.pagan_fb_kernel_ms.restype = C.c_int
+    lib.pagan_fb_groups.argtypes = [C.c_void_p]
+    lib.pagan_fb_groups.restype = C.c_int
     lib.pagan_fb_dump.argtypes = [C.c_void_p, C.c_int32, f64p]
     lib.pagan_fb_dump.restype = C.c_int
     lib.pagan_fb_posterior_cells.argtypes = [C.c_void_p, C.c_int32, _i32p, f64p]
@@ -251,5 +253,5 @@ EXPORTED = ["pagan_dp_align", "pagan_dp_align_batch", "pagan_result_free", "paga
             "pagan_dp_count_cells", "pagan_dp_device_count", "pagan_dp_select_device", "pagan_batch_create",
             "pagan_batch_run", "pagan_batch_sync", "pagan_batch_fetch", "pagan_batch_last_ms",
             "pagan_batch_cells", "pagan_batch_last_ms_detail", "pagan_batch_destroy", "pagan_batch_debug_trace", "pagan_dp_debug_plan", "pagan_dp_debug_far", "pagan_dp_debug_strips", "pagan_dp_debug_tiles", "pagan_dp_debug_compact", "pagan_dp_debug_tiles_staircase", "pagan_dp_release_cache", "pagan_dp_cached_device_bytes", "pagan_dp_debug_route", "pagan_batch_debug_scores", "pagan_batch_debug_backptrs", "pagan_batch_debug_poison", "pagan_batch_debug_followed", "pagan_batch_debug_poke_bp", "pagan_batch_debug_reruns",
-            "pagan_fb_run", "pagan_fb_run_batch", "pagan_fb_totals", "pagan_fb_kernel_ms", "pagan_fb_dump", "pagan_fb_posterior_cells", "pagan_fb_sample_path",
+            "pagan_fb_run", "pagan_fb_run_batch", "pagan_fb_totals", "pagan_fb_kernel_ms", "pagan_fb_groups", "pagan_fb_dump", "pagan_fb_posterior_cells", "pagan_fb_sample_path",
             "pagan_fb_destroy", "pagan_dp_version"]

@@ -309,6 +309,23 @@ __device__ __forceinline__ bool fb_block_live(const PgFbJob &J, int i0, int j0, 
     return __builtin_amdgcn_ballot_w64(any) != 0;
 }
 
+// The block rows a <= a' <= b that can hold a cell of block anti-diagonal t: the rows of the band's cells on its 127 cell
+// diagonals (exact for any band: a minimum and a maximum over the diagonals' intervals).  A tunnel around the main diagonal of
+// 2 x 100 kb has 1,563 blocks on its longest block anti-diagonal and a cell in two or three of them.
+__device__ __forceinline__ void fb_live_rows(const PgFbJob &J, int t, int r, int &a_first, int &a_last) {
+    int lo = 0x7fffffff, hi = -1;
+    for (int u = 0; u < 2; ++u) {
+        const int d = FB_T * t + r + 64 * u;
+        if (d < J.nd && r + 64 * u <= 2 * FB_T - 2) {
+            const int mn = J.imin[d], mx = J.imax[d];
+            if (mx >= mn) { lo = min(lo, mn); hi = max(hi, mx); }
+        }
+    }
+    for (int w = 32; w >= 1; w >>= 1) { lo = min(lo, __shfl_xor(lo, w, 64)); hi = max(hi, __shfl_xor(hi, w, 64)); }
+    a_first = hi < 0 ? 1 : lo / FB_T;
+    a_last = hi < 0 ? 0 : hi / FB_T;
+}
+
 // lane n takes lane n-1's v; lane 0 keeps `lane0`
 __device__ __forceinline__ double fb_shr1(double v, double lane0) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -347,7 +364,12 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs) {
     const bool tab_lds = J.S * J.S <= 256;
     if (tab_lds) for (int k = r; k < J.S * J.S; k += 64) M.ltab[k] = J.ltab[k];
     for (int t = 0; t < nbr + nbc - 1; ++t) {
-        const int a_lo = max(0, t - (nbc - 1)), a_hi = min(t, nbr - 1);
+        int a_lo = max(0, t - (nbc - 1)), a_hi = min(t, nbr - 1);
+        {
+            int a_first, a_last;
+            fb_live_rows(J, t, r, a_first, a_last);
+            a_lo = max(a_lo, a_first); a_hi = min(a_hi, a_last);
+        }
         for (int a = a_lo + (int)blockIdx.x; a <= a_hi; a += G) {
             const int i0 = a * FB_T, j0 = (t - a) * FB_T, dbase = i0 + j0;
             if (!fb_block_live(J, i0, j0, r)) continue;
@@ -519,7 +541,12 @@ __global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs) 
     //  cell starts from, in the blocks that hold such a cell)
     int round = 0;
     for (int t = nbr + nbc - 2; t >= 0; --t) {
-        const int a_lo = max(0, t - (nbc - 1)), a_hi = min(t, nbr - 1);
+        int a_lo = max(0, t - (nbc - 1)), a_hi = min(t, nbr - 1);
+        {
+            int a_first, a_last;
+            fb_live_rows(J, t, r, a_first, a_last);
+            a_lo = max(a_lo, a_first); a_hi = min(a_hi, a_last);
+        }
         for (int a = a_lo + (int)blockIdx.x; a <= a_hi; a += G) {
             const int i0 = a * FB_T, j0 = (t - a) * FB_T, dbase = i0 + j0;
             if (!fb_block_live(J, i0, j0, r)) continue;
@@ -854,6 +881,17 @@ static int fb_stage(const pagan_graph *left, const pagan_graph *right, const pag
     // one-workgroup sweeps
     const int mw = fb->dx.max_width;
     int groups = mw > 256 ? std::min({FB_MAX_GROUPS, (Lx + FB_T - 1) / FB_T, (Ly + FB_T - 1) / FB_T}) : 1;
+    // A long tunnel (round 5; the leaf pairs of 32 x 100 kb: 2e5 diagonals of ~25 cells) on the block schedule as well: its one
+    // workgroup paid a __syncthreads() and a round trip to L2 per cell diagonal (2.7 us: 0.55 s a sweep); as blocks it is the few
+    // blocks the band has on a block anti-diagonal (fb_live_rows), a wave each, operands in registers / LDS, one counter barrier per
+    // 64 diagonals.  Workgroups: the blocks a diagonal of `mw` cells can lie in while it moves through 127 diagonals.
+    // PAGAN_FB_BAND_MIN_ND: the shortest pair (in cell diagonals) that takes this path (tests: 0; "off": none).
+    {
+        int min_nd = 4096;
+        if (const char *e = std::getenv("PAGAN_FB_BAND_MIN_ND")) min_nd = std::strcmp(e, "off") == 0 ? 0x7fffffff : std::atoi(e);
+        if (groups == 1 && nd >= min_nd && Lx >= 2 && Ly >= 2)
+            groups = std::max(2, std::min({FB_MAX_GROUPS, (mw + FB_T - 1) / FB_T + 2, (Lx + FB_T - 1) / FB_T, (Ly + FB_T - 1) / FB_T}));
+    }
     if (const char *e = std::getenv("PAGAN_FB_GROUPS")) groups = std::max(1, std::min(FB_MAX_GROUPS, std::atoi(e)));
     const int groups_b = groups > 1 ? std::max(2, std::min(groups, groups_cap_b)) : 1;
     if (groups > 1) groups = std::max(2, std::min(groups, groups_cap));
@@ -1092,6 +1130,8 @@ int pagan_fb_kernel_ms(const pagan_fb *fb, double ms[2]) {
     ms[0] = fb->kernel_ms[0]; ms[1] = fb->kernel_ms[1];
     return PAGAN_OK;
 }
+
+int pagan_fb_groups(const pagan_fb *fb) { return fb ? fb->groups : PAGAN_E_ARG; }
 
 int pagan_fb_totals(const pagan_fb *fb, double *log_fwd, double *log_bwd, int64_t *cells) {
     if (!fb) return PAGAN_E_ARG;

@@ -162,3 +162,66 @@ def test_a_batch_larger_than_one_launch_holds(pg, oracle):
         lf, lb, _post, _logf = oracle.fb(gl, gr, mp_, band=band, matrices=False)
         assert abs(batch[k].log_fwd - lf) <= LOG_TOL * max(1, abs(lf)) and abs(batch[k].log_bwd - lb) <= LOG_TOL * max(1, abs(lb)), k
         batch[k].close()
+
+
+def _random_tunnel(rng, Lx, Ly, lo_half, hi_half):
+    half = rng.integers(lo_half, hi_half, Lx)
+    centre = np.arange(Lx) * (Ly - 1) // max(Lx - 1, 1)
+    upper = np.maximum.accumulate(np.maximum(centre - half, 0))
+    lower = np.maximum.accumulate(np.minimum(centre + half, Ly - 1))
+    upper[0] = 0
+    lower[-1] = Ly - 1
+    return abi.Band(upper.astype(np.int32), lower.astype(np.int32))
+
+
+def test_tunnels_on_the_block_schedule(pg, oracle, monkeypatch):
+    """A long narrow tunnel runs as 64 x 64 blocks too (round 5: fb_live_rows picks the few blocks the band has on a block
+    anti-diagonal).  PAGAN_FB_BAND_MIN_ND=0 sends pairs of any length there: leaf pairs and graph pairs with multi-edge sites
+    behind random tunnels (5 to 70 columns either side: narrower and wider than a block, edges that leave it), every cell of both
+    matrices against the oracle; the same pairs on the one-workgroup kernels ("off") give the same sums."""
+    rng = np.random.default_rng(77)
+    names, seqs, nwk = synth.evolve_balanced(4, 700, branch=0.04, sub=0.04, indel_start=0.01, mean_len=4, seed=46)
+    msa = host.Msa(names, seqs, nwk, use_anchors=0).align()
+    bf = np.array([sum(s.count(x) for s in seqs) for x in "ACGT"], np.float32)
+    bf /= bf.sum()
+    cases = []
+    for k in range(msa.n_internal):
+        left, right, _model, _band = msa.node_job(k)
+        mp = host.model_prob(1, msa.node_info(k).dist, base_freq=bf)
+        for lo_half, hi_half in ((5, 12), (20, 70)):
+            cases.append((left, right, mp, _random_tunnel(rng, left.n_sites - 1, right.n_sites - 1, lo_half, hi_half)))
+    assert sum(int((np.diff(c[0].bwd_off) > 1).sum() + (np.diff(c[1].bwd_off) > 1).sum()) for c in cases) > 0
+    monkeypatch.setenv("PAGAN_FB_BAND_MIN_ND", "0")
+    blocked = []
+    for left, right, mp, band in cases:
+        fb = pgm.FullProbability(left, right, mp, band)
+        lf, lb, post, logf = oracle.fb(left, right, mp, band=band)
+        assert abs(fb.log_fwd - lf) <= LOG_TOL * max(1, abs(lf)) and abs(fb.log_bwd - lb) <= LOG_TOL * max(1, abs(lb))
+        assert close_logs(fb.log_forward(), logf)
+        assert np.allclose(fb.posterior(), post, rtol=1e-7, atol=1e-12)
+        blocked.append((fb.log_fwd, fb.log_bwd))
+        fb.close()
+    # ... and through the batch call (all pairs' sweeps in one launch per direction)
+    fbs = pgm.full_probability_batch(cases)
+    for fb, (f, b) in zip(fbs, blocked):
+        assert fb.log_fwd == f and fb.log_bwd == b
+        fb.close()
+    monkeypatch.setenv("PAGAN_FB_BAND_MIN_ND", "off")
+    for (left, right, mp, band), (f, b) in zip(cases, blocked):
+        fb = pgm.FullProbability(left, right, mp, band)
+        assert abs(fb.log_fwd - f) <= LOG_TOL * max(1, abs(f)) and abs(fb.log_bwd - b) <= LOG_TOL * max(1, abs(b))
+        fb.close()
+
+
+def test_long_tunnel_takes_the_block_schedule_by_default(pg, oracle):
+    """2 x 6 kb inside define_tunnel's band (12 k cell diagonals: beyond the default threshold): totals against the oracle."""
+    _, seqs, _ = synth.evolve_balanced(2, 6000, branch=0.02, sub=0.02, indel_start=0.003, mean_len=4, seed=47)
+    gl, gr = (host.HGraph.leaf(s).flatten() for s in seqs)
+    band, _ = host.define_tunnel(seqs[0], seqs[1], seqs[0], seqs[1])
+    mp = host.model_prob(1, 0.04, base_freq=[0.25] * 4)
+    fb = pgm.FullProbability(gl, gr, mp, band)
+    assert fb.groups > 1
+    lf, lb, _, _ = oracle.fb(gl, gr, mp, band=band, matrices=False)
+    assert abs(fb.log_fwd - lf) <= LOG_TOL * abs(lf) and abs(fb.log_bwd - lb) <= LOG_TOL * abs(lb)
+    assert abs(fb.log_fwd - fb.log_bwd) < 1e-7
+    fb.close()
