@@ -891,6 +891,9 @@ static int fb_stage(const pagan_graph *left, const pagan_graph *right, const pag
         if (const char *e = std::getenv("PAGAN_FB_BAND_MIN_ND")) min_nd = std::strcmp(e, "off") == 0 ? 0x7fffffff : std::atoi(e);
         if (groups == 1 && nd >= min_nd && Lx >= 2 && Ly >= 2)
             groups = std::max(2, std::min({FB_MAX_GROUPS, (mw + FB_T - 1) / FB_T + 2, (Lx + FB_T - 1) / FB_T, (Ly + FB_T - 1) / FB_T}));
+        // (and a pair that is "wide" by a box of its tunnel -- one of the 16 leaf pairs has a diagonal of 295 cells -- does not need
+        //  the 64 workgroups of a full matrix at every barrier: a diagonal of mw cells lies in mw / 64 + 2 blocks at most)
+        else if (groups > 1) groups = std::max(2, std::min(groups, (mw + FB_T - 1) / FB_T + 2));
     }
     if (const char *e = std::getenv("PAGAN_FB_GROUPS")) groups = std::max(1, std::min(FB_MAX_GROUPS, std::atoi(e)));
     const int groups_b = groups > 1 ? std::max(2, std::min(groups, groups_cap_b)) : 1;
