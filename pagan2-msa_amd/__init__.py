@@ -115,7 +115,7 @@ class FullProbability:
         kms = (C.c_double * 2)()
         _check(self._L.pagan_fb_kernel_ms(self._h, kms), "pagan_fb_kernel_ms")
         self.forward_ms, self.backward_ms = kms[0], kms[1]
-        self.groups = self._L.pagan_fb_groups(self._h)       # 1: one-workgroup sweeps; > 1: 64 x 64 blocks, a wave each
+        self.groups = self._L.pagan_fb_groups(self._h)       # 1: one-workgroup sweeps; > 1: 64 x 64 blocks, a wave each; 0: LDS-ring sweeps
         self.shape = (left.n_sites - 1, right.n_sites - 1, 3)
 
     def _dump(self, which):

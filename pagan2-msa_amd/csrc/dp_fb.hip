@@ -56,6 +56,7 @@ struct PgFbJob {
     // pagan_fb_run_batch): the pair's own workgroup count and barrier words
     int groups, groups_b;                    // workgroups of this pair's forward / backward sweep (blockIdx.x beyond: nothing to do)
     int *sync;                               // [64] ints: forward barrier at [0..7], backward at [8..15], diagnostics behind
+    int init_dmin;                           // the first cell diagonal that holds a cell of init_at (nd: none)
 };
 
 namespace {
@@ -123,6 +124,16 @@ __device__ __forceinline__ double lse3(double a, double b, double c) {
     // the two that are not the (first) largest
     const double u = a == hi ? b : a, v = (a == hi || b == hi) ? c : b;
     return hi + fb_log_1to3(1.0 + (fb_exp_neg(u - hi) + fb_exp_neg(v - hi)));
+}
+
+// The model's log score: from the LDS copy when the table fits (S * S <= 256), else from memory -- as two loads in two address
+// spaces behind a uniform branch.  Written as `tab_lds ? M.ltab[k] : J.ltab[k]` the compiler selects the POINTER and emits one
+// flat load, and a flat load is a vector memory operation: s_waitcnt vmcnt(0) behind it waited for the wave's stores of the step
+// before, on every step of every sweep.
+typedef const __attribute__((address_space(1))) double *fb_gcd;
+__device__ __forceinline__ double fb_score(bool tab_lds, const double *lds_tab, const double *mem_tab, int a, int b, int S) {
+    if (tab_lds) return lds_tab[a + b * S];
+    return ((fb_gcd)(unsigned long long)mem_tab)[a + (long long)b * S];
 }
 
 __device__ __forceinline__ long long cell_at(const PgFbJob &J, int p, int q) {
@@ -231,6 +242,206 @@ __global__ __launch_bounds__(1024) void pg_fb_backward(const PgFbJob *jobs) {
         }
         __syncthreads();
     }
+    if (threadIdx.x == 0) J.totals[1] = rd(J.B, cell_at(J, 0, 0), 2);
+}
+
+// ---- long tunnels between plain sequences: one workgroup, lane = row mod B, the last diagonals in an LDS ring ----
+// (round 5, last session.)  The one-workgroup sweeps above pay a full __syncthreads() -- the wave's stores acknowledged -- and
+// round trips to L2 for operands and list entries on every cell diagonal (2.7 us); the block schedule sweeps every cell diagonal
+// of a tunnel twice, with 25 of 64 lanes at work, behind a counter barrier.  When every site of both graphs has exactly one edge,
+// from the site before it (leaf sequences: what a tunnel of 2 x 100 kb is made of), a cell reads (i-1, j), (i, j-1) of the
+// diagonal before and (i-1, j-1) of the one before that, and nothing else.  Thread x owns the row i = x (mod B) of the current
+// diagonal (B = blockDim >= the widest diagonal: at most one such row), the last three diagonals live in LDS ([slot][state][x]; an
+// idle thread writes -inf), an operand is a read of the neighbouring lane's slot -- valid if that row was in the band on that
+// diagonal, which two compares against the diagonal's interval tell --, the rows' and the columns' records (state, log weight of
+// the one edge) and the diagonals' intervals sit in LDS windows refilled every FB_RG_REFILL diagonals, and the step ends in
+// s_waitcnt lgkmcnt(0) + s_barrier: the scores go to memory unwaited-for.  Graph pairs (any site with another edge
+// list) and diagonals wider than 512 cells keep the block schedule.
+#define FB_RG_COLS 1024          // columns / rows in the LDS windows (>= B + 2 * FB_RG_REFILL)
+#define FB_RG_REFILL 256
+#define FB_RG_MAXB 512
+typedef __attribute__((address_space(1))) double *fb_gd;
+
+__device__ __forceinline__ void fb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Nothing on a step's path is a load from memory (a vector load would wait behind the wave's stores -- memory operations
+// complete in order --, and the compiler cannot make scalar loads of arrays it has only a pointer from memory to): the diagonals'
+// intervals and offsets, the rows' and the columns' records are staged every FB_RG_REFILL diagonals for the next FB_RG_REFILL.
+struct FbRingSmem {
+    double ring[3][3][FB_RG_MAXB];           // [diagonal slot][X, Y, M][thread]
+    int c_st[FB_RG_COLS]; float c_lw[FB_RG_COLS];      // column j at j % FB_RG_COLS: state, log weight of the edge (j-1) -> j
+    int r_st[FB_RG_COLS]; float r_lw[FB_RG_COLS];      // row i the same way
+    int dmin[FB_RG_REFILL], dmax[FB_RG_REFILL]; long long doff[FB_RG_REFILL];     // diagonal d at d % FB_RG_REFILL
+    double ltab[256];
+};
+
+__global__ __launch_bounds__(FB_RG_MAXB) void pg_fb_forward_ring(const PgFbJob *jobs) {
+    __shared__ FbRingSmem M;
+    const PgFbJob J = jobs[blockIdx.x];
+    const int B = (int)blockDim.x, x = (int)threadIdx.x, xm1 = (x - 1) & (B - 1);
+    const double NI = ninf();
+    const bool tab_lds = J.S * J.S <= 256;
+    if (tab_lds) for (int k = x; k < J.S * J.S; k += B) M.ltab[k] = J.ltab[k];
+    for (int q = 0; q < 9; ++q) (&M.ring[0][0][0])[q * FB_RG_MAXB + x] = NI;
+    int mn1 = 0, mx1 = -1, mn2 = 0, mx2 = -1;            // the intervals of the diagonals d-1, d-2
+    int s0 = 0, s1 = 2, s2 = 1;                          // ring slots of d, d-1, d-2
+    int cols_hi = -1, rows_hi = -1;                      // columns <= cols_hi, rows <= rows_hi are in the windows
+    const fb_gd F = (fb_gd)(unsigned long long)J.F;
+    __syncthreads();
+    for (int d = 0; d < J.nd; ++d) {
+        if ((d & (FB_RG_REFILL - 1)) == 0) {
+            // the next FB_RG_REFILL diagonals; their columns and rows: the largest of either grows by at most one a diagonal
+            for (int k = x; k < FB_RG_REFILL; k += B) {
+                const int dd = d + k;
+                const bool in = dd < J.nd;
+                M.dmin[k] = in ? J.imin[dd] : 0; M.dmax[k] = in ? J.imax[dd] : -1; M.doff[k] = in ? J.doff[dd] : 0;
+            }
+            const int mn_ = J.imin[d], mx_ = J.imax[d];
+            const int want_c = min(J.Ly - 1, d - mn_ + FB_RG_REFILL), want_r = min(J.Lx - 1, mx_ + FB_RG_REFILL);
+            for (int j = cols_hi + 1 + x; j <= want_c; j += B) {
+                M.c_st[j & (FB_RG_COLS - 1)] = J.stR[j];
+                M.c_lw[j & (FB_RG_COLS - 1)] = j > 0 ? J.lwR[j - 1] : 0.0f;       // (plain graph: site j's one edge is list entry j - 1)
+            }
+            for (int i = rows_hi + 1 + x; i <= want_r; i += B) {
+                M.r_st[i & (FB_RG_COLS - 1)] = J.stL[i];
+                M.r_lw[i & (FB_RG_COLS - 1)] = i > 0 ? J.lwL[i - 1] : 0.0f;
+            }
+            cols_hi = max(cols_hi, want_c); rows_hi = max(rows_hi, want_r);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fb_lds_barrier();
+        }
+        const int mn = M.dmin[d & (FB_RG_REFILL - 1)], mx = M.dmax[d & (FB_RG_REFILL - 1)];
+        const int i = mn + ((x - mn) & (B - 1));
+        const bool active = i <= mx;
+        double fx = NI, fy = NI, fm = NI;
+        if (active) {
+            const int j = d - i;
+            if (i == 0 && j == 0) {
+                fm = 0.0;                                                          // fwd_score = 1, VA:730
+            } else {
+                if (i > 0 && i - 1 >= mn1 && i - 1 <= mx1) {                       // (i-1, j): VA:2153, 2184, 2215
+                    const double ax = M.ring[s1][0][xm1], ay = M.ring[s1][1][xm1], am = M.ring[s1][2][xm1];
+                    fx = lse3(ax + J.l_ext, ay + J.l_open, am + J.l_ng + J.l_open);
+                }
+                if (j > 0 && i >= mn1 && i <= mx1) {                               // (i, j-1)
+                    const double px = M.ring[s1][0][x], py = M.ring[s1][1][x], pm = M.ring[s1][2][x];
+                    fy = lse3(py + J.l_ext, px + J.l_open, pm + J.l_ng + J.l_open);
+                }
+                if (i > 0 && j > 0 && i - 1 >= mn2 && i - 1 <= mx2) {              // (i-1, j-1): VA:2051, 2080, 2108
+                    const double cx = M.ring[s2][0][xm1], cy = M.ring[s2][1][xm1], cm = M.ring[s2][2][xm1];
+                    const int str = M.r_st[i & (FB_RG_COLS - 1)], stc = M.c_st[j & (FB_RG_COLS - 1)];
+                    const double sc = fb_score(tab_lds, M.ltab, J.ltab, str, stc, J.S);
+                    const double w = (double)M.r_lw[i & (FB_RG_COLS - 1)] + (double)M.c_lw[j & (FB_RG_COLS - 1)];
+                    const double mm = J.l_ng + J.l_ng + sc + w, xm = J.l_ng + sc + w;   // VA:1383-1391
+                    fm = lse3(cm + mm, cx + xm, cy + xm);
+                }
+            }
+            const fb_gd o = F + 3 * (M.doff[d & (FB_RG_REFILL - 1)] + (i - mn));
+            o[0] = fx; o[1] = fy; o[2] = fm;
+        }
+        M.ring[s0][0][x] = fx; M.ring[s0][1][x] = fy; M.ring[s0][2][x] = fm;
+        mn2 = mn1; mx2 = mx1; mn1 = mn; mx1 = mx;
+        { const int t = s2; s2 = s1; s1 = s0; s0 = t; }
+        fb_lds_barrier();
+    }
+    __syncthreads();                                                               // (the end corner reads the scores from memory)
+    if (threadIdx.x == 0) {
+        // end corner, VA:1440-1552
+        double acc = ninf();
+        const int l0 = J.offL[J.Lx], l1 = J.offL[J.Lx + 1], r0 = J.offR[J.Ly], r1 = J.offR[J.Ly + 1];
+        auto mt = [&](int k1, int k2) { return rd(J.F, cell_at(J, J.srcL[k1], J.srcR[k2]), 2) + J.l_ng + (double)J.lwL[k1] + (double)J.lwR[k2]; };
+        auto xc = [&](int k1) { return rd(J.F, cell_at(J, J.srcL[k1], J.Ly - 1), 0); };
+        auto yc = [&](int k2) { return rd(J.F, cell_at(J, J.Lx - 1, J.srcR[k2]), 1); };
+        if (l1 > l0 && r1 > r0) {
+            acc = lse(acc, mt(l0, r0)); acc = lse(acc, xc(l0)); acc = lse(acc, yc(r0));
+            for (int k2 = r0 + 1; k2 < r1; ++k2) { acc = lse(acc, mt(l0, k2)); acc = lse(acc, yc(k2)); }
+            for (int k1 = l0 + 1; k1 < l1; ++k1) {
+                acc = lse(acc, mt(k1, r0)); acc = lse(acc, xc(k1));
+                for (int k2 = r0 + 1; k2 < r1; ++k2) { acc = lse(acc, mt(k1, k2)); acc = lse(acc, yc(k2)); }
+            }
+        }
+        J.totals[0] = acc;
+    }
+}
+
+// Mirrored: diagonals nd-1 .. 0; a cell reads (i+1, j), (i, j+1) of the diagonal after it and (i+1, j+1) of the one after that;
+// the windows hold row t = i+1's and column u = j+1's records (state, weight of the edge from the site before).
+// What initialise_array_corner_bwd assigns (a handful of cells on the last diagonals, VA:740-854) is laid over the -inf a cell
+// starts from on the diagonals >= init_dmin, and there the sums are taken one by one as pg_fb_backward takes them.
+__global__ __launch_bounds__(FB_RG_MAXB) void pg_fb_backward_ring(const PgFbJob *jobs) {
+    __shared__ FbRingSmem M;
+    const PgFbJob J = jobs[blockIdx.x];
+    const int B = (int)blockDim.x, x = (int)threadIdx.x, xp1 = (x + 1) & (B - 1);
+    const double NI = ninf();
+    const bool tab_lds = J.S * J.S <= 256;
+    if (tab_lds) for (int k = x; k < J.S * J.S; k += B) M.ltab[k] = J.ltab[k];
+    for (int q = 0; q < 9; ++q) (&M.ring[0][0][0])[q * FB_RG_MAXB + x] = NI;
+    int mn1 = 0, mx1 = -1, mn2 = 0, mx2 = -1;            // the intervals of the diagonals d+1, d+2
+    int s0 = 0, s1 = 2, s2 = 1;
+    int cols_lo = J.Ly, rows_lo = J.Lx;                  // columns >= cols_lo, rows >= rows_lo are in the windows
+    const fb_gd Bm = (fb_gd)(unsigned long long)J.B;
+    __syncthreads();
+    for (int d = J.nd - 1; d >= 0; --d) {
+        if (d == J.nd - 1 || (d & (FB_RG_REFILL - 1)) == FB_RG_REFILL - 1) {
+            // the diagonals down to the next multiple of FB_RG_REFILL; columns u = j + 1 and rows t = i + 1: the smallest of either
+            // falls by at most one a diagonal
+            for (int k = x; k < FB_RG_REFILL; k += B) {
+                const int dd = (d & ~(FB_RG_REFILL - 1)) + k;
+                if (dd <= d) { M.dmin[k] = J.imin[dd]; M.dmax[k] = J.imax[dd]; M.doff[k] = J.doff[dd]; }
+            }
+            const int mn_ = J.imin[d], mx_ = J.imax[d];
+            const int want_c = max(0, d - mx_ + 1 - FB_RG_REFILL), want_r = max(0, mn_ + 1 - FB_RG_REFILL);
+            for (int u = cols_lo - 1 - x; u >= want_c; u -= B) {
+                M.c_st[u & (FB_RG_COLS - 1)] = J.stR[u];
+                M.c_lw[u & (FB_RG_COLS - 1)] = u > 0 ? J.lwR[u - 1] : 0.0f;
+            }
+            for (int t = rows_lo - 1 - x; t >= want_r; t -= B) {
+                M.r_st[t & (FB_RG_COLS - 1)] = J.stL[t];
+                M.r_lw[t & (FB_RG_COLS - 1)] = t > 0 ? J.lwL[t - 1] : 0.0f;
+            }
+            cols_lo = min(cols_lo, want_c); rows_lo = min(rows_lo, want_r);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fb_lds_barrier();
+        }
+        const int mn = M.dmin[d & (FB_RG_REFILL - 1)], mx = M.dmax[d & (FB_RG_REFILL - 1)];
+        const int i = mn + ((x - mn) & (B - 1));
+        const bool active = i <= mx;
+        double bx = NI, by = NI, bm = NI;
+        if (active) {
+            const int j = d - i;
+            const bool has_a = i + 1 < J.Lx && i + 1 >= mn1 && i + 1 <= mx1;       // (i+1, j)
+            const bool has_p = j + 1 < J.Ly && i >= mn1 && i <= mx1;               // (i, j+1)
+            const bool has_c = i + 1 < J.Lx && j + 1 < J.Ly && i + 1 >= mn2 && i + 1 <= mx2;   // (i+1, j+1)
+            const double nx = has_a ? M.ring[s1][0][xp1] : NI, ny = has_p ? M.ring[s1][1][x] : NI;
+            double thru = NI;
+            if (i + 1 < J.Lx && j + 1 < J.Ly) {
+                const int str = M.r_st[(i + 1) & (FB_RG_COLS - 1)], stc = M.c_st[(j + 1) & (FB_RG_COLS - 1)];
+                const double sc = fb_score(tab_lds, M.ltab, J.ltab, str, stc, J.S);
+                thru = (has_c ? M.ring[s2][2][xp1] : NI) + sc + (double)M.r_lw[(i + 1) & (FB_RG_COLS - 1)] + (double)M.c_lw[(j + 1) & (FB_RG_COLS - 1)];   // VA:2269-2271
+            }
+            const long long at = M.doff[d & (FB_RG_REFILL - 1)] + (i - mn);
+            if (d >= J.init_dmin) {
+                for (int k = 0; k < J.n_init; ++k) {
+                    const long long w = J.init_at[k] - 3 * at;
+                    if (w == 0) bx = J.init_val[k]; else if (w == 1) by = J.init_val[k]; else if (w == 2) bm = J.init_val[k];
+                }
+                if (i + 1 < J.Lx) { bx = lse(bx, nx + J.l_ext); by = lse(by, nx + J.l_open); bm = lse(bm, nx + J.l_ng + J.l_open); }   // VA:2281-2303
+                if (j + 1 < J.Ly) { by = lse(by, ny + J.l_ext); bx = lse(bx, ny + J.l_open); bm = lse(bm, ny + J.l_ng + J.l_open); }
+                if (i + 1 < J.Lx && j + 1 < J.Ly) { bx = lse(bx, thru + J.l_ng); by = lse(by, thru + J.l_ng); bm = lse(bm, thru + J.l_ng + J.l_ng); }
+            } else {
+                bx = lse3(nx + J.l_ext, ny + J.l_open, thru + J.l_ng);
+                by = lse3(nx + J.l_open, ny + J.l_ext, thru + J.l_ng);
+                bm = lse3(nx + J.l_ng + J.l_open, ny + J.l_ng + J.l_open, thru + J.l_ng + J.l_ng);
+            }
+            const fb_gd o = Bm + 3 * at;
+            o[0] = bx; o[1] = by; o[2] = bm;
+        }
+        M.ring[s0][0][x] = bx; M.ring[s0][1][x] = by; M.ring[s0][2][x] = bm;
+        mn2 = mn1; mx2 = mx1; mn1 = mn; mx1 = mx;
+        { const int t = s2; s2 = s1; s1 = s0; s0 = t; }
+        fb_lds_barrier();
+    }
+    __syncthreads();
     if (threadIdx.x == 0) J.totals[1] = rd(J.B, cell_at(J, 0, 0), 2);
 }
 
@@ -430,7 +641,7 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs) {
                 const bool col_simple = active && M.c_n[jj] == 1 && M.c_e0[jj] == j - 1;
                 if (__builtin_amdgcn_ballot_w64(active && !(row_simple && col_simple)) == 0) {
                     if (active) {
-                        const double sc = tab_lds ? M.ltab[stl + M.c_st[jj] * J.S] : J.ltab[stl + (long long)M.c_st[jj] * J.S];
+                        const double sc = fb_score(tab_lds, M.ltab, J.ltab, stl, M.c_st[jj], J.S);
                         const double w = lwl0 + (double)M.c_lw0[jj];
                         const double mm = J.l_ng + J.l_ng + sc + w, xm = J.l_ng + sc + w;
                         fx = lse3(Ax + J.l_ext, Ay + J.l_open, Am + J.l_ng + J.l_open);                        // VA:2153, 2184, 2215
@@ -471,8 +682,7 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs) {
                             fy = lse(fy, lse3(y + J.l_ext, x + J.l_open, m + J.l_ng + J.l_open));
                         }
                         if (nl > 0 && nr > 0) {
-                            const int ti = stl + M.c_st[jj] * J.S;
-                            const double sc = tab_lds ? M.ltab[ti] : J.ltab[stl + (long long)M.c_st[jj] * J.S];
+                            const double sc = fb_score(tab_lds, M.ltab, J.ltab, stl, M.c_st[jj], J.S);
                             const double mm = J.l_ng + J.l_ng + sc, xm = J.l_ng + sc;                         // VA:1383-1391
                             for (int k1 = 0; k1 < nl; ++k1)
                                 for (int k2 = 0; k2 < nr; ++k2) {
@@ -616,8 +826,7 @@ __global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs) 
                 const bool col_simple = active && M.c_n[jj] == 1 && M.c_e0[jj] == j + 1 && j + 1 < J.Ly;
                 if (!blk_init && __builtin_amdgcn_ballot_w64(active && !(row_simple && col_simple)) == 0) {
                     if (active) {
-                        const int ti = st_t0 + M.c_st[jj + 1] * J.S;
-                        const double sc = tab_lds ? M.ltab[ti] : J.ltab[st_t0 + (long long)M.c_st[jj + 1] * J.S];
+                        const double sc = fb_score(tab_lds, M.ltab, J.ltab, st_t0, M.c_st[jj + 1], J.S);
                         const double thru = Cm + sc + lwl0 + (double)M.c_lw0[jj];             // VA:2269-2271
                         bx = lse3(Ax + J.l_ext, Py + J.l_open, thru + J.l_ng);               // VA:2281-2303
                         by = lse3(Ax + J.l_open, Py + J.l_ext, thru + J.l_ng);
@@ -667,7 +876,7 @@ __global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs) 
                             if (t_ >= J.Lx || u >= J.Ly) continue;
                             const int sl = k1 == 0 ? st_t0 : (k1 == 1 ? st_t1 : J.stL[t_]);
                             const int sr = (u >= j0 && u <= j0 + FB_T) ? M.c_st[u - j0] : J.stR[u];
-                            const double sc = tab_lds ? M.ltab[sl + sr * J.S] : J.ltab[sl + (long long)sr * J.S];
+                            const double sc = fb_score(tab_lds, M.ltab, J.ltab, sl, sr, J.S);
                             const double thru = fetch(t_, u, 2) + sc + (k1 == 0 ? lwl0 : (k1 == 1 ? lwl1 : (double)J.flwL[l0 + k1])) +
                                                 (k2 == 0 ? lwr0 : (k2 == 1 ? lwr1 : (double)J.flwR[r0 + k2]));   // VA:2269-2271
                             bx = lse(bx, thru + J.l_ng); by = lse(by, thru + J.l_ng); bm = lse(bm, thru + J.l_ng + J.l_ng);
@@ -773,6 +982,7 @@ struct pagan_fb {
     double totals[2] = {0, 0};
     float kernel_ms[2] = {0, 0};                        // pg_fb_forward, pg_fb_backward (HIP events)
     int groups = 1;                                     // workgroups a diagonal's cells were spread over
+    bool ring = false;                                  // the LDS-ring sweeps ran
     std::vector<double> hF;                             // downloaded lazily
     long long at(int i, int j) const {
         if (i < 0 || j < 0 || i >= Lx || j >= Ly) return -1;
@@ -794,6 +1004,7 @@ struct FbStaged {
     PgFbJob job;                             // ... and what it holds
     char *d_tot = nullptr, *d_sync = nullptr;
     int groups = 1, groups_b = 1, block = 64;
+    bool ring = false;                       // the sweeps are pg_fb_forward_ring / pg_fb_backward_ring (block = their B)
     double t_host[4] = {0, 0, 0, 0};         // band index + lists, arena, staging, upload (seconds)
     size_t arena_bytes = 0;
 };
@@ -830,9 +1041,11 @@ static int fb_stage(const pagan_graph *left, const pagan_graph *right, const pag
     std::vector<long long> init_at;
     std::vector<double> init_val;
     const double l_ng = std::log((double)model->non_gap);
+    int init_dmin = nd;
     auto put_init = [&](int i, int j, int s, double v) {
         const long long a = fb->at(i, j);
         if (a < 0) return;
+        init_dmin = std::min(init_dmin, i + j);
         for (size_t k = 0; k < init_at.size(); ++k) if (init_at[k] == 3 * a + s) { init_val[k] = v; return; }   // later assignment wins
         init_at.push_back(3 * a + s); init_val.push_back(v);
     };
@@ -886,16 +1099,34 @@ static int fb_stage(const pagan_graph *left, const pagan_graph *right, const pag
     // blocks the band has on a block anti-diagonal (fb_live_rows), a wave each, operands in registers / LDS, one counter barrier per
     // 64 diagonals.  Workgroups: the blocks a diagonal of `mw` cells can lie in while it moves through 127 diagonals.
     // PAGAN_FB_BAND_MIN_ND: the shortest pair (in cell diagonals) that takes this path (tests: 0; "off": none).
+    // ... and a long tunnel between plain sequences (every site one edge, from the site before it: leaves) on the LDS-ring sweeps
+    // (pg_fb_forward_ring): PAGAN_FB_RING=0 switches them off, PAGAN_FB_RING_MIN_ND is their shortest pair (default 4,096 diagonals)
+    bool ring = false;
+    {
+        int min_nd = 4096;
+        if (const char *e = std::getenv("PAGAN_FB_RING_MIN_ND")) min_nd = std::atoi(e);
+        const char *re = std::getenv("PAGAN_FB_RING");
+        auto plain = [](const pagan_graph *g) {
+            for (int sidx = 1; sidx < g->n_sites; ++sidx)
+                if (g->bwd_off[sidx + 1] - g->bwd_off[sidx] != 1 || g->bwd_src[g->bwd_off[sidx]] != sidx - 1) return false;
+            return g->bwd_off[1] == 0;
+        };
+        bool gapless = true;                                          // (no cell diagonal without a cell)
+        for (int d = 0; d < nd && gapless; ++d) gapless = fb->dx.imax[d] >= fb->dx.imin[d];
+        ring = !(re && std::strcmp(re, "0") == 0) && nd >= min_nd && mw <= FB_RG_MAXB && Lx >= 2 && Ly >= 2 && gapless && plain(left) && plain(right);
+        if (ring && !std::getenv("PAGAN_FB_GROUPS")) groups = 1;
+    }
     {
         int min_nd = 4096;
         if (const char *e = std::getenv("PAGAN_FB_BAND_MIN_ND")) min_nd = std::strcmp(e, "off") == 0 ? 0x7fffffff : std::atoi(e);
-        if (groups == 1 && nd >= min_nd && Lx >= 2 && Ly >= 2)
+        if (ring) {}
+        else if (groups == 1 && nd >= min_nd && Lx >= 2 && Ly >= 2)
             groups = std::max(2, std::min({FB_MAX_GROUPS, (mw + FB_T - 1) / FB_T + 2, (Lx + FB_T - 1) / FB_T, (Ly + FB_T - 1) / FB_T}));
         // (and a pair that is "wide" by a box of its tunnel -- one of the 16 leaf pairs has a diagonal of 295 cells -- does not need
         //  the 64 workgroups of a full matrix at every barrier: a diagonal of mw cells lies in mw / 64 + 2 blocks at most)
         else if (groups > 1) groups = std::max(2, std::min(groups, (mw + FB_T - 1) / FB_T + 2));
     }
-    if (const char *e = std::getenv("PAGAN_FB_GROUPS")) groups = std::max(1, std::min(FB_MAX_GROUPS, std::atoi(e)));
+    if (const char *e = std::getenv("PAGAN_FB_GROUPS")) { groups = std::max(1, std::min(FB_MAX_GROUPS, std::atoi(e))); ring = false; }
     const int groups_b = groups > 1 ? std::max(2, std::min(groups, groups_cap_b)) : 1;
     if (groups > 1) groups = std::max(2, std::min(groups, groups_cap));
     fb->groups = groups;
@@ -913,6 +1144,7 @@ static int fb_stage(const pagan_graph *left, const pagan_graph *right, const pag
     J.n_init = (int)init_at.size(); J.init_at = (const long long *)(b + o_iat); J.init_val = (const double *)(b + o_ival);
     J.totals = (double *)(b + o_tot);
     J.groups = groups; J.groups_b = groups_b; J.sync = (int *)(b + o_sync);
+    J.init_dmin = init_dmin;
     std::memcpy(stage.data() + o_job, &J, sizeof(J));
     fb->dF = J.F; fb->dB = J.B;
     const double th2 = now_();
@@ -921,6 +1153,9 @@ static int fb_stage(const pagan_graph *left, const pagan_graph *right, const pag
     // a thread per cell of the widest diagonal, up to the 1024 of a workgroup (a cell is ~20 exp / log1p calls: a thread with
     // eight cells of a 2,000-cell diagonal was the whole sweep's pace)
     st->block = mw >= 768 ? 1024 : mw >= 384 ? 512 : mw >= 192 ? 256 : (mw >= 96 ? 128 : 64);
+    st->ring = ring && groups == 1;
+    if (st->ring) st->block = mw > 256 ? 512 : (mw > 128 ? 256 : (mw > 64 ? 128 : 64));     // a thread per row of the widest diagonal
+    fb->ring = st->ring;
     st->groups = groups; st->groups_b = groups_b;
     st->d_job = (const PgFbJob *)(b + o_job); st->d_tot = b + o_tot; st->d_sync = b + o_sync; st->job = J;
     st->t_host[0] = th1 - th0; st->t_host[1] = th2 - th1; st->t_host[2] = 0.0; st->t_host[3] = th3 - th2;
@@ -992,10 +1227,12 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     FbSlotLease lease{&slots, groups > 1 ? 2 * groups : 0};
     if (groups > 1) slots.take(2 * groups, fb_slot_cap(fb->device));
     if (groups > 1) hipLaunchKernelGGL(pg_fb_forward_tiled, dim3(groups, 1), dim3(64), 0, s1, st.d_job);
+    else if (st.ring) hipLaunchKernelGGL(pg_fb_forward_ring, dim3(1), dim3(block), 0, s1, st.d_job);
     else hipLaunchKernelGGL(pg_fb_forward, dim3(1), dim3(block), 0, s1, st.d_job);
     FB_TRY(hipEventRecord(e1, s1));
     FB_TRY(hipEventRecord(e2, s2));
     if (groups > 1) hipLaunchKernelGGL(pg_fb_backward_tiled, dim3(groups, 1), dim3(64), 0, s2, st.d_job);
+    else if (st.ring) hipLaunchKernelGGL(pg_fb_backward_ring, dim3(1), dim3(block), 0, s2, st.d_job);
     else hipLaunchKernelGGL(pg_fb_backward, dim3(1), dim3(block), 0, s2, st.d_job);
     FB_TRY(hipEventRecord(e3, s2));
     FB_TRY(hipGetLastError());
@@ -1058,26 +1295,34 @@ int pagan_fb_run_batch(int32_t n, const pagan_graph *const *left, const pagan_gr
         for (int q = 0; q < chunk; ++q) if (rcs[done + q] != PAGAN_OK) rc = rcs[done + q];
         if (rc != PAGAN_OK) break;
         std::vector<PgFbJob> tiled;
-        std::vector<int> tiled_k, small_k;
+        std::vector<int> tiled_k, small_k, ring_k;
         int gmax = 0, gmax_b = 0, slots_needed = 0;
         for (int q = 0; q < chunk; ++q) {
             const int k = done + q;
             if (st[k].groups > 1) {
                 tiled.push_back(st[k].job); tiled_k.push_back(k);
                 gmax = std::max(gmax, st[k].groups); gmax_b = std::max(gmax_b, st[k].groups_b); slots_needed += st[k].groups + st[k].groups_b;
-            } else small_k.push_back(k);
+            } else if (st[k].ring) ring_k.push_back(k);
+            else small_k.push_back(k);
         }
+        // the LDS-ring sweeps of the chunk: one launch per direction and workgroup size (a workgroup a pair)
+        std::stable_sort(ring_k.begin(), ring_k.end(), [&](int a, int b_) { return st[a].block < st[b_].block; });
+        std::vector<PgFbJob> ring_jobs;
+        for (int k : ring_k) ring_jobs.push_back(st[k].job);
         if (rc != PAGAN_OK) break;
-        PgFbJob *d_jobs = nullptr;
-        hipStream_t s1 = nullptr, s2 = nullptr;
-        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
-        std::vector<hipStream_t> small_s(2 * small_k.size(), nullptr);
+        PgFbJob *d_jobs = nullptr, *d_ring = nullptr;
+        hipStream_t s1 = nullptr, s2 = nullptr, r1 = nullptr, r2 = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, g0 = nullptr, g1 = nullptr, g2 = nullptr, g3 = nullptr;
+        std::vector<hipStream_t> small_s(2 * small_k.size(), nullptr), ring_s;
+        std::vector<hipEvent_t> ring_e;
         auto release = [&]() {
             if (d_jobs) (void)hipFree(d_jobs);
-            if (s1) (void)hipStreamDestroy(s1);
-            if (s2) (void)hipStreamDestroy(s2);
-            for (hipEvent_t e : {e0, e1, e2, e3}) if (e) (void)hipEventDestroy(e);
+            if (d_ring) (void)hipFree(d_ring);
+            for (hipStream_t x : {s1, s2, r1, r2}) if (x) (void)hipStreamDestroy(x);
+            for (hipEvent_t e : {e0, e1, e2, e3, g0, g1, g2, g3}) if (e) (void)hipEventDestroy(e);
             for (hipStream_t x : small_s) if (x) (void)hipStreamDestroy(x);
+            for (hipStream_t x : ring_s) if (x) (void)hipStreamDestroy(x);
+            for (hipEvent_t e : ring_e) if (e) (void)hipEventDestroy(e);
         };
         auto body = [&]() -> int {
             FB_TRY(hipStreamCreate(&s1)); FB_TRY(hipStreamCreate(&s2));
@@ -1103,6 +1348,38 @@ int pagan_fb_run_batch(int32_t n, const pagan_graph *const *left, const pagan_gr
                     FB_TRY(hipEventRecord(e3, s2));
                 }
             }
+            if (!ring_jobs.empty()) {
+                FB_TRY(hipStreamCreate(&r1)); FB_TRY(hipStreamCreate(&r2));
+                FB_TRY(hipEventCreate(&g0)); FB_TRY(hipEventCreate(&g1)); FB_TRY(hipEventCreate(&g2)); FB_TRY(hipEventCreate(&g3));
+                FB_TRY(hipMalloc((void **)&d_ring, ring_jobs.size() * sizeof(PgFbJob)));
+                FB_TRY(hipMemcpy(d_ring, ring_jobs.data(), ring_jobs.size() * sizeof(PgFbJob), hipMemcpyHostToDevice));
+                FB_TRY(hipEventRecord(g0, r1)); FB_TRY(hipEventRecord(g2, r2));
+                // (the workgroup sizes side by side, not one after the other: the first size on r1 / r2, the others -- at most three --
+                //  on streams of their own that r1 / r2 wait for)
+                for (size_t a = 0; a < ring_k.size();) {
+                    size_t z = a;
+                    while (z < ring_k.size() && st[ring_k[z]].block == st[ring_k[a]].block) ++z;
+                    const int blk = st[ring_k[a]].block;
+                    hipStream_t f = r1, bk = r2;
+                    if (a > 0) {
+                        hipStream_t x1 = nullptr, x2 = nullptr;
+                        FB_TRY(hipStreamCreate(&x1)); ring_s.push_back(x1);
+                        FB_TRY(hipStreamCreate(&x2)); ring_s.push_back(x2);
+                        f = x1; bk = x2;
+                    }
+                    hipLaunchKernelGGL(pg_fb_forward_ring, dim3((unsigned)(z - a)), dim3(blk), 0, f, (const PgFbJob *)(d_ring + a));
+                    hipLaunchKernelGGL(pg_fb_backward_ring, dim3((unsigned)(z - a)), dim3(blk), 0, bk, (const PgFbJob *)(d_ring + a));
+                    if (a > 0) {
+                        hipEvent_t ev1 = nullptr, ev2 = nullptr;
+                        FB_TRY(hipEventCreateWithFlags(&ev1, hipEventDisableTiming)); ring_e.push_back(ev1);
+                        FB_TRY(hipEventCreateWithFlags(&ev2, hipEventDisableTiming)); ring_e.push_back(ev2);
+                        FB_TRY(hipEventRecord(ev1, f)); FB_TRY(hipStreamWaitEvent(r1, ev1, 0));
+                        FB_TRY(hipEventRecord(ev2, bk)); FB_TRY(hipStreamWaitEvent(r2, ev2, 0));
+                    }
+                    a = z;
+                }
+                FB_TRY(hipEventRecord(g1, r1)); FB_TRY(hipEventRecord(g3, r2));
+            }
             for (size_t q = 0; q < small_k.size(); ++q) {
                 const FbStaged &x = st[small_k[q]];
                 FB_TRY(hipStreamCreate(&small_s[2 * q])); FB_TRY(hipStreamCreate(&small_s[2 * q + 1]));
@@ -1111,9 +1388,12 @@ int pagan_fb_run_batch(int32_t n, const pagan_graph *const *left, const pagan_gr
             }
             FB_TRY(hipGetLastError());
             FB_TRY(hipStreamSynchronize(s1)); FB_TRY(hipStreamSynchronize(s2));
+            if (r1) { FB_TRY(hipStreamSynchronize(r1)); FB_TRY(hipStreamSynchronize(r2)); }
             for (hipStream_t x : small_s) FB_TRY(hipStreamSynchronize(x));
-            float fwd_ms = 0, bwd_ms = 0;
+            float fwd_ms = 0, bwd_ms = 0, rf_ms = 0, rb_ms = 0;
             if (!tiled.empty()) { (void)hipEventElapsedTime(&fwd_ms, e0, e1); (void)hipEventElapsedTime(&bwd_ms, e2, e3); }
+            if (!ring_jobs.empty()) { (void)hipEventElapsedTime(&rf_ms, g0, g1); (void)hipEventElapsedTime(&rb_ms, g2, g3); }
+            for (size_t q = 0; q < ring_k.size(); ++q) { const int r_ = fb_finish(&st[ring_k[q]], q == 0 ? rf_ms : 0.0f, q == 0 ? rb_ms : 0.0f); if (r_ != PAGAN_OK) return r_; }
             // (the launch's kernel times go to its first pair; the others report 0: a sum over the batch is the launch's)
             for (size_t q = 0; q < tiled_k.size(); ++q) { const int r_ = fb_finish(&st[tiled_k[q]], q == 0 ? fwd_ms : 0.0f, q == 0 ? bwd_ms : 0.0f); if (r_ != PAGAN_OK) return r_; }
             for (int k : small_k) { const int r_ = fb_finish(&st[k], 0.0f, 0.0f); if (r_ != PAGAN_OK) return r_; }
@@ -1134,7 +1414,7 @@ int pagan_fb_kernel_ms(const pagan_fb *fb, double ms[2]) {
     return PAGAN_OK;
 }
 
-int pagan_fb_groups(const pagan_fb *fb) { return fb ? fb->groups : PAGAN_E_ARG; }
+int pagan_fb_groups(const pagan_fb *fb) { return fb ? (fb->ring ? 0 : fb->groups) : PAGAN_E_ARG; }
 
 int pagan_fb_totals(const pagan_fb *fb, double *log_fwd, double *log_bwd, int64_t *cells) {
     if (!fb) return PAGAN_E_ARG;

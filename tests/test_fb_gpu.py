@@ -213,15 +213,57 @@ def test_tunnels_on_the_block_schedule(pg, oracle, monkeypatch):
         fb.close()
 
 
-def test_long_tunnel_takes_the_block_schedule_by_default(pg, oracle):
-    """2 x 6 kb inside define_tunnel's band (12 k cell diagonals: beyond the default threshold): totals against the oracle."""
+def test_long_tunnel_between_leaves_by_default(pg, oracle, monkeypatch):
+    """2 x 6 kb inside define_tunnel's band (12 k cell diagonals: beyond the default thresholds): plain sequences take the
+    LDS-ring sweeps (groups 0), with PAGAN_FB_RING=0 the block schedule (groups > 1); totals against the oracle, both."""
     _, seqs, _ = synth.evolve_balanced(2, 6000, branch=0.02, sub=0.02, indel_start=0.003, mean_len=4, seed=47)
     gl, gr = (host.HGraph.leaf(s).flatten() for s in seqs)
     band, _ = host.define_tunnel(seqs[0], seqs[1], seqs[0], seqs[1])
     mp = host.model_prob(1, 0.04, base_freq=[0.25] * 4)
-    fb = pgm.FullProbability(gl, gr, mp, band)
-    assert fb.groups > 1
     lf, lb, _, _ = oracle.fb(gl, gr, mp, band=band, matrices=False)
-    assert abs(fb.log_fwd - lf) <= LOG_TOL * abs(lf) and abs(fb.log_bwd - lb) <= LOG_TOL * abs(lb)
-    assert abs(fb.log_fwd - fb.log_bwd) < 1e-7
-    fb.close()
+    for ring, want_groups in (("1", 0), ("0", None)):
+        monkeypatch.setenv("PAGAN_FB_RING", ring)
+        fb = pgm.FullProbability(gl, gr, mp, band)
+        assert fb.groups == want_groups if want_groups is not None else fb.groups > 1
+        assert abs(fb.log_fwd - lf) <= LOG_TOL * abs(lf) and abs(fb.log_bwd - lb) <= LOG_TOL * abs(lb)
+        assert abs(fb.log_fwd - fb.log_bwd) < 1e-7
+        fb.close()
+
+
+def test_ring_sweeps_cell_by_cell(pg, oracle, monkeypatch):
+    """The LDS-ring sweeps (PAGAN_FB_RING_MIN_ND=0: pairs of any length) on leaf pairs behind random tunnels -- 5 to 12, 20 to 70
+    and 100 to 180 columns either side: workgroups of 64 to 512 threads, rows re-used by their threads many times over --, DNA and
+    protein (a score table that does not fit LDS), no tunnel at all on a short pair; every cell of both matrices and the
+    posteriors against the oracle, one call per pair and all pairs in one batch."""
+    rng = np.random.default_rng(78)
+    monkeypatch.setenv("PAGAN_FB_RING_MIN_ND", "0")
+    cases = []
+    _, seqs, _ = synth.evolve_balanced(2, 900, branch=0.04, sub=0.05, indel_start=0.01, mean_len=4, seed=48)
+    gl, gr = (host.HGraph.leaf(s).flatten() for s in seqs)
+    mp = host.model_prob(1, 0.08, base_freq=[0.3, 0.2, 0.2, 0.3])
+    for lo_half, hi_half in ((5, 12), (20, 70), (100, 180)):
+        cases.append((gl, gr, mp, _random_tunnel(rng, gl.n_sites - 1, gr.n_sites - 1, lo_half, hi_half)))
+    _, short, _ = synth.evolve_balanced(2, 150, branch=0.04, sub=0.05, indel_start=0.01, mean_len=3, seed=49)
+    sl, sr = (host.HGraph.leaf(s).flatten() for s in short)
+    cases.append((sl, sr, mp, None))
+    aa = "ARNDCQEGHILKMFPSTWYV"
+    _, ps, _ = synth.evolve_balanced(2, 400, branch=0.05, sub=0.08, indel_start=0.01, mean_len=3, seed=50, alphabet=aa)
+    leaf_alpha, _ = host.alphabets(2)
+    pl, pr = (host.HGraph.leaf(s, leaf_alpha).flatten() for s in ps)
+    cases.append((pl, pr, host.model_prob(2, 0.2), _random_tunnel(rng, pl.n_sites - 1, pr.n_sites - 1, 10, 40)))
+    singles = []
+    for left, right, m, band in cases:
+        fb = pgm.FullProbability(left, right, m, band)
+        assert fb.groups == 0
+        lf, lb, post, logf = oracle.fb(left, right, m, band=band)
+        assert abs(fb.log_fwd - lf) <= LOG_TOL * max(1, abs(lf)) and abs(fb.log_bwd - lb) <= LOG_TOL * max(1, abs(lb))
+        assert close_logs(fb.log_forward(), logf)
+        assert np.allclose(fb.posterior(), post, rtol=1e-7, atol=1e-12)
+        singles.append((fb.log_fwd, fb.log_bwd))
+        fb.close()
+    fbs = pgm.full_probability_batch(cases)
+    for fb, (f, b), (left, right, m, band) in zip(fbs, singles, cases):
+        assert fb.groups == 0 and fb.log_fwd == f and fb.log_bwd == b
+        _lf, _lb, post, _logf = oracle.fb(left, right, m, band=band)
+        assert np.allclose(fb.posterior(), post, rtol=1e-7, atol=1e-12)
+        fb.close()

@@ -11,7 +11,10 @@ gl, gr = (host.HGraph.leaf(s).flatten() for s in seqs)
 band, _ = host.define_tunnel(seqs[0], seqs[1], seqs[0], seqs[1])
 mp = host.model_prob(1, 0.02, base_freq=[0.25] * 4)
 for groups in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("2", "3", "4")):
-    os.environ["PAGAN_FB_GROUPS"] = groups
+    if groups == "ring":                       # (the default for plain sequences: the LDS-ring sweeps)
+        os.environ.pop("PAGAN_FB_GROUPS", None)
+    else:
+        os.environ["PAGAN_FB_GROUPS"] = groups
     best = None
     for rep in range(2):
         t0 = time.perf_counter()
