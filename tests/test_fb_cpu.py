@@ -92,3 +92,44 @@ def test_sampled_paths_follow_the_posterior(oracle, pg):
     big = post > 0.05
     big[0, 0, :] = False                                        # the walk stops on reaching the start corner
     assert np.abs(freq[big] - post[big]).max() < 0.04          # Monte-Carlo error at n = 4000
+
+
+def test_band_storage_long_tunnel_and_ragged_band(oracle, pg):
+    """The restatement stores the band's cells only (a tunnel of 2 x 100 kb is 9e6 of 1e10 cells: bench.py's forward/backward
+    baseline on cfg4's leaf pairs) and walks a column's band rows in the backward pass.  (i) 2 x 20 kb inside a tunnel of 31
+    columns -- 4e8 cells as a full matrix, 6e5 in the band --: forward total = backward total (the reference's own check,
+    VA:351-355).  (ii) A ragged band with a box, a short pair: the matrices inside the band equal those of the same pair with
+    the cells outside the band ... computed as a full matrix restricted by a band that holds everything (the band argument is
+    then only a different storage), and outside the band the outputs are -inf / 0."""
+    (gl, gr), _ = leaf_pair(oracle, 20000, 11)
+    mp = oracle.model_prob(1, 0.1, base_freq=[0.25] * 4)
+    Lx, Ly = gl.n_sites - 1, gr.n_sites - 1
+    centre = np.arange(Lx) * (Ly - 1) // (Lx - 1)
+    up = np.maximum.accumulate(np.maximum(centre - 15, 0)).astype(np.int32)
+    lo = np.maximum.accumulate(np.minimum(centre + 15, Ly - 1)).astype(np.int32)
+    up[0] = 0
+    lo[-1] = Ly - 1
+    lf, lb, _, _ = oracle.fb(gl, gr, mp, band=abi.Band(up, lo), matrices=False)
+    assert np.isfinite(lf) and abs(lf - lb) <= 1e-9 * abs(lf)
+    (sl, sr), _ = leaf_pair(oracle, 120, 12)
+    Lx, Ly = sl.n_sites - 1, sr.n_sites - 1
+    everything = abi.Band(np.zeros(Lx, np.int32), np.full(Lx, Ly - 1, np.int32))
+    full = oracle.fb(sl, sr, mp)
+    same = oracle.fb(sl, sr, mp, band=everything)
+    assert full[0] == same[0] and full[1] == same[1] and np.array_equal(full[2], same[2]) and np.array_equal(full[3], same[3])
+    centre = np.arange(Lx) * (Ly - 1) // (Lx - 1)
+    up = np.maximum(centre - 9, 0)
+    lo = np.minimum(centre + 9, Ly - 1)
+    up[40:70] = up[40]
+    lo[40:70] = min(lo[69] + 25, Ly - 1)
+    up = np.maximum.accumulate(up).astype(np.int32)
+    lo = np.maximum.accumulate(lo).astype(np.int32)
+    up[0] = 0
+    lo[-1] = Ly - 1
+    lf, lb, post, logf = oracle.fb(sl, sr, mp, band=abi.Band(up, lo))
+    assert abs(lf - lb) <= 1e-9 * abs(lf) and lf < full[0]
+    outside = np.ones((Lx, Ly), bool)
+    for i in range(Lx):
+        outside[i, up[i]:lo[i] + 1] = False
+    assert np.all(post[outside] == 0) and np.all(np.isneginf(logf[outside]))
+    assert np.isfinite(logf[~outside][:, 2]).sum() > 0
