@@ -131,8 +131,12 @@ __device__ __forceinline__ double lse3(double a, double b, double c) {
 // flat load, and a flat load is a vector memory operation: s_waitcnt vmcnt(0) behind it waited for the wave's stores of the step
 // before, on every step of every sweep.
 typedef const __attribute__((address_space(1))) double *fb_gcd;
+// ALL_LDS: the launch holds only pairs whose table is in LDS, and the load from memory is not even compiled: with both paths in one
+// kernel the LDS read still waited -- s_waitcnt vmcnt(0): the wave's stores of the step before -- because its destination register
+// is the memory load's too, and the compiler cannot know that load was never issued.
+template <bool ALL_LDS>
 __device__ __forceinline__ double fb_score(bool tab_lds, const double *lds_tab, const double *mem_tab, int a, int b, int S) {
-    if (tab_lds) return lds_tab[a + b * S];
+    if (ALL_LDS || tab_lds) return lds_tab[a + b * S];
     return ((fb_gcd)(unsigned long long)mem_tab)[a + (long long)b * S];
 }
 
@@ -260,6 +264,20 @@ __global__ __launch_bounds__(1024) void pg_fb_backward(const PgFbJob *jobs) {
 #define FB_RG_COLS 1024          // columns / rows in the LDS windows (>= B + 2 * FB_RG_REFILL)
 #define FB_RG_REFILL 256
 #define FB_RG_MAXB 512
+#define FB_RG_THREADS 1024       // B = 64 ... 256: three threads a row, one per state; B = 512: two (X and Y; M)
+// Who a thread is.  A cell's three states are three independent log-sum-exps of the same size -- the step's latency is one wave's
+// way through them --, so up to B = 256 a row has THREE threads, one per state (NSPLIT = 3, blockDim = 3 B), and with B = 512 two
+// (NSPLIT = 2: X and Y in one, M in the other; 1,024 threads is what a workgroup holds): wave w works on part w % NSPLIT of the
+// rows 64 (w / NSPLIT) ..., which puts the waves of a block of rows on different SIMDs (waves go to the SIMDs round-robin).
+// NSPLIT is a template argument: with the parts as run-time flags the one-thread-per-row sweeps lost a third of their speed.
+// x: the thread's row modulo B; do_x / do_y / do_m: its states; tid / nt: for the staging loops, which all threads share.
+#define FB_RING_THREADS                                                                                       \
+    const int tid = (int)threadIdx.x, nt = (int)blockDim.x;                                                   \
+    const int B = nt / NSPLIT;                                                                                \
+    const int part = (tid >> 6) % NSPLIT;                                                                     \
+    const int x = ((tid >> 6) / NSPLIT) * 64 + (tid & 63);                                                    \
+    const bool do_x = NSPLIT == 1 || part == 0, do_y = NSPLIT == 1 || (NSPLIT == 2 ? part == 0 : part == 1), \
+               do_m = NSPLIT == 1 || part == NSPLIT - 1;
 typedef __attribute__((address_space(1))) double *fb_gd;
 
 __device__ __forceinline__ void fb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -275,13 +293,15 @@ struct FbRingSmem {
     double ltab[256];
 };
 
-__global__ __launch_bounds__(FB_RG_MAXB) void pg_fb_forward_ring(const PgFbJob *jobs) {
+template <bool ALL_LDS, int NSPLIT>
+__global__ __launch_bounds__(FB_RG_THREADS) void pg_fb_forward_ring(const PgFbJob *jobs) {
     __shared__ FbRingSmem M;
     const PgFbJob J = jobs[blockIdx.x];
-    const int B = (int)blockDim.x, x = (int)threadIdx.x, xm1 = (x - 1) & (B - 1);
+    FB_RING_THREADS
+    const int xm1 = (x - 1) & (B - 1);
     const double NI = ninf();
     const bool tab_lds = J.S * J.S <= 256;
-    if (tab_lds) for (int k = x; k < J.S * J.S; k += B) M.ltab[k] = J.ltab[k];
+    if (tab_lds) for (int k = tid; k < J.S * J.S; k += nt) M.ltab[k] = J.ltab[k];
     for (int q = 0; q < 9; ++q) (&M.ring[0][0][0])[q * FB_RG_MAXB + x] = NI;
     int mn1 = 0, mx1 = -1, mn2 = 0, mx2 = -1;            // the intervals of the diagonals d-1, d-2
     int s0 = 0, s1 = 2, s2 = 1;                          // ring slots of d, d-1, d-2
@@ -291,18 +311,18 @@ __global__ __launch_bounds__(FB_RG_MAXB) void pg_fb_forward_ring(const PgFbJob *
     for (int d = 0; d < J.nd; ++d) {
         if ((d & (FB_RG_REFILL - 1)) == 0) {
             // the next FB_RG_REFILL diagonals; their columns and rows: the largest of either grows by at most one a diagonal
-            for (int k = x; k < FB_RG_REFILL; k += B) {
+            for (int k = tid; k < FB_RG_REFILL; k += nt) {
                 const int dd = d + k;
                 const bool in = dd < J.nd;
                 M.dmin[k] = in ? J.imin[dd] : 0; M.dmax[k] = in ? J.imax[dd] : -1; M.doff[k] = in ? J.doff[dd] : 0;
             }
             const int mn_ = J.imin[d], mx_ = J.imax[d];
             const int want_c = min(J.Ly - 1, d - mn_ + FB_RG_REFILL), want_r = min(J.Lx - 1, mx_ + FB_RG_REFILL);
-            for (int j = cols_hi + 1 + x; j <= want_c; j += B) {
+            for (int j = cols_hi + 1 + tid; j <= want_c; j += nt) {
                 M.c_st[j & (FB_RG_COLS - 1)] = J.stR[j];
                 M.c_lw[j & (FB_RG_COLS - 1)] = j > 0 ? J.lwR[j - 1] : 0.0f;       // (plain graph: site j's one edge is list entry j - 1)
             }
-            for (int i = rows_hi + 1 + x; i <= want_r; i += B) {
+            for (int i = rows_hi + 1 + tid; i <= want_r; i += nt) {
                 M.r_st[i & (FB_RG_COLS - 1)] = J.stL[i];
                 M.r_lw[i & (FB_RG_COLS - 1)] = i > 0 ? J.lwL[i - 1] : 0.0f;
             }
@@ -319,27 +339,31 @@ __global__ __launch_bounds__(FB_RG_MAXB) void pg_fb_forward_ring(const PgFbJob *
             if (i == 0 && j == 0) {
                 fm = 0.0;                                                          // fwd_score = 1, VA:730
             } else {
-                if (i > 0 && i - 1 >= mn1 && i - 1 <= mx1) {                       // (i-1, j): VA:2153, 2184, 2215
+                if (do_x && i > 0 && i - 1 >= mn1 && i - 1 <= mx1) {               // (i-1, j): VA:2153, 2184, 2215
                     const double ax = M.ring[s1][0][xm1], ay = M.ring[s1][1][xm1], am = M.ring[s1][2][xm1];
                     fx = lse3(ax + J.l_ext, ay + J.l_open, am + J.l_ng + J.l_open);
                 }
-                if (j > 0 && i >= mn1 && i <= mx1) {                               // (i, j-1)
+                if (do_y && j > 0 && i >= mn1 && i <= mx1) {                       // (i, j-1)
                     const double px = M.ring[s1][0][x], py = M.ring[s1][1][x], pm = M.ring[s1][2][x];
                     fy = lse3(py + J.l_ext, px + J.l_open, pm + J.l_ng + J.l_open);
                 }
-                if (i > 0 && j > 0 && i - 1 >= mn2 && i - 1 <= mx2) {              // (i-1, j-1): VA:2051, 2080, 2108
+                if (do_m && i > 0 && j > 0 && i - 1 >= mn2 && i - 1 <= mx2) {      // (i-1, j-1): VA:2051, 2080, 2108
                     const double cx = M.ring[s2][0][xm1], cy = M.ring[s2][1][xm1], cm = M.ring[s2][2][xm1];
                     const int str = M.r_st[i & (FB_RG_COLS - 1)], stc = M.c_st[j & (FB_RG_COLS - 1)];
-                    const double sc = fb_score(tab_lds, M.ltab, J.ltab, str, stc, J.S);
+                    const double sc = fb_score<ALL_LDS>(tab_lds, M.ltab, J.ltab, str, stc, J.S);
                     const double w = (double)M.r_lw[i & (FB_RG_COLS - 1)] + (double)M.c_lw[j & (FB_RG_COLS - 1)];
                     const double mm = J.l_ng + J.l_ng + sc + w, xm = J.l_ng + sc + w;   // VA:1383-1391
                     fm = lse3(cm + mm, cx + xm, cy + xm);
                 }
             }
             const fb_gd o = F + 3 * (M.doff[d & (FB_RG_REFILL - 1)] + (i - mn));
-            o[0] = fx; o[1] = fy; o[2] = fm;
+            if (do_x) o[0] = fx;
+            if (do_y) o[1] = fy;
+            if (do_m) o[2] = fm;
         }
-        M.ring[s0][0][x] = fx; M.ring[s0][1][x] = fy; M.ring[s0][2][x] = fm;
+        if (do_x) M.ring[s0][0][x] = fx;
+        if (do_y) M.ring[s0][1][x] = fy;
+        if (do_m) M.ring[s0][2][x] = fm;
         mn2 = mn1; mx2 = mx1; mn1 = mn; mx1 = mx;
         { const int t = s2; s2 = s1; s1 = s0; s0 = t; }
         fb_lds_barrier();
@@ -368,13 +392,15 @@ __global__ __launch_bounds__(FB_RG_MAXB) void pg_fb_forward_ring(const PgFbJob *
 // the windows hold row t = i+1's and column u = j+1's records (state, weight of the edge from the site before).
 // What initialise_array_corner_bwd assigns (a handful of cells on the last diagonals, VA:740-854) is laid over the -inf a cell
 // starts from on the diagonals >= init_dmin, and there the sums are taken one by one as pg_fb_backward takes them.
-__global__ __launch_bounds__(FB_RG_MAXB) void pg_fb_backward_ring(const PgFbJob *jobs) {
+template <bool ALL_LDS, int NSPLIT>
+__global__ __launch_bounds__(FB_RG_THREADS) void pg_fb_backward_ring(const PgFbJob *jobs) {
     __shared__ FbRingSmem M;
     const PgFbJob J = jobs[blockIdx.x];
-    const int B = (int)blockDim.x, x = (int)threadIdx.x, xp1 = (x + 1) & (B - 1);
+    FB_RING_THREADS
+    const int xp1 = (x + 1) & (B - 1);
     const double NI = ninf();
     const bool tab_lds = J.S * J.S <= 256;
-    if (tab_lds) for (int k = x; k < J.S * J.S; k += B) M.ltab[k] = J.ltab[k];
+    if (tab_lds) for (int k = tid; k < J.S * J.S; k += nt) M.ltab[k] = J.ltab[k];
     for (int q = 0; q < 9; ++q) (&M.ring[0][0][0])[q * FB_RG_MAXB + x] = NI;
     int mn1 = 0, mx1 = -1, mn2 = 0, mx2 = -1;            // the intervals of the diagonals d+1, d+2
     int s0 = 0, s1 = 2, s2 = 1;
@@ -385,17 +411,17 @@ __global__ __launch_bounds__(FB_RG_MAXB) void pg_fb_backward_ring(const PgFbJob 
         if (d == J.nd - 1 || (d & (FB_RG_REFILL - 1)) == FB_RG_REFILL - 1) {
             // the diagonals down to the next multiple of FB_RG_REFILL; columns u = j + 1 and rows t = i + 1: the smallest of either
             // falls by at most one a diagonal
-            for (int k = x; k < FB_RG_REFILL; k += B) {
+            for (int k = tid; k < FB_RG_REFILL; k += nt) {
                 const int dd = (d & ~(FB_RG_REFILL - 1)) + k;
                 if (dd <= d) { M.dmin[k] = J.imin[dd]; M.dmax[k] = J.imax[dd]; M.doff[k] = J.doff[dd]; }
             }
             const int mn_ = J.imin[d], mx_ = J.imax[d];
             const int want_c = max(0, d - mx_ + 1 - FB_RG_REFILL), want_r = max(0, mn_ + 1 - FB_RG_REFILL);
-            for (int u = cols_lo - 1 - x; u >= want_c; u -= B) {
+            for (int u = cols_lo - 1 - tid; u >= want_c; u -= nt) {
                 M.c_st[u & (FB_RG_COLS - 1)] = J.stR[u];
                 M.c_lw[u & (FB_RG_COLS - 1)] = u > 0 ? J.lwR[u - 1] : 0.0f;
             }
-            for (int t = rows_lo - 1 - x; t >= want_r; t -= B) {
+            for (int t = rows_lo - 1 - tid; t >= want_r; t -= nt) {
                 M.r_st[t & (FB_RG_COLS - 1)] = J.stL[t];
                 M.r_lw[t & (FB_RG_COLS - 1)] = t > 0 ? J.lwL[t - 1] : 0.0f;
             }
@@ -416,7 +442,7 @@ __global__ __launch_bounds__(FB_RG_MAXB) void pg_fb_backward_ring(const PgFbJob 
             double thru = NI;
             if (i + 1 < J.Lx && j + 1 < J.Ly) {
                 const int str = M.r_st[(i + 1) & (FB_RG_COLS - 1)], stc = M.c_st[(j + 1) & (FB_RG_COLS - 1)];
-                const double sc = fb_score(tab_lds, M.ltab, J.ltab, str, stc, J.S);
+                const double sc = fb_score<ALL_LDS>(tab_lds, M.ltab, J.ltab, str, stc, J.S);
                 thru = (has_c ? M.ring[s2][2][xp1] : NI) + sc + (double)M.r_lw[(i + 1) & (FB_RG_COLS - 1)] + (double)M.c_lw[(j + 1) & (FB_RG_COLS - 1)];   // VA:2269-2271
             }
             const long long at = M.doff[d & (FB_RG_REFILL - 1)] + (i - mn);
@@ -425,18 +451,23 @@ __global__ __launch_bounds__(FB_RG_MAXB) void pg_fb_backward_ring(const PgFbJob 
                     const long long w = J.init_at[k] - 3 * at;
                     if (w == 0) bx = J.init_val[k]; else if (w == 1) by = J.init_val[k]; else if (w == 2) bm = J.init_val[k];
                 }
-                if (i + 1 < J.Lx) { bx = lse(bx, nx + J.l_ext); by = lse(by, nx + J.l_open); bm = lse(bm, nx + J.l_ng + J.l_open); }   // VA:2281-2303
-                if (j + 1 < J.Ly) { by = lse(by, ny + J.l_ext); bx = lse(bx, ny + J.l_open); bm = lse(bm, ny + J.l_ng + J.l_open); }
-                if (i + 1 < J.Lx && j + 1 < J.Ly) { bx = lse(bx, thru + J.l_ng); by = lse(by, thru + J.l_ng); bm = lse(bm, thru + J.l_ng + J.l_ng); }
+                // (one by one, as pg_fb_backward takes them; a state's sums do not look at the other states')
+                if (i + 1 < J.Lx) { if (do_x) bx = lse(bx, nx + J.l_ext); if (do_y) by = lse(by, nx + J.l_open); if (do_m) bm = lse(bm, nx + J.l_ng + J.l_open); }   // VA:2281-2303
+                if (j + 1 < J.Ly) { if (do_y) by = lse(by, ny + J.l_ext); if (do_x) bx = lse(bx, ny + J.l_open); if (do_m) bm = lse(bm, ny + J.l_ng + J.l_open); }
+                if (i + 1 < J.Lx && j + 1 < J.Ly) { if (do_x) bx = lse(bx, thru + J.l_ng); if (do_y) by = lse(by, thru + J.l_ng); if (do_m) bm = lse(bm, thru + J.l_ng + J.l_ng); }
             } else {
-                bx = lse3(nx + J.l_ext, ny + J.l_open, thru + J.l_ng);
-                by = lse3(nx + J.l_open, ny + J.l_ext, thru + J.l_ng);
-                bm = lse3(nx + J.l_ng + J.l_open, ny + J.l_ng + J.l_open, thru + J.l_ng + J.l_ng);
+                if (do_x) bx = lse3(nx + J.l_ext, ny + J.l_open, thru + J.l_ng);
+                if (do_y) by = lse3(nx + J.l_open, ny + J.l_ext, thru + J.l_ng);
+                if (do_m) bm = lse3(nx + J.l_ng + J.l_open, ny + J.l_ng + J.l_open, thru + J.l_ng + J.l_ng);
             }
             const fb_gd o = Bm + 3 * at;
-            o[0] = bx; o[1] = by; o[2] = bm;
+            if (do_x) o[0] = bx;
+            if (do_y) o[1] = by;
+            if (do_m) o[2] = bm;
         }
-        M.ring[s0][0][x] = bx; M.ring[s0][1][x] = by; M.ring[s0][2][x] = bm;
+        if (do_x) M.ring[s0][0][x] = bx;
+        if (do_y) M.ring[s0][1][x] = by;
+        if (do_m) M.ring[s0][2][x] = bm;
         mn2 = mn1; mx2 = mx1; mn1 = mn; mx1 = mx;
         { const int t = s2; s2 = s1; s1 = s0; s0 = t; }
         fb_lds_barrier();
@@ -444,6 +475,7 @@ __global__ __launch_bounds__(FB_RG_MAXB) void pg_fb_backward_ring(const PgFbJob 
     __syncthreads();
     if (threadIdx.x == 0) J.totals[1] = rd(J.B, cell_at(J, 0, 0), 2);
 }
+#undef FB_RING_THREADS
 
 // ---- wide alignments: 64 x 64 blocks on a block-anti-diagonal schedule ----
 // Block (a, b) needs blocks (a', b') <= (a, b) only (bwd edges point to earlier sites), so the blocks of one block
@@ -564,6 +596,7 @@ __device__ __forceinline__ void fb_stage_diagonals(const PgFbJob &J, FbSmem &M, 
     }
 }
 
+template <bool ALL_LDS>
 __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs) {
     __shared__ FbSmem M;
     const PgFbJob J = jobs[blockIdx.y];
@@ -641,7 +674,7 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs) {
                 const bool col_simple = active && M.c_n[jj] == 1 && M.c_e0[jj] == j - 1;
                 if (__builtin_amdgcn_ballot_w64(active && !(row_simple && col_simple)) == 0) {
                     if (active) {
-                        const double sc = fb_score(tab_lds, M.ltab, J.ltab, stl, M.c_st[jj], J.S);
+                        const double sc = fb_score<ALL_LDS>(tab_lds, M.ltab, J.ltab, stl, M.c_st[jj], J.S);
                         const double w = lwl0 + (double)M.c_lw0[jj];
                         const double mm = J.l_ng + J.l_ng + sc + w, xm = J.l_ng + sc + w;
                         fx = lse3(Ax + J.l_ext, Ay + J.l_open, Am + J.l_ng + J.l_open);                        // VA:2153, 2184, 2215
@@ -682,7 +715,7 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs) {
                             fy = lse(fy, lse3(y + J.l_ext, x + J.l_open, m + J.l_ng + J.l_open));
                         }
                         if (nl > 0 && nr > 0) {
-                            const double sc = fb_score(tab_lds, M.ltab, J.ltab, stl, M.c_st[jj], J.S);
+                            const double sc = fb_score<ALL_LDS>(tab_lds, M.ltab, J.ltab, stl, M.c_st[jj], J.S);
                             const double mm = J.l_ng + J.l_ng + sc, xm = J.l_ng + sc;                         // VA:1383-1391
                             for (int k1 = 0; k1 < nl; ++k1)
                                 for (int k2 = 0; k2 < nr; ++k2) {
@@ -736,6 +769,7 @@ __global__ __launch_bounds__(64) void pg_fb_forward_tiled(const PgFbJob *jobs) {
     }
 }
 
+template <bool ALL_LDS>
 __global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs) {
     __shared__ FbSmem M;
     const PgFbJob J = jobs[blockIdx.y];
@@ -826,7 +860,7 @@ __global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs) 
                 const bool col_simple = active && M.c_n[jj] == 1 && M.c_e0[jj] == j + 1 && j + 1 < J.Ly;
                 if (!blk_init && __builtin_amdgcn_ballot_w64(active && !(row_simple && col_simple)) == 0) {
                     if (active) {
-                        const double sc = fb_score(tab_lds, M.ltab, J.ltab, st_t0, M.c_st[jj + 1], J.S);
+                        const double sc = fb_score<ALL_LDS>(tab_lds, M.ltab, J.ltab, st_t0, M.c_st[jj + 1], J.S);
                         const double thru = Cm + sc + lwl0 + (double)M.c_lw0[jj];             // VA:2269-2271
                         bx = lse3(Ax + J.l_ext, Py + J.l_open, thru + J.l_ng);               // VA:2281-2303
                         by = lse3(Ax + J.l_open, Py + J.l_ext, thru + J.l_ng);
@@ -876,7 +910,7 @@ __global__ __launch_bounds__(64) void pg_fb_backward_tiled(const PgFbJob *jobs) 
                             if (t_ >= J.Lx || u >= J.Ly) continue;
                             const int sl = k1 == 0 ? st_t0 : (k1 == 1 ? st_t1 : J.stL[t_]);
                             const int sr = (u >= j0 && u <= j0 + FB_T) ? M.c_st[u - j0] : J.stR[u];
-                            const double sc = fb_score(tab_lds, M.ltab, J.ltab, sl, sr, J.S);
+                            const double sc = fb_score<ALL_LDS>(tab_lds, M.ltab, J.ltab, sl, sr, J.S);
                             const double thru = fetch(t_, u, 2) + sc + (k1 == 0 ? lwl0 : (k1 == 1 ? lwl1 : (double)J.flwL[l0 + k1])) +
                                                 (k2 == 0 ? lwr0 : (k2 == 1 ? lwr1 : (double)J.flwR[r0 + k2]));   // VA:2269-2271
                             bx = lse(bx, thru + J.l_ng); by = lse(by, thru + J.l_ng); bm = lse(bm, thru + J.l_ng + J.l_ng);
@@ -1200,6 +1234,31 @@ static int fb_slot_cap(int device) {
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) return per_cu_x16 * n_cu / 16;
     return 512;
 }
+// threads a row of a ring sweep's workgroup of B rows: three up to B = 256, two with 512 (PAGAN_FB_RING_SPLIT=0: one), see FB_RING_THREADS
+static int fb_ring_split(int B) {
+    const char *e = std::getenv("PAGAN_FB_RING_SPLIT");
+    if (e && std::strcmp(e, "0") == 0) return 1;
+    return B <= 256 ? 3 : 2;
+}
+template <bool FWD, bool ALL_LDS>
+static void fb_launch_ring_(int nsplit, unsigned grid, int B, hipStream_t st, const PgFbJob *jobs) {
+    const dim3 g(grid), t((unsigned)(nsplit * B));
+    if (FWD) {
+        if (nsplit == 3) hipLaunchKernelGGL((pg_fb_forward_ring<ALL_LDS, 3>), g, t, 0, st, jobs);
+        else if (nsplit == 2) hipLaunchKernelGGL((pg_fb_forward_ring<ALL_LDS, 2>), g, t, 0, st, jobs);
+        else hipLaunchKernelGGL((pg_fb_forward_ring<ALL_LDS, 1>), g, t, 0, st, jobs);
+    } else {
+        if (nsplit == 3) hipLaunchKernelGGL((pg_fb_backward_ring<ALL_LDS, 3>), g, t, 0, st, jobs);
+        else if (nsplit == 2) hipLaunchKernelGGL((pg_fb_backward_ring<ALL_LDS, 2>), g, t, 0, st, jobs);
+        else hipLaunchKernelGGL((pg_fb_backward_ring<ALL_LDS, 1>), g, t, 0, st, jobs);
+    }
+}
+// one launch of ring sweeps: `grid` pairs of B rows each, forward or backward, score tables all in LDS or not
+static void fb_launch_ring(bool fwd, bool all_lds, unsigned grid, int B, hipStream_t st, const PgFbJob *jobs) {
+    const int ns = fb_ring_split(B);
+    if (fwd) { if (all_lds) fb_launch_ring_<true, true>(ns, grid, B, st, jobs); else fb_launch_ring_<true, false>(ns, grid, B, st, jobs); }
+    else { if (all_lds) fb_launch_ring_<false, true>(ns, grid, B, st, jobs); else fb_launch_ring_<false, false>(ns, grid, B, st, jobs); }
+}
 struct FbSlotLease { FbSlots *s; int n; ~FbSlotLease() { if (n > 0) s->give(n); } };
 
 } // namespace
@@ -1217,6 +1276,7 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     std::unique_ptr<pagan_fb, void (*)(pagan_fb *)> guard(fb, [](pagan_fb *p) { pagan_fb_destroy(p); });
     const double th3 = now_();
     const int groups = st.groups, block = st.block;
+    const bool all_lds = st.job.S * st.job.S <= 256;         // (the kernels without the score table's load from memory)
     // the two sweeps are independent of each other: side by side on two streams
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     hipStream_t s1 = nullptr, s2 = nullptr;
@@ -1226,13 +1286,13 @@ int pagan_fb_run(const pagan_graph *left, const pagan_graph *right, const pagan_
     FbSlots &slots = fb_slots_of[fb->device & 63];
     FbSlotLease lease{&slots, groups > 1 ? 2 * groups : 0};
     if (groups > 1) slots.take(2 * groups, fb_slot_cap(fb->device));
-    if (groups > 1) hipLaunchKernelGGL(pg_fb_forward_tiled, dim3(groups, 1), dim3(64), 0, s1, st.d_job);
-    else if (st.ring) hipLaunchKernelGGL(pg_fb_forward_ring, dim3(1), dim3(block), 0, s1, st.d_job);
+    if (groups > 1) { if (all_lds) hipLaunchKernelGGL((pg_fb_forward_tiled<true>), dim3(groups, 1), dim3(64), 0, s1, st.d_job); else hipLaunchKernelGGL((pg_fb_forward_tiled<false>), dim3(groups, 1), dim3(64), 0, s1, st.d_job); }
+    else if (st.ring) fb_launch_ring(true, all_lds, 1, block, s1, st.d_job);
     else hipLaunchKernelGGL(pg_fb_forward, dim3(1), dim3(block), 0, s1, st.d_job);
     FB_TRY(hipEventRecord(e1, s1));
     FB_TRY(hipEventRecord(e2, s2));
-    if (groups > 1) hipLaunchKernelGGL(pg_fb_backward_tiled, dim3(groups, 1), dim3(64), 0, s2, st.d_job);
-    else if (st.ring) hipLaunchKernelGGL(pg_fb_backward_ring, dim3(1), dim3(block), 0, s2, st.d_job);
+    if (groups > 1) { if (all_lds) hipLaunchKernelGGL((pg_fb_backward_tiled<true>), dim3(groups, 1), dim3(64), 0, s2, st.d_job); else hipLaunchKernelGGL((pg_fb_backward_tiled<false>), dim3(groups, 1), dim3(64), 0, s2, st.d_job); }
+    else if (st.ring) fb_launch_ring(false, all_lds, 1, block, s2, st.d_job);
     else hipLaunchKernelGGL(pg_fb_backward, dim3(1), dim3(block), 0, s2, st.d_job);
     FB_TRY(hipEventRecord(e3, s2));
     FB_TRY(hipGetLastError());
@@ -1297,16 +1357,19 @@ int pagan_fb_run_batch(int32_t n, const pagan_graph *const *left, const pagan_gr
         std::vector<PgFbJob> tiled;
         std::vector<int> tiled_k, small_k, ring_k;
         int gmax = 0, gmax_b = 0, slots_needed = 0;
+        bool tiled_all_lds = true;                                // every tiled pair's score table fits LDS
         for (int q = 0; q < chunk; ++q) {
             const int k = done + q;
             if (st[k].groups > 1) {
                 tiled.push_back(st[k].job); tiled_k.push_back(k);
+                tiled_all_lds = tiled_all_lds && st[k].job.S * st[k].job.S <= 256;
                 gmax = std::max(gmax, st[k].groups); gmax_b = std::max(gmax_b, st[k].groups_b); slots_needed += st[k].groups + st[k].groups_b;
             } else if (st[k].ring) ring_k.push_back(k);
             else small_k.push_back(k);
         }
         // the LDS-ring sweeps of the chunk: one launch per direction and workgroup size (a workgroup a pair)
-        std::stable_sort(ring_k.begin(), ring_k.end(), [&](int a, int b_) { return st[a].block < st[b_].block; });
+        auto ring_key = [&](int k) { return 2 * st[k].block + (st[k].job.S * st[k].job.S <= 256 ? 1 : 0); };     // workgroup size, table in LDS
+        std::stable_sort(ring_k.begin(), ring_k.end(), [&](int a, int b_) { return ring_key(a) < ring_key(b_); });
         std::vector<PgFbJob> ring_jobs;
         for (int k : ring_k) ring_jobs.push_back(st[k].job);
         if (rc != PAGAN_OK) break;
@@ -1336,15 +1399,15 @@ int pagan_fb_run_batch(int32_t n, const pagan_graph *const *left, const pagan_gr
                 const bool bwd_first = std::getenv("PAGAN_FB_BWD_FIRST") != nullptr;      // (A/B: which sweep's workgroups are dealt out first)
                 if (bwd_first) {
                     FB_TRY(hipEventRecord(e2, s2));
-                    hipLaunchKernelGGL(pg_fb_backward_tiled, dim3(gmax_b, (unsigned)tiled.size()), dim3(64), 0, s2, (const PgFbJob *)d_jobs);
+                    { if (tiled_all_lds) hipLaunchKernelGGL((pg_fb_backward_tiled<true>), dim3(gmax_b, (unsigned)tiled.size()), dim3(64), 0, s2, (const PgFbJob *)d_jobs); else hipLaunchKernelGGL((pg_fb_backward_tiled<false>), dim3(gmax_b, (unsigned)tiled.size()), dim3(64), 0, s2, (const PgFbJob *)d_jobs); }
                     FB_TRY(hipEventRecord(e3, s2));
                 }
                 FB_TRY(hipEventRecord(e0, s1));
-                hipLaunchKernelGGL(pg_fb_forward_tiled, dim3(gmax, (unsigned)tiled.size()), dim3(64), 0, s1, (const PgFbJob *)d_jobs);
+                { if (tiled_all_lds) hipLaunchKernelGGL((pg_fb_forward_tiled<true>), dim3(gmax, (unsigned)tiled.size()), dim3(64), 0, s1, (const PgFbJob *)d_jobs); else hipLaunchKernelGGL((pg_fb_forward_tiled<false>), dim3(gmax, (unsigned)tiled.size()), dim3(64), 0, s1, (const PgFbJob *)d_jobs); }
                 FB_TRY(hipEventRecord(e1, s1));
                 if (!bwd_first) {
                     FB_TRY(hipEventRecord(e2, s2));
-                    hipLaunchKernelGGL(pg_fb_backward_tiled, dim3(gmax_b, (unsigned)tiled.size()), dim3(64), 0, s2, (const PgFbJob *)d_jobs);
+                    { if (tiled_all_lds) hipLaunchKernelGGL((pg_fb_backward_tiled<true>), dim3(gmax_b, (unsigned)tiled.size()), dim3(64), 0, s2, (const PgFbJob *)d_jobs); else hipLaunchKernelGGL((pg_fb_backward_tiled<false>), dim3(gmax_b, (unsigned)tiled.size()), dim3(64), 0, s2, (const PgFbJob *)d_jobs); }
                     FB_TRY(hipEventRecord(e3, s2));
                 }
             }
@@ -1354,12 +1417,13 @@ int pagan_fb_run_batch(int32_t n, const pagan_graph *const *left, const pagan_gr
                 FB_TRY(hipMalloc((void **)&d_ring, ring_jobs.size() * sizeof(PgFbJob)));
                 FB_TRY(hipMemcpy(d_ring, ring_jobs.data(), ring_jobs.size() * sizeof(PgFbJob), hipMemcpyHostToDevice));
                 FB_TRY(hipEventRecord(g0, r1)); FB_TRY(hipEventRecord(g2, r2));
-                // (the workgroup sizes side by side, not one after the other: the first size on r1 / r2, the others -- at most three --
+                // (the workgroup sizes side by side, not one after the other: the first group (size, table in LDS or not) on r1 / r2, the others -- a handful at most --
                 //  on streams of their own that r1 / r2 wait for)
                 for (size_t a = 0; a < ring_k.size();) {
                     size_t z = a;
-                    while (z < ring_k.size() && st[ring_k[z]].block == st[ring_k[a]].block) ++z;
+                    while (z < ring_k.size() && ring_key(ring_k[z]) == ring_key(ring_k[a])) ++z;
                     const int blk = st[ring_k[a]].block;
+                    const bool lds = (ring_key(ring_k[a]) & 1) != 0;
                     hipStream_t f = r1, bk = r2;
                     if (a > 0) {
                         hipStream_t x1 = nullptr, x2 = nullptr;
@@ -1367,8 +1431,8 @@ int pagan_fb_run_batch(int32_t n, const pagan_graph *const *left, const pagan_gr
                         FB_TRY(hipStreamCreate(&x2)); ring_s.push_back(x2);
                         f = x1; bk = x2;
                     }
-                    hipLaunchKernelGGL(pg_fb_forward_ring, dim3((unsigned)(z - a)), dim3(blk), 0, f, (const PgFbJob *)(d_ring + a));
-                    hipLaunchKernelGGL(pg_fb_backward_ring, dim3((unsigned)(z - a)), dim3(blk), 0, bk, (const PgFbJob *)(d_ring + a));
+                    fb_launch_ring(true, lds, (unsigned)(z - a), blk, f, (const PgFbJob *)(d_ring + a));
+                    fb_launch_ring(false, lds, (unsigned)(z - a), blk, bk, (const PgFbJob *)(d_ring + a));
                     if (a > 0) {
                         hipEvent_t ev1 = nullptr, ev2 = nullptr;
                         FB_TRY(hipEventCreateWithFlags(&ev1, hipEventDisableTiming)); ring_e.push_back(ev1);
