@@ -1134,10 +1134,10 @@ static int fb_stage(const pagan_graph *left, const pagan_graph *right, const pag
     // 64 diagonals.  Workgroups: the blocks a diagonal of `mw` cells can lie in while it moves through 127 diagonals.
     // PAGAN_FB_BAND_MIN_ND: the shortest pair (in cell diagonals) that takes this path (tests: 0; "off": none).
     // ... and a long tunnel between plain sequences (every site one edge, from the site before it: leaves) on the LDS-ring sweeps
-    // (pg_fb_forward_ring): PAGAN_FB_RING=0 switches them off, PAGAN_FB_RING_MIN_ND is their shortest pair (default 4,096 diagonals)
+    // (pg_fb_forward_ring): PAGAN_FB_RING=0 switches them off, PAGAN_FB_RING_MIN_ND is their shortest pair (default 256 diagonals)
     bool ring = false;
     {
-        int min_nd = 4096;
+        int min_nd = 256;            // (a step of the ring sweeps is 1 us against the one-workgroup kernels' 2.7: worth it from a few hundred diagonals on)
         if (const char *e = std::getenv("PAGAN_FB_RING_MIN_ND")) min_nd = std::atoi(e);
         const char *re = std::getenv("PAGAN_FB_RING");
         auto plain = [](const pagan_graph *g) {
