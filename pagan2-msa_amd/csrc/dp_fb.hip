@@ -264,6 +264,7 @@ __global__ __launch_bounds__(1024) void pg_fb_backward(const PgFbJob *jobs) {
 #define FB_RG_COLS 1024          // columns / rows in the LDS windows (>= B + 2 * FB_RG_REFILL)
 #define FB_RG_REFILL 256
 #define FB_RG_MAXB 512
+#define FB_RG_INIT 32           // assignments of initialise_array_corner_bwd a ring sweep holds (a pair with more takes the block schedule)
 #define FB_RG_THREADS 1024       // B = 64 ... 256: three threads a row, one per state; B = 512: two (X and Y; M)
 // Who a thread is.  A cell's three states are three independent log-sum-exps of the same size -- the step's latency is one wave's
 // way through them --, so up to B = 256 a row has THREE threads, one per state (NSPLIT = 3, blockDim = 3 B), and with B = 512 two
@@ -291,6 +292,7 @@ struct FbRingSmem {
     int r_st[FB_RG_COLS]; float r_lw[FB_RG_COLS];      // row i the same way
     int dmin[FB_RG_REFILL], dmax[FB_RG_REFILL]; long long doff[FB_RG_REFILL];     // diagonal d at d % FB_RG_REFILL
     double ltab[256];
+    long long i_at[FB_RG_INIT]; double i_val[FB_RG_INIT];                         // initialise_array_corner_bwd's assignments (backward sweep)
 };
 
 template <bool ALL_LDS, int NSPLIT>
@@ -327,8 +329,7 @@ __global__ __launch_bounds__(FB_RG_THREADS) void pg_fb_forward_ring(const PgFbJo
                 M.r_lw[i & (FB_RG_COLS - 1)] = i > 0 ? J.lwL[i - 1] : 0.0f;
             }
             cols_hi = max(cols_hi, want_c); rows_hi = max(rows_hi, want_r);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            fb_lds_barrier();
+            fb_lds_barrier();                                      // (the staged values went through registers into LDS: the loads are done)
         }
         const int mn = M.dmin[d & (FB_RG_REFILL - 1)], mx = M.dmax[d & (FB_RG_REFILL - 1)];
         const int i = mn + ((x - mn) & (B - 1));
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(FB_RG_THREADS) void pg_fb_backward_ring(const PgFbJ
     for (int q = 0; q < 9; ++q) (&M.ring[0][0][0])[q * FB_RG_MAXB + x] = NI;
     int mn1 = 0, mx1 = -1, mn2 = 0, mx2 = -1;            // the intervals of the diagonals d+1, d+2
     int s0 = 0, s1 = 2, s2 = 1;
+    for (int k = tid; k < J.n_init && k < FB_RG_INIT; k += nt) { M.i_at[k] = J.init_at[k]; M.i_val[k] = J.init_val[k]; }   // (in LDS: no load from memory inside the sweep's loop but the staging's)
     int cols_lo = J.Ly, rows_lo = J.Lx;                  // columns >= cols_lo, rows >= rows_lo are in the windows
     const fb_gd Bm = (fb_gd)(unsigned long long)J.B;
     __syncthreads();
@@ -426,8 +428,7 @@ __global__ __launch_bounds__(FB_RG_THREADS) void pg_fb_backward_ring(const PgFbJ
                 M.r_lw[t & (FB_RG_COLS - 1)] = t > 0 ? J.lwL[t - 1] : 0.0f;
             }
             cols_lo = min(cols_lo, want_c); rows_lo = min(rows_lo, want_r);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            fb_lds_barrier();
+            fb_lds_barrier();                                      // (the staged values went through registers into LDS: the loads are done)
         }
         const int mn = M.dmin[d & (FB_RG_REFILL - 1)], mx = M.dmax[d & (FB_RG_REFILL - 1)];
         const int i = mn + ((x - mn) & (B - 1));
@@ -448,8 +449,8 @@ __global__ __launch_bounds__(FB_RG_THREADS) void pg_fb_backward_ring(const PgFbJ
             const long long at = M.doff[d & (FB_RG_REFILL - 1)] + (i - mn);
             if (d >= J.init_dmin) {
                 for (int k = 0; k < J.n_init; ++k) {
-                    const long long w = J.init_at[k] - 3 * at;
-                    if (w == 0) bx = J.init_val[k]; else if (w == 1) by = J.init_val[k]; else if (w == 2) bm = J.init_val[k];
+                    const long long w = M.i_at[k] - 3 * at;
+                    if (w == 0) bx = M.i_val[k]; else if (w == 1) by = M.i_val[k]; else if (w == 2) bm = M.i_val[k];
                 }
                 // (one by one, as pg_fb_backward takes them; a state's sums do not look at the other states')
                 if (i + 1 < J.Lx) { if (do_x) bx = lse(bx, nx + J.l_ext); if (do_y) by = lse(by, nx + J.l_open); if (do_m) bm = lse(bm, nx + J.l_ng + J.l_open); }   // VA:2281-2303
@@ -1147,7 +1148,7 @@ static int fb_stage(const pagan_graph *left, const pagan_graph *right, const pag
         };
         bool gapless = true;                                          // (no cell diagonal without a cell)
         for (int d = 0; d < nd && gapless; ++d) gapless = fb->dx.imax[d] >= fb->dx.imin[d];
-        ring = !(re && std::strcmp(re, "0") == 0) && nd >= min_nd && mw <= FB_RG_MAXB && Lx >= 2 && Ly >= 2 && gapless && plain(left) && plain(right);
+        ring = !(re && std::strcmp(re, "0") == 0) && nd >= min_nd && mw <= FB_RG_MAXB && Lx >= 2 && Ly >= 2 && (int)init_at.size() <= FB_RG_INIT && gapless && plain(left) && plain(right);
         if (ring && !std::getenv("PAGAN_FB_GROUPS")) groups = 1;
     }
     {
