@@ -65,6 +65,7 @@ BYTES_PER_CELL = 36            # 3 states x (f64 score + u32 back-pointer), SURV
 CHAIN_FLOOR_US = 2 * 8.4 / 2400.0
 STEP_FLOOR_US = 489 / 2400.0
 PMC_PROFILE = os.path.join("profiles", "r05_pmc_fill.json")
+PMC_FB_PROFILE = os.path.join("profiles", "r05_pmc_fb_band.json")      # the tunnels' forward/backward workload
 KERNELS = ("pg_fill_pipe", "pg_backptr", "pg_fill_tiles_flow", "pg_fill_wavefront")
 
 
@@ -211,6 +212,14 @@ def bench_forward_backward(args, device):
                                  {"kernel": "pg_fb_backward", "ms_per_step": bwd_ms, "achieved": 24 * cells / (bwd_ms * 1e-3) / 1e9}]},
         "parity_self_check": bool(ok),
     }
+    # HBM bytes per pass from the committed PMC passes of this same command (tools/profile_fb_band.sh), when they describe this run
+    try:
+        prof = json.load(open(os.path.join(ROOT, PMC_FB_PROFILE)))
+        if prof.get("workload") == workload and prof.get("cells_per_step") == int(cells):
+            out["roofline"].update({"traffic": prof["hbm_bytes_per_step"], "traffic_source": PMC_FB_PROFILE,
+                                    "traffic_over_algorithmic": prof["hbm_bytes_per_step"] / (48.0 * cells)})
+    except (OSError, ValueError):
+        pass
     if not args.no_cpu_baseline:
         import oracle
         oracle.build()
