@@ -281,7 +281,7 @@ int  pagan_fb_totals(const pagan_fb *fb, double *log_fwd, double *log_bwd, int64
 int  pagan_fb_kernel_ms(const pagan_fb *fb, double ms[2]);
 /* workgroups of the pair's forward sweep: 1 = the one-workgroup kernel (a barrier per cell diagonal), > 1 = 64 x 64 blocks,
  * a wave each (wide matrices, and -- round 5 -- tunnels of 4,096 cell diagonals or more), 0 = the LDS-ring sweeps (two
- * plain sequences, widest diagonal <= 512 cells: one workgroup, lane = row mod B); diagnostic, for the tests                          */
+ * plain sequences, widest diagonal <= 1,024 cells: one workgroup, lane = row mod B); diagnostic, for the tests                          */
 int  pagan_fb_groups(const pagan_fb *fb);
 /* which: 0 log forward, 1 log backward, 2 posterior (compute_posterior_score, VA:1029-1034);
  * dst [Lx][Ly][3] row-major, states X, Y, M; outside the tunnel -inf / 0.                                  */

@@ -261,9 +261,9 @@ __global__ __launch_bounds__(1024) void pg_fb_backward(const PgFbJob *jobs) {
 // the one edge) and the diagonals' intervals sit in LDS windows refilled every FB_RG_REFILL diagonals, and the step ends in
 // s_waitcnt lgkmcnt(0) + s_barrier: the scores go to memory unwaited-for.  Graph pairs (any site with another edge
 // list) and diagonals wider than 512 cells keep the block schedule.
-#define FB_RG_COLS 1024          // columns / rows in the LDS windows (>= B + 2 * FB_RG_REFILL)
+#define FB_RG_COLS 1024          // columns / rows in the LDS windows (>= B + 2 * FB_RG_REFILL) up to B = 512; 2,048 for B = 1,024
 #define FB_RG_REFILL 256
-#define FB_RG_MAXB 512
+#define FB_RG_MAXB 1024         // rows of the widest diagonal a ring sweep takes
 #define FB_RG_INIT 32           // assignments of initialise_array_corner_bwd a ring sweep holds (a pair with more takes the block schedule)
 #define FB_RG_THREADS 1024       // B = 64 ... 256: three threads a row, one per state; B = 512: two (X and Y; M)
 // Who a thread is.  A cell's three states are three independent log-sum-exps of the same size -- the step's latency is one wave's
@@ -286,25 +286,30 @@ __device__ __forceinline__ void fb_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // Nothing on a step's path is a load from memory (a vector load would wait behind the wave's stores -- memory operations
 // complete in order --, and the compiler cannot make scalar loads of arrays it has only a pointer from memory to): the diagonals'
 // intervals and offsets, the rows' and the columns' records are staged every FB_RG_REFILL diagonals for the next FB_RG_REFILL.
+// MAXB = 512: 59 KB.  MAXB = 1024 (one thread a row; round 5: a workgroup's LDS is not bounded by 64 KB on gfx950 --
+// tools/ubench/lds_big.hip): a ring of 74 KB, windows of 2,048 rows / columns, 113 KB in all.
+template <int MAXB>
 struct FbRingSmem {
-    double ring[3][3][FB_RG_MAXB];           // [diagonal slot][X, Y, M][thread]
-    int c_st[FB_RG_COLS]; float c_lw[FB_RG_COLS];      // column j at j % FB_RG_COLS: state, log weight of the edge (j-1) -> j
-    int r_st[FB_RG_COLS]; float r_lw[FB_RG_COLS];      // row i the same way
+    static constexpr int COLS = MAXB > 512 ? 2048 : FB_RG_COLS;
+    double ring[3][3][MAXB];           // [diagonal slot][X, Y, M][thread]
+    int c_st[COLS]; float c_lw[COLS];      // column j at j % FB_RG_COLS: state, log weight of the edge (j-1) -> j
+    int r_st[COLS]; float r_lw[COLS];      // row i the same way
     int dmin[FB_RG_REFILL], dmax[FB_RG_REFILL]; long long doff[FB_RG_REFILL];     // diagonal d at d % FB_RG_REFILL
     double ltab[256];
     long long i_at[FB_RG_INIT]; double i_val[FB_RG_INIT];                         // initialise_array_corner_bwd's assignments (backward sweep)
 };
 
-template <bool ALL_LDS, int NSPLIT>
+template <bool ALL_LDS, int NSPLIT, int MAXB>
 __global__ __launch_bounds__(FB_RG_THREADS) void pg_fb_forward_ring(const PgFbJob *jobs) {
-    __shared__ FbRingSmem M;
+    __shared__ FbRingSmem<MAXB> M;
+    constexpr int CMASK = FbRingSmem<MAXB>::COLS - 1;
     const PgFbJob J = jobs[blockIdx.x];
     FB_RING_THREADS
     const int xm1 = (x - 1) & (B - 1);
     const double NI = ninf();
     const bool tab_lds = J.S * J.S <= 256;
     if (tab_lds) for (int k = tid; k < J.S * J.S; k += nt) M.ltab[k] = J.ltab[k];
-    for (int q = 0; q < 9; ++q) (&M.ring[0][0][0])[q * FB_RG_MAXB + x] = NI;
+    for (int q = 0; q < 9; ++q) (&M.ring[0][0][0])[q * MAXB + x] = NI;
     int mn1 = 0, mx1 = -1, mn2 = 0, mx2 = -1;            // the intervals of the diagonals d-1, d-2
     int s0 = 0, s1 = 2, s2 = 1;                          // ring slots of d, d-1, d-2
     int cols_hi = -1, rows_hi = -1;                      // columns <= cols_hi, rows <= rows_hi are in the windows
@@ -321,12 +326,12 @@ __global__ __launch_bounds__(FB_RG_THREADS) void pg_fb_forward_ring(const PgFbJo
             const int mn_ = J.imin[d], mx_ = J.imax[d];
             const int want_c = min(J.Ly - 1, d - mn_ + FB_RG_REFILL), want_r = min(J.Lx - 1, mx_ + FB_RG_REFILL);
             for (int j = cols_hi + 1 + tid; j <= want_c; j += nt) {
-                M.c_st[j & (FB_RG_COLS - 1)] = J.stR[j];
-                M.c_lw[j & (FB_RG_COLS - 1)] = j > 0 ? J.lwR[j - 1] : 0.0f;       // (plain graph: site j's one edge is list entry j - 1)
+                M.c_st[j & CMASK] = J.stR[j];
+                M.c_lw[j & CMASK] = j > 0 ? J.lwR[j - 1] : 0.0f;       // (plain graph: site j's one edge is list entry j - 1)
             }
             for (int i = rows_hi + 1 + tid; i <= want_r; i += nt) {
-                M.r_st[i & (FB_RG_COLS - 1)] = J.stL[i];
-                M.r_lw[i & (FB_RG_COLS - 1)] = i > 0 ? J.lwL[i - 1] : 0.0f;
+                M.r_st[i & CMASK] = J.stL[i];
+                M.r_lw[i & CMASK] = i > 0 ? J.lwL[i - 1] : 0.0f;
             }
             cols_hi = max(cols_hi, want_c); rows_hi = max(rows_hi, want_r);
             fb_lds_barrier();                                      // (the staged values went through registers into LDS: the loads are done)
@@ -350,9 +355,9 @@ __global__ __launch_bounds__(FB_RG_THREADS) void pg_fb_forward_ring(const PgFbJo
                 }
                 if (do_m && i > 0 && j > 0 && i - 1 >= mn2 && i - 1 <= mx2) {      // (i-1, j-1): VA:2051, 2080, 2108
                     const double cx = M.ring[s2][0][xm1], cy = M.ring[s2][1][xm1], cm = M.ring[s2][2][xm1];
-                    const int str = M.r_st[i & (FB_RG_COLS - 1)], stc = M.c_st[j & (FB_RG_COLS - 1)];
+                    const int str = M.r_st[i & CMASK], stc = M.c_st[j & CMASK];
                     const double sc = fb_score<ALL_LDS>(tab_lds, M.ltab, J.ltab, str, stc, J.S);
-                    const double w = (double)M.r_lw[i & (FB_RG_COLS - 1)] + (double)M.c_lw[j & (FB_RG_COLS - 1)];
+                    const double w = (double)M.r_lw[i & CMASK] + (double)M.c_lw[j & CMASK];
                     const double mm = J.l_ng + J.l_ng + sc + w, xm = J.l_ng + sc + w;   // VA:1383-1391
                     fm = lse3(cm + mm, cx + xm, cy + xm);
                 }
@@ -393,16 +398,17 @@ __global__ __launch_bounds__(FB_RG_THREADS) void pg_fb_forward_ring(const PgFbJo
 // the windows hold row t = i+1's and column u = j+1's records (state, weight of the edge from the site before).
 // What initialise_array_corner_bwd assigns (a handful of cells on the last diagonals, VA:740-854) is laid over the -inf a cell
 // starts from on the diagonals >= init_dmin, and there the sums are taken one by one as pg_fb_backward takes them.
-template <bool ALL_LDS, int NSPLIT>
+template <bool ALL_LDS, int NSPLIT, int MAXB>
 __global__ __launch_bounds__(FB_RG_THREADS) void pg_fb_backward_ring(const PgFbJob *jobs) {
-    __shared__ FbRingSmem M;
+    __shared__ FbRingSmem<MAXB> M;
+    constexpr int CMASK = FbRingSmem<MAXB>::COLS - 1;
     const PgFbJob J = jobs[blockIdx.x];
     FB_RING_THREADS
     const int xp1 = (x + 1) & (B - 1);
     const double NI = ninf();
     const bool tab_lds = J.S * J.S <= 256;
     if (tab_lds) for (int k = tid; k < J.S * J.S; k += nt) M.ltab[k] = J.ltab[k];
-    for (int q = 0; q < 9; ++q) (&M.ring[0][0][0])[q * FB_RG_MAXB + x] = NI;
+    for (int q = 0; q < 9; ++q) (&M.ring[0][0][0])[q * MAXB + x] = NI;
     int mn1 = 0, mx1 = -1, mn2 = 0, mx2 = -1;            // the intervals of the diagonals d+1, d+2
     int s0 = 0, s1 = 2, s2 = 1;
     for (int k = tid; k < J.n_init && k < FB_RG_INIT; k += nt) { M.i_at[k] = J.init_at[k]; M.i_val[k] = J.init_val[k]; }   // (in LDS: no load from memory inside the sweep's loop but the staging's)
@@ -420,12 +426,12 @@ __global__ __launch_bounds__(FB_RG_THREADS) void pg_fb_backward_ring(const PgFbJ
             const int mn_ = J.imin[d], mx_ = J.imax[d];
             const int want_c = max(0, d - mx_ + 1 - FB_RG_REFILL), want_r = max(0, mn_ + 1 - FB_RG_REFILL);
             for (int u = cols_lo - 1 - tid; u >= want_c; u -= nt) {
-                M.c_st[u & (FB_RG_COLS - 1)] = J.stR[u];
-                M.c_lw[u & (FB_RG_COLS - 1)] = u > 0 ? J.lwR[u - 1] : 0.0f;
+                M.c_st[u & CMASK] = J.stR[u];
+                M.c_lw[u & CMASK] = u > 0 ? J.lwR[u - 1] : 0.0f;
             }
             for (int t = rows_lo - 1 - tid; t >= want_r; t -= nt) {
-                M.r_st[t & (FB_RG_COLS - 1)] = J.stL[t];
-                M.r_lw[t & (FB_RG_COLS - 1)] = t > 0 ? J.lwL[t - 1] : 0.0f;
+                M.r_st[t & CMASK] = J.stL[t];
+                M.r_lw[t & CMASK] = t > 0 ? J.lwL[t - 1] : 0.0f;
             }
             cols_lo = min(cols_lo, want_c); rows_lo = min(rows_lo, want_r);
             fb_lds_barrier();                                      // (the staged values went through registers into LDS: the loads are done)
@@ -442,9 +448,9 @@ __global__ __launch_bounds__(FB_RG_THREADS) void pg_fb_backward_ring(const PgFbJ
             const double nx = has_a ? M.ring[s1][0][xp1] : NI, ny = has_p ? M.ring[s1][1][x] : NI;
             double thru = NI;
             if (i + 1 < J.Lx && j + 1 < J.Ly) {
-                const int str = M.r_st[(i + 1) & (FB_RG_COLS - 1)], stc = M.c_st[(j + 1) & (FB_RG_COLS - 1)];
+                const int str = M.r_st[(i + 1) & CMASK], stc = M.c_st[(j + 1) & CMASK];
                 const double sc = fb_score<ALL_LDS>(tab_lds, M.ltab, J.ltab, str, stc, J.S);
-                thru = (has_c ? M.ring[s2][2][xp1] : NI) + sc + (double)M.r_lw[(i + 1) & (FB_RG_COLS - 1)] + (double)M.c_lw[(j + 1) & (FB_RG_COLS - 1)];   // VA:2269-2271
+                thru = (has_c ? M.ring[s2][2][xp1] : NI) + sc + (double)M.r_lw[(i + 1) & CMASK] + (double)M.c_lw[(j + 1) & CMASK];   // VA:2269-2271
             }
             const long long at = M.doff[d & (FB_RG_REFILL - 1)] + (i - mn);
             if (d >= J.init_dmin) {
@@ -1189,7 +1195,7 @@ static int fb_stage(const pagan_graph *left, const pagan_graph *right, const pag
     // eight cells of a 2,000-cell diagonal was the whole sweep's pace)
     st->block = mw >= 768 ? 1024 : mw >= 384 ? 512 : mw >= 192 ? 256 : (mw >= 96 ? 128 : 64);
     st->ring = ring && groups == 1;
-    if (st->ring) st->block = mw > 256 ? 512 : (mw > 128 ? 256 : (mw > 64 ? 128 : 64));     // a thread per row of the widest diagonal
+    if (st->ring) st->block = mw > 512 ? 1024 : (mw > 256 ? 512 : (mw > 128 ? 256 : (mw > 64 ? 128 : 64)));     // a thread per row of the widest diagonal
     fb->ring = st->ring;
     st->groups = groups; st->groups_b = groups_b;
     st->d_job = (const PgFbJob *)(b + o_job); st->d_tot = b + o_tot; st->d_sync = b + o_sync; st->job = J;
@@ -1239,19 +1245,21 @@ static int fb_slot_cap(int device) {
 static int fb_ring_split(int B) {
     const char *e = std::getenv("PAGAN_FB_RING_SPLIT");
     if (e && std::strcmp(e, "0") == 0) return 1;
-    return B <= 256 ? 3 : 2;
+    return B <= 256 ? 3 : (B <= 512 ? 2 : 1);          // (1,024 threads is what a workgroup holds)
 }
 template <bool FWD, bool ALL_LDS>
 static void fb_launch_ring_(int nsplit, unsigned grid, int B, hipStream_t st, const PgFbJob *jobs) {
     const dim3 g(grid), t((unsigned)(nsplit * B));
     if (FWD) {
-        if (nsplit == 3) hipLaunchKernelGGL((pg_fb_forward_ring<ALL_LDS, 3>), g, t, 0, st, jobs);
-        else if (nsplit == 2) hipLaunchKernelGGL((pg_fb_forward_ring<ALL_LDS, 2>), g, t, 0, st, jobs);
-        else hipLaunchKernelGGL((pg_fb_forward_ring<ALL_LDS, 1>), g, t, 0, st, jobs);
+        if (B > 512) hipLaunchKernelGGL((pg_fb_forward_ring<ALL_LDS, 1, 1024>), g, t, 0, st, jobs);
+        else if (nsplit == 3) hipLaunchKernelGGL((pg_fb_forward_ring<ALL_LDS, 3, 512>), g, t, 0, st, jobs);
+        else if (nsplit == 2) hipLaunchKernelGGL((pg_fb_forward_ring<ALL_LDS, 2, 512>), g, t, 0, st, jobs);
+        else hipLaunchKernelGGL((pg_fb_forward_ring<ALL_LDS, 1, 512>), g, t, 0, st, jobs);
     } else {
-        if (nsplit == 3) hipLaunchKernelGGL((pg_fb_backward_ring<ALL_LDS, 3>), g, t, 0, st, jobs);
-        else if (nsplit == 2) hipLaunchKernelGGL((pg_fb_backward_ring<ALL_LDS, 2>), g, t, 0, st, jobs);
-        else hipLaunchKernelGGL((pg_fb_backward_ring<ALL_LDS, 1>), g, t, 0, st, jobs);
+        if (B > 512) hipLaunchKernelGGL((pg_fb_backward_ring<ALL_LDS, 1, 1024>), g, t, 0, st, jobs);
+        else if (nsplit == 3) hipLaunchKernelGGL((pg_fb_backward_ring<ALL_LDS, 3, 512>), g, t, 0, st, jobs);
+        else if (nsplit == 2) hipLaunchKernelGGL((pg_fb_backward_ring<ALL_LDS, 2, 512>), g, t, 0, st, jobs);
+        else hipLaunchKernelGGL((pg_fb_backward_ring<ALL_LDS, 1, 512>), g, t, 0, st, jobs);
     }
 }
 // one launch of ring sweeps: `grid` pairs of B rows each, forward or backward, score tables all in LDS or not

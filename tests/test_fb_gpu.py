@@ -232,7 +232,7 @@ def test_long_tunnel_between_leaves_by_default(pg, oracle, monkeypatch):
 
 def test_ring_sweeps_cell_by_cell(pg, oracle, monkeypatch):
     """The LDS-ring sweeps (PAGAN_FB_RING_MIN_ND=0: pairs of any length) on leaf pairs behind random tunnels -- 5 to 12, 20 to 70
-    and 100 to 180 columns either side: workgroups of 64 to 512 threads, rows re-used by their threads many times over --, DNA and
+    100 to 180 and 270 to 330 columns either side: 64 to 1,024 rows a workgroup, rows re-used by their threads many times over --, DNA and
     protein (a score table that does not fit LDS), no tunnel at all on a short pair; every cell of both matrices and the
     posteriors against the oracle, one call per pair and all pairs in one batch."""
     rng = np.random.default_rng(78)
@@ -243,6 +243,10 @@ def test_ring_sweeps_cell_by_cell(pg, oracle, monkeypatch):
     mp = host.model_prob(1, 0.08, base_freq=[0.3, 0.2, 0.2, 0.3])
     for lo_half, hi_half in ((5, 12), (20, 70), (100, 180)):
         cases.append((gl, gr, mp, _random_tunnel(rng, gl.n_sites - 1, gr.n_sites - 1, lo_half, hi_half)))
+    # a tunnel wider than 512 cells on its widest diagonal: 1,024 threads, one a row, 113 KB of LDS
+    _, wide, _ = synth.evolve_balanced(2, 1400, branch=0.04, sub=0.05, indel_start=0.01, mean_len=4, seed=51)
+    wl, wr = (host.HGraph.leaf(s).flatten() for s in wide)
+    cases.append((wl, wr, mp, _random_tunnel(rng, wl.n_sites - 1, wr.n_sites - 1, 270, 330)))
     _, short, _ = synth.evolve_balanced(2, 150, branch=0.04, sub=0.05, indel_start=0.01, mean_len=3, seed=49)
     sl, sr = (host.HGraph.leaf(s).flatten() for s in short)
     cases.append((sl, sr, mp, None))
